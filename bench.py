@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py — PageRank pull sweeps on synthetic R-MAT, the metric of BASELINE.json.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+A *step* is one PageRank sweep (page_rank_iteration, crates/algos/src/page_rank.rs:113-168) over the
+whole graph: K timed sweeps after W warm-up sweeps, bracketed by barrier + synchronize, MAX over
+ranks.  value = m * K / seconds in GTEPS (whole job).  Inputs are resident in HBM when the timed
+region starts (R-MAT generated and turned into a Sorted in-CSR on the device).
+
+N = 1: the whole graph on one GPU.  N > 1: 1-D vertex-range partition (reference's greedy in-degree
+partitioner), replicated out_scores, one RCCL all-gather per sweep — strong scaling (fixed graph).
+
+Extra objects in the JSON line:
+  roofline      dominant kernel (pr_tile_kernel): algorithmic bytes per launch (8m + 20n + 4 over the
+                rank's rows) / its average duration measured here with HIP events on the launch stream
+  cpu_baseline  the oracle's restatement of the reference's threaded path (oracle/graph_oracle.c:
+                orc_page_rank_chunked; kind "port") timed on this box's host cores on the same graph
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)   # PageRankConfig::DEFAULT_MAX_ITERATIONS
+    ap.add_argument("--warmup", type=int, default=5)   # crates/app/src/app.rs:124-153: 5 warm-up runs
+    ap.add_argument("--scale", type=int, default=26)   # BASELINE.json metric: RMAT scale-26
+    ap.add_argument("--edge-factor", type=int, default=16)
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--cpu-sweeps", type=int, default=3, help="sweeps of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores (available_parallelism)")
+    ap.add_argument("--relabel", type=int, default=0, help="(experimental) internal degree-ordered layout")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import graph_amd
+    from graph_amd import synth
+    from graph_amd.engine import PageRankEngine
+    from graph_amd.prelude import CsrLayout, Direction
+    from graph_amd._lib import check, lib, vp
+    import ctypes as C
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                         f"--nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available() or graph_amd.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    scale, n = args.scale, 1 << args.scale
+    t_build = time.time()
+    src, dst = synth.rmat_edges(scale, args.seed, args.edge_factor, local_rank)
+    m = src.numel()
+    out_deg = torch.bincount(src, minlength=n).to(torch.int32)
+    in_csr = synth.build_csr(n, src, dst, Direction.Incoming, CsrLayout.Sorted, None, local_rank)
+    del src, dst
+    torch.cuda.empty_cache()
+    t_build = time.time() - t_build
+
+    # ---- partition --------------------------------------------------------------------------
+    if world == 1:
+        local_csr, row_lo, n_local, stride = in_csr, 0, n, n
+        out_deg_local = out_deg
+    else:
+        from graph_amd.distributed import greedy_degree_partition, pad_bounds
+
+        off_host = np.empty(n + 1, np.uint32)
+        check(lib().gm_csr_download(in_csr.handle, off_host.ctypes.data_as(vp), None, None))
+        bounds, stride = pad_bounds(greedy_degree_partition(off_host, world), world, n)
+        row_lo, row_hi = int(bounds[rank]), int(bounds[rank + 1])
+        n_local = row_hi - row_lo
+        h = vp()
+        check(lib().gm_csr_slice_rows(in_csr.handle, row_lo, row_hi, bounds.ctypes.data_as(vp), world, stride,
+                                      C.byref(h)))
+        from graph_amd.prelude import DeviceCsr
+
+        local_csr = DeviceCsr(h)
+        out_deg_local = out_deg[row_lo:row_hi].contiguous() if n_local else torch.zeros(1, dtype=torch.int32, device=dev)
+        del in_csr, off_host
+        torch.cuda.empty_cache()
+    m_local = local_csr.m
+
+    engine = PageRankEngine(local_csr.handle, n, row_lo, out_deg_local, 0.85)
+    x = [torch.zeros(world * stride if world > 1 else n, dtype=torch.float32, device=dev) for _ in range(2)]
+    x_loc = torch.zeros(stride, dtype=torch.float32, device=dev) if world > 1 else None
+    scores = torch.zeros(max(n_local, 1), dtype=torch.float32, device=dev)
+    err = torch.zeros(1, dtype=torch.float64, device=dev)
+
+    def exchange(dst_buf):
+        dist.all_gather_into_tensor(dst_buf, x_loc)
+
+    if world == 1:
+        engine.init(scores, x[0])
+    else:
+        engine.init(scores, x_loc)
+        exchange(x[0])
+    cur = 0
+
+    def step(timed_events=None):
+        nonlocal cur
+        out_local = x[1 - cur] if world == 1 else x_loc
+        if timed_events is not None:
+            e0, e1 = timed_events
+            e0.record()
+            engine.sweep_tiles(x[cur], out_local, scores)
+            e1.record()
+        else:
+            engine.sweep_tiles(x[cur], out_local, scores)
+        engine.sweep_fixup(out_local, scores, err)
+        if world > 1:
+            exchange(x[1 - cur])
+        cur = 1 - cur
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(evs[k])
+    sync_all()
+    seconds = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([seconds], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        seconds = float(tt.item())
+    tile_ms = [a.elapsed_time(b) for a, b in evs]
+    tile_ms_avg = sum(tile_ms) / max(len(tile_ms), 1)
+    final_err = float(err.item())
+
+    ms_per_step = seconds * 1e3 / max(args.steps, 1)
+    gteps = m * args.steps / seconds / 1e9
+    alg_bytes = engine.algorithmic_bytes  # 8*m_local + 20*n_local + 4
+    achieved = alg_bytes / (tile_ms_avg * 1e-3) / 1e9 if tile_ms_avg > 0 else 0.0
+
+    # PMC-derived HBM traffic per launch, if a matching rocprofv3 --pmc summary was committed
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_path):
+        try:
+            rec = json.load(open(pmc_path))
+            key = f"scale{scale}_gpus{world}"
+            traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    result = {
+        "metric": "pagerank_edges_per_sec",
+        "value": round(gteps, 4),
+        "unit": "GTEPS",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 5),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"PageRank pull sweep, RMAT scale-{scale} (A=.57 B=.19 C=.19 D=.05, edge factor "
+                        f"{args.edge_factor}, seed {args.seed}), DirectedCsrGraph<u32> CsrLayout::Sorted, damping 0.85",
+            "nodes": n, "edges": m, "step": "one sweep over all in-edges",
+            "partition": "none" if world == 1 else f"1-D vertex ranges (greedy in-degree), {world} ranks, all-gather/sweep",
+            "csr_build_s": round(t_build, 3), "final_sweep_error": final_err, "tiles_per_sweep": engine.tiles,
+        },
+        "roofline": {
+            "kernel": "pr_tile_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(tile_ms_avg, 5),
+            "edges_per_launch": m_local, "rows_per_launch": n_local,
+        },
+    }
+
+    # ---- CPU baseline on rank 0 at N = 1 (bounded sample: a few sweeps of the same graph) -----
+    if world == 1 and args.cpu_sweeps > 0:
+        from oracle import oracle as O  # checker / timed CPU baseline only (see oracle/graph_oracle.c header)
+
+        off_h = np.empty(n + 1, np.uint32)
+        tgt_h = np.empty(m, np.uint32)
+        check(lib().gm_csr_download(in_csr.handle, off_h.ctypes.data_as(vp), tgt_h.ctypes.data_as(vp), None))
+        od_h = out_deg.cpu().numpy().astype(np.uint32)
+        cores = args.cpu_threads or (os.cpu_count() or 4)
+        O.page_rank_chunked(off_h, tgt_h, od_h, 1, 0.0, 0.85, cores)  # warm-up (page cache, thread pool)
+        t1 = time.perf_counter()
+        O.page_rank_chunked(off_h, tgt_h, od_h, args.cpu_sweeps, 0.0, 0.85, cores)
+        cpu_s = time.perf_counter() - t1
+        result["cpu_baseline"] = {
+            "value": round(m * args.cpu_sweeps / cpu_s / 1e9, 4), "unit": "GTEPS", "cores": cores, "kind": "port",
+            "sample": f"{args.cpu_sweeps} sweeps of the same scale-{scale} graph (after 1 warm-up sweep), "
+                      f"orc_page_rank_chunked: 16384-node dynamic chunks, threads re-spawned per sweep",
+            "ms_per_step": round(cpu_s * 1e3 / args.cpu_sweeps, 3),
+        }
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,133 @@
+// common.hpp — shared host-side plumbing of libgraph_mi355x (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/graph_mi355x.h"
+
+#define GM_API extern "C" __attribute__((visibility("default")))
+
+namespace gm {
+
+void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+
+struct HipFail {
+    hipError_t err;
+};
+
+#define GM_HIP(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t gm_e_ = (expr);                                                                \
+        if (gm_e_ != hipSuccess) {                                                                \
+            gm::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(gm_e_), __FILE__,     \
+                          __LINE__);                                                              \
+            return gm_e_ == hipErrorOutOfMemory ? GM_ERR_NOMEM : GM_ERR_HIP;                       \
+        }                                                                                         \
+    } while (0)
+
+#define GM_CHECK(cond, status, ...)                                                               \
+    do {                                                                                          \
+        if (!(cond)) {                                                                            \
+            gm::set_error(__VA_ARGS__);                                                           \
+            return (status);                                                                      \
+        }                                                                                         \
+    } while (0)
+
+#define GM_TRY(expr)                                                                              \
+    do {                                                                                          \
+        int gm_s_ = (expr);                                                                       \
+        if (gm_s_ != GM_OK)                                                                       \
+            return gm_s_;                                                                         \
+    } while (0)
+
+// RAII device allocation (hipMalloc / hipFree); movable, not copyable.
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept
+    {
+        if (this != &o) {
+            release();
+            p = o.p;
+            bytes = o.bytes;
+            o.p = nullptr;
+            o.bytes = 0;
+        }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    int alloc(size_t nbytes)
+    {
+        release();
+        if (nbytes == 0)
+            nbytes = 16; // keep pointers non-null for empty graphs
+        GM_HIP(hipMalloc(&p, nbytes));
+        bytes = nbytes;
+        return GM_OK;
+    }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+// Pinned host scratch for small read-backs (error values, counters).
+struct PinnedBuf {
+    void *p = nullptr;
+    ~PinnedBuf()
+    {
+        if (p)
+            (void)hipHostFree(p);
+    }
+    int alloc(size_t nbytes)
+    {
+        GM_HIP(hipHostMalloc(&p, nbytes, hipHostMallocDefault));
+        return GM_OK;
+    }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(dev) == hipSuccess)
+            ok = true;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0)
+            (void)hipSetDevice(prev);
+    }
+};
+
+inline unsigned div_up(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
+
+} // namespace gm
+
+// The opaque handle of include/graph_mi355x.h.
+struct gm_csr {
+    uint64_t n = 0;
+    uint64_t m = 0;
+    int device = 0;
+    const uint32_t *offsets = nullptr; // n+1
+    const uint32_t *targets = nullptr; // m
+    const float *weights = nullptr;    // m or null
+    bool owns = false;
+    gm::DevBuf own_offsets, own_targets, own_weights;
+};

@@ -1,0 +1,597 @@
+// pagerank.hip — PageRank pull sweeps on a device-resident in-CSR (gfx950 / wave64).
+//
+// Replaces crates/algos/src/page_rank.rs:58-168 of the reference.  Per node u the arithmetic is
+// the reference's, op for op in f32 with no contraction:
+//     incoming = sum_{v in in_neighbors(u)} out_scores[v]        (page_rank.rs:143-146)
+//     new      = base + damping * incoming                        (:149)
+//     error   += |new - old| widened to f64                       (:152-153)
+//     out_scores[u] = new / out_degree(u)                         (:155-159)
+// What differs is scheduling.  The reference pulls 16384-node chunks with an atomic cursor and
+// races on out_scores in place; here a sweep is synchronous (reads x_in, writes x_out) and its
+// work unit is a *merge tile*: W consecutive items of the merged sequence
+// "row marker r, then row r's in-edges" (position of row r's marker = off[r] + r).  Every
+// tile therefore holds at most W edges AND at most W rows whatever the degree distribution
+// (RMAT hubs with 10^5..10^6 in-edges, or millions of empty rows), so all workgroups stream
+// the same number of bytes.
+//
+//   pr_tile_kernel   one 256-thread workgroup per tile: coalesced read of the tile's targets,
+//                    up to 8 independent gathers of x_in per lane in flight, values parked in
+//                    LDS, then one lane per row sums its LDS slice (rows longer than 32 edges
+//                    are summed by a whole wavefront with a shuffle tree), fused epilogue
+//                    (new score, |delta|, out_score).  A row that crosses a tile boundary leaves
+//                    partial sums in tail[t] / head[t'].
+//   pr_fixup_kernel  one lane per tile: finishes the (at most one) row that starts in the tile
+//                    and crosses its end, sums the per-tile f64 errors in a fixed order (last
+//                    block done reduces) -> deterministic results and error, no float atomics.
+//
+// Roofline: HBM.  Algorithmic bytes per sweep = 8m + 20n + 4: offsets 4(n+1),
+// targets 4m, gathered out_scores 4m, old score 4n, new score 4n, out_score 4n, out-degree 4n.
+//
+// pr_seq_kernel is the reference's exact sequential order (one wavefront, out_scores in LDS):
+// bit-exact with the reference wherever the reference is deterministic (n <= 16384).
+#include "common.hpp"
+#include "device_utils.hpp"
+
+namespace {
+
+using namespace gm;
+
+constexpr int PR_BLOCK = 256;
+constexpr int PR_WAVES = PR_BLOCK / kWave;
+constexpr int PR_W = 2048;     // merged items per tile
+constexpr int PR_EPT = PR_W / PR_BLOCK;
+constexpr int PR_SHORT = 32;   // rows up to this many in-tile edges are summed by one lane
+constexpr int PR_MAXLONG = PR_W / (PR_SHORT + 1) + 2;
+
+// ---- per-node arithmetic, exactly the reference's f32 ops (no FMA contraction) ----------------
+__device__ __forceinline__ float pr_new_score(float base, float damping, float incoming)
+{
+    return __fadd_rn(base, __fmul_rn(damping, incoming));
+}
+
+__device__ __forceinline__ double pr_finalize(uint32_t r, float incoming, float base, float damping,
+                                              const uint32_t *__restrict__ outdeg, float *__restrict__ scores,
+                                              float *__restrict__ x_out)
+{
+    const float old = scores[r];
+    const float nw = pr_new_score(base, damping, incoming);
+    scores[r] = nw;
+    x_out[r] = __fdiv_rn(nw, (float)outdeg[r]); // out_degree 0 -> +inf, never gathered (page_rank.rs:78,158)
+    return fabs((double)__fsub_rn(nw, old));
+}
+
+// ---- setup: first row whose marker lies in tile t --------------------------------------------
+// tile_row[t] = #rows r with off[r] + r < t*W  (t = 0..T-1), tile_row[T] = n.
+__global__ void pr_tile_rows_kernel(const uint32_t *__restrict__ off, uint32_t n, uint32_t T,
+                                    uint32_t *__restrict__ tile_row)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > T)
+        return;
+    if (t == T) {
+        tile_row[t] = n;
+        return;
+    }
+    const uint64_t target = (uint64_t)t * PR_W;
+    tile_row[t] = (uint32_t)lower_bound_fn(0, n, target, [&](uint64_t r) { return (uint64_t)off[r] + r; });
+}
+
+__global__ void pr_init_kernel(uint32_t n_local, float init, const uint32_t *__restrict__ outdeg,
+                               float *__restrict__ scores, float *__restrict__ x)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n_local; u += stride) {
+        scores[u] = init;
+        x[u] = __fdiv_rn(init, (float)outdeg[u]);
+    }
+}
+
+// out_degree[v] = number of occurrences of v in the in-lists
+__global__ void pr_count_outdeg_kernel(const uint32_t *__restrict__ tgt, uint64_t m, uint32_t *__restrict__ outdeg)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride)
+        atomicAdd(&outdeg[tgt[i]], 1u);
+}
+
+// ---- the sweep ---------------------------------------------------------------------------------
+struct Seg {
+    uint32_t r;    // local row
+    uint32_t s, e; // in-tile edge range, relative to the tile's first edge
+    int kind;      // 0 = whole row (finalize), 1 = head partial, 2 = tail partial, -1 = nothing
+};
+
+__device__ __forceinline__ Seg pr_decode_seg(uint32_t j, uint32_t rs, uint32_t eb, uint32_t ee,
+                                             const uint32_t *__restrict__ off)
+{
+    Seg g;
+    if (j == 0) { // the row that started before this tile and still has edges here
+        g.r = rs - 1;
+        g.s = 0;
+        const uint32_t end = off[rs]; // rs <= n_local: off has n_local + 1 entries
+        g.e = (end < ee ? end : ee) - eb;
+        g.kind = rs > 0 ? 1 : -1;
+        if (rs == 0)
+            g.e = 0;
+        return g;
+    }
+    g.r = rs + j - 1;
+    const uint32_t s = off[g.r], e = off[g.r + 1];
+    g.s = s - eb; // s >= eb by construction of the tile
+    if (e > ee) {
+        g.e = ee - eb;
+        g.kind = 2;
+    } else {
+        g.e = e - eb;
+        g.kind = 0;
+    }
+    return g;
+}
+
+__global__ __launch_bounds__(PR_BLOCK) void pr_tile_kernel(
+    const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const uint32_t *__restrict__ tile_row,
+    const float *__restrict__ x_in, const uint32_t *__restrict__ outdeg, float *__restrict__ scores,
+    float *__restrict__ x_out, float *__restrict__ head, float *__restrict__ tail, double *__restrict__ tile_err,
+    uint32_t m, float base, float damping)
+{
+    __shared__ float vals[PR_W];
+    __shared__ uint32_t longseg[PR_MAXLONG];
+    __shared__ uint32_t nlong;
+    __shared__ float head_v, tail_v;
+    __shared__ double red[PR_WAVES];
+
+    const uint32_t t = blockIdx.x, tid = threadIdx.x;
+    const uint32_t rs = tile_row[t], re = tile_row[t + 1];
+    const uint32_t eb = (uint32_t)((uint64_t)t * PR_W - rs);
+    const uint64_t ee64 = (uint64_t)(t + 1) * PR_W - re;
+    const uint32_t ee = ee64 < m ? (uint32_t)ee64 : m;
+    const uint32_t ne = ee - eb;
+
+    if (tid == 0) {
+        nlong = 0;
+        head_v = 0.0f;
+        tail_v = 0.0f;
+    }
+
+    // phase 1: stream the tile's targets (coalesced), gather x_in, park in LDS
+    {
+        uint32_t v[PR_EPT];
+#pragma unroll
+        for (int k = 0; k < PR_EPT; ++k) {
+            const uint32_t i = tid + k * PR_BLOCK;
+            v[k] = i < ne ? tgt[eb + i] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < PR_EPT; ++k) {
+            const uint32_t i = tid + k * PR_BLOCK;
+            if (i < ne)
+                vals[i] = x_in[v[k]];
+        }
+    }
+    __syncthreads();
+
+    // phase 2: one lane per row (segment 0 is the head partial)
+    const uint32_t nseg = re - rs + 1;
+    double err = 0.0;
+    for (uint32_t j = tid; j < nseg; j += PR_BLOCK) {
+        const Seg g = pr_decode_seg(j, rs, eb, ee, off);
+        if (g.kind < 0)
+            continue;
+        const uint32_t len = g.e - g.s;
+        if (len > PR_SHORT) {
+            longseg[atomicAdd(&nlong, 1u)] = j;
+            continue;
+        }
+        float sum = 0.0f;
+        for (uint32_t i = g.s; i < g.e; ++i)
+            sum += vals[i];
+        if (g.kind == 0)
+            err += pr_finalize(g.r, sum, base, damping, outdeg, scores, x_out);
+        else if (g.kind == 1)
+            head_v = sum;
+        else
+            tail_v = sum;
+    }
+    __syncthreads();
+
+    // phase 3: long rows, one wavefront each
+    const uint32_t nl = nlong;
+    const uint32_t lane = tid & (kWave - 1), wave = tid >> 6;
+    for (uint32_t k = wave; k < nl; k += PR_WAVES) {
+        const Seg g = pr_decode_seg(longseg[k], rs, eb, ee, off);
+        float sum = 0.0f;
+        for (uint32_t i = g.s + lane; i < g.e; i += kWave)
+            sum += vals[i];
+        sum = wave_sum(sum);
+        if (lane == 0) {
+            if (g.kind == 0)
+                err += pr_finalize(g.r, sum, base, damping, outdeg, scores, x_out);
+            else if (g.kind == 1)
+                head_v = sum;
+            else
+                tail_v = sum;
+        }
+    }
+    const double total = block_sum<double, PR_WAVES>(err, red); // contains a __syncthreads()
+    if (tid == 0) {
+        tile_err[t] = total;
+        head[t] = head_v;
+        tail[t] = tail_v;
+    }
+}
+
+// One lane per tile: finish the row that starts in tile t and ends in a later tile, then reduce
+// the sweep's error deterministically (last block done sums the block partials in index order).
+__global__ __launch_bounds__(PR_BLOCK) void pr_fixup_kernel(
+    const uint32_t *__restrict__ off, const uint32_t *__restrict__ tile_row, const uint32_t *__restrict__ outdeg,
+    float *__restrict__ scores, float *__restrict__ x_out, const float *__restrict__ head,
+    const float *__restrict__ tail, const double *__restrict__ tile_err, double *__restrict__ blk_err,
+    uint32_t *__restrict__ ticket, double *__restrict__ err_out, uint32_t T, uint32_t m, float base, float damping)
+{
+    __shared__ double red[PR_WAVES];
+    __shared__ bool is_last;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t t = blockIdx.x * PR_BLOCK + tid;
+    double err = 0.0;
+    if (t < T) {
+        err = tile_err[t];
+        const uint32_t rs = tile_row[t], re = tile_row[t + 1];
+        if (re > rs) {
+            const uint32_t r = re - 1; // last row whose marker is in tile t
+            const uint64_t ee64 = (uint64_t)(t + 1) * PR_W - re;
+            const uint32_t ee = ee64 < m ? (uint32_t)ee64 : m;
+            const uint32_t e = off[r + 1];
+            if (e > ee) { // it crosses the tile end: its last edge sits at merged position e + r
+                const uint32_t t1 = (uint32_t)(((uint64_t)e + r) / PR_W);
+                float sum = tail[t];
+                for (uint32_t k = t + 1; k <= t1; ++k)
+                    sum += head[k];
+                err += pr_finalize(r, sum, base, damping, outdeg, scores, x_out);
+            }
+        }
+    }
+    const double total = block_sum<double, PR_WAVES>(err, red);
+    if (tid == 0) {
+        st_agent(&blk_err[blockIdx.x], total);
+        __threadfence();
+        const uint32_t prev = atomicAdd(ticket, 1u);
+        is_last = (prev == gridDim.x - 1);
+    }
+    __syncthreads();
+    if (!is_last)
+        return;
+    __threadfence();
+    double acc = 0.0;
+    for (uint32_t b = tid; b < gridDim.x; b += PR_BLOCK)
+        acc += ld_agent(&blk_err[b]);
+    __syncthreads(); // red[] is reused
+    const double sweep = block_sum<double, PR_WAVES>(acc, red);
+    if (tid == 0) {
+        *err_out = sweep;
+        st_agent(ticket, 0u);
+    }
+}
+
+// ---- the reference's exact sequential order on one wavefront ----------------------------------
+// X_IN_LDS: out_scores live in LDS (n <= 16384 -> 64 KiB); otherwise in global memory, accessed
+// with L1-bypassing loads/stores so every lane sees lane 0's in-place update.
+template <bool X_IN_LDS>
+__global__ __launch_bounds__(kWave) void pr_seq_kernel(const uint32_t *__restrict__ off,
+                                                       const uint32_t *__restrict__ tgt,
+                                                       const uint32_t *__restrict__ outdeg, float *__restrict__ scores,
+                                                       float *xg, uint32_t n, float init, float base, float damping,
+                                                       uint64_t max_iterations, double tolerance,
+                                                       uint64_t *__restrict__ iterations_out,
+                                                       double *__restrict__ error_out)
+{
+    extern __shared__ float xs[];
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t u = lane; u < n; u += kWave) {
+        scores[u] = init;
+        const float o = __fdiv_rn(init, (float)outdeg[u]);
+        if (X_IN_LDS)
+            xs[u] = o;
+        else
+            st_agent(&xg[u], o);
+    }
+    __syncthreads();
+    uint64_t iter = 0;
+    double err = 0.0;
+    for (;;) {
+        err = 0.0;
+        for (uint32_t u = 0; u < n; ++u) {
+            const uint32_t s = off[u], e = off[u + 1];
+            float sum = 0.0f;
+            for (uint32_t c = s; c < e; c += kWave) {
+                const uint32_t idx = c + lane;
+                float v = 0.0f;
+                if (idx < e) {
+                    const uint32_t w = tgt[idx];
+                    v = X_IN_LDS ? xs[w] : ld_agent(&xg[w]);
+                }
+                const uint32_t cnt = (e - c) < (uint32_t)kWave ? (e - c) : (uint32_t)kWave;
+                for (uint32_t i = 0; i < cnt; ++i) // CSR order, one f32 add per edge (page_rank.rs:143-146)
+                    sum = __fadd_rn(sum, __shfl(v, (int)i, kWave));
+            }
+            const float old = scores[u];
+            const float nw = pr_new_score(base, damping, sum);
+            err += fabs((double)__fsub_rn(nw, old));
+            __syncthreads(); // every lane has read scores[u] / x before lane 0 overwrites them
+            if (lane == 0) {
+                scores[u] = nw;
+                const float o = __fdiv_rn(nw, (float)outdeg[u]);
+                if (X_IN_LDS)
+                    xs[u] = o;
+                else
+                    st_agent(&xg[u], o);
+            }
+            __syncthreads();
+        }
+        iter += 1;
+        if (err < tolerance || iter == max_iterations)
+            break;
+    }
+    if (lane == 0) {
+        *iterations_out = iter;
+        *error_out = err;
+    }
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------
+struct gm_pr {
+    const gm_csr *csr = nullptr;
+    uint64_t n_global = 0, row_begin = 0;
+    uint32_t n_local = 0, m = 0, T = 0, G = 0;
+    const uint32_t *outdeg = nullptr;
+    float damping = 0.85f, base = 0.0f, init = 0.0f;
+    gm::DevBuf tile_row, head, tail, tile_err, blk_err, ticket;
+};
+
+GM_API int gm_pr_create(const gm_csr *csr, uint64_t n_global, uint64_t row_begin, uint64_t d_out_degree_local,
+                        float damping_factor, gm_pr **out)
+{
+    GM_CHECK(csr && out, GM_ERR_INVALID, "gm_pr_create: null argument");
+    GM_CHECK(n_global > 0 && row_begin + csr->n <= n_global, GM_ERR_INVALID,
+             "gm_pr_create: rows [%llu, %llu) outside a graph of %llu nodes", (unsigned long long)row_begin,
+             (unsigned long long)(row_begin + csr->n), (unsigned long long)n_global);
+    GM_CHECK(d_out_degree_local != 0 || csr->n == 0, GM_ERR_INVALID, "gm_pr_create: out-degree pointer is null");
+    GM_CHECK(csr->n + csr->m < (1ull << 32), GM_ERR_RANGE, "gm_pr_create: n + m = %llu does not fit 32-bit tile positions",
+             (unsigned long long)(csr->n + csr->m));
+    gm::DeviceGuard guard(csr->device);
+    gm_pr *pr = new (std::nothrow) gm_pr();
+    GM_CHECK(pr, GM_ERR_NOMEM, "gm_pr_create: out of host memory");
+    pr->csr = csr;
+    pr->n_global = n_global;
+    pr->row_begin = row_begin;
+    pr->n_local = (uint32_t)csr->n;
+    pr->m = (uint32_t)csr->m;
+    pr->outdeg = reinterpret_cast<const uint32_t *>(d_out_degree_local);
+    pr->damping = damping_factor;
+    // page_rank.rs:70-71: init_score = 1/n, base_score = (1 - damping)/n, in f32
+    pr->init = 1.0f / (float)n_global;
+    pr->base = (1.0f - damping_factor) / (float)n_global;
+    const uint64_t items = csr->n + csr->m;
+    pr->T = (uint32_t)((items + PR_W - 1) / PR_W);
+    if (pr->T == 0)
+        pr->T = 1;
+    pr->G = gm::div_up(pr->T, PR_BLOCK);
+    int rc = GM_OK;
+    if ((rc = pr->tile_row.alloc(((size_t)pr->T + 1) * 4)) || (rc = pr->head.alloc((size_t)pr->T * 4)) ||
+        (rc = pr->tail.alloc((size_t)pr->T * 4)) || (rc = pr->tile_err.alloc((size_t)pr->T * 8)) ||
+        (rc = pr->blk_err.alloc((size_t)pr->G * 8)) || (rc = pr->ticket.alloc(16))) {
+        delete pr;
+        return rc;
+    }
+    hipError_t e = hipMemset(pr->ticket.p, 0, 16);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(pr_tile_rows_kernel, dim3(gm::div_up((uint64_t)pr->T + 1, 256)), dim3(256), 0, 0,
+                           csr->offsets, pr->n_local, pr->T, pr->tile_row.as<uint32_t>());
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        gm::set_error("gm_pr_create: %s", hipGetErrorString(e));
+        delete pr;
+        return GM_ERR_HIP;
+    }
+    *out = pr;
+    return GM_OK;
+}
+
+GM_API void gm_pr_destroy(gm_pr *pr) { delete pr; }
+
+GM_API uint64_t gm_pr_algorithmic_bytes(const gm_pr *pr)
+{
+    return pr ? 8ull * pr->m + 20ull * pr->n_local + 4ull : 0;
+}
+
+GM_API uint64_t gm_pr_tile_count(const gm_pr *pr) { return pr ? pr->T : 0; }
+
+GM_API int gm_pr_init(gm_pr *pr, uint64_t d_scores_local, uint64_t d_x_local, void *stream)
+{
+    GM_CHECK(pr, GM_ERR_INVALID, "gm_pr_init: null engine");
+    if (pr->n_local == 0)
+        return GM_OK;
+    gm::DeviceGuard guard(pr->csr->device);
+    unsigned grid = gm::div_up(pr->n_local, 256);
+    if (grid > 256 * 8)
+        grid = 256 * 8;
+    hipLaunchKernelGGL(pr_init_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, pr->n_local, pr->init,
+                       pr->outdeg, reinterpret_cast<float *>(d_scores_local), reinterpret_cast<float *>(d_x_local));
+    GM_HIP(hipGetLastError());
+    return GM_OK;
+}
+
+GM_API int gm_pr_sweep_tiles(gm_pr *pr, uint64_t d_x_in_global, uint64_t d_x_out_local, uint64_t d_scores_local,
+                             void *stream)
+{
+    GM_CHECK(pr, GM_ERR_INVALID, "gm_pr_sweep_tiles: null engine");
+    gm::DeviceGuard guard(pr->csr->device);
+    hipLaunchKernelGGL(pr_tile_kernel, dim3(pr->T), dim3(PR_BLOCK), 0, (hipStream_t)stream, pr->csr->offsets,
+                       pr->csr->targets, pr->tile_row.as<uint32_t>(), reinterpret_cast<const float *>(d_x_in_global),
+                       pr->outdeg, reinterpret_cast<float *>(d_scores_local), reinterpret_cast<float *>(d_x_out_local),
+                       pr->head.as<float>(), pr->tail.as<float>(), pr->tile_err.as<double>(), pr->m, pr->base,
+                       pr->damping);
+    GM_HIP(hipGetLastError());
+    return GM_OK;
+}
+
+GM_API int gm_pr_sweep_fixup(gm_pr *pr, uint64_t d_x_out_local, uint64_t d_scores_local, uint64_t d_error_out,
+                             void *stream)
+{
+    GM_CHECK(pr && d_error_out, GM_ERR_INVALID, "gm_pr_sweep_fixup: null argument");
+    gm::DeviceGuard guard(pr->csr->device);
+    hipLaunchKernelGGL(pr_fixup_kernel, dim3(pr->G), dim3(PR_BLOCK), 0, (hipStream_t)stream, pr->csr->offsets,
+                       pr->tile_row.as<uint32_t>(), pr->outdeg, reinterpret_cast<float *>(d_scores_local),
+                       reinterpret_cast<float *>(d_x_out_local), pr->head.as<float>(), pr->tail.as<float>(),
+                       pr->tile_err.as<double>(), pr->blk_err.as<double>(), pr->ticket.as<uint32_t>(),
+                       reinterpret_cast<double *>(d_error_out), pr->T, pr->m, pr->base, pr->damping);
+    GM_HIP(hipGetLastError());
+    return GM_OK;
+}
+
+GM_API int gm_pr_sweep(gm_pr *pr, uint64_t d_x_in_global, uint64_t d_x_out_local, uint64_t d_scores_local,
+                       uint64_t d_error_out, void *stream)
+{
+    GM_CHECK(pr && d_error_out, GM_ERR_INVALID, "gm_pr_sweep: null argument");
+    GM_TRY(gm_pr_sweep_tiles(pr, d_x_in_global, d_x_out_local, d_scores_local, stream));
+    return gm_pr_sweep_fixup(pr, d_x_out_local, d_scores_local, d_error_out, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gm_page_rank: the whole `page_rank()` call on one GPU with host result buffers.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+int pr_out_degrees(const gm_csr *csr, const uint32_t *host_outdeg, gm::DevBuf &buf, hipStream_t st)
+{
+    GM_TRY(buf.alloc((size_t)csr->n * 4));
+    if (host_outdeg) {
+        GM_HIP(hipMemcpyAsync(buf.p, host_outdeg, (size_t)csr->n * 4, hipMemcpyHostToDevice, st));
+    } else {
+        GM_HIP(hipMemsetAsync(buf.p, 0, (size_t)csr->n * 4, st));
+        if (csr->m) {
+            unsigned grid = gm::div_up(csr->m, 256);
+            if (grid > 256 * 16)
+                grid = 256 * 16;
+            hipLaunchKernelGGL(pr_count_outdeg_kernel, dim3(grid), dim3(256), 0, st, csr->targets, csr->m,
+                               buf.as<uint32_t>());
+            GM_HIP(hipGetLastError());
+        }
+    }
+    return GM_OK;
+}
+
+struct StreamHolder {
+    hipStream_t s = nullptr;
+    ~StreamHolder()
+    {
+        if (s)
+            (void)hipStreamDestroy(s);
+    }
+};
+
+struct PrHolder {
+    gm_pr *p = nullptr;
+    ~PrHolder() { delete p; }
+};
+
+} // namespace
+
+GM_API int gm_page_rank(const gm_csr *in_csr, const uint32_t *out_degree, uint64_t max_iterations, double tolerance,
+                        float damping_factor, int mode, float *scores_out, uint64_t *iterations_out,
+                        double *error_out)
+{
+    GM_CHECK(in_csr && iterations_out && error_out, GM_ERR_INVALID, "gm_page_rank: null argument");
+    GM_CHECK(mode == GM_PR_AUTO || mode == GM_PR_JACOBI || mode == GM_PR_SEQUENTIAL, GM_ERR_INVALID,
+             "gm_page_rank: unknown mode %d", mode);
+    // page_rank.rs:105-109: the loop only ends on error < tolerance or iteration == max_iterations
+    GM_CHECK(max_iterations != 0 || tolerance > 0.0, GM_ERR_INVALID,
+             "gm_page_rank: max_iterations == 0 with tolerance <= 0 never terminates (reference: infinite loop)");
+    const uint64_t n = in_csr->n;
+    if (n == 0) { // one empty sweep: error 0.0
+        GM_CHECK(0.0 < tolerance || max_iterations == 1, GM_ERR_INVALID,
+                 "gm_page_rank: empty graph with tolerance <= 0 never terminates (reference: infinite loop)");
+        *iterations_out = 1;
+        *error_out = 0.0;
+        return GM_OK;
+    }
+    GM_CHECK(scores_out, GM_ERR_INVALID, "gm_page_rank: scores_out is null");
+    if (mode == GM_PR_AUTO)
+        mode = n <= 16384 ? GM_PR_SEQUENTIAL : GM_PR_JACOBI;
+
+    gm::DeviceGuard guard(in_csr->device);
+    StreamHolder sh;
+    GM_HIP(hipStreamCreateWithFlags(&sh.s, hipStreamNonBlocking));
+    hipStream_t st = sh.s;
+
+    gm::DevBuf outdeg, scores, x0, x1, dres;
+    gm::PinnedBuf hres;
+    GM_TRY(pr_out_degrees(in_csr, out_degree, outdeg, st));
+    GM_TRY(scores.alloc(n * 4));
+    GM_TRY(dres.alloc(16));
+    GM_TRY(hres.alloc(16));
+
+    const float init = 1.0f / (float)n;
+    const float base = (1.0f - damping_factor) / (float)n;
+
+    if (mode == GM_PR_SEQUENTIAL) {
+        const bool lds = n <= 16384;
+        if (!lds)
+            GM_TRY(x0.alloc(n * 4));
+        uint64_t *d_iter = dres.as<uint64_t>();
+        double *d_err = reinterpret_cast<double *>(dres.as<char>() + 8);
+        if (lds)
+            GM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pr_seq_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4));
+        if (lds)
+            hipLaunchKernelGGL(pr_seq_kernel<true>, dim3(1), dim3(kWave), n * 4, st, in_csr->offsets,
+                               in_csr->targets, outdeg.as<uint32_t>(), scores.as<float>(), (float *)nullptr,
+                               (uint32_t)n, init, base, damping_factor, max_iterations, tolerance, d_iter, d_err);
+        else
+            hipLaunchKernelGGL(pr_seq_kernel<false>, dim3(1), dim3(kWave), 0, st, in_csr->offsets, in_csr->targets,
+                               outdeg.as<uint32_t>(), scores.as<float>(), x0.as<float>(), (uint32_t)n, init, base,
+                               damping_factor, max_iterations, tolerance, d_iter, d_err);
+        GM_HIP(hipGetLastError());
+        GM_HIP(hipMemcpyAsync(hres.p, dres.p, 16, hipMemcpyDeviceToHost, st));
+        GM_HIP(hipMemcpyAsync(scores_out, scores.p, n * 4, hipMemcpyDeviceToHost, st));
+        GM_HIP(hipStreamSynchronize(st));
+        *iterations_out = hres.as<uint64_t>()[0];
+        *error_out = hres.as<double>()[1];
+        return GM_OK;
+    }
+
+    // synchronous sweeps
+    GM_TRY(x0.alloc(n * 4));
+    GM_TRY(x1.alloc(n * 4));
+    PrHolder ph;
+    GM_TRY(gm_pr_create(in_csr, n, 0, (uint64_t)outdeg.p, damping_factor, &ph.p));
+    GM_TRY(gm_pr_init(ph.p, (uint64_t)scores.p, (uint64_t)x0.p, st));
+    uint64_t iter = 0;
+    double err = 0.0;
+    float *xin = x0.as<float>(), *xout = x1.as<float>();
+    const bool can_stop_early = tolerance > 0.0; // error >= 0 always
+    for (;;) {
+        GM_TRY(gm_pr_sweep(ph.p, (uint64_t)xin, (uint64_t)xout, (uint64_t)scores.p, (uint64_t)dres.p, st));
+        iter += 1;
+        float *tmp = xin;
+        xin = xout;
+        xout = tmp;
+        const bool last = iter == max_iterations;
+        if (can_stop_early || last) {
+            GM_HIP(hipMemcpyAsync(hres.p, dres.p, 8, hipMemcpyDeviceToHost, st));
+            GM_HIP(hipStreamSynchronize(st));
+            err = hres.as<double>()[0];
+            if (err < tolerance || last)
+                break;
+        }
+    }
+    GM_HIP(hipMemcpyAsync(scores_out, scores.p, n * 4, hipMemcpyDeviceToHost, st));
+    GM_HIP(hipStreamSynchronize(st));
+    *iterations_out = iter;
+    *error_out = err;
+    return GM_OK;
+}

@@ -1,0 +1,236 @@
+// wcc.hip — weakly connected components (Afforest) on device-resident out-/in-CSR.
+//
+// Replaces crates/algos/src/wcc.rs:103-301 + crates/algos/src/afforest.rs:22-56.
+// The parent array lives in HBM (u32[n]); `link` is the reference's Afforest::union with
+// atomicCAS (agent scope) and L1-bypassing loads — a plain load could spin forever on a stale L1
+// line that another CU has since rewritten (MI355X_MICROARCH.md, inter-workgroup visibility).
+// Invariant parent[x] <= x  =>  after the final compress parent[u] is the minimum node id of u's
+// component, independent of schedule: results are bit-exact with the reference's
+// Components::component(u) for wcc_afforest, wcc_afforest_dss and wcc_baseline alike.
+//
+// Pipeline (wcc.rs:164-182): sample_subgraph -> compress -> find_largest_component ->
+// link_remaining -> compress.  Work distribution: one lane per node for short lists; lists longer
+// than 32 entries are spread over the node's whole wavefront (RMAT hubs).
+#include "common.hpp"
+#include "device_utils.hpp"
+
+namespace {
+
+using namespace gm;
+
+constexpr int WCC_BLOCK = 256;
+constexpr uint32_t WCC_COOP = 32; // lists longer than this are linked by the whole wavefront
+
+// afforest.rs:22-39
+__device__ __forceinline__ void af_link(uint32_t *parent, uint32_t u, uint32_t v)
+{
+    uint32_t p1 = ld_agent(&parent[u]);
+    uint32_t p2 = ld_agent(&parent[v]);
+    while (p1 != p2) {
+        const uint32_t high = p1 > p2 ? p1 : p2;
+        const uint32_t low = p1 + p2 - high;
+        const uint32_t p_high = ld_agent(&parent[high]);
+        if (p_high == low)
+            break;
+        if (p_high == high && atomicCAS(&parent[high], high, low) == high)
+            break;
+        p1 = ld_agent(&parent[ld_agent(&parent[high])]);
+        p2 = ld_agent(&parent[low]);
+    }
+}
+
+__global__ void wcc_init_kernel(uint32_t *__restrict__ parent, uint32_t n)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += stride)
+        parent[u] = u;
+}
+
+// afforest.rs:50-56
+__global__ void wcc_compress_kernel(uint32_t *parent, uint32_t n)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += stride) {
+        uint32_t p = ld_agent(&parent[u]);
+        uint32_t pp = ld_agent(&parent[p]);
+        while (p != pp) {
+            st_agent(&parent[u], pp);
+            p = pp;
+            pp = ld_agent(&parent[p]);
+        }
+    }
+}
+
+// wcc.rs:186-204: link u with its first `rounds` out-neighbours
+__global__ void wcc_sample_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt,
+                                  uint32_t *parent, uint32_t n, uint64_t rounds)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += stride) {
+        const uint32_t s = off[u], e = off[u + 1];
+        const uint64_t take = (uint64_t)(e - s) < rounds ? (uint64_t)(e - s) : rounds;
+        for (uint64_t k = 0; k < take; ++k)
+            af_link(parent, u, tgt[s + k]);
+    }
+}
+
+// Link u with list[s..e): short lists by the owning lane, long lists by the whole wavefront.
+// Must be called by all 64 lanes of a wavefront (lanes without work pass s == e).
+__device__ __forceinline__ void wcc_link_list(const uint32_t *__restrict__ tgt, uint32_t *parent, uint32_t u,
+                                              uint32_t s, uint32_t e)
+{
+    const uint32_t len = e - s;
+    if (len <= WCC_COOP)
+        for (uint32_t i = s; i < e; ++i)
+            af_link(parent, u, tgt[i]);
+    uint64_t big = __ballot(len > WCC_COOP);
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    while (big) {
+        const int src = __ffsll((unsigned long long)big) - 1;
+        big &= big - 1;
+        const uint32_t bu = __shfl(u, src, kWave), bs = __shfl(s, src, kWave), be = __shfl(e, src, kWave);
+        for (uint32_t i = bs + lane; i < be; i += kWave)
+            af_link(parent, bu, tgt[i]);
+    }
+}
+
+// wcc.rs:274-301 (skip = UINT32_MAX never matches a parent: link everything, used by wcc_baseline
+// with rounds = 0 and no in-CSR)
+__global__ __launch_bounds__(WCC_BLOCK) void wcc_link_remaining_kernel(
+    const uint32_t *__restrict__ out_off, const uint32_t *__restrict__ out_tgt, const uint32_t *__restrict__ in_off,
+    const uint32_t *__restrict__ in_tgt, uint32_t *parent, uint32_t n, uint64_t rounds, const uint32_t *skip_ptr)
+{
+    const uint32_t skip = skip_ptr ? *skip_ptr : 0xFFFFFFFFu;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t n_pad = (n + kWave - 1) / kWave * kWave; // whole wavefronts enter the loop together
+    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n_pad; u += stride) {
+        const bool active = u < n && ld_agent(&parent[u]) != skip;
+        uint32_t s = 0, e = 0;
+        if (active) {
+            s = out_off[u];
+            e = out_off[u + 1];
+            s = (uint64_t)(e - s) > rounds ? s + (uint32_t)rounds : e;
+        }
+        wcc_link_list(out_tgt, parent, u, s, e);
+        if (in_off) {
+            s = e = 0;
+            if (active) {
+                s = in_off[u];
+                e = in_off[u + 1];
+            }
+            wcc_link_list(in_tgt, parent, u, s, e);
+        }
+    }
+}
+
+// wcc.rs:245-271: most frequent component among `samples` random nodes.  The reference draws from
+// an unseeded WyRand; the choice only decides which component link_remaining skips and never
+// changes the result.  One workgroup; ties -> smallest id.
+__global__ __launch_bounds__(WCC_BLOCK) void wcc_sample_mode_kernel(const uint32_t *parent, uint32_t n,
+                                                                     uint32_t samples, uint64_t seed,
+                                                                     uint32_t *__restrict__ sample_buf,
+                                                                     uint32_t *__restrict__ skip_out)
+{
+    __shared__ unsigned long long best; // (count << 32) | ~id  -> max picks highest count, then smallest id
+    if (threadIdx.x == 0)
+        best = 0ull;
+    for (uint32_t k = threadIdx.x; k < samples; k += WCC_BLOCK) {
+        uint64_t x = seed + k;
+        x += 0x9E3779B97F4A7C15ull;
+        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+        x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+        x ^= x >> 31;
+        sample_buf[k] = ld_agent(&parent[(uint32_t)(x % n)]);
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < samples; k += WCC_BLOCK) {
+        const uint32_t c = sample_buf[k];
+        uint32_t cnt = 0;
+        for (uint32_t j = 0; j < samples; ++j)
+            cnt += sample_buf[j] == c;
+        atomicMax(&best, ((unsigned long long)cnt << 32) | (uint32_t)~c);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        *skip_out = ~(uint32_t)best;
+}
+
+unsigned wcc_grid(uint64_t n)
+{
+    unsigned g = gm::div_up(n, WCC_BLOCK);
+    return g > 256 * 8 ? 256 * 8 : (g ? g : 1);
+}
+
+} // namespace
+
+namespace gm {
+// Shared by gm_wcc_afforest / gm_wcc_baseline; leaves the labels in d_parent (u32[n]).
+int wcc_device(const gm_csr *out_csr, const gm_csr *in_csr, uint64_t rounds, uint64_t sampling, bool afforest,
+               uint32_t *d_parent, hipStream_t st)
+{
+    const uint32_t n = (uint32_t)out_csr->n;
+    const unsigned grid = wcc_grid(n);
+    hipLaunchKernelGGL(wcc_init_kernel, dim3(grid), dim3(WCC_BLOCK), 0, st, d_parent, n);
+    if (!afforest) { // wcc.rs:103-122: union every out-edge
+        hipLaunchKernelGGL(wcc_link_remaining_kernel, dim3(grid), dim3(WCC_BLOCK), 0, st, out_csr->offsets,
+                           out_csr->targets, (const uint32_t *)nullptr, (const uint32_t *)nullptr, d_parent, n,
+                           (uint64_t)0, (const uint32_t *)nullptr);
+        hipLaunchKernelGGL(wcc_compress_kernel, dim3(grid), dim3(WCC_BLOCK), 0, st, d_parent, n);
+        GM_HIP(hipGetLastError());
+        return GM_OK;
+    }
+    gm::DevBuf scratch;
+    GM_TRY(scratch.alloc((sampling + 1) * 4));
+    uint32_t *d_skip = scratch.as<uint32_t>() + sampling;
+    hipLaunchKernelGGL(wcc_sample_kernel, dim3(grid), dim3(WCC_BLOCK), 0, st, out_csr->offsets, out_csr->targets,
+                       d_parent, n, rounds);
+    hipLaunchKernelGGL(wcc_compress_kernel, dim3(grid), dim3(WCC_BLOCK), 0, st, d_parent, n);
+    hipLaunchKernelGGL(wcc_sample_mode_kernel, dim3(1), dim3(WCC_BLOCK), 0, st, d_parent, n, (uint32_t)sampling,
+                       (uint64_t)0x2545F4914F6CDD1Dull, scratch.as<uint32_t>(), d_skip);
+    hipLaunchKernelGGL(wcc_link_remaining_kernel, dim3(grid), dim3(WCC_BLOCK), 0, st, out_csr->offsets,
+                       out_csr->targets, in_csr->offsets, in_csr->targets, d_parent, n, rounds,
+                       (const uint32_t *)d_skip);
+    hipLaunchKernelGGL(wcc_compress_kernel, dim3(grid), dim3(WCC_BLOCK), 0, st, d_parent, n);
+    GM_HIP(hipGetLastError());
+    GM_HIP(hipStreamSynchronize(st)); // scratch is freed on return
+    return GM_OK;
+}
+} // namespace gm
+
+GM_API int gm_wcc_afforest(const gm_csr *out_csr, const gm_csr *in_csr, uint64_t neighbor_rounds,
+                           uint64_t sampling_size, uint32_t *components_out)
+{
+    GM_CHECK(out_csr && in_csr, GM_ERR_INVALID, "gm_wcc_afforest: null CSR");
+    GM_CHECK(out_csr->n == in_csr->n && out_csr->device == in_csr->device, GM_ERR_INVALID,
+             "gm_wcc_afforest: out/in CSR disagree (n %llu vs %llu)", (unsigned long long)out_csr->n,
+             (unsigned long long)in_csr->n);
+    // wcc.rs:260-263: max_by(...).unwrap() on an empty sample map panics
+    GM_CHECK(sampling_size > 0, GM_ERR_INVALID, "gm_wcc_afforest: sampling_size must be > 0 (reference panics)");
+    GM_CHECK(sampling_size <= (1u << 20), GM_ERR_RANGE, "gm_wcc_afforest: sampling_size %llu too large",
+             (unsigned long long)sampling_size);
+    const uint64_t n = out_csr->n;
+    // wcc.rs:256: generate_range(0..0) on an empty graph panics
+    GM_CHECK(n > 0, GM_ERR_INVALID, "gm_wcc_afforest: empty graph (reference panics when sampling)");
+    GM_CHECK(components_out, GM_ERR_INVALID, "gm_wcc_afforest: components_out is null");
+    gm::DeviceGuard guard(out_csr->device);
+    gm::DevBuf parent;
+    GM_TRY(parent.alloc(n * 4));
+    GM_TRY(gm::wcc_device(out_csr, in_csr, neighbor_rounds, sampling_size, true, parent.as<uint32_t>(), 0));
+    GM_HIP(hipMemcpy(components_out, parent.p, n * 4, hipMemcpyDeviceToHost));
+    return GM_OK;
+}
+
+GM_API int gm_wcc_baseline(const gm_csr *out_csr, uint32_t *components_out)
+{
+    GM_CHECK(out_csr, GM_ERR_INVALID, "gm_wcc_baseline: null CSR");
+    const uint64_t n = out_csr->n;
+    if (n == 0)
+        return GM_OK;
+    GM_CHECK(components_out, GM_ERR_INVALID, "gm_wcc_baseline: components_out is null");
+    gm::DeviceGuard guard(out_csr->device);
+    gm::DevBuf parent;
+    GM_TRY(parent.alloc(n * 4));
+    GM_TRY(gm::wcc_device(out_csr, nullptr, 0, 0, false, parent.as<uint32_t>(), 0));
+    GM_HIP(hipMemcpy(components_out, parent.p, n * 4, hipMemcpyDeviceToHost));
+    return GM_OK;
+}

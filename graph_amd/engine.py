@@ -1,0 +1,61 @@
+"""Resident PageRank engine over torch device tensors (plumbing: memory + streams only).
+
+Wraps gm_pr_create / gm_pr_init / gm_pr_sweep: the sweep kernels of graph_amd/csrc/pagerank.hip
+run on torch's current HIP stream, so torch.cuda.Event brackets them exactly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from ._lib import check, lib, vp
+
+
+def current_stream_ptr() -> vp:
+    return vp(torch.cuda.current_stream().cuda_stream)
+
+
+class PageRankEngine:
+    """page_rank_iteration (crates/algos/src/page_rank.rs:113-168) over rows
+    [row_begin, row_begin + n_local) of a graph with n_global nodes; arrays are torch tensors."""
+
+    def __init__(self, in_csr_handle, n_global: int, row_begin: int, out_degree_local: torch.Tensor,
+                 damping_factor: float = 0.85):
+        assert out_degree_local.dtype == torch.int32 and out_degree_local.is_cuda
+        self._keep = (in_csr_handle, out_degree_local)
+        h = vp()
+        check(lib().gm_pr_create(in_csr_handle, n_global, row_begin, out_degree_local.data_ptr(),
+                                 damping_factor, C.byref(h)))
+        self._h = h
+        self.n_local = int(out_degree_local.numel())
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib().gm_pr_destroy(h)
+
+    @property
+    def algorithmic_bytes(self) -> int:
+        return int(lib().gm_pr_algorithmic_bytes(self._h))
+
+    @property
+    def tiles(self) -> int:
+        return int(lib().gm_pr_tile_count(self._h))
+
+    def init(self, scores_local: torch.Tensor, x_local: torch.Tensor):
+        check(lib().gm_pr_init(self._h, scores_local.data_ptr(), x_local.data_ptr(), current_stream_ptr()))
+
+    def sweep(self, x_in: torch.Tensor, x_out_local: torch.Tensor, scores_local: torch.Tensor,
+              err_out: torch.Tensor):
+        """one synchronous sweep; err_out: f64[1] device tensor receiving this rank's L1 error share"""
+        check(lib().gm_pr_sweep(self._h, x_in.data_ptr(), x_out_local.data_ptr(), scores_local.data_ptr(),
+                                err_out.data_ptr(), current_stream_ptr()))
+
+    def sweep_tiles(self, x_in, x_out_local, scores_local):
+        check(lib().gm_pr_sweep_tiles(self._h, x_in.data_ptr(), x_out_local.data_ptr(), scores_local.data_ptr(),
+                                      current_stream_ptr()))
+
+    def sweep_fixup(self, x_out_local, scores_local, err_out):
+        check(lib().gm_pr_sweep_fixup(self._h, x_out_local.data_ptr(), scores_local.data_ptr(), err_out.data_ptr(),
+                                      current_stream_ptr()))

@@ -1,0 +1,426 @@
+"""Host-side mirror of the reference's ``graph::prelude`` over the MI355X C ABI.
+
+Same names, argument meaning and error behaviour as the Rust API
+(crates/algos/src/prelude.rs:1-7 re-exporting crates/builder/src/prelude.rs), so the parity tests
+read like the reference's own tests:
+
+    g = GraphBuilder().csr_layout(CsrLayout.Sorted).edges([(0, 1), (1, 2)]).build(DirectedCsrGraph)
+    scores, iterations, error = page_rank(g, PageRankConfig(10, 1e-4, 0.85))
+    components = wcc_afforest(g, WccConfig()).to_vec()
+    distances = delta_stepping(gw, DeltaSteppingConfig(0, 3.0))
+    triangles = global_triangle_count(ug)
+
+Graph objects own device-resident CSR handles (uploaded / built once); every algorithm runs in the
+hand-written HIP kernels of graph_amd/csrc.  Where the reference panics (out-of-range start node,
+empty sample set, ...) these functions raise.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib, vp, u64, f64
+
+
+class CsrLayout(enum.IntEnum):
+    """crates/builder/src/graph/csr.rs:34-45 (default: Unsorted)."""
+    Unsorted = 0
+    Sorted = 1
+    Deduplicated = 2
+
+
+class Direction(enum.IntEnum):
+    Outgoing = 0
+    Incoming = 1
+    Undirected = 2
+
+
+def _u32(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(vp) if a is not None else None
+
+
+class DeviceCsr:
+    """One device-resident CSR (offsets/targets[/weights] in HBM); lazily mirrored to the host for
+    the per-node accessors of the reference's graph traits."""
+
+    def __init__(self, handle):
+        self._h = handle
+        self._host = None
+
+    @classmethod
+    def from_edges(cls, n, src, dst, weights, direction, layout, device=0):
+        src, dst = _u32(src), _u32(dst)
+        w = None if weights is None else np.ascontiguousarray(weights, np.float32)
+        h = vp()
+        check(lib().gm_csr_build_host(n, src.size, _ptr(src), _ptr(dst), _ptr(w), int(direction), int(layout),
+                                      device, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_arrays(cls, offsets, targets, weights=None, device=0):
+        offsets = np.ascontiguousarray(offsets)
+        targets = np.ascontiguousarray(targets)
+        w = None if weights is None else np.ascontiguousarray(weights, np.float32)
+        h = vp()
+        n, m = offsets.size - 1, targets.size
+        if offsets.dtype == np.uint64 or targets.dtype == np.uint64:  # usize graphs
+            o64, t64 = offsets.astype(np.uint64), targets.astype(np.uint64)
+            check(lib().gm_csr_upload_u64(_ptr(o64), _ptr(t64), _ptr(w), n, m, device, C.byref(h)))
+        else:
+            o32, t32 = _u32(offsets), _u32(targets)
+            check(lib().gm_csr_upload_u32(_ptr(o32), _ptr(t32), _ptr(w), n, m, device, C.byref(h)))
+        return cls(h)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                lib().gm_csr_free(h)
+            except Exception:
+                pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def n(self):
+        return int(lib().gm_csr_node_count(self._h))
+
+    @property
+    def m(self):
+        return int(lib().gm_csr_edge_count(self._h))
+
+    @property
+    def weighted(self):
+        return lib().gm_csr_weights_ptr(self._h) != 0
+
+    def host(self):
+        if self._host is None:
+            off = np.empty(self.n + 1, np.uint32)
+            tgt = np.empty(self.m, np.uint32)
+            w = np.empty(self.m, np.float32) if self.weighted else None
+            check(lib().gm_csr_download(self._h, _ptr(off), _ptr(tgt) if self.m else None,
+                                        _ptr(w) if (w is not None and self.m) else None))
+            self._host = (off, tgt, w)
+        return self._host
+
+    def degrees(self):
+        d = np.empty(self.n, np.uint32)
+        check(lib().gm_csr_degrees(self._h, _ptr(d) if self.n else None))
+        return d
+
+
+class _GraphBase:
+    def node_count(self):
+        return self._n
+
+    def _check_node(self, u):
+        if not 0 <= u < self._n:
+            raise IndexError(f"node {u} out of range (node_count {self._n})")
+
+
+class DirectedCsrGraph(_GraphBase):
+    """DirectedCsrGraph = csr_out + csr_inc (crates/builder/src/graph/csr.rs:364-520)."""
+
+    def __init__(self, csr_out: DeviceCsr, csr_inc: DeviceCsr, layout=CsrLayout.Unsorted, edges=None):
+        self.csr_out, self.csr_inc = csr_out, csr_inc
+        self._n = csr_out.n
+        self.layout = layout
+        self._edges = edges  # (src, dst, weights) kept for to_undirected
+
+    def edge_count(self):
+        return self.csr_out.m
+
+    def out_degree(self, u):
+        self._check_node(u)
+        off = self.csr_out.host()[0]
+        return int(off[u + 1] - off[u])
+
+    def in_degree(self, u):
+        self._check_node(u)
+        off = self.csr_inc.host()[0]
+        return int(off[u + 1] - off[u])
+
+    def out_neighbors(self, u):
+        self._check_node(u)
+        off, tgt, _ = self.csr_out.host()
+        return tgt[off[u]:off[u + 1]]
+
+    def in_neighbors(self, u):
+        self._check_node(u)
+        off, tgt, _ = self.csr_inc.host()
+        return tgt[off[u]:off[u + 1]]
+
+    def out_neighbors_with_values(self, u):
+        self._check_node(u)
+        off, tgt, w = self.csr_out.host()
+        return list(zip(tgt[off[u]:off[u + 1]].tolist(), w[off[u]:off[u + 1]].tolist()))
+
+    def in_neighbors_with_values(self, u):
+        self._check_node(u)
+        off, tgt, w = self.csr_inc.host()
+        return list(zip(tgt[off[u]:off[u + 1]].tolist(), w[off[u]:off[u + 1]].tolist()))
+
+    def to_undirected(self, layout=None):
+        """ToUndirectedOp (crates/builder/src/graph_ops.rs:176-230, csr.rs:391-464): an Undirected
+        build over this graph's out-edges."""
+        layout = self.layout if layout is None else layout
+        off, tgt, w = self.csr_out.host()
+        src = np.repeat(np.arange(self._n, dtype=np.uint32), np.diff(off))
+        csr = DeviceCsr.from_edges(self._n, src, tgt, w, Direction.Undirected, layout)
+        return UndirectedCsrGraph(csr, layout)
+
+
+class UndirectedCsrGraph(_GraphBase):
+    """UndirectedCsrGraph = one symmetrised CSR (crates/builder/src/graph/csr.rs:658-732)."""
+
+    def __init__(self, csr: DeviceCsr, layout=CsrLayout.Unsorted):
+        self.csr = csr
+        self._n = csr.n
+        self.layout = layout
+
+    def edge_count(self):
+        return self.csr.m // 2  # csr.rs:687-689
+
+    def degree(self, u):
+        self._check_node(u)
+        off = self.csr.host()[0]
+        return int(off[u + 1] - off[u])
+
+    def neighbors(self, u):
+        self._check_node(u)
+        off, tgt, _ = self.csr.host()
+        return tgt[off[u]:off[u + 1]]
+
+    def make_degree_ordered(self):
+        """RelabelByDegreeOp (graph_ops.rs:240-253, 511-638); swaps the CSR in place and returns
+        the old-id -> new-id map."""
+        new_id = np.empty(self._n, np.uint32)
+        h = vp()
+        check(lib().gm_csr_relabel_by_degree(self.csr.handle, C.byref(h), _ptr(new_id) if self._n else None))
+        self.csr = DeviceCsr(h)
+        return new_id
+
+
+# ------------------------------------------------------------------------------------------------
+# inputs (crates/builder/src/input/{edgelist,graph500}.rs) and the builder
+# ------------------------------------------------------------------------------------------------
+class EdgeListInput:
+    """`source target[ weight]` per line, \\n or \\r\\n (input/edgelist.rs:181-265)."""
+
+    def __init__(self, weighted=False):
+        self.weighted = weighted
+
+    def read(self, path):
+        cols = 3 if self.weighted else 2
+        with open(path, "rb") as f:
+            toks = f.read().split()
+        if len(toks) % cols:
+            raise ValueError(f"{path}: malformed edge list")
+        arr = np.array(toks).reshape(-1, cols)
+        src = arr[:, 0].astype(np.uint64)
+        dst = arr[:, 1].astype(np.uint64)
+        w = arr[:, 2].astype(np.float32) if self.weighted else None
+        n = int(max(src.max(), dst.max())) + 1 if src.size else 0  # csr.rs:530: max id + 1
+        return src, dst, w, n
+
+
+class Graph500Input:
+    """12-byte packed edges (input/graph500.rs:111-127); node_count = edge_count / 16 (:74)."""
+
+    def read(self, path):
+        raw = np.fromfile(path, dtype="<u4")
+        if raw.size % 3:
+            raise ValueError(f"{path}: size is not a multiple of 12 bytes")
+        raw = raw.reshape(-1, 3)
+        hi = raw[:, 2].astype(np.uint64)
+        src = raw[:, 0].astype(np.uint64) | ((hi & np.uint64(0xFFFF)) << np.uint64(32))
+        dst = raw[:, 1].astype(np.uint64) | ((hi >> np.uint64(16)) << np.uint64(32))
+        return src, dst, None, raw.shape[0] // 16
+
+
+class GraphBuilder:
+    """GraphBuilder::new().csr_layout(..).edges(..) | .file_format(..).path(..) -> build()
+    (crates/builder/src/builder.rs:123-540).  ``build(kind)`` takes the graph type the Rust
+    caller would name in its type annotation."""
+
+    def __init__(self):
+        self._layout = CsrLayout.Unsorted
+        self._edges = None
+        self._format = None
+        self._path = None
+        self._device = 0
+
+    def csr_layout(self, layout):
+        self._layout = CsrLayout(layout)
+        return self
+
+    def device(self, device):
+        self._device = device
+        return self
+
+    def edges(self, edges):
+        e = np.asarray(list(edges), dtype=np.uint64).reshape(-1, 2)
+        self._edges = (e[:, 0], e[:, 1], None)
+        return self
+
+    def edges_with_values(self, edges):
+        lst = list(edges)
+        s = np.array([x[0] for x in lst], np.uint64)
+        d = np.array([x[1] for x in lst], np.uint64)
+        w = np.array([x[2] for x in lst], np.float32)
+        self._edges = (s, d, w)
+        return self
+
+    def file_format(self, fmt):
+        self._format = fmt
+        return self
+
+    def path(self, path):
+        self._path = os.fspath(path)
+        return self
+
+    def build(self, kind=None):
+        kind = kind or DirectedCsrGraph
+        if self._edges is not None:
+            src, dst, w = self._edges
+            n = int(max(src.max(), dst.max())) + 1 if src.size else 0
+        elif self._format is not None and self._path is not None:
+            src, dst, w, n = self._format.read(self._path)
+        else:
+            raise ValueError("GraphBuilder: no edges and no file_format/path")
+        if n >= 2**32 or (src.size and max(int(src.max()), int(dst.max())) >= 2**32):
+            raise OverflowError("node ids do not fit the u32 device id type")
+        src, dst = src.astype(np.uint32), dst.astype(np.uint32)
+        if kind is DirectedCsrGraph:
+            out = DeviceCsr.from_edges(n, src, dst, w, Direction.Outgoing, self._layout, self._device)
+            inc = DeviceCsr.from_edges(n, src, dst, w, Direction.Incoming, self._layout, self._device)
+            return DirectedCsrGraph(out, inc, self._layout)
+        if kind is UndirectedCsrGraph:
+            csr = DeviceCsr.from_edges(n, src, dst, w, Direction.Undirected, self._layout, self._device)
+            return UndirectedCsrGraph(csr, self._layout)
+        raise TypeError(f"unknown graph kind {kind!r}")
+
+
+# ------------------------------------------------------------------------------------------------
+# algorithms
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class PageRankConfig:
+    """crates/algos/src/page_rank.rs:14-56"""
+    max_iterations: int = 20
+    tolerance: float = 1e-4
+    damping_factor: float = 0.85
+
+    DEFAULT_MAX_ITERATIONS = 20
+    DEFAULT_TOLERANCE = 1e-4
+    DEFAULT_DAMPING_FACTOR = 0.85
+
+
+class PageRankMode(enum.IntEnum):
+    Auto = 0        # n <= 16384: Sequential (bit-exact with the reference), else Jacobi
+    Jacobi = 1
+    Sequential = 2
+
+
+def page_rank(graph: DirectedCsrGraph, config: PageRankConfig | None = None, mode=PageRankMode.Auto):
+    """page_rank(&graph, config) -> (scores, iterations, error) — crates/algos/src/page_rank.rs:58-111."""
+    config = config or PageRankConfig()
+    n = graph.node_count()
+    out_deg = graph.csr_out.degrees()
+    scores = np.empty(n, np.float32)
+    it, err = u64(0), f64(0.0)
+    check(lib().gm_page_rank(graph.csr_inc.handle, _ptr(out_deg) if n else None, int(config.max_iterations),
+                             float(config.tolerance), float(config.damping_factor), int(mode),
+                             _ptr(scores) if n else None, C.byref(it), C.byref(err)))
+    return scores, int(it.value), float(err.value)
+
+
+@dataclass
+class WccConfig:
+    """crates/algos/src/wcc.rs:43-79 (chunk_size is a CPU scheduling knob; ignored on the device)"""
+    chunk_size: int = 16384
+    neighbor_rounds: int = 2
+    sampling_size: int = 1024
+
+
+class Components:
+    """Components<NI> (wcc.rs:95-99)"""
+
+    def __init__(self, labels):
+        self._labels = labels
+
+    def component(self, node):
+        return int(self._labels[node])
+
+    def to_vec(self):
+        return self._labels
+
+
+def wcc_afforest(graph: DirectedCsrGraph, config: WccConfig | None = None) -> Components:
+    """wcc_afforest — crates/algos/src/wcc.rs:127-141"""
+    config = config or WccConfig()
+    labels = np.empty(graph.node_count(), np.uint32)
+    check(lib().gm_wcc_afforest(graph.csr_out.handle, graph.csr_inc.handle, int(config.neighbor_rounds),
+                                int(config.sampling_size), _ptr(labels) if labels.size else None))
+    return Components(labels)
+
+
+def wcc_afforest_dss(graph: DirectedCsrGraph, config: WccConfig | None = None) -> Components:
+    """wcc_afforest_dss — crates/algos/src/wcc.rs:144-156.  The union-find backend is a CPU data
+    structure choice; component(u) (the root = minimum id) is identical, so the device path is shared."""
+    return wcc_afforest(graph, config)
+
+
+def wcc_baseline(graph: DirectedCsrGraph, config: WccConfig | None = None) -> Components:
+    """wcc_baseline — crates/algos/src/wcc.rs:103-122"""
+    labels = np.empty(graph.node_count(), np.uint32)
+    check(lib().gm_wcc_baseline(graph.csr_out.handle, _ptr(labels) if labels.size else None))
+    return Components(labels)
+
+
+@dataclass
+class DeltaSteppingConfig:
+    """crates/algos/src/sssp.rs:18-36"""
+    start_node: int
+    delta: float
+
+
+def delta_stepping(graph: DirectedCsrGraph, config: DeltaSteppingConfig):
+    """delta_stepping — crates/algos/src/sssp.rs:38-102; returns f32 distances, f32::MAX = unreachable."""
+    if not 0 <= config.start_node < graph.node_count():
+        raise IndexError(f"start_node {config.start_node} out of range")  # sssp.rs:52 panics
+    dist = np.empty(graph.node_count(), np.float32)
+    check(lib().gm_sssp_delta_stepping(graph.csr_out.handle, int(config.start_node), float(config.delta),
+                                       _ptr(dist)))
+    return dist
+
+
+def global_triangle_count(graph: UndirectedCsrGraph) -> int:
+    """global_triangle_count — crates/algos/src/triangle_count.rs:22-86"""
+    out = u64(0)
+    check(lib().gm_triangle_count(graph.csr.handle, C.byref(out)))
+    return int(out.value)
+
+
+def relabel_graph(graph: UndirectedCsrGraph):
+    """relabel_graph — crates/algos/src/triangle_count.rs:12-20"""
+    graph.make_degree_ordered()
+
+
+__all__ = [
+    "CsrLayout", "Direction", "DeviceCsr", "DirectedCsrGraph", "UndirectedCsrGraph", "EdgeListInput",
+    "Graph500Input", "GraphBuilder", "PageRankConfig", "PageRankMode", "page_rank", "WccConfig", "Components",
+    "wcc_afforest", "wcc_afforest_dss", "wcc_baseline", "DeltaSteppingConfig", "delta_stepping",
+    "global_triangle_count", "relabel_graph",
+]

@@ -1,0 +1,191 @@
+/*
+ * graph_mi355x.h — C ABI of the MI355X-native hot path behind neo4j-labs/graph's `graph::prelude`.
+ *
+ * The reference (Rust) has no FFI for its algorithms: they are generic free functions
+ * re-exported from crates/algos/src/prelude.rs:1-7.  This header is the boundary a Rust
+ * `extern "C"` shim (bindings/rust/) binds so that
+ *   page_rank / wcc_afforest / delta_stepping / global_triangle_count
+ * run on a CSR that was uploaded to HBM once.  Each entry point cites the reference
+ * interface it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every function returns GM_OK (0) or a negative gm_status; nothing aborts across the ABI.
+ *     gm_last_error() gives a thread-local message for the last failure on this thread.
+ *   - node ids on the device are u32 (the reference's NI = u32; usize graphs are narrowed at
+ *     upload with a range check -> GM_ERR_RANGE).
+ *   - host buffers are owned by the caller; a gm_csr is immutable after creation and may be
+ *     used from several host threads at once (every call allocates its own scratch).
+ *   - "device pointer" arguments are plain addresses in the HBM of the handle's device
+ *     (e.g. hipMalloc or torch.Tensor.data_ptr()); `stream` is a hipStream_t passed as void*.
+ */
+#ifndef GRAPH_MI355X_H
+#define GRAPH_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GM_ABI_VERSION 1
+
+typedef enum gm_status {
+    GM_OK = 0,
+    GM_ERR_INVALID = -1,     /* bad argument (null pointer, n == 0 where the reference panics, ...) */
+    GM_ERR_RANGE = -2,       /* id / count does not fit the device id type, start_node >= n */
+    GM_ERR_HIP = -3,         /* a HIP runtime call failed (message has the hipError string) */
+    GM_ERR_NOMEM = -4,
+    GM_ERR_UNSUPPORTED = -5  /* e.g. unsorted lists handed to triangle count */
+} gm_status;
+
+/* crates/builder/src/graph/csr.rs:34-45 */
+typedef enum gm_layout { GM_LAYOUT_UNSORTED = 0, GM_LAYOUT_SORTED = 1, GM_LAYOUT_DEDUPLICATED = 2 } gm_layout;
+/* crates/builder/src/lib.rs Direction (Outgoing / Incoming / Undirected) */
+typedef enum gm_direction { GM_DIR_OUTGOING = 0, GM_DIR_INCOMING = 1, GM_DIR_UNDIRECTED = 2 } gm_direction;
+
+const char *gm_last_error(void);
+int gm_abi_version(void);
+int gm_device_count(int *count_out);
+
+/* ---------------------------------------------------------------------------------------------
+ * Device-resident CSR.  Replaces the host `Csr<Index, NI, EV>{offsets, targets}` of
+ * crates/builder/src/graph/csr.rs:58-118 as the thing the algorithms read; one gm_csr per
+ * direction (DirectedCsrGraph = csr_out + csr_inc, csr.rs:364-368; UndirectedCsrGraph = csr,
+ * csr.rs:658-661).  `weights` (optional) are the f32 edge values of Target<NI, f32>
+ * (crates/builder/src/graph/mod.rs:5-10), stored SoA on the device.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct gm_csr gm_csr;
+
+int gm_csr_upload_u32(const uint32_t *offsets /* n+1 */, const uint32_t *targets /* m */,
+                      const float *weights /* m or NULL */, uint64_t n, uint64_t m, int device,
+                      gm_csr **out);
+/* usize / u64 graphs: narrowed to u32, GM_ERR_RANGE when n or m >= 2^32 */
+int gm_csr_upload_u64(const uint64_t *offsets, const uint64_t *targets, const float *weights, uint64_t n,
+                      uint64_t m, int device, gm_csr **out);
+/* Borrow arrays that already live in HBM (u32 offsets n+1, u32 targets m, f32 weights or 0).
+ * The caller keeps them alive for the lifetime of the handle. */
+int gm_csr_wrap_device(uint64_t d_offsets, uint64_t d_targets, uint64_t d_weights, uint64_t n, uint64_t m,
+                       int device, gm_csr **out);
+void gm_csr_free(gm_csr *csr);
+uint64_t gm_csr_node_count(const gm_csr *csr);
+uint64_t gm_csr_edge_count(const gm_csr *csr); /* number of target entries (csr.rs:76-78) */
+int gm_csr_device(const gm_csr *csr);
+uint64_t gm_csr_offsets_ptr(const gm_csr *csr); /* device addresses, for zero-copy consumers */
+uint64_t gm_csr_targets_ptr(const gm_csr *csr);
+uint64_t gm_csr_weights_ptr(const gm_csr *csr);
+int gm_csr_download(const gm_csr *csr, uint32_t *offsets, uint32_t *targets, float *weights_or_null);
+/* per-node degree = offsets[u+1]-offsets[u] (DirectedDegrees, crates/builder/src/lib.rs:330-340) */
+int gm_csr_degrees(const gm_csr *csr, uint32_t *degrees_out /* n, host */);
+
+/* Device-side CSR construction from an edge list in HBM — the sequential semantics of
+ * `Csr::from((edges, node_count, direction, layout))`, crates/builder/src/graph/csr.rs:124-221
+ * (+ sort_targets :886-895, sort_and_deduplicate_targets :897-948): Unsorted keeps edge-list
+ * arrival order inside a list (out-direction entries first for Undirected), Sorted orders by
+ * target (equal targets keep arrival order), Deduplicated also drops duplicates and self-loops.
+ * d_src / d_dst: u32[m], d_weights: f32[m] or 0.  The inputs are not modified. */
+int gm_csr_build_device(uint64_t n, uint64_t m, uint64_t d_src, uint64_t d_dst, uint64_t d_weights,
+                        int direction, int layout, int device, gm_csr **out);
+/* Same, from host edge arrays (uploads them, then builds on the device) — the device-resident
+ * counterpart of GraphBuilder::new().csr_layout(l).edges(..).build(), crates/builder/src/builder.rs:123-540. */
+int gm_csr_build_host(uint64_t n, uint64_t m, const uint32_t *src, const uint32_t *dst, const float *weights,
+                      int direction, int layout, int device, gm_csr **out);
+/* RelabelByDegreeOp::make_degree_ordered, crates/builder/src/graph_ops.rs:511-638: returns a new
+ * handle; new_id_out (host, n, optional) receives old id -> new id. */
+int gm_csr_relabel_by_degree(const gm_csr *undirected, gm_csr **out, uint32_t *new_id_out);
+
+/* Row slice for 1-D vertex-range partitioning: rows [row_lo, row_hi) of `full` with offsets
+ * rebased to 0.  If `bounds` (host, parts+1 ascending node ids, bounds[0] = 0, bounds[parts] = n)
+ * is given, every target id v in part p is rewritten to p*stride + (v - bounds[p]) — the index
+ * of v in a rank-major all-gather buffer whose per-rank slot is `stride` floats — so the gathered
+ * vector can be consumed without unpacking.  bounds == NULL keeps target ids. */
+int gm_csr_slice_rows(const gm_csr *full, uint64_t row_lo, uint64_t row_hi, const uint32_t *bounds,
+                      uint32_t parts, uint32_t stride, gm_csr **out);
+
+/* ---------------------------------------------------------------------------------------------
+ * PageRank — replaces `page_rank(&G, PageRankConfig) -> (Vec<f32>, usize, f64)`,
+ * crates/algos/src/page_rank.rs:58-111 (config :14-56: max_iterations 20, tolerance 1e-4,
+ * damping_factor 0.85).  `in_csr` is the Incoming CSR (in_neighbors), `out_degree` the
+ * per-node out-degrees (host, n; NULL = derive them on the device by counting each id's
+ * occurrences in the in-lists, which equals out_degree for a DirectedCsrGraph).
+ *
+ * mode GM_PR_AUTO   : n <= 16384 -> GM_PR_SEQUENTIAL, else GM_PR_JACOBI
+ *      GM_PR_JACOBI : synchronous sweeps (double-buffered out_scores), deterministic
+ *      GM_PR_SEQUENTIAL : the reference's exact in-place ascending-u order on one wavefront;
+ *                     bit-exact with the reference wherever the reference itself is
+ *                     deterministic (n <= CHUNK_SIZE = 16384, page_rank.rs:12,135)
+ * Stop rule as page_rank.rs:105-109: iteration += 1; stop if error < tolerance ||
+ * iteration == max_iterations (so at least one sweep always runs).
+ * ------------------------------------------------------------------------------------------- */
+typedef enum gm_pr_mode { GM_PR_AUTO = 0, GM_PR_JACOBI = 1, GM_PR_SEQUENTIAL = 2 } gm_pr_mode;
+
+int gm_page_rank(const gm_csr *in_csr, const uint32_t *out_degree, uint64_t max_iterations, double tolerance,
+                 float damping_factor, int mode, float *scores_out /* n, host */, uint64_t *iterations_out,
+                 double *error_out);
+
+/* Resident PageRank engine: the per-sweep hot loop (page_rank_iteration, page_rank.rs:113-168)
+ * over rows [row_begin, row_begin + n_local) of a graph with n_global nodes.  One engine per
+ * GPU; with n_local == n_global it is the single-GPU path.  All arrays are device pointers. */
+typedef struct gm_pr gm_pr;
+int gm_pr_create(const gm_csr *in_csr_rows /* n_local rows, targets are global ids */, uint64_t n_global,
+                 uint64_t row_begin, uint64_t d_out_degree_local /* u32[n_local] */, float damping_factor,
+                 gm_pr **out);
+void gm_pr_destroy(gm_pr *pr);
+/* scores[i] = 1/n_global, x_local[i] = (1/n_global)/out_degree[i]   (page_rank.rs:70-81) */
+int gm_pr_init(gm_pr *pr, uint64_t d_scores_local, uint64_t d_x_local, void *stream);
+/* one synchronous sweep: reads x_in (f32[n_global], out_scores of the previous sweep), updates
+ * scores_local in place, writes x_out_local (f32[n_local]) and this rank's share of the sweep's
+ * L1 error to *d_error_out (f64, device).  Enqueues two kernels on `stream`; never synchronises.
+ * Deterministic: no floating-point atomics anywhere. */
+int gm_pr_sweep(gm_pr *pr, uint64_t d_x_in_global, uint64_t d_x_out_local, uint64_t d_scores_local,
+                uint64_t d_error_out, void *stream);
+/* the two launches of gm_pr_sweep separately (bench.py brackets the dominant tile kernel with
+ * its own HIP events): tiles = gather + per-row reduce + fused epilogue; fixup = rows that cross
+ * a tile boundary + the deterministic error reduction. */
+int gm_pr_sweep_tiles(gm_pr *pr, uint64_t d_x_in_global, uint64_t d_x_out_local, uint64_t d_scores_local,
+                      void *stream);
+int gm_pr_sweep_fixup(gm_pr *pr, uint64_t d_x_out_local, uint64_t d_scores_local, uint64_t d_error_out,
+                      void *stream);
+/* algorithmic HBM bytes of one sweep, SURVEY §8(d): 8*m_local + 20*n_local + 4 */
+uint64_t gm_pr_algorithmic_bytes(const gm_pr *pr);
+uint64_t gm_pr_tile_count(const gm_pr *pr); /* workgroups per sweep (diagnostics) */
+
+/* ---------------------------------------------------------------------------------------------
+ * WCC — replaces wcc_afforest / wcc_afforest_dss / wcc_baseline(&G, WccConfig) -> impl
+ * Components<NI>, crates/algos/src/wcc.rs:103-183 (config :43-79: chunk_size 16384 is a CPU
+ * scheduling knob and has no device meaning, neighbor_rounds 2, sampling_size 1024).
+ * components_out[u] = Components::component(u) = minimum node id of u's weakly connected
+ * component — identical for all three reference entry points.
+ * ------------------------------------------------------------------------------------------- */
+int gm_wcc_afforest(const gm_csr *out_csr, const gm_csr *in_csr, uint64_t neighbor_rounds,
+                    uint64_t sampling_size, uint32_t *components_out /* n, host */);
+int gm_wcc_baseline(const gm_csr *out_csr, uint32_t *components_out);
+
+/* ---------------------------------------------------------------------------------------------
+ * SSSP — replaces delta_stepping(&G, DeltaSteppingConfig{start_node, delta}) -> Vec<AtomicF32>,
+ * crates/algos/src/sssp.rs:38-102.  `out_csr` must carry weights (>= 0).  Unreachable nodes get
+ * f32::MAX (sssp.rs:12), not inf.  start_node >= n -> GM_ERR_RANGE (the reference panics, :52).
+ * ------------------------------------------------------------------------------------------- */
+int gm_sssp_delta_stepping(const gm_csr *out_csr, uint64_t start_node, float delta, float *distances_out);
+
+/* ---------------------------------------------------------------------------------------------
+ * Triangle count — replaces global_triangle_count(&G) -> u64, crates/algos/src/triangle_count.rs:22-86,
+ * including its put-back-iterator semantics on lists with duplicates / self-loops
+ * (crates/algos/src/utils.rs:8-101).  Lists must be sorted (layout Sorted or Deduplicated);
+ * unsorted lists are rejected with GM_ERR_UNSUPPORTED (the reference returns garbage silently).
+ * ------------------------------------------------------------------------------------------- */
+int gm_triangle_count(const gm_csr *undirected_csr, uint64_t *triangles_out);
+
+/* ---------------------------------------------------------------------------------------------
+ * Synthetic inputs (no reference counterpart: the reference downloads Graph500 files,
+ * crates/builder/benches/common/mod.rs:15-41).  R-MAT A=.57 B=.19 C=.19 D=.05, integer-only
+ * arithmetic shared bit-for-bit with oracle/graph_oracle.c:orc_rmat_edges.
+ * ------------------------------------------------------------------------------------------- */
+int gm_rmat_edges_device(uint32_t scale, uint64_t seed, uint64_t first_edge, uint64_t count, uint64_t d_src,
+                         uint64_t d_dst, int device, void *stream);
+int gm_rmat_weights_device(uint64_t seed, uint64_t first_edge, uint64_t count, uint64_t d_weights, int device,
+                           void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRAPH_MI355X_H */

@@ -1,0 +1,122 @@
+"""world_size-2 (and 3) gloo runs of the multi-GPU PageRank driver on CPU: partition, padded
+all-gather exchange, error all-reduce and the stop rule — with an oracle-backed stand-in for the
+local HIP sweep (the oracle is the checker here, never the product)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+class _OracleRankEngine:
+    """Per-rank sweep over rows [lo, hi) reading the padded rank-major x vector."""
+
+    def __init__(self, O, ioff, itgt, od, bounds, stride, rank, damping):
+        self.O, self.damping = O, damping
+        lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+        self.lo, self.hi, self.n = lo, hi, ioff.size - 1
+        self.off = (ioff[lo:hi + 1] - ioff[lo]).astype(np.uint32)
+        tg = itgt[ioff[lo]:ioff[hi]]
+        part = np.searchsorted(bounds[1:], tg, side="right")
+        self.tgt = (part * stride + (tg - bounds[part])).astype(np.uint32)
+        self.od = od[lo:hi].copy()
+
+    def init(self, scores, x_loc):
+        init = np.float32(1.0) / np.float32(self.n)
+        scores[: self.hi - self.lo] = float(init)
+        with np.errstate(divide="ignore"):
+            x_loc[: self.hi - self.lo] = torch.from_numpy((init / self.od.astype(np.float32)).astype(np.float32))
+
+    def sweep(self, x_in, x_out_local, scores, err):
+        nl = self.hi - self.lo
+        base = (np.float32(1.0) - np.float32(self.damping)) / np.float32(self.n)
+        xin = x_in.numpy()
+        sc = scores.numpy()
+        e = 0.0
+        out = np.zeros(nl, np.float32)
+        for u in range(nl):
+            ssum = np.float32(0)
+            for i in range(self.off[u], self.off[u + 1]):
+                ssum = np.float32(ssum + xin[self.tgt[i]])
+            nw = np.float32(base + np.float32(np.float32(self.damping) * ssum))
+            e += abs(float(np.float32(nw - sc[u])))
+            sc[u] = nw
+            with np.errstate(divide="ignore"):
+                out[u] = np.float32(nw) / np.float32(self.od[u])
+        x_out_local[:nl] = torch.from_numpy(out)
+        err[0] = e
+
+
+def _worker(rank, world, port, scale, max_iter, tol, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    from graph_amd.distributed import greedy_degree_partition, pad_bounds, page_rank_partitioned
+
+    s, d = O.rmat_edges(scale, seed=3)
+    n = 1 << scale
+    ioff, itgt = O.csr_build(n, s, d, O.INCOMING, O.SORTED)
+    od = O.out_degrees_from(n, s)
+    bounds, stride = pad_bounds(greedy_degree_partition(ioff, world), world, n)
+    eng = _OracleRankEngine(O, ioff, itgt, od, bounds, stride, rank, 0.85)
+    scores, it, err = page_rank_partitioned(eng, n, int(bounds[rank + 1] - bounds[rank]), stride, max_iter, tol,
+                                            torch.device("cpu"))
+    q.put((rank, int(bounds[rank]), scores.numpy().copy(), it, err))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world,max_iter,tol", [(2, 4, 0.0), (3, 20, 1e-3)])
+def test_partitioned_page_rank_matches_single_rank_jacobi(oracle, world, max_iter, tol):
+    scale = 7
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, scale, max_iter, tol, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n = 1 << scale
+    s, d = oracle.rmat_edges(scale, seed=3)
+    ioff, itgt = oracle.csr_build(n, s, d, oracle.INCOMING, oracle.SORTED)
+    od = oracle.out_degrees_from(n, s)
+    # single-rank synchronous reference with the same stop rule
+    init = np.float32(1.0) / np.float32(n)
+    scores = np.full(n, init, np.float32)
+    with np.errstate(divide="ignore"):
+        outs = (init / od.astype(np.float32)).astype(np.float32)
+    it = 0
+    while True:
+        outs, err = oracle.page_rank_jacobi_sweep(ioff, itgt, od, 0.85, scores, outs)
+        it += 1
+        if err < tol or it == max_iter:
+            break
+    got = np.zeros(n, np.float32)
+    for rank, lo, sc, it_r, err_r in results:
+        got[lo:lo + sc.size] = sc
+        assert it_r == it
+        assert abs(err_r - err) <= 1e-9 * max(err, 1e-30) + 1e-15
+    assert np.array_equal(got, scores)  # same per-row order -> bit-exact across the partition
+
+
+def test_pad_bounds_and_partition_edge_cases():
+    from graph_amd.distributed import greedy_degree_partition, pad_bounds
+
+    off = np.array([0, 100, 100, 100, 101], np.uint32)
+    r = greedy_degree_partition(off, 4)
+    assert r[0] == (0, 1) and r[-1][1] == 4 and len(r) <= 4
+    b, stride = pad_bounds(r, 4, 4)
+    assert b[0] == 0 and b[-1] == 4 and stride >= 1 and len(b) == 5
+    assert greedy_degree_partition(np.zeros(1, np.uint32), 2) == []

@@ -1,0 +1,348 @@
+"""GPU parity tests: the HIP path (through the C ABI, via graph_amd.prelude) against the CPU oracle
+and the reference's golden vectors.  Bit-exact for integer work (CSR build, WCC ids, triangle
+counts, SSSP distances — which are schedule-free) and for PageRank wherever the reference itself
+is deterministic; PageRank on large graphs within 1e-5 relative at convergence (BASELINE north_star).
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+F32_MAX = np.finfo(np.float32).max
+
+README_EDGES = [(1, 2), (2, 1), (4, 0), (4, 1), (5, 4), (5, 1), (5, 6), (6, 1), (6, 5), (7, 1), (7, 5),
+                (8, 1), (8, 5), (9, 1), (9, 5), (10, 1), (10, 5), (11, 5), (12, 5)]
+README_SCORES = np.array([0.024064068, 0.3145448, 0.27890152, 0.01153846, 0.029471997, 0.06329483,
+                          0.029471997] + [0.01153846] * 6, np.float32)
+
+
+@pytest.fixture(scope="module")
+def P():
+    import graph_amd
+    from graph_amd import prelude
+
+    assert os.path.exists(graph_amd.LIB_PATH), "HIP library missing: the GPU tests never fall back"
+    assert graph_amd.device_count() >= 1, "no MI355X visible"
+    return prelude
+
+
+def _directed(P, n, s, d, layout, w=None):
+    out = P.DeviceCsr.from_edges(n, s, d, w, P.Direction.Outgoing, layout)
+    inc = P.DeviceCsr.from_edges(n, s, d, w, P.Direction.Incoming, layout)
+    return P.DirectedCsrGraph(out, inc, layout)
+
+
+def _oracle_directed(O, n, s, d, layout, w=None):
+    return (O.csr_build(n, s, d, O.OUTGOING, int(layout), w), O.csr_build(n, s, d, O.INCOMING, int(layout), w))
+
+
+# ------------------------------------------------------------------------------------------------
+# inputs: generator + device CSR construction
+# ------------------------------------------------------------------------------------------------
+def test_rmat_generator_matches_oracle(P, oracle):
+    import torch
+    from graph_amd import synth
+
+    src, dst = synth.rmat_edges(12, seed=42)
+    s, d = oracle.rmat_edges(12, seed=42)
+    assert np.array_equal(src.cpu().numpy().view(np.uint32), s)
+    assert np.array_equal(dst.cpu().numpy().view(np.uint32), d)
+    w = synth.rmat_weights(1000, seed=44)
+    assert np.array_equal(w.cpu().numpy(), oracle.rmat_weights(1000, seed=44))
+    src, dst = synth.rmat_edges(17, seed=7)  # odd scale
+    s, d = oracle.rmat_edges(17, seed=7)
+    assert np.array_equal(src.cpu().numpy().view(np.uint32), s) and np.array_equal(dst.cpu().numpy().view(np.uint32), d)
+    del torch
+
+
+@pytest.mark.parametrize("direction", [0, 1, 2])
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_csr_build_matches_oracle(P, oracle, scale8, direction, layout, weighted):
+    for (s, d, n) in (scale8, oracle.rmat_edges(11, seed=3) + (1 << 11,)):
+        w = oracle.rmat_weights(s.size, seed=5) if weighted else None
+        ref = oracle.csr_build(n, s, d, direction, layout, w)
+        csr = P.DeviceCsr.from_edges(n, s, d, w, direction, layout)
+        off, tgt, wv = csr.host()
+        assert np.array_equal(off, ref[0])
+        assert np.array_equal(tgt, ref[1])
+        if weighted:
+            assert np.array_equal(wv, ref[2])
+
+
+def test_csr_build_golden_lists(P, golden_dir):
+    # crates/builder/tests/builder.rs:448-491
+    g = (P.GraphBuilder().csr_layout(P.CsrLayout.Sorted).file_format(P.Graph500Input())
+         .path(os.path.join(golden_dir, "scale_8.graph500")).build(P.DirectedCsrGraph))
+    assert g.node_count() == 256 and g.edge_count() == 4096
+    assert list(g.out_neighbors(0)) == [37, 157]
+    assert list(g.in_neighbors(0)) == [12, 26, 50, 50, 52, 82, 82, 82, 106, 109, 172, 186, 250, 250]
+    ug = g.to_undirected(P.CsrLayout.Sorted)
+    assert ug.degree(0) == 16 and ug.edge_count() == 4096
+    # crates/builder/src/lib.rs:104-160: example.el / example.wel
+    g = (P.GraphBuilder().csr_layout(P.CsrLayout.Sorted).file_format(P.EdgeListInput())
+         .path(os.path.join(golden_dir, "example.el")).build(P.DirectedCsrGraph))
+    assert g.node_count() == 4 and g.edge_count() == 5
+    assert list(g.out_neighbors(1)) == [2, 3] and list(g.in_neighbors(1)) == [0]
+    gw = (P.GraphBuilder().csr_layout(P.CsrLayout.Sorted).file_format(P.EdgeListInput(weighted=True))
+          .path(os.path.join(golden_dir, "example.wel")).build(P.DirectedCsrGraph))
+    assert gw.out_neighbors_with_values(1) == [(2, 0.25), (3, 1.0)]
+    g = (P.GraphBuilder().file_format(P.EdgeListInput()).path(os.path.join(golden_dir, "windows.el"))
+         .build(P.DirectedCsrGraph))
+    assert g.node_count() == 4  # input/edgelist.rs:337-346
+    with pytest.raises(Exception):
+        P.DeviceCsr.from_edges(2, [0, 5], [1, 1], None, 0, 1)  # endpoint >= node_count
+
+
+def test_relabel_matches_oracle(P, oracle, scale8):
+    s, d, n = scale8
+    for layout in (oracle.SORTED, oracle.DEDUPLICATED):
+        uoff, utgt = oracle.csr_build(n, s, d, oracle.UNDIRECTED, layout)
+        roff, rtgt, new_id = oracle.relabel_by_degree(uoff, utgt)
+        ug = P.UndirectedCsrGraph(P.DeviceCsr.from_edges(n, s, d, None, 2, layout), layout)
+        got_id = ug.make_degree_ordered()
+        off, tgt, _ = ug.csr.host()
+        assert np.array_equal(got_id, new_id) and np.array_equal(off, roff) and np.array_equal(tgt, rtgt)
+
+
+# ------------------------------------------------------------------------------------------------
+# PageRank
+# ------------------------------------------------------------------------------------------------
+def test_page_rank_readme_vector_bit_exact(P):
+    # crates/algos/src/lib.rs:92-141: default (Unsorted) layout, PageRankConfig::new(10, 1e-4, 0.85)
+    g = P.GraphBuilder().edges(README_EDGES).build(P.DirectedCsrGraph)
+    scores, iterations, _ = P.page_rank(g, P.PageRankConfig(10, 1e-4, 0.85))
+    assert iterations == 10
+    assert np.array_equal(scores, README_SCORES)
+
+
+def test_page_rank_two_components_bit_exact(P):
+    # crates/algos/src/page_rank.rs:175-197
+    g = (P.GraphBuilder().csr_layout(P.CsrLayout.Sorted)
+         .edges([(0, 1), (1, 2), (0, 2), (3, 4), (4, 5), (3, 5)]).build(P.DirectedCsrGraph))
+    scores, _, _ = P.page_rank(g, P.PageRankConfig())
+    assert np.array_equal(scores, np.array([0.024999997, 0.035624996, 0.06590624] * 2, np.float32))
+
+
+def test_page_rank_example_el(P, golden_dir):
+    # BASELINE config 0
+    g = (P.GraphBuilder().csr_layout(P.CsrLayout.Sorted).file_format(P.EdgeListInput())
+         .path(os.path.join(golden_dir, "example.el")).build(P.DirectedCsrGraph))
+    scores, iterations, error = P.page_rank(g, P.PageRankConfig(10, 1e-4, 0.85))
+    assert iterations == 2 and error == 0.0
+    assert np.array_equal(scores, np.array([0.037499994, 0.053437494, 0.07614843, 0.124937095], np.float32))
+
+
+def test_page_rank_behaviours_scale8(P, oracle, scale8):
+    # crates/mate/tests/page_rank_test.py:19-33
+    s, d, n = scale8
+    g = _directed(P, n, s, d, P.CsrLayout.Sorted)
+    assert P.page_rank(g, P.PageRankConfig(max_iterations=1))[1] == 1
+    assert P.page_rank(g, P.PageRankConfig(tolerance=1.0))[1] == 1
+    scores, iterations, _ = P.page_rank(g, P.PageRankConfig(damping_factor=0.0))
+    assert iterations == 1 and np.all(scores == np.float32(1.0) / np.float32(256))
+    # whole default run: bit-exact with the sequential oracle (scores, iterations, error)
+    (_, _), (ioff, itgt) = _oracle_directed(oracle, n, s, d, oracle.SORTED)
+    ref = oracle.page_rank_seq(ioff, itgt, oracle.out_degrees_from(n, s))
+    got = P.page_rank(g, P.PageRankConfig())
+    assert got[1] == ref[1] == 7 and got[2] == ref[2] and np.array_equal(got[0], ref[0])
+    for mode in (P.PageRankMode.Jacobi, P.PageRankMode.Sequential):
+        assert P.page_rank(g, P.PageRankConfig(max_iterations=1), mode)[1] == 1
+        sc, it, _ = P.page_rank(g, P.PageRankConfig(damping_factor=0.0), mode)
+        assert it == 1 and np.all(sc == np.float32(1.0) / np.float32(256))
+
+
+def test_page_rank_sequential_mode_large_n_bit_exact(P, oracle):
+    # n > 16384: the Sequential kernel keeps out_scores in HBM; still the reference's exact order
+    s, d = oracle.rmat_edges(15, seed=11)
+    n = 1 << 15
+    g = _directed(P, n, s, d, P.CsrLayout.Sorted)
+    (_, _), (ioff, itgt) = _oracle_directed(oracle, n, s, d, oracle.SORTED)
+    ref = oracle.page_rank_seq(ioff, itgt, oracle.out_degrees_from(n, s), 3, 0.0, 0.85)
+    got = P.page_rank(g, P.PageRankConfig(3, 0.0, 0.85), P.PageRankMode.Sequential)
+    assert got[1] == 3 and got[2] == ref[2] and np.array_equal(got[0], ref[0])
+
+
+def _jacobi_reference(O, ioff, itgt, od, sweeps, damping=0.85):
+    n = ioff.size - 1
+    init = np.float32(1.0) / np.float32(n)
+    scores = np.full(n, init, np.float32)
+    with np.errstate(divide="ignore"):
+        outs = (init / od.astype(np.float32)).astype(np.float32)
+    err = 0.0
+    for _ in range(sweeps):
+        outs, err = O.page_rank_jacobi_sweep(ioff, itgt, od, damping, scores, outs)
+    return scores, err
+
+
+def _ragged_graphs(O):
+    rng = np.random.default_rng(5)
+    n = 40000
+    # a hub with 30000 in-edges (spans ~15 tiles), empty rows, and a block of medium rows
+    s = np.concatenate([rng.integers(0, n, 30000), rng.integers(0, n, 20000), np.arange(100, 164).repeat(40)])
+    d = np.concatenate([np.full(30000, 7), rng.integers(20000, 20100, 20000), rng.integers(30000, 30003, 64 * 40)])
+    yield n, s.astype(np.uint32), d.astype(np.uint32)
+    # every edge into the last node; first node isolated
+    yield 5000, np.arange(1, 4999, dtype=np.uint32), np.full(4998, 4999, np.uint32)
+    # no edges at all
+    yield 20000, np.zeros(0, np.uint32), np.zeros(0, np.uint32)
+    # exactly one tile worth of rows and edges mixed
+    s, d = O.rmat_edges(9, seed=2)
+    yield 1 << 9, s, d
+
+
+def test_page_rank_jacobi_sweeps_match_oracle_on_ragged_inputs(P, oracle):
+    for n, s, d in _ragged_graphs(oracle):
+        g = _directed(P, n, s, d, P.CsrLayout.Sorted)
+        (_, _), (ioff, itgt) = _oracle_directed(oracle, n, s, d, oracle.SORTED)
+        od = oracle.out_degrees_from(n, s)
+        for sweeps in (1, 3):
+            ref_scores, ref_err = _jacobi_reference(oracle, ioff, itgt, od, sweeps)
+            got, it, err = P.page_rank(g, P.PageRankConfig(sweeps, 0.0, 0.85), P.PageRankMode.Jacobi)
+            assert it == sweeps
+            # identical per-node arithmetic; only the order of the f32 sum over a row differs
+            np.testing.assert_allclose(got, ref_scores, rtol=2e-6, atol=0)
+            assert abs(err - ref_err) <= 1e-6 * max(ref_err, 1e-30) + 1e-12
+        # deterministic: no floating-point atomics anywhere
+        a = P.page_rank(g, P.PageRankConfig(3, 0.0, 0.85), P.PageRankMode.Jacobi)
+        b = P.page_rank(g, P.PageRankConfig(3, 0.0, 0.85), P.PageRankMode.Jacobi)
+        assert np.array_equal(a[0], b[0]) and a[2] == b[2]
+
+
+@pytest.mark.parametrize("scale", [14, 18])
+def test_page_rank_converged_matches_reference_order(P, oracle, scale):
+    # BASELINE parity config: PageRankConfig::new(200, 1e-10, 0.85) on both sides, fixed points compared.
+    s, d = oracle.rmat_edges(scale, seed=42)
+    n = 1 << scale
+    g = _directed(P, n, s, d, P.CsrLayout.Sorted)
+    (_, _), (ioff, itgt) = _oracle_directed(oracle, n, s, d, oracle.SORTED)
+    od = oracle.out_degrees_from(n, s)
+    ref, _, _ = oracle.page_rank_chunked(ioff, itgt, od, 200, 1e-10, 0.85)  # the reference's threaded order
+    got, iterations, error = P.page_rank(g, P.PageRankConfig(200, 1e-10, 0.85), P.PageRankMode.Jacobi)
+    rel = np.abs(got.astype(np.float64) - ref) / ref
+    assert rel.max() <= 1e-5, rel.max()
+    exact, _, _ = oracle.page_rank_f64(ioff, itgt, od)
+    assert (np.abs(got - exact) / exact).max() <= 1e-5
+    # default config: same stop rule, result within the tolerance the config itself allows
+    got_d, it_d, err_d = P.page_rank(g, P.PageRankConfig(), P.PageRankMode.Jacobi)
+    assert 1 <= it_d <= 20 and (err_d < 1e-4 or it_d == 20)
+
+
+def test_page_rank_argument_errors(P, scale8):
+    s, d, n = scale8
+    g = _directed(P, n, s, d, P.CsrLayout.Sorted)
+    with pytest.raises(Exception):
+        P.page_rank(g, P.PageRankConfig(0, 0.0, 0.85))  # reference: never terminates
+
+
+# ------------------------------------------------------------------------------------------------
+# WCC
+# ------------------------------------------------------------------------------------------------
+def test_wcc_two_components(P):
+    # crates/algos/src/wcc.rs:307-329
+    g = P.GraphBuilder().edges([(0, 1), (2, 3)]).build(P.DirectedCsrGraph)
+    for fn in (P.wcc_afforest, P.wcc_afforest_dss, P.wcc_baseline):
+        res = fn(g, P.WccConfig())
+        assert res.component(0) == res.component(1)
+        assert res.component(2) == res.component(3)
+        assert res.component(1) != res.component(2)
+
+
+def _wcc_graphs(O, scale8):
+    yield scale8
+    s, d = O.rmat_edges(16, seed=42)
+    yield s, d, 1 << 16
+    n = 50000  # one long path (deep pointer jumping) + a star (cooperative hub linking) + isolated nodes
+    s = np.concatenate([np.arange(0, 19999), np.full(20000, 20000)]).astype(np.uint32)
+    d = np.concatenate([np.arange(1, 20000), np.arange(20001, 40001)]).astype(np.uint32)
+    yield s, d, n
+    yield s[::-1].copy(), d[::-1].copy(), n
+
+
+def test_wcc_component_ids_bit_exact(P, oracle, scale8):
+    for s, d, n in _wcc_graphs(oracle, scale8):
+        g = _directed(P, n, s, d, P.CsrLayout.Sorted)
+        (ooff, otgt), (ioff, itgt) = _oracle_directed(oracle, n, s, d, oracle.SORTED)
+        ref = oracle.wcc(ooff, otgt, ioff, itgt, oracle.AFFOREST)
+        for cfg in (P.WccConfig(), P.WccConfig(neighbor_rounds=0), P.WccConfig(neighbor_rounds=5, sampling_size=7)):
+            assert np.array_equal(P.wcc_afforest(g, cfg).to_vec(), ref)
+        assert np.array_equal(P.wcc_baseline(g).to_vec(), ref)
+        assert np.array_equal(P.wcc_afforest_dss(g).to_vec(), ref)
+    with pytest.raises(Exception):
+        P.wcc_afforest(g, P.WccConfig(sampling_size=0))  # reference panics (wcc.rs:260-263)
+
+
+# ------------------------------------------------------------------------------------------------
+# SSSP
+# ------------------------------------------------------------------------------------------------
+def test_sssp_golden(P):
+    # crates/algos/src/sssp.rs:282-313
+    g = (P.GraphBuilder().csr_layout(P.CsrLayout.Deduplicated)
+         .edges_with_values([(0, 1, 4.0), (0, 2, 2.0), (1, 2, 5.0), (1, 3, 10.0), (2, 4, 3.0), (3, 5, 11.0),
+                             (4, 3, 4.0)]).build(P.DirectedCsrGraph))
+    dist = P.delta_stepping(g, P.DeltaSteppingConfig(0, 3.0))
+    assert np.array_equal(dist, np.array([0, 4, 2, 9, 5, 20], np.float32))
+    with pytest.raises(IndexError):
+        P.delta_stepping(g, P.DeltaSteppingConfig(6, 3.0))
+    with pytest.raises(Exception):
+        P.delta_stepping(g, P.DeltaSteppingConfig(0, 0.0))
+
+
+@pytest.mark.parametrize("scale,delta", [(10, 0.05), (14, 0.1), (14, 3.0), (16, 0.1)])
+def test_sssp_bit_exact_vs_oracle(P, oracle, scale, delta):
+    s, d = oracle.rmat_edges(scale, seed=42)
+    w = oracle.rmat_weights(s.size, seed=44)
+    n = 1 << scale
+    g = _directed(P, n, s, d, P.CsrLayout.Sorted, w)
+    off, tgt, wv = oracle.csr_build(n, s, d, oracle.OUTGOING, oracle.SORTED, w)
+    start = int(np.flatnonzero(np.diff(off) > 0)[0])
+    ref = oracle.delta_stepping(off, tgt, wv, start, delta)
+    got = P.delta_stepping(g, P.DeltaSteppingConfig(start, delta))
+    assert np.array_equal(got, ref)
+    assert (got == F32_MAX).any() and not np.isinf(got).any()
+
+
+# ------------------------------------------------------------------------------------------------
+# triangle count
+# ------------------------------------------------------------------------------------------------
+def test_triangle_count_goldens(P, golden_dir):
+    ug = (P.GraphBuilder().csr_layout(P.CsrLayout.Sorted).file_format(P.Graph500Input())
+          .path(os.path.join(golden_dir, "scale_8.graph500")).build(P.UndirectedCsrGraph))
+    assert P.global_triangle_count(ug) == 256533            # derived: Sorted, un-relabelled
+    P.relabel_graph(ug)
+    assert P.global_triangle_count(ug) == 227874            # crates/mate/tests/triangle_count_test.py:5-9
+    dg = (P.GraphBuilder().csr_layout(P.CsrLayout.Deduplicated).file_format(P.Graph500Input())
+          .path(os.path.join(golden_dir, "scale_8.graph500")).build(P.UndirectedCsrGraph))
+    assert P.global_triangle_count(dg) == 10508
+    P.relabel_graph(dg)
+    assert P.global_triangle_count(dg) == 10508
+    unsorted = (P.GraphBuilder().file_format(P.Graph500Input())
+                .path(os.path.join(golden_dir, "scale_8.graph500")).build(P.UndirectedCsrGraph))
+    with pytest.raises(Exception):
+        P.global_triangle_count(unsorted)
+
+
+@pytest.mark.parametrize("edges", [
+    [(0, 1), (1, 2), (2, 0), (3, 4), (4, 5), (5, 3)],
+    [(0, 1), (1, 2), (2, 0), (0, 3), (3, 4), (4, 0)],
+    [(0, 1), (1, 2), (2, 0), (1, 3), (3, 2)],
+])
+def test_triangle_count_shapes(P, edges):
+    # crates/algos/src/triangle_count.rs:93-130
+    g = P.GraphBuilder().csr_layout(P.CsrLayout.Deduplicated).edges(edges).build(P.UndirectedCsrGraph)
+    assert P.global_triangle_count(g) == 2
+
+
+@pytest.mark.parametrize("layout", [1, 2])
+@pytest.mark.parametrize("relabel", [False, True])
+def test_triangle_count_vs_oracle(P, oracle, layout, relabel):
+    s, d = oracle.rmat_edges(13, seed=42)
+    n = 1 << 13
+    off, tgt = oracle.csr_build(n, s, d, oracle.UNDIRECTED, layout)
+    ug = P.UndirectedCsrGraph(P.DeviceCsr.from_edges(n, s, d, None, 2, layout), layout)
+    if relabel:
+        off, tgt, _ = oracle.relabel_by_degree(off, tgt)
+        P.relabel_graph(ug)
+    assert P.global_triangle_count(ug) == oracle.triangle_count(off, tgt, threads=8)

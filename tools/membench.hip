@@ -1,0 +1,91 @@
+// membench.hip — memory-system ceilings that bound the PageRank pull sweep on MI355X:
+// streaming read rate, and random 4-byte gather rate as a function of the gathered table size
+// (L2-resident / Infinity-Cache-resident / HBM-resident), with 8 independent gathers per lane.
+// Usage: tools/membench   (prints one line per experiment)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+__global__ void stream_read(const uint4 *__restrict__ in, uint64_t n16, uint32_t *out)
+{
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint32_t acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        uint4 v = in[i];
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x12345678u) *out = acc;
+}
+
+// idx: m random indices (streamed, coalesced); table: gathered; 8 per lane in flight
+__global__ __launch_bounds__(256) void gather8(const uint32_t *__restrict__ idx, const float *__restrict__ table,
+                                               uint64_t m, float *out)
+{
+    uint64_t base = (uint64_t)blockIdx.x * 2048;
+    uint64_t stride = (uint64_t)gridDim.x * 2048;
+    float acc = 0.f;
+    for (; base < m; base += stride) {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { uint64_t i = base + threadIdx.x + k * 256; v[k] = i < m ? idx[i] : 0; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += table[v[k]];
+    }
+    if (acc == 1.2345f) *out = acc;
+}
+
+static uint64_t sm64(uint64_t x) { x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; return x ^ (x >> 31); }
+
+__global__ void fill_idx(uint32_t *idx, uint64_t m, uint32_t mask, int skew)
+{
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
+        uint64_t x = i * 0xD1342543DE82EF95ull + 12345;
+        x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; x ^= x >> 31;
+        uint32_t r = (uint32_t)x & mask;
+        if (skew) { // product of two uniforms -> skewed toward small ids
+            uint32_t r2 = (uint32_t)(x >> 32) & mask;
+            r = (uint32_t)(((uint64_t)r * r2) >> __builtin_ctz(mask + 1));
+        }
+        idx[i] = r;
+    }
+}
+
+int main()
+{
+    const uint64_t m = 1ull << 28; // 268M indices = 1 GiB
+    uint32_t *idx; float *table, *out;
+    CK(hipMalloc(&idx, m * 4));
+    CK(hipMalloc(&table, (1ull << 28) * 4));
+    CK(hipMalloc(&out, 64));
+    CK(hipMemset(table, 0, (1ull << 28) * 4));
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    float ms;
+    // streaming read
+    for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(a));
+        hipLaunchKernelGGL(stream_read, dim3(256 * 16), dim3(256), 0, 0, (const uint4 *)table, (1ull << 28) * 4 / 16, (uint32_t *)out);
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms, a, b));
+        printf("stream_read 1GiB: %.3f ms  %.1f GB/s\n", ms, (1ull << 30) / ms / 1e6);
+    }
+    for (int skew = 0; skew < 2; ++skew)
+        for (int lg = 18; lg <= 28; lg += 2) {
+            uint32_t mask = (1u << lg) - 1;
+            hipLaunchKernelGGL(fill_idx, dim3(8192), dim3(256), 0, 0, idx, m, mask, skew);
+            CK(hipDeviceSynchronize());
+            float best = 1e30f;
+            for (int rep = 0; rep < 3; ++rep) {
+                CK(hipEventRecord(a));
+                hipLaunchKernelGGL(gather8, dim3(256 * 8), dim3(256), 0, 0, idx, table, m, out);
+                CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms, a, b));
+                if (ms < best) best = ms;
+            }
+            printf("gather8 %s table=%4u MiB: %.3f ms  %.2f Ggather/s  (idx stream %.1f GB/s)\n", skew ? "skewed " : "uniform",
+                   (unsigned)((4ull << lg) >> 20), best, m / best / 1e6, m * 4 / best / 1e6);
+        }
+    return 0;
+}
