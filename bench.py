@@ -77,6 +77,17 @@ def main():
     t_build = time.time()
     src, dst = synth.rmat_edges(scale, args.seed, args.edge_factor, local_rank)
     m = src.numel()
+    if args.relabel:
+        # experiment: ids re-ranked by out-degree (descending) so the most-gathered out_scores are packed
+        deg = torch.bincount(src, minlength=n)
+        if args.relabel == 2:
+            deg = deg + torch.bincount(dst, minlength=n)
+        order = torch.argsort(deg, descending=True, stable=True)
+        new_id = torch.empty(n, dtype=torch.int32, device=dev)
+        new_id[order] = torch.arange(n, dtype=torch.int32, device=dev)
+        src = new_id[src.long()]
+        dst = new_id[dst.long()]
+        del deg, order, new_id
     out_deg = torch.bincount(src, minlength=n).to(torch.int32)
     in_csr = synth.build_csr(n, src, dst, Direction.Incoming, CsrLayout.Sorted, None, local_rank)
     del src, dst
