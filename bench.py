@@ -43,6 +43,7 @@ def parse_args():
     ap.add_argument("--cpu-sweeps", type=int, default=3, help="sweeps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores (available_parallelism)")
     ap.add_argument("--relabel", type=int, default=0, help="(experimental) internal degree-ordered layout")
+    ap.add_argument("--engine", choices=["auto", "pull", "pb"], default="auto")
     return ap.parse_args()
 
 
@@ -117,7 +118,9 @@ def main():
         torch.cuda.empty_cache()
     m_local = local_csr.m
 
-    engine = PageRankEngine(local_csr.handle, n, row_lo, out_deg_local, 0.85)
+    engine = PageRankEngine(local_csr.handle, n, row_lo, out_deg_local, 0.85,
+                            x_len=world * stride if world > 1 else n,
+                            engine={"auto": 0, "pull": 1, "pb": 2}[args.engine])
     x = [torch.zeros(world * stride if world > 1 else n, dtype=torch.float32, device=dev) for _ in range(2)]
     x_loc = torch.zeros(stride, dtype=torch.float32, device=dev) if world > 1 else None
     scores = torch.zeros(max(n_local, 1), dtype=torch.float32, device=dev)
@@ -204,10 +207,11 @@ def main():
                         f"{args.edge_factor}, seed {args.seed}), DirectedCsrGraph<u32> CsrLayout::Sorted, damping 0.85",
             "nodes": n, "edges": m, "step": "one sweep over all in-edges",
             "partition": "none" if world == 1 else f"1-D vertex ranges (greedy in-degree), {world} ranks, all-gather/sweep",
-            "csr_build_s": round(t_build, 3), "final_sweep_error": final_err, "tiles_per_sweep": engine.tiles,
+            "csr_build_s": round(t_build, 3), "final_sweep_error": final_err, "workgroups_per_sweep": engine.tiles, "engine": engine.engine,
         },
         "roofline": {
-            "kernel": "pr_tile_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "kernel": "pr_tile_kernel" if engine.engine == "pull" else "pb_bin_kernel+pb_accum_kernel",
+            "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(tile_ms_avg, 5),
             "edges_per_launch": m_local, "rows_per_launch": n_local,

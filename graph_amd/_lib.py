@@ -43,6 +43,8 @@ SIGNATURES = {
     "gm_csr_relabel_by_degree": (i32, [vp, PP, vp]),
     "gm_page_rank": (i32, [vp, vp, u64, f64, f32, i32, vp, C.POINTER(u64), C.POINTER(f64)]),
     "gm_pr_create": (i32, [vp, u64, u64, u64, f32, PP]),
+    "gm_pr_create_with": (i32, [vp, u64, u64, u64, u64, f32, i32, PP]),
+    "gm_pr_engine": (i32, [vp]),
     "gm_pr_destroy": (None, [vp]),
     "gm_pr_init": (i32, [vp, u64, u64, vp]),
     "gm_pr_sweep": (i32, [vp, u64, u64, u64, u64, vp]),

@@ -29,8 +29,7 @@
 //
 // pr_seq_kernel is the reference's exact sequential order (one wavefront, out_scores in LDS):
 // bit-exact with the reference wherever the reference is deterministic (n <= 16384).
-#include "common.hpp"
-#include "device_utils.hpp"
+#include "pagerank.hpp"
 
 namespace {
 
@@ -42,23 +41,6 @@ constexpr int PR_W = 2048;     // merged items per tile
 constexpr int PR_EPT = PR_W / PR_BLOCK;
 constexpr int PR_SHORT = 32;   // rows up to this many in-tile edges are summed by one lane
 constexpr int PR_MAXLONG = PR_W / (PR_SHORT + 1) + 2;
-
-// ---- per-node arithmetic, exactly the reference's f32 ops (no FMA contraction) ----------------
-__device__ __forceinline__ float pr_new_score(float base, float damping, float incoming)
-{
-    return __fadd_rn(base, __fmul_rn(damping, incoming));
-}
-
-__device__ __forceinline__ double pr_finalize(uint32_t r, float incoming, float base, float damping,
-                                              const uint32_t *__restrict__ outdeg, float *__restrict__ scores,
-                                              float *__restrict__ x_out)
-{
-    const float old = scores[r];
-    const float nw = pr_new_score(base, damping, incoming);
-    scores[r] = nw;
-    x_out[r] = __fdiv_rn(nw, (float)outdeg[r]); // out_degree 0 -> +inf, never gathered (page_rank.rs:78,158)
-    return fabs((double)__fsub_rn(nw, old));
-}
 
 // ---- setup: first row whose marker lies in tile t --------------------------------------------
 // tile_row[t] = #rows r with off[r] + r < t*W  (t = 0..T-1), tile_row[T] = n.
@@ -340,17 +322,8 @@ __global__ __launch_bounds__(kWave) void pr_seq_kernel(const uint32_t *__restric
 } // namespace
 
 // ------------------------------------------------------------------------------------------------
-struct gm_pr {
-    const gm_csr *csr = nullptr;
-    uint64_t n_global = 0, row_begin = 0;
-    uint32_t n_local = 0, m = 0, T = 0, G = 0;
-    const uint32_t *outdeg = nullptr;
-    float damping = 0.85f, base = 0.0f, init = 0.0f;
-    gm::DevBuf tile_row, head, tail, tile_err, blk_err, ticket;
-};
-
-GM_API int gm_pr_create(const gm_csr *csr, uint64_t n_global, uint64_t row_begin, uint64_t d_out_degree_local,
-                        float damping_factor, gm_pr **out)
+GM_API int gm_pr_create_with(const gm_csr *csr, uint64_t n_global, uint64_t row_begin, uint64_t x_len,
+                             uint64_t d_out_degree_local, float damping_factor, int engine, gm_pr **out)
 {
     GM_CHECK(csr && out, GM_ERR_INVALID, "gm_pr_create: null argument");
     GM_CHECK(n_global > 0 && row_begin + csr->n <= n_global, GM_ERR_INVALID,
@@ -359,12 +332,19 @@ GM_API int gm_pr_create(const gm_csr *csr, uint64_t n_global, uint64_t row_begin
     GM_CHECK(d_out_degree_local != 0 || csr->n == 0, GM_ERR_INVALID, "gm_pr_create: out-degree pointer is null");
     GM_CHECK(csr->n + csr->m < (1ull << 32), GM_ERR_RANGE, "gm_pr_create: n + m = %llu does not fit 32-bit tile positions",
              (unsigned long long)(csr->n + csr->m));
+    GM_CHECK(x_len >= n_global && x_len < (1ull << 32), GM_ERR_RANGE, "gm_pr_create: x_len %llu out of range",
+             (unsigned long long)x_len);
+    GM_CHECK(engine >= GM_PR_ENGINE_AUTO && engine <= GM_PR_ENGINE_PB, GM_ERR_INVALID, "gm_pr_create: unknown engine %d", engine);
+    if (engine == GM_PR_ENGINE_AUTO) // below ~16M edges the gathered vector is cache-resident: the pull tiles win
+        engine = csr->m >= (1ull << 24) ? GM_PR_ENGINE_PB : GM_PR_ENGINE_PULL;
     gm::DeviceGuard guard(csr->device);
     gm_pr *pr = new (std::nothrow) gm_pr();
     GM_CHECK(pr, GM_ERR_NOMEM, "gm_pr_create: out of host memory");
     pr->csr = csr;
     pr->n_global = n_global;
     pr->row_begin = row_begin;
+    pr->x_len = x_len;
+    pr->engine = engine;
     pr->n_local = (uint32_t)csr->n;
     pr->m = (uint32_t)csr->m;
     pr->outdeg = reinterpret_cast<const uint32_t *>(d_out_degree_local);
@@ -372,6 +352,16 @@ GM_API int gm_pr_create(const gm_csr *csr, uint64_t n_global, uint64_t row_begin
     // page_rank.rs:70-71: init_score = 1/n, base_score = (1 - damping)/n, in f32
     pr->init = 1.0f / (float)n_global;
     pr->base = (1.0f - damping_factor) / (float)n_global;
+    if (engine == GM_PR_ENGINE_PB) {
+        const int rc = gm::pb_plan_create(csr, x_len, &pr->pb);
+        if (rc != GM_OK) {
+            delete pr;
+            return rc;
+        }
+        pr->T = (uint32_t)gm::pb_work_items(pr->pb);
+        *out = pr;
+        return GM_OK;
+    }
     const uint64_t items = csr->n + csr->m;
     pr->T = (uint32_t)((items + PR_W - 1) / PR_W);
     if (pr->T == 0)
@@ -401,6 +391,13 @@ GM_API int gm_pr_create(const gm_csr *csr, uint64_t n_global, uint64_t row_begin
     return GM_OK;
 }
 
+GM_API int gm_pr_create(const gm_csr *csr, uint64_t n_global, uint64_t row_begin, uint64_t d_out_degree_local,
+                        float damping_factor, gm_pr **out)
+{
+    return gm_pr_create_with(csr, n_global, row_begin, n_global, d_out_degree_local, damping_factor, GM_PR_ENGINE_AUTO,
+                             out);
+}
+
 GM_API void gm_pr_destroy(gm_pr *pr) { delete pr; }
 
 GM_API uint64_t gm_pr_algorithmic_bytes(const gm_pr *pr)
@@ -409,6 +406,7 @@ GM_API uint64_t gm_pr_algorithmic_bytes(const gm_pr *pr)
 }
 
 GM_API uint64_t gm_pr_tile_count(const gm_pr *pr) { return pr ? pr->T : 0; }
+GM_API int gm_pr_engine(const gm_pr *pr) { return pr ? pr->engine : 0; }
 
 GM_API int gm_pr_init(gm_pr *pr, uint64_t d_scores_local, uint64_t d_x_local, void *stream)
 {
@@ -430,6 +428,10 @@ GM_API int gm_pr_sweep_tiles(gm_pr *pr, uint64_t d_x_in_global, uint64_t d_x_out
 {
     GM_CHECK(pr, GM_ERR_INVALID, "gm_pr_sweep_tiles: null engine");
     gm::DeviceGuard guard(pr->csr->device);
+    if (pr->engine == GM_PR_ENGINE_PB)
+        return gm::pb_sweep_main(pr->pb, reinterpret_cast<const float *>(d_x_in_global),
+                                 reinterpret_cast<float *>(d_x_out_local), reinterpret_cast<float *>(d_scores_local),
+                                 pr->outdeg, pr->base, pr->damping, (hipStream_t)stream);
     hipLaunchKernelGGL(pr_tile_kernel, dim3(pr->T), dim3(PR_BLOCK), 0, (hipStream_t)stream, pr->csr->offsets,
                        pr->csr->targets, pr->tile_row.as<uint32_t>(), reinterpret_cast<const float *>(d_x_in_global),
                        pr->outdeg, reinterpret_cast<float *>(d_scores_local), reinterpret_cast<float *>(d_x_out_local),
@@ -444,6 +446,8 @@ GM_API int gm_pr_sweep_fixup(gm_pr *pr, uint64_t d_x_out_local, uint64_t d_score
 {
     GM_CHECK(pr && d_error_out, GM_ERR_INVALID, "gm_pr_sweep_fixup: null argument");
     gm::DeviceGuard guard(pr->csr->device);
+    if (pr->engine == GM_PR_ENGINE_PB)
+        return gm::pb_sweep_error(pr->pb, reinterpret_cast<double *>(d_error_out), (hipStream_t)stream);
     hipLaunchKernelGGL(pr_fixup_kernel, dim3(pr->G), dim3(PR_BLOCK), 0, (hipStream_t)stream, pr->csr->offsets,
                        pr->tile_row.as<uint32_t>(), pr->outdeg, reinterpret_cast<float *>(d_scores_local),
                        reinterpret_cast<float *>(d_x_out_local), pr->head.as<float>(), pr->tail.as<float>(),
@@ -506,8 +510,7 @@ GM_API int gm_page_rank(const gm_csr *in_csr, const uint32_t *out_degree, uint64
                         double *error_out)
 {
     GM_CHECK(in_csr && iterations_out && error_out, GM_ERR_INVALID, "gm_page_rank: null argument");
-    GM_CHECK(mode == GM_PR_AUTO || mode == GM_PR_JACOBI || mode == GM_PR_SEQUENTIAL, GM_ERR_INVALID,
-             "gm_page_rank: unknown mode %d", mode);
+    GM_CHECK(mode >= GM_PR_AUTO && mode <= GM_PR_JACOBI_PB, GM_ERR_INVALID, "gm_page_rank: unknown mode %d", mode);
     // page_rank.rs:105-109: the loop only ends on error < tolerance or iteration == max_iterations
     GM_CHECK(max_iterations != 0 || tolerance > 0.0, GM_ERR_INVALID,
              "gm_page_rank: max_iterations == 0 with tolerance <= 0 never terminates (reference: infinite loop)");
@@ -568,7 +571,10 @@ GM_API int gm_page_rank(const gm_csr *in_csr, const uint32_t *out_degree, uint64
     GM_TRY(x0.alloc(n * 4));
     GM_TRY(x1.alloc(n * 4));
     PrHolder ph;
-    GM_TRY(gm_pr_create(in_csr, n, 0, (uint64_t)outdeg.p, damping_factor, &ph.p));
+    const int engine = mode == GM_PR_JACOBI_PULL ? GM_PR_ENGINE_PULL
+                       : mode == GM_PR_JACOBI_PB ? GM_PR_ENGINE_PB
+                                                 : GM_PR_ENGINE_AUTO;
+    GM_TRY(gm_pr_create_with(in_csr, n, 0, n, (uint64_t)outdeg.p, damping_factor, engine, &ph.p));
     GM_TRY(gm_pr_init(ph.p, (uint64_t)scores.p, (uint64_t)x0.p, st));
     uint64_t iter = 0;
     double err = 0.0;

@@ -1,0 +1,52 @@
+// pagerank.hpp — shared between the two PageRank sweep engines (pagerank.hip: pull tiles,
+// pagerank_pb.hip: propagation blocking).
+#pragma once
+#include "common.hpp"
+#include "device_utils.hpp"
+
+namespace gm {
+
+// ---- per-node arithmetic, exactly the reference's f32 ops (no FMA contraction) ----------------
+// crates/algos/src/page_rank.rs:149-159
+__device__ __forceinline__ float pr_new_score(float base, float damping, float incoming)
+{
+    return __fadd_rn(base, __fmul_rn(damping, incoming));
+}
+
+__device__ __forceinline__ double pr_finalize(uint32_t r, float incoming, float base, float damping,
+                                              const uint32_t *__restrict__ outdeg, float *__restrict__ scores,
+                                              float *__restrict__ x_out)
+{
+    const float old = scores[r];
+    const float nw = pr_new_score(base, damping, incoming);
+    scores[r] = nw;
+    x_out[r] = __fdiv_rn(nw, (float)outdeg[r]); // out_degree 0 -> +inf, never gathered (page_rank.rs:78,158)
+    return fabs((double)__fsub_rn(nw, old));
+}
+
+struct PbPlan; // pagerank_pb.hip
+int pb_plan_create(const gm_csr *csr, uint64_t x_len, PbPlan **out);
+void pb_plan_destroy(PbPlan *plan);
+int pb_sweep_main(PbPlan *plan, const float *x_in, float *x_out, float *scores, const uint32_t *outdeg, float base,
+                  float damping, hipStream_t st);
+int pb_sweep_error(PbPlan *plan, double *err_out, hipStream_t st);
+uint64_t pb_work_items(const PbPlan *plan);
+
+} // namespace gm
+
+
+struct gm_pr {
+    const gm_csr *csr = nullptr;
+    uint64_t n_global = 0, row_begin = 0, x_len = 0;
+    uint32_t n_local = 0, m = 0, T = 0, G = 0;
+    int engine = GM_PR_ENGINE_PULL;
+    const uint32_t *outdeg = nullptr;
+    float damping = 0.85f, base = 0.0f, init = 0.0f;
+    gm::DevBuf tile_row, head, tail, tile_err, blk_err, ticket; // pull engine
+    gm::PbPlan *pb = nullptr;                                   // propagation-blocking engine
+    ~gm_pr()
+    {
+        if (pb)
+            gm::pb_plan_destroy(pb);
+    }
+};

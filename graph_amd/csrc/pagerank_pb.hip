@@ -1,0 +1,564 @@
+// pagerank_pb.hip — PageRank sweeps by propagation blocking (gfx950 / wave64).
+//
+// Why: the pull sweep's gather out_scores[v] (crates/algos/src/page_rank.rs:143-146) touches one
+// 128-byte line per 4 useful bytes once the vector outgrows the caches; measured on MI355X
+// (tools/membench.hip) a random 4-byte gather runs at ~55 G/s from HBM and ~200 G/s even when the
+// table sits in L2 — the sweep is bound by line transactions, not by bytes.  Only LDS serves
+// random 4-byte accesses fast enough, so the sweep is restructured so that every random access
+// lands in LDS and everything that touches HBM is a sequential stream:
+//
+//   pb_bin_kernel    one workgroup per SOURCE TILE (S = 16384 consecutive node ids): the tile's
+//                    out_scores are loaded into LDS (64 KiB, coalesced); the tile's edges — stored
+//                    once, at plan creation, as 2-byte local source ids grouped by destination bin
+//                    — are streamed and each edge's value xs[src] is appended to its bin's slice of
+//                    the `vals` stream (4-byte coalesced writes, runs of (tile, bin) segments).
+//   pb_accum_kernel  one workgroup per DESTINATION BIN (R <= 16384 consecutive rows): streams the
+//                    bin's values and 2-byte local row ids and accumulates into an LDS array of
+//                    64-bit fixed-point sums (ds_add_u64, scale 2^62: exact, order-independent), then
+//                    the fused epilogue of the reference (new score, |delta|, out_score) for its rows.
+//   pb_err_kernel    sums the per-bin f64 errors in index order.
+//
+// The row sum is therefore the exactly rounded sum of the f32 out_scores: deterministic, identical
+// for any partition of the rows over GPUs, and closer to the real-number fixed point than any f32
+// summation order (the reference's left-to-right order drifts by ~sqrt(in-degree) * 2^-24).
+//
+// HBM traffic per edge and sweep: 2 B (source id) + 4 B (value write) + 4 B (value read) + 2 B (row id)
+// = 12 B, all streaming, against 8 B "algorithmic" of which 4 B are a random gather.
+#include "pagerank.hpp"
+
+#include <rocprim/rocprim.hpp>
+
+#include <utility>
+
+namespace gm {
+
+namespace {
+
+constexpr int PB_S_LOG = 14;
+constexpr uint32_t PB_S = 1u << PB_S_LOG; // sources per tile (x tile = 64 KiB of LDS)
+constexpr int PB_BIN_BLOCK = 512;
+constexpr int PB_ACC_BLOCK = 1024;
+constexpr uint16_t PB_NULL = 0xFFFFu;
+constexpr uint16_t PB_FLAG = 0x8000u;
+constexpr float PB_FIX_SCALE = 4611686018427387904.0f;     // 2^62
+constexpr float PB_FIX_INV = 2.168404344971008868e-19f;    // 2^-62
+
+} // namespace
+
+struct PbPlan {
+    uint32_t n_local = 0, m = 0;
+    uint64_t x_len = 0;
+    int rb = 0;            // log2(rows per bin)
+    uint32_t R = 0, B = 0; // rows per bin, bins
+    uint32_t NT = 0;       // source tiles
+    uint32_t NS = 0;       // non-empty (tile, bin) segments
+    uint64_t Mp = 0;       // padded length of the phase-1 stream
+    int device = 0;
+    DevBuf p1_src;      // u16[Mp]   local source id | PB_FLAG on the first entry of a segment, PB_NULL = padding
+    DevBuf chunk_seg;   // u32[Mp/64] segments started before each 64-entry chunk
+    DevBuf delta;       // u32[NS]   slot = p + delta[segment]   (mod 2^32)
+    DevBuf tile_p;      // u32[NT+1] phase-1 range of each tile (multiples of 64)
+    DevBuf vals;        // f32[m]    per-edge values, bin-major
+    DevBuf p2_dst;      // u16[m]    local row id inside the bin
+    DevBuf bin_v;       // u32[B+1]  value range of each bin
+    DevBuf bin_err;     // f64[B]
+};
+
+namespace {
+
+// ---- plan construction ---------------------------------------------------------------------------
+// key = bin << (sb + rb) | src << rb | row_in_bin      (sorted ascending = bin-major, then source, then row)
+__global__ __launch_bounds__(256) void pb_keys_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt,
+                                                      uint32_t n, int rb, int sb, uint64_t *__restrict__ keys)
+{
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t n_pad = (n + kWave - 1) / kWave * kWave;
+    const uint32_t rmask = (1u << rb) - 1u;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_pad; r += stride) {
+        uint32_t s = 0, e = 0;
+        if (r < n) {
+            s = off[r];
+            e = off[r + 1];
+        }
+        const uint64_t hi = ((uint64_t)(r >> rb) << (sb + rb)) | (r & rmask);
+        const uint32_t len = e - s;
+        if (len <= 32)
+            for (uint32_t i = s; i < e; ++i)
+                keys[i] = hi | ((uint64_t)tgt[i] << rb);
+        uint64_t big = __ballot(len > 32);
+        while (big) {
+            const int src = __ffsll((unsigned long long)big) - 1;
+            big &= big - 1;
+            const uint32_t bs = __shfl(s, src, kWave), be = __shfl(e, src, kWave);
+            const uint64_t bhi = __shfl(hi, src, kWave);
+            for (uint32_t i = bs + lane; i < be; i += kWave)
+                keys[i] = bhi | ((uint64_t)tgt[i] << rb);
+        }
+    }
+}
+
+__device__ __forceinline__ uint64_t pb_seg_of_key(uint64_t k, int rb, int sb)
+{
+    // (bin, tile) as one comparable integer: bin << 32 | tile
+    const uint64_t bin = k >> (sb + rb);
+    const uint64_t src = (k >> rb) & ((1ull << sb) - 1ull);
+    return (bin << 32) | (src >> PB_S_LOG);
+}
+
+__global__ void pb_flags_kernel(const uint64_t *__restrict__ keys, uint32_t m, int rb, int sb, uint32_t *__restrict__ flag,
+                                uint16_t *__restrict__ p2_dst)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t rmask = (1u << rb) - 1u;
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < m; q += stride) {
+        const uint64_t k = keys[q];
+        flag[q] = (q == 0 || pb_seg_of_key(keys[q - 1], rb, sb) != pb_seg_of_key(k, rb, sb)) ? 1u : 0u;
+        p2_dst[q] = (uint16_t)((uint32_t)k & rmask);
+    }
+}
+
+// segid = inclusive_scan(flag); for every segment start: vstart[j] = q, segkey[j] = tile << 32 | bin, segval[j] = j
+__global__ void pb_segments_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ flag,
+                                   const uint32_t *__restrict__ segid_incl, uint32_t m, int rb, int sb,
+                                   uint32_t *__restrict__ vstart, uint64_t *__restrict__ segkey,
+                                   uint32_t *__restrict__ segval)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < m; q += stride)
+        if (flag[q]) {
+            const uint32_t j = segid_incl[q] - 1;
+            const uint64_t bt = pb_seg_of_key(keys[q], rb, sb);
+            vstart[j] = q;
+            segkey[j] = ((bt & 0xFFFFFFFFull) << 32) | (bt >> 32);
+            segval[j] = j;
+        }
+}
+
+// segments in phase-1 order (rank r): cnt[r]; tile_seg[t] = first rank of tile t
+__global__ void pb_seg_counts_kernel(const uint32_t *__restrict__ segval_sorted, const uint32_t *__restrict__ vstart,
+                                     uint32_t NS, uint32_t m, uint32_t *__restrict__ cnt)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r <= NS; r += stride) {
+        if (r == NS) {
+            cnt[r] = 0;
+            continue;
+        }
+        const uint32_t j = segval_sorted[r];
+        const uint32_t end = j + 1 < NS ? vstart[j + 1] : m;
+        cnt[r] = end - vstart[j];
+    }
+}
+
+// padded tile sizes from the exclusive scan `cs` of cnt and the tile boundaries
+__global__ void pb_tile_sizes_kernel(const uint32_t *__restrict__ tile_seg, const uint32_t *__restrict__ cs, uint32_t NT,
+                                     uint32_t *__restrict__ tile_pad)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t <= NT; t += stride) {
+        if (t == NT) {
+            tile_pad[t] = 0;
+            continue;
+        }
+        const uint32_t c = cs[tile_seg[t + 1]] - cs[tile_seg[t]];
+        tile_pad[t] = (c + 63u) & ~63u;
+    }
+}
+
+// per phase-1 segment r: pstart, delta; and the inverse permutation rank_of[j] = r
+__global__ void pb_seg_layout_kernel(const uint64_t *__restrict__ segkey_sorted, const uint32_t *__restrict__ segval_sorted,
+                                     const uint32_t *__restrict__ vstart, const uint32_t *__restrict__ cs,
+                                     const uint32_t *__restrict__ tile_seg, const uint32_t *__restrict__ tile_p,
+                                     uint32_t NS, uint32_t *__restrict__ pstart, uint32_t *__restrict__ delta,
+                                     uint32_t *__restrict__ rank_of)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < NS; r += stride) {
+        const uint32_t t = (uint32_t)(segkey_sorted[r] >> 32);
+        const uint32_t j = segval_sorted[r];
+        const uint32_t ps = tile_p[t] + (cs[r] - cs[tile_seg[t]]);
+        pstart[r] = ps;
+        delta[r] = vstart[j] - ps;
+        rank_of[j] = r;
+    }
+}
+
+__global__ void pb_p1_fill_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ segid_incl,
+                                  const uint32_t *__restrict__ vstart, const uint32_t *__restrict__ rank_of,
+                                  const uint32_t *__restrict__ pstart, uint32_t m, int rb, int sb,
+                                  uint16_t *__restrict__ p1_src)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < m; q += stride) {
+        const uint32_t j = segid_incl[q] - 1;
+        const uint32_t vs = vstart[j];
+        const uint32_t p = pstart[rank_of[j]] + (q - vs);
+        const uint32_t src = (uint32_t)((keys[q] >> rb) & ((1ull << sb) - 1ull));
+        p1_src[p] = (uint16_t)((src & (PB_S - 1u)) | (q == vs ? PB_FLAG : 0));
+    }
+}
+
+// chunk_seg[c] = number of segments with pstart < 64 c
+__global__ void pb_chunk_seg_kernel(const uint32_t *__restrict__ pstart, uint32_t NS, uint32_t nchunks,
+                                    uint32_t *__restrict__ chunk_seg)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nchunks; c += stride) {
+        const uint64_t target = (uint64_t)c * 64;
+        chunk_seg[c] = (uint32_t)lower_bound_fn(0, NS, target, [&](uint64_t r) { return (uint64_t)pstart[r]; });
+    }
+}
+
+// boundaries of a sorted u64 key array after a shift: out[v] = first index whose key >> shift is >= v
+__global__ void pb_bounds_kernel(const uint64_t *__restrict__ keys, uint32_t count, int shift, uint32_t nvals,
+                                 uint32_t *__restrict__ out)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= count; i += stride) {
+        const uint32_t lo = i == 0 ? 0u : (uint32_t)(keys[i - 1] >> shift) + 1u;
+        const uint32_t hi = i == count ? nvals : (uint32_t)(keys[i] >> shift);
+        for (uint32_t v = lo; v <= hi; ++v)
+            out[v] = i;
+    }
+}
+
+// ---- the sweep -----------------------------------------------------------------------------------
+__global__ __launch_bounds__(PB_BIN_BLOCK) void pb_bin_kernel(const float *__restrict__ x_in, uint64_t x_len,
+                                                              const uint32_t *__restrict__ tile_p,
+                                                              const uint16_t *__restrict__ p1_src,
+                                                              const uint32_t *__restrict__ chunk_seg,
+                                                              const uint32_t *__restrict__ delta, float *__restrict__ vals)
+{
+    extern __shared__ float xs[]; // PB_S floats
+    const uint32_t t = blockIdx.x, tid = threadIdx.x;
+    const uint32_t pb = tile_p[t], pe = tile_p[t + 1];
+    if (pb == pe)
+        return;
+    const uint64_t x0 = (uint64_t)t * PB_S;
+    const uint32_t xn = (uint32_t)((x_len - x0) < PB_S ? (x_len - x0) : PB_S);
+    for (uint32_t i = tid; i < xn; i += PB_BIN_BLOCK)
+        xs[i] = x_in[x0 + i];
+    __syncthreads();
+    const uint32_t lane = tid & (kWave - 1);
+    const uint64_t le_mask = (lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull);
+    constexpr int U = 4;
+    for (uint32_t p0 = pb + tid; p0 < pe; p0 += PB_BIN_BLOCK * U) {
+        uint16_t v[U];
+        uint32_t cs[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const uint32_t p = p0 + k * PB_BIN_BLOCK; // pb, pe and the block size are multiples of 64:
+            const bool in = p < pe;                   // a wavefront's 64 entries are one aligned chunk
+            v[k] = in ? p1_src[p] : PB_NULL;
+            cs[k] = in ? chunk_seg[p >> 6] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const uint32_t p = p0 + k * PB_BIN_BLOCK;
+            const bool valid = v[k] != PB_NULL;
+            const uint64_t starts = __ballot(valid && (v[k] & PB_FLAG));
+            if (valid) {
+                const uint32_t rank = cs[k] + (uint32_t)__popcll(starts & le_mask) - 1u;
+                vals[p + delta[rank]] = xs[v[k] & (PB_S - 1u)];
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ unsigned long long pb_to_fix(float x)
+{
+    return (unsigned long long)(x * PB_FIX_SCALE); // exact scaling by 2^62, truncation below 2^-62
+}
+
+__global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__restrict__ vals,
+                                                                const uint16_t *__restrict__ p2_dst,
+                                                                const uint32_t *__restrict__ bin_v,
+                                                                const uint32_t *__restrict__ outdeg, float *__restrict__ scores,
+                                                                float *__restrict__ x_out, double *__restrict__ bin_err,
+                                                                uint32_t n_local, uint32_t R, float base, float damping)
+{
+    extern __shared__ unsigned long long acc[]; // R fixed-point sums
+    __shared__ double red[PB_ACC_BLOCK / kWave];
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    for (uint32_t i = tid; i < R; i += PB_ACC_BLOCK)
+        acc[i] = 0ull;
+    __syncthreads();
+    const uint32_t qb = bin_v[b], qe = bin_v[b + 1];
+    constexpr int U = 4;
+    for (uint32_t q0 = qb + tid; q0 < qe; q0 += PB_ACC_BLOCK * U) {
+        float v[U];
+        uint16_t d[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const uint32_t q = q0 + k * PB_ACC_BLOCK;
+            v[k] = q < qe ? vals[q] : 0.0f;
+            d[k] = q < qe ? p2_dst[q] : (uint16_t)0;
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const uint32_t q = q0 + k * PB_ACC_BLOCK;
+            if (q < qe)
+                atomicAdd(&acc[d[k]], pb_to_fix(v[k]));
+        }
+    }
+    __syncthreads();
+    double err = 0.0;
+    const uint32_t r0 = b * R;
+    for (uint32_t i = tid; i < R; i += PB_ACC_BLOCK) {
+        const uint32_t r = r0 + i;
+        if (r < n_local) {
+            const float incoming = (float)acc[i] * PB_FIX_INV; // one rounding: the exactly rounded row sum
+            err += pr_finalize(r, incoming, base, damping, outdeg, scores, x_out);
+        }
+    }
+    const double total = block_sum<double, PB_ACC_BLOCK / kWave>(err, red);
+    if (tid == 0)
+        bin_err[b] = total;
+}
+
+__global__ __launch_bounds__(1024) void pb_err_kernel(const double *__restrict__ bin_err, uint32_t B, double *__restrict__ err_out)
+{
+    __shared__ double red[1024 / kWave];
+    double acc = 0.0;
+    for (uint32_t b = threadIdx.x; b < B; b += 1024)
+        acc += bin_err[b];
+    const double total = block_sum<double, 1024 / kWave>(acc, red);
+    if (threadIdx.x == 0)
+        *err_out = total;
+}
+
+unsigned pb_grid(uint64_t count)
+{
+    unsigned g = div_up(count, 256);
+    return g > 256 * 32 ? 256 * 32 : (g ? g : 1);
+}
+
+int bits_for(uint64_t x) // smallest b with x <= 2^b
+{
+    int b = 0;
+    while ((1ull << b) < x)
+        ++b;
+    return b;
+}
+
+template <class T> int scan_exclusive(const T *in, T *out, uint64_t count)
+{
+    size_t tmp_bytes = 0;
+    GM_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, in, out, T(0), count, rocprim::plus<T>(), (hipStream_t)0));
+    DevBuf tmp;
+    GM_TRY(tmp.alloc(tmp_bytes));
+    GM_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, in, out, T(0), count, rocprim::plus<T>(), (hipStream_t)0));
+    return GM_OK;
+}
+
+int scan_inclusive_u32(const uint32_t *in, uint32_t *out, uint64_t count)
+{
+    size_t tmp_bytes = 0;
+    GM_HIP(rocprim::inclusive_scan(nullptr, tmp_bytes, in, out, count, rocprim::plus<uint32_t>(), (hipStream_t)0));
+    DevBuf tmp;
+    GM_TRY(tmp.alloc(tmp_bytes));
+    GM_HIP(rocprim::inclusive_scan(tmp.p, tmp_bytes, in, out, count, rocprim::plus<uint32_t>(), (hipStream_t)0));
+    return GM_OK;
+}
+
+int sort_keys_u64(DevBuf &keys, DevBuf &alt, uint64_t count, int end_bit)
+{
+    rocprim::double_buffer<uint64_t> db(keys.as<uint64_t>(), alt.as<uint64_t>());
+    size_t tmp_bytes = 0;
+    GM_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, db, count, 0u, (unsigned)end_bit, (hipStream_t)0));
+    DevBuf tmp;
+    GM_TRY(tmp.alloc(tmp_bytes));
+    GM_HIP(rocprim::radix_sort_keys(tmp.p, tmp_bytes, db, count, 0u, (unsigned)end_bit, (hipStream_t)0));
+    GM_HIP(hipDeviceSynchronize());
+    if (db.current() != keys.as<uint64_t>())
+        std::swap(keys, alt);
+    return GM_OK;
+}
+
+int sort_pairs_u64_u32(DevBuf &keys, DevBuf &kalt, DevBuf &vals, DevBuf &valt, uint64_t count, int end_bit)
+{
+    rocprim::double_buffer<uint64_t> dk(keys.as<uint64_t>(), kalt.as<uint64_t>());
+    rocprim::double_buffer<uint32_t> dv(vals.as<uint32_t>(), valt.as<uint32_t>());
+    size_t tmp_bytes = 0;
+    GM_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, dk, dv, count, 0u, (unsigned)end_bit, (hipStream_t)0));
+    DevBuf tmp;
+    GM_TRY(tmp.alloc(tmp_bytes));
+    GM_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, dk, dv, count, 0u, (unsigned)end_bit, (hipStream_t)0));
+    GM_HIP(hipDeviceSynchronize());
+    if (dk.current() != keys.as<uint64_t>())
+        std::swap(keys, kalt);
+    if (dv.current() != vals.as<uint32_t>())
+        std::swap(vals, valt);
+    return GM_OK;
+}
+
+int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
+{
+    const uint32_t n = (uint32_t)csr->n, m = (uint32_t)csr->m;
+    pl->n_local = n;
+    pl->m = m;
+    pl->x_len = x_len;
+    pl->device = csr->device;
+    // rows per bin: keep >= ~2048 bins so the accumulate kernel fills the chip, cap the LDS slice at 128 KiB
+    int rb = bits_for(n) - 11;
+    if (rb < 8)
+        rb = 8;
+    if (rb > 14)
+        rb = 14;
+    pl->rb = rb;
+    pl->R = 1u << rb;
+    pl->B = (uint32_t)(((uint64_t)n + pl->R - 1) >> rb);
+    if (pl->B == 0)
+        pl->B = 1;
+    pl->NT = (uint32_t)((x_len + PB_S - 1) >> PB_S_LOG);
+    if (pl->NT == 0)
+        pl->NT = 1;
+    const int sb = bits_for(x_len) < 1 ? 1 : bits_for(x_len);
+    const int bin_bits = bits_for(pl->B) < 1 ? 1 : bits_for(pl->B);
+    GM_CHECK(bin_bits + sb + rb <= 64, GM_ERR_RANGE, "pb_build: key does not fit 64 bits");
+
+    GM_TRY(pl->bin_v.alloc(((size_t)pl->B + 1) * 4));
+    GM_TRY(pl->bin_err.alloc((size_t)pl->B * 8));
+    GM_TRY(pl->tile_p.alloc(((size_t)pl->NT + 1) * 4));
+    GM_TRY(pl->vals.alloc((size_t)m * 4));
+    GM_TRY(pl->p2_dst.alloc((size_t)m * 2));
+    if (m == 0) {
+        GM_HIP(hipMemset(pl->bin_v.p, 0, ((size_t)pl->B + 1) * 4));
+        GM_HIP(hipMemset(pl->tile_p.p, 0, ((size_t)pl->NT + 1) * 4));
+        return GM_OK;
+    }
+    const unsigned gm_ = pb_grid(m);
+
+    DevBuf keys, kalt;
+    GM_TRY(keys.alloc((size_t)m * 8));
+    GM_TRY(kalt.alloc((size_t)m * 8));
+    hipLaunchKernelGGL(pb_keys_kernel, dim3(pb_grid(n)), dim3(256), 0, 0, csr->offsets, csr->targets, n, rb, sb,
+                       keys.as<uint64_t>());
+    GM_HIP(hipGetLastError());
+    GM_TRY(sort_keys_u64(keys, kalt, m, bin_bits + sb + rb));
+    kalt.release();
+
+    // bins
+    hipLaunchKernelGGL(pb_bounds_kernel, dim3(gm_), dim3(256), 0, 0, keys.as<uint64_t>(), m, sb + rb, pl->B,
+                       pl->bin_v.as<uint32_t>());
+    // (bin, tile) segments
+    DevBuf flag, segid;
+    GM_TRY(flag.alloc((size_t)m * 4));
+    GM_TRY(segid.alloc((size_t)m * 4));
+    hipLaunchKernelGGL(pb_flags_kernel, dim3(gm_), dim3(256), 0, 0, keys.as<uint64_t>(), m, rb, sb, flag.as<uint32_t>(),
+                       pl->p2_dst.as<uint16_t>());
+    GM_HIP(hipGetLastError());
+    GM_TRY(scan_inclusive_u32(flag.as<uint32_t>(), segid.as<uint32_t>(), m));
+    uint32_t NS = 0;
+    GM_HIP(hipMemcpy(&NS, segid.as<uint32_t>() + (m - 1), 4, hipMemcpyDeviceToHost));
+    pl->NS = NS;
+
+    DevBuf vstart, segkey, segkalt, segval, segvalt;
+    GM_TRY(vstart.alloc((size_t)NS * 4));
+    GM_TRY(segkey.alloc((size_t)NS * 8));
+    GM_TRY(segkalt.alloc((size_t)NS * 8));
+    GM_TRY(segval.alloc((size_t)NS * 4));
+    GM_TRY(segvalt.alloc((size_t)NS * 4));
+    hipLaunchKernelGGL(pb_segments_kernel, dim3(gm_), dim3(256), 0, 0, keys.as<uint64_t>(), flag.as<uint32_t>(),
+                       segid.as<uint32_t>(), m, rb, sb, vstart.as<uint32_t>(), segkey.as<uint64_t>(),
+                       segval.as<uint32_t>());
+    GM_HIP(hipGetLastError());
+    flag.release();
+    // phase-1 order of the segments: by (tile, bin)
+    GM_TRY(sort_pairs_u64_u32(segkey, segkalt, segval, segvalt, NS, 64));
+    segkalt.release();
+    segvalt.release();
+
+    DevBuf cnt, cs, tile_seg, tile_pad, pstart, rank_of;
+    GM_TRY(cnt.alloc(((size_t)NS + 1) * 4));
+    GM_TRY(cs.alloc(((size_t)NS + 1) * 4));
+    GM_TRY(tile_seg.alloc(((size_t)pl->NT + 1) * 4));
+    GM_TRY(tile_pad.alloc(((size_t)pl->NT + 1) * 4));
+    GM_TRY(pstart.alloc((size_t)NS * 4));
+    GM_TRY(rank_of.alloc((size_t)NS * 4));
+    GM_TRY(pl->delta.alloc((size_t)NS * 4));
+    const unsigned gs = pb_grid((uint64_t)NS + 1);
+    hipLaunchKernelGGL(pb_seg_counts_kernel, dim3(gs), dim3(256), 0, 0, segval.as<uint32_t>(), vstart.as<uint32_t>(), NS,
+                       m, cnt.as<uint32_t>());
+    GM_HIP(hipGetLastError());
+    GM_TRY(scan_exclusive<uint32_t>(cnt.as<uint32_t>(), cs.as<uint32_t>(), (uint64_t)NS + 1));
+    hipLaunchKernelGGL(pb_bounds_kernel, dim3(gs), dim3(256), 0, 0, segkey.as<uint64_t>(), NS, 32, pl->NT,
+                       tile_seg.as<uint32_t>());
+    hipLaunchKernelGGL(pb_tile_sizes_kernel, dim3(pb_grid((uint64_t)pl->NT + 1)), dim3(256), 0, 0,
+                       tile_seg.as<uint32_t>(), cs.as<uint32_t>(), pl->NT, tile_pad.as<uint32_t>());
+    GM_HIP(hipGetLastError());
+    GM_TRY(scan_exclusive<uint32_t>(tile_pad.as<uint32_t>(), pl->tile_p.as<uint32_t>(), (uint64_t)pl->NT + 1));
+    uint32_t Mp = 0;
+    GM_HIP(hipMemcpy(&Mp, pl->tile_p.as<uint32_t>() + pl->NT, 4, hipMemcpyDeviceToHost));
+    pl->Mp = Mp;
+    GM_CHECK((uint64_t)m + (uint64_t)pl->NT * 64 < (1ull << 32), GM_ERR_RANGE, "pb_build: phase-1 stream exceeds 2^32 entries");
+    hipLaunchKernelGGL(pb_seg_layout_kernel, dim3(gs), dim3(256), 0, 0, segkey.as<uint64_t>(), segval.as<uint32_t>(),
+                       vstart.as<uint32_t>(), cs.as<uint32_t>(), tile_seg.as<uint32_t>(), pl->tile_p.as<uint32_t>(), NS,
+                       pstart.as<uint32_t>(), pl->delta.as<uint32_t>(), rank_of.as<uint32_t>());
+    GM_HIP(hipGetLastError());
+
+    GM_TRY(pl->p1_src.alloc((size_t)Mp * 2));
+    GM_TRY(pl->chunk_seg.alloc(((size_t)Mp / 64 + 1) * 4));
+    GM_HIP(hipMemset(pl->p1_src.p, 0xFF, (size_t)Mp * 2));
+    hipLaunchKernelGGL(pb_p1_fill_kernel, dim3(gm_), dim3(256), 0, 0, keys.as<uint64_t>(), segid.as<uint32_t>(),
+                       vstart.as<uint32_t>(), rank_of.as<uint32_t>(), pstart.as<uint32_t>(), m, rb, sb,
+                       pl->p1_src.as<uint16_t>());
+    hipLaunchKernelGGL(pb_chunk_seg_kernel, dim3(pb_grid(Mp / 64 + 1)), dim3(256), 0, 0, pstart.as<uint32_t>(), NS,
+                       Mp / 64, pl->chunk_seg.as<uint32_t>());
+    GM_HIP(hipGetLastError());
+    GM_HIP(hipDeviceSynchronize());
+    return GM_OK;
+}
+
+} // namespace
+
+int pb_plan_create(const gm_csr *csr, uint64_t x_len, PbPlan **out)
+{
+    PbPlan *pl = new (std::nothrow) PbPlan();
+    GM_CHECK(pl, GM_ERR_NOMEM, "pb_plan_create: out of host memory");
+    const int rc = pb_build(csr, x_len, pl);
+    if (rc != GM_OK) {
+        delete pl;
+        return rc;
+    }
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pb_bin_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PB_S * 4);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pb_accum_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (1 << 14) * 8);
+    if (e != hipSuccess) {
+        set_error("pb_plan_create: %s", hipGetErrorString(e));
+        delete pl;
+        return GM_ERR_HIP;
+    }
+    *out = pl;
+    return GM_OK;
+}
+
+void pb_plan_destroy(PbPlan *plan) { delete plan; }
+
+uint64_t pb_work_items(const PbPlan *plan) { return plan ? (uint64_t)plan->NT + plan->B : 0; }
+
+int pb_sweep_main(PbPlan *pl, const float *x_in, float *x_out, float *scores, const uint32_t *outdeg, float base,
+                  float damping, hipStream_t st)
+{
+    if (pl->m)
+        hipLaunchKernelGGL(pb_bin_kernel, dim3(pl->NT), dim3(PB_BIN_BLOCK), PB_S * 4, st, x_in, pl->x_len,
+                           pl->tile_p.as<uint32_t>(), pl->p1_src.as<uint16_t>(), pl->chunk_seg.as<uint32_t>(),
+                           pl->delta.as<uint32_t>(), pl->vals.as<float>());
+    hipLaunchKernelGGL(pb_accum_kernel, dim3(pl->B), dim3(PB_ACC_BLOCK), (size_t)pl->R * 8, st, pl->vals.as<float>(),
+                       pl->p2_dst.as<uint16_t>(), pl->bin_v.as<uint32_t>(), outdeg, scores, x_out,
+                       pl->bin_err.as<double>(), pl->n_local, pl->R, base, damping);
+    GM_HIP(hipGetLastError());
+    return GM_OK;
+}
+
+int pb_sweep_error(PbPlan *pl, double *err_out, hipStream_t st)
+{
+    hipLaunchKernelGGL(pb_err_kernel, dim3(1), dim3(1024), 0, st, pl->bin_err.as<double>(), pl->B, err_out);
+    GM_HIP(hipGetLastError());
+    return GM_OK;
+}
+
+} // namespace gm

@@ -20,13 +20,15 @@ class PageRankEngine:
     """page_rank_iteration (crates/algos/src/page_rank.rs:113-168) over rows
     [row_begin, row_begin + n_local) of a graph with n_global nodes; arrays are torch tensors."""
 
+    AUTO, PULL, PB = 0, 1, 2
+
     def __init__(self, in_csr_handle, n_global: int, row_begin: int, out_degree_local: torch.Tensor,
-                 damping_factor: float = 0.85):
+                 damping_factor: float = 0.85, x_len: int | None = None, engine: int = 0):
         assert out_degree_local.dtype == torch.int32 and out_degree_local.is_cuda
         self._keep = (in_csr_handle, out_degree_local)
         h = vp()
-        check(lib().gm_pr_create(in_csr_handle, n_global, row_begin, out_degree_local.data_ptr(),
-                                 damping_factor, C.byref(h)))
+        check(lib().gm_pr_create_with(in_csr_handle, n_global, row_begin, x_len if x_len is not None else n_global,
+                                      out_degree_local.data_ptr(), damping_factor, engine, C.byref(h)))
         self._h = h
         self.n_local = int(out_degree_local.numel())
 
@@ -38,6 +40,10 @@ class PageRankEngine:
     @property
     def algorithmic_bytes(self) -> int:
         return int(lib().gm_pr_algorithmic_bytes(self._h))
+
+    @property
+    def engine(self) -> str:
+        return {1: "pull", 2: "pb"}[int(lib().gm_pr_engine(self._h))]
 
     @property
     def tiles(self) -> int:

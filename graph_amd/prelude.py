@@ -329,8 +329,10 @@ class PageRankConfig:
 
 class PageRankMode(enum.IntEnum):
     Auto = 0        # n <= 16384: Sequential (bit-exact with the reference), else Jacobi
-    Jacobi = 1
+    Jacobi = 1      # synchronous sweeps, engine picked by graph size
     Sequential = 2
+    JacobiPull = 3  # force the pull-tile sweep kernels
+    JacobiPB = 4    # force the propagation-blocking sweep kernels
 
 
 def page_rank(graph: DirectedCsrGraph, config: PageRankConfig | None = None, mode=PageRankMode.Auto):

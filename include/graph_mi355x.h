@@ -116,7 +116,13 @@ int gm_csr_slice_rows(const gm_csr *full, uint64_t row_lo, uint64_t row_hi, cons
  * Stop rule as page_rank.rs:105-109: iteration += 1; stop if error < tolerance ||
  * iteration == max_iterations (so at least one sweep always runs).
  * ------------------------------------------------------------------------------------------- */
-typedef enum gm_pr_mode { GM_PR_AUTO = 0, GM_PR_JACOBI = 1, GM_PR_SEQUENTIAL = 2 } gm_pr_mode;
+typedef enum gm_pr_mode {
+    GM_PR_AUTO = 0,
+    GM_PR_JACOBI = 1,      /* synchronous sweeps, engine chosen by size (gm_pr_engine_kind below) */
+    GM_PR_SEQUENTIAL = 2,
+    GM_PR_JACOBI_PULL = 3, /* synchronous sweeps, force the pull-tile engine */
+    GM_PR_JACOBI_PB = 4    /* synchronous sweeps, force the propagation-blocking engine */
+} gm_pr_mode;
 
 int gm_page_rank(const gm_csr *in_csr, const uint32_t *out_degree, uint64_t max_iterations, double tolerance,
                  float damping_factor, int mode, float *scores_out /* n, host */, uint64_t *iterations_out,
@@ -129,6 +135,16 @@ typedef struct gm_pr gm_pr;
 int gm_pr_create(const gm_csr *in_csr_rows /* n_local rows, targets are global ids */, uint64_t n_global,
                  uint64_t row_begin, uint64_t d_out_degree_local /* u32[n_local] */, float damping_factor,
                  gm_pr **out);
+/* Same with explicit choices.  x_len: length of the x_in vector the sweeps will read (n_global, or
+ * parts*stride when targets were rewritten by gm_csr_slice_rows).  engine:
+ *   GM_PR_ENGINE_PULL  merge-tile pull sweep (gather out_scores through the caches)
+ *   GM_PR_ENGINE_PB    propagation blocking: values binned by destination range, accumulated in LDS
+ *                      as exact 64-bit fixed point — all HBM traffic sequential (large graphs)
+ *   GM_PR_ENGINE_AUTO  PB from 2^24 edges up, else PULL */
+typedef enum gm_pr_engine_kind { GM_PR_ENGINE_AUTO = 0, GM_PR_ENGINE_PULL = 1, GM_PR_ENGINE_PB = 2 } gm_pr_engine_kind;
+int gm_pr_create_with(const gm_csr *in_csr_rows, uint64_t n_global, uint64_t row_begin, uint64_t x_len,
+                      uint64_t d_out_degree_local, float damping_factor, int engine, gm_pr **out);
+int gm_pr_engine(const gm_pr *pr); /* the engine actually chosen */
 void gm_pr_destroy(gm_pr *pr);
 /* scores[i] = 1/n_global, x_local[i] = (1/n_global)/out_degree[i]   (page_rank.rs:70-81) */
 int gm_pr_init(gm_pr *pr, uint64_t d_scores_local, uint64_t d_x_local, void *stream);

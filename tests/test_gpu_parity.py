@@ -384,3 +384,103 @@ def test_triangle_count_vs_oracle(P, oracle, layout, relabel):
         off, tgt, _ = oracle.relabel_by_degree(off, tgt)
         P.relabel_graph(ug)
     assert P.global_triangle_count(ug) == oracle.triangle_count(off, tgt, threads=8)
+
+
+# ------------------------------------------------------------------------------------------------
+# PageRank: propagation-blocking engine (exact fixed-point row sums) and the partitioned path
+# ------------------------------------------------------------------------------------------------
+def test_page_rank_pb_engine_matches_exact_row_sums(P, oracle):
+    for n, s, d in _ragged_graphs(oracle):
+        g = _directed(P, n, s, d, P.CsrLayout.Sorted)
+        (_, _), (ioff, itgt) = _oracle_directed(oracle, n, s, d, oracle.SORTED)
+        od = oracle.out_degrees_from(n, s)
+        for sweeps in (1, 3):
+            ref_scores, ref_err = _jacobi_reference(ioff, itgt, od, sweeps)
+            got, it, err = P.page_rank(g, P.PageRankConfig(sweeps, 0.0, 0.85), P.PageRankMode.JacobiPB)
+            assert it == sweeps
+            # the row sum is exactly rounded: at most an ulp from the f64-accumulated reference
+            np.testing.assert_allclose(got, ref_scores, rtol=1.5e-7, atol=0)
+            assert abs(err - ref_err) <= 1e-6 * max(ref_err, 1e-30) + 1e-12
+        a = P.page_rank(g, P.PageRankConfig(3, 0.0, 0.85), P.PageRankMode.JacobiPB)
+        b = P.page_rank(g, P.PageRankConfig(3, 0.0, 0.85), P.PageRankMode.JacobiPB)
+        assert np.array_equal(a[0], b[0]) and a[2] == b[2]
+        c = P.page_rank(g, P.PageRankConfig(3, 0.0, 0.85), P.PageRankMode.JacobiPull)
+        np.testing.assert_allclose(a[0], c[0], rtol=2e-6, atol=0)
+
+
+@pytest.mark.parametrize("scale", [16, 20])
+def test_page_rank_pb_engine_converged(P, oracle, scale):
+    s, d = oracle.rmat_edges(scale, seed=42)
+    n = 1 << scale
+    g = _directed(P, n, s, d, P.CsrLayout.Sorted)
+    (_, _), (ioff, itgt) = _oracle_directed(oracle, n, s, d, oracle.SORTED)
+    od = oracle.out_degrees_from(n, s)
+    deg = np.diff(ioff).astype(np.float64)
+    got, iterations, error = P.page_rank(g, P.PageRankConfig(200, 1e-10, 0.85), P.PageRankMode.JacobiPB)
+    exact, _, _ = oracle.page_rank_f64(ioff, itgt, od)
+    rel_exact = np.abs(got - exact) / exact
+    assert rel_exact.max() <= 2e-6, rel_exact.max()
+    ref, _, _ = oracle.page_rank_chunked(ioff, itgt, od, 200, 1e-10, 0.85)
+    rel = np.abs(got.astype(np.float64) - ref) / ref
+    assert rel[deg < 4096].max() <= 1e-5
+    assert np.all(rel <= np.maximum(1e-5, 8 * np.sqrt(deg) * 2.0 ** -24)), rel.max()
+    print(f"PB scale {scale}: {iterations} sweeps, max rel err vs exact {rel_exact.max():.2e}, vs reference order {rel.max():.2e}")
+
+
+def test_partitioned_engines_on_one_device_match_single_engine(P, oracle):
+    """The multi-GPU path (row slices, targets rewritten into the padded all-gather index space, one
+    engine per rank) exercised with 3 virtual ranks on one GPU, copies standing in for the all-gather."""
+    import ctypes as C
+
+    import torch
+
+    from graph_amd._lib import check, lib, vp
+    from graph_amd.distributed import greedy_degree_partition, pad_bounds
+    from graph_amd.engine import PageRankEngine
+
+    scale, world = 16, 3
+    n = 1 << scale
+    s, d = oracle.rmat_edges(scale, seed=9)
+    inc = P.DeviceCsr.from_edges(n, s, d, None, P.Direction.Incoming, P.CsrLayout.Sorted)
+    ioff = inc.host()[0]
+    od = torch.from_numpy(oracle.out_degrees_from(n, s).astype(np.int32)).cuda()
+    bounds, stride = pad_bounds(greedy_degree_partition(ioff, world), world, n)
+    dev = torch.device("cuda", 0)
+    for kind in (PageRankEngine.PULL, PageRankEngine.PB):
+        # single engine
+        eng = PageRankEngine(inc.handle, n, 0, od, 0.85, engine=kind)
+        x = [torch.zeros(n, device=dev), torch.zeros(n, device=dev)]
+        sc = torch.zeros(n, device=dev)
+        err = torch.zeros(1, dtype=torch.float64, device=dev)
+        eng.init(sc, x[0])
+        errs = []
+        for k in range(4):
+            eng.sweep(x[k % 2], x[1 - k % 2], sc, err)
+            errs.append(float(err.item()))
+        # partitioned
+        parts = []
+        for r in range(world):
+            lo, hi = int(bounds[r]), int(bounds[r + 1])
+            h = vp()
+            check(lib().gm_csr_slice_rows(inc.handle, lo, hi, bounds.ctypes.data_as(vp), world, stride, C.byref(h)))
+            csr = P.DeviceCsr(h)
+            odl = od[lo:hi].contiguous() if hi > lo else torch.zeros(1, dtype=torch.int32, device=dev)
+            e = PageRankEngine(csr.handle, n, lo, odl, 0.85, x_len=world * stride, engine=kind)
+            parts.append((csr, odl, e, torch.zeros(max(hi - lo, 1), device=dev), torch.zeros(stride, device=dev),
+                          torch.zeros(1, dtype=torch.float64, device=dev), lo, hi))
+        xp = [torch.zeros(world * stride, device=dev), torch.zeros(world * stride, device=dev)]
+        for r, (_, _, e, scl, xl, _, lo, hi) in enumerate(parts):
+            e.init(scl, xl)
+            xp[0][r * stride:(r + 1) * stride] = xl
+        for k in range(4):
+            tot = 0.0
+            for r, (_, _, e, scl, xl, el, lo, hi) in enumerate(parts):
+                e.sweep(xp[k % 2], xl, scl, el)
+                xp[1 - k % 2][r * stride:(r + 1) * stride] = xl
+                tot += float(el.item())
+            assert abs(tot - errs[k]) <= 1e-9 * errs[k] + 1e-15
+        got = torch.cat([p[3][: p[7] - p[6]] for p in parts])
+        if kind == PageRankEngine.PB:
+            assert torch.equal(got, sc)  # exact row sums: identical for any partition
+        else:
+            torch.testing.assert_close(got, sc, rtol=2e-6, atol=0)

@@ -11,7 +11,7 @@ line = sys.stdin.read().strip()
 try:
     d = json.loads(line)
     r = d['roofline']
-    print('scale=$scale relabel=$relabel extra=[$*] GTEPS=%.1f ms/step=%.4f tile_ms=%.4f frac=%.4f achieved=%.0fGB/s build=%.2fs' % (d['value'], d['ms_per_step'], r['avg_launch_ms'], r['frac'], r['achieved'], d['config']['csr_build_s']))
+    print('scale=$scale relabel=$relabel extra=[$*] engine=%s GTEPS=%.1f ms/step=%.4f tile_ms=%.4f frac=%.4f achieved=%.0fGB/s build=%.2fs' % (d['config']['engine'], d['value'], d['ms_per_step'], r['avg_launch_ms'], r['frac'], r['achieved'], d['config']['csr_build_s']))
 except Exception as e:
     print('scale=$scale relabel=$relabel FAILED:', line[-400:])
 "
