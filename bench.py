@@ -242,14 +242,15 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    # release device objects explicitly, then leave without running interpreter-exit destructors:
-    # under rocprofv3 a HIP call made during Python finalisation can block forever after the tool
-    # has finalised (observed: the process hung after printing its result).
+    # release every device object explicitly before interpreter shutdown (a HIP call from a
+    # destructor during Python finalisation was seen to block forever under rocprofv3)
     del engine, local_csr
+    in_csr = None
+    import gc
+
+    gc.collect()
     torch.cuda.synchronize()
     sys.stdout.flush()
-    sys.stderr.flush()
-    os._exit(0)
 
 
 if __name__ == "__main__":

@@ -36,8 +36,11 @@ namespace {
 
 constexpr int PB_S_LOG = 14;
 constexpr uint32_t PB_S = 1u << PB_S_LOG; // sources per tile (x tile = 64 KiB of LDS)
-constexpr int PB_BIN_BLOCK = 512;
+constexpr int PB_BIN_BLOCK = 1024;
 constexpr int PB_ACC_BLOCK = 1024;
+constexpr uint32_t PB_VEC = 4;                  // segments are padded to multiples of 4 entries in both streams
+constexpr uint32_t PB_WBLK = kWave * PB_VEC;    // entries one wavefront covers per step (256)
+constexpr uint32_t PB_BIN_CHUNK = 1u << 16;     // phase-1 entries per workgroup (a tile is split into chunks)
 constexpr uint16_t PB_NULL = 0xFFFFu;
 constexpr uint16_t PB_FLAG = 0x8000u;
 constexpr float PB_FIX_SCALE = 4611686018427387904.0f;     // 2^62
@@ -53,14 +56,18 @@ struct PbPlan {
     uint32_t NT = 0;       // source tiles
     uint32_t NS = 0;       // non-empty (tile, bin) segments
     uint64_t Mp = 0;       // padded length of the phase-1 stream
+    uint64_t Mv = 0;       // padded length of the value stream
+    uint32_t NW = 0;       // phase-1 workgroups
     int device = 0;
     DevBuf p1_src;      // u16[Mp]   local source id | PB_FLAG on the first entry of a segment, PB_NULL = padding
-    DevBuf chunk_seg;   // u32[Mp/64] segments started before each 64-entry chunk
-    DevBuf delta;       // u32[NS]   slot = p + delta[segment]   (mod 2^32)
-    DevBuf tile_p;      // u32[NT+1] phase-1 range of each tile (multiples of 64)
-    DevBuf vals;        // f32[m]    per-edge values, bin-major
-    DevBuf p2_dst;      // u16[m]    local row id inside the bin
-    DevBuf bin_v;       // u32[B+1]  value range of each bin
+    DevBuf chunk_seg;   // u32[Mp/256] segments started before each 256-entry wavefront block
+    DevBuf delta;       // u32[NS]   slot = p + delta[segment]   (mod 2^32, a multiple of 4)
+    DevBuf tile_p;      // u32[NT+1] phase-1 range of each tile (multiples of 256)
+    DevBuf wg_tile;     // u32[NW]   tile of each phase-1 workgroup
+    DevBuf wg_p0;       // u32[NW]   first phase-1 entry of each workgroup
+    DevBuf vals;        // f32[Mv]   per-edge values, bin-major, segments padded to 4
+    DevBuf p2_dst;      // u16[Mv]   local row id inside the bin, PB_NULL = padding
+    DevBuf bin_v;       // u32[B+1]  value range of each bin (multiples of 4)
     DevBuf bin_err;     // f64[B]
 };
 
@@ -106,15 +113,12 @@ __device__ __forceinline__ uint64_t pb_seg_of_key(uint64_t k, int rb, int sb)
     return (bin << 32) | (src >> PB_S_LOG);
 }
 
-__global__ void pb_flags_kernel(const uint64_t *__restrict__ keys, uint32_t m, int rb, int sb, uint32_t *__restrict__ flag,
-                                uint16_t *__restrict__ p2_dst)
+__global__ void pb_flags_kernel(const uint64_t *__restrict__ keys, uint32_t m, int rb, int sb, uint32_t *__restrict__ flag)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t rmask = (1u << rb) - 1u;
     for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < m; q += stride) {
         const uint64_t k = keys[q];
         flag[q] = (q == 0 || pb_seg_of_key(keys[q - 1], rb, sb) != pb_seg_of_key(k, rb, sb)) ? 1u : 0u;
-        p2_dst[q] = (uint16_t)((uint32_t)k & rmask);
     }
 }
 
@@ -122,7 +126,7 @@ __global__ void pb_flags_kernel(const uint64_t *__restrict__ keys, uint32_t m, i
 __global__ void pb_segments_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ flag,
                                    const uint32_t *__restrict__ segid_incl, uint32_t m, int rb, int sb,
                                    uint32_t *__restrict__ vstart, uint64_t *__restrict__ segkey,
-                                   uint32_t *__restrict__ segval)
+                                   uint32_t *__restrict__ segval, uint64_t *__restrict__ segbin)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < m; q += stride)
@@ -132,22 +136,27 @@ __global__ void pb_segments_kernel(const uint64_t *__restrict__ keys, const uint
             vstart[j] = q;
             segkey[j] = ((bt & 0xFFFFFFFFull) << 32) | (bt >> 32);
             segval[j] = j;
+            segbin[j] = bt >> 32;
         }
 }
 
 // segments in phase-1 order (rank r): cnt[r]; tile_seg[t] = first rank of tile t
+// padded (multiple of 4) segment sizes: cnt_p1[r] in phase-1 order, cnt_v[j] in bin-major order
 __global__ void pb_seg_counts_kernel(const uint32_t *__restrict__ segval_sorted, const uint32_t *__restrict__ vstart,
-                                     uint32_t NS, uint32_t m, uint32_t *__restrict__ cnt)
+                                     uint32_t NS, uint32_t m, uint32_t *__restrict__ cnt_p1, uint32_t *__restrict__ cnt_v)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r <= NS; r += stride) {
         if (r == NS) {
-            cnt[r] = 0;
+            cnt_p1[r] = 0;
+            cnt_v[r] = 0;
             continue;
         }
         const uint32_t j = segval_sorted[r];
         const uint32_t end = j + 1 < NS ? vstart[j + 1] : m;
-        cnt[r] = end - vstart[j];
+        cnt_p1[r] = (end - vstart[j] + PB_VEC - 1u) & ~(PB_VEC - 1u);
+        const uint32_t end2 = r + 1 < NS ? vstart[r + 1] : m; // r doubles as a bin-major index here
+        cnt_v[r] = (end2 - vstart[r] + PB_VEC - 1u) & ~(PB_VEC - 1u);
     }
 }
 
@@ -162,13 +171,13 @@ __global__ void pb_tile_sizes_kernel(const uint32_t *__restrict__ tile_seg, cons
             continue;
         }
         const uint32_t c = cs[tile_seg[t + 1]] - cs[tile_seg[t]];
-        tile_pad[t] = (c + 63u) & ~63u;
+        tile_pad[t] = (c + PB_WBLK - 1u) & ~(PB_WBLK - 1u);
     }
 }
 
 // per phase-1 segment r: pstart, delta; and the inverse permutation rank_of[j] = r
 __global__ void pb_seg_layout_kernel(const uint64_t *__restrict__ segkey_sorted, const uint32_t *__restrict__ segval_sorted,
-                                     const uint32_t *__restrict__ vstart, const uint32_t *__restrict__ cs,
+                                     const uint32_t *__restrict__ vstart4, const uint32_t *__restrict__ cs,
                                      const uint32_t *__restrict__ tile_seg, const uint32_t *__restrict__ tile_p,
                                      uint32_t NS, uint32_t *__restrict__ pstart, uint32_t *__restrict__ delta,
                                      uint32_t *__restrict__ rank_of)
@@ -179,33 +188,66 @@ __global__ void pb_seg_layout_kernel(const uint64_t *__restrict__ segkey_sorted,
         const uint32_t j = segval_sorted[r];
         const uint32_t ps = tile_p[t] + (cs[r] - cs[tile_seg[t]]);
         pstart[r] = ps;
-        delta[r] = vstart[j] - ps;
+        delta[r] = vstart4[j] - ps;
         rank_of[j] = r;
     }
 }
 
-__global__ void pb_p1_fill_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ segid_incl,
-                                  const uint32_t *__restrict__ vstart, const uint32_t *__restrict__ rank_of,
-                                  const uint32_t *__restrict__ pstart, uint32_t m, int rb, int sb,
-                                  uint16_t *__restrict__ p1_src)
+__global__ void pb_fill_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ segid_incl,
+                               const uint32_t *__restrict__ vstart, const uint32_t *__restrict__ vstart4,
+                               const uint32_t *__restrict__ rank_of, const uint32_t *__restrict__ pstart, uint32_t m,
+                               int rb, int sb, uint16_t *__restrict__ p1_src, uint16_t *__restrict__ p2_dst)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t rmask = (1u << rb) - 1u;
     for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < m; q += stride) {
         const uint32_t j = segid_incl[q] - 1;
         const uint32_t vs = vstart[j];
+        const uint64_t k = keys[q];
         const uint32_t p = pstart[rank_of[j]] + (q - vs);
-        const uint32_t src = (uint32_t)((keys[q] >> rb) & ((1ull << sb) - 1ull));
+        const uint32_t src = (uint32_t)((k >> rb) & ((1ull << sb) - 1ull));
         p1_src[p] = (uint16_t)((src & (PB_S - 1u)) | (q == vs ? PB_FLAG : 0));
+        p2_dst[vstart4[j] + (q - vs)] = (uint16_t)((uint32_t)k & rmask);
     }
 }
 
-// chunk_seg[c] = number of segments with pstart < 64 c
+// bin_v[b] = padded value-stream position of the first segment of a bin >= b
+__global__ void pb_bin_ranges_kernel(const uint32_t *__restrict__ bin_seg, const uint32_t *__restrict__ vstart4, uint32_t B,
+                                     uint32_t *__restrict__ bin_v)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b <= B; b += stride)
+        bin_v[b] = vstart4[bin_seg[b]];
+}
+
+// phase-1 workgroups: tile t is split into ceil(len / PB_BIN_CHUNK) chunks
+__global__ void pb_wg_count_kernel(const uint32_t *__restrict__ tile_p, uint32_t NT, uint32_t *__restrict__ wg_cnt)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t <= NT; t += stride)
+        wg_cnt[t] = t == NT ? 0u : (tile_p[t + 1] - tile_p[t] + PB_BIN_CHUNK - 1u) / PB_BIN_CHUNK;
+}
+
+__global__ void pb_wg_fill_kernel(const uint32_t *__restrict__ tile_p, const uint32_t *__restrict__ wg_first, uint32_t NT,
+                                  uint32_t *__restrict__ wg_tile, uint32_t *__restrict__ wg_p0)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < NT; t += stride) {
+        const uint32_t w0 = wg_first[t], w1 = wg_first[t + 1];
+        for (uint32_t w = w0; w < w1; ++w) {
+            wg_tile[w] = t;
+            wg_p0[w] = tile_p[t] + (w - w0) * PB_BIN_CHUNK;
+        }
+    }
+}
+
+// chunk_seg[c] = number of segments with pstart < 256 c
 __global__ void pb_chunk_seg_kernel(const uint32_t *__restrict__ pstart, uint32_t NS, uint32_t nchunks,
                                     uint32_t *__restrict__ chunk_seg)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nchunks; c += stride) {
-        const uint64_t target = (uint64_t)c * 64;
+        const uint64_t target = (uint64_t)c * PB_WBLK;
         chunk_seg[c] = (uint32_t)lower_bound_fn(0, NS, target, [&](uint64_t r) { return (uint64_t)pstart[r]; });
     }
 }
@@ -224,43 +266,64 @@ __global__ void pb_bounds_kernel(const uint64_t *__restrict__ keys, uint32_t cou
 }
 
 // ---- the sweep -----------------------------------------------------------------------------------
+struct alignas(8) U16x4 {
+    uint16_t a, b, c, d;
+};
+
 __global__ __launch_bounds__(PB_BIN_BLOCK) void pb_bin_kernel(const float *__restrict__ x_in, uint64_t x_len,
                                                               const uint32_t *__restrict__ tile_p,
+                                                              const uint32_t *__restrict__ wg_tile,
+                                                              const uint32_t *__restrict__ wg_p0,
                                                               const uint16_t *__restrict__ p1_src,
                                                               const uint32_t *__restrict__ chunk_seg,
                                                               const uint32_t *__restrict__ delta, float *__restrict__ vals)
 {
     extern __shared__ float xs[]; // PB_S floats
-    const uint32_t t = blockIdx.x, tid = threadIdx.x;
-    const uint32_t pb = tile_p[t], pe = tile_p[t + 1];
-    if (pb == pe)
-        return;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t t = wg_tile[blockIdx.x];
+    const uint32_t p_begin = wg_p0[blockIdx.x];
+    const uint32_t tile_end = tile_p[t + 1];
+    const uint32_t p_end = (tile_end - p_begin) < PB_BIN_CHUNK ? tile_end : p_begin + PB_BIN_CHUNK;
     const uint64_t x0 = (uint64_t)t * PB_S;
     const uint32_t xn = (uint32_t)((x_len - x0) < PB_S ? (x_len - x0) : PB_S);
-    for (uint32_t i = tid; i < xn; i += PB_BIN_BLOCK)
-        xs[i] = x_in[x0 + i];
+    if ((xn & 3u) == 0 && ((x0 & 3u) == 0)) {
+        const float4 *src4 = reinterpret_cast<const float4 *>(x_in + x0);
+        float4 *dst4 = reinterpret_cast<float4 *>(xs);
+        for (uint32_t i = tid; i < xn / 4; i += PB_BIN_BLOCK)
+            dst4[i] = src4[i];
+    } else {
+        for (uint32_t i = tid; i < xn; i += PB_BIN_BLOCK)
+            xs[i] = x_in[x0 + i];
+    }
     __syncthreads();
     const uint32_t lane = tid & (kWave - 1);
     const uint64_t le_mask = (lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull);
     constexpr int U = 4;
-    for (uint32_t p0 = pb + tid; p0 < pe; p0 += PB_BIN_BLOCK * U) {
-        uint16_t v[U];
+    constexpr uint32_t STEP = PB_BIN_BLOCK * PB_VEC; // entries per workgroup step (4096)
+    // every wavefront covers one aligned 256-entry block per step: lane l owns entries 4l..4l+3
+    for (uint32_t p0 = p_begin + tid * PB_VEC; p0 < p_end; p0 += STEP * U) {
+        U16x4 v[U];
         uint32_t cs[U];
 #pragma unroll
         for (int k = 0; k < U; ++k) {
-            const uint32_t p = p0 + k * PB_BIN_BLOCK; // pb, pe and the block size are multiples of 64:
-            const bool in = p < pe;                   // a wavefront's 64 entries are one aligned chunk
-            v[k] = in ? p1_src[p] : PB_NULL;
-            cs[k] = in ? chunk_seg[p >> 6] : 0u;
+            const uint32_t p = p0 + k * STEP;
+            const bool in = p < p_end; // uniform per wavefront: ranges are multiples of 256
+            v[k] = in ? *reinterpret_cast<const U16x4 *>(p1_src + p) : U16x4{PB_NULL, PB_NULL, PB_NULL, PB_NULL};
+            cs[k] = in ? chunk_seg[p / PB_WBLK] : 0u;
         }
 #pragma unroll
         for (int k = 0; k < U; ++k) {
-            const uint32_t p = p0 + k * PB_BIN_BLOCK;
-            const bool valid = v[k] != PB_NULL;
-            const uint64_t starts = __ballot(valid && (v[k] & PB_FLAG));
+            const uint32_t p = p0 + k * STEP;
+            const bool valid = v[k].a != PB_NULL; // a segment's first entry is never padding
+            const uint64_t starts = __ballot(valid && (v[k].a & PB_FLAG));
             if (valid) {
                 const uint32_t rank = cs[k] + (uint32_t)__popcll(starts & le_mask) - 1u;
-                vals[p + delta[rank]] = xs[v[k] & (PB_S - 1u)];
+                float4 o;
+                o.x = xs[v[k].a & (PB_S - 1u)];
+                o.y = xs[v[k].b & (PB_S - 1u)];
+                o.z = xs[v[k].c & (PB_S - 1u)];
+                o.w = xs[v[k].d & (PB_S - 1u)];
+                *reinterpret_cast<float4 *>(vals + (p + delta[rank])) = o; // padding lanes write padding slots
             }
         }
     }
@@ -284,22 +347,32 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
     for (uint32_t i = tid; i < R; i += PB_ACC_BLOCK)
         acc[i] = 0ull;
     __syncthreads();
-    const uint32_t qb = bin_v[b], qe = bin_v[b + 1];
+    const uint32_t qb = bin_v[b], qe = bin_v[b + 1]; // multiples of 4
     constexpr int U = 4;
-    for (uint32_t q0 = qb + tid; q0 < qe; q0 += PB_ACC_BLOCK * U) {
-        float v[U];
-        uint16_t d[U];
+    constexpr uint32_t STEP = PB_ACC_BLOCK * PB_VEC;
+    for (uint32_t q0 = qb + tid * PB_VEC; q0 < qe; q0 += STEP * U) {
+        float4 v[U];
+        U16x4 d[U];
 #pragma unroll
         for (int k = 0; k < U; ++k) {
-            const uint32_t q = q0 + k * PB_ACC_BLOCK;
-            v[k] = q < qe ? vals[q] : 0.0f;
-            d[k] = q < qe ? p2_dst[q] : (uint16_t)0;
+            const uint32_t q = q0 + k * STEP;
+            if (q < qe) {
+                v[k] = *reinterpret_cast<const float4 *>(vals + q);
+                d[k] = *reinterpret_cast<const U16x4 *>(p2_dst + q);
+            } else {
+                d[k] = U16x4{PB_NULL, PB_NULL, PB_NULL, PB_NULL};
+            }
         }
 #pragma unroll
         for (int k = 0; k < U; ++k) {
-            const uint32_t q = q0 + k * PB_ACC_BLOCK;
-            if (q < qe)
-                atomicAdd(&acc[d[k]], pb_to_fix(v[k]));
+            if (d[k].a != PB_NULL)
+                atomicAdd(&acc[d[k].a], pb_to_fix(v[k].x));
+            if (d[k].b != PB_NULL)
+                atomicAdd(&acc[d[k].b], pb_to_fix(v[k].y));
+            if (d[k].c != PB_NULL)
+                atomicAdd(&acc[d[k].c], pb_to_fix(v[k].z));
+            if (d[k].d != PB_NULL)
+                atomicAdd(&acc[d[k].d], pb_to_fix(v[k].w));
         }
     }
     __syncthreads();
@@ -421,11 +494,12 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     GM_TRY(pl->bin_v.alloc(((size_t)pl->B + 1) * 4));
     GM_TRY(pl->bin_err.alloc((size_t)pl->B * 8));
     GM_TRY(pl->tile_p.alloc(((size_t)pl->NT + 1) * 4));
-    GM_TRY(pl->vals.alloc((size_t)m * 4));
-    GM_TRY(pl->p2_dst.alloc((size_t)m * 2));
     if (m == 0) {
+        GM_TRY(pl->vals.alloc(16));
+        GM_TRY(pl->p2_dst.alloc(16));
         GM_HIP(hipMemset(pl->bin_v.p, 0, ((size_t)pl->B + 1) * 4));
         GM_HIP(hipMemset(pl->tile_p.p, 0, ((size_t)pl->NT + 1) * 4));
+        pl->NW = 0;
         return GM_OK;
     }
     const unsigned gm_ = pb_grid(m);
@@ -439,50 +513,65 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     GM_TRY(sort_keys_u64(keys, kalt, m, bin_bits + sb + rb));
     kalt.release();
 
-    // bins
-    hipLaunchKernelGGL(pb_bounds_kernel, dim3(gm_), dim3(256), 0, 0, keys.as<uint64_t>(), m, sb + rb, pl->B,
-                       pl->bin_v.as<uint32_t>());
-    // (bin, tile) segments
+    // (bin, tile) segments of the sorted entries
     DevBuf flag, segid;
     GM_TRY(flag.alloc((size_t)m * 4));
     GM_TRY(segid.alloc((size_t)m * 4));
-    hipLaunchKernelGGL(pb_flags_kernel, dim3(gm_), dim3(256), 0, 0, keys.as<uint64_t>(), m, rb, sb, flag.as<uint32_t>(),
-                       pl->p2_dst.as<uint16_t>());
+    hipLaunchKernelGGL(pb_flags_kernel, dim3(gm_), dim3(256), 0, 0, keys.as<uint64_t>(), m, rb, sb, flag.as<uint32_t>());
     GM_HIP(hipGetLastError());
     GM_TRY(scan_inclusive_u32(flag.as<uint32_t>(), segid.as<uint32_t>(), m));
     uint32_t NS = 0;
     GM_HIP(hipMemcpy(&NS, segid.as<uint32_t>() + (m - 1), 4, hipMemcpyDeviceToHost));
     pl->NS = NS;
+    GM_CHECK((uint64_t)m + 3ull * NS + (uint64_t)pl->NT * PB_WBLK < (1ull << 32), GM_ERR_RANGE,
+             "pb_build: padded streams exceed 2^32 entries");
 
-    DevBuf vstart, segkey, segkalt, segval, segvalt;
+    DevBuf vstart, segkey, segkalt, segval, segvalt, segbin;
     GM_TRY(vstart.alloc((size_t)NS * 4));
     GM_TRY(segkey.alloc((size_t)NS * 8));
     GM_TRY(segkalt.alloc((size_t)NS * 8));
     GM_TRY(segval.alloc((size_t)NS * 4));
     GM_TRY(segvalt.alloc((size_t)NS * 4));
+    GM_TRY(segbin.alloc((size_t)NS * 8));
     hipLaunchKernelGGL(pb_segments_kernel, dim3(gm_), dim3(256), 0, 0, keys.as<uint64_t>(), flag.as<uint32_t>(),
                        segid.as<uint32_t>(), m, rb, sb, vstart.as<uint32_t>(), segkey.as<uint64_t>(),
-                       segval.as<uint32_t>());
+                       segval.as<uint32_t>(), segbin.as<uint64_t>());
     GM_HIP(hipGetLastError());
+    GM_HIP(hipDeviceSynchronize());
     flag.release();
+    // first segment of every bin (segments are bin-major already)
+    DevBuf bin_seg;
+    GM_TRY(bin_seg.alloc(((size_t)pl->B + 1) * 4));
+    const unsigned gs = pb_grid((uint64_t)NS + 1);
+    hipLaunchKernelGGL(pb_bounds_kernel, dim3(gs), dim3(256), 0, 0, segbin.as<uint64_t>(), NS, 0, pl->B,
+                       bin_seg.as<uint32_t>());
+    GM_HIP(hipGetLastError());
     // phase-1 order of the segments: by (tile, bin)
     GM_TRY(sort_pairs_u64_u32(segkey, segkalt, segval, segvalt, NS, 64));
     segkalt.release();
     segvalt.release();
+    segbin.release();
 
-    DevBuf cnt, cs, tile_seg, tile_pad, pstart, rank_of;
+    DevBuf cnt, cs, cntv, vstart4, tile_seg, tile_pad, pstart, rank_of;
     GM_TRY(cnt.alloc(((size_t)NS + 1) * 4));
     GM_TRY(cs.alloc(((size_t)NS + 1) * 4));
+    GM_TRY(cntv.alloc(((size_t)NS + 1) * 4));
+    GM_TRY(vstart4.alloc(((size_t)NS + 1) * 4));
     GM_TRY(tile_seg.alloc(((size_t)pl->NT + 1) * 4));
     GM_TRY(tile_pad.alloc(((size_t)pl->NT + 1) * 4));
     GM_TRY(pstart.alloc((size_t)NS * 4));
     GM_TRY(rank_of.alloc((size_t)NS * 4));
     GM_TRY(pl->delta.alloc((size_t)NS * 4));
-    const unsigned gs = pb_grid((uint64_t)NS + 1);
     hipLaunchKernelGGL(pb_seg_counts_kernel, dim3(gs), dim3(256), 0, 0, segval.as<uint32_t>(), vstart.as<uint32_t>(), NS,
-                       m, cnt.as<uint32_t>());
+                       m, cnt.as<uint32_t>(), cntv.as<uint32_t>());
     GM_HIP(hipGetLastError());
     GM_TRY(scan_exclusive<uint32_t>(cnt.as<uint32_t>(), cs.as<uint32_t>(), (uint64_t)NS + 1));
+    GM_TRY(scan_exclusive<uint32_t>(cntv.as<uint32_t>(), vstart4.as<uint32_t>(), (uint64_t)NS + 1));
+    uint32_t Mv = 0;
+    GM_HIP(hipMemcpy(&Mv, vstart4.as<uint32_t>() + NS, 4, hipMemcpyDeviceToHost));
+    pl->Mv = Mv;
+    hipLaunchKernelGGL(pb_bin_ranges_kernel, dim3(pb_grid((uint64_t)pl->B + 1)), dim3(256), 0, 0, bin_seg.as<uint32_t>(),
+                       vstart4.as<uint32_t>(), pl->B, pl->bin_v.as<uint32_t>());
     hipLaunchKernelGGL(pb_bounds_kernel, dim3(gs), dim3(256), 0, 0, segkey.as<uint64_t>(), NS, 32, pl->NT,
                        tile_seg.as<uint32_t>());
     hipLaunchKernelGGL(pb_tile_sizes_kernel, dim3(pb_grid((uint64_t)pl->NT + 1)), dim3(256), 0, 0,
@@ -492,20 +581,39 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     uint32_t Mp = 0;
     GM_HIP(hipMemcpy(&Mp, pl->tile_p.as<uint32_t>() + pl->NT, 4, hipMemcpyDeviceToHost));
     pl->Mp = Mp;
-    GM_CHECK((uint64_t)m + (uint64_t)pl->NT * 64 < (1ull << 32), GM_ERR_RANGE, "pb_build: phase-1 stream exceeds 2^32 entries");
     hipLaunchKernelGGL(pb_seg_layout_kernel, dim3(gs), dim3(256), 0, 0, segkey.as<uint64_t>(), segval.as<uint32_t>(),
-                       vstart.as<uint32_t>(), cs.as<uint32_t>(), tile_seg.as<uint32_t>(), pl->tile_p.as<uint32_t>(), NS,
+                       vstart4.as<uint32_t>(), cs.as<uint32_t>(), tile_seg.as<uint32_t>(), pl->tile_p.as<uint32_t>(), NS,
                        pstart.as<uint32_t>(), pl->delta.as<uint32_t>(), rank_of.as<uint32_t>());
     GM_HIP(hipGetLastError());
 
+    GM_TRY(pl->vals.alloc((size_t)Mv * 4));
+    GM_TRY(pl->p2_dst.alloc((size_t)Mv * 2));
     GM_TRY(pl->p1_src.alloc((size_t)Mp * 2));
-    GM_TRY(pl->chunk_seg.alloc(((size_t)Mp / 64 + 1) * 4));
+    GM_TRY(pl->chunk_seg.alloc(((size_t)Mp / PB_WBLK + 1) * 4));
     GM_HIP(hipMemset(pl->p1_src.p, 0xFF, (size_t)Mp * 2));
-    hipLaunchKernelGGL(pb_p1_fill_kernel, dim3(gm_), dim3(256), 0, 0, keys.as<uint64_t>(), segid.as<uint32_t>(),
-                       vstart.as<uint32_t>(), rank_of.as<uint32_t>(), pstart.as<uint32_t>(), m, rb, sb,
-                       pl->p1_src.as<uint16_t>());
-    hipLaunchKernelGGL(pb_chunk_seg_kernel, dim3(pb_grid(Mp / 64 + 1)), dim3(256), 0, 0, pstart.as<uint32_t>(), NS,
-                       Mp / 64, pl->chunk_seg.as<uint32_t>());
+    GM_HIP(hipMemset(pl->p2_dst.p, 0xFF, (size_t)Mv * 2));
+    GM_HIP(hipMemset(pl->vals.p, 0, (size_t)Mv * 4));
+    hipLaunchKernelGGL(pb_fill_kernel, dim3(gm_), dim3(256), 0, 0, keys.as<uint64_t>(), segid.as<uint32_t>(),
+                       vstart.as<uint32_t>(), vstart4.as<uint32_t>(), rank_of.as<uint32_t>(), pstart.as<uint32_t>(), m, rb,
+                       sb, pl->p1_src.as<uint16_t>(), pl->p2_dst.as<uint16_t>());
+    hipLaunchKernelGGL(pb_chunk_seg_kernel, dim3(pb_grid(Mp / PB_WBLK + 1)), dim3(256), 0, 0, pstart.as<uint32_t>(), NS,
+                       Mp / PB_WBLK, pl->chunk_seg.as<uint32_t>());
+    GM_HIP(hipGetLastError());
+    // phase-1 workgroup list
+    DevBuf wg_cnt, wg_first;
+    GM_TRY(wg_cnt.alloc(((size_t)pl->NT + 1) * 4));
+    GM_TRY(wg_first.alloc(((size_t)pl->NT + 1) * 4));
+    hipLaunchKernelGGL(pb_wg_count_kernel, dim3(pb_grid((uint64_t)pl->NT + 1)), dim3(256), 0, 0, pl->tile_p.as<uint32_t>(),
+                       pl->NT, wg_cnt.as<uint32_t>());
+    GM_HIP(hipGetLastError());
+    GM_TRY(scan_exclusive<uint32_t>(wg_cnt.as<uint32_t>(), wg_first.as<uint32_t>(), (uint64_t)pl->NT + 1));
+    uint32_t NW = 0;
+    GM_HIP(hipMemcpy(&NW, wg_first.as<uint32_t>() + pl->NT, 4, hipMemcpyDeviceToHost));
+    pl->NW = NW;
+    GM_TRY(pl->wg_tile.alloc((size_t)NW * 4));
+    GM_TRY(pl->wg_p0.alloc((size_t)NW * 4));
+    hipLaunchKernelGGL(pb_wg_fill_kernel, dim3(pb_grid(pl->NT)), dim3(256), 0, 0, pl->tile_p.as<uint32_t>(),
+                       wg_first.as<uint32_t>(), pl->NT, pl->wg_tile.as<uint32_t>(), pl->wg_p0.as<uint32_t>());
     GM_HIP(hipGetLastError());
     GM_HIP(hipDeviceSynchronize());
     return GM_OK;
@@ -538,15 +646,16 @@ int pb_plan_create(const gm_csr *csr, uint64_t x_len, PbPlan **out)
 
 void pb_plan_destroy(PbPlan *plan) { delete plan; }
 
-uint64_t pb_work_items(const PbPlan *plan) { return plan ? (uint64_t)plan->NT + plan->B : 0; }
+uint64_t pb_work_items(const PbPlan *plan) { return plan ? (uint64_t)plan->NW + plan->B : 0; }
 
 int pb_sweep_main(PbPlan *pl, const float *x_in, float *x_out, float *scores, const uint32_t *outdeg, float base,
                   float damping, hipStream_t st)
 {
-    if (pl->m)
-        hipLaunchKernelGGL(pb_bin_kernel, dim3(pl->NT), dim3(PB_BIN_BLOCK), PB_S * 4, st, x_in, pl->x_len,
-                           pl->tile_p.as<uint32_t>(), pl->p1_src.as<uint16_t>(), pl->chunk_seg.as<uint32_t>(),
-                           pl->delta.as<uint32_t>(), pl->vals.as<float>());
+    if (pl->NW)
+        hipLaunchKernelGGL(pb_bin_kernel, dim3(pl->NW), dim3(PB_BIN_BLOCK), PB_S * 4, st, x_in, pl->x_len,
+                           pl->tile_p.as<uint32_t>(), pl->wg_tile.as<uint32_t>(), pl->wg_p0.as<uint32_t>(),
+                           pl->p1_src.as<uint16_t>(), pl->chunk_seg.as<uint32_t>(), pl->delta.as<uint32_t>(),
+                           pl->vals.as<float>());
     hipLaunchKernelGGL(pb_accum_kernel, dim3(pl->B), dim3(PB_ACC_BLOCK), (size_t)pl->R * 8, st, pl->vals.as<float>(),
                        pl->p2_dst.as<uint16_t>(), pl->bin_v.as<uint32_t>(), outdeg, scores, x_out,
                        pl->bin_err.as<double>(), pl->n_local, pl->R, base, damping);

@@ -6,6 +6,7 @@ run on torch's current HIP stream, so torch.cuda.Event brackets them exactly.
 from __future__ import annotations
 
 import ctypes as C
+import sys
 
 import torch
 
@@ -34,7 +35,7 @@ class PageRankEngine:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and not sys.is_finalizing():
             lib().gm_pr_destroy(h)
 
     @property

@@ -17,6 +17,7 @@ empty sample set, ...) these functions raise.  There is no CPU fallback.
 from __future__ import annotations
 
 import ctypes as C
+import sys
 import enum
 import os
 from dataclasses import dataclass
@@ -82,7 +83,7 @@ class DeviceCsr:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and not sys.is_finalizing():  # at interpreter exit the HIP runtime may already be gone
             try:
                 lib().gm_csr_free(h)
             except Exception:

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <vector>
+#include <cstdlib>
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
@@ -35,6 +36,36 @@ __global__ __launch_bounds__(256) void gather8(const uint32_t *__restrict__ idx,
         for (int k = 0; k < 8; ++k) acc += table[v[k]];
     }
     if (acc == 1.2345f) *out = acc;
+}
+
+// LDS atomic throughput: every lane adds into a pseudo-random slot of an LDS table
+template <class T, int SLOTS>
+__global__ __launch_bounds__(1024) void lds_atomic(int iters, T *out)
+{
+    __shared__ T tab[SLOTS];
+    for (int i = threadIdx.x; i < SLOTS; i += 1024) tab[i] = T(0);
+    __syncthreads();
+    uint32_t x = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 1u;
+    for (int i = 0; i < iters; ++i) {
+        x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+        atomicAdd(&tab[x % SLOTS], T(1));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && tab[0] == T(123456789)) *out = tab[1];
+}
+
+template <class T, int SLOTS> static void run_lds(const char *name, T *out)
+{
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    const int iters = 2048;
+    float best = 1e30f, ms;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(a);
+        hipLaunchKernelGGL((lds_atomic<T, SLOTS>), dim3(256 * 4), dim3(1024), 0, 0, iters, out);
+        hipEventRecord(b); hipEventSynchronize(b); hipEventElapsedTime(&ms, a, b);
+        if (ms < best) best = ms;
+    }
+    printf("lds_atomic %-28s: %.3f ms  %.1f Gatomic/s\n", name, best, 256.0 * 4 * 1024 * iters / best / 1e6);
 }
 
 static uint64_t sm64(uint64_t x) { x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; return x ^ (x >> 31); }
@@ -72,6 +103,13 @@ int main()
         CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms, a, b));
         printf("stream_read 1GiB: %.3f ms  %.1f GB/s\n", ms, (1ull << 30) / ms / 1e6);
     }
+    run_lds<unsigned long long, 16384>("u64 x 16384 slots (128KiB)", (unsigned long long *)out);
+    run_lds<unsigned long long, 2048>("u64 x 2048 slots", (unsigned long long *)out);
+    run_lds<unsigned int, 16384>("u32 x 16384 slots", (unsigned int *)out);
+    run_lds<float, 16384>("f32 x 16384 slots", (float *)out);
+    run_lds<unsigned long long, 64>("u64 x 64 slots (conflicts)", (unsigned long long *)out);
+    run_lds<unsigned long long, 1>("u64 x 1 slot (all collide)", (unsigned long long *)out);
+    if (getenv("MEMBENCH_LDS_ONLY")) return 0;
     for (int skew = 0; skew < 2; ++skew)
         for (int lg = 18; lg <= 28; lg += 2) {
             uint32_t mask = (1u << lg) - 1;
