@@ -79,6 +79,29 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7).  Our library
+    needs the same SONAME; whichever copy is loaded first wins for us, but a later `import torch`
+    would still map its bundled copy by path -> two HIP runtimes in one process (streams and
+    events of one are meaningless to the other, device discovery can fail).  So when torch is
+    installed but not imported yet, map its bundled runtime first; then both sides share it."""
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        bundled = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(bundled):
+            C.CDLL(bundled, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass  # no torch: the system ROCm runtime is used
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -87,6 +110,7 @@ def lib():
                 f"{LIB_PATH} is missing: the MI355X HIP library has not been built "
                 "(run `python -c 'import __graft_entry__ as g; g.build()'`). graph_amd has no CPU fallback."
             )
+        _share_hip_runtime_with_torch()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the .so lost a symbol

@@ -28,6 +28,7 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include <cstdlib>
 #include <utility>
 
 namespace gm {
@@ -40,7 +41,6 @@ constexpr int PB_BIN_BLOCK = 1024;
 constexpr int PB_ACC_BLOCK = 1024;
 constexpr uint32_t PB_VEC = 4;                  // segments are padded to multiples of 4 entries in both streams
 constexpr uint32_t PB_WBLK = kWave * PB_VEC;    // entries one wavefront covers per step (256)
-constexpr uint32_t PB_BIN_CHUNK = 1u << 16;     // phase-1 entries per workgroup (a tile is split into chunks)
 constexpr uint16_t PB_NULL = 0xFFFFu;
 constexpr uint16_t PB_FLAG = 0x8000u;
 constexpr float PB_FIX_SCALE = 4611686018427387904.0f;     // 2^62
@@ -58,6 +58,7 @@ struct PbPlan {
     uint64_t Mp = 0;       // padded length of the phase-1 stream
     uint64_t Mv = 0;       // padded length of the value stream
     uint32_t NW = 0;       // phase-1 workgroups
+    uint32_t chunk = 0;    // phase-1 entries per workgroup (multiple of 256)
     int device = 0;
     DevBuf p1_src;      // u16[Mp]   local source id | PB_FLAG on the first entry of a segment, PB_NULL = padding
     DevBuf chunk_seg;   // u32[Mp/256] segments started before each 256-entry wavefront block
@@ -68,6 +69,7 @@ struct PbPlan {
     DevBuf vals;        // f32[Mv]   per-edge values, bin-major, segments padded to 4
     DevBuf p2_dst;      // u16[Mv]   local row id inside the bin, PB_NULL = padding
     DevBuf bin_v;       // u32[B+1]  value range of each bin (multiples of 4)
+    DevBuf bin_order;   // u32[B]    bins by decreasing size (longest first)
     DevBuf bin_err;     // f64[B]
 };
 
@@ -221,23 +223,53 @@ __global__ void pb_bin_ranges_kernel(const uint32_t *__restrict__ bin_seg, const
 }
 
 // phase-1 workgroups: tile t is split into ceil(len / PB_BIN_CHUNK) chunks
-__global__ void pb_wg_count_kernel(const uint32_t *__restrict__ tile_p, uint32_t NT, uint32_t *__restrict__ wg_cnt)
+__global__ void pb_wg_count_kernel(const uint32_t *__restrict__ tile_p, uint32_t NT, uint32_t chunk,
+                                   uint32_t *__restrict__ wg_cnt)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t <= NT; t += stride)
-        wg_cnt[t] = t == NT ? 0u : (tile_p[t + 1] - tile_p[t] + PB_BIN_CHUNK - 1u) / PB_BIN_CHUNK;
+        wg_cnt[t] = t == NT ? 0u : (tile_p[t + 1] - tile_p[t] + chunk - 1u) / chunk;
 }
 
-__global__ void pb_wg_fill_kernel(const uint32_t *__restrict__ tile_p, const uint32_t *__restrict__ wg_first, uint32_t NT,
-                                  uint32_t *__restrict__ wg_tile, uint32_t *__restrict__ wg_p0)
+__global__ void pb_bin_sizes_kernel(const uint32_t *__restrict__ bin_v, uint32_t B, uint32_t *__restrict__ key,
+                                    uint32_t *__restrict__ val)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < NT; t += stride) {
-        const uint32_t w0 = wg_first[t], w1 = wg_first[t + 1];
-        for (uint32_t w = w0; w < w1; ++w) {
-            wg_tile[w] = t;
-            wg_p0[w] = tile_p[t] + (w - w0) * PB_BIN_CHUNK;
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += stride) {
+        key[b] = bin_v[b + 1] - bin_v[b];
+        val[b] = b;
+    }
+}
+
+// Launch slot s runs on XCD s % 8 (observed dispatch rule; used for speed only).  With xcd_aware the
+// slots of one XCD take consecutive work items (tile-major order), so the cache lines shared by the
+// adjacent segments of consecutive tiles in the value stream are completed inside one L2 instead of
+// leaving two partial write-backs.  slot -> item is a bijection: item = base[s % 8] + s / 8.
+__global__ void pb_wg_fill_kernel(const uint32_t *__restrict__ tile_p, const uint32_t *__restrict__ wg_first, uint32_t NT,
+                                  uint32_t PB_BIN_CHUNK, uint32_t NW, int xcd_aware, uint32_t *__restrict__ wg_tile,
+                                  uint32_t *__restrict__ wg_p0)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < NW; s += stride) {
+        uint32_t w = s;
+        if (xcd_aware) {
+            const uint32_t x = s & 7u;
+            uint32_t base = 0;
+            for (uint32_t y = 0; y < x; ++y)
+                base += (NW - y + 7u) / 8u;
+            w = base + (s >> 3);
         }
+        // tile of item w: last t with wg_first[t] <= w
+        uint32_t lo = 0, hi = NT;
+        while (hi - lo > 1) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (wg_first[mid] <= w)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        wg_tile[s] = lo;
+        wg_p0[s] = tile_p[lo] + (w - wg_first[lo]) * PB_BIN_CHUNK;
     }
 }
 
@@ -266,19 +298,27 @@ __global__ void pb_bounds_kernel(const uint64_t *__restrict__ keys, uint32_t cou
 }
 
 // ---- the sweep -----------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
 struct alignas(8) U16x4 {
     uint16_t a, b, c, d;
 };
 
+constexpr uint32_t PB_DCACHE = 4096; // segment deltas cached in LDS per workgroup (16 KiB)
+
+template <bool NT>
 __global__ __launch_bounds__(PB_BIN_BLOCK) void pb_bin_kernel(const float *__restrict__ x_in, uint64_t x_len,
                                                               const uint32_t *__restrict__ tile_p,
                                                               const uint32_t *__restrict__ wg_tile,
                                                               const uint32_t *__restrict__ wg_p0,
                                                               const uint16_t *__restrict__ p1_src,
                                                               const uint32_t *__restrict__ chunk_seg,
-                                                              const uint32_t *__restrict__ delta, float *__restrict__ vals)
+                                                              const uint32_t *__restrict__ delta, float *__restrict__ vals,
+                                                              uint32_t PB_BIN_CHUNK)
 {
-    extern __shared__ float xs[]; // PB_S floats
+    extern __shared__ float xs[];                                   // PB_S floats ...
+    uint32_t *dl = reinterpret_cast<uint32_t *>(xs + PB_S);         // ... + PB_DCACHE segment deltas
     const uint32_t tid = threadIdx.x;
     const uint32_t t = wg_tile[blockIdx.x];
     const uint32_t p_begin = wg_p0[blockIdx.x];
@@ -295,10 +335,17 @@ __global__ __launch_bounds__(PB_BIN_BLOCK) void pb_bin_kernel(const float *__res
         for (uint32_t i = tid; i < xn; i += PB_BIN_BLOCK)
             xs[i] = x_in[x0 + i];
     }
+    // segments this workgroup can touch: ranks [r_lo, r_hi)
+    const uint32_t cs_first = chunk_seg[p_begin / PB_WBLK];
+    const uint32_t r_lo = cs_first ? cs_first - 1u : 0u;
+    const uint32_t r_hi = chunk_seg[p_end / PB_WBLK];
+    const uint32_t r_cached = (r_hi - r_lo) < PB_DCACHE ? (r_hi - r_lo) : PB_DCACHE;
+    for (uint32_t i = tid; i < r_cached; i += PB_BIN_BLOCK)
+        dl[i] = delta[r_lo + i];
     __syncthreads();
     const uint32_t lane = tid & (kWave - 1);
     const uint64_t le_mask = (lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull);
-    constexpr int U = 4;
+    constexpr int U = 8;
     constexpr uint32_t STEP = PB_BIN_BLOCK * PB_VEC; // entries per workgroup step (4096)
     // every wavefront covers one aligned 256-entry block per step: lane l owns entries 4l..4l+3
     for (uint32_t p0 = p_begin + tid * PB_VEC; p0 < p_end; p0 += STEP * U) {
@@ -308,7 +355,13 @@ __global__ __launch_bounds__(PB_BIN_BLOCK) void pb_bin_kernel(const float *__res
         for (int k = 0; k < U; ++k) {
             const uint32_t p = p0 + k * STEP;
             const bool in = p < p_end; // uniform per wavefront: ranges are multiples of 256
-            v[k] = in ? *reinterpret_cast<const U16x4 *>(p1_src + p) : U16x4{PB_NULL, PB_NULL, PB_NULL, PB_NULL};
+            if (in) {
+                const u32x2 raw = NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(p1_src + p))
+                                     : *reinterpret_cast<const u32x2 *>(p1_src + p);
+                v[k] = U16x4{(uint16_t)raw.x, (uint16_t)(raw.x >> 16), (uint16_t)raw.y, (uint16_t)(raw.y >> 16)};
+            } else {
+                v[k] = U16x4{PB_NULL, PB_NULL, PB_NULL, PB_NULL};
+            }
             cs[k] = in ? chunk_seg[p / PB_WBLK] : 0u;
         }
 #pragma unroll
@@ -318,12 +371,18 @@ __global__ __launch_bounds__(PB_BIN_BLOCK) void pb_bin_kernel(const float *__res
             const uint64_t starts = __ballot(valid && (v[k].a & PB_FLAG));
             if (valid) {
                 const uint32_t rank = cs[k] + (uint32_t)__popcll(starts & le_mask) - 1u;
-                float4 o;
+                const uint32_t ri = rank - r_lo;
+                const uint32_t dlt = ri < PB_DCACHE ? dl[ri] : delta[rank];
+                f32x4 o;
                 o.x = xs[v[k].a & (PB_S - 1u)];
                 o.y = xs[v[k].b & (PB_S - 1u)];
                 o.z = xs[v[k].c & (PB_S - 1u)];
                 o.w = xs[v[k].d & (PB_S - 1u)];
-                *reinterpret_cast<float4 *>(vals + (p + delta[rank])) = o; // padding lanes write padding slots
+                // padding lanes write padding slots
+                if (NT)
+                    __builtin_nontemporal_store(o, reinterpret_cast<f32x4 *>(vals + (p + dlt)));
+                else
+                    *reinterpret_cast<f32x4 *>(vals + (p + dlt)) = o;
             }
         }
     }
@@ -334,16 +393,18 @@ __device__ __forceinline__ unsigned long long pb_to_fix(float x)
     return (unsigned long long)(x * PB_FIX_SCALE); // exact scaling by 2^62, truncation below 2^-62
 }
 
+template <bool NT>
 __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__restrict__ vals,
                                                                 const uint16_t *__restrict__ p2_dst,
                                                                 const uint32_t *__restrict__ bin_v,
+                                                                const uint32_t *__restrict__ bin_order,
                                                                 const uint32_t *__restrict__ outdeg, float *__restrict__ scores,
                                                                 float *__restrict__ x_out, double *__restrict__ bin_err,
                                                                 uint32_t n_local, uint32_t R, float base, float damping)
 {
     extern __shared__ unsigned long long acc[]; // R fixed-point sums
     __shared__ double red[PB_ACC_BLOCK / kWave];
-    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    const uint32_t b = bin_order[blockIdx.x], tid = threadIdx.x; // longest bins are dispatched first
     for (uint32_t i = tid; i < R; i += PB_ACC_BLOCK)
         acc[i] = 0ull;
     __syncthreads();
@@ -351,14 +412,17 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
     constexpr int U = 4;
     constexpr uint32_t STEP = PB_ACC_BLOCK * PB_VEC;
     for (uint32_t q0 = qb + tid * PB_VEC; q0 < qe; q0 += STEP * U) {
-        float4 v[U];
+        f32x4 v[U];
         U16x4 d[U];
 #pragma unroll
         for (int k = 0; k < U; ++k) {
             const uint32_t q = q0 + k * STEP;
             if (q < qe) {
-                v[k] = *reinterpret_cast<const float4 *>(vals + q);
-                d[k] = *reinterpret_cast<const U16x4 *>(p2_dst + q);
+                v[k] = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(vals + q))
+                          : *reinterpret_cast<const f32x4 *>(vals + q);
+                const u32x2 raw = NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(p2_dst + q))
+                                     : *reinterpret_cast<const u32x2 *>(p2_dst + q);
+                d[k] = U16x4{(uint16_t)raw.x, (uint16_t)(raw.x >> 16), (uint16_t)raw.y, (uint16_t)(raw.y >> 16)};
             } else {
                 d[k] = U16x4{PB_NULL, PB_NULL, PB_NULL, PB_NULL};
             }
@@ -399,6 +463,14 @@ __global__ __launch_bounds__(1024) void pb_err_kernel(const double *__restrict__
     const double total = block_sum<double, 1024 / kWave>(acc, red);
     if (threadIdx.x == 0)
         *err_out = total;
+}
+
+// tuning knobs (environment, read once): GM_PB_NT=0/1 streaming hints, GM_PB_CHUNK=<entries> phase-1
+// workgroup size (0 = automatic), GM_PB_ORDER=0/1 longest-bin-first dispatch, GM_PB_RB=<log2 rows per bin>
+int pb_env(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
 }
 
 unsigned pb_grid(uint64_t count)
@@ -479,6 +551,8 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
         rb = 8;
     if (rb > 14)
         rb = 14;
+    if (pb_env("GM_PB_RB", 0) >= 8 && pb_env("GM_PB_RB", 0) <= 14)
+        rb = pb_env("GM_PB_RB", 0);
     pl->rb = rb;
     pl->R = 1u << rb;
     pl->B = (uint32_t)(((uint64_t)n + pl->R - 1) >> rb);
@@ -492,6 +566,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     GM_CHECK(bin_bits + sb + rb <= 64, GM_ERR_RANGE, "pb_build: key does not fit 64 bits");
 
     GM_TRY(pl->bin_v.alloc(((size_t)pl->B + 1) * 4));
+    GM_TRY(pl->bin_order.alloc((size_t)pl->B * 4));
     GM_TRY(pl->bin_err.alloc((size_t)pl->B * 8));
     GM_TRY(pl->tile_p.alloc(((size_t)pl->NT + 1) * 4));
     if (m == 0) {
@@ -499,6 +574,13 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
         GM_TRY(pl->p2_dst.alloc(16));
         GM_HIP(hipMemset(pl->bin_v.p, 0, ((size_t)pl->B + 1) * 4));
         GM_HIP(hipMemset(pl->tile_p.p, 0, ((size_t)pl->NT + 1) * 4));
+        {
+            DevBuf key;
+            GM_TRY(key.alloc((size_t)pl->B * 4));
+            hipLaunchKernelGGL(pb_bin_sizes_kernel, dim3(pb_grid(pl->B)), dim3(256), 0, 0, pl->bin_v.as<uint32_t>(), pl->B,
+                               key.as<uint32_t>(), pl->bin_order.as<uint32_t>());
+            GM_HIP(hipDeviceSynchronize());
+        }
         pl->NW = 0;
         return GM_OK;
     }
@@ -597,14 +679,44 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
                        vstart.as<uint32_t>(), vstart4.as<uint32_t>(), rank_of.as<uint32_t>(), pstart.as<uint32_t>(), m, rb,
                        sb, pl->p1_src.as<uint16_t>(), pl->p2_dst.as<uint16_t>());
     hipLaunchKernelGGL(pb_chunk_seg_kernel, dim3(pb_grid(Mp / PB_WBLK + 1)), dim3(256), 0, 0, pstart.as<uint32_t>(), NS,
-                       Mp / PB_WBLK, pl->chunk_seg.as<uint32_t>());
+                       Mp / PB_WBLK + 1, pl->chunk_seg.as<uint32_t>());
     GM_HIP(hipGetLastError());
-    // phase-1 workgroup list
+    // accumulate longest bins first
+    {
+        DevBuf key, kalt2, valt2;
+        GM_TRY(key.alloc((size_t)pl->B * 4));
+        GM_TRY(kalt2.alloc((size_t)pl->B * 4));
+        GM_TRY(valt2.alloc((size_t)pl->B * 4));
+        hipLaunchKernelGGL(pb_bin_sizes_kernel, dim3(pb_grid(pl->B)), dim3(256), 0, 0, pl->bin_v.as<uint32_t>(), pl->B,
+                           key.as<uint32_t>(), pl->bin_order.as<uint32_t>());
+        GM_HIP(hipGetLastError());
+        rocprim::double_buffer<uint32_t> dk(key.as<uint32_t>(), kalt2.as<uint32_t>());
+        rocprim::double_buffer<uint32_t> dv(pl->bin_order.as<uint32_t>(), valt2.as<uint32_t>());
+        size_t tmp_bytes = 0;
+        GM_HIP(rocprim::radix_sort_pairs_desc(nullptr, tmp_bytes, dk, dv, pl->B, 0u, 32u, (hipStream_t)0));
+        DevBuf tmp;
+        GM_TRY(tmp.alloc(tmp_bytes));
+        GM_HIP(rocprim::radix_sort_pairs_desc(tmp.p, tmp_bytes, dk, dv, pl->B, 0u, 32u, (hipStream_t)0));
+        GM_HIP(hipDeviceSynchronize());
+        if (dv.current() != pl->bin_order.as<uint32_t>())
+            GM_HIP(hipMemcpy(pl->bin_order.p, dv.current(), (size_t)pl->B * 4, hipMemcpyDeviceToDevice));
+        if (!pb_env("GM_PB_ORDER", 1)) // natural order
+            hipLaunchKernelGGL(pb_bin_sizes_kernel, dim3(pb_grid(pl->B)), dim3(256), 0, 0, pl->bin_v.as<uint32_t>(), pl->B,
+                               key.as<uint32_t>(), pl->bin_order.as<uint32_t>());
+    }
+    // phase-1 workgroup list: a tile's stream is cut into chunks of 32768 entries (measured best on
+    // MI355X at scales 22-26: enough workgroups to hide latency, x-tile reloads stay in L2)
+    {
+        uint64_t chunk = 32768;
+        if (pb_env("GM_PB_CHUNK", 0) > 0)
+            chunk = ((uint64_t)pb_env("GM_PB_CHUNK", 0) + PB_WBLK - 1) & ~(uint64_t)(PB_WBLK - 1);
+        pl->chunk = (uint32_t)chunk;
+    }
     DevBuf wg_cnt, wg_first;
     GM_TRY(wg_cnt.alloc(((size_t)pl->NT + 1) * 4));
     GM_TRY(wg_first.alloc(((size_t)pl->NT + 1) * 4));
     hipLaunchKernelGGL(pb_wg_count_kernel, dim3(pb_grid((uint64_t)pl->NT + 1)), dim3(256), 0, 0, pl->tile_p.as<uint32_t>(),
-                       pl->NT, wg_cnt.as<uint32_t>());
+                       pl->NT, pl->chunk, wg_cnt.as<uint32_t>());
     GM_HIP(hipGetLastError());
     GM_TRY(scan_exclusive<uint32_t>(wg_cnt.as<uint32_t>(), wg_first.as<uint32_t>(), (uint64_t)pl->NT + 1));
     uint32_t NW = 0;
@@ -612,8 +724,9 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     pl->NW = NW;
     GM_TRY(pl->wg_tile.alloc((size_t)NW * 4));
     GM_TRY(pl->wg_p0.alloc((size_t)NW * 4));
-    hipLaunchKernelGGL(pb_wg_fill_kernel, dim3(pb_grid(pl->NT)), dim3(256), 0, 0, pl->tile_p.as<uint32_t>(),
-                       wg_first.as<uint32_t>(), pl->NT, pl->wg_tile.as<uint32_t>(), pl->wg_p0.as<uint32_t>());
+    hipLaunchKernelGGL(pb_wg_fill_kernel, dim3(pb_grid(NW)), dim3(256), 0, 0, pl->tile_p.as<uint32_t>(),
+                       wg_first.as<uint32_t>(), pl->NT, pl->chunk, NW, pb_env("GM_PB_XCD", 1), pl->wg_tile.as<uint32_t>(),
+                       pl->wg_p0.as<uint32_t>());
     GM_HIP(hipGetLastError());
     GM_HIP(hipDeviceSynchronize());
     return GM_OK;
@@ -630,11 +743,16 @@ int pb_plan_create(const gm_csr *csr, uint64_t x_len, PbPlan **out)
         delete pl;
         return rc;
     }
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pb_bin_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, PB_S * 4);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pb_accum_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (1 << 14) * 8);
+    hipError_t e = hipSuccess;
+    const void *bin_fns[2] = {reinterpret_cast<const void *>(&pb_bin_kernel<false>),
+                              reinterpret_cast<const void *>(&pb_bin_kernel<true>)};
+    const void *acc_fns[2] = {reinterpret_cast<const void *>(&pb_accum_kernel<false>),
+                              reinterpret_cast<const void *>(&pb_accum_kernel<true>)};
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipFuncSetAttribute(bin_fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, PB_S * 4 + PB_DCACHE * 4);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(acc_fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (1 << 14) * 8);
+    }
     if (e != hipSuccess) {
         set_error("pb_plan_create: %s", hipGetErrorString(e));
         delete pl;
@@ -651,14 +769,29 @@ uint64_t pb_work_items(const PbPlan *plan) { return plan ? (uint64_t)plan->NW + 
 int pb_sweep_main(PbPlan *pl, const float *x_in, float *x_out, float *scores, const uint32_t *outdeg, float base,
                   float damping, hipStream_t st)
 {
-    if (pl->NW)
-        hipLaunchKernelGGL(pb_bin_kernel, dim3(pl->NW), dim3(PB_BIN_BLOCK), PB_S * 4, st, x_in, pl->x_len,
-                           pl->tile_p.as<uint32_t>(), pl->wg_tile.as<uint32_t>(), pl->wg_p0.as<uint32_t>(),
-                           pl->p1_src.as<uint16_t>(), pl->chunk_seg.as<uint32_t>(), pl->delta.as<uint32_t>(),
-                           pl->vals.as<float>());
-    hipLaunchKernelGGL(pb_accum_kernel, dim3(pl->B), dim3(PB_ACC_BLOCK), (size_t)pl->R * 8, st, pl->vals.as<float>(),
-                       pl->p2_dst.as<uint16_t>(), pl->bin_v.as<uint32_t>(), outdeg, scores, x_out,
-                       pl->bin_err.as<double>(), pl->n_local, pl->R, base, damping);
+    static const int nt = pb_env("GM_PB_NT", 0); // measured: streaming hints cost 8-10 % here
+    if (pl->NW) {
+        if (nt)
+            hipLaunchKernelGGL(pb_bin_kernel<true>, dim3(pl->NW), dim3(PB_BIN_BLOCK), PB_S * 4 + PB_DCACHE * 4, st, x_in, pl->x_len,
+                               pl->tile_p.as<uint32_t>(), pl->wg_tile.as<uint32_t>(), pl->wg_p0.as<uint32_t>(),
+                               pl->p1_src.as<uint16_t>(), pl->chunk_seg.as<uint32_t>(), pl->delta.as<uint32_t>(),
+                               pl->vals.as<float>(), pl->chunk);
+        else
+            hipLaunchKernelGGL(pb_bin_kernel<false>, dim3(pl->NW), dim3(PB_BIN_BLOCK), PB_S * 4 + PB_DCACHE * 4, st, x_in, pl->x_len,
+                               pl->tile_p.as<uint32_t>(), pl->wg_tile.as<uint32_t>(), pl->wg_p0.as<uint32_t>(),
+                               pl->p1_src.as<uint16_t>(), pl->chunk_seg.as<uint32_t>(), pl->delta.as<uint32_t>(),
+                               pl->vals.as<float>(), pl->chunk);
+    }
+    if (nt)
+        hipLaunchKernelGGL(pb_accum_kernel<true>, dim3(pl->B), dim3(PB_ACC_BLOCK), (size_t)pl->R * 8, st,
+                           pl->vals.as<float>(), pl->p2_dst.as<uint16_t>(), pl->bin_v.as<uint32_t>(),
+                           pl->bin_order.as<uint32_t>(), outdeg, scores, x_out, pl->bin_err.as<double>(), pl->n_local,
+                           pl->R, base, damping);
+    else
+        hipLaunchKernelGGL(pb_accum_kernel<false>, dim3(pl->B), dim3(PB_ACC_BLOCK), (size_t)pl->R * 8, st,
+                           pl->vals.as<float>(), pl->p2_dst.as<uint16_t>(), pl->bin_v.as<uint32_t>(),
+                           pl->bin_order.as<uint32_t>(), outdeg, scores, x_out, pl->bin_err.as<double>(), pl->n_local,
+                           pl->R, base, damping);
     GM_HIP(hipGetLastError());
     return GM_OK;
 }
