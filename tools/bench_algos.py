@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""Timing + full-size property checks of the non-headline algorithms at BASELINE.json's configs:
+   RMAT scale-22 WCC (bit-exact vs the oracle), RMAT scale-24 weighted SSSP and triangle count."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--wcc-scale", type=int, default=22)
+    ap.add_argument("--sssp-scale", type=int, default=24)
+    ap.add_argument("--tc-scale", type=int, default=24)
+    ap.add_argument("--oracle", type=int, default=1)
+    ap.add_argument("--skip", default="")
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+
+    from graph_amd import synth
+    from graph_amd import prelude as P
+    from graph_amd._lib import check, lib, vp, u64
+
+    out = {}
+    dev = 0
+
+    def timed(fn, reps=3):
+        best = None
+        res = None
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            res = fn()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t
+            best = dt if best is None else min(best, dt)
+        return best, res
+
+    if "wcc" not in args.skip:
+        sc = args.wcc_scale
+        n = 1 << sc
+        src, dst = synth.rmat_edges(sc, 42)
+        g_out = synth.build_csr(n, src, dst, P.Direction.Outgoing, P.CsrLayout.Sorted)
+        g_in = synth.build_csr(n, src, dst, P.Direction.Incoming, P.CsrLayout.Sorted)
+        g = P.DirectedCsrGraph(g_out, g_in, P.CsrLayout.Sorted)
+        t_aff, comp = timed(lambda: P.wcc_afforest(g, P.WccConfig()).to_vec())
+        t_base, comp_b = timed(lambda: P.wcc_baseline(g).to_vec())
+        rec = {"scale": sc, "edges": int(src.numel()), "afforest_ms": t_aff * 1e3, "baseline_ms": t_base * 1e3,
+               "components": int(np.unique(comp).size), "afforest_eq_baseline": bool(np.array_equal(comp, comp_b)),
+               "edges_per_s_afforest": src.numel() / t_aff}
+        if args.oracle:
+            from oracle import oracle as O
+
+            ooff, otgt, _ = g_out.host()
+            ioff, itgt, _ = g_in.host()
+            t = time.perf_counter()
+            ref = O.wcc(ooff, otgt, ioff, itgt, O.AFFOREST)
+            rec["oracle_s"] = time.perf_counter() - t
+            rec["bit_exact_vs_oracle"] = bool(np.array_equal(ref, comp))
+        out["wcc"] = rec
+        del g, g_out, g_in, src, dst
+        torch.cuda.empty_cache()
+
+    if "sssp" not in args.skip:
+        sc = args.sssp_scale
+        n = 1 << sc
+        src, dst = synth.rmat_edges(sc, 42)
+        w = synth.rmat_weights(src.numel(), 44)
+        g_out = synth.build_csr(n, src, dst, P.Direction.Outgoing, P.CsrLayout.Sorted, w)
+        g = P.DirectedCsrGraph(g_out, g_out, P.CsrLayout.Sorted)
+        deg = g_out.degrees()
+        start = int(np.flatnonzero(deg > 0)[0])
+        t_s, dist = timed(lambda: P.delta_stepping(g, P.DeltaSteppingConfig(start, 0.1)), reps=2)
+        # fixed-point property on the device: d[v] <= d[u] (+) w for every edge, equality attained for every reached v
+        d = torch.from_numpy(dist).cuda()
+        off = torch.from_numpy(g_out.host()[0].astype(np.int64)).cuda()
+        tg = torch.from_numpy(g_out.host()[1].astype(np.int64)).cuda()
+        wv = torch.from_numpy(g_out.host()[2]).cuda()
+        su = torch.repeat_interleave(torch.arange(n, device="cuda"), off[1:] - off[:-1])
+        cand = d[su] + wv
+        reach = d[su] < 3.0e38
+        ok_le = bool((d[tg][reach] <= cand[reach]).all())
+        best = torch.full((n,), float("inf"), device="cuda")
+        best.scatter_reduce_(0, tg[reach], cand[reach], reduce="amin")
+        reached = (d < 3.0e38)
+        reached[start] = False
+        ok_eq = bool((best[reached] == d[reached]).all())
+        out["sssp"] = {"scale": sc, "edges": int(src.numel()), "ms": t_s * 1e3, "delta": 0.1, "start": start,
+                       "reached": int((dist < 3.0e38).sum()), "relaxed_edges_per_s": int(reach.sum()) / t_s,
+                       "fixed_point_le": ok_le, "fixed_point_attained": ok_eq}
+        del g, g_out, src, dst, w, d, off, tg, wv, su, cand, best
+        torch.cuda.empty_cache()
+
+    if "tc" not in args.skip:
+        sc = args.tc_scale
+        n = 1 << sc
+        src, dst = synth.rmat_edges(sc, 42)
+        t0 = time.perf_counter()
+        ug = P.UndirectedCsrGraph(synth.build_csr(n, src, dst, P.Direction.Undirected, P.CsrLayout.Deduplicated),
+                                  P.CsrLayout.Deduplicated)
+        t_build = time.perf_counter() - t0
+        del src, dst
+        t_plain, tri_plain = (None, None)
+        if sc <= 22:
+            t_plain, tri_plain = timed(lambda: P.global_triangle_count(ug), reps=1)
+        t0 = time.perf_counter()
+        P.relabel_graph(ug)
+        torch.cuda.synchronize()
+        t_relabel = time.perf_counter() - t0
+        t_tc, tri = timed(lambda: P.global_triangle_count(ug), reps=2)
+        out["tc"] = {"scale": sc, "undirected_entries": ug.csr.m, "build_s": t_build, "relabel_s": t_relabel,
+                     "tc_ms": t_tc * 1e3, "triangles": tri, "edges_per_s": ug.csr.m / 2 / t_tc,
+                     "tc_unrelabelled_ms": None if t_plain is None else t_plain * 1e3,
+                     "relabel_invariant": None if tri_plain is None else bool(tri_plain == tri)}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
