@@ -44,6 +44,9 @@ def parse_args():
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores (available_parallelism)")
     ap.add_argument("--relabel", type=int, default=0, help="(experimental) internal degree-ordered layout")
     ap.add_argument("--engine", choices=["auto", "pull", "pb"], default="auto")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
+                    "exercising the multi-rank path with several ranks on ONE device)")
+    ap.add_argument("--single-device", type=int, default=0, help="debug: all ranks use cuda:0 (needs --backend gloo)")
     return ap.parse_args()
 
 
@@ -68,11 +71,16 @@ def main():
                          f"--nproc-per-node {args.gpus}")
     if not torch.cuda.is_available() or graph_amd.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     scale, n = args.scale, 1 << args.scale
     t_build = time.time()

@@ -28,8 +28,10 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include <algorithm>
 #include <cstdlib>
 #include <utility>
+#include <vector>
 
 namespace gm {
 
@@ -47,6 +49,11 @@ constexpr float PB_FIX_SCALE = 4611686018427387904.0f;     // 2^62
 constexpr float PB_FIX_INV = 2.168404344971008868e-19f;    // 2^-62
 
 } // namespace
+
+struct PbItem {
+    uint32_t bin, q0, q1;          // value-stream range [q0, q1) of bin `bin`
+    uint32_t nparts, slot0, part;  // slices of this bin, first partial-accumulator slot of the bin, this slice
+};
 
 struct PbPlan {
     uint32_t n_local = 0, m = 0;
@@ -69,7 +76,10 @@ struct PbPlan {
     DevBuf vals;        // f32[Mv]   per-edge values, bin-major, segments padded to 4
     DevBuf p2_dst;      // u16[Mv]   local row id inside the bin, PB_NULL = padding
     DevBuf bin_v;       // u32[B+1]  value range of each bin (multiples of 4)
-    DevBuf bin_order;   // u32[B]    bins by decreasing size (longest first)
+    DevBuf items;       // PbItem[NI] accumulate work items (a bin, or a slice of an over-long bin), longest first
+    DevBuf partials;    // u64[parts of split bins x R] partial LDS accumulators of split bins
+    DevBuf tickets;     // u32[B]    arrival counters of split bins (self-resetting)
+    uint32_t NI = 0;    // accumulate workgroups
     DevBuf bin_err;     // f64[B]
 };
 
@@ -231,16 +241,6 @@ __global__ void pb_wg_count_kernel(const uint32_t *__restrict__ tile_p, uint32_t
         wg_cnt[t] = t == NT ? 0u : (tile_p[t + 1] - tile_p[t] + chunk - 1u) / chunk;
 }
 
-__global__ void pb_bin_sizes_kernel(const uint32_t *__restrict__ bin_v, uint32_t B, uint32_t *__restrict__ key,
-                                    uint32_t *__restrict__ val)
-{
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += stride) {
-        key[b] = bin_v[b + 1] - bin_v[b];
-        val[b] = b;
-    }
-}
-
 // Launch slot s runs on XCD s % 8 (observed dispatch rule; used for speed only).  With xcd_aware the
 // slots of one XCD take consecutive work items (tile-major order), so the cache lines shared by the
 // adjacent segments of consecutive tiles in the value stream are completed inside one L2 instead of
@@ -396,19 +396,21 @@ __device__ __forceinline__ unsigned long long pb_to_fix(float x)
 template <bool NT>
 __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__restrict__ vals,
                                                                 const uint16_t *__restrict__ p2_dst,
-                                                                const uint32_t *__restrict__ bin_v,
-                                                                const uint32_t *__restrict__ bin_order,
+                                                                const PbItem *__restrict__ items,
+                                                                unsigned long long *partials, uint32_t *tickets,
                                                                 const uint32_t *__restrict__ outdeg, float *__restrict__ scores,
                                                                 float *__restrict__ x_out, double *__restrict__ bin_err,
                                                                 uint32_t n_local, uint32_t R, float base, float damping)
 {
     extern __shared__ unsigned long long acc[]; // R fixed-point sums
     __shared__ double red[PB_ACC_BLOCK / kWave];
-    const uint32_t b = bin_order[blockIdx.x], tid = threadIdx.x; // longest bins are dispatched first
+    __shared__ bool is_last;
+    const PbItem item = items[blockIdx.x]; // longest items are dispatched first
+    const uint32_t b = item.bin, tid = threadIdx.x;
     for (uint32_t i = tid; i < R; i += PB_ACC_BLOCK)
         acc[i] = 0ull;
     __syncthreads();
-    const uint32_t qb = bin_v[b], qe = bin_v[b + 1]; // multiples of 4
+    const uint32_t qb = item.q0, qe = item.q1; // multiples of 4
     constexpr int U = 4;
     constexpr uint32_t STEP = PB_ACC_BLOCK * PB_VEC;
     for (uint32_t q0 = qb + tid * PB_VEC; q0 < qe; q0 += STEP * U) {
@@ -440,12 +442,41 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
         }
     }
     __syncthreads();
+    if (item.nparts > 1) {
+        // An over-long bin is accumulated by several workgroups; integer partial sums commute, so the
+        // last one to arrive adds them up and runs the epilogue.  Hand-off per the agent-scope
+        // release/acquire recipe (cdna_hip_programming.md, Guideline 16).
+        unsigned long long *mine = partials + (size_t)(item.slot0 + item.part) * R;
+        for (uint32_t i = tid; i < R; i += PB_ACC_BLOCK)
+            mine[i] = acc[i];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const uint32_t prev = atomicAdd(&tickets[b], 1u);
+            is_last = prev == item.nparts - 1u;
+            if (is_last) {
+                st_agent(&tickets[b], 0u); // ready for the next sweep
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+        }
+        __syncthreads();
+        if (!is_last)
+            return;
+    }
     double err = 0.0;
     const uint32_t r0 = b * R;
     for (uint32_t i = tid; i < R; i += PB_ACC_BLOCK) {
         const uint32_t r = r0 + i;
         if (r < n_local) {
-            const float incoming = (float)acc[i] * PB_FIX_INV; // one rounding: the exactly rounded row sum
+            unsigned long long sum = acc[i];
+            if (item.nparts > 1) { // slices of one bin own consecutive partial slots [slot0, slot0 + nparts)
+                sum = 0ull;
+                for (uint32_t k = 0; k < item.nparts; ++k)
+                    sum += partials[(size_t)(item.slot0 + k) * R + i];
+            }
+            const float incoming = (float)sum * PB_FIX_INV; // one rounding: the exactly rounded row sum
             err += pr_finalize(r, incoming, base, damping, outdeg, scores, x_out);
         }
     }
@@ -538,6 +569,50 @@ int sort_pairs_u64_u32(DevBuf &keys, DevBuf &kalt, DevBuf &vals, DevBuf &valt, u
     return GM_OK;
 }
 
+// Accumulate work items: one per bin, except that a bin more than twice the average size (a range of
+// rows that attracts a large share of the edges, e.g. degree-sorted ids) is cut into slices so that no
+// workgroup streams more than ~2x the average; longest first.  Built on the host from the B+1 bin
+// boundaries (a few KiB).
+int pb_make_items(PbPlan *pl)
+{
+    std::vector<uint32_t> bv((size_t)pl->B + 1);
+    GM_HIP(hipMemcpy(bv.data(), pl->bin_v.p, bv.size() * 4, hipMemcpyDeviceToHost));
+    const uint64_t total = bv[pl->B];
+    uint64_t limit = 2 * (total / pl->B + 1);
+    if (limit < 65536)
+        limit = 65536;
+    if (pb_env("GM_PB_SPLIT", 0) > 0)
+        limit = (uint64_t)pb_env("GM_PB_SPLIT", 0);
+    limit = (limit + 3) & ~3ull;
+    std::vector<PbItem> items;
+    uint32_t slots = 0;
+    for (uint32_t b = 0; b < pl->B; ++b) {
+        const uint32_t q0 = bv[b], q1 = bv[b + 1];
+        const uint32_t len = q1 - q0;
+        const uint32_t parts = len > limit ? (uint32_t)((len + limit - 1) / limit) : 1u;
+        if (parts == 1) {
+            items.push_back(PbItem{b, q0, q1, 1u, 0u, 0u});
+            continue;
+        }
+        uint32_t per = ((len + parts - 1) / parts + 3u) & ~3u;
+        for (uint32_t k = 0; k < parts; ++k) {
+            const uint32_t s = q0 + k * per, e = (q1 - s) < per ? q1 : s + per;
+            items.push_back(PbItem{b, s < q1 ? s : q1, s < q1 ? e : q1, parts, slots, k});
+        }
+        slots += parts;
+    }
+    if (pb_env("GM_PB_ORDER", 1))
+        std::stable_sort(items.begin(), items.end(),
+                         [](const PbItem &a, const PbItem &c) { return (a.q1 - a.q0) > (c.q1 - c.q0); });
+    pl->NI = (uint32_t)items.size();
+    GM_TRY(pl->items.alloc(items.size() * sizeof(PbItem)));
+    GM_HIP(hipMemcpy(pl->items.p, items.data(), items.size() * sizeof(PbItem), hipMemcpyHostToDevice));
+    GM_TRY(pl->partials.alloc((size_t)(slots ? slots : 1) * pl->R * 8));
+    GM_TRY(pl->tickets.alloc((size_t)pl->B * 4));
+    GM_HIP(hipMemset(pl->tickets.p, 0, (size_t)pl->B * 4));
+    return GM_OK;
+}
+
 int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
 {
     const uint32_t n = (uint32_t)csr->n, m = (uint32_t)csr->m;
@@ -566,7 +641,6 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     GM_CHECK(bin_bits + sb + rb <= 64, GM_ERR_RANGE, "pb_build: key does not fit 64 bits");
 
     GM_TRY(pl->bin_v.alloc(((size_t)pl->B + 1) * 4));
-    GM_TRY(pl->bin_order.alloc((size_t)pl->B * 4));
     GM_TRY(pl->bin_err.alloc((size_t)pl->B * 8));
     GM_TRY(pl->tile_p.alloc(((size_t)pl->NT + 1) * 4));
     if (m == 0) {
@@ -574,13 +648,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
         GM_TRY(pl->p2_dst.alloc(16));
         GM_HIP(hipMemset(pl->bin_v.p, 0, ((size_t)pl->B + 1) * 4));
         GM_HIP(hipMemset(pl->tile_p.p, 0, ((size_t)pl->NT + 1) * 4));
-        {
-            DevBuf key;
-            GM_TRY(key.alloc((size_t)pl->B * 4));
-            hipLaunchKernelGGL(pb_bin_sizes_kernel, dim3(pb_grid(pl->B)), dim3(256), 0, 0, pl->bin_v.as<uint32_t>(), pl->B,
-                               key.as<uint32_t>(), pl->bin_order.as<uint32_t>());
-            GM_HIP(hipDeviceSynchronize());
-        }
+        GM_TRY(pb_make_items(pl));
         pl->NW = 0;
         return GM_OK;
     }
@@ -681,29 +749,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     hipLaunchKernelGGL(pb_chunk_seg_kernel, dim3(pb_grid(Mp / PB_WBLK + 1)), dim3(256), 0, 0, pstart.as<uint32_t>(), NS,
                        Mp / PB_WBLK + 1, pl->chunk_seg.as<uint32_t>());
     GM_HIP(hipGetLastError());
-    // accumulate longest bins first
-    {
-        DevBuf key, kalt2, valt2;
-        GM_TRY(key.alloc((size_t)pl->B * 4));
-        GM_TRY(kalt2.alloc((size_t)pl->B * 4));
-        GM_TRY(valt2.alloc((size_t)pl->B * 4));
-        hipLaunchKernelGGL(pb_bin_sizes_kernel, dim3(pb_grid(pl->B)), dim3(256), 0, 0, pl->bin_v.as<uint32_t>(), pl->B,
-                           key.as<uint32_t>(), pl->bin_order.as<uint32_t>());
-        GM_HIP(hipGetLastError());
-        rocprim::double_buffer<uint32_t> dk(key.as<uint32_t>(), kalt2.as<uint32_t>());
-        rocprim::double_buffer<uint32_t> dv(pl->bin_order.as<uint32_t>(), valt2.as<uint32_t>());
-        size_t tmp_bytes = 0;
-        GM_HIP(rocprim::radix_sort_pairs_desc(nullptr, tmp_bytes, dk, dv, pl->B, 0u, 32u, (hipStream_t)0));
-        DevBuf tmp;
-        GM_TRY(tmp.alloc(tmp_bytes));
-        GM_HIP(rocprim::radix_sort_pairs_desc(tmp.p, tmp_bytes, dk, dv, pl->B, 0u, 32u, (hipStream_t)0));
-        GM_HIP(hipDeviceSynchronize());
-        if (dv.current() != pl->bin_order.as<uint32_t>())
-            GM_HIP(hipMemcpy(pl->bin_order.p, dv.current(), (size_t)pl->B * 4, hipMemcpyDeviceToDevice));
-        if (!pb_env("GM_PB_ORDER", 1)) // natural order
-            hipLaunchKernelGGL(pb_bin_sizes_kernel, dim3(pb_grid(pl->B)), dim3(256), 0, 0, pl->bin_v.as<uint32_t>(), pl->B,
-                               key.as<uint32_t>(), pl->bin_order.as<uint32_t>());
-    }
+    GM_TRY(pb_make_items(pl));
     // phase-1 workgroup list: a tile's stream is cut into chunks of 32768 entries (measured best on
     // MI355X at scales 22-26: enough workgroups to hide latency, x-tile reloads stay in L2)
     {
@@ -764,7 +810,7 @@ int pb_plan_create(const gm_csr *csr, uint64_t x_len, PbPlan **out)
 
 void pb_plan_destroy(PbPlan *plan) { delete plan; }
 
-uint64_t pb_work_items(const PbPlan *plan) { return plan ? (uint64_t)plan->NW + plan->B : 0; }
+uint64_t pb_work_items(const PbPlan *plan) { return plan ? (uint64_t)plan->NW + plan->NI : 0; }
 
 int pb_sweep_main(PbPlan *pl, const float *x_in, float *x_out, float *scores, const uint32_t *outdeg, float base,
                   float damping, hipStream_t st)
@@ -783,15 +829,15 @@ int pb_sweep_main(PbPlan *pl, const float *x_in, float *x_out, float *scores, co
                                pl->vals.as<float>(), pl->chunk);
     }
     if (nt)
-        hipLaunchKernelGGL(pb_accum_kernel<true>, dim3(pl->B), dim3(PB_ACC_BLOCK), (size_t)pl->R * 8, st,
-                           pl->vals.as<float>(), pl->p2_dst.as<uint16_t>(), pl->bin_v.as<uint32_t>(),
-                           pl->bin_order.as<uint32_t>(), outdeg, scores, x_out, pl->bin_err.as<double>(), pl->n_local,
-                           pl->R, base, damping);
+        hipLaunchKernelGGL(pb_accum_kernel<true>, dim3(pl->NI), dim3(PB_ACC_BLOCK), (size_t)pl->R * 8, st,
+                           pl->vals.as<float>(), pl->p2_dst.as<uint16_t>(), pl->items.as<PbItem>(),
+                           pl->partials.as<unsigned long long>(), pl->tickets.as<uint32_t>(), outdeg, scores, x_out,
+                           pl->bin_err.as<double>(), pl->n_local, pl->R, base, damping);
     else
-        hipLaunchKernelGGL(pb_accum_kernel<false>, dim3(pl->B), dim3(PB_ACC_BLOCK), (size_t)pl->R * 8, st,
-                           pl->vals.as<float>(), pl->p2_dst.as<uint16_t>(), pl->bin_v.as<uint32_t>(),
-                           pl->bin_order.as<uint32_t>(), outdeg, scores, x_out, pl->bin_err.as<double>(), pl->n_local,
-                           pl->R, base, damping);
+        hipLaunchKernelGGL(pb_accum_kernel<false>, dim3(pl->NI), dim3(PB_ACC_BLOCK), (size_t)pl->R * 8, st,
+                           pl->vals.as<float>(), pl->p2_dst.as<uint16_t>(), pl->items.as<PbItem>(),
+                           pl->partials.as<unsigned long long>(), pl->tickets.as<uint32_t>(), outdeg, scores, x_out,
+                           pl->bin_err.as<double>(), pl->n_local, pl->R, base, damping);
     GM_HIP(hipGetLastError());
     return GM_OK;
 }

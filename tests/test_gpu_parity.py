@@ -488,3 +488,26 @@ def test_partitioned_engines_on_one_device_match_single_engine(P, oracle):
             assert torch.equal(got, sc)  # exact row sums: identical for any partition
         else:
             torch.testing.assert_close(got, sc, rtol=2e-6, atol=0)
+
+
+def test_page_rank_pb_split_bins(P, oracle, monkeypatch):
+    """Over-long destination bins (ids sorted by in-degree put all hubs into bin 0) are accumulated by
+    several workgroups whose integer partial sums are merged by the last arrival: same exact result."""
+    s, d = oracle.rmat_edges(16, seed=42)
+    n = 1 << 16
+    indeg = np.bincount(d, minlength=n)
+    order = np.argsort(-indeg, kind="stable")
+    new_id = np.empty(n, np.uint32)
+    new_id[order] = np.arange(n, dtype=np.uint32)
+    s2, d2 = new_id[s], new_id[d]
+    g = _directed(P, n, s2, d2, P.CsrLayout.Sorted)
+    (_, _), (ioff, itgt) = _oracle_directed(oracle, n, s2, d2, oracle.SORTED)
+    od = oracle.out_degrees_from(n, s2)
+    ref_scores, ref_err = _jacobi_reference(ioff, itgt, od, 3)
+    whole = P.page_rank(g, P.PageRankConfig(3, 0.0, 0.85), P.PageRankMode.JacobiPB)
+    monkeypatch.setenv("GM_PB_SPLIT", "4096")  # force many slices per bin
+    split = P.page_rank(g, P.PageRankConfig(3, 0.0, 0.85), P.PageRankMode.JacobiPB)
+    assert np.array_equal(whole[0], split[0]) and abs(whole[2] - split[2]) <= 1e-12 * whole[2]
+    np.testing.assert_allclose(split[0], ref_scores, rtol=1.5e-7, atol=0)
+    again = P.page_rank(g, P.PageRankConfig(3, 0.0, 0.85), P.PageRankMode.JacobiPB)
+    assert np.array_equal(split[0], again[0])
