@@ -179,6 +179,8 @@ def main():
         seconds = float(tt.item())
     tile_ms = [a.elapsed_time(b) for a, b in evs]
     tile_ms_avg = sum(tile_ms) / max(len(tile_ms), 1)
+    if world > 1:
+        dist.all_reduce(err, op=dist.ReduceOp.SUM)
     final_err = float(err.item())
 
     ms_per_step = seconds * 1e3 / max(args.steps, 1)
