@@ -52,6 +52,7 @@ constexpr float PB_FIX_INV = 2.168404344971008868e-19f;    // 2^-62
 
 struct PbItem {
     uint32_t bin, q0, q1;          // value-stream range [q0, q1) of bin `bin`
+    uint32_t h0, h1;               // hot-edge range of this item
     uint32_t nparts, slot0, part;  // slices of this bin, first partial-accumulator slot of the bin, this slice
 };
 
@@ -80,6 +81,14 @@ struct PbPlan {
     DevBuf partials;    // u64[parts of split bins x R] partial LDS accumulators of split bins
     DevBuf tickets;     // u32[B]    arrival counters of split bins (self-resetting)
     uint32_t NI = 0;    // accumulate workgroups
+    // hot sources: the H most frequent sources of this rank's edges skip the value stream; their
+    // out_scores are staged in LDS by the accumulate kernel and gathered there
+    uint32_t H = 0;     // hot sources (0 = feature off)
+    DevBuf hot_ids;     // u32[H]   x index of each hot source
+    DevBuf hot_x;       // f32[H]   their out_scores, refreshed every sweep
+    DevBuf hot_ent;     // u32[Mh]  hot edges, bin-major: row_in_bin << 16 | hot index; 0xFFFFFFFF = padding
+    DevBuf hbin_v;      // u32[B+1] hot-edge range of each bin (multiples of 4)
+    uint64_t Mh = 0;
     DevBuf bin_err;     // f64[B]
 };
 
@@ -87,8 +96,77 @@ namespace {
 
 // ---- plan construction ---------------------------------------------------------------------------
 // key = bin << (sb + rb) | src << rb | row_in_bin      (sorted ascending = bin-major, then source, then row)
+constexpr uint64_t PB_HOT_KEY = 1ull << 63; // hot-edge keys sort behind every cold key
+// hot key: PB_HOT_KEY | bin << 32 | hot index << 16 | row_in_bin
+__device__ __forceinline__ uint64_t pb_make_key(uint64_t hi_cold, uint32_t r, uint32_t src, int rb,
+                                                const uint16_t *__restrict__ hot_rank)
+{
+    if (hot_rank) {
+        const uint16_t h = hot_rank[src];
+        if (h != PB_NULL)
+            return PB_HOT_KEY | ((uint64_t)(r >> rb) << 32) | ((uint64_t)h << 16) | (r & ((1u << rb) - 1u));
+    }
+    return hi_cold | ((uint64_t)src << rb);
+}
+
+__global__ void pb_count_sources_kernel(const uint32_t *__restrict__ tgt, uint32_t m, uint32_t *__restrict__ cnt)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride)
+        atomicAdd(&cnt[tgt[i]], 1u);
+}
+
+__global__ void pb_count_keys_kernel(const uint32_t *__restrict__ cnt, uint32_t x_len, uint64_t *__restrict__ keys)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < x_len; i += stride)
+        keys[i] = ((uint64_t)cnt[i] << 32) | i;
+}
+
+// sorted descending by (count, id): the first H entries with count >= 2 become hot
+__global__ void pb_hot_select_kernel(const uint64_t *__restrict__ sorted, uint32_t H, uint32_t *__restrict__ hot_ids,
+                                     uint16_t *__restrict__ hot_rank, uint32_t *__restrict__ h_eff)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= H)
+        return;
+    const uint64_t e = sorted[k];
+    if ((uint32_t)(e >> 32) >= 2u) {
+        hot_ids[k] = (uint32_t)e;
+        hot_rank[(uint32_t)e] = (uint16_t)k;
+        atomicMax(h_eff, k + 1u);
+    }
+}
+
+__global__ void pb_hot_fill_kernel(const uint64_t *__restrict__ hkeys, uint32_t mh, const uint32_t *__restrict__ hstart,
+                                   const uint32_t *__restrict__ hbin_v, uint32_t *__restrict__ hot_ent)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < mh; i += stride) {
+        const uint64_t k = hkeys[i];
+        const uint32_t bin = (uint32_t)((k >> 32) & 0x7FFFFFFFu);
+        hot_ent[hbin_v[bin] + (i - hstart[bin])] = ((uint32_t)k & 0xFFFFu) << 16 | (uint32_t)((k >> 16) & 0xFFFFu);
+    }
+}
+
+__global__ void pb_pad4_sizes_kernel(const uint32_t *__restrict__ start, uint32_t count, uint32_t *__restrict__ padded)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b <= count; b += stride)
+        padded[b] = b == count ? 0u : ((start[b + 1] - start[b] + 3u) & ~3u);
+}
+
+__global__ void pb_hot_gather_kernel(const float *__restrict__ x_in, const uint32_t *__restrict__ hot_ids, uint32_t H,
+                                     float *__restrict__ hot_x)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < H)
+        hot_x[k] = x_in[hot_ids[k]];
+}
+
 __global__ __launch_bounds__(256) void pb_keys_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt,
-                                                      uint32_t n, int rb, int sb, uint64_t *__restrict__ keys)
+                                                      uint32_t n, int rb, int sb, const uint16_t *__restrict__ hot_rank,
+                                                      uint64_t *__restrict__ keys)
 {
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -104,15 +182,16 @@ __global__ __launch_bounds__(256) void pb_keys_kernel(const uint32_t *__restrict
         const uint32_t len = e - s;
         if (len <= 32)
             for (uint32_t i = s; i < e; ++i)
-                keys[i] = hi | ((uint64_t)tgt[i] << rb);
+                keys[i] = pb_make_key(hi, r, tgt[i], rb, hot_rank);
         uint64_t big = __ballot(len > 32);
         while (big) {
             const int src = __ffsll((unsigned long long)big) - 1;
             big &= big - 1;
             const uint32_t bs = __shfl(s, src, kWave), be = __shfl(e, src, kWave);
             const uint64_t bhi = __shfl(hi, src, kWave);
+            const uint32_t br = __shfl(r, src, kWave);
             for (uint32_t i = bs + lane; i < be; i += kWave)
-                keys[i] = bhi | ((uint64_t)tgt[i] << rb);
+                keys[i] = pb_make_key(bhi, br, tgt[i], rb, hot_rank);
         }
     }
 }
@@ -286,12 +365,12 @@ __global__ void pb_chunk_seg_kernel(const uint32_t *__restrict__ pstart, uint32_
 
 // boundaries of a sorted u64 key array after a shift: out[v] = first index whose key >> shift is >= v
 __global__ void pb_bounds_kernel(const uint64_t *__restrict__ keys, uint32_t count, int shift, uint32_t nvals,
-                                 uint32_t *__restrict__ out)
+                                 uint32_t *__restrict__ out, uint32_t mask = 0xFFFFFFFFu)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= count; i += stride) {
-        const uint32_t lo = i == 0 ? 0u : (uint32_t)(keys[i - 1] >> shift) + 1u;
-        const uint32_t hi = i == count ? nvals : (uint32_t)(keys[i] >> shift);
+        const uint32_t lo = i == 0 ? 0u : ((uint32_t)(keys[i - 1] >> shift) & mask) + 1u;
+        const uint32_t hi = i == count ? nvals : ((uint32_t)(keys[i] >> shift) & mask);
         for (uint32_t v = lo; v <= hi; ++v)
             out[v] = i;
     }
@@ -397,6 +476,8 @@ template <bool NT>
 __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__restrict__ vals,
                                                                 const uint16_t *__restrict__ p2_dst,
                                                                 const PbItem *__restrict__ items,
+                                                                const uint32_t *__restrict__ hot_ent,
+                                                                const float *__restrict__ hot_x, uint32_t H,
                                                                 unsigned long long *partials, uint32_t *tickets,
                                                                 const uint32_t *__restrict__ outdeg, float *__restrict__ scores,
                                                                 float *__restrict__ x_out, double *__restrict__ bin_err,
@@ -407,8 +488,12 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
     __shared__ bool is_last;
     const PbItem item = items[blockIdx.x]; // longest items are dispatched first
     const uint32_t b = item.bin, tid = threadIdx.x;
+    float *hot = reinterpret_cast<float *>(acc + R); // H out_scores of the hot sources
     for (uint32_t i = tid; i < R; i += PB_ACC_BLOCK)
         acc[i] = 0ull;
+    if (item.h1 > item.h0)
+        for (uint32_t i = tid; i < H; i += PB_ACC_BLOCK)
+            hot[i] = hot_x[i];
     __syncthreads();
     const uint32_t qb = item.q0, qe = item.q1; // multiples of 4
     constexpr int U = 4;
@@ -440,6 +525,18 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
             if (d[k].d != PB_NULL)
                 atomicAdd(&acc[d[k].d], pb_to_fix(v[k].w));
         }
+    }
+    // hot edges: 4 bytes each (row_in_bin << 16 | hot index), the value comes from the LDS table
+    for (uint32_t h0 = item.h0 + tid * PB_VEC; h0 < item.h1; h0 += PB_ACC_BLOCK * PB_VEC) {
+        const uint4 e = *reinterpret_cast<const uint4 *>(hot_ent + h0);
+        if (e.x != 0xFFFFFFFFu)
+            atomicAdd(&acc[e.x >> 16], pb_to_fix(hot[e.x & 0xFFFFu]));
+        if (e.y != 0xFFFFFFFFu)
+            atomicAdd(&acc[e.y >> 16], pb_to_fix(hot[e.y & 0xFFFFu]));
+        if (e.z != 0xFFFFFFFFu)
+            atomicAdd(&acc[e.z >> 16], pb_to_fix(hot[e.z & 0xFFFFu]));
+        if (e.w != 0xFFFFFFFFu)
+            atomicAdd(&acc[e.w >> 16], pb_to_fix(hot[e.w & 0xFFFFu]));
     }
     __syncthreads();
     if (item.nparts > 1) {
@@ -575,9 +672,11 @@ int sort_pairs_u64_u32(DevBuf &keys, DevBuf &kalt, DevBuf &vals, DevBuf &valt, u
 // boundaries (a few KiB).
 int pb_make_items(PbPlan *pl)
 {
-    std::vector<uint32_t> bv((size_t)pl->B + 1);
+    std::vector<uint32_t> bv((size_t)pl->B + 1), hv((size_t)pl->B + 1, 0u);
     GM_HIP(hipMemcpy(bv.data(), pl->bin_v.p, bv.size() * 4, hipMemcpyDeviceToHost));
-    const uint64_t total = bv[pl->B];
+    if (pl->H)
+        GM_HIP(hipMemcpy(hv.data(), pl->hbin_v.p, hv.size() * 4, hipMemcpyDeviceToHost));
+    const uint64_t total = (uint64_t)bv[pl->B] + hv[pl->B];
     uint64_t limit = 2 * (total / pl->B + 1);
     if (limit < 65536)
         limit = 65536;
@@ -587,23 +686,31 @@ int pb_make_items(PbPlan *pl)
     std::vector<PbItem> items;
     uint32_t slots = 0;
     for (uint32_t b = 0; b < pl->B; ++b) {
-        const uint32_t q0 = bv[b], q1 = bv[b + 1];
-        const uint32_t len = q1 - q0;
+        const uint32_t q0 = bv[b], q1 = bv[b + 1], g0 = hv[b], g1 = hv[b + 1];
+        const uint64_t len = (uint64_t)(q1 - q0) + (g1 - g0);
         const uint32_t parts = len > limit ? (uint32_t)((len + limit - 1) / limit) : 1u;
         if (parts == 1) {
-            items.push_back(PbItem{b, q0, q1, 1u, 0u, 0u});
+            items.push_back(PbItem{b, q0, q1, g0, g1, 1u, 0u, 0u});
             continue;
         }
-        uint32_t per = ((len + parts - 1) / parts + 3u) & ~3u;
+        const uint32_t per = (((q1 - q0) + parts - 1) / parts + 3u) & ~3u;
+        const uint32_t hper = (((g1 - g0) + parts - 1) / parts + 3u) & ~3u;
         for (uint32_t k = 0; k < parts; ++k) {
-            const uint32_t s = q0 + k * per, e = (q1 - s) < per ? q1 : s + per;
-            items.push_back(PbItem{b, s < q1 ? s : q1, s < q1 ? e : q1, parts, slots, k});
+            uint64_t s = (uint64_t)q0 + (uint64_t)k * per, e = s + per;
+            uint64_t hs = (uint64_t)g0 + (uint64_t)k * hper, he = hs + hper;
+            s = s < q1 ? s : q1;
+            e = e < q1 ? e : q1;
+            hs = hs < g1 ? hs : g1;
+            he = he < g1 ? he : g1;
+            items.push_back(PbItem{b, (uint32_t)s, (uint32_t)e, (uint32_t)hs, (uint32_t)he, parts, slots, k});
         }
         slots += parts;
     }
     if (pb_env("GM_PB_ORDER", 1))
         std::stable_sort(items.begin(), items.end(),
-                         [](const PbItem &a, const PbItem &c) { return (a.q1 - a.q0) > (c.q1 - c.q0); });
+                         [](const PbItem &a, const PbItem &c) {
+                             return (uint64_t)(a.q1 - a.q0) + (a.h1 - a.h0) > (uint64_t)(c.q1 - c.q0) + (c.h1 - c.h0);
+                         });
     pl->NI = (uint32_t)items.size();
     GM_TRY(pl->items.alloc(items.size() * sizeof(PbItem)));
     GM_HIP(hipMemcpy(pl->items.p, items.data(), items.size() * sizeof(PbItem), hipMemcpyHostToDevice));
@@ -615,9 +722,10 @@ int pb_make_items(PbPlan *pl)
 
 int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
 {
-    const uint32_t n = (uint32_t)csr->n, m = (uint32_t)csr->m;
+    const uint32_t n = (uint32_t)csr->n, m_all = (uint32_t)csr->m;
+    uint32_t m = m_all; // becomes the number of cold (value-stream) edges once the hot ones are split off
     pl->n_local = n;
-    pl->m = m;
+    pl->m = m_all;
     pl->x_len = x_len;
     pl->device = csr->device;
     // rows per bin: keep >= ~2048 bins so the accumulate kernel fills the chip, cap the LDS slice at 128 KiB
@@ -638,12 +746,120 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
         pl->NT = 1;
     const int sb = bits_for(x_len) < 1 ? 1 : bits_for(x_len);
     const int bin_bits = bits_for(pl->B) < 1 ? 1 : bits_for(pl->B);
-    GM_CHECK(bin_bits + sb + rb <= 64, GM_ERR_RANGE, "pb_build: key does not fit 64 bits");
+    GM_CHECK(bin_bits + sb + rb <= 63, GM_ERR_RANGE, "pb_build: key does not fit 63 bits");
+
+    // hot table size: what is left of the LDS beside the accumulators (2 workgroups per CU when the
+    // accumulators are <= 64 KiB, else 1)
+    uint32_t H = 0;
+    {
+        const size_t acc_bytes = (size_t)pl->R * 8;
+        const size_t budget = acc_bytes > 65536 ? (163840 - 512 - acc_bytes) : (81920 - 512 - acc_bytes);
+        H = (uint32_t)(budget / 4) & ~63u;
+        if (H > 32768)
+            H = 32768;
+        const int cap = pb_env("GM_PB_HOT", -1);
+        if (cap >= 0 && (uint32_t)cap < H)
+            H = (uint32_t)cap & ~63u;
+    }
 
     GM_TRY(pl->bin_v.alloc(((size_t)pl->B + 1) * 4));
+    GM_TRY(pl->hbin_v.alloc(((size_t)pl->B + 1) * 4));
     GM_TRY(pl->bin_err.alloc((size_t)pl->B * 8));
     GM_TRY(pl->tile_p.alloc(((size_t)pl->NT + 1) * 4));
-    if (m == 0) {
+    GM_HIP(hipMemset(pl->hbin_v.p, 0, ((size_t)pl->B + 1) * 4));
+    GM_TRY(pl->hot_ent.alloc(16));
+    GM_TRY(pl->hot_x.alloc((size_t)(H ? H : 1) * 4));
+    GM_TRY(pl->hot_ids.alloc((size_t)(H ? H : 1) * 4));
+    if (m_all == 0) {
+        GM_TRY(pl->vals.alloc(16));
+        GM_TRY(pl->p2_dst.alloc(16));
+        GM_HIP(hipMemset(pl->bin_v.p, 0, ((size_t)pl->B + 1) * 4));
+        GM_HIP(hipMemset(pl->tile_p.p, 0, ((size_t)pl->NT + 1) * 4));
+        pl->H = 0;
+        GM_TRY(pb_make_items(pl));
+        pl->NW = 0;
+        return GM_OK;
+    }
+
+    // ---- hot sources: the H most frequent source ids (>= 2 edges) of this rank's edges ----------------
+    DevBuf hot_rank;
+    if (H) {
+        DevBuf cnt, ckeys, calt, heff;
+        GM_TRY(cnt.alloc((size_t)x_len * 4));
+        GM_TRY(ckeys.alloc((size_t)x_len * 8));
+        GM_TRY(calt.alloc((size_t)x_len * 8));
+        GM_TRY(heff.alloc(4));
+        GM_TRY(hot_rank.alloc((size_t)x_len * 2));
+        GM_HIP(hipMemset(cnt.p, 0, (size_t)x_len * 4));
+        GM_HIP(hipMemset(heff.p, 0, 4));
+        GM_HIP(hipMemset(hot_rank.p, 0xFF, (size_t)x_len * 2));
+        hipLaunchKernelGGL(pb_count_sources_kernel, dim3(pb_grid(m_all)), dim3(256), 0, 0, csr->targets, m_all,
+                           cnt.as<uint32_t>());
+        hipLaunchKernelGGL(pb_count_keys_kernel, dim3(pb_grid(x_len)), dim3(256), 0, 0, cnt.as<uint32_t>(), (uint32_t)x_len,
+                           ckeys.as<uint64_t>());
+        GM_HIP(hipGetLastError());
+        {
+            rocprim::double_buffer<uint64_t> db(ckeys.as<uint64_t>(), calt.as<uint64_t>());
+            size_t tmp_bytes = 0;
+            GM_HIP(rocprim::radix_sort_keys_desc(nullptr, tmp_bytes, db, x_len, 0u, 64u, (hipStream_t)0));
+            DevBuf tmp;
+            GM_TRY(tmp.alloc(tmp_bytes));
+            GM_HIP(rocprim::radix_sort_keys_desc(tmp.p, tmp_bytes, db, x_len, 0u, 64u, (hipStream_t)0));
+            GM_HIP(hipDeviceSynchronize());
+            if (db.current() != ckeys.as<uint64_t>())
+                std::swap(ckeys, calt);
+        }
+        const uint32_t h_try = H < x_len ? H : (uint32_t)x_len;
+        hipLaunchKernelGGL(pb_hot_select_kernel, dim3(div_up(h_try, 256)), dim3(256), 0, 0, ckeys.as<uint64_t>(), h_try,
+                           pl->hot_ids.as<uint32_t>(), hot_rank.as<uint16_t>(), heff.as<uint32_t>());
+        GM_HIP(hipGetLastError());
+        GM_HIP(hipMemcpy(&H, heff.p, 4, hipMemcpyDeviceToHost));
+        if (H == 0)
+            hot_rank.release();
+    }
+    pl->H = H;
+
+    DevBuf keys, kalt;
+    GM_TRY(keys.alloc((size_t)m_all * 8));
+    GM_TRY(kalt.alloc((size_t)m_all * 8));
+    hipLaunchKernelGGL(pb_keys_kernel, dim3(pb_grid(n)), dim3(256), 0, 0, csr->offsets, csr->targets, n, rb, sb,
+                       H ? hot_rank.as<uint16_t>() : (const uint16_t *)nullptr, keys.as<uint64_t>());
+    GM_HIP(hipGetLastError());
+    GM_TRY(sort_keys_u64(keys, kalt, m_all, H ? 64 : bin_bits + sb + rb));
+    kalt.release();
+    hot_rank.release();
+
+    if (H) { // hot keys (top bit set) sit behind the cold ones, already ordered by (bin, hot index, row)
+        DevBuf split;
+        GM_TRY(split.alloc(3 * 4));
+        hipLaunchKernelGGL(pb_bounds_kernel, dim3(pb_grid(m_all)), dim3(256), 0, 0, keys.as<uint64_t>(), m_all, 63, 2u,
+                           split.as<uint32_t>(), 0xFFFFFFFFu);
+        GM_HIP(hipGetLastError());
+        GM_HIP(hipMemcpy(&m, split.as<uint32_t>() + 1, 4, hipMemcpyDeviceToHost));
+        const uint32_t mh = m_all - m;
+        if (mh) {
+            const uint64_t *hkeys = keys.as<uint64_t>() + m;
+            DevBuf hstart, hpad;
+            GM_TRY(hstart.alloc(((size_t)pl->B + 1) * 4));
+            GM_TRY(hpad.alloc(((size_t)pl->B + 1) * 4));
+            hipLaunchKernelGGL(pb_bounds_kernel, dim3(pb_grid(mh)), dim3(256), 0, 0, hkeys, mh, 32, pl->B,
+                               hstart.as<uint32_t>(), 0x7FFFFFFFu);
+            hipLaunchKernelGGL(pb_pad4_sizes_kernel, dim3(pb_grid((uint64_t)pl->B + 1)), dim3(256), 0, 0,
+                               hstart.as<uint32_t>(), pl->B, hpad.as<uint32_t>());
+            GM_HIP(hipGetLastError());
+            GM_TRY(scan_exclusive<uint32_t>(hpad.as<uint32_t>(), pl->hbin_v.as<uint32_t>(), (uint64_t)pl->B + 1));
+            uint32_t Mh = 0;
+            GM_HIP(hipMemcpy(&Mh, pl->hbin_v.as<uint32_t>() + pl->B, 4, hipMemcpyDeviceToHost));
+            pl->Mh = Mh;
+            GM_TRY(pl->hot_ent.alloc((size_t)Mh * 4));
+            GM_HIP(hipMemset(pl->hot_ent.p, 0xFF, (size_t)Mh * 4));
+            hipLaunchKernelGGL(pb_hot_fill_kernel, dim3(pb_grid(mh)), dim3(256), 0, 0, hkeys, mh, hstart.as<uint32_t>(),
+                               pl->hbin_v.as<uint32_t>(), pl->hot_ent.as<uint32_t>());
+            GM_HIP(hipGetLastError());
+            GM_HIP(hipDeviceSynchronize());
+        }
+    }
+    if (m == 0) { // every edge is hot
         GM_TRY(pl->vals.alloc(16));
         GM_TRY(pl->p2_dst.alloc(16));
         GM_HIP(hipMemset(pl->bin_v.p, 0, ((size_t)pl->B + 1) * 4));
@@ -653,15 +869,6 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
         return GM_OK;
     }
     const unsigned gm_ = pb_grid(m);
-
-    DevBuf keys, kalt;
-    GM_TRY(keys.alloc((size_t)m * 8));
-    GM_TRY(kalt.alloc((size_t)m * 8));
-    hipLaunchKernelGGL(pb_keys_kernel, dim3(pb_grid(n)), dim3(256), 0, 0, csr->offsets, csr->targets, n, rb, sb,
-                       keys.as<uint64_t>());
-    GM_HIP(hipGetLastError());
-    GM_TRY(sort_keys_u64(keys, kalt, m, bin_bits + sb + rb));
-    kalt.release();
 
     // (bin, tile) segments of the sorted entries
     DevBuf flag, segid;
@@ -797,7 +1004,7 @@ int pb_plan_create(const gm_csr *csr, uint64_t x_len, PbPlan **out)
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
         e = hipFuncSetAttribute(bin_fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, PB_S * 4 + PB_DCACHE * 4);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(acc_fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (1 << 14) * 8);
+            e = hipFuncSetAttribute(acc_fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 163840 - 512);
     }
     if (e != hipSuccess) {
         set_error("pb_plan_create: %s", hipGetErrorString(e));
@@ -816,6 +1023,9 @@ int pb_sweep_main(PbPlan *pl, const float *x_in, float *x_out, float *scores, co
                   float damping, hipStream_t st)
 {
     static const int nt = pb_env("GM_PB_NT", 0); // measured: streaming hints cost 8-10 % here
+    if (pl->H)
+        hipLaunchKernelGGL(pb_hot_gather_kernel, dim3(div_up(pl->H, 256)), dim3(256), 0, st, x_in,
+                           pl->hot_ids.as<uint32_t>(), pl->H, pl->hot_x.as<float>());
     if (pl->NW) {
         if (nt)
             hipLaunchKernelGGL(pb_bin_kernel<true>, dim3(pl->NW), dim3(PB_BIN_BLOCK), PB_S * 4 + PB_DCACHE * 4, st, x_in, pl->x_len,
@@ -829,13 +1039,15 @@ int pb_sweep_main(PbPlan *pl, const float *x_in, float *x_out, float *scores, co
                                pl->vals.as<float>(), pl->chunk);
     }
     if (nt)
-        hipLaunchKernelGGL(pb_accum_kernel<true>, dim3(pl->NI), dim3(PB_ACC_BLOCK), (size_t)pl->R * 8, st,
-                           pl->vals.as<float>(), pl->p2_dst.as<uint16_t>(), pl->items.as<PbItem>(),
+        hipLaunchKernelGGL(pb_accum_kernel<true>, dim3(pl->NI), dim3(PB_ACC_BLOCK), (size_t)pl->R * 8 + (size_t)pl->H * 4,
+                           st, pl->vals.as<float>(), pl->p2_dst.as<uint16_t>(), pl->items.as<PbItem>(),
+                           pl->hot_ent.as<uint32_t>(), pl->hot_x.as<float>(), pl->H,
                            pl->partials.as<unsigned long long>(), pl->tickets.as<uint32_t>(), outdeg, scores, x_out,
                            pl->bin_err.as<double>(), pl->n_local, pl->R, base, damping);
     else
-        hipLaunchKernelGGL(pb_accum_kernel<false>, dim3(pl->NI), dim3(PB_ACC_BLOCK), (size_t)pl->R * 8, st,
-                           pl->vals.as<float>(), pl->p2_dst.as<uint16_t>(), pl->items.as<PbItem>(),
+        hipLaunchKernelGGL(pb_accum_kernel<false>, dim3(pl->NI), dim3(PB_ACC_BLOCK), (size_t)pl->R * 8 + (size_t)pl->H * 4,
+                           st, pl->vals.as<float>(), pl->p2_dst.as<uint16_t>(), pl->items.as<PbItem>(),
+                           pl->hot_ent.as<uint32_t>(), pl->hot_x.as<float>(), pl->H,
                            pl->partials.as<unsigned long long>(), pl->tickets.as<uint32_t>(), outdeg, scores, x_out,
                            pl->bin_err.as<double>(), pl->n_local, pl->R, base, damping);
     GM_HIP(hipGetLastError());
