@@ -732,6 +732,15 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     int rb = bits_for(n) - 11;
     if (rb < 8)
         rb = 8;
+    // ... but keep (tile, bin) segments >= ~64 entries (256-byte write runs): a tile sends about
+    // m * S / x_len edges to this rank's rows, so at most that / 64 bins (matters for row slices of a
+    // partitioned graph, where every source tile holds only 1/P of its edges)
+    {
+        const uint64_t per_tile = x_len ? (uint64_t)m_all * PB_S / x_len : 0;
+        const uint64_t max_bins = per_tile / 64 > 1 ? per_tile / 64 : 1;
+        while (rb < 14 && (((uint64_t)n + (1ull << rb) - 1) >> rb) > max_bins)
+            ++rb;
+    }
     if (rb > 14)
         rb = 14;
     if (pb_env("GM_PB_RB", 0) >= 8 && pb_env("GM_PB_RB", 0) <= 14)
