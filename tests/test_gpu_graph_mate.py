@@ -1,0 +1,126 @@
+"""Acceptance checks of the graph_mate-shaped front end (graph_amd/graph_mate.py) on a GPU.
+
+Each check restates, in this repository's own words, an expectation pinned by the reference's Python
+suite (crates/mate/tests/, cited per test); the fixtures follow the reference's sharing: ONE undirected
+scale_8 graph for the whole module, relabelled in place by the reorder check before the triangle count
+— the order that produces the reference's 227874."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+NODES, EDGES = 1 << 8, 1 << 12
+
+
+@pytest.fixture(scope="module")
+def M():
+    from graph_amd import graph_mate
+
+    return graph_mate
+
+
+@pytest.fixture(scope="module")
+def digraph(M, golden_dir):
+    return M.DiGraph.load(os.path.join(golden_dir, "scale_8.graph500"), layout=M.Layout.Sorted)
+
+
+@pytest.fixture(scope="module")
+def shared_undirected(M, golden_dir):
+    return M.Graph.load(os.path.join(golden_dir, "scale_8.graph500"), layout=M.Layout.Sorted)
+
+
+# ---- loading and accessors (graph_test.py:10-12, graph_edgelist_test.py:5-24, numpy_neighbors_test.py:4-40)
+def test_sizes_and_neighbor_views(M, digraph, shared_undirected, golden_dir):
+    assert (digraph.node_count(), digraph.edge_count()) == (NODES, EDGES)
+    for node in range(NODES):
+        for view, degree, copied in ((digraph.out_neighbors(node), digraph.out_degree(node), digraph.copy_out_neighbors(node)),
+                                     (digraph.in_neighbors(node), digraph.in_degree(node), digraph.copy_in_neighbors(node)),
+                                     (shared_undirected.neighbors(node), shared_undirected.degree(node),
+                                      shared_undirected.copy_neighbors(node))):
+            assert len(view) == degree and view.base is not None and view.tolist() == copied
+    keep = digraph.in_neighbors(82)  # a view must outlive the handle it came from
+    expected_len = digraph.in_degree(82)
+    other = M.DiGraph.load(os.path.join(golden_dir, "scale_8.graph500"), layout=M.Layout.Sorted)
+    view = other.in_neighbors(82)
+    del other
+    assert len(view) == expected_len == len(keep) and np.all((view >= 0) & (view < NODES))
+
+    el = os.path.join(golden_dir, "test.el")
+    d = M.DiGraph.load(el, layout=M.Layout.Sorted, file_format=M.FileFormat.EdgeList)
+    u = M.Graph.load(el, layout=M.Layout.Sorted, file_format=M.FileFormat.EdgeList)
+    assert (d.node_count(), d.edge_count(), u.node_count(), u.edge_count()) == (5, 6, 5, 6)
+    assert [d.copy_out_neighbors(n) for n in range(5)] == [[1, 2], [2, 3], [4], [4], []]
+    assert [u.copy_neighbors(n) for n in range(5)] == [[1, 2], [0, 2, 3], [0, 1, 4], [1, 4], [2, 3]]
+
+
+# ---- construction from arrays / frames (ds_test.py:7-62)
+@pytest.mark.parametrize("source", ["numpy", "pandas"])
+def test_build_from_numpy_and_pandas(M, source):
+    pairs = np.array([[0, 1], [2, 3], [4, 1]], dtype=np.uint32)
+    if source == "pandas":
+        import pandas as pd
+
+        frame = pd.DataFrame({"source": pairs[:, 0], "target": pairs[:, 1]})
+        und, dirg = M.Graph.from_pandas(frame, layout=M.Layout.Sorted), M.DiGraph.from_pandas(frame, layout=M.Layout.Sorted)
+    else:
+        und, dirg = M.Graph.from_numpy(pairs, layout=M.Layout.Sorted), M.DiGraph.from_numpy(pairs, layout=M.Layout.Sorted)
+    assert (und.node_count(), und.edge_count(), dirg.node_count(), dirg.edge_count()) == (5, 3, 5, 3)
+    assert [und.copy_neighbors(n) for n in range(5)] == [[1], [0, 4], [3], [2], [1]]
+    assert [dirg.copy_out_neighbors(n) for n in (0, 2, 4)] == [[1], [3], [1]]
+    assert [dirg.copy_in_neighbors(n) for n in (1, 3)] == [[0, 4], [2]]
+
+
+# ---- to_undirected (graph_test.py:15-58)
+def test_to_undirected_layouts(M, digraph, shared_undirected):
+    converted = digraph.to_undirected()
+    assert all(set(converted.copy_neighbors(n)) == set(shared_undirected.copy_neighbors(n)) for n in range(NODES))
+    small = M.DiGraph.from_numpy(np.array([[0, 1], [0, 1], [0, 2], [1, 2], [2, 1], [0, 3]], dtype=np.uint32))
+    with_duplicates = [[1, 1, 2, 3], [0, 0, 2, 2], [0, 1, 1], [0]]
+    for layout in (None, M.Layout.Unsorted):
+        ug = small.to_undirected(layout) if layout else small.to_undirected()
+        assert [sorted(ug.copy_neighbors(n)) for n in range(4)] == with_duplicates
+    assert [small.to_undirected(M.Layout.Sorted).copy_neighbors(n) for n in range(4)] == with_duplicates
+    assert [small.to_undirected(M.Layout.Deduplicated).copy_neighbors(n) for n in range(4)] == [[1, 2, 3], [0, 2], [0, 1], [0]]
+
+
+# ---- PageRank (page_rank_test.py:6-38)
+def test_page_rank_results_and_config(digraph):
+    pr = digraph.page_rank()
+    assert pr.ran_iterations >= 1 and pr.error < 1.0 and pr.micros > 0
+    assert len(pr.scores()) == NODES and np.all(pr.scores() > 0.0)
+    assert digraph.page_rank(max_iterations=1).ran_iterations == 1
+    assert digraph.page_rank(tolerance=1).ran_iterations == 1
+    flat = digraph.page_rank(damping_factor=0)
+    assert flat.ran_iterations == 1 and all(score == 1 / NODES for score in flat.scores())
+    with pytest.raises(TypeError):
+        digraph.page_rank(42, 1.0, 0.1)  # configuration is keyword-only
+
+
+# ---- WCC (wcc_test.py:6-21)
+def test_wcc_results_and_config(digraph):
+    res = digraph.wcc()
+    comp = res.components()
+    assert res.micros > 0 and len(comp) == NODES and np.all((comp >= 0) & (comp < digraph.node_count()))
+    with pytest.raises(TypeError):
+        digraph.wcc(42, 1.0, 0.1)
+
+
+# ---- relabel, then triangles (graph_test.py:56-64 runs before triangle_count_test.py:5-9 on the shared graph)
+def test_reorder_then_triangle_count(shared_undirected):
+    before = sorted((shared_undirected.degree(n) for n in range(NODES)), reverse=True)
+    shared_undirected.make_degree_ordered()
+    assert [shared_undirected.degree(n) for n in range(NODES)] == before
+    tc = shared_undirected.global_triangle_count()
+    assert tc.triangles == 227874 and tc.micros > 0
+
+
+@pytest.mark.parametrize("pairs", [  # triangle_count_test.py:12-77
+    [[0, 1], [1, 2], [2, 0], [3, 4], [4, 5], [5, 3]],
+    [[0, 1], [1, 2], [2, 0], [0, 3], [3, 4], [4, 0]],
+    [[0, 1], [1, 2], [2, 0], [1, 3], [3, 2]],
+])
+def test_triangle_shapes(M, pairs):
+    graph = M.Graph.from_numpy(np.array(pairs, dtype=np.uint32), layout=M.Layout.Deduplicated)
+    assert graph.global_triangle_count().triangles == 2
