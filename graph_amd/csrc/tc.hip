@@ -19,6 +19,8 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include <cstdlib>
+
 namespace {
 
 using namespace gm;
@@ -108,11 +110,29 @@ __device__ __forceinline__ bool tc_contains(const uint32_t *__restrict__ list, u
     return lo < len && list[lo] == x;
 }
 
+// Triangular adjacency bitmap of the K smallest ids (after make_degree_ordered: the K highest
+// degrees): bit (x, y), y < x < K, is set iff y is in L(x).  Row x starts at bit x(x-1)/2.
+__device__ __forceinline__ uint64_t tc_bit_index(uint32_t x, uint32_t y) { return (uint64_t)x * (x - 1) / 2 + y; }
+
+__global__ void tc_bitmap_fill_kernel(const uint32_t *__restrict__ dag_src, const uint32_t *__restrict__ dag_tgt,
+                                      uint64_t dag_m, uint32_t K, uint32_t *__restrict__ bits)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < dag_m; k += stride) {
+        const uint32_t x = dag_src[k], y = dag_tgt[k];
+        if (x < K && y < x) {
+            const uint64_t b = tc_bit_index(x, y);
+            atomicOr(&bits[b >> 5], 1u << (b & 31));
+        }
+    }
+}
+
 // one lane per DAG entry (u, v): count entries w of L(v) that occur in L(u)
 template <bool STRICT>
 __global__ __launch_bounds__(TC_BLOCK) void tc_count_kernel(const uint32_t *__restrict__ loff,
                                                             const uint32_t *__restrict__ dag_src,
                                                             const uint32_t *__restrict__ dag_tgt, uint64_t dag_m,
+                                                            const uint32_t *__restrict__ bits, uint32_t K,
                                                             unsigned long long *__restrict__ total)
 {
     __shared__ uint64_t red[TC_WAVES];
@@ -120,6 +140,20 @@ __global__ __launch_bounds__(TC_BLOCK) void tc_count_kernel(const uint32_t *__re
     uint64_t count = 0;
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < dag_m; k += stride) {
         const uint32_t u = dag_src[k], v = dag_tgt[k];
+        if (STRICT && v < K && v < u) {
+            // lists are sets: |L(u) ∩ L(v)| = number of w in L(u), w < v, with bit (v, w) set; the w < v
+            // are exactly the entries of L(u) in front of this one — one load per candidate, no search
+            const uint32_t *lu = dag_tgt + loff[u];
+            const uint32_t rank = (uint32_t)(k - loff[u]);
+            const uint64_t row = (uint64_t)v * (v - 1) / 2;
+            uint32_t c = 0;
+            for (uint32_t i = 0; i < rank; ++i) {
+                const uint64_t b = row + lu[i];
+                c += (bits[b >> 5] >> (b & 31)) & 1u;
+            }
+            count += c;
+            continue;
+        }
         const uint32_t *lu = dag_tgt + loff[u];
         const uint32_t *lv = dag_tgt + loff[v];
         uint32_t nu = loff[u + 1] - loff[u], nv = loff[v + 1] - loff[v];
@@ -186,12 +220,33 @@ GM_API int gm_triangle_count(const gm_csr *g, uint64_t *triangles_out)
     if (cgrid > 256 * 16)
         cgrid = 256 * 16;
     unsigned long long *d_total = reinterpret_cast<unsigned long long *>(ctrl.p);
-    if (flags & 2u)
+    if (flags & 2u) {
         hipLaunchKernelGGL(tc_count_kernel<false>, dim3(cgrid), dim3(TC_BLOCK), 0, 0, loff.as<uint32_t>(),
-                           dag_src.as<uint32_t>(), dag_tgt.as<uint32_t>(), (uint64_t)dag_m, d_total);
-    else
+                           dag_src.as<uint32_t>(), dag_tgt.as<uint32_t>(), (uint64_t)dag_m, (const uint32_t *)nullptr, 0u,
+                           d_total);
+    } else {
+        // strictly increasing lists: membership in the prefix lists of the K smallest ids through a
+        // triangular bitmap (K = 262144 -> 4.3 GB of the 288 GB; GM_TC_K overrides, 0 disables)
+        uint32_t K = n < (1u << 18) ? n : (1u << 18);
+        if (const char *e = getenv("GM_TC_K"))
+            K = (uint32_t)atoll(e) < n ? (uint32_t)atoll(e) : n;
+        gm::DevBuf bits;
+        if (K >= 2) {
+            const uint64_t nbits = (uint64_t)K * (K - 1) / 2;
+            const size_t words = (size_t)((nbits + 31) / 32) + 1;
+            GM_TRY(bits.alloc(words * 4));
+            GM_HIP(hipMemset(bits.p, 0, words * 4));
+            hipLaunchKernelGGL(tc_bitmap_fill_kernel, dim3(cgrid), dim3(TC_BLOCK), 0, 0, dag_src.as<uint32_t>(),
+                               dag_tgt.as<uint32_t>(), (uint64_t)dag_m, K, bits.as<uint32_t>());
+        } else {
+            K = 0;
+        }
         hipLaunchKernelGGL(tc_count_kernel<true>, dim3(cgrid), dim3(TC_BLOCK), 0, 0, loff.as<uint32_t>(),
-                           dag_src.as<uint32_t>(), dag_tgt.as<uint32_t>(), (uint64_t)dag_m, d_total);
+                           dag_src.as<uint32_t>(), dag_tgt.as<uint32_t>(), (uint64_t)dag_m,
+                           K ? bits.as<uint32_t>() : (const uint32_t *)nullptr, K, d_total);
+        GM_HIP(hipGetLastError());
+        GM_HIP(hipDeviceSynchronize()); // bits is released on scope exit
+    }
     GM_HIP(hipGetLastError());
     unsigned long long total = 0;
     GM_HIP(hipMemcpy(&total, d_total, 8, hipMemcpyDeviceToHost));
