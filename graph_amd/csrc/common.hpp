@@ -7,6 +7,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
 
 #include "../../include/graph_mi355x.h"
@@ -120,6 +122,11 @@ inline unsigned div_up(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) /
 
 } // namespace gm
 
+namespace gm {
+struct PbPlan; // propagation-blocking layout of a CSR (pagerank_pb.hip); immutable once built
+void pb_plan_destroy(PbPlan *plan);
+} // namespace gm
+
 // The opaque handle of include/graph_mi355x.h.
 struct gm_csr {
     uint64_t n = 0;
@@ -130,4 +137,13 @@ struct gm_csr {
     const float *weights = nullptr;    // m or null
     bool owns = false;
     gm::DevBuf own_offsets, own_targets, own_weights;
+    // Derived, immutable layouts built on first use and kept for the lifetime of the handle ("upload
+    // once"): PageRank's propagation-blocking plan, keyed by the length of the x vector it was built for.
+    mutable std::mutex cache_mu;
+    mutable std::map<uint64_t, gm::PbPlan *> pb_plans;
+    ~gm_csr()
+    {
+        for (auto &kv : pb_plans)
+            gm::pb_plan_destroy(kv.second);
+    }
 };

@@ -353,7 +353,9 @@ GM_API int gm_pr_create_with(const gm_csr *csr, uint64_t n_global, uint64_t row_
     pr->init = 1.0f / (float)n_global;
     pr->base = (1.0f - damping_factor) / (float)n_global;
     if (engine == GM_PR_ENGINE_PB) {
-        const int rc = gm::pb_plan_create(csr, x_len, &pr->pb);
+        int rc = gm::pb_plan_get(csr, x_len, &pr->pb);
+        if (rc == GM_OK)
+            rc = gm::pb_scratch_create(pr->pb, &pr->pb_scratch);
         if (rc != GM_OK) {
             delete pr;
             return rc;
@@ -429,7 +431,7 @@ GM_API int gm_pr_sweep_tiles(gm_pr *pr, uint64_t d_x_in_global, uint64_t d_x_out
     GM_CHECK(pr, GM_ERR_INVALID, "gm_pr_sweep_tiles: null engine");
     gm::DeviceGuard guard(pr->csr->device);
     if (pr->engine == GM_PR_ENGINE_PB)
-        return gm::pb_sweep_main(pr->pb, reinterpret_cast<const float *>(d_x_in_global),
+        return gm::pb_sweep_main(pr->pb, pr->pb_scratch, reinterpret_cast<const float *>(d_x_in_global),
                                  reinterpret_cast<float *>(d_x_out_local), reinterpret_cast<float *>(d_scores_local),
                                  pr->outdeg, pr->base, pr->damping, (hipStream_t)stream);
     hipLaunchKernelGGL(pr_tile_kernel, dim3(pr->T), dim3(PR_BLOCK), 0, (hipStream_t)stream, pr->csr->offsets,
@@ -447,7 +449,7 @@ GM_API int gm_pr_sweep_fixup(gm_pr *pr, uint64_t d_x_out_local, uint64_t d_score
     GM_CHECK(pr && d_error_out, GM_ERR_INVALID, "gm_pr_sweep_fixup: null argument");
     gm::DeviceGuard guard(pr->csr->device);
     if (pr->engine == GM_PR_ENGINE_PB)
-        return gm::pb_sweep_error(pr->pb, reinterpret_cast<double *>(d_error_out), (hipStream_t)stream);
+        return gm::pb_sweep_error(pr->pb, pr->pb_scratch, reinterpret_cast<double *>(d_error_out), (hipStream_t)stream);
     hipLaunchKernelGGL(pr_fixup_kernel, dim3(pr->G), dim3(PR_BLOCK), 0, (hipStream_t)stream, pr->csr->offsets,
                        pr->tile_row.as<uint32_t>(), pr->outdeg, reinterpret_cast<float *>(d_scores_local),
                        reinterpret_cast<float *>(d_x_out_local), pr->head.as<float>(), pr->tail.as<float>(),

@@ -24,12 +24,14 @@ __device__ __forceinline__ double pr_finalize(uint32_t r, float incoming, float 
     return fabs((double)__fsub_rn(nw, old));
 }
 
-struct PbPlan; // pagerank_pb.hip
-int pb_plan_create(const gm_csr *csr, uint64_t x_len, PbPlan **out);
-void pb_plan_destroy(PbPlan *plan);
-int pb_sweep_main(PbPlan *plan, const float *x_in, float *x_out, float *scores, const uint32_t *outdeg, float base,
-                  float damping, hipStream_t st);
-int pb_sweep_error(PbPlan *plan, double *err_out, hipStream_t st);
+struct PbPlan;    // pagerank_pb.hip: immutable layout, cached in the gm_csr handle
+struct PbScratch; // per-engine mutable buffers (value stream, partial sums, tickets, errors, hot values)
+int pb_plan_get(const gm_csr *csr, uint64_t x_len, const PbPlan **out); // build on first use, then shared
+int pb_scratch_create(const PbPlan *plan, PbScratch **out);
+void pb_scratch_destroy(PbScratch *scratch);
+int pb_sweep_main(const PbPlan *plan, PbScratch *scratch, const float *x_in, float *x_out, float *scores,
+                  const uint32_t *outdeg, float base, float damping, hipStream_t st);
+int pb_sweep_error(const PbPlan *plan, PbScratch *scratch, double *err_out, hipStream_t st);
 uint64_t pb_work_items(const PbPlan *plan);
 
 } // namespace gm
@@ -43,10 +45,11 @@ struct gm_pr {
     const uint32_t *outdeg = nullptr;
     float damping = 0.85f, base = 0.0f, init = 0.0f;
     gm::DevBuf tile_row, head, tail, tile_err, blk_err, ticket; // pull engine
-    gm::PbPlan *pb = nullptr;                                   // propagation-blocking engine
+    const gm::PbPlan *pb = nullptr;                             // propagation-blocking engine (plan owned by csr)
+    gm::PbScratch *pb_scratch = nullptr;
     ~gm_pr()
     {
-        if (pb)
-            gm::pb_plan_destroy(pb);
+        if (pb_scratch)
+            gm::pb_scratch_destroy(pb_scratch);
     }
 };

@@ -50,6 +50,15 @@ constexpr float PB_FIX_INV = 2.168404344971008868e-19f;    // 2^-62
 
 } // namespace
 
+// mutable per-engine buffers: engines on one shared plan never touch each other's data
+struct PbScratch {
+    DevBuf vals;     // f32[Mv]   per-edge values, bin-major, segments padded to 4
+    DevBuf partials; // u64[slots x R] partial LDS accumulators of split bins
+    DevBuf tickets;  // u32[B]    arrival counters of split bins (self-resetting)
+    DevBuf bin_err;  // f64[B]
+    DevBuf hot_x;    // f32[H]    out_scores of the hot sources, refreshed every sweep
+};
+
 struct PbItem {
     uint32_t bin, q0, q1;          // value-stream range [q0, q1) of bin `bin`
     uint32_t h0, h1;               // hot-edge range of this item
@@ -74,22 +83,18 @@ struct PbPlan {
     DevBuf tile_p;      // u32[NT+1] phase-1 range of each tile (multiples of 256)
     DevBuf wg_tile;     // u32[NW]   tile of each phase-1 workgroup
     DevBuf wg_p0;       // u32[NW]   first phase-1 entry of each workgroup
-    DevBuf vals;        // f32[Mv]   per-edge values, bin-major, segments padded to 4
     DevBuf p2_dst;      // u16[Mv]   local row id inside the bin, PB_NULL = padding
     DevBuf bin_v;       // u32[B+1]  value range of each bin (multiples of 4)
     DevBuf items;       // PbItem[NI] accumulate work items (a bin, or a slice of an over-long bin), longest first
-    DevBuf partials;    // u64[parts of split bins x R] partial LDS accumulators of split bins
-    DevBuf tickets;     // u32[B]    arrival counters of split bins (self-resetting)
+    uint32_t slots = 0; // partial-accumulator slots needed by split bins
     uint32_t NI = 0;    // accumulate workgroups
     // hot sources: the H most frequent sources of this rank's edges skip the value stream; their
     // out_scores are staged in LDS by the accumulate kernel and gathered there
     uint32_t H = 0;     // hot sources (0 = feature off)
     DevBuf hot_ids;     // u32[H]   x index of each hot source
-    DevBuf hot_x;       // f32[H]   their out_scores, refreshed every sweep
     DevBuf hot_ent;     // u32[Mh]  hot edges, bin-major: row_in_bin << 16 | hot index; 0xFFFFFFFF = padding
     DevBuf hbin_v;      // u32[B+1] hot-edge range of each bin (multiples of 4)
     uint64_t Mh = 0;
-    DevBuf bin_err;     // f64[B]
 };
 
 namespace {
@@ -714,9 +719,7 @@ int pb_make_items(PbPlan *pl)
     pl->NI = (uint32_t)items.size();
     GM_TRY(pl->items.alloc(items.size() * sizeof(PbItem)));
     GM_HIP(hipMemcpy(pl->items.p, items.data(), items.size() * sizeof(PbItem), hipMemcpyHostToDevice));
-    GM_TRY(pl->partials.alloc((size_t)(slots ? slots : 1) * pl->R * 8));
-    GM_TRY(pl->tickets.alloc((size_t)pl->B * 4));
-    GM_HIP(hipMemset(pl->tickets.p, 0, (size_t)pl->B * 4));
+    pl->slots = slots;
     return GM_OK;
 }
 
@@ -773,14 +776,11 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
 
     GM_TRY(pl->bin_v.alloc(((size_t)pl->B + 1) * 4));
     GM_TRY(pl->hbin_v.alloc(((size_t)pl->B + 1) * 4));
-    GM_TRY(pl->bin_err.alloc((size_t)pl->B * 8));
     GM_TRY(pl->tile_p.alloc(((size_t)pl->NT + 1) * 4));
     GM_HIP(hipMemset(pl->hbin_v.p, 0, ((size_t)pl->B + 1) * 4));
     GM_TRY(pl->hot_ent.alloc(16));
-    GM_TRY(pl->hot_x.alloc((size_t)(H ? H : 1) * 4));
     GM_TRY(pl->hot_ids.alloc((size_t)(H ? H : 1) * 4));
     if (m_all == 0) {
-        GM_TRY(pl->vals.alloc(16));
         GM_TRY(pl->p2_dst.alloc(16));
         GM_HIP(hipMemset(pl->bin_v.p, 0, ((size_t)pl->B + 1) * 4));
         GM_HIP(hipMemset(pl->tile_p.p, 0, ((size_t)pl->NT + 1) * 4));
@@ -869,7 +869,6 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
         }
     }
     if (m == 0) { // every edge is hot
-        GM_TRY(pl->vals.alloc(16));
         GM_TRY(pl->p2_dst.alloc(16));
         GM_HIP(hipMemset(pl->bin_v.p, 0, ((size_t)pl->B + 1) * 4));
         GM_HIP(hipMemset(pl->tile_p.p, 0, ((size_t)pl->NT + 1) * 4));
@@ -952,13 +951,11 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
                        pstart.as<uint32_t>(), pl->delta.as<uint32_t>(), rank_of.as<uint32_t>());
     GM_HIP(hipGetLastError());
 
-    GM_TRY(pl->vals.alloc((size_t)Mv * 4));
     GM_TRY(pl->p2_dst.alloc((size_t)Mv * 2));
     GM_TRY(pl->p1_src.alloc((size_t)Mp * 2));
     GM_TRY(pl->chunk_seg.alloc(((size_t)Mp / PB_WBLK + 1) * 4));
     GM_HIP(hipMemset(pl->p1_src.p, 0xFF, (size_t)Mp * 2));
     GM_HIP(hipMemset(pl->p2_dst.p, 0xFF, (size_t)Mv * 2));
-    GM_HIP(hipMemset(pl->vals.p, 0, (size_t)Mv * 4));
     hipLaunchKernelGGL(pb_fill_kernel, dim3(gm_), dim3(256), 0, 0, keys.as<uint64_t>(), segid.as<uint32_t>(),
                        vstart.as<uint32_t>(), vstart4.as<uint32_t>(), rank_of.as<uint32_t>(), pstart.as<uint32_t>(), m, rb,
                        sb, pl->p1_src.as<uint16_t>(), pl->p2_dst.as<uint16_t>());
@@ -996,7 +993,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
 
 } // namespace
 
-int pb_plan_create(const gm_csr *csr, uint64_t x_len, PbPlan **out)
+static int pb_plan_create(const gm_csr *csr, uint64_t x_len, PbPlan **out)
 {
     PbPlan *pl = new (std::nothrow) PbPlan();
     GM_CHECK(pl, GM_ERR_NOMEM, "pb_plan_create: out of host memory");
@@ -1024,48 +1021,94 @@ int pb_plan_create(const gm_csr *csr, uint64_t x_len, PbPlan **out)
     return GM_OK;
 }
 
+// The plan depends only on the CSR and on x_len: build it on first use and keep it in the handle, so
+// repeated page_rank() calls on one graph (the reference app's warm-up + timed runs) pay for it once.
+int pb_plan_get(const gm_csr *csr, uint64_t x_len, const PbPlan **out)
+{
+    std::lock_guard<std::mutex> lock(csr->cache_mu);
+    auto it = csr->pb_plans.find(x_len);
+    if (it == csr->pb_plans.end() || pb_env("GM_PB_NOCACHE", 0)) {
+        PbPlan *pl = nullptr;
+        GM_TRY(pb_plan_create(csr, x_len, &pl));
+        if (it != csr->pb_plans.end()) {
+            delete it->second;
+            it->second = pl;
+        } else {
+            it = csr->pb_plans.emplace(x_len, pl).first;
+        }
+    }
+    *out = it->second;
+    return GM_OK;
+}
+
 void pb_plan_destroy(PbPlan *plan) { delete plan; }
+
+int pb_scratch_create(const PbPlan *pl, PbScratch **out)
+{
+    PbScratch *sc = new (std::nothrow) PbScratch();
+    GM_CHECK(sc, GM_ERR_NOMEM, "pb_scratch_create: out of host memory");
+    int rc;
+    if ((rc = sc->vals.alloc((size_t)(pl->Mv ? pl->Mv : 4) * 4)) ||
+        (rc = sc->partials.alloc((size_t)(pl->slots ? pl->slots : 1) * pl->R * 8)) ||
+        (rc = sc->tickets.alloc((size_t)pl->B * 4)) || (rc = sc->bin_err.alloc((size_t)pl->B * 8)) ||
+        (rc = sc->hot_x.alloc((size_t)(pl->H ? pl->H : 1) * 4))) {
+        delete sc;
+        return rc;
+    }
+    hipError_t e = hipMemset(sc->tickets.p, 0, (size_t)pl->B * 4);
+    if (e == hipSuccess)
+        e = hipMemset(sc->vals.p, 0, sc->vals.bytes);
+    if (e != hipSuccess) {
+        set_error("pb_scratch_create: %s", hipGetErrorString(e));
+        delete sc;
+        return GM_ERR_HIP;
+    }
+    *out = sc;
+    return GM_OK;
+}
+
+void pb_scratch_destroy(PbScratch *scratch) { delete scratch; }
 
 uint64_t pb_work_items(const PbPlan *plan) { return plan ? (uint64_t)plan->NW + plan->NI : 0; }
 
-int pb_sweep_main(PbPlan *pl, const float *x_in, float *x_out, float *scores, const uint32_t *outdeg, float base,
-                  float damping, hipStream_t st)
+int pb_sweep_main(const PbPlan *pl, PbScratch *sc, const float *x_in, float *x_out, float *scores,
+                  const uint32_t *outdeg, float base, float damping, hipStream_t st)
 {
     static const int nt = pb_env("GM_PB_NT", 0); // measured: streaming hints cost 8-10 % here
     if (pl->H)
         hipLaunchKernelGGL(pb_hot_gather_kernel, dim3(div_up(pl->H, 256)), dim3(256), 0, st, x_in,
-                           pl->hot_ids.as<uint32_t>(), pl->H, pl->hot_x.as<float>());
+                           pl->hot_ids.as<uint32_t>(), pl->H, sc->hot_x.as<float>());
     if (pl->NW) {
         if (nt)
             hipLaunchKernelGGL(pb_bin_kernel<true>, dim3(pl->NW), dim3(PB_BIN_BLOCK), PB_S * 4 + PB_DCACHE * 4, st, x_in, pl->x_len,
                                pl->tile_p.as<uint32_t>(), pl->wg_tile.as<uint32_t>(), pl->wg_p0.as<uint32_t>(),
                                pl->p1_src.as<uint16_t>(), pl->chunk_seg.as<uint32_t>(), pl->delta.as<uint32_t>(),
-                               pl->vals.as<float>(), pl->chunk);
+                               sc->vals.as<float>(), pl->chunk);
         else
             hipLaunchKernelGGL(pb_bin_kernel<false>, dim3(pl->NW), dim3(PB_BIN_BLOCK), PB_S * 4 + PB_DCACHE * 4, st, x_in, pl->x_len,
                                pl->tile_p.as<uint32_t>(), pl->wg_tile.as<uint32_t>(), pl->wg_p0.as<uint32_t>(),
                                pl->p1_src.as<uint16_t>(), pl->chunk_seg.as<uint32_t>(), pl->delta.as<uint32_t>(),
-                               pl->vals.as<float>(), pl->chunk);
+                               sc->vals.as<float>(), pl->chunk);
     }
     if (nt)
         hipLaunchKernelGGL(pb_accum_kernel<true>, dim3(pl->NI), dim3(PB_ACC_BLOCK), (size_t)pl->R * 8 + (size_t)pl->H * 4,
-                           st, pl->vals.as<float>(), pl->p2_dst.as<uint16_t>(), pl->items.as<PbItem>(),
-                           pl->hot_ent.as<uint32_t>(), pl->hot_x.as<float>(), pl->H,
-                           pl->partials.as<unsigned long long>(), pl->tickets.as<uint32_t>(), outdeg, scores, x_out,
-                           pl->bin_err.as<double>(), pl->n_local, pl->R, base, damping);
+                           st, sc->vals.as<float>(), pl->p2_dst.as<uint16_t>(), pl->items.as<PbItem>(),
+                           pl->hot_ent.as<uint32_t>(), sc->hot_x.as<float>(), pl->H,
+                           sc->partials.as<unsigned long long>(), sc->tickets.as<uint32_t>(), outdeg, scores, x_out,
+                           sc->bin_err.as<double>(), pl->n_local, pl->R, base, damping);
     else
         hipLaunchKernelGGL(pb_accum_kernel<false>, dim3(pl->NI), dim3(PB_ACC_BLOCK), (size_t)pl->R * 8 + (size_t)pl->H * 4,
-                           st, pl->vals.as<float>(), pl->p2_dst.as<uint16_t>(), pl->items.as<PbItem>(),
-                           pl->hot_ent.as<uint32_t>(), pl->hot_x.as<float>(), pl->H,
-                           pl->partials.as<unsigned long long>(), pl->tickets.as<uint32_t>(), outdeg, scores, x_out,
-                           pl->bin_err.as<double>(), pl->n_local, pl->R, base, damping);
+                           st, sc->vals.as<float>(), pl->p2_dst.as<uint16_t>(), pl->items.as<PbItem>(),
+                           pl->hot_ent.as<uint32_t>(), sc->hot_x.as<float>(), pl->H,
+                           sc->partials.as<unsigned long long>(), sc->tickets.as<uint32_t>(), outdeg, scores, x_out,
+                           sc->bin_err.as<double>(), pl->n_local, pl->R, base, damping);
     GM_HIP(hipGetLastError());
     return GM_OK;
 }
 
-int pb_sweep_error(PbPlan *pl, double *err_out, hipStream_t st)
+int pb_sweep_error(const PbPlan *pl, PbScratch *sc, double *err_out, hipStream_t st)
 {
-    hipLaunchKernelGGL(pb_err_kernel, dim3(1), dim3(1024), 0, st, pl->bin_err.as<double>(), pl->B, err_out);
+    hipLaunchKernelGGL(pb_err_kernel, dim3(1), dim3(1024), 0, st, sc->bin_err.as<double>(), pl->B, err_out);
     GM_HIP(hipGetLastError());
     return GM_OK;
 }

@@ -506,6 +506,7 @@ def test_page_rank_pb_split_bins(P, oracle, monkeypatch):
     ref_scores, ref_err = _jacobi_reference(ioff, itgt, od, 3)
     whole = P.page_rank(g, P.PageRankConfig(3, 0.0, 0.85), P.PageRankMode.JacobiPB)
     monkeypatch.setenv("GM_PB_SPLIT", "4096")  # force many slices per bin
+    g = _directed(P, n, s2, d2, P.CsrLayout.Sorted)  # a fresh handle: the plan is cached per CSR handle
     split = P.page_rank(g, P.PageRankConfig(3, 0.0, 0.85), P.PageRankMode.JacobiPB)
     assert np.array_equal(whole[0], split[0]) and abs(whole[2] - split[2]) <= 1e-12 * whole[2]
     np.testing.assert_allclose(split[0], ref_scores, rtol=1.5e-7, atol=0)
