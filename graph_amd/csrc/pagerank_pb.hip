@@ -70,6 +70,8 @@ struct PbPlan {
     uint64_t x_len = 0;
     int rb = 0;            // log2(rows per bin)
     uint32_t R = 0, B = 0; // rows per bin, bins
+    uint32_t Racc = 0;     // accumulators per bin = max number of rows with in-edges in one bin (<= R)
+    DevBuf cidx;           // u16[n]  accumulator slot of each row inside its bin, PB_NULL = no in-edges
     uint32_t NT = 0;       // source tiles
     uint32_t NS = 0;       // non-empty (tile, bin) segments
     uint64_t Mp = 0;       // padded length of the phase-1 stream
@@ -103,15 +105,37 @@ namespace {
 // key = bin << (sb + rb) | src << rb | row_in_bin      (sorted ascending = bin-major, then source, then row)
 constexpr uint64_t PB_HOT_KEY = 1ull << 63; // hot-edge keys sort behind every cold key
 // hot key: PB_HOT_KEY | bin << 32 | hot index << 16 | row_in_bin
-__device__ __forceinline__ uint64_t pb_make_key(uint64_t hi_cold, uint32_t r, uint32_t src, int rb,
+__device__ __forceinline__ uint64_t pb_make_key(uint64_t hi_cold, uint32_t r, uint32_t slot, uint32_t src, int rb,
                                                 const uint16_t *__restrict__ hot_rank)
 {
     if (hot_rank) {
         const uint16_t h = hot_rank[src];
         if (h != PB_NULL)
-            return PB_HOT_KEY | ((uint64_t)(r >> rb) << 32) | ((uint64_t)h << 16) | (r & ((1u << rb) - 1u));
+            return PB_HOT_KEY | ((uint64_t)(r >> rb) << 32) | ((uint64_t)h << 16) | slot;
     }
     return hi_cold | ((uint64_t)src << rb);
+}
+
+// accumulator slots: rows with in-edges are numbered consecutively inside their bin
+__global__ void pb_rowflag_kernel(const uint32_t *__restrict__ off, uint32_t n, uint32_t *__restrict__ flag)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r <= n; r += stride)
+        flag[r] = (r < n && off[r + 1] > off[r]) ? 1u : 0u;
+}
+
+__global__ void pb_cidx_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ pos, uint32_t n, int rb,
+                               uint16_t *__restrict__ cidx, uint32_t *__restrict__ bin_rows, uint32_t B)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
+        const uint32_t base = pos[(r >> rb) << rb];
+        cidx[r] = off[r + 1] > off[r] ? (uint16_t)(pos[r] - base) : PB_NULL;
+        if ((r & ((1u << rb) - 1u)) == 0) {
+            const uint64_t end = ((uint64_t)((r >> rb) + 1) << rb);
+            bin_rows[r >> rb] = pos[end < n ? end : n] - base;
+        }
+    }
 }
 
 __global__ void pb_count_sources_kernel(const uint32_t *__restrict__ tgt, uint32_t m, uint32_t *__restrict__ cnt)
@@ -171,7 +195,7 @@ __global__ void pb_hot_gather_kernel(const float *__restrict__ x_in, const uint3
 
 __global__ __launch_bounds__(256) void pb_keys_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt,
                                                       uint32_t n, int rb, int sb, const uint16_t *__restrict__ hot_rank,
-                                                      uint64_t *__restrict__ keys)
+                                                      const uint16_t *__restrict__ cidx, uint64_t *__restrict__ keys)
 {
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -183,20 +207,21 @@ __global__ __launch_bounds__(256) void pb_keys_kernel(const uint32_t *__restrict
             s = off[r];
             e = off[r + 1];
         }
-        const uint64_t hi = ((uint64_t)(r >> rb) << (sb + rb)) | (r & rmask);
+        const uint32_t slot = r < n ? cidx[r] : 0u; // rows with edges always own a slot
+        const uint64_t hi = ((uint64_t)(r >> rb) << (sb + rb)) | (slot & rmask);
         const uint32_t len = e - s;
         if (len <= 32)
             for (uint32_t i = s; i < e; ++i)
-                keys[i] = pb_make_key(hi, r, tgt[i], rb, hot_rank);
+                keys[i] = pb_make_key(hi, r, slot, tgt[i], rb, hot_rank);
         uint64_t big = __ballot(len > 32);
         while (big) {
             const int src = __ffsll((unsigned long long)big) - 1;
             big &= big - 1;
             const uint32_t bs = __shfl(s, src, kWave), be = __shfl(e, src, kWave);
             const uint64_t bhi = __shfl(hi, src, kWave);
-            const uint32_t br = __shfl(r, src, kWave);
+            const uint32_t br = __shfl(r, src, kWave), bslot = __shfl(slot, src, kWave);
             for (uint32_t i = bs + lane; i < be; i += kWave)
-                keys[i] = pb_make_key(bhi, br, tgt[i], rb, hot_rank);
+                keys[i] = pb_make_key(bhi, br, bslot, tgt[i], rb, hot_rank);
         }
     }
 }
@@ -484,17 +509,19 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
                                                                 const uint32_t *__restrict__ hot_ent,
                                                                 const float *__restrict__ hot_x, uint32_t H,
                                                                 unsigned long long *partials, uint32_t *tickets,
+                                                                const uint16_t *__restrict__ cidx,
                                                                 const uint32_t *__restrict__ outdeg, float *__restrict__ scores,
                                                                 float *__restrict__ x_out, double *__restrict__ bin_err,
-                                                                uint32_t n_local, uint32_t R, float base, float damping)
+                                                                uint32_t n_local, uint32_t R, uint32_t Racc, float base,
+                                                                float damping)
 {
-    extern __shared__ unsigned long long acc[]; // R fixed-point sums
+    extern __shared__ unsigned long long acc[]; // Racc fixed-point sums (one per row WITH in-edges)
     __shared__ double red[PB_ACC_BLOCK / kWave];
     __shared__ bool is_last;
     const PbItem item = items[blockIdx.x]; // longest items are dispatched first
     const uint32_t b = item.bin, tid = threadIdx.x;
-    float *hot = reinterpret_cast<float *>(acc + R); // H out_scores of the hot sources
-    for (uint32_t i = tid; i < R; i += PB_ACC_BLOCK)
+    float *hot = reinterpret_cast<float *>(acc + Racc); // H out_scores of the hot sources
+    for (uint32_t i = tid; i < Racc; i += PB_ACC_BLOCK)
         acc[i] = 0ull;
     if (item.h1 > item.h0)
         for (uint32_t i = tid; i < H; i += PB_ACC_BLOCK)
@@ -548,8 +575,8 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
         // An over-long bin is accumulated by several workgroups; integer partial sums commute, so the
         // last one to arrive adds them up and runs the epilogue.  Hand-off per the agent-scope
         // release/acquire recipe (cdna_hip_programming.md, Guideline 16).
-        unsigned long long *mine = partials + (size_t)(item.slot0 + item.part) * R;
-        for (uint32_t i = tid; i < R; i += PB_ACC_BLOCK)
+        unsigned long long *mine = partials + (size_t)(item.slot0 + item.part) * Racc;
+        for (uint32_t i = tid; i < Racc; i += PB_ACC_BLOCK)
             mine[i] = acc[i];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -572,11 +599,15 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
     for (uint32_t i = tid; i < R; i += PB_ACC_BLOCK) {
         const uint32_t r = r0 + i;
         if (r < n_local) {
-            unsigned long long sum = acc[i];
-            if (item.nparts > 1) { // slices of one bin own consecutive partial slots [slot0, slot0 + nparts)
-                sum = 0ull;
-                for (uint32_t k = 0; k < item.nparts; ++k)
-                    sum += partials[(size_t)(item.slot0 + k) * R + i];
+            const uint32_t c = cidx[r]; // rows without in-edges own no accumulator: incoming = 0
+            unsigned long long sum = 0ull;
+            if (c != PB_NULL) {
+                if (item.nparts > 1) { // slices of one bin own consecutive partial slots [slot0, slot0 + nparts)
+                    for (uint32_t k = 0; k < item.nparts; ++k)
+                        sum += partials[(size_t)(item.slot0 + k) * Racc + c];
+                } else {
+                    sum = acc[c];
+                }
             }
             const float incoming = (float)sum * PB_FIX_INV; // one rounding: the exactly rounded row sum
             err += pr_finalize(r, incoming, base, damping, outdeg, scores, x_out);
@@ -760,12 +791,42 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     const int bin_bits = bits_for(pl->B) < 1 ? 1 : bits_for(pl->B);
     GM_CHECK(bin_bits + sb + rb <= 63, GM_ERR_RANGE, "pb_build: key does not fit 63 bits");
 
+    // accumulator slots only for rows that have in-edges (RMAT: about half of the rows have none)
+    GM_TRY(pl->cidx.alloc((size_t)(n ? n : 1) * 2));
+    pl->Racc = 1;
+    if (n) {
+        DevBuf flag, pos, bin_rows;
+        GM_TRY(flag.alloc(((size_t)n + 1) * 4));
+        GM_TRY(pos.alloc(((size_t)n + 1) * 4));
+        GM_TRY(bin_rows.alloc((size_t)pl->B * 4));
+        hipLaunchKernelGGL(pb_rowflag_kernel, dim3(pb_grid((uint64_t)n + 1)), dim3(256), 0, 0, csr->offsets, n,
+                           flag.as<uint32_t>());
+        GM_HIP(hipGetLastError());
+        GM_TRY(scan_exclusive<uint32_t>(flag.as<uint32_t>(), pos.as<uint32_t>(), (uint64_t)n + 1));
+        hipLaunchKernelGGL(pb_cidx_kernel, dim3(pb_grid(n)), dim3(256), 0, 0, csr->offsets, pos.as<uint32_t>(), n, rb,
+                           pl->cidx.as<uint16_t>(), bin_rows.as<uint32_t>(), pl->B);
+        GM_HIP(hipGetLastError());
+        std::vector<uint32_t> rows(pl->B);
+        GM_HIP(hipMemcpy(rows.data(), bin_rows.p, (size_t)pl->B * 4, hipMemcpyDeviceToHost));
+        uint32_t mx = 1;
+        for (uint32_t v : rows)
+            mx = v > mx ? v : mx;
+        pl->Racc = (mx + 63u) & ~63u;
+        if (pl->Racc > pl->R)
+            pl->Racc = pl->R;
+        if (pb_env("GM_PB_COMPACT", 1) == 0)
+            pl->Racc = pl->R; // keep the slot numbering, size the LDS as if every row had one
+    }
+
     // hot table size: what is left of the LDS beside the accumulators (2 workgroups per CU when the
     // accumulators are <= 64 KiB, else 1)
     uint32_t H = 0;
     {
-        const size_t acc_bytes = (size_t)pl->R * 8;
-        const size_t budget = acc_bytes > 65536 ? (163840 - 512 - acc_bytes) : (81920 - 512 - acc_bytes);
+        const size_t acc_bytes = (size_t)pl->Racc * 8;
+        int wgs = acc_bytes > 65536 ? 1 : 2; // accumulate workgroups per CU the LDS request should allow
+        if (pb_env("GM_PB_WGS", 0) == 1 || (pb_env("GM_PB_WGS", 0) == 0 && acc_bytes > 32768))
+            wgs = 1;
+        const size_t budget = wgs == 1 ? (163840 - 512 - acc_bytes) : (81920 - 512 - acc_bytes);
         H = (uint32_t)(budget / 4) & ~63u;
         if (H > 32768)
             H = 32768;
@@ -832,7 +893,8 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     GM_TRY(keys.alloc((size_t)m_all * 8));
     GM_TRY(kalt.alloc((size_t)m_all * 8));
     hipLaunchKernelGGL(pb_keys_kernel, dim3(pb_grid(n)), dim3(256), 0, 0, csr->offsets, csr->targets, n, rb, sb,
-                       H ? hot_rank.as<uint16_t>() : (const uint16_t *)nullptr, keys.as<uint64_t>());
+                       H ? hot_rank.as<uint16_t>() : (const uint16_t *)nullptr, pl->cidx.as<uint16_t>(),
+                       keys.as<uint64_t>());
     GM_HIP(hipGetLastError());
     GM_TRY(sort_keys_u64(keys, kalt, m_all, H ? 64 : bin_bits + sb + rb));
     kalt.release();
@@ -1049,7 +1111,7 @@ int pb_scratch_create(const PbPlan *pl, PbScratch **out)
     GM_CHECK(sc, GM_ERR_NOMEM, "pb_scratch_create: out of host memory");
     int rc;
     if ((rc = sc->vals.alloc((size_t)(pl->Mv ? pl->Mv : 4) * 4)) ||
-        (rc = sc->partials.alloc((size_t)(pl->slots ? pl->slots : 1) * pl->R * 8)) ||
+        (rc = sc->partials.alloc((size_t)(pl->slots ? pl->slots : 1) * pl->Racc * 8)) ||
         (rc = sc->tickets.alloc((size_t)pl->B * 4)) || (rc = sc->bin_err.alloc((size_t)pl->B * 8)) ||
         (rc = sc->hot_x.alloc((size_t)(pl->H ? pl->H : 1) * 4))) {
         delete sc;
@@ -1091,17 +1153,19 @@ int pb_sweep_main(const PbPlan *pl, PbScratch *sc, const float *x_in, float *x_o
                                sc->vals.as<float>(), pl->chunk);
     }
     if (nt)
-        hipLaunchKernelGGL(pb_accum_kernel<true>, dim3(pl->NI), dim3(PB_ACC_BLOCK), (size_t)pl->R * 8 + (size_t)pl->H * 4,
+        hipLaunchKernelGGL(pb_accum_kernel<true>, dim3(pl->NI), dim3(PB_ACC_BLOCK), (size_t)pl->Racc * 8 + (size_t)pl->H * 4,
                            st, sc->vals.as<float>(), pl->p2_dst.as<uint16_t>(), pl->items.as<PbItem>(),
                            pl->hot_ent.as<uint32_t>(), sc->hot_x.as<float>(), pl->H,
-                           sc->partials.as<unsigned long long>(), sc->tickets.as<uint32_t>(), outdeg, scores, x_out,
-                           sc->bin_err.as<double>(), pl->n_local, pl->R, base, damping);
+                           sc->partials.as<unsigned long long>(), sc->tickets.as<uint32_t>(), pl->cidx.as<uint16_t>(), outdeg, scores,
+                           x_out,
+                           sc->bin_err.as<double>(), pl->n_local, pl->R, pl->Racc, base, damping);
     else
-        hipLaunchKernelGGL(pb_accum_kernel<false>, dim3(pl->NI), dim3(PB_ACC_BLOCK), (size_t)pl->R * 8 + (size_t)pl->H * 4,
+        hipLaunchKernelGGL(pb_accum_kernel<false>, dim3(pl->NI), dim3(PB_ACC_BLOCK), (size_t)pl->Racc * 8 + (size_t)pl->H * 4,
                            st, sc->vals.as<float>(), pl->p2_dst.as<uint16_t>(), pl->items.as<PbItem>(),
                            pl->hot_ent.as<uint32_t>(), sc->hot_x.as<float>(), pl->H,
-                           sc->partials.as<unsigned long long>(), sc->tickets.as<uint32_t>(), outdeg, scores, x_out,
-                           sc->bin_err.as<double>(), pl->n_local, pl->R, base, damping);
+                           sc->partials.as<unsigned long long>(), sc->tickets.as<uint32_t>(), pl->cidx.as<uint16_t>(), outdeg, scores,
+                           x_out,
+                           sc->bin_err.as<double>(), pl->n_local, pl->R, pl->Racc, base, damping);
     GM_HIP(hipGetLastError());
     return GM_OK;
 }
