@@ -44,6 +44,8 @@ def parse_args():
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores (available_parallelism)")
     ap.add_argument("--relabel", type=int, default=0, help="(experimental) internal degree-ordered layout")
     ap.add_argument("--engine", choices=["auto", "pull", "pb"], default="auto")
+    ap.add_argument("--prewarm-ms", type=float, default=400.0, help="untimed sweeps before the W warm-up steps so "
+                    "the GPU leaves its idle clock state (sclk idles at 576 MHz; short runs otherwise vary by 10 %%)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
                     "exercising the multi-rank path with several ranks on ONE device)")
     ap.add_argument("--single-device", type=int, default=0, help="debug: all ranks use cuda:0 (needs --backend gloo)")
@@ -175,6 +177,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.prewarm_ms > 0:  # clock ramp: not part of the W warm-up steps, nothing is measured here
+        t_pre = time.perf_counter()
+        while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
+            for _ in range(8):
+                step()
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     sync_all()

@@ -52,7 +52,8 @@ constexpr float PB_FIX_INV = 2.168404344971008868e-19f;    // 2^-62
 
 // mutable per-engine buffers: engines on one shared plan never touch each other's data
 struct PbScratch {
-    DevBuf vals;     // f32[Mv]   per-edge values, bin-major, segments padded to 4
+    DevBuf vals_raw; // backing allocation of the value stream
+    float *vals = nullptr; // f32[Mv] per-edge values, bin-major, segments padded to 4
     DevBuf partials; // u64[slots x R] partial LDS accumulators of split bins
     DevBuf tickets;  // u32[B]    arrival counters of split bins (self-resetting)
     DevBuf bin_err;  // f64[B]
@@ -1110,16 +1111,17 @@ int pb_scratch_create(const PbPlan *pl, PbScratch **out)
     PbScratch *sc = new (std::nothrow) PbScratch();
     GM_CHECK(sc, GM_ERR_NOMEM, "pb_scratch_create: out of host memory");
     int rc;
-    if ((rc = sc->vals.alloc((size_t)(pl->Mv ? pl->Mv : 4) * 4)) ||
+    if ((rc = sc->vals_raw.alloc((size_t)(pl->Mv ? pl->Mv : 4) * 4)) ||
         (rc = sc->partials.alloc((size_t)(pl->slots ? pl->slots : 1) * pl->Racc * 8)) ||
         (rc = sc->tickets.alloc((size_t)pl->B * 4)) || (rc = sc->bin_err.alloc((size_t)pl->B * 8)) ||
         (rc = sc->hot_x.alloc((size_t)(pl->H ? pl->H : 1) * 4))) {
         delete sc;
         return rc;
     }
+    sc->vals = sc->vals_raw.as<float>();
     hipError_t e = hipMemset(sc->tickets.p, 0, (size_t)pl->B * 4);
     if (e == hipSuccess)
-        e = hipMemset(sc->vals.p, 0, sc->vals.bytes);
+        e = hipMemset(sc->vals_raw.p, 0, sc->vals_raw.bytes);
     if (e != hipSuccess) {
         set_error("pb_scratch_create: %s", hipGetErrorString(e));
         delete sc;
@@ -1145,23 +1147,23 @@ int pb_sweep_main(const PbPlan *pl, PbScratch *sc, const float *x_in, float *x_o
             hipLaunchKernelGGL(pb_bin_kernel<true>, dim3(pl->NW), dim3(PB_BIN_BLOCK), PB_S * 4 + PB_DCACHE * 4, st, x_in, pl->x_len,
                                pl->tile_p.as<uint32_t>(), pl->wg_tile.as<uint32_t>(), pl->wg_p0.as<uint32_t>(),
                                pl->p1_src.as<uint16_t>(), pl->chunk_seg.as<uint32_t>(), pl->delta.as<uint32_t>(),
-                               sc->vals.as<float>(), pl->chunk);
+                               sc->vals, pl->chunk);
         else
             hipLaunchKernelGGL(pb_bin_kernel<false>, dim3(pl->NW), dim3(PB_BIN_BLOCK), PB_S * 4 + PB_DCACHE * 4, st, x_in, pl->x_len,
                                pl->tile_p.as<uint32_t>(), pl->wg_tile.as<uint32_t>(), pl->wg_p0.as<uint32_t>(),
                                pl->p1_src.as<uint16_t>(), pl->chunk_seg.as<uint32_t>(), pl->delta.as<uint32_t>(),
-                               sc->vals.as<float>(), pl->chunk);
+                               sc->vals, pl->chunk);
     }
     if (nt)
         hipLaunchKernelGGL(pb_accum_kernel<true>, dim3(pl->NI), dim3(PB_ACC_BLOCK), (size_t)pl->Racc * 8 + (size_t)pl->H * 4,
-                           st, sc->vals.as<float>(), pl->p2_dst.as<uint16_t>(), pl->items.as<PbItem>(),
+                           st, sc->vals, pl->p2_dst.as<uint16_t>(), pl->items.as<PbItem>(),
                            pl->hot_ent.as<uint32_t>(), sc->hot_x.as<float>(), pl->H,
                            sc->partials.as<unsigned long long>(), sc->tickets.as<uint32_t>(), pl->cidx.as<uint16_t>(), outdeg, scores,
                            x_out,
                            sc->bin_err.as<double>(), pl->n_local, pl->R, pl->Racc, base, damping);
     else
         hipLaunchKernelGGL(pb_accum_kernel<false>, dim3(pl->NI), dim3(PB_ACC_BLOCK), (size_t)pl->Racc * 8 + (size_t)pl->H * 4,
-                           st, sc->vals.as<float>(), pl->p2_dst.as<uint16_t>(), pl->items.as<PbItem>(),
+                           st, sc->vals, pl->p2_dst.as<uint16_t>(), pl->items.as<PbItem>(),
                            pl->hot_ent.as<uint32_t>(), sc->hot_x.as<float>(), pl->H,
                            sc->partials.as<unsigned long long>(), sc->tickets.as<uint32_t>(), pl->cidx.as<uint16_t>(), outdeg, scores,
                            x_out,
