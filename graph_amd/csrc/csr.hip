@@ -283,6 +283,48 @@ GM_API int gm_csr_slice_rows(const gm_csr *full, uint64_t row_lo, uint64_t row_h
     return GM_OK;
 }
 
+namespace {
+__global__ void slice_targets_map_kernel(const uint32_t *__restrict__ tgt, const float *__restrict__ w, uint64_t first,
+                                         uint64_t count, const uint32_t *__restrict__ map, uint32_t *__restrict__ new_tgt,
+                                         float *__restrict__ new_w)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        new_tgt[i] = map[tgt[first + i]];
+        if (new_w)
+            new_w[i] = w[first + i];
+    }
+}
+} // namespace
+
+GM_API int gm_csr_slice_rows_map(const gm_csr *full, uint64_t row_lo, uint64_t row_hi, uint64_t d_map, gm_csr **out)
+{
+    GM_CHECK(full && out && d_map, GM_ERR_INVALID, "gm_csr_slice_rows_map: null argument");
+    GM_CHECK(row_lo <= row_hi && row_hi <= full->n, GM_ERR_RANGE, "gm_csr_slice_rows_map: rows [%llu, %llu) outside [0, %llu)",
+             (unsigned long long)row_lo, (unsigned long long)row_hi, (unsigned long long)full->n);
+    gm::DeviceGuard guard(full->device);
+    uint32_t lohi[2] = {0, 0};
+    GM_HIP(hipMemcpy(&lohi[0], full->offsets + row_lo, 4, hipMemcpyDeviceToHost));
+    GM_HIP(hipMemcpy(&lohi[1], full->offsets + row_hi, 4, hipMemcpyDeviceToHost));
+    const uint64_t rows = row_hi - row_lo, count = lohi[1] - lohi[0];
+    gm_csr *c = nullptr;
+    GM_TRY(new_owned_csr(rows, count, full->weights != nullptr, full->device, &c));
+    hipLaunchKernelGGL(slice_offsets_kernel, dim3(gm::div_up(rows + 1, 256) > 8192 ? 8192 : gm::div_up(rows + 1, 256)),
+                       dim3(256), 0, 0, full->offsets, (uint32_t)row_lo, (uint32_t)rows, c->own_offsets.as<uint32_t>());
+    if (count)
+        hipLaunchKernelGGL(slice_targets_map_kernel, dim3(gm::div_up(count, 256) > 8192 ? 8192 : gm::div_up(count, 256)),
+                           dim3(256), 0, 0, full->targets, full->weights, (uint64_t)lohi[0], count,
+                           reinterpret_cast<const uint32_t *>(d_map), c->own_targets.as<uint32_t>(),
+                           full->weights ? c->own_weights.as<float>() : nullptr);
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        gm::set_error("gm_csr_slice_rows_map: kernel failure");
+        delete c;
+        return GM_ERR_HIP;
+    }
+    *out = c;
+    return GM_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // R-MAT generator — integer-only, identical to oracle/graph_oracle.c:orc_rmat_edge
 // ------------------------------------------------------------------------------------------------

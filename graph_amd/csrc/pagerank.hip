@@ -332,7 +332,8 @@ GM_API int gm_pr_create_with(const gm_csr *csr, uint64_t n_global, uint64_t row_
     GM_CHECK(d_out_degree_local != 0 || csr->n == 0, GM_ERR_INVALID, "gm_pr_create: out-degree pointer is null");
     GM_CHECK(csr->n + csr->m < (1ull << 32), GM_ERR_RANGE, "gm_pr_create: n + m = %llu does not fit 32-bit tile positions",
              (unsigned long long)(csr->n + csr->m));
-    GM_CHECK(x_len >= n_global && x_len < (1ull << 32), GM_ERR_RANGE, "gm_pr_create: x_len %llu out of range",
+    // x_len may be smaller than n_global: a compacted exchange buffer only holds nodes with out-edges
+    GM_CHECK(x_len >= 1 && x_len < (1ull << 32), GM_ERR_RANGE, "gm_pr_create: x_len %llu out of range",
              (unsigned long long)x_len);
     GM_CHECK(engine >= GM_PR_ENGINE_AUTO && engine <= GM_PR_ENGINE_PB, GM_ERR_INVALID, "gm_pr_create: unknown engine %d", engine);
     if (engine == GM_PR_ENGINE_AUTO) // below ~16M edges the gathered vector is cache-resident: the pull tiles win

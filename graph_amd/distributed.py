@@ -56,28 +56,62 @@ def pad_bounds(ranges, world_size: int, n: int):
     return np.asarray(bounds, np.uint32), stride
 
 
+def compact_exchange_layout(out_degree, bounds):
+    """Only nodes WITH out-edges are ever gathered (out_scores of the others is +inf and unused,
+    page_rank.rs:78,158), so only those are exchanged: node v of rank p becomes slot
+    p*stride + (number of out-degree>0 nodes of rank p before v).  out_degree: 1-D integer torch tensor
+    (any device), bounds: world+1 node ids.  Returns (map int32[n] with -1 for nodes that are never a
+    source, counts per rank, stride, and per rank the local row indices to send)."""
+    import torch
+
+    has_out = out_degree > 0
+    world = len(bounds) - 1
+    n = out_degree.numel()
+    node_map = torch.full((n,), -1, dtype=torch.int32, device=out_degree.device)
+    counts, send_rows = [], []
+    for p in range(world):
+        lo, hi = int(bounds[p]), int(bounds[p + 1])
+        rows = torch.nonzero(has_out[lo:hi], as_tuple=False).flatten()
+        counts.append(int(rows.numel()))
+        send_rows.append(rows)
+    stride = max(1, max(counts))
+    for p in range(world):
+        lo = int(bounds[p])
+        node_map[lo + send_rows[p]] = (p * stride + torch.arange(counts[p], device=out_degree.device)).to(torch.int32)
+    return node_map, counts, stride, send_rows
+
+
 def page_rank_partitioned(engine, n_global: int, n_local: int, stride: int, max_iterations: int, tolerance: float,
-                          device, group=None, init_fn=None):
+                          device, group=None, send_rows=None):
     """Runs the sweeps of page_rank (page_rank.rs:88-110) across the ranks of `group`.
 
     engine.sweep(x_in_padded, x_out_local, scores_local, err) computes this rank's rows;
     engine.init(scores_local, x_local) fills the initial values (page_rank.rs:70-81).
+    send_rows (optional): local row indices whose out_scores are exchanged, in slot order (see
+    compact_exchange_layout; `stride` is then the compact stride); default: every local row.
     Returns (scores_local, iterations, error)."""
     world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
     x_pad = [torch.zeros(world * stride, dtype=torch.float32, device=device) for _ in range(2)]
-    x_loc = torch.zeros(stride, dtype=torch.float32, device=device)
+    compact = send_rows is not None
+    x_loc = torch.zeros(max(n_local, 1) if compact else stride, dtype=torch.float32, device=device)
+    x_send = torch.zeros(stride, dtype=torch.float32, device=device) if compact else x_loc
     scores = torch.zeros(max(n_local, 1), dtype=torch.float32, device=device)
     err = torch.zeros(1, dtype=torch.float64, device=device)
+
+    def exchange(dst):
+        if compact:
+            x_send[: send_rows.numel()] = x_loc[send_rows]
+        dist.all_gather_into_tensor(dst, x_send, group=group)
+
     engine.init(scores, x_loc)
-    dist.all_gather_into_tensor(x_pad[0], x_loc, group=group)
+    exchange(x_pad[0])
     iteration, error, cur = 0, 0.0, 0
     can_stop_early = tolerance > 0.0
     if max_iterations == 0 and not can_stop_early:
         raise ValueError("max_iterations == 0 with tolerance <= 0 never terminates (reference: infinite loop)")
     while True:
         engine.sweep(x_pad[cur], x_loc, scores, err)
-        dist.all_gather_into_tensor(x_pad[1 - cur], x_loc, group=group)
+        exchange(x_pad[1 - cur])
         cur = 1 - cur
         iteration += 1
         last = iteration == max_iterations

@@ -101,6 +101,12 @@ int gm_csr_relabel_by_degree(const gm_csr *undirected, gm_csr **out, uint32_t *n
 int gm_csr_slice_rows(const gm_csr *full, uint64_t row_lo, uint64_t row_hi, const uint32_t *bounds,
                       uint32_t parts, uint32_t stride, gm_csr **out);
 
+/* Same, with an arbitrary rewrite of the target ids: d_map is a device array u32[n], every target v of
+ * the slice becomes d_map[v].  Used to exchange only the out_scores of nodes that HAVE out-edges
+ * (the others are never gathered): the map sends node v to its slot in the compacted rank-major
+ * all-gather buffer (graph_amd/distributed.py:compact_exchange_layout). */
+int gm_csr_slice_rows_map(const gm_csr *full, uint64_t row_lo, uint64_t row_hi, uint64_t d_map, gm_csr **out);
+
 /* ---------------------------------------------------------------------------------------------
  * PageRank — replaces `page_rank(&G, PageRankConfig) -> (Vec<f32>, usize, f64)`,
  * crates/algos/src/page_rank.rs:58-111 (config :14-56: max_iterations 20, tolerance 1e-4,

@@ -14,14 +14,18 @@ import torch.multiprocessing as mp
 class _OracleRankEngine:
     """Per-rank sweep over rows [lo, hi) reading the padded rank-major x vector."""
 
-    def __init__(self, O, ioff, itgt, od, bounds, stride, rank, damping):
+    def __init__(self, O, ioff, itgt, od, bounds, stride, rank, damping, node_map=None):
         self.O, self.damping = O, damping
         lo, hi = int(bounds[rank]), int(bounds[rank + 1])
         self.lo, self.hi, self.n = lo, hi, ioff.size - 1
         self.off = (ioff[lo:hi + 1] - ioff[lo]).astype(np.uint32)
         tg = itgt[ioff[lo]:ioff[hi]]
-        part = np.searchsorted(bounds[1:], tg, side="right")
-        self.tgt = (part * stride + (tg - bounds[part])).astype(np.uint32)
+        if node_map is None:  # padded exchange of every row
+            part = np.searchsorted(bounds[1:], tg, side="right")
+            self.tgt = (part * stride + (tg - bounds[part])).astype(np.uint32)
+        else:  # compact exchange: only nodes with out-edges own a slot
+            self.tgt = node_map[tg].astype(np.uint32)
+            assert (node_map[tg] >= 0).all()
         self.od = od[lo:hi].copy()
 
     def init(self, scores, x_loc):
@@ -50,20 +54,26 @@ class _OracleRankEngine:
         err[0] = e
 
 
-def _worker(rank, world, port, scale, max_iter, tol, q):
+def _worker(rank, world, port, scale, max_iter, tol, q, compact=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import oracle as O
-    from graph_amd.distributed import greedy_degree_partition, pad_bounds, page_rank_partitioned
+    from graph_amd.distributed import (compact_exchange_layout, greedy_degree_partition, pad_bounds,
+                                       page_rank_partitioned)
 
     s, d = O.rmat_edges(scale, seed=3)
     n = 1 << scale
     ioff, itgt = O.csr_build(n, s, d, O.INCOMING, O.SORTED)
     od = O.out_degrees_from(n, s)
     bounds, stride = pad_bounds(greedy_degree_partition(ioff, world), world, n)
-    eng = _OracleRankEngine(O, ioff, itgt, od, bounds, stride, rank, 0.85)
+    node_map, send_rows = None, None
+    if compact:
+        nm, counts, stride, rows = compact_exchange_layout(torch.from_numpy(od.astype(np.int64)), bounds)
+        node_map, send_rows = nm.numpy(), rows[rank]
+        assert stride == max(counts) and int((nm >= 0).sum()) == int((od > 0).sum())
+    eng = _OracleRankEngine(O, ioff, itgt, od, bounds, stride, rank, 0.85, node_map)
     scores, it, err = page_rank_partitioned(eng, n, int(bounds[rank + 1] - bounds[rank]), stride, max_iter, tol,
-                                            torch.device("cpu"))
+                                            torch.device("cpu"), send_rows=send_rows)
     q.put((rank, int(bounds[rank]), scores.numpy().copy(), it, err))
     dist.barrier()
     dist.destroy_process_group()
@@ -75,13 +85,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,max_iter,tol", [(2, 4, 0.0), (3, 20, 1e-3)])
-def test_partitioned_page_rank_matches_single_rank_jacobi(oracle, world, max_iter, tol):
+@pytest.mark.parametrize("world,max_iter,tol,compact", [(2, 4, 0.0, False), (3, 20, 1e-3, False), (2, 5, 0.0, True),
+                                                        (3, 20, 1e-3, True)])
+def test_partitioned_page_rank_matches_single_rank_jacobi(oracle, world, max_iter, tol, compact):
     scale = 7
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, scale, max_iter, tol, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, scale, max_iter, tol, q, compact)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=120) for _ in range(world)]

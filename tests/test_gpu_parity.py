@@ -437,7 +437,7 @@ def test_partitioned_engines_on_one_device_match_single_engine(P, oracle):
     import torch
 
     from graph_amd._lib import check, lib, vp
-    from graph_amd.distributed import greedy_degree_partition, pad_bounds
+    from graph_amd.distributed import compact_exchange_layout, greedy_degree_partition, pad_bounds
     from graph_amd.engine import PageRankEngine
 
     scale, world = 16, 3
@@ -448,6 +448,9 @@ def test_partitioned_engines_on_one_device_match_single_engine(P, oracle):
     od = torch.from_numpy(oracle.out_degrees_from(n, s).astype(np.int32)).cuda()
     bounds, stride = pad_bounds(greedy_degree_partition(ioff, world), world, n)
     dev = torch.device("cuda", 0)
+    # compact exchange layout: only nodes with out-edges own a slot of the gathered vector
+    node_map, counts, cstride, send_rows = compact_exchange_layout(od, bounds)
+    assert int((node_map >= 0).sum()) == int((od > 0).sum()) and cstride == max(counts) < stride
     for kind in (PageRankEngine.PULL, PageRankEngine.PB):
         # single engine
         eng = PageRankEngine(inc.handle, n, 0, od, 0.85, engine=kind)
@@ -488,6 +491,31 @@ def test_partitioned_engines_on_one_device_match_single_engine(P, oracle):
             assert torch.equal(got, sc)  # exact row sums: identical for any partition
         else:
             torch.testing.assert_close(got, sc, rtol=2e-6, atol=0)
+        # the same with the compacted exchange (targets rewritten through node_map)
+        cparts = []
+        for r in range(world):
+            lo, hi = int(bounds[r]), int(bounds[r + 1])
+            h = vp()
+            check(lib().gm_csr_slice_rows_map(inc.handle, lo, hi, node_map.data_ptr(), C.byref(h)))
+            csr = P.DeviceCsr(h)
+            odl = od[lo:hi].contiguous() if hi > lo else torch.zeros(1, dtype=torch.int32, device=dev)
+            e = PageRankEngine(csr.handle, n, lo, odl, 0.85, x_len=world * cstride, engine=kind)
+            cparts.append((csr, odl, e, torch.zeros(max(hi - lo, 1), device=dev), torch.zeros(max(hi - lo, 1), device=dev),
+                           torch.zeros(1, dtype=torch.float64, device=dev), lo, hi))
+        xc = [torch.zeros(world * cstride, device=dev), torch.zeros(world * cstride, device=dev)]
+
+        def publish(dst, r, xl):
+            dst[r * cstride:r * cstride + counts[r]] = xl[send_rows[r]]
+
+        for r, (_, _, e, scl, xl, _, lo, hi) in enumerate(cparts):
+            e.init(scl, xl)
+            publish(xc[0], r, xl)
+        for k in range(4):
+            for r, (_, _, e, scl, xl, el, lo, hi) in enumerate(cparts):
+                e.sweep(xc[k % 2], xl, scl, el)
+                publish(xc[1 - k % 2], r, xl)
+        got_c = torch.cat([p[3][: p[7] - p[6]] for p in cparts])
+        assert torch.equal(got_c, got)
 
 
 def test_page_rank_pb_split_bins(P, oracle, monkeypatch):
