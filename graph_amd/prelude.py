@@ -54,7 +54,8 @@ class DeviceCsr:
     the per-node accessors of the reference's graph traits."""
 
     def __init__(self, handle):
-        self._h = handle
+        # own a private copy of the pointer value: callers may reuse their ctypes out-parameter
+        self._h = vp(handle.value if isinstance(handle, vp) else handle)
         self._host = None
 
     @classmethod

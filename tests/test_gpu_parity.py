@@ -540,3 +540,55 @@ def test_page_rank_pb_split_bins(P, oracle, monkeypatch):
     np.testing.assert_allclose(split[0], ref_scores, rtol=1.5e-7, atol=0)
     again = P.page_rank(g, P.PageRankConfig(3, 0.0, 0.85), P.PageRankMode.JacobiPB)
     assert np.array_equal(split[0], again[0])
+
+
+# ------------------------------------------------------------------------------------------------
+# remaining C-ABI entry points
+# ------------------------------------------------------------------------------------------------
+def test_abi_upload_u64_wrap_device_and_slices(P, oracle, scale8):
+    import ctypes as C
+
+    import torch
+
+    from graph_amd._lib import GraphMI355XError, check, lib, vp
+
+    s, d, n = scale8
+    ioff, itgt = oracle.csr_build(n, s, d, oracle.INCOMING, oracle.SORTED)
+    ooff, otgt = oracle.csr_build(n, s, d, oracle.OUTGOING, oracle.SORTED)
+    # usize graphs: narrowed at upload (crates/builder/src/index.rs: Idx for usize)
+    g64 = P.DirectedCsrGraph(P.DeviceCsr.from_arrays(ooff.astype(np.uint64), otgt.astype(np.uint64)),
+                             P.DeviceCsr.from_arrays(ioff.astype(np.uint64), itgt.astype(np.uint64)), P.CsrLayout.Sorted)
+    ref = oracle.page_rank_seq(ioff, itgt, oracle.out_degrees_from(n, s))
+    got = P.page_rank(g64)
+    assert np.array_equal(got[0], ref[0]) and got[1] == ref[1]
+    with pytest.raises(GraphMI355XError) as ei:
+        P.DeviceCsr.from_arrays(np.array([0, 1], np.uint64), np.array([5], np.uint64))  # target >= n
+    assert ei.value.status == -2
+    # borrowed device arrays (torch tensors) wrapped without a copy
+    t_off = torch.from_numpy(ioff.astype(np.int32)).cuda()
+    t_tgt = torch.from_numpy(itgt.astype(np.int32)).cuda()
+    h = vp()
+    check(lib().gm_csr_wrap_device(t_off.data_ptr(), t_tgt.data_ptr(), 0, n, itgt.size, 0, C.byref(h)))
+    wrapped = P.DeviceCsr(h)
+    assert lib().gm_csr_offsets_ptr(wrapped.handle) == t_off.data_ptr() and wrapped.n == n and wrapped.m == itgt.size
+    off2, tgt2, _ = wrapped.host()
+    assert np.array_equal(off2, ioff) and np.array_equal(tgt2, itgt)
+    assert np.array_equal(wrapped.degrees(), np.diff(ioff).astype(np.uint32))
+    # row slices: plain, padded-rank remap, explicit map
+    for lo, hi in ((0, n), (17, 200), (255, 256), (5, 5)):
+        check(lib().gm_csr_slice_rows(wrapped.handle, lo, hi, None, 0, 0, C.byref(h)))
+        sl = P.DeviceCsr(h)
+        o, t, _ = sl.host()
+        assert np.array_equal(o, ioff[lo:hi + 1] - ioff[lo]) and np.array_equal(t, itgt[ioff[lo]:ioff[hi]])
+    bounds = np.array([0, 100, 256], np.uint32)
+    check(lib().gm_csr_slice_rows(wrapped.handle, 100, 256, bounds.ctypes.data_as(vp), 2, 160, C.byref(h)))
+    _, t, _ = P.DeviceCsr(h).host()
+    src = itgt[ioff[100]:ioff[256]].astype(np.int64)
+    assert np.array_equal(t, np.where(src < 100, src, 160 + src - 100))
+    with pytest.raises(GraphMI355XError):
+        check(lib().gm_csr_slice_rows(wrapped.handle, 0, 256, bounds.ctypes.data_as(vp), 2, 100, C.byref(h)))  # stride too small
+    node_map = torch.arange(n, dtype=torch.int32, device="cuda").flip(0).contiguous()
+    check(lib().gm_csr_slice_rows_map(wrapped.handle, 10, 20, node_map.data_ptr(), C.byref(h)))
+    _, t, _ = P.DeviceCsr(h).host()
+    assert np.array_equal(t, (n - 1 - itgt[ioff[10]:ioff[20]]))
+    del wrapped
