@@ -17,6 +17,8 @@
 #include "common.hpp"
 #include "device_utils.hpp"
 
+#include <cstdlib>
+
 namespace {
 
 using namespace gm;
@@ -161,7 +163,9 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
 
     uint32_t cur = 0;
     const uint32_t reset[2] = {0u, NO_BUCKET};
+    uint64_t rounds = 0, bucket_moves = 0;
     for (;;) {
+        ++rounds;
         GM_HIP(hipMemcpyAsync(ctrl.p, reset, 8, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(sssp_round_kernel, dim3(grid), dim3(SSSP_BLOCK), 0, st, g->offsets, g->targets, g->weights,
                            dist.as<uint32_t>(), fcur, fnext, n, cur, delta, ctrl.as<uint32_t>());
@@ -177,7 +181,11 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
         if (far == NO_BUCKET)
             break;
         cur = far;
+        ++bucket_moves;
     }
+    if (getenv("GM_SSSP_STATS"))
+        fprintf(stderr, "sssp: %llu rounds, %llu bucket advances, last bucket %u\n", (unsigned long long)rounds,
+                (unsigned long long)bucket_moves, cur);
     GM_HIP(hipMemcpy(distances_out, dist.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return GM_OK;
 }

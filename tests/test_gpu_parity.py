@@ -592,3 +592,38 @@ def test_abi_upload_u64_wrap_device_and_slices(P, oracle, scale8):
     _, t, _ = P.DeviceCsr(h).host()
     assert np.array_equal(t, (n - 1 - itgt[ioff[10]:ioff[20]]))
     del wrapped
+
+
+# ------------------------------------------------------------------------------------------------
+# degenerate inputs (empty / single node / no edges) through every entry point
+# ------------------------------------------------------------------------------------------------
+def test_degenerate_graphs(P, oracle):
+    e = np.zeros(0, np.uint32)
+    for n in (1, 3, 70):
+        g = _directed(P, n, e, e, P.CsrLayout.Sorted)
+        assert g.edge_count() == 0 and g.node_count() == n
+        for mode in (P.PageRankMode.Auto, P.PageRankMode.JacobiPull, P.PageRankMode.JacobiPB, P.PageRankMode.Sequential):
+            scores, it, err = P.page_rank(g, P.PageRankConfig(5, 1e-4, 0.85), mode)
+            # first sweep moves every score from 1/n to (1-d)/n, the second changes nothing
+            base = (np.float32(1.0) - np.float32(0.85)) / np.float32(n)
+            assert it == 2 and err == 0.0 and np.all(scores == base)
+        assert np.array_equal(P.wcc_afforest(g).to_vec(), np.arange(n, dtype=np.uint32))
+        assert np.array_equal(P.wcc_baseline(g).to_vec(), np.arange(n, dtype=np.uint32))
+        ug = P.UndirectedCsrGraph(P.DeviceCsr.from_edges(n, e, e, None, 2, P.CsrLayout.Deduplicated), P.CsrLayout.Deduplicated)
+        assert P.global_triangle_count(ug) == 0
+        P.relabel_graph(ug)
+        assert ug.edge_count() == 0
+        gw = _directed(P, n, e, e, P.CsrLayout.Sorted, np.zeros(0, np.float32))
+        dist = P.delta_stepping(gw, P.DeltaSteppingConfig(n - 1, 0.5))
+        assert dist[n - 1] == 0 and np.all(np.delete(dist, n - 1) == F32_MAX)
+    # a single self-loop and a 2-cycle
+    g = _directed(P, 1, np.array([0], np.uint32), np.array([0], np.uint32), P.CsrLayout.Sorted)
+    ioff, itgt = oracle.csr_build(1, np.array([0], np.uint32), np.array([0], np.uint32), oracle.INCOMING, oracle.SORTED)
+    ref = oracle.page_rank_seq(ioff, itgt, np.array([1], np.uint32))
+    got = P.page_rank(g)
+    assert np.array_equal(got[0], ref[0]) and got[1] == ref[1] and got[2] == ref[2]
+    for mode in (P.PageRankMode.JacobiPull, P.PageRankMode.JacobiPB):
+        s2, d2 = np.array([0, 1], np.uint32), np.array([1, 0], np.uint32)
+        g2 = _directed(P, 2, s2, d2, P.CsrLayout.Sorted)
+        sc, it, _ = P.page_rank(g2, P.PageRankConfig(50, 1e-12, 0.85), mode)
+        assert abs(float(sc[0]) - float(sc[1])) < 1e-7 and 1 <= it <= 50
