@@ -141,6 +141,7 @@ struct gm_csr {
     // once"): PageRank's propagation-blocking plan, keyed by the length of the x vector it was built for.
     mutable std::mutex cache_mu;
     mutable std::map<uint64_t, gm::PbPlan *> pb_plans;
+    mutable uint64_t page_rank_calls = 0; // gm_page_rank calls seen by this handle (engine choice, below)
     ~gm_csr()
     {
         for (auto &kv : pb_plans)
