@@ -71,6 +71,18 @@ int new_owned_csr(uint64_t n, uint64_t m, bool weighted, int device, gm_csr **ou
     return GM_OK;
 }
 
+// deletes the handle under construction on every early return
+struct CsrHolder {
+    gm_csr *c = nullptr;
+    ~CsrHolder() { delete c; }
+    gm_csr *release()
+    {
+        gm_csr *t = c;
+        c = nullptr;
+        return t;
+    }
+};
+
 int check_device(int device)
 {
     int count = 0;
@@ -634,18 +646,16 @@ GM_API int gm_csr_build_device(uint64_t n, uint64_t m, uint64_t d_src, uint64_t 
     GM_TRY(bad.alloc(4));
     GM_HIP(hipMemset(bad.p, 0, 4));
 
-    gm_csr *c = nullptr;
+    CsrHolder hold;
+    gm_csr *&c = hold.c;
     if (total == 0) {
         GM_TRY(new_owned_csr(n, 0, weighted, device, &c));
         GM_HIP(hipMemset(c->own_offsets.p, 0, (n + 1) * 4));
-        *out = c;
+        *out = hold.release();
         return GM_OK;
     }
 
-    auto fail = [&](int rc) {
-        delete c;
-        return rc;
-    };
+    auto fail = [&](int rc) { return rc; }; // `hold` frees the handle
 
     if (layout == GM_LAYOUT_UNSORTED) {
         gm::DevBuf keys, kalt, idx, ialt;
@@ -737,7 +747,7 @@ GM_API int gm_csr_build_device(uint64_t n, uint64_t m, uint64_t d_src, uint64_t 
         gm::set_error("gm_csr_build_device: an edge endpoint is >= node_count (%llu)", (unsigned long long)n);
         return fail(GM_ERR_RANGE);
     }
-    *out = c;
+    *out = hold.release();
     return GM_OK;
 }
 
@@ -810,15 +820,13 @@ GM_API int gm_csr_relabel_by_degree(const gm_csr *g, gm_csr **out, uint32_t *new
              "gm_csr_relabel_by_degree: weighted graphs are not relabelled (reference requires EV: Ord)");
     gm::DeviceGuard guard(g->device);
     const uint64_t n = g->n, m = g->m;
-    gm_csr *c = nullptr;
+    CsrHolder hold;
+    gm_csr *&c = hold.c;
     GM_TRY(new_owned_csr(n, m, false, g->device, &c));
-    auto fail = [&](int rc) {
-        delete c;
-        return rc;
-    };
+    auto fail = [&](int rc) { return rc; }; // `hold` frees the handle
     if (n == 0) {
         GM_HIP(hipMemset(c->own_offsets.p, 0, 4));
-        *out = c;
+        *out = hold.release();
         return GM_OK;
     }
     gm::DevBuf pairs, palt, new_id, new_deg;
@@ -873,6 +881,6 @@ GM_API int gm_csr_relabel_by_degree(const gm_csr *g, gm_csr **out, uint32_t *new
         gm::set_error("gm_csr_relabel_by_degree: sync failed");
         return fail(GM_ERR_HIP);
     }
-    *out = c;
+    *out = hold.release();
     return GM_OK;
 }

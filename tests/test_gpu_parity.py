@@ -561,6 +561,11 @@ def test_abi_upload_u64_wrap_device_and_slices(P, oracle, scale8):
     ref = oracle.page_rank_seq(ioff, itgt, oracle.out_degrees_from(n, s))
     got = P.page_rank(g64)
     assert np.array_equal(got[0], ref[0]) and got[1] == ref[1]
+    # out_degree = NULL: derived on the device from the in-lists
+    sc2 = np.empty(n, np.float32)
+    it2, er2 = C.c_uint64(), C.c_double()
+    check(lib().gm_page_rank(g64.csr_inc.handle, None, 20, 1e-4, 0.85, 0, sc2.ctypes.data_as(vp), C.byref(it2), C.byref(er2)))
+    assert np.array_equal(sc2, ref[0]) and it2.value == ref[1] and er2.value == ref[2]
     with pytest.raises(GraphMI355XError) as ei:
         P.DeviceCsr.from_arrays(np.array([0, 1], np.uint64), np.array([5], np.uint64))  # target >= n
     assert ei.value.status == -2
