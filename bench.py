@@ -184,11 +184,17 @@ def main():
         torch.cuda.synchronize()
 
     if args.prewarm_ms > 0:  # clock ramp: not part of the W warm-up steps, nothing is measured here
-        t_pre = time.perf_counter()
-        while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
-            for _ in range(8):
+        if world > 1 and not emu:
+            # every rank must issue the same number of collectives: a fixed count, not a wall-clock loop
+            for _ in range(64):
                 step()
             torch.cuda.synchronize()
+        else:
+            t_pre = time.perf_counter()
+            while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
+                for _ in range(8):
+                    step()
+                torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     sync_all()
