@@ -203,6 +203,10 @@ def _ragged_graphs(O):
     # exactly one tile worth of rows and edges mixed
     s, d = O.rmat_edges(9, seed=2)
     yield 1 << 9, s, d
+    # tiny: the README graph (13 nodes) and the reference's Graph500 fixture (duplicates, self-loops)
+    yield 13, np.array([e[0] for e in README_EDGES], np.uint32), np.array([e[1] for e in README_EDGES], np.uint32)
+    s, d, n = O.read_graph500(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scale_8.graph500"))
+    yield n, s, d
 
 
 def test_page_rank_jacobi_sweeps_match_oracle_on_ragged_inputs(P, oracle):
