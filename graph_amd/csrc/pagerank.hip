@@ -254,6 +254,43 @@ __global__ __launch_bounds__(PR_BLOCK) void pr_fixup_kernel(
     }
 }
 
+// ---- synchronous sweep with the reference's per-row summation order --------------------------------
+// One lane per row adds out_scores[v] left to right in CSR order with one f32 add per edge — the exact
+// rounding of page_rank.rs:143-146.  Hub rows make it slow; it exists to show that the only
+// difference between the fast engines and the reference at the fixed point is this summation order.
+__global__ __launch_bounds__(PR_BLOCK) void pr_reforder_kernel(const uint32_t *__restrict__ off,
+                                                               const uint32_t *__restrict__ tgt,
+                                                               const float *__restrict__ x_in,
+                                                               const uint32_t *__restrict__ outdeg, float *__restrict__ scores,
+                                                               float *__restrict__ x_out, double *__restrict__ blk_err,
+                                                               uint32_t n, float base, float damping)
+{
+    __shared__ double red[PR_WAVES];
+    const uint32_t stride = gridDim.x * blockDim.x;
+    double err = 0.0;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
+        float sum = 0.0f;
+        for (uint32_t i = off[r]; i < off[r + 1]; ++i)
+            sum = __fadd_rn(sum, x_in[tgt[i]]);
+        err += pr_finalize(r, sum, base, damping, outdeg, scores, x_out);
+    }
+    const double total = block_sum<double, PR_WAVES>(err, red);
+    if (threadIdx.x == 0)
+        blk_err[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void pr_sum_partials_kernel(const double *__restrict__ part, uint32_t count,
+                                                               double *__restrict__ err_out)
+{
+    __shared__ double red[1024 / kWave];
+    double acc = 0.0;
+    for (uint32_t b = threadIdx.x; b < count; b += 1024)
+        acc += part[b];
+    const double total = block_sum<double, 1024 / kWave>(acc, red);
+    if (threadIdx.x == 0)
+        *err_out = total;
+}
+
 // ---- the reference's exact sequential order on one wavefront ----------------------------------
 // X_IN_LDS: out_scores live in LDS (n <= 16384 -> 64 KiB); otherwise in global memory, accessed
 // with L1-bypassing loads/stores so every lane sees lane 0's in-place update.
@@ -335,7 +372,7 @@ GM_API int gm_pr_create_with(const gm_csr *csr, uint64_t n_global, uint64_t row_
     // x_len may be smaller than n_global: a compacted exchange buffer only holds nodes with out-edges
     GM_CHECK(x_len >= 1 && x_len < (1ull << 32), GM_ERR_RANGE, "gm_pr_create: x_len %llu out of range",
              (unsigned long long)x_len);
-    GM_CHECK(engine >= GM_PR_ENGINE_AUTO && engine <= GM_PR_ENGINE_PB, GM_ERR_INVALID, "gm_pr_create: unknown engine %d", engine);
+    GM_CHECK(engine >= GM_PR_ENGINE_AUTO && engine <= GM_PR_ENGINE_REFORDER, GM_ERR_INVALID, "gm_pr_create: unknown engine %d", engine);
     if (engine == GM_PR_ENGINE_AUTO) // below ~16M edges the gathered vector is cache-resident: the pull tiles win
         engine = csr->m >= (1ull << 24) ? GM_PR_ENGINE_PB : GM_PR_ENGINE_PULL;
     gm::DeviceGuard guard(csr->device);
@@ -362,6 +399,19 @@ GM_API int gm_pr_create_with(const gm_csr *csr, uint64_t n_global, uint64_t row_
             return rc;
         }
         pr->T = (uint32_t)gm::pb_work_items(pr->pb);
+        *out = pr;
+        return GM_OK;
+    }
+    if (engine == GM_PR_ENGINE_REFORDER) {
+        pr->G = gm::div_up(csr->n ? csr->n : 1, PR_BLOCK);
+        if (pr->G > 8192)
+            pr->G = 8192;
+        pr->T = pr->G;
+        const int rc = pr->blk_err.alloc((size_t)pr->G * 8);
+        if (rc != GM_OK) {
+            delete pr;
+            return rc;
+        }
         *out = pr;
         return GM_OK;
     }
@@ -431,6 +481,14 @@ GM_API int gm_pr_sweep_tiles(gm_pr *pr, uint64_t d_x_in_global, uint64_t d_x_out
 {
     GM_CHECK(pr, GM_ERR_INVALID, "gm_pr_sweep_tiles: null engine");
     gm::DeviceGuard guard(pr->csr->device);
+    if (pr->engine == GM_PR_ENGINE_REFORDER) {
+        hipLaunchKernelGGL(pr_reforder_kernel, dim3(pr->G), dim3(PR_BLOCK), 0, (hipStream_t)stream, pr->csr->offsets,
+                           pr->csr->targets, reinterpret_cast<const float *>(d_x_in_global), pr->outdeg,
+                           reinterpret_cast<float *>(d_scores_local), reinterpret_cast<float *>(d_x_out_local),
+                           pr->blk_err.as<double>(), pr->n_local, pr->base, pr->damping);
+        GM_HIP(hipGetLastError());
+        return GM_OK;
+    }
     if (pr->engine == GM_PR_ENGINE_PB)
         return gm::pb_sweep_main(pr->pb, pr->pb_scratch, reinterpret_cast<const float *>(d_x_in_global),
                                  reinterpret_cast<float *>(d_x_out_local), reinterpret_cast<float *>(d_scores_local),
@@ -449,6 +507,12 @@ GM_API int gm_pr_sweep_fixup(gm_pr *pr, uint64_t d_x_out_local, uint64_t d_score
 {
     GM_CHECK(pr && d_error_out, GM_ERR_INVALID, "gm_pr_sweep_fixup: null argument");
     gm::DeviceGuard guard(pr->csr->device);
+    if (pr->engine == GM_PR_ENGINE_REFORDER) {
+        hipLaunchKernelGGL(pr_sum_partials_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pr->blk_err.as<double>(),
+                           pr->G, reinterpret_cast<double *>(d_error_out));
+        GM_HIP(hipGetLastError());
+        return GM_OK;
+    }
     if (pr->engine == GM_PR_ENGINE_PB)
         return gm::pb_sweep_error(pr->pb, pr->pb_scratch, reinterpret_cast<double *>(d_error_out), (hipStream_t)stream);
     hipLaunchKernelGGL(pr_fixup_kernel, dim3(pr->G), dim3(PR_BLOCK), 0, (hipStream_t)stream, pr->csr->offsets,
@@ -513,7 +577,7 @@ GM_API int gm_page_rank(const gm_csr *in_csr, const uint32_t *out_degree, uint64
                         double *error_out)
 {
     GM_CHECK(in_csr && iterations_out && error_out, GM_ERR_INVALID, "gm_page_rank: null argument");
-    GM_CHECK(mode >= GM_PR_AUTO && mode <= GM_PR_JACOBI_PB, GM_ERR_INVALID, "gm_page_rank: unknown mode %d", mode);
+    GM_CHECK(mode >= GM_PR_AUTO && mode <= GM_PR_JACOBI_REFORDER, GM_ERR_INVALID, "gm_page_rank: unknown mode %d", mode);
     // page_rank.rs:105-109: the loop only ends on error < tolerance or iteration == max_iterations
     GM_CHECK(max_iterations != 0 || tolerance > 0.0, GM_ERR_INVALID,
              "gm_page_rank: max_iterations == 0 with tolerance <= 0 never terminates (reference: infinite loop)");
@@ -574,7 +638,10 @@ GM_API int gm_page_rank(const gm_csr *in_csr, const uint32_t *out_degree, uint64
     GM_TRY(x0.alloc(n * 4));
     GM_TRY(x1.alloc(n * 4));
     PrHolder ph;
-    int engine = mode == GM_PR_JACOBI_PULL ? GM_PR_ENGINE_PULL : mode == GM_PR_JACOBI_PB ? GM_PR_ENGINE_PB : GM_PR_ENGINE_AUTO;
+    int engine = mode == GM_PR_JACOBI_PULL       ? GM_PR_ENGINE_PULL
+                 : mode == GM_PR_JACOBI_PB       ? GM_PR_ENGINE_PB
+                 : mode == GM_PR_JACOBI_REFORDER ? GM_PR_ENGINE_REFORDER
+                                                 : GM_PR_ENGINE_AUTO;
     if (engine == GM_PR_ENGINE_AUTO) {
         // One-shot economics: building the propagation-blocking plan costs ~85 ms at 2^26 edges and ~260 ms
         // at 2^30, a pull sweep ~m / 100 G/s, a PB sweep ~m / 350 G/s.  So: use the plan if this handle

@@ -21,7 +21,7 @@ class PageRankEngine:
     """page_rank_iteration (crates/algos/src/page_rank.rs:113-168) over rows
     [row_begin, row_begin + n_local) of a graph with n_global nodes; arrays are torch tensors."""
 
-    AUTO, PULL, PB = 0, 1, 2
+    AUTO, PULL, PB, REFORDER = 0, 1, 2, 3
 
     def __init__(self, in_csr_handle, n_global: int, row_begin: int, out_degree_local: torch.Tensor,
                  damping_factor: float = 0.85, x_len: int | None = None, engine: int = 0):
@@ -44,7 +44,7 @@ class PageRankEngine:
 
     @property
     def engine(self) -> str:
-        return {1: "pull", 2: "pb"}[int(lib().gm_pr_engine(self._h))]
+        return {1: "pull", 2: "pb", 3: "reforder"}[int(lib().gm_pr_engine(self._h))]
 
     @property
     def tiles(self) -> int:

@@ -335,6 +335,7 @@ class PageRankMode(enum.IntEnum):
     Sequential = 2
     JacobiPull = 3  # force the pull-tile sweep kernels
     JacobiPB = 4    # force the propagation-blocking sweep kernels
+    JacobiRefOrder = 5  # synchronous sweeps with the reference's left-to-right f32 row sums (parity instrument)
 
 
 def page_rank(graph: DirectedCsrGraph, config: PageRankConfig | None = None, mode=PageRankMode.Auto):

@@ -127,7 +127,10 @@ typedef enum gm_pr_mode {
     GM_PR_JACOBI = 1,      /* synchronous sweeps, engine chosen by size (gm_pr_engine_kind below) */
     GM_PR_SEQUENTIAL = 2,
     GM_PR_JACOBI_PULL = 3, /* synchronous sweeps, force the pull-tile engine */
-    GM_PR_JACOBI_PB = 4    /* synchronous sweeps, force the propagation-blocking engine */
+    GM_PR_JACOBI_PB = 4,   /* synchronous sweeps, force the propagation-blocking engine */
+    GM_PR_JACOBI_REFORDER = 5 /* synchronous sweeps whose row sums are added left to right in f32 in CSR
+                                 order, exactly like page_rank.rs:143-146 (one lane per row: a parity
+                                 instrument, not a fast path) */
 } gm_pr_mode;
 
 int gm_page_rank(const gm_csr *in_csr, const uint32_t *out_degree, uint64_t max_iterations, double tolerance,
@@ -147,7 +150,12 @@ int gm_pr_create(const gm_csr *in_csr_rows /* n_local rows, targets are global i
  *   GM_PR_ENGINE_PB    propagation blocking: values binned by destination range, accumulated in LDS
  *                      as exact 64-bit fixed point — all HBM traffic sequential (large graphs)
  *   GM_PR_ENGINE_AUTO  PB from 2^24 edges up, else PULL */
-typedef enum gm_pr_engine_kind { GM_PR_ENGINE_AUTO = 0, GM_PR_ENGINE_PULL = 1, GM_PR_ENGINE_PB = 2 } gm_pr_engine_kind;
+typedef enum gm_pr_engine_kind {
+    GM_PR_ENGINE_AUTO = 0,
+    GM_PR_ENGINE_PULL = 1,
+    GM_PR_ENGINE_PB = 2,
+    GM_PR_ENGINE_REFORDER = 3 /* per-row left-to-right f32 sums (the reference's rounding); slow, for parity studies */
+} gm_pr_engine_kind;
 int gm_pr_create_with(const gm_csr *in_csr_rows, uint64_t n_global, uint64_t row_begin, uint64_t x_len,
                       uint64_t d_out_degree_local, float damping_factor, int engine, gm_pr **out);
 int gm_pr_engine(const gm_pr *pr); /* the engine actually chosen */

@@ -50,6 +50,11 @@ def test_scale22_page_rank_engines_agree_and_match_reference_order(env, oracle, 
     assert np.all(rel <= np.maximum(1e-5, deg * 2.0 ** -24))            # hubs: the reference order's own drift bound
     print(f"scale 22: {it_pb} sweeps; vs reference order: max rel {rel.max():.2e} overall, "
           f"{rel[deg < 4096].max():.2e} below in-degree 4096 (max in-degree {int(deg.max())})")
+    # the same sweeps with the reference's left-to-right f32 row sums meet 1e-5 on EVERY row, hubs included
+    ro, it_ro, _ = P.page_rank(g, cfg, P.PageRankMode.JacobiRefOrder)
+    rel_ro = np.abs(ro.astype(np.float64) - ref) / ref
+    assert rel_ro.max() <= 1e-5, rel_ro.max()
+    print(f"scale 22, reference summation order: {it_ro} sweeps, max rel vs reference {rel_ro.max():.2e}")
 
 
 def test_scale22_wcc_bit_exact(env, oracle, rmat22):

@@ -636,3 +636,30 @@ def test_degenerate_graphs(P, oracle):
         g2 = _directed(P, 2, s2, d2, P.CsrLayout.Sorted)
         sc, it, _ = P.page_rank(g2, P.PageRankConfig(50, 1e-12, 0.85), mode)
         assert abs(float(sc[0]) - float(sc[1])) < 1e-7 and 1 <= it <= 50
+
+
+@pytest.mark.parametrize("scale", [14, 18])
+def test_page_rank_reference_summation_order_closes_the_hub_gap(P, oracle, scale):
+    """With the reference's own row-sum order (left to right in f32, page_rank.rs:143-146) the synchronous
+    HIP sweeps reach the reference's fixed point on EVERY node, hubs included: the residual of the fast
+    engines on hub rows is exactly that summation order, nothing else."""
+    s, d = oracle.rmat_edges(scale, seed=42)
+    n = 1 << scale
+    g = _directed(P, n, s, d, P.CsrLayout.Sorted)
+    (_, _), (ioff, itgt) = _oracle_directed(oracle, n, s, d, oracle.SORTED)
+    od = oracle.out_degrees_from(n, s)
+    ref, _, _ = oracle.page_rank_chunked(ioff, itgt, od, 300, 1e-12, 0.85)
+    got, it, err = P.page_rank(g, P.PageRankConfig(300, 1e-12, 0.85), P.PageRankMode.JacobiRefOrder)
+    rel = np.abs(got.astype(np.float64) - ref) / ref
+    assert rel.max() <= 1e-5, rel.max()          # north_star tolerance, all rows
+    fast, _, _ = P.page_rank(g, P.PageRankConfig(300, 1e-12, 0.85), P.PageRankMode.JacobiPB)
+    rel_fast = np.abs(fast.astype(np.float64) - ref) / ref
+    print(f"scale {scale}: vs reference order — RefOrder sweeps {rel.max():.2e}, PB engine {rel_fast.max():.2e}")
+    # one sweep from the initial state is bit-identical to the oracle's synchronous sweep in CSR order
+    one, _, e1 = P.page_rank(g, P.PageRankConfig(1, 0.0, 0.85), P.PageRankMode.JacobiRefOrder)
+    init = np.float32(1.0) / np.float32(n)
+    sc0 = np.full(n, init, np.float32)
+    with np.errstate(divide="ignore"):
+        outs0 = (init / od.astype(np.float32)).astype(np.float32)
+    _, e_ref = oracle.page_rank_jacobi_sweep(ioff, itgt, od, 0.85, sc0, outs0)
+    assert np.array_equal(one, sc0) and abs(e1 - e_ref) <= 1e-12 * e_ref
