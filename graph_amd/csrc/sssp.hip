@@ -24,7 +24,7 @@ namespace {
 using namespace gm;
 
 constexpr int SSSP_BLOCK = 256;
-constexpr uint32_t SSSP_COOP = 32;
+constexpr uint32_t SSSP_COOP = 32; // lists longer than this are relaxed by the whole wavefront
 constexpr uint32_t SSSP_INF_BITS = 0x7F7FFFFFu; // f32::MAX
 constexpr uint32_t NO_BUCKET = 0xFFFFFFFFu;
 
@@ -57,42 +57,57 @@ __device__ __forceinline__ void relax_edge(uint32_t *dist, uint8_t *__restrict__
     }
 }
 
+// One round.  A wavefront takes 256 consecutive nodes at a time: a 4-byte flag load per lane decides
+// whether anything in the group is flagged (in the long tail of rounds almost nothing is), then each
+// 64-node quarter is relaxed one lane per node.
 __global__ __launch_bounds__(SSSP_BLOCK) void sssp_round_kernel(
     const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const float *__restrict__ w, uint32_t *dist,
     uint8_t *__restrict__ flag_cur, uint8_t *__restrict__ flag_next, uint32_t n, uint32_t cur, float delta,
     uint32_t *__restrict__ ctrl /* [0] again, [1] min far bucket */)
 {
     const uint32_t lane = threadIdx.x & (kWave - 1);
-    const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t n_pad = (n + kWave - 1) / kWave * kWave;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t ngroups = (n + 255u) >> 8; // the flag arrays are padded to a multiple of 256 bytes
+    const uint32_t *flag_words = reinterpret_cast<const uint32_t *>(flag_cur);
     RelaxOut ro{0u, NO_BUCKET};
-    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n_pad; u += stride) {
-        uint32_t s = 0, e = 0;
-        float du = 0.0f;
-        if (u < n && flag_cur[u]) {
-            flag_cur[u] = 0; // this lane is the only reader/writer of flag_cur[u] in this round
-            du = __uint_as_float(ld_agent(&dist[u]));
-            const uint32_t b = bucket_of(du, delta);
-            if (b <= cur) {
-                s = off[u];
-                e = off[u + 1];
-            } else { // not yet its turn: carry over
-                flag_next[u] = 1;
-                ro.far = b < ro.far ? b : ro.far;
+    for (uint32_t grp = wave; grp < ngroups; grp += nwaves) {
+        const uint32_t word = flag_words[grp * 64u + lane];
+        if (__ballot(word != 0u) == 0ull)
+            continue;
+        for (uint32_t quarter = 0; quarter < 4; ++quarter) {
+            // lanes whose word covers this quarter: bytes [quarter*64, quarter*64+64) = words quarter*16 .. +16
+            const uint32_t u = (grp << 8) + quarter * 64u + lane;
+            uint32_t s = 0, e = 0;
+            float du = 0.0f;
+            if (u < n && flag_cur[u]) {
+                flag_cur[u] = 0; // this lane is the only reader/writer of flag_cur[u] in this round
+                du = __uint_as_float(ld_agent(&dist[u]));
+                const uint32_t b = bucket_of(du, delta);
+                if (b <= cur) {
+                    s = off[u];
+                    e = off[u + 1];
+                } else { // not yet its turn: carry over
+                    flag_next[u] = 1;
+                    ro.far = b < ro.far ? b : ro.far;
+                }
             }
-        }
-        const uint32_t len = e - s;
-        if (len <= SSSP_COOP)
-            for (uint32_t i = s; i < e; ++i)
-                relax_edge(dist, flag_next, du, tgt[i], w[i], cur, delta, ro);
-        uint64_t big = __ballot(len > SSSP_COOP);
-        while (big) {
-            const int src = __ffsll((unsigned long long)big) - 1;
-            big &= big - 1;
-            const uint32_t bs = __shfl(s, src, kWave), be = __shfl(e, src, kWave);
-            const float bd = __shfl(du, src, kWave);
-            for (uint32_t i = bs + lane; i < be; i += kWave)
-                relax_edge(dist, flag_next, bd, tgt[i], w[i], cur, delta, ro);
+            // short lists by their own lane, lists longer than 32 edges by the whole wavefront (measured:
+            // an edge-balanced expansion with a shuffle search per edge was 25 % slower — the round is bound
+            // by the random dist[] accesses, not by the target stream)
+            const uint32_t len = e - s;
+            if (len <= SSSP_COOP)
+                for (uint32_t i = s; i < e; ++i)
+                    relax_edge(dist, flag_next, du, tgt[i], w[i], cur, delta, ro);
+            uint64_t big = __ballot(len > SSSP_COOP);
+            while (big) {
+                const int src = __ffsll((unsigned long long)big) - 1;
+                big &= big - 1;
+                const uint32_t bs = __shfl(s, src, kWave), be = __shfl(e, src, kWave);
+                const float bd = __shfl(du, src, kWave);
+                for (uint32_t i = bs + lane; i < be; i += kWave)
+                    relax_edge(dist, flag_next, bd, tgt[i], w[i], cur, delta, ro);
+            }
         }
     }
     const uint32_t far = wave_min(ro.far);
@@ -137,7 +152,8 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
     gm::DevBuf dist, flags, ctrl;
     gm::PinnedBuf hctrl;
     GM_TRY(dist.alloc((size_t)n * 4));
-    GM_TRY(flags.alloc((size_t)n * 2));
+    const size_t n_flags = ((size_t)n + 255) & ~(size_t)255; // the round kernel reads flags 4 bytes per lane
+    GM_TRY(flags.alloc(n_flags * 2));
     GM_TRY(ctrl.alloc(16));
     GM_TRY(hctrl.alloc(16));
     hipStream_t st = 0;
@@ -153,8 +169,8 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
     }
     hipLaunchKernelGGL(sssp_init_kernel, dim3(grid), dim3(SSSP_BLOCK), 0, st, dist.as<uint32_t>(), n,
                        (uint32_t)start_node);
-    GM_HIP(hipMemsetAsync(flags.p, 0, (size_t)n * 2, st));
-    uint8_t *fcur = flags.as<uint8_t>(), *fnext = flags.as<uint8_t>() + n;
+    GM_HIP(hipMemsetAsync(flags.p, 0, n_flags * 2, st));
+    uint8_t *fcur = flags.as<uint8_t>(), *fnext = flags.as<uint8_t>() + n_flags;
     GM_HIP(hipMemsetAsync(fcur + start_node, 1, 1, st));
     GM_HIP(hipMemcpyAsync(hctrl.p, ctrl.p, 16, hipMemcpyDeviceToHost, st));
     GM_HIP(hipStreamSynchronize(st));
