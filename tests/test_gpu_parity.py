@@ -663,3 +663,18 @@ def test_page_rank_reference_summation_order_closes_the_hub_gap(P, oracle, scale
         outs0 = (init / od.astype(np.float32)).astype(np.float32)
     _, e_ref = oracle.page_rank_jacobi_sweep(ioff, itgt, od, 0.85, sc0, outs0)
     assert np.array_equal(one, sc0) and abs(e1 - e_ref) <= 1e-12 * e_ref
+
+
+def test_page_rank_pb_split_bins_stress(P, oracle, monkeypatch):
+    """The slice hand-off (partials + ticket + agent-scope release/acquire) under load: thousands of
+    split bins, 60 sweeps, every score compared bit for bit with the unsplit run."""
+    s, d = oracle.rmat_edges(19, seed=3)
+    n = 1 << 19
+    whole = P.page_rank(_directed(P, n, s, d, P.CsrLayout.Sorted), P.PageRankConfig(60, 0.0, 0.85), P.PageRankMode.JacobiPB)
+    for split in ("1024", "20000"):
+        monkeypatch.setenv("GM_PB_SPLIT", split)
+        g = _directed(P, n, s, d, P.CsrLayout.Sorted)
+        for _ in range(2):
+            got = P.page_rank(g, P.PageRankConfig(60, 0.0, 0.85), P.PageRankMode.JacobiPB)
+            assert np.array_equal(got[0], whole[0]), split
+            assert abs(got[2] - whole[2]) <= 1e-12 * whole[2]
