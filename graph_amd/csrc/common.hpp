@@ -3,7 +3,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -119,6 +121,43 @@ struct DeviceGuard {
 };
 
 inline unsigned div_up(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
+
+// GM_LOG=1: phase timings on stderr, the counterpart of the reference's `log::info!` lines
+// (page_rank.rs:95-100, wcc.rs:132-182, sssp.rs:99).  Costs a stream synchronisation per phase.
+inline bool log_enabled()
+{
+    static const bool on = [] {
+        const char *v = getenv("GM_LOG");
+        return v && *v && *v != '0';
+    }();
+    return on;
+}
+
+struct PhaseTimer { // wall clock around stream-ordered work; only active under GM_LOG
+    hipStream_t st;
+    std::chrono::steady_clock::time_point t0;
+    explicit PhaseTimer(hipStream_t s) : st(s)
+    {
+        if (log_enabled()) {
+            (void)hipStreamSynchronize(st);
+            t0 = std::chrono::steady_clock::now();
+        }
+    }
+    void done(const char *fmt, ...) __attribute__((format(printf, 2, 3)))
+    {
+        if (!log_enabled())
+            return;
+        (void)hipStreamSynchronize(st);
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        char buf[256];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        fprintf(stderr, "[graph_mi355x] %s took %.3f ms\n", buf, ms);
+        t0 = std::chrono::steady_clock::now();
+    }
+};
 
 } // namespace gm
 

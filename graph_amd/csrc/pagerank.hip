@@ -661,7 +661,14 @@ GM_API int gm_page_rank(const gm_csr *in_csr, const uint32_t *out_degree, uint64
     float *xin = x0.as<float>(), *xout = x1.as<float>();
     const bool can_stop_early = tolerance > 0.0; // error >= 0 always
     for (;;) {
+        gm::PhaseTimer timer(st);
         GM_TRY(gm_pr_sweep(ph.p, (uint64_t)xin, (uint64_t)xout, (uint64_t)scores.p, (uint64_t)dres.p, st));
+        if (gm::log_enabled()) { // page_rank.rs:95-100: "Finished iteration {} with an error of {:.6} in {:?}"
+            double e = 0.0;
+            (void)hipMemcpyAsync(&e, dres.p, 8, hipMemcpyDeviceToHost, st);
+            (void)hipStreamSynchronize(st);
+            timer.done("Finished iteration %llu with an error of %.6f;", (unsigned long long)iter, e);
+        }
         iter += 1;
         float *tmp = xin;
         xin = xout;

@@ -182,15 +182,21 @@ int wcc_device(const gm_csr *out_csr, const gm_csr *in_csr, uint64_t rounds, uin
     gm::DevBuf scratch;
     GM_TRY(scratch.alloc((sampling + 1) * 4));
     uint32_t *d_skip = scratch.as<uint32_t>() + sampling;
+    gm::PhaseTimer timer(st); // phase names as logged by the reference, wcc.rs:164-182
     hipLaunchKernelGGL(wcc_sample_kernel, dim3(grid), dim3(WCC_BLOCK), 0, st, out_csr->offsets, out_csr->targets,
                        d_parent, n, rounds);
+    timer.done("Link subgraph");
     hipLaunchKernelGGL(wcc_compress_kernel, dim3(grid), dim3(WCC_BLOCK), 0, st, d_parent, n);
+    timer.done("Sample compress");
     hipLaunchKernelGGL(wcc_sample_mode_kernel, dim3(1), dim3(WCC_BLOCK), 0, st, d_parent, n, (uint32_t)sampling,
                        (uint64_t)0x2545F4914F6CDD1Dull, scratch.as<uint32_t>(), d_skip);
+    timer.done("Get component");
     hipLaunchKernelGGL(wcc_link_remaining_kernel, dim3(grid), dim3(WCC_BLOCK), 0, st, out_csr->offsets,
                        out_csr->targets, in_csr->offsets, in_csr->targets, d_parent, n, rounds,
                        (const uint32_t *)d_skip);
+    timer.done("Link remaining");
     hipLaunchKernelGGL(wcc_compress_kernel, dim3(grid), dim3(WCC_BLOCK), 0, st, d_parent, n);
+    timer.done("Final compress");
     GM_HIP(hipGetLastError());
     GM_HIP(hipStreamSynchronize(st)); // scratch is freed on return
     return GM_OK;
