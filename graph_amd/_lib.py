@@ -55,6 +55,8 @@ SIGNATURES = {
     "gm_pr_tile_count": (u64, [vp]),
     "gm_wcc_afforest": (i32, [vp, vp, u64, u64, vp]),
     "gm_wcc_baseline": (i32, [vp, vp]),
+    "gm_wcc_init_labels": (i32, [u64, u64, i32, vp]),
+    "gm_wcc_link_rows": (i32, [vp, vp, u64, u64, u64, vp]),
     "gm_sssp_delta_stepping": (i32, [vp, u64, f32, vp]),
     "gm_triangle_count": (i32, [vp, C.POINTER(u64)]),
     "gm_rmat_edges_device": (i32, [u32, u64, u64, u64, u64, u64, i32, vp]),

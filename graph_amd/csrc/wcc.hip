@@ -98,25 +98,27 @@ __device__ __forceinline__ void wcc_link_list(const uint32_t *__restrict__ tgt, 
 // with rounds = 0 and no in-CSR)
 __global__ __launch_bounds__(WCC_BLOCK) void wcc_link_remaining_kernel(
     const uint32_t *__restrict__ out_off, const uint32_t *__restrict__ out_tgt, const uint32_t *__restrict__ in_off,
-    const uint32_t *__restrict__ in_tgt, uint32_t *parent, uint32_t n, uint64_t rounds, const uint32_t *skip_ptr)
+    const uint32_t *__restrict__ in_tgt, uint32_t *parent, uint32_t n, uint64_t rounds, const uint32_t *skip_ptr,
+    uint32_t row_base = 0 /* node id of CSR row 0 (row slices of a partitioned graph) */)
 {
     const uint32_t skip = skip_ptr ? *skip_ptr : 0xFFFFFFFFu;
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t n_pad = (n + kWave - 1) / kWave * kWave; // whole wavefronts enter the loop together
-    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n_pad; u += stride) {
-        const bool active = u < n && ld_agent(&parent[u]) != skip;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_pad; r += stride) {
+        const uint32_t u = row_base + r;
+        const bool active = r < n && ld_agent(&parent[u]) != skip;
         uint32_t s = 0, e = 0;
         if (active) {
-            s = out_off[u];
-            e = out_off[u + 1];
+            s = out_off[r];
+            e = out_off[r + 1];
             s = (uint64_t)(e - s) > rounds ? s + (uint32_t)rounds : e;
         }
         wcc_link_list(out_tgt, parent, u, s, e);
         if (in_off) {
             s = e = 0;
             if (active) {
-                s = in_off[u];
-                e = in_off[u + 1];
+                s = in_off[r];
+                e = in_off[r + 1];
             }
             wcc_link_list(in_tgt, parent, u, s, e);
         }
@@ -238,5 +240,44 @@ GM_API int gm_wcc_baseline(const gm_csr *out_csr, uint32_t *components_out)
     GM_TRY(parent.alloc(n * 4));
     GM_TRY(gm::wcc_device(out_csr, nullptr, 0, 0, false, parent.as<uint32_t>(), 0));
     GM_HIP(hipMemcpy(components_out, parent.p, n * 4, hipMemcpyDeviceToHost));
+    return GM_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Building blocks of the partitioned run (labels replicated, every rank links the edges
+// of its own rows, min-all-reduce of the label vector between rounds until nothing changes).
+// ------------------------------------------------------------------------------------------------
+GM_API int gm_wcc_init_labels(uint64_t n, uint64_t d_parent, int device, void *stream)
+{
+    GM_CHECK(d_parent || n == 0, GM_ERR_INVALID, "gm_wcc_init_labels: null labels");
+    GM_CHECK(n < (1ull << 32), GM_ERR_RANGE, "gm_wcc_init_labels: n exceeds u32");
+    if (n == 0)
+        return GM_OK;
+    gm::DeviceGuard guard(device);
+    hipLaunchKernelGGL(wcc_init_kernel, dim3(wcc_grid(n)), dim3(WCC_BLOCK), 0, (hipStream_t)stream,
+                       reinterpret_cast<uint32_t *>(d_parent), (uint32_t)n);
+    GM_HIP(hipGetLastError());
+    return GM_OK;
+}
+
+GM_API int gm_wcc_link_rows(const gm_csr *out_rows, const gm_csr *in_rows, uint64_t row_begin, uint64_t n_global,
+                            uint64_t d_parent, void *stream)
+{
+    GM_CHECK(out_rows && d_parent, GM_ERR_INVALID, "gm_wcc_link_rows: null argument");
+    GM_CHECK(!in_rows || in_rows->n == out_rows->n, GM_ERR_INVALID, "gm_wcc_link_rows: out/in slices disagree");
+    GM_CHECK(row_begin + out_rows->n <= n_global && n_global < (1ull << 32), GM_ERR_RANGE,
+             "gm_wcc_link_rows: rows [%llu, %llu) outside a graph of %llu nodes", (unsigned long long)row_begin,
+             (unsigned long long)(row_begin + out_rows->n), (unsigned long long)n_global);
+    gm::DeviceGuard guard(out_rows->device);
+    uint32_t *parent = reinterpret_cast<uint32_t *>(d_parent);
+    hipStream_t st = (hipStream_t)stream;
+    if (out_rows->n)
+        hipLaunchKernelGGL(wcc_link_remaining_kernel, dim3(wcc_grid(out_rows->n)), dim3(WCC_BLOCK), 0, st,
+                           out_rows->offsets, out_rows->targets, in_rows ? in_rows->offsets : (const uint32_t *)nullptr,
+                           in_rows ? in_rows->targets : (const uint32_t *)nullptr, parent, (uint32_t)out_rows->n,
+                           (uint64_t)0, (const uint32_t *)nullptr, (uint32_t)row_begin);
+    hipLaunchKernelGGL(wcc_compress_kernel, dim3(wcc_grid(n_global)), dim3(WCC_BLOCK), 0, st, parent, (uint32_t)n_global);
+    GM_HIP(hipGetLastError());
     return GM_OK;
 }

@@ -121,3 +121,21 @@ def page_rank_partitioned(engine, n_global: int, n_local: int, stride: int, max_
             if error < tolerance or last:
                 break
     return scores[:n_local], iteration, error
+
+
+def wcc_partitioned(link_rows, labels: torch.Tensor, group=None, max_rounds: int = 64):
+    """Partitioned WCC: `labels` (int32/uint32 view of u32[n], replicated, initialised to
+    0..n-1) is updated in place.  link_rows(labels) links the edges of this rank's rows into the local
+    replica and compresses it; then the replicas are min-all-reduced; repeat until no rank changed
+    anything.  Labels only ever decrease and every value is a node of the same component, so the loop
+    ends with labels[u] = minimum node id of u's component on every rank.  Returns the number of rounds."""
+    changed = torch.zeros(1, dtype=torch.int32, device=labels.device)
+    for rounds in range(1, max_rounds + 1):
+        before = labels.clone()
+        link_rows(labels)
+        dist.all_reduce(labels, op=dist.ReduceOp.MIN, group=group)
+        changed[0] = int(not torch.equal(before, labels))
+        dist.all_reduce(changed, op=dist.ReduceOp.MAX, group=group)
+        if int(changed.item()) == 0:
+            return rounds
+    raise RuntimeError("wcc_partitioned did not converge")

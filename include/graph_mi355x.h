@@ -189,6 +189,14 @@ uint64_t gm_pr_tile_count(const gm_pr *pr); /* workgroups per sweep (diagnostics
 int gm_wcc_afforest(const gm_csr *out_csr, const gm_csr *in_csr, uint64_t neighbor_rounds,
                     uint64_t sampling_size, uint32_t *components_out /* n, host */);
 int gm_wcc_baseline(const gm_csr *out_csr, uint32_t *components_out);
+/* Partitioned run (labels replicated on every GPU, u32[n_global] in HBM): gm_wcc_init_labels sets
+ * label[i] = i; gm_wcc_link_rows links every edge of a rank's row slice(s) (row r of the slice is node
+ * row_begin + r; targets are global ids; in_rows may be NULL) into the labels and compresses them.
+ * Between rounds the ranks min-all-reduce the label vector (graph_amd/distributed.py:wcc_partitioned);
+ * the fixed point is label[u] = minimum node id of u's component, as in the single-GPU path. */
+int gm_wcc_init_labels(uint64_t n, uint64_t d_labels, int device, void *stream);
+int gm_wcc_link_rows(const gm_csr *out_rows, const gm_csr *in_rows, uint64_t row_begin, uint64_t n_global,
+                     uint64_t d_labels, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * SSSP — replaces delta_stepping(&G, DeltaSteppingConfig{start_node, delta}) -> Vec<AtomicF32>,

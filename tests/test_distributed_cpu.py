@@ -131,3 +131,63 @@ def test_pad_bounds_and_partition_edge_cases():
     b, stride = pad_bounds(r, 4, 4)
     assert b[0] == 0 and b[-1] == 4 and stride >= 1 and len(b) == 5
     assert greedy_degree_partition(np.zeros(1, np.uint32), 2) == []
+
+
+def _wcc_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    from graph_amd.distributed import wcc_partitioned
+
+    s, d = O.rmat_edges(9, seed=11)
+    n = 1 << 9
+    lo, hi = rank * n // world, (rank + 1) * n // world
+    mine = (s >= lo) & (s < hi)  # this rank owns the out-edges of its rows
+    es, ed = s[mine].astype(np.int64), d[mine].astype(np.int64)
+
+    def link_rows(labels):  # numpy stand-in for gm_wcc_link_rows: min-label hooking + full compression
+        lab = labels.numpy()
+        changed = True
+        while changed:
+            changed = False
+            for a, b in zip(es, ed):
+                ra, rb = a, b
+                while lab[ra] != ra:
+                    ra = lab[ra]
+                while lab[rb] != rb:
+                    rb = lab[rb]
+                if ra != rb:
+                    lab[max(ra, rb)] = min(ra, rb)
+                    changed = True
+        for v in range(n):
+            r = v
+            while lab[r] != r:
+                r = lab[r]
+            lab[v] = r
+
+    labels = torch.arange(n, dtype=torch.int32)
+    rounds = wcc_partitioned(link_rows, labels)
+    q.put((rank, labels.numpy().copy(), rounds))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_partitioned_wcc_driver_gloo(oracle):
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_wcc_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    s, d = oracle.rmat_edges(9, seed=11)
+    n = 1 << 9
+    ooff, otgt = oracle.csr_build(n, s, d, oracle.OUTGOING, oracle.SORTED)
+    ioff, itgt = oracle.csr_build(n, s, d, oracle.INCOMING, oracle.SORTED)
+    ref = oracle.wcc(ooff, otgt, ioff, itgt)
+    for rank, lab, rounds in results:
+        assert np.array_equal(lab.astype(np.uint32), ref) and 1 <= rounds <= 10

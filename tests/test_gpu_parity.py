@@ -678,3 +678,48 @@ def test_page_rank_pb_split_bins_stress(P, oracle, monkeypatch):
             got = P.page_rank(g, P.PageRankConfig(60, 0.0, 0.85), P.PageRankMode.JacobiPB)
             assert np.array_equal(got[0], whole[0]), split
             assert abs(got[2] - whole[2]) <= 1e-12 * whole[2]
+
+
+def test_wcc_partitioned_virtual_ranks(P, oracle, scale8):
+    """Row-sliced WCC with replicated labels and a min-reduction between rounds, with 3
+    virtual ranks on one GPU: elementwise torch.minimum stands in for ncclAllReduce(min)."""
+    import ctypes as C
+
+    import torch
+
+    from graph_amd._lib import check, lib, vp
+
+    for s, d, n in (scale8, oracle.rmat_edges(15, seed=5) + (1 << 15,)):
+        g = _directed(P, n, s, d, P.CsrLayout.Sorted)
+        expect = P.wcc_afforest(g).to_vec()
+        world = 3
+        cuts = [0, n // 5, n // 2, n]
+        slices = []
+        for r in range(world):
+            ho, hi_ = vp(), vp()
+            check(lib().gm_csr_slice_rows(g.csr_out.handle, cuts[r], cuts[r + 1], None, 0, 0, C.byref(ho)))
+            check(lib().gm_csr_slice_rows(g.csr_inc.handle, cuts[r], cuts[r + 1], None, 0, 0, C.byref(hi_)))
+            slices.append((P.DeviceCsr(ho), P.DeviceCsr(hi_)))
+        labels = [torch.empty(n, dtype=torch.int32, device="cuda") for _ in range(world)]
+        for lab in labels:
+            check(lib().gm_wcc_init_labels(n, lab.data_ptr(), 0, None))
+        rounds = 0
+        while True:
+            rounds += 1
+            before = labels[0].clone()
+            for r in range(world):
+                check(lib().gm_wcc_link_rows(slices[r][0].handle, slices[r][1].handle, cuts[r], n, labels[r].data_ptr(), None))
+            merged = torch.minimum(torch.minimum(labels[0], labels[1]), labels[2])
+            for lab in labels:
+                lab.copy_(merged)
+            if torch.equal(before, merged):
+                break
+            assert rounds < 20
+        assert np.array_equal(merged.cpu().numpy().view(np.uint32), expect)
+        # out-slices alone (wcc_baseline semantics) reach the same labels
+        lab = torch.empty(n, dtype=torch.int32, device="cuda")
+        check(lib().gm_wcc_init_labels(n, lab.data_ptr(), 0, None))
+        for _ in range(rounds + 1):
+            for r in range(world):
+                check(lib().gm_wcc_link_rows(slices[r][0].handle, None, cuts[r], n, lab.data_ptr(), None))
+        assert np.array_equal(lab.cpu().numpy().view(np.uint32), expect)
