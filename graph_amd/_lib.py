@@ -58,6 +58,8 @@ SIGNATURES = {
     "gm_wcc_init_labels": (i32, [u64, u64, i32, vp]),
     "gm_wcc_link_rows": (i32, [vp, vp, u64, u64, u64, vp]),
     "gm_sssp_delta_stepping": (i32, [vp, u64, f32, vp]),
+    "gm_sssp_init_distances": (i32, [u64, u64, u64, i32, vp]),
+    "gm_sssp_relax_rows": (i32, [vp, u64, u64, u64, u64, vp]),
     "gm_triangle_count": (i32, [vp, C.POINTER(u64)]),
     "gm_rmat_edges_device": (i32, [u32, u64, u64, u64, u64, u64, i32, vp]),
     "gm_rmat_weights_device": (i32, [u64, u64, u64, u64, i32, vp]),

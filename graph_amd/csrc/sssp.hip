@@ -120,6 +120,53 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_round_kernel(
     }
 }
 
+// Partitioned building block: relax every out-edge of the slice's rows whose distance is finite
+// (row r of the slice is node row_base + r).  changed[0] is set when any distance improved.
+__global__ __launch_bounds__(SSSP_BLOCK) void sssp_relax_rows_kernel(const uint32_t *__restrict__ off,
+                                                                     const uint32_t *__restrict__ tgt,
+                                                                     const float *__restrict__ w, uint32_t *dist,
+                                                                     uint32_t rows, uint32_t row_base,
+                                                                     uint32_t *__restrict__ changed)
+{
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t rows_pad = (rows + kWave - 1) / kWave * kWave;
+    bool improved = false;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < rows_pad; r += stride) {
+        uint32_t s = 0, e = 0;
+        float du = 0.0f;
+        if (r < rows) {
+            const uint32_t bits = ld_agent(&dist[row_base + r]);
+            if (bits != SSSP_INF_BITS) {
+                du = __uint_as_float(bits);
+                s = off[r];
+                e = off[r + 1];
+            }
+        }
+        const uint32_t len = e - s;
+        if (len <= SSSP_COOP)
+            for (uint32_t i = s; i < e; ++i) {
+                const uint32_t nb = __float_as_uint(__fadd_rn(du, w[i]));
+                if (nb < ld_agent(&dist[tgt[i]]) && nb < atomicMin(&dist[tgt[i]], nb))
+                    improved = true;
+            }
+        uint64_t big = __ballot(len > SSSP_COOP);
+        while (big) {
+            const int src = __ffsll((unsigned long long)big) - 1;
+            big &= big - 1;
+            const uint32_t bs = __shfl(s, src, kWave), be = __shfl(e, src, kWave);
+            const float bd = __shfl(du, src, kWave);
+            for (uint32_t i = bs + lane; i < be; i += kWave) {
+                const uint32_t nb = __float_as_uint(__fadd_rn(bd, w[i]));
+                if (nb < ld_agent(&dist[tgt[i]]) && nb < atomicMin(&dist[tgt[i]], nb))
+                    improved = true;
+            }
+        }
+    }
+    if (__ballot(improved) && lane == 0)
+        atomicOr(changed, 1u);
+}
+
 __global__ void sssp_init_kernel(uint32_t *__restrict__ dist, uint32_t n, uint32_t start)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -203,5 +250,46 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
         fprintf(stderr, "sssp: %llu rounds, %llu bucket advances, last bucket %u\n", (unsigned long long)rounds,
                 (unsigned long long)bucket_moves, cur);
     GM_HIP(hipMemcpy(distances_out, dist.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return GM_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Building blocks of the partitioned run (distances replicated as u32 bit patterns, every
+// rank relaxes the out-edges of its own rows, min-all-reduce between rounds until nothing changes).
+// The result is the same least fixed point as gm_sssp_delta_stepping — schedule-free.
+// ------------------------------------------------------------------------------------------------
+GM_API int gm_sssp_init_distances(uint64_t n, uint64_t start_node, uint64_t d_dist_bits, int device, void *stream)
+{
+    GM_CHECK(d_dist_bits, GM_ERR_INVALID, "gm_sssp_init_distances: null distances");
+    GM_CHECK(start_node < n && n < (1ull << 32), GM_ERR_RANGE, "gm_sssp_init_distances: start_node %llu >= node_count %llu",
+             (unsigned long long)start_node, (unsigned long long)n);
+    gm::DeviceGuard guard(device);
+    unsigned grid = gm::div_up(n, SSSP_BLOCK);
+    if (grid > 256 * 8)
+        grid = 256 * 8;
+    hipLaunchKernelGGL(sssp_init_kernel, dim3(grid), dim3(SSSP_BLOCK), 0, (hipStream_t)stream,
+                       reinterpret_cast<uint32_t *>(d_dist_bits), (uint32_t)n, (uint32_t)start_node);
+    GM_HIP(hipGetLastError());
+    return GM_OK;
+}
+
+GM_API int gm_sssp_relax_rows(const gm_csr *out_rows, uint64_t row_begin, uint64_t n_global, uint64_t d_dist_bits,
+                              uint64_t d_changed, void *stream)
+{
+    GM_CHECK(out_rows && d_dist_bits && d_changed, GM_ERR_INVALID, "gm_sssp_relax_rows: null argument");
+    GM_CHECK(out_rows->weights || out_rows->m == 0, GM_ERR_INVALID, "gm_sssp_relax_rows: the CSR carries no weights");
+    GM_CHECK(row_begin + out_rows->n <= n_global && n_global < (1ull << 32), GM_ERR_RANGE,
+             "gm_sssp_relax_rows: rows outside the graph");
+    if (out_rows->n == 0)
+        return GM_OK;
+    gm::DeviceGuard guard(out_rows->device);
+    unsigned grid = gm::div_up(out_rows->n, SSSP_BLOCK);
+    if (grid > 256 * 8)
+        grid = 256 * 8;
+    hipLaunchKernelGGL(sssp_relax_rows_kernel, dim3(grid), dim3(SSSP_BLOCK), 0, (hipStream_t)stream, out_rows->offsets,
+                       out_rows->targets, out_rows->weights, reinterpret_cast<uint32_t *>(d_dist_bits),
+                       (uint32_t)out_rows->n, (uint32_t)row_begin, reinterpret_cast<uint32_t *>(d_changed));
+    GM_HIP(hipGetLastError());
     return GM_OK;
 }

@@ -139,3 +139,24 @@ def wcc_partitioned(link_rows, labels: torch.Tensor, group=None, max_rounds: int
         if int(changed.item()) == 0:
             return rounds
     raise RuntimeError("wcc_partitioned did not converge")
+
+
+def sssp_partitioned(relax_rows, dist_bits: torch.Tensor, group=None, max_rounds: int = 100000):
+    """Partitioned SSSP: `dist_bits` (int32 view of the u32 bit patterns of non-negative
+    f32 distances, replicated; f32::MAX everywhere except 0 at the start node) is updated in place.
+    relax_rows(dist_bits) -> bool runs one relaxation pass over this rank's rows and tells whether any
+    distance improved.  Each round: local passes to a local fixed point, then an integer min-all-reduce
+    (bit patterns of non-negative floats order like the floats); stop when no rank improved anything.
+    The result is the least fixed point — identical to delta_stepping.  Returns the number of rounds."""
+    flag = torch.zeros(1, dtype=torch.int32, device=dist_bits.device)
+    for rounds in range(1, max_rounds + 1):
+        improved = False
+        while relax_rows(dist_bits):
+            improved = True
+        before = dist_bits.clone()
+        dist.all_reduce(dist_bits, op=dist.ReduceOp.MIN, group=group)
+        flag[0] = int(improved or not torch.equal(before, dist_bits))
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        if int(flag.item()) == 0:
+            return rounds
+    raise RuntimeError("sssp_partitioned did not converge")

@@ -204,6 +204,15 @@ int gm_wcc_link_rows(const gm_csr *out_rows, const gm_csr *in_rows, uint64_t row
  * f32::MAX (sssp.rs:12), not inf.  start_node >= n -> GM_ERR_RANGE (the reference panics, :52).
  * ------------------------------------------------------------------------------------------- */
 int gm_sssp_delta_stepping(const gm_csr *out_csr, uint64_t start_node, float delta, float *distances_out);
+/* Partitioned run (distances replicated on every GPU as u32 bit patterns of non-negative f32, so an
+ * integer min-all-reduce orders them): gm_sssp_init_distances fills f32::MAX and 0 at the start node;
+ * gm_sssp_relax_rows relaxes every out-edge of a rank's weighted row slice whose source is reached and
+ * ORs 1 into *d_changed (u32, device) when a distance improved.  graph_amd/distributed.py:
+ * sssp_partitioned alternates local passes and min-all-reduces until nothing changes — the same least
+ * fixed point as gm_sssp_delta_stepping. */
+int gm_sssp_init_distances(uint64_t n, uint64_t start_node, uint64_t d_dist_bits, int device, void *stream);
+int gm_sssp_relax_rows(const gm_csr *out_rows, uint64_t row_begin, uint64_t n_global, uint64_t d_dist_bits,
+                       uint64_t d_changed, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Triangle count — replaces global_triangle_count(&G) -> u64, crates/algos/src/triangle_count.rs:22-86,

@@ -191,3 +191,57 @@ def test_partitioned_wcc_driver_gloo(oracle):
     ref = oracle.wcc(ooff, otgt, ioff, itgt)
     for rank, lab, rounds in results:
         assert np.array_equal(lab.astype(np.uint32), ref) and 1 <= rounds <= 10
+
+
+def _sssp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    from graph_amd.distributed import sssp_partitioned
+
+    s, d = O.rmat_edges(9, seed=13)
+    w = O.rmat_weights(s.size, seed=44)
+    n = 1 << 9
+    off, tgt, wv = O.csr_build(n, s, d, O.OUTGOING, O.SORTED, w)
+    start = int(np.flatnonzero(np.diff(off) > 0)[0])
+    lo, hi = rank * n // world, (rank + 1) * n // world
+    inf_bits = np.array([np.finfo(np.float32).max], np.float32).view(np.int32)[0]
+
+    def relax_rows(bits):  # numpy stand-in for gm_sssp_relax_rows over rows [lo, hi)
+        dv = bits.numpy().view(np.float32)
+        improved = False
+        for u in range(lo, hi):
+            if bits[u] == inf_bits:
+                continue
+            for i in range(off[u], off[u + 1]):
+                nd = np.float32(dv[u] + wv[i])
+                if nd < dv[tgt[i]]:
+                    dv[tgt[i]] = nd
+                    improved = True
+        return improved
+
+    bits = torch.full((n,), int(inf_bits), dtype=torch.int32)
+    bits[start] = 0
+    rounds = sssp_partitioned(relax_rows, bits)
+    q.put((rank, bits.numpy().view(np.float32).copy(), rounds, start))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_partitioned_sssp_driver_gloo(oracle):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sssp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    s, d = oracle.rmat_edges(9, seed=13)
+    w = oracle.rmat_weights(s.size, seed=44)
+    off, tgt, wv = oracle.csr_build(1 << 9, s, d, oracle.OUTGOING, oracle.SORTED, w)
+    for rank, dv, rounds, start in results:
+        assert np.array_equal(dv, oracle.delta_stepping(off, tgt, wv, start, 0.25)) and rounds >= 1

@@ -723,3 +723,52 @@ def test_wcc_partitioned_virtual_ranks(P, oracle, scale8):
             for r in range(world):
                 check(lib().gm_wcc_link_rows(slices[r][0].handle, None, cuts[r], n, lab.data_ptr(), None))
         assert np.array_equal(lab.cpu().numpy().view(np.uint32), expect)
+
+
+def test_sssp_partitioned_virtual_ranks(P, oracle):
+    """Row-sliced SSSP with replicated distances and a min-reduction between rounds, 3
+    virtual ranks on one GPU; bit-exact with delta_stepping (the least fixed point is schedule-free)."""
+    import ctypes as C
+
+    import torch
+
+    from graph_amd._lib import check, lib, vp
+
+    scale, n = 14, 1 << 14
+    s, d = oracle.rmat_edges(scale, seed=42)
+    w = oracle.rmat_weights(s.size, seed=44)
+    g = _directed(P, n, s, d, P.CsrLayout.Sorted, w)
+    start = int(np.flatnonzero(g.csr_out.degrees() > 0)[0])
+    expect = P.delta_stepping(g, P.DeltaSteppingConfig(start, 0.1))
+    world, cuts = 3, [0, n // 4, n // 2, n]
+    slices = []
+    for r in range(world):
+        h = vp()
+        check(lib().gm_csr_slice_rows(g.csr_out.handle, cuts[r], cuts[r + 1], None, 0, 0, C.byref(h)))
+        slices.append(P.DeviceCsr(h))
+    dist = [torch.empty(n, dtype=torch.int32, device="cuda") for _ in range(world)]
+    changed = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for x in dist:
+        check(lib().gm_sssp_init_distances(n, start, x.data_ptr(), 0, None))
+    rounds = 0
+    while True:
+        rounds += 1
+        improved = False
+        for r in range(world):
+            while True:
+                changed.zero_()
+                check(lib().gm_sssp_relax_rows(slices[r].handle, cuts[r], n, dist[r].data_ptr(), changed.data_ptr(), None))
+                if int(changed.item()) == 0:
+                    break
+                improved = True
+        merged = torch.minimum(torch.minimum(dist[0], dist[1]), dist[2])  # stands in for ncclAllReduce(min)
+        moved = any(not torch.equal(merged, x) for x in dist)
+        for x in dist:
+            x.copy_(merged)
+        if not improved and not moved:
+            break
+        assert rounds < 1000
+    got = merged.cpu().numpy().view(np.float32)
+    assert np.array_equal(got, expect)
+    with pytest.raises(Exception):
+        check(lib().gm_sssp_init_distances(n, n, dist[0].data_ptr(), 0, None))
