@@ -41,6 +41,7 @@ SIGNATURES = {
     "gm_csr_build_host": (i32, [u64, u64, vp, vp, vp, i32, i32, i32, PP]),
     "gm_csr_slice_rows": (i32, [vp, u64, u64, vp, u32, u32, PP]),
     "gm_csr_slice_rows_map": (i32, [vp, u64, u64, u64, PP]),
+    "gm_csr_to_undirected": (i32, [vp, i32, PP]),
     "gm_csr_relabel_by_degree": (i32, [vp, PP, vp]),
     "gm_page_rank": (i32, [vp, vp, u64, f64, f32, i32, vp, C.POINTER(u64), C.POINTER(f64)]),
     "gm_pr_create": (i32, [vp, u64, u64, u64, f32, PP]),

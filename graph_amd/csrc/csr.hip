@@ -774,6 +774,55 @@ GM_API int gm_csr_build_host(uint64_t n, uint64_t m, const uint32_t *src, const 
 }
 
 // ------------------------------------------------------------------------------------------------
+// to_undirected (crates/builder/src/graph_ops.rs:176-230, csr.rs:391-464): an Undirected build over the
+// out-edges of a directed graph, entirely on the device.
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void expand_rows_kernel(const uint32_t *__restrict__ off, uint32_t n,
+                                                          uint32_t *__restrict__ src)
+{
+    const uint32_t lane = threadIdx.x & (gm::kWave - 1);
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t n_pad = (n + gm::kWave - 1) / gm::kWave * gm::kWave;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_pad; r += stride) {
+        uint32_t s = 0, e = 0;
+        if (r < n) {
+            s = off[r];
+            e = off[r + 1];
+        }
+        const uint32_t len = e - s;
+        if (len <= 32)
+            for (uint32_t i = s; i < e; ++i)
+                src[i] = r;
+        uint64_t big = __ballot(len > 32);
+        while (big) {
+            const int from = __ffsll((unsigned long long)big) - 1;
+            big &= big - 1;
+            const uint32_t br = __shfl(r, from, gm::kWave), bs = __shfl(s, from, gm::kWave), be = __shfl(e, from, gm::kWave);
+            for (uint32_t i = bs + lane; i < be; i += gm::kWave)
+                src[i] = br;
+        }
+    }
+}
+} // namespace
+
+GM_API int gm_csr_to_undirected(const gm_csr *out_csr, int layout, gm_csr **out)
+{
+    GM_CHECK(out_csr && out, GM_ERR_INVALID, "gm_csr_to_undirected: null argument");
+    gm::DeviceGuard guard(out_csr->device);
+    gm::DevBuf src;
+    GM_TRY(src.alloc(out_csr->m * 4));
+    if (out_csr->m) {
+        hipLaunchKernelGGL(expand_rows_kernel, dim3(stream_grid(out_csr->n)), dim3(256), 0, 0, out_csr->offsets,
+                           (uint32_t)out_csr->n, src.as<uint32_t>());
+        GM_HIP(hipGetLastError());
+        GM_HIP(hipDeviceSynchronize());
+    }
+    return gm_csr_build_device(out_csr->n, out_csr->m, (uint64_t)src.p, (uint64_t)out_csr->targets,
+                               (uint64_t)out_csr->weights, GM_DIR_UNDIRECTED, layout, out_csr->device, out);
+}
+
+// ------------------------------------------------------------------------------------------------
 // make_degree_ordered (crates/builder/src/graph_ops.rs:511-638) on the device
 // ------------------------------------------------------------------------------------------------
 namespace {

@@ -177,10 +177,9 @@ class DirectedCsrGraph(_GraphBase):
         """ToUndirectedOp (crates/builder/src/graph_ops.rs:176-230, csr.rs:391-464): an Undirected
         build over this graph's out-edges."""
         layout = self.layout if layout is None else layout
-        off, tgt, w = self.csr_out.host()
-        src = np.repeat(np.arange(self._n, dtype=np.uint32), np.diff(off))
-        csr = DeviceCsr.from_edges(self._n, src, tgt, w, Direction.Undirected, layout)
-        return UndirectedCsrGraph(csr, layout)
+        h = vp()
+        check(lib().gm_csr_to_undirected(self.csr_out.handle, int(layout), C.byref(h)))
+        return UndirectedCsrGraph(DeviceCsr(h), layout)
 
 
 class UndirectedCsrGraph(_GraphBase):

@@ -89,6 +89,9 @@ int gm_csr_build_device(uint64_t n, uint64_t m, uint64_t d_src, uint64_t d_dst, 
  * counterpart of GraphBuilder::new().csr_layout(l).edges(..).build(), crates/builder/src/builder.rs:123-540. */
 int gm_csr_build_host(uint64_t n, uint64_t m, const uint32_t *src, const uint32_t *dst, const float *weights,
                       int direction, int layout, int device, gm_csr **out);
+/* ToUndirectedOp::to_undirected(layout), crates/builder/src/graph_ops.rs:176-230 + csr.rs:391-464: an
+ * Undirected build over the out-edges of a directed graph's out-CSR, on the device. */
+int gm_csr_to_undirected(const gm_csr *out_csr, int layout, gm_csr **out);
 /* RelabelByDegreeOp::make_degree_ordered, crates/builder/src/graph_ops.rs:511-638: returns a new
  * handle; new_id_out (host, n, optional) receives old id -> new id. */
 int gm_csr_relabel_by_degree(const gm_csr *undirected, gm_csr **out, uint32_t *new_id_out);

@@ -86,6 +86,8 @@ public:
     const gm_csr *csr_out() const { return out_.get(); }
     const gm_csr *csr_inc() const { return inc_.get(); }
     CsrLayout layout() const { return layout_; }
+    // ToUndirectedOp::to_undirected (crates/builder/src/graph_ops.rs:176-230); defined after UndirectedCsrGraph
+    template <class U = NI> auto to_undirected(CsrLayout layout) const;
 
 private:
     void check_node(NI u) const { if ((uint64_t)u >= gm_csr_node_count(out_.get())) throw Error(GM_ERR_RANGE, "node id out of range"); }
@@ -120,6 +122,13 @@ private:
     CsrLayout layout_;
     mutable detail::HostCsr host_;
 };
+
+template <class NI> template <class U> auto DirectedCsrGraph<NI>::to_undirected(CsrLayout layout) const
+{
+    gm_csr *c = nullptr;
+    detail::check(gm_csr_to_undirected(out_.get(), (int)layout, &c));
+    return UndirectedCsrGraph<U>(detail::CsrPtr(c), layout);
+}
 
 // GraphBuilder::new().csr_layout(..).edges(..).build()   (crates/builder/src/builder.rs:123-540)
 class GraphBuilder {

@@ -49,6 +49,8 @@ int main()
                                            0.024999997f, 0.035624996f, 0.06590624f};
             EXPECT(bits_equal(scores, expected));
             EXPECT(g.out_degree(0) == 2 && g.in_degree(2) == 2 && g.out_neighbors(0)[1] == 2);
+            auto ug = g.to_undirected(CsrLayout::Deduplicated); // two directed triangles -> 2 triangles
+            EXPECT(ug.edge_count() == 6 && global_triangle_count(ug) == 2);
             (void)iterations;
             (void)error;
         }
