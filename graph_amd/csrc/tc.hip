@@ -28,32 +28,51 @@ using namespace gm;
 constexpr int TC_BLOCK = 256;
 constexpr int TC_WAVES = TC_BLOCK / kWave;
 
-// flags[0] |= 1 if some list is not sorted ascending, |= 2 if some list has equal neighbours
-__global__ void tc_low_len_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, uint32_t n,
-                                  uint32_t *__restrict__ low_len /* n+1 */, uint32_t *__restrict__ flags)
+// flags[0] |= 1 if some list is not sorted ascending, |= 2 if some list has equal neighbours.
+// One lane per node; the order check of lists longer than 32 entries is spread over the wavefront.
+__global__ __launch_bounds__(TC_BLOCK) void tc_low_len_kernel(const uint32_t *__restrict__ off,
+                                                              const uint32_t *__restrict__ tgt, uint32_t n,
+                                                              uint32_t *__restrict__ low_len /* n+1 */,
+                                                              uint32_t *__restrict__ flags)
 {
+    const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t n_pad = (n + 1 + kWave - 1) / kWave * kWave;
     uint32_t f = 0;
-    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u <= n; u += stride) {
-        if (u == n) {
+    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n_pad; u += stride) {
+        uint32_t s = 0, e = 0;
+        if (u < n) {
+            s = off[u];
+            e = off[u + 1];
+            uint32_t lo = s, hi = e; // first position with tgt > u
+            while (lo < hi) {
+                const uint32_t mid = lo + ((hi - lo) >> 1);
+                if (tgt[mid] <= u)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            low_len[u] = lo - s;
+        } else if (u == n) {
             low_len[u] = 0;
-            continue;
         }
-        const uint32_t s = off[u], e = off[u + 1];
-        // first position with tgt > u
-        uint32_t lo = s, hi = e;
-        while (lo < hi) {
-            const uint32_t mid = lo + ((hi - lo) >> 1);
-            if (tgt[mid] <= u)
-                lo = mid + 1;
-            else
-                hi = mid;
-        }
-        low_len[u] = lo - s;
-        for (uint32_t i = s + 1; i < e; ++i) {
-            const uint32_t a = tgt[i - 1], b = tgt[i];
-            f |= (a > b) ? 1u : 0u;
-            f |= (a == b) ? 2u : 0u;
+        const uint32_t len = e - s;
+        if (len <= 32)
+            for (uint32_t i = s + 1; i < e; ++i) {
+                const uint32_t a = tgt[i - 1], b = tgt[i];
+                f |= (a > b) ? 1u : 0u;
+                f |= (a == b) ? 2u : 0u;
+            }
+        uint64_t big = __ballot(len > 32);
+        while (big) {
+            const int src = __ffsll((unsigned long long)big) - 1;
+            big &= big - 1;
+            const uint32_t bs = __shfl(s, src, kWave), be = __shfl(e, src, kWave);
+            for (uint32_t i = bs + 1 + lane; i < be; i += kWave) {
+                const uint32_t a = tgt[i - 1], b = tgt[i];
+                f |= (a > b) ? 1u : 0u;
+                f |= (a == b) ? 2u : 0u;
+            }
         }
     }
     if (f)
