@@ -156,23 +156,48 @@ __global__ __launch_bounds__(TC_BLOCK) void tc_count_kernel(const uint32_t *__re
 {
     __shared__ uint64_t red[TC_WAVES];
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint64_t dag_pad = (dag_m + kWave - 1) / kWave * kWave; // whole wavefronts iterate together
     uint64_t count = 0;
-    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < dag_m; k += stride) {
-        const uint32_t u = dag_src[k], v = dag_tgt[k];
-        if (STRICT && v < K && v < u) {
-            // lists are sets: |L(u) ∩ L(v)| = number of w in L(u), w < v, with bit (v, w) set; the w < v
-            // are exactly the entries of L(u) in front of this one — one load per candidate, no search
-            const uint32_t *lu = dag_tgt + loff[u];
-            const uint32_t rank = (uint32_t)(k - loff[u]);
-            const uint64_t row = (uint64_t)v * (v - 1) / 2;
-            uint32_t c = 0;
-            for (uint32_t i = 0; i < rank; ++i) {
-                const uint64_t b = row + lu[i];
-                c += (bits[b >> 5] >> (b & 31)) & 1u;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < dag_pad; k += stride) {
+        const bool live = k < dag_m;
+        const uint32_t u = live ? dag_src[k] : 0u, v = live ? dag_tgt[k] : 0u;
+        bool handled = !live;
+        if (STRICT) {
+            // lists are sets: |L(u) ∩ L(v)| = number of w in L(u), w < v, with bit (v, w) set; the w < v are
+            // exactly the entries of L(u) in front of this one — one load per candidate, no search.
+            // Short prefixes by the owning lane, long ones spread over the wavefront.
+            const bool bitmap = live && v < K && v < u;
+            const uint32_t lo_u = bitmap ? loff[u] : 0u;
+            const uint32_t rank = bitmap ? (uint32_t)(k - lo_u) : 0u;
+            const uint64_t row = (uint64_t)v * (v ? v - 1 : 0) / 2;
+            if (bitmap && rank <= 64) {
+                const uint32_t *lu = dag_tgt + lo_u;
+                uint32_t c = 0;
+                for (uint32_t i = 0; i < rank; ++i) {
+                    const uint64_t b = row + lu[i];
+                    c += (bits[b >> 5] >> (b & 31)) & 1u;
+                }
+                count += c;
             }
-            count += c;
-            continue;
+            uint64_t big = __ballot(bitmap && rank > 64);
+            while (big) {
+                const int src = __ffsll((unsigned long long)big) - 1;
+                big &= big - 1;
+                const uint32_t b_lo = __shfl(lo_u, src, kWave), b_rank = __shfl(rank, src, kWave);
+                const uint64_t b_row = __shfl(row, src, kWave);
+                const uint32_t *lu = dag_tgt + b_lo;
+                uint32_t c = 0;
+                for (uint32_t i = lane; i < b_rank; i += kWave) {
+                    const uint64_t b = b_row + lu[i];
+                    c += (bits[b >> 5] >> (b & 31)) & 1u;
+                }
+                count += c; // the total is a plain sum: any lane may carry any part of it
+            }
+            handled = handled || bitmap;
         }
+        if (handled)
+            continue;
         const uint32_t *lu = dag_tgt + loff[u];
         const uint32_t *lv = dag_tgt + loff[v];
         uint32_t nu = loff[u + 1] - loff[u], nv = loff[v + 1] - loff[v];
