@@ -643,15 +643,15 @@ GM_API int gm_page_rank(const gm_csr *in_csr, const uint32_t *out_degree, uint64
                  : mode == GM_PR_JACOBI_REFORDER ? GM_PR_ENGINE_REFORDER
                                                  : GM_PR_ENGINE_AUTO;
     if (engine == GM_PR_ENGINE_AUTO) {
-        // One-shot economics: building the propagation-blocking plan costs ~85 ms at 2^26 edges and ~260 ms
-        // at 2^30, a pull sweep ~m / 100 G/s, a PB sweep ~m / 350 G/s.  So: use the plan if this handle
-        // already has one; build it straight away only where ~20 sweeps repay it (>= 2^29 edges); otherwise
+        // One-shot economics: building the propagation-blocking plan costs ~27 ms at 2^26 edges and ~120 ms
+        // at 2^30, a pull sweep ~m / 100 G/s (far less beyond 2^28 edges), a PB sweep ~m / 350 G/s.  So: use the
+        // plan if this handle already has one; build it straight away where ~20 sweeps repay it (>= 2^28 edges); otherwise
         // run this call on the pull tiles and build the plan on the second call of the same graph (the
         // reference's app runs 5 warm-ups + N timed runs on one graph, crates/app/src/app.rs:124-153).
         std::lock_guard<std::mutex> lock(in_csr->cache_mu);
         const uint64_t calls = ++in_csr->page_rank_calls;
         const bool cached = in_csr->pb_plans.count(n) != 0;
-        const bool big = in_csr->m >= (1ull << 29), mid = in_csr->m >= (1ull << 24);
+        const bool big = in_csr->m >= (1ull << 28), mid = in_csr->m >= (1ull << 24);
         engine = (cached || big || (mid && calls >= 2)) ? GM_PR_ENGINE_PB : GM_PR_ENGINE_PULL;
     }
     GM_TRY(gm_pr_create_with(in_csr, n, 0, n, (uint64_t)outdeg.p, damping_factor, engine, &ph.p));

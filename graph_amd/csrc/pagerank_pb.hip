@@ -104,15 +104,16 @@ namespace {
 
 // ---- plan construction ---------------------------------------------------------------------------
 // key = bin << (sb + rb) | src << rb | row_in_bin      (sorted ascending = bin-major, then source, then row)
-constexpr uint64_t PB_HOT_KEY = 1ull << 63; // hot-edge keys sort behind every cold key
-// hot key: PB_HOT_KEY | bin << 32 | hot index << 16 | row_in_bin
-__device__ __forceinline__ uint64_t pb_make_key(uint64_t hi_cold, uint32_t r, uint32_t slot, uint32_t src, int rb,
-                                                const uint16_t *__restrict__ hot_rank)
+// cold key: bin << (sb+rb) | src << rb | slot.   hot key: 1 << (bin_bits+sb+rb) | bin << (sb+rb) | hot index << rb
+// | slot (the hot index is < x_len, so it fits the source field) — the flag bit sits just above the cold key, so
+// hot keys sort behind every cold key, bin-major; only bits [0, bin_bits+sb+rb] take part in the sort.
+__device__ __forceinline__ uint64_t pb_make_key(uint64_t hi_cold, uint32_t r, uint32_t slot, uint32_t src, int rb, int sb,
+                                                int hot_bit, const uint16_t *__restrict__ hot_rank)
 {
     if (hot_rank) {
         const uint16_t h = hot_rank[src];
         if (h != PB_NULL)
-            return PB_HOT_KEY | ((uint64_t)(r >> rb) << 32) | ((uint64_t)h << 16) | slot;
+            return (1ull << hot_bit) | ((uint64_t)(r >> rb) << (sb + rb)) | ((uint64_t)h << rb) | slot;
     }
     return hi_cold | ((uint64_t)src << rb);
 }
@@ -139,10 +140,13 @@ __global__ void pb_cidx_kernel(const uint32_t *__restrict__ off, const uint32_t 
     }
 }
 
-__global__ void pb_count_sources_kernel(const uint32_t *__restrict__ tgt, uint32_t m, uint32_t *__restrict__ cnt)
+// occurrences of every source among (a sample of) the edges: every `step`-th edge is counted — the H most
+// frequent sources of a 1/8 sample are the same hubs, and any choice of hot set is correct
+__global__ void pb_count_sources_kernel(const uint32_t *__restrict__ tgt, uint32_t m, uint32_t step,
+                                        uint32_t *__restrict__ cnt)
 {
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride)
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * step;
+    for (uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * step; i < m; i += stride)
         atomicAdd(&cnt[tgt[i]], 1u);
 }
 
@@ -169,13 +173,16 @@ __global__ void pb_hot_select_kernel(const uint64_t *__restrict__ sorted, uint32
 }
 
 __global__ void pb_hot_fill_kernel(const uint64_t *__restrict__ hkeys, uint32_t mh, const uint32_t *__restrict__ hstart,
-                                   const uint32_t *__restrict__ hbin_v, uint32_t *__restrict__ hot_ent)
+                                   const uint32_t *__restrict__ hbin_v, int bin_shift, uint32_t bin_mask, int rb,
+                                   uint32_t *__restrict__ hot_ent)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < mh; i += stride) {
         const uint64_t k = hkeys[i];
-        const uint32_t bin = (uint32_t)((k >> 32) & 0x7FFFFFFFu);
-        hot_ent[hbin_v[bin] + (i - hstart[bin])] = ((uint32_t)k & 0xFFFFu) << 16 | (uint32_t)((k >> 16) & 0xFFFFu);
+        const uint32_t bin = (uint32_t)(k >> bin_shift) & bin_mask;
+        const uint32_t slot = (uint32_t)k & ((1u << rb) - 1u);
+        const uint32_t h = (uint32_t)((k >> rb) & ((1ull << (bin_shift - rb)) - 1ull));
+        hot_ent[hbin_v[bin] + (i - hstart[bin])] = (slot << 16) | h;
     }
 }
 
@@ -195,7 +202,8 @@ __global__ void pb_hot_gather_kernel(const float *__restrict__ x_in, const uint3
 }
 
 __global__ __launch_bounds__(256) void pb_keys_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt,
-                                                      uint32_t n, int rb, int sb, const uint16_t *__restrict__ hot_rank,
+                                                      uint32_t n, int rb, int sb, int hot_bit,
+                                                      const uint16_t *__restrict__ hot_rank,
                                                       const uint16_t *__restrict__ cidx, uint64_t *__restrict__ keys)
 {
     const uint32_t lane = threadIdx.x & (kWave - 1);
@@ -213,7 +221,7 @@ __global__ __launch_bounds__(256) void pb_keys_kernel(const uint32_t *__restrict
         const uint32_t len = e - s;
         if (len <= 32)
             for (uint32_t i = s; i < e; ++i)
-                keys[i] = pb_make_key(hi, r, slot, tgt[i], rb, hot_rank);
+                keys[i] = pb_make_key(hi, r, slot, tgt[i], rb, sb, hot_bit, hot_rank);
         uint64_t big = __ballot(len > 32);
         while (big) {
             const int src = __ffsll((unsigned long long)big) - 1;
@@ -222,7 +230,7 @@ __global__ __launch_bounds__(256) void pb_keys_kernel(const uint32_t *__restrict
             const uint64_t bhi = __shfl(hi, src, kWave);
             const uint32_t br = __shfl(r, src, kWave), bslot = __shfl(slot, src, kWave);
             for (uint32_t i = bs + lane; i < be; i += kWave)
-                keys[i] = pb_make_key(bhi, br, bslot, tgt[i], rb, hot_rank);
+                keys[i] = pb_make_key(bhi, br, bslot, tgt[i], rb, sb, hot_bit, hot_rank);
         }
     }
 }
@@ -672,14 +680,14 @@ int scan_inclusive_u32(const uint32_t *in, uint32_t *out, uint64_t count)
     return GM_OK;
 }
 
-int sort_keys_u64(DevBuf &keys, DevBuf &alt, uint64_t count, int end_bit)
+int sort_keys_u64(DevBuf &keys, DevBuf &alt, uint64_t count, int begin_bit, int end_bit)
 {
     rocprim::double_buffer<uint64_t> db(keys.as<uint64_t>(), alt.as<uint64_t>());
     size_t tmp_bytes = 0;
-    GM_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, db, count, 0u, (unsigned)end_bit, (hipStream_t)0));
+    GM_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, db, count, (unsigned)begin_bit, (unsigned)end_bit, (hipStream_t)0));
     DevBuf tmp;
     GM_TRY(tmp.alloc(tmp_bytes));
-    GM_HIP(rocprim::radix_sort_keys(tmp.p, tmp_bytes, db, count, 0u, (unsigned)end_bit, (hipStream_t)0));
+    GM_HIP(rocprim::radix_sort_keys(tmp.p, tmp_bytes, db, count, (unsigned)begin_bit, (unsigned)end_bit, (hipStream_t)0));
     GM_HIP(hipDeviceSynchronize());
     if (db.current() != keys.as<uint64_t>())
         std::swap(keys, alt);
@@ -792,6 +800,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     const int bin_bits = bits_for(pl->B) < 1 ? 1 : bits_for(pl->B);
     GM_CHECK(bin_bits + sb + rb <= 63, GM_ERR_RANGE, "pb_build: key does not fit 63 bits");
 
+    gm::PhaseTimer timer((hipStream_t)0); // GM_LOG=1: where the plan construction time goes
     // accumulator slots only for rows that have in-edges (RMAT: about half of the rows have none)
     GM_TRY(pl->cidx.alloc((size_t)(n ? n : 1) * 2));
     pl->Racc = 1;
@@ -852,6 +861,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
         return GM_OK;
     }
 
+    timer.done("pb plan: accumulator slots");
     // ---- hot sources: the H most frequent source ids (>= 2 edges) of this rank's edges ----------------
     DevBuf hot_rank;
     if (H) {
@@ -864,8 +874,9 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
         GM_HIP(hipMemset(cnt.p, 0, (size_t)x_len * 4));
         GM_HIP(hipMemset(heff.p, 0, 4));
         GM_HIP(hipMemset(hot_rank.p, 0xFF, (size_t)x_len * 2));
-        hipLaunchKernelGGL(pb_count_sources_kernel, dim3(pb_grid(m_all)), dim3(256), 0, 0, csr->targets, m_all,
-                           cnt.as<uint32_t>());
+        const uint32_t sample_step = m_all > (1u << 26) ? 8u : 1u;
+        hipLaunchKernelGGL(pb_count_sources_kernel, dim3(pb_grid(m_all / sample_step + 1)), dim3(256), 0, 0, csr->targets,
+                           m_all, sample_step, cnt.as<uint32_t>());
         hipLaunchKernelGGL(pb_count_keys_kernel, dim3(pb_grid(x_len)), dim3(256), 0, 0, cnt.as<uint32_t>(), (uint32_t)x_len,
                            ckeys.as<uint64_t>());
         GM_HIP(hipGetLastError());
@@ -889,22 +900,27 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
             hot_rank.release();
     }
     pl->H = H;
+    timer.done("pb plan: hot source selection");
 
     DevBuf keys, kalt;
     GM_TRY(keys.alloc((size_t)m_all * 8));
     GM_TRY(kalt.alloc((size_t)m_all * 8));
-    hipLaunchKernelGGL(pb_keys_kernel, dim3(pb_grid(n)), dim3(256), 0, 0, csr->offsets, csr->targets, n, rb, sb,
+    const int hot_bit = bin_bits + sb + rb; // <= 63
+    hipLaunchKernelGGL(pb_keys_kernel, dim3(pb_grid(n)), dim3(256), 0, 0, csr->offsets, csr->targets, n, rb, sb, hot_bit,
                        H ? hot_rank.as<uint16_t>() : (const uint16_t *)nullptr, pl->cidx.as<uint16_t>(),
                        keys.as<uint64_t>());
     GM_HIP(hipGetLastError());
-    GM_TRY(sort_keys_u64(keys, kalt, m_all, H ? 64 : bin_bits + sb + rb));
+    // (sorting only bits [rb, ..) would do — the slot order inside a (bin, source) is irrelevant — but rocPRIM's
+    // radix sort was measured 14x slower with a non-zero begin bit at this size)
+    GM_TRY(sort_keys_u64(keys, kalt, m_all, 0, H ? hot_bit + 1 : hot_bit));
     kalt.release();
     hot_rank.release();
+    timer.done("pb plan: edge keys + sort");
 
     if (H) { // hot keys (top bit set) sit behind the cold ones, already ordered by (bin, hot index, row)
         DevBuf split;
         GM_TRY(split.alloc(3 * 4));
-        hipLaunchKernelGGL(pb_bounds_kernel, dim3(pb_grid(m_all)), dim3(256), 0, 0, keys.as<uint64_t>(), m_all, 63, 2u,
+        hipLaunchKernelGGL(pb_bounds_kernel, dim3(pb_grid(m_all)), dim3(256), 0, 0, keys.as<uint64_t>(), m_all, hot_bit, 2u,
                            split.as<uint32_t>(), 0xFFFFFFFFu);
         GM_HIP(hipGetLastError());
         GM_HIP(hipMemcpy(&m, split.as<uint32_t>() + 1, 4, hipMemcpyDeviceToHost));
@@ -914,8 +930,9 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
             DevBuf hstart, hpad;
             GM_TRY(hstart.alloc(((size_t)pl->B + 1) * 4));
             GM_TRY(hpad.alloc(((size_t)pl->B + 1) * 4));
-            hipLaunchKernelGGL(pb_bounds_kernel, dim3(pb_grid(mh)), dim3(256), 0, 0, hkeys, mh, 32, pl->B,
-                               hstart.as<uint32_t>(), 0x7FFFFFFFu);
+            const uint32_t bin_mask = (uint32_t)((1ull << bin_bits) - 1ull);
+            hipLaunchKernelGGL(pb_bounds_kernel, dim3(pb_grid(mh)), dim3(256), 0, 0, hkeys, mh, sb + rb, pl->B,
+                               hstart.as<uint32_t>(), bin_mask);
             hipLaunchKernelGGL(pb_pad4_sizes_kernel, dim3(pb_grid((uint64_t)pl->B + 1)), dim3(256), 0, 0,
                                hstart.as<uint32_t>(), pl->B, hpad.as<uint32_t>());
             GM_HIP(hipGetLastError());
@@ -926,7 +943,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
             GM_TRY(pl->hot_ent.alloc((size_t)Mh * 4));
             GM_HIP(hipMemset(pl->hot_ent.p, 0xFF, (size_t)Mh * 4));
             hipLaunchKernelGGL(pb_hot_fill_kernel, dim3(pb_grid(mh)), dim3(256), 0, 0, hkeys, mh, hstart.as<uint32_t>(),
-                               pl->hbin_v.as<uint32_t>(), pl->hot_ent.as<uint32_t>());
+                               pl->hbin_v.as<uint32_t>(), sb + rb, bin_mask, rb, pl->hot_ent.as<uint32_t>());
             GM_HIP(hipGetLastError());
             GM_HIP(hipDeviceSynchronize());
         }
@@ -941,6 +958,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     }
     const unsigned gm_ = pb_grid(m);
 
+    timer.done("pb plan: hot edge stream");
     // (bin, tile) segments of the sorted entries
     DevBuf flag, segid;
     GM_TRY(flag.alloc((size_t)m * 4));
@@ -974,6 +992,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     hipLaunchKernelGGL(pb_bounds_kernel, dim3(gs), dim3(256), 0, 0, segbin.as<uint64_t>(), NS, 0, pl->B,
                        bin_seg.as<uint32_t>());
     GM_HIP(hipGetLastError());
+    timer.done("pb plan: segments");
     // phase-1 order of the segments: by (tile, bin)
     GM_TRY(sort_pairs_u64_u32(segkey, segkalt, segval, segvalt, NS, 64));
     segkalt.release();
@@ -1025,6 +1044,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     hipLaunchKernelGGL(pb_chunk_seg_kernel, dim3(pb_grid(Mp / PB_WBLK + 1)), dim3(256), 0, 0, pstart.as<uint32_t>(), NS,
                        Mp / PB_WBLK + 1, pl->chunk_seg.as<uint32_t>());
     GM_HIP(hipGetLastError());
+    timer.done("pb plan: segment layout + stream fill");
     GM_TRY(pb_make_items(pl));
     // phase-1 workgroup list: a tile's stream is cut into chunks of 32768 entries (measured best on
     // MI355X at scales 22-26: enough workgroups to hide latency, x-tile reloads stay in L2)
