@@ -423,9 +423,16 @@ struct alignas(8) U16x4 {
     uint16_t a, b, c, d;
 };
 
+constexpr int PB_BIN_U = 4;         // 256-entry blocks a wavefront of pb_bin_kernel handles per pipeline stage
+constexpr int PB_ACC_U = 2;         // float4 groups per lane and pipeline stage of pb_accum_kernel's value stream
+constexpr int PB_EPI = 2;           // groups of 4 rows a lane of the accumulate epilogue keeps in flight
 constexpr uint32_t PB_DCACHE = 4096; // segment deltas cached in LDS per workgroup (16 KiB)
 
-template <bool NT>
+// ABL != 0 are measurement-only variants (GM_PB_ABLATE, wrong results by design): they remove one
+// ingredient at a time to show what bounds the kernel.  bin: 1 = no LDS gather, 3 = no stores.  accumulate: 3 = no epilogue, 4 = no streaming loops
+// (removing the LDS atomics or making them conflict-free changed nothing: measured, then deleted).  bin: 4 = no x tile load,
+// 5 = x tile load only.
+template <int ABL>
 __global__ __launch_bounds__(PB_BIN_BLOCK) void pb_bin_kernel(const float *__restrict__ x_in, uint64_t x_len,
                                                               const uint32_t *__restrict__ tile_p,
                                                               const uint32_t *__restrict__ wg_tile,
@@ -444,7 +451,35 @@ __global__ __launch_bounds__(PB_BIN_BLOCK) void pb_bin_kernel(const float *__res
     const uint32_t p_end = (tile_end - p_begin) < PB_BIN_CHUNK ? tile_end : p_begin + PB_BIN_CHUNK;
     const uint64_t x0 = (uint64_t)t * PB_S;
     const uint32_t xn = (uint32_t)((x_len - x0) < PB_S ? (x_len - x0) : PB_S);
-    if ((xn & 3u) == 0 && ((x0 & 3u) == 0)) {
+    constexpr int U = PB_BIN_U;
+    constexpr uint32_t STEP = PB_BIN_BLOCK * PB_VEC; // entries per workgroup step (4096)
+    float sink = 0.f;
+    // every wavefront covers one aligned 256-entry block per step: lane l owns entries 4l..4l+3.
+    // Software-pipelined: the ids of step group i+1 are requested BEFORE the stores of group i are issued.
+    // Memory operations of a wavefront retire in order (one vmcnt), so loads issued after the stores
+    // could only be consumed once those stores have drained — measured as load and store time adding
+    // up (0.57 + 0.94 ms at scale 26) instead of overlapping.
+    U16x4 v[U];
+    uint32_t cs[U];
+    auto fetch = [&](uint32_t p0, U16x4(&vv)[U], uint32_t(&cc)[U]) {
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const uint32_t p = p0 + k * STEP;
+            const bool in = p < p_end; // uniform per wavefront: ranges are multiples of 256
+            if (in) {
+                const u32x2 raw = *reinterpret_cast<const u32x2 *>(p1_src + p);
+                vv[k] = U16x4{(uint16_t)raw.x, (uint16_t)(raw.x >> 16), (uint16_t)raw.y, (uint16_t)(raw.y >> 16)};
+            } else {
+                vv[k] = U16x4{PB_NULL, PB_NULL, PB_NULL, PB_NULL};
+            }
+            cc[k] = in ? chunk_seg[p / PB_WBLK] : 0u;
+        }
+    };
+    const uint32_t p_first = p_begin + tid * PB_VEC;
+    if (ABL != 5 && p_first < p_end)
+        fetch(p_first, v, cs);
+    if (ABL == 4) {
+    } else if ((xn & 3u) == 0 && ((x0 & 3u) == 0)) {
         const float4 *src4 = reinterpret_cast<const float4 *>(x_in + x0);
         float4 *dst4 = reinterpret_cast<float4 *>(xs);
         for (uint32_t i = tid; i < xn / 4; i += PB_BIN_BLOCK)
@@ -463,25 +498,12 @@ __global__ __launch_bounds__(PB_BIN_BLOCK) void pb_bin_kernel(const float *__res
     __syncthreads();
     const uint32_t lane = tid & (kWave - 1);
     const uint64_t le_mask = (lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull);
-    constexpr int U = 8;
-    constexpr uint32_t STEP = PB_BIN_BLOCK * PB_VEC; // entries per workgroup step (4096)
-    // every wavefront covers one aligned 256-entry block per step: lane l owns entries 4l..4l+3
-    for (uint32_t p0 = p_begin + tid * PB_VEC; p0 < p_end; p0 += STEP * U) {
-        U16x4 v[U];
-        uint32_t cs[U];
-#pragma unroll
-        for (int k = 0; k < U; ++k) {
-            const uint32_t p = p0 + k * STEP;
-            const bool in = p < p_end; // uniform per wavefront: ranges are multiples of 256
-            if (in) {
-                const u32x2 raw = NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(p1_src + p))
-                                     : *reinterpret_cast<const u32x2 *>(p1_src + p);
-                v[k] = U16x4{(uint16_t)raw.x, (uint16_t)(raw.x >> 16), (uint16_t)raw.y, (uint16_t)(raw.y >> 16)};
-            } else {
-                v[k] = U16x4{PB_NULL, PB_NULL, PB_NULL, PB_NULL};
-            }
-            cs[k] = in ? chunk_seg[p / PB_WBLK] : 0u;
-        }
+    for (uint32_t p0 = p_first; p0 < (ABL == 5 ? p_begin : p_end); p0 += STEP * U) {
+        U16x4 vn[U];
+        uint32_t cn[U];
+        const uint32_t pn = p0 + STEP * U;
+        if (pn < p_end)
+            fetch(pn, vn, cn);
 #pragma unroll
         for (int k = 0; k < U; ++k) {
             const uint32_t p = p0 + k * STEP;
@@ -492,18 +514,33 @@ __global__ __launch_bounds__(PB_BIN_BLOCK) void pb_bin_kernel(const float *__res
                 const uint32_t ri = rank - r_lo;
                 const uint32_t dlt = ri < PB_DCACHE ? dl[ri] : delta[rank];
                 f32x4 o;
-                o.x = xs[v[k].a & (PB_S - 1u)];
-                o.y = xs[v[k].b & (PB_S - 1u)];
-                o.z = xs[v[k].c & (PB_S - 1u)];
-                o.w = xs[v[k].d & (PB_S - 1u)];
+                if (ABL == 1) {
+                    o.x = (float)v[k].a, o.y = (float)v[k].b, o.z = (float)v[k].c, o.w = (float)v[k].d;
+                } else {
+                    o.x = xs[v[k].a & (PB_S - 1u)];
+                    o.y = xs[v[k].b & (PB_S - 1u)];
+                    o.z = xs[v[k].c & (PB_S - 1u)];
+                    o.w = xs[v[k].d & (PB_S - 1u)];
+                }
                 // padding lanes write padding slots
-                if (NT)
-                    __builtin_nontemporal_store(o, reinterpret_cast<f32x4 *>(vals + (p + dlt)));
+                if (ABL == 3)
+                    sink += o.x + o.y + o.z + o.w + (float)dlt;
                 else
                     *reinterpret_cast<f32x4 *>(vals + (p + dlt)) = o;
             }
         }
+        if (pn < p_end) {
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                v[k] = vn[k];
+                cs[k] = cn[k];
+            }
+        }
     }
+    if (ABL == 5)
+        sink = xs[(tid * 17u) & (PB_S - 1u)];
+    if ((ABL == 3 || ABL == 5) && sink == 12345.678f)
+        vals[tid] = sink;
 }
 
 __device__ __forceinline__ unsigned long long pb_to_fix(float x)
@@ -511,7 +548,7 @@ __device__ __forceinline__ unsigned long long pb_to_fix(float x)
     return (unsigned long long)(x * PB_FIX_SCALE); // exact scaling by 2^62, truncation below 2^-62
 }
 
-template <bool NT>
+template <int ABL>
 __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__restrict__ vals,
                                                                 const uint16_t *__restrict__ p2_dst,
                                                                 const PbItem *__restrict__ items,
@@ -530,31 +567,55 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
     const PbItem item = items[blockIdx.x]; // longest items are dispatched first
     const uint32_t b = item.bin, tid = threadIdx.x;
     float *hot = reinterpret_cast<float *>(acc + Racc); // H out_scores of the hot sources
-    for (uint32_t i = tid; i < Racc; i += PB_ACC_BLOCK)
-        acc[i] = 0ull;
-    if (item.h1 > item.h0)
-        for (uint32_t i = tid; i < H; i += PB_ACC_BLOCK)
-            hot[i] = hot_x[i];
-    __syncthreads();
-    const uint32_t qb = item.q0, qe = item.q1; // multiples of 4
-    constexpr int U = 4;
+    const uint32_t qb = item.q0, qe = (ABL == 4 ? item.q0 : item.q1); // multiples of 4
+    constexpr int U = PB_ACC_U;
     constexpr uint32_t STEP = PB_ACC_BLOCK * PB_VEC;
-    for (uint32_t q0 = qb + tid * PB_VEC; q0 < qe; q0 += STEP * U) {
-        f32x4 v[U];
-        U16x4 d[U];
+    // Every phase keeps several independent loads per lane in flight and the first group of the value
+    // stream is requested before the prologue: with one or two workgroups per CU nothing else hides a
+    // phase that waits for one load at a time (measured at scale 26: hot table 27 + hot edges 18 +
+    // epilogue 32 dependent round trips per workgroup were a third of the kernel).
+    f32x4 v[U];
+    U16x4 d[U];
+    auto fetch = [&](uint32_t q0, f32x4(&vv)[U], U16x4(&dd)[U]) {
 #pragma unroll
         for (int k = 0; k < U; ++k) {
             const uint32_t q = q0 + k * STEP;
             if (q < qe) {
-                v[k] = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(vals + q))
-                          : *reinterpret_cast<const f32x4 *>(vals + q);
-                const u32x2 raw = NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(p2_dst + q))
-                                     : *reinterpret_cast<const u32x2 *>(p2_dst + q);
-                d[k] = U16x4{(uint16_t)raw.x, (uint16_t)(raw.x >> 16), (uint16_t)raw.y, (uint16_t)(raw.y >> 16)};
+                vv[k] = *reinterpret_cast<const f32x4 *>(vals + q);
+                const u32x2 raw = *reinterpret_cast<const u32x2 *>(p2_dst + q);
+                dd[k] = U16x4{(uint16_t)raw.x, (uint16_t)(raw.x >> 16), (uint16_t)raw.y, (uint16_t)(raw.y >> 16)};
             } else {
-                d[k] = U16x4{PB_NULL, PB_NULL, PB_NULL, PB_NULL};
+                dd[k] = U16x4{PB_NULL, PB_NULL, PB_NULL, PB_NULL};
             }
         }
+    };
+    const uint32_t q_first = qb + tid * PB_VEC;
+    if (q_first < qe)
+        fetch(q_first, v, d);
+    for (uint32_t i = tid; i < Racc; i += PB_ACC_BLOCK)
+        acc[i] = 0ull;
+    if (item.h1 > item.h0) { // hot_x and the LDS table are 16-byte aligned and padded to a multiple of 4
+        constexpr int HB = 4;
+        const uint32_t H4 = (H + 3u) / 4u;
+        for (uint32_t i0 = tid; i0 < H4; i0 += PB_ACC_BLOCK * HB) {
+            f32x4 t[HB];
+#pragma unroll
+            for (int k = 0; k < HB; ++k)
+                if (i0 + k * PB_ACC_BLOCK < H4)
+                    t[k] = *reinterpret_cast<const f32x4 *>(hot_x + 4u * (i0 + k * PB_ACC_BLOCK));
+#pragma unroll
+            for (int k = 0; k < HB; ++k)
+                if (i0 + k * PB_ACC_BLOCK < H4)
+                    *reinterpret_cast<f32x4 *>(hot + 4u * (i0 + k * PB_ACC_BLOCK)) = t[k];
+        }
+    }
+    __syncthreads();
+    for (uint32_t q0 = q_first; q0 < qe; q0 += STEP * U) {
+        f32x4 vn[U];
+        U16x4 dn[U];
+        const uint32_t qn = q0 + STEP * U;
+        if (qn < qe)
+            fetch(qn, vn, dn);
 #pragma unroll
         for (int k = 0; k < U; ++k) {
             if (d[k].a != PB_NULL)
@@ -566,18 +627,38 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
             if (d[k].d != PB_NULL)
                 atomicAdd(&acc[d[k].d], pb_to_fix(v[k].w));
         }
+        if (qn < qe) {
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                v[k] = vn[k];
+                d[k] = dn[k];
+            }
+        }
     }
     // hot edges: 4 bytes each (row_in_bin << 16 | hot index), the value comes from the LDS table
-    for (uint32_t h0 = item.h0 + tid * PB_VEC; h0 < item.h1; h0 += PB_ACC_BLOCK * PB_VEC) {
-        const uint4 e = *reinterpret_cast<const uint4 *>(hot_ent + h0);
-        if (e.x != 0xFFFFFFFFu)
-            atomicAdd(&acc[e.x >> 16], pb_to_fix(hot[e.x & 0xFFFFu]));
-        if (e.y != 0xFFFFFFFFu)
-            atomicAdd(&acc[e.y >> 16], pb_to_fix(hot[e.y & 0xFFFFu]));
-        if (e.z != 0xFFFFFFFFu)
-            atomicAdd(&acc[e.z >> 16], pb_to_fix(hot[e.z & 0xFFFFu]));
-        if (e.w != 0xFFFFFFFFu)
-            atomicAdd(&acc[e.w >> 16], pb_to_fix(hot[e.w & 0xFFFFu]));
+    {
+        constexpr int HU = 4;
+        const uint32_t h_end = ABL == 4 ? item.h0 : item.h1;
+        for (uint32_t h0 = item.h0 + tid * PB_VEC; h0 < h_end; h0 += PB_ACC_BLOCK * PB_VEC * HU) {
+            uint4 e[HU];
+#pragma unroll
+            for (int k = 0; k < HU; ++k) {
+                const uint32_t h = h0 + (uint32_t)k * PB_ACC_BLOCK * PB_VEC;
+                e[k] = h < h_end ? *reinterpret_cast<const uint4 *>(hot_ent + h)
+                                 : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+            }
+#pragma unroll
+            for (int k = 0; k < HU; ++k) {
+                if (e[k].x != 0xFFFFFFFFu)
+                    atomicAdd(&acc[e[k].x >> 16], pb_to_fix(hot[e[k].x & 0xFFFFu]));
+                if (e[k].y != 0xFFFFFFFFu)
+                    atomicAdd(&acc[e[k].y >> 16], pb_to_fix(hot[e[k].y & 0xFFFFu]));
+                if (e[k].z != 0xFFFFFFFFu)
+                    atomicAdd(&acc[e[k].z >> 16], pb_to_fix(hot[e[k].z & 0xFFFFu]));
+                if (e[k].w != 0xFFFFFFFFu)
+                    atomicAdd(&acc[e[k].w >> 16], pb_to_fix(hot[e[k].w & 0xFFFFu]));
+            }
+        }
     }
     __syncthreads();
     if (item.nparts > 1) {
@@ -605,21 +686,82 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
     }
     double err = 0.0;
     const uint32_t r0 = b * R;
-    for (uint32_t i = tid; i < R; i += PB_ACC_BLOCK) {
-        const uint32_t r = r0 + i;
-        if (r < n_local) {
-            const uint32_t c = cidx[r]; // rows without in-edges own no accumulator: incoming = 0
-            unsigned long long sum = 0ull;
-            if (c != PB_NULL) {
-                if (item.nparts > 1) { // slices of one bin own consecutive partial slots [slot0, slot0 + nparts)
-                    for (uint32_t k = 0; k < item.nparts; ++k)
-                        sum += partials[(size_t)(item.slot0 + k) * Racc + c];
-                } else {
-                    sum = acc[c];
+    if (ABL == 3) {
+        if (acc[tid % Racc] == 0x123456789ull)
+            bin_err[b] = 1.0;
+        return;
+    }
+    const bool vec_ok = (((uintptr_t)scores | (uintptr_t)x_out | (uintptr_t)outdeg) & 15u) == 0;
+    if (item.nparts == 1 && (R & 3u) == 0 && vec_ok) {
+        // Fused epilogue, 4 consecutive rows per lane and PB_EPI groups in flight: with one workgroup
+        // per CU nothing else hides this phase's load latency (measured: 0.56 ms of a 1.7 ms kernel
+        // at scale 26 when it ran one row per lane and iteration).
+        constexpr int E = PB_EPI;
+        for (uint32_t i0 = tid * 4u; i0 < R; i0 += PB_ACC_BLOCK * 4u * E) {
+            U16x4 c4[E];
+            f32x4 old4[E];
+            uint4 od4[E];
+            bool full[E];
+#pragma unroll
+            for (int k = 0; k < E; ++k) {
+                const uint32_t i = i0 + (uint32_t)k * PB_ACC_BLOCK * 4u;
+                const uint32_t r = r0 + i;
+                full[k] = i < R && r + 3u < n_local;
+                if (full[k]) {
+                    const u32x2 raw = *reinterpret_cast<const u32x2 *>(cidx + r);
+                    c4[k] = U16x4{(uint16_t)raw.x, (uint16_t)(raw.x >> 16), (uint16_t)raw.y, (uint16_t)(raw.y >> 16)};
+                    old4[k] = *reinterpret_cast<const f32x4 *>(scores + r);
+                    od4[k] = *reinterpret_cast<const uint4 *>(outdeg + r);
                 }
             }
-            const float incoming = (float)sum * PB_FIX_INV; // one rounding: the exactly rounded row sum
-            err += pr_finalize(r, incoming, base, damping, outdeg, scores, x_out);
+#pragma unroll
+            for (int k = 0; k < E; ++k) {
+                const uint32_t i = i0 + (uint32_t)k * PB_ACC_BLOCK * 4u;
+                const uint32_t r = r0 + i;
+                if (full[k]) {
+                    const uint16_t cs4[4] = {c4[k].a, c4[k].b, c4[k].c, c4[k].d};
+                    const float olds[4] = {old4[k].x, old4[k].y, old4[k].z, old4[k].w};
+                    const uint32_t ods[4] = {od4[k].x, od4[k].y, od4[k].z, od4[k].w};
+                    float nw[4], xo[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const unsigned long long sum = cs4[j] != PB_NULL ? acc[cs4[j]] : 0ull;
+                        const float incoming = (float)sum * PB_FIX_INV; // one rounding: the exactly rounded row sum
+                        nw[j] = pr_new_score(base, damping, incoming);
+                        xo[j] = __fdiv_rn(nw[j], (float)ods[j]);
+                        err += fabs((double)__fsub_rn(nw[j], olds[j]));
+                    }
+                    f32x4 o;
+                    o.x = nw[0], o.y = nw[1], o.z = nw[2], o.w = nw[3];
+                    *reinterpret_cast<f32x4 *>(scores + r) = o;
+                    o.x = xo[0], o.y = xo[1], o.z = xo[2], o.w = xo[3];
+                    *reinterpret_cast<f32x4 *>(x_out + r) = o;
+                } else if (i < R) { // the last rows of the slice
+                    for (uint32_t rr = r; rr < n_local && rr < r + 4u; ++rr) {
+                        const uint32_t c = cidx[rr];
+                        const unsigned long long sum = c != PB_NULL ? acc[c] : 0ull;
+                        err += pr_finalize(rr, (float)sum * PB_FIX_INV, base, damping, outdeg, scores, x_out);
+                    }
+                }
+            }
+        }
+    } else {
+        for (uint32_t i = tid; i < R; i += PB_ACC_BLOCK) {
+            const uint32_t r = r0 + i;
+            if (r < n_local) {
+                const uint32_t c = cidx[r]; // rows without in-edges own no accumulator: incoming = 0
+                unsigned long long sum = 0ull;
+                if (c != PB_NULL) {
+                    if (item.nparts > 1) { // slices of one bin own consecutive partial slots [slot0, slot0 + nparts)
+                        for (uint32_t k = 0; k < item.nparts; ++k)
+                            sum += partials[(size_t)(item.slot0 + k) * Racc + c];
+                    } else {
+                        sum = acc[c];
+                    }
+                }
+                const float incoming = (float)sum * PB_FIX_INV; // one rounding: the exactly rounded row sum
+                err += pr_finalize(r, incoming, base, damping, outdeg, scores, x_out);
+            }
         }
     }
     const double total = block_sum<double, PB_ACC_BLOCK / kWave>(err, red);
@@ -638,7 +780,7 @@ __global__ __launch_bounds__(1024) void pb_err_kernel(const double *__restrict__
         *err_out = total;
 }
 
-// tuning knobs (environment, read once): GM_PB_NT=0/1 streaming hints, GM_PB_CHUNK=<entries> phase-1
+// tuning knobs (environment, read once): GM_PB_ABLATE measurement variants, GM_PB_CHUNK=<entries> phase-1
 // workgroup size (0 = automatic), GM_PB_ORDER=0/1 longest-bin-first dispatch, GM_PB_RB=<log2 rows per bin>
 int pb_env(const char *name, int dflt)
 {
@@ -1076,7 +1218,25 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
 
 } // namespace
 
-static int pb_plan_create(const gm_csr *csr, uint64_t x_len, PbPlan **out)
+static hipError_t pb_set_kernel_attributes()
+{
+    const void *bin_fns[] = {reinterpret_cast<const void *>(&pb_bin_kernel<0>), reinterpret_cast<const void *>(&pb_bin_kernel<1>),
+                             reinterpret_cast<const void *>(&pb_bin_kernel<3>), reinterpret_cast<const void *>(&pb_bin_kernel<4>),
+                             reinterpret_cast<const void *>(&pb_bin_kernel<5>)};
+    const void *acc_fns[] = {reinterpret_cast<const void *>(&pb_accum_kernel<0>),
+                             reinterpret_cast<const void *>(&pb_accum_kernel<3>),
+                             reinterpret_cast<const void *>(&pb_accum_kernel<4>)};
+    hipError_t e = hipSuccess;
+    for (const void *f : bin_fns)
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, PB_S * 4 + PB_DCACHE * 4);
+    for (const void *f : acc_fns)
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 163840 - 512);
+    return e;
+}
+
+int pb_plan_create(const gm_csr *csr, uint64_t x_len, PbPlan **out)
 {
     PbPlan *pl = new (std::nothrow) PbPlan();
     GM_CHECK(pl, GM_ERR_NOMEM, "pb_plan_create: out of host memory");
@@ -1085,16 +1245,7 @@ static int pb_plan_create(const gm_csr *csr, uint64_t x_len, PbPlan **out)
         delete pl;
         return rc;
     }
-    hipError_t e = hipSuccess;
-    const void *bin_fns[2] = {reinterpret_cast<const void *>(&pb_bin_kernel<false>),
-                              reinterpret_cast<const void *>(&pb_bin_kernel<true>)};
-    const void *acc_fns[2] = {reinterpret_cast<const void *>(&pb_accum_kernel<false>),
-                              reinterpret_cast<const void *>(&pb_accum_kernel<true>)};
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
-        e = hipFuncSetAttribute(bin_fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, PB_S * 4 + PB_DCACHE * 4);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(acc_fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, 163840 - 512);
-    }
+    hipError_t e = pb_set_kernel_attributes();
     if (e != hipSuccess) {
         set_error("pb_plan_create: %s", hipGetErrorString(e));
         delete pl;
@@ -1134,7 +1285,7 @@ int pb_scratch_create(const PbPlan *pl, PbScratch **out)
     if ((rc = sc->vals_raw.alloc((size_t)(pl->Mv ? pl->Mv : 4) * 4)) ||
         (rc = sc->partials.alloc((size_t)(pl->slots ? pl->slots : 1) * pl->Racc * 8)) ||
         (rc = sc->tickets.alloc((size_t)pl->B * 4)) || (rc = sc->bin_err.alloc((size_t)pl->B * 8)) ||
-        (rc = sc->hot_x.alloc((size_t)(pl->H ? pl->H : 1) * 4))) {
+        (rc = sc->hot_x.alloc(((size_t)pl->H + 4) * 4))) {
         delete sc;
         return rc;
     }
@@ -1142,6 +1293,10 @@ int pb_scratch_create(const PbPlan *pl, PbScratch **out)
     hipError_t e = hipMemset(sc->tickets.p, 0, (size_t)pl->B * 4);
     if (e == hipSuccess)
         e = hipMemset(sc->vals_raw.p, 0, sc->vals_raw.bytes);
+    // hipMemset on device memory returns before the fill has run, and the sweeps run on the caller's
+    // (possibly non-blocking) stream, which the null stream does not order against
+    if (e == hipSuccess)
+        e = hipDeviceSynchronize();
     if (e != hipSuccess) {
         set_error("pb_scratch_create: %s", hipGetErrorString(e));
         delete sc;
@@ -1155,39 +1310,48 @@ void pb_scratch_destroy(PbScratch *scratch) { delete scratch; }
 
 uint64_t pb_work_items(const PbPlan *plan) { return plan ? (uint64_t)plan->NW + plan->NI : 0; }
 
+template <int ABL> void pb_launch_bin(const PbPlan *pl, PbScratch *sc, const float *x_in, hipStream_t st)
+{
+    hipLaunchKernelGGL(pb_bin_kernel<ABL>, dim3(pl->NW), dim3(PB_BIN_BLOCK), PB_S * 4 + PB_DCACHE * 4, st, x_in, pl->x_len,
+                       pl->tile_p.as<uint32_t>(), pl->wg_tile.as<uint32_t>(), pl->wg_p0.as<uint32_t>(),
+                       pl->p1_src.as<uint16_t>(), pl->chunk_seg.as<uint32_t>(), pl->delta.as<uint32_t>(), sc->vals,
+                       pl->chunk);
+}
+
+template <int ABL>
+void pb_launch_accum(const PbPlan *pl, PbScratch *sc, float *x_out, float *scores, const uint32_t *outdeg, float base,
+                     float damping, hipStream_t st)
+{
+    hipLaunchKernelGGL(pb_accum_kernel<ABL>, dim3(pl->NI), dim3(PB_ACC_BLOCK), (size_t)pl->Racc * 8 + (((size_t)pl->H + 3) & ~(size_t)3) * 4, st,
+                       sc->vals, pl->p2_dst.as<uint16_t>(), pl->items.as<PbItem>(), pl->hot_ent.as<uint32_t>(),
+                       sc->hot_x.as<float>(), pl->H, sc->partials.as<unsigned long long>(), sc->tickets.as<uint32_t>(),
+                       pl->cidx.as<uint16_t>(), outdeg, scores, x_out, sc->bin_err.as<double>(), pl->n_local, pl->R,
+                       pl->Racc, base, damping);
+}
+
 int pb_sweep_main(const PbPlan *pl, PbScratch *sc, const float *x_in, float *x_out, float *scores,
                   const uint32_t *outdeg, float base, float damping, hipStream_t st)
 {
-    static const int nt = pb_env("GM_PB_NT", 0); // measured: streaming hints cost 8-10 % here
+    // GM_PB_ABLATE = 10*accumulate variant + bin variant; 0 = the product kernels (re-read per call so
+    // that tools/ablate.py can switch variants on one resident graph)
+    const int ablate = pb_env("GM_PB_ABLATE", 0);
     if (pl->H)
         hipLaunchKernelGGL(pb_hot_gather_kernel, dim3(div_up(pl->H, 256)), dim3(256), 0, st, x_in,
                            pl->hot_ids.as<uint32_t>(), pl->H, sc->hot_x.as<float>());
     if (pl->NW) {
-        if (nt)
-            hipLaunchKernelGGL(pb_bin_kernel<true>, dim3(pl->NW), dim3(PB_BIN_BLOCK), PB_S * 4 + PB_DCACHE * 4, st, x_in, pl->x_len,
-                               pl->tile_p.as<uint32_t>(), pl->wg_tile.as<uint32_t>(), pl->wg_p0.as<uint32_t>(),
-                               pl->p1_src.as<uint16_t>(), pl->chunk_seg.as<uint32_t>(), pl->delta.as<uint32_t>(),
-                               sc->vals, pl->chunk);
-        else
-            hipLaunchKernelGGL(pb_bin_kernel<false>, dim3(pl->NW), dim3(PB_BIN_BLOCK), PB_S * 4 + PB_DCACHE * 4, st, x_in, pl->x_len,
-                               pl->tile_p.as<uint32_t>(), pl->wg_tile.as<uint32_t>(), pl->wg_p0.as<uint32_t>(),
-                               pl->p1_src.as<uint16_t>(), pl->chunk_seg.as<uint32_t>(), pl->delta.as<uint32_t>(),
-                               sc->vals, pl->chunk);
+        switch (ablate % 10) {
+        case 1: pb_launch_bin<1>(pl, sc, x_in, st); break;
+        case 3: pb_launch_bin<3>(pl, sc, x_in, st); break;
+        case 4: pb_launch_bin<4>(pl, sc, x_in, st); break;
+        case 5: pb_launch_bin<5>(pl, sc, x_in, st); break;
+        default: pb_launch_bin<0>(pl, sc, x_in, st); break;
+        }
     }
-    if (nt)
-        hipLaunchKernelGGL(pb_accum_kernel<true>, dim3(pl->NI), dim3(PB_ACC_BLOCK), (size_t)pl->Racc * 8 + (size_t)pl->H * 4,
-                           st, sc->vals, pl->p2_dst.as<uint16_t>(), pl->items.as<PbItem>(),
-                           pl->hot_ent.as<uint32_t>(), sc->hot_x.as<float>(), pl->H,
-                           sc->partials.as<unsigned long long>(), sc->tickets.as<uint32_t>(), pl->cidx.as<uint16_t>(), outdeg, scores,
-                           x_out,
-                           sc->bin_err.as<double>(), pl->n_local, pl->R, pl->Racc, base, damping);
-    else
-        hipLaunchKernelGGL(pb_accum_kernel<false>, dim3(pl->NI), dim3(PB_ACC_BLOCK), (size_t)pl->Racc * 8 + (size_t)pl->H * 4,
-                           st, sc->vals, pl->p2_dst.as<uint16_t>(), pl->items.as<PbItem>(),
-                           pl->hot_ent.as<uint32_t>(), sc->hot_x.as<float>(), pl->H,
-                           sc->partials.as<unsigned long long>(), sc->tickets.as<uint32_t>(), pl->cidx.as<uint16_t>(), outdeg, scores,
-                           x_out,
-                           sc->bin_err.as<double>(), pl->n_local, pl->R, pl->Racc, base, damping);
+    switch (ablate / 10) {
+    case 3: pb_launch_accum<3>(pl, sc, x_out, scores, outdeg, base, damping, st); break;
+    case 4: pb_launch_accum<4>(pl, sc, x_out, scores, outdeg, base, damping, st); break;
+    default: pb_launch_accum<0>(pl, sc, x_out, scores, outdeg, base, damping, st); break;
+    }
     GM_HIP(hipGetLastError());
     return GM_OK;
 }

@@ -21,6 +21,32 @@ __global__ void stream_read(const uint4 *__restrict__ in, uint64_t n16, uint32_t
     if (acc == 0x12345678u) *out = acc;
 }
 
+// float4 copy (the guide's 6.29 TB/s figure counts read + written bytes)
+__global__ __launch_bounds__(256) void stream_copy(const float4 *__restrict__ in, float4 *__restrict__ out, uint64_t n16)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride)
+        out[i] = in[i];
+}
+
+// the byte mix of pb_bin_kernel: read 2 B/entry (coalesced), write 4 B/entry in runs of `run` entries
+// (run*4 bytes, 16-byte aligned) whose destinations are scattered (a multiplicative permutation of
+// the run index), every wavefront writing whole 1 KiB pieces of a run.  run = 0: contiguous.
+__global__ __launch_bounds__(1024) void bin_like(const uint2 *__restrict__ in, float4 *__restrict__ out, uint64_t n4, uint32_t run4,
+                                                 uint64_t nruns, uint64_t mult)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const uint2 v = in[i];
+        uint64_t o = i;
+        if (run4) {
+            const uint64_t r = i / run4, k = i % run4;
+            o = ((r * mult) % nruns) * run4 + k;
+        }
+        out[o] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.x >> 16), __uint_as_float(v.y >> 16));
+    }
+}
+
 // idx: m random indices (streamed, coalesced); table: gathered; 8 per lane in flight
 __global__ __launch_bounds__(256) void gather8(const uint32_t *__restrict__ idx, const float *__restrict__ table,
                                                uint64_t m, float *out)
@@ -102,6 +128,31 @@ int main()
         hipLaunchKernelGGL(stream_read, dim3(256 * 16), dim3(256), 0, 0, (const uint4 *)table, (1ull << 28) * 4 / 16, (uint32_t *)out);
         CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms, a, b));
         printf("stream_read 1GiB: %.3f ms  %.1f GB/s\n", ms, (1ull << 30) / ms / 1e6);
+    }
+    {   // copy + bin-like write mixes
+        float *dst;
+        CK(hipMalloc(&dst, 1ull << 30));
+        CK(hipMemset(dst, 0, 1ull << 30));
+        for (int rep = 0; rep < 3; ++rep) {
+            CK(hipEventRecord(a));
+            hipLaunchKernelGGL(stream_copy, dim3(256 * 16), dim3(256), 0, 0, (const float4 *)table, (float4 *)dst, (1ull << 30) / 16);
+            CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms, a, b));
+            printf("stream_copy 1GiB->1GiB: %.3f ms  %.1f GB/s (read+write)\n", ms, 2.0 * (1ull << 30) / ms / 1e6);
+        }
+        const uint64_t n4 = (1ull << 30) / 16; // 64M float4 = 256M entries
+        const uint32_t runs4[] = {0, 8, 16, 28, 32, 56, 64, 128, 256, 1024};
+        for (uint32_t run4 : runs4) {
+            const uint64_t nruns = run4 ? n4 / run4 : 1;
+            for (int rep = 0; rep < 2; ++rep) {
+                CK(hipEventRecord(a));
+                hipLaunchKernelGGL(bin_like, dim3(512), dim3(1024), 0, 0, (const uint2 *)table, (float4 *)dst, n4, run4, nruns,
+                                   (uint64_t)1000003);
+                CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms, a, b));
+            }
+            printf("bin_like run=%5u B: %.3f ms  %.1f GB/s (2 B read + 4 B written per entry)\n", run4 * 16, ms,
+                   (double)n4 * 24 / ms / 1e6);
+        }
+        CK(hipFree(dst));
     }
     run_lds<unsigned long long, 16384>("u64 x 16384 slots (128KiB)", (unsigned long long *)out);
     run_lds<unsigned long long, 2048>("u64 x 2048 slots", (unsigned long long *)out);
