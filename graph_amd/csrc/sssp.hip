@@ -9,9 +9,15 @@
 //   * instead of per-thread bins copied into a shared frontier (sssp.rs:85-94) there are two
 //     byte-flag arrays (double-buffered per round, so no in-round ordering is needed): a node is
 //     flagged when its distance improved since its edges were last relaxed; a round relaxes every
-//     flagged node whose bucket (u32)(d/delta) (sssp.rs:192) is <= the current bucket and carries
-//     the others over, tracking the minimum far bucket — the reference's min_non_empty_bin
-//     (sssp.rs:159-168);
+//     flagged node whose distance is <= the current threshold and carries the others over,
+//     tracking the minimum pending distance — the role of the reference's min_non_empty_bin
+//     (sssp.rs:159-168).  The threshold advances to (minimum pending distance + width) when a round
+//     leaves nothing below it; width = delta * GM_SSSP_WIDTH (default 1): `delta` only shapes the
+//     schedule, never the result (measured at RMAT scale 24, delta 0.1: widths from delta/16 to pure
+//     Bellman-Ford all take 74-98 ms — the small-world graph needs ~7 near-full passes over the edges
+//     whatever the order, and finer steps only add rounds);
+//   * the bucket bookkeeping lives on the device (sssp_advance_kernel): the host enqueues rounds in
+//     batches and reads one flag per batch instead of synchronising after every round;
 //   * INF = f32::MAX (sssp.rs:12), never +inf.
 // One lane per node; adjacency lists longer than 32 edges are relaxed by the whole wavefront.
 #include "common.hpp"
@@ -28,43 +34,69 @@ constexpr uint32_t SSSP_COOP = 32; // lists longer than this are relaxed by the 
 constexpr uint32_t SSSP_INF_BITS = 0x7F7FFFFFu; // f32::MAX
 constexpr uint32_t NO_BUCKET = 0xFFFFFFFFu;
 
-__device__ __forceinline__ uint32_t bucket_of(float d, float delta)
-{
-    const float q = __fdiv_rn(d, delta);
-    return q >= 4294967040.0f ? 0xFFFFFFFEu : (uint32_t)q; // saturating, like Rust's `as usize`
-}
-
 struct RelaxOut {
     uint32_t again;
     uint32_t far;
 };
 
-__device__ __forceinline__ void relax_edge(uint32_t *dist, uint8_t *__restrict__ flag_next, float du, uint32_t t,
-                                           float wt, uint32_t cur, float delta, RelaxOut &ro)
+// thr: bit pattern of the current distance threshold (non-negative f32 order == unsigned order).
+// `pre` is dist[t] as read by the caller's batched pre-check (several independent random reads in
+// flight per lane); the atomic only runs when the candidate still looks like an improvement.
+__device__ __forceinline__ void relax_checked(uint32_t *dist, uint8_t *__restrict__ flag_next, uint32_t nb, uint32_t pre,
+                                              uint32_t t, uint32_t thr, RelaxOut &ro)
 {
-    const float nd = __fadd_rn(du, wt);
-    const uint32_t nb = __float_as_uint(nd);
-    if (nb < ld_agent(&dist[t])) { // cheap pre-check, then the real atomic
+    if (nb < pre) {
         const uint32_t old = atomicMin(&dist[t], nb);
         if (nb < old) {
             flag_next[t] = 1;
-            const uint32_t b = bucket_of(nd, delta);
-            if (b <= cur)
+            if (nb <= thr)
                 ro.again = 1;
             else
-                ro.far = b < ro.far ? b : ro.far;
+                ro.far = nb < ro.far ? nb : ro.far;
         }
     }
 }
+
+// relaxes edges i = first, first + step, ... < end of one source at distance du, SSSP_MLP at a time
+constexpr int SSSP_MLP = 4;
+__device__ __forceinline__ void relax_range(const uint32_t *__restrict__ tgt, const float *__restrict__ w, uint32_t *dist,
+                                            uint8_t *__restrict__ flag_next, float du, uint32_t first, uint32_t end,
+                                            uint32_t step, uint32_t thr, RelaxOut &ro)
+{
+    for (uint32_t i = first; i < end; i += step * SSSP_MLP) {
+        uint32_t t[SSSP_MLP], nb[SSSP_MLP], pre[SSSP_MLP];
+#pragma unroll
+        for (int k = 0; k < SSSP_MLP; ++k) {
+            const uint32_t j = i + (uint32_t)k * step;
+            const bool in = j < end;
+            t[k] = in ? tgt[j] : 0u;
+            nb[k] = in ? __float_as_uint(__fadd_rn(du, w[j])) : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int k = 0; k < SSSP_MLP; ++k)
+            pre[k] = nb[k] != 0xFFFFFFFFu ? ld_agent(&dist[t[k]]) : 0u;
+#pragma unroll
+        for (int k = 0; k < SSSP_MLP; ++k)
+            relax_checked(dist, flag_next, nb[k], pre[k], t[k], thr, ro);
+    }
+}
+
+// ctrl words shared by the round and advance kernels
+enum : uint32_t { C_AGAIN = 0, C_FAR = 1, C_BAD = 2, C_THR = 3, C_DONE = 4, C_ROUND = 5, C_ADVANCES = 6 };
 
 // One round.  A wavefront takes 256 consecutive nodes at a time: a 4-byte flag load per lane decides
 // whether anything in the group is flagged (in the long tail of rounds almost nothing is), then each
 // 64-node quarter is relaxed one lane per node.
 __global__ __launch_bounds__(SSSP_BLOCK) void sssp_round_kernel(
     const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const float *__restrict__ w, uint32_t *dist,
-    uint8_t *__restrict__ flag_cur, uint8_t *__restrict__ flag_next, uint32_t n, uint32_t cur, float delta,
-    uint32_t *__restrict__ ctrl /* [0] again, [1] min far bucket */)
+    uint8_t *__restrict__ flags, size_t n_flags, uint32_t n, uint32_t *ctrl)
 {
+    if (ld_agent(&ctrl[C_DONE]))
+        return; // a round enqueued behind the last one of its batch
+    const uint32_t thr = ld_agent(&ctrl[C_THR]);
+    const uint32_t parity = ld_agent(&ctrl[C_ROUND]) & 1u;
+    uint8_t *__restrict__ flag_cur = flags + (parity ? n_flags : 0);
+    uint8_t *__restrict__ flag_next = flags + (parity ? 0 : n_flags);
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -82,14 +114,14 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_round_kernel(
             float du = 0.0f;
             if (u < n && flag_cur[u]) {
                 flag_cur[u] = 0; // this lane is the only reader/writer of flag_cur[u] in this round
-                du = __uint_as_float(ld_agent(&dist[u]));
-                const uint32_t b = bucket_of(du, delta);
-                if (b <= cur) {
+                const uint32_t db = ld_agent(&dist[u]);
+                du = __uint_as_float(db);
+                if (db <= thr) {
                     s = off[u];
                     e = off[u + 1];
                 } else { // not yet its turn: carry over
                     flag_next[u] = 1;
-                    ro.far = b < ro.far ? b : ro.far;
+                    ro.far = db < ro.far ? db : ro.far;
                 }
             }
             // short lists by their own lane, lists longer than 32 edges by the whole wavefront (measured:
@@ -97,16 +129,14 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_round_kernel(
             // by the random dist[] accesses, not by the target stream)
             const uint32_t len = e - s;
             if (len <= SSSP_COOP)
-                for (uint32_t i = s; i < e; ++i)
-                    relax_edge(dist, flag_next, du, tgt[i], w[i], cur, delta, ro);
+                relax_range(tgt, w, dist, flag_next, du, s, e, 1u, thr, ro);
             uint64_t big = __ballot(len > SSSP_COOP);
             while (big) {
                 const int src = __ffsll((unsigned long long)big) - 1;
                 big &= big - 1;
                 const uint32_t bs = __shfl(s, src, kWave), be = __shfl(e, src, kWave);
                 const float bd = __shfl(du, src, kWave);
-                for (uint32_t i = bs + lane; i < be; i += kWave)
-                    relax_edge(dist, flag_next, bd, tgt[i], w[i], cur, delta, ro);
+                relax_range(tgt, w, dist, flag_next, bd, bs + lane, be, kWave, thr, ro);
             }
         }
     }
@@ -114,10 +144,31 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_round_kernel(
     const uint64_t any = __ballot(ro.again != 0);
     if (lane == 0) {
         if (any)
-            atomicOr(&ctrl[0], 1u);
+            atomicOr(&ctrl[C_AGAIN], 1u);
         if (far != NO_BUCKET)
-            atomicMin(&ctrl[1], far);
+            atomicMin(&ctrl[C_FAR], far);
     }
+}
+
+// Between two rounds (one thread): nothing left below the threshold -> move it to the minimum pending
+// distance + width, or finish; then swap the flag buffers (round parity) and clear the round's outputs.
+__global__ void sssp_advance_kernel(uint32_t *ctrl, float width)
+{
+    if (ctrl[C_DONE])
+        return;
+    if (!ctrl[C_AGAIN]) {
+        if (ctrl[C_FAR] == NO_BUCKET) {
+            ctrl[C_DONE] = 1u;
+        } else {
+            const float next = __fadd_rn(__uint_as_float(ctrl[C_FAR]), width);
+            const uint32_t nb = __float_as_uint(next);
+            ctrl[C_THR] = nb > ctrl[C_FAR] && next < 3.0e38f ? nb : ctrl[C_FAR]; // always covers the pending minimum
+            ctrl[C_ADVANCES] += 1u;
+        }
+    }
+    ctrl[C_AGAIN] = 0u;
+    ctrl[C_FAR] = NO_BUCKET;
+    ctrl[C_ROUND] += 1u;
 }
 
 // Partitioned building block: relax every out-edge of the slice's rows whose distance is finite
@@ -201,54 +252,61 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
     GM_TRY(dist.alloc((size_t)n * 4));
     const size_t n_flags = ((size_t)n + 255) & ~(size_t)255; // the round kernel reads flags 4 bytes per lane
     GM_TRY(flags.alloc(n_flags * 2));
-    GM_TRY(ctrl.alloc(16));
-    GM_TRY(hctrl.alloc(16));
+    GM_TRY(ctrl.alloc(32));
+    GM_TRY(hctrl.alloc(32));
     hipStream_t st = 0;
     unsigned grid = gm::div_up(n, SSSP_BLOCK);
     if (grid > 256 * 8)
         grid = 256 * 8;
+    float frac = 1.0f;
+    if (const char *v = getenv("GM_SSSP_WIDTH"))
+        frac = (float)atof(v);
+    if (!(frac > 0.0f))
+        frac = 1.0f;
+    const float width = delta * frac;
 
-    GM_HIP(hipMemsetAsync(ctrl.p, 0, 16, st));
+    // ctrl: again 0, far NONE, bad 0, threshold 0.0 (only the start node qualifies), done 0, round 0, advances 0
+    const uint32_t init_ctrl[8] = {0u, NO_BUCKET, 0u, 0u, 0u, 0u, 0u, 0u};
+    GM_HIP(hipMemcpyAsync(ctrl.p, init_ctrl, 32, hipMemcpyHostToDevice, st));
     if (g->m) {
         unsigned wg = gm::div_up(g->m, 256);
         hipLaunchKernelGGL(sssp_check_weights_kernel, dim3(wg > 8192 ? 8192 : wg), dim3(256), 0, st, g->weights, g->m,
-                           ctrl.as<uint32_t>() + 2);
+                           ctrl.as<uint32_t>() + C_BAD);
     }
     hipLaunchKernelGGL(sssp_init_kernel, dim3(grid), dim3(SSSP_BLOCK), 0, st, dist.as<uint32_t>(), n,
                        (uint32_t)start_node);
     GM_HIP(hipMemsetAsync(flags.p, 0, n_flags * 2, st));
-    uint8_t *fcur = flags.as<uint8_t>(), *fnext = flags.as<uint8_t>() + n_flags;
-    GM_HIP(hipMemsetAsync(fcur + start_node, 1, 1, st));
-    GM_HIP(hipMemcpyAsync(hctrl.p, ctrl.p, 16, hipMemcpyDeviceToHost, st));
+    GM_HIP(hipMemsetAsync(flags.as<uint8_t>() + start_node, 1, 1, st));
+    GM_HIP(hipMemcpyAsync(hctrl.p, ctrl.p, 32, hipMemcpyDeviceToHost, st));
     GM_HIP(hipStreamSynchronize(st));
-    GM_CHECK(hctrl.as<uint32_t>()[2] == 0, GM_ERR_UNSUPPORTED,
+    GM_CHECK(hctrl.as<uint32_t>()[C_BAD] == 0, GM_ERR_UNSUPPORTED,
              "gm_sssp_delta_stepping: negative or NaN edge weight (the reference assumes weights >= 0)");
 
-    uint32_t cur = 0;
-    const uint32_t reset[2] = {0u, NO_BUCKET};
-    uint64_t rounds = 0, bucket_moves = 0;
+    const bool stats = getenv("GM_SSSP_STATS") != nullptr;
+    const int batch = stats ? 1 : 8; // rounds enqueued per host synchronisation
+    auto t_prev = std::chrono::steady_clock::now();
     for (;;) {
-        ++rounds;
-        GM_HIP(hipMemcpyAsync(ctrl.p, reset, 8, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(sssp_round_kernel, dim3(grid), dim3(SSSP_BLOCK), 0, st, g->offsets, g->targets, g->weights,
-                           dist.as<uint32_t>(), fcur, fnext, n, cur, delta, ctrl.as<uint32_t>());
+        for (int k = 0; k < batch; ++k) {
+            hipLaunchKernelGGL(sssp_round_kernel, dim3(grid), dim3(SSSP_BLOCK), 0, st, g->offsets, g->targets, g->weights,
+                               dist.as<uint32_t>(), flags.as<uint8_t>(), n_flags, n, ctrl.as<uint32_t>());
+            hipLaunchKernelGGL(sssp_advance_kernel, dim3(1), dim3(1), 0, st, ctrl.as<uint32_t>(), width);
+        }
         GM_HIP(hipGetLastError());
-        GM_HIP(hipMemcpyAsync(hctrl.p, ctrl.p, 8, hipMemcpyDeviceToHost, st));
+        GM_HIP(hipMemcpyAsync(hctrl.p, ctrl.p, 32, hipMemcpyDeviceToHost, st));
         GM_HIP(hipStreamSynchronize(st));
-        uint8_t *tmp = fcur;
-        fcur = fnext;
-        fnext = tmp;
-        const uint32_t again = hctrl.as<uint32_t>()[0], far = hctrl.as<uint32_t>()[1];
-        if (again)
-            continue;
-        if (far == NO_BUCKET)
+        const uint32_t *hc = hctrl.as<uint32_t>();
+        if (stats) { // batch = 1: wall clock between synchronisations is the round time
+            const auto t_now = std::chrono::steady_clock::now();
+            fprintf(stderr, "sssp round %u threshold %.6f: %.3f ms\n", hc[C_ROUND], __builtin_bit_cast(float, hc[C_THR]),
+                    std::chrono::duration<double, std::milli>(t_now - t_prev).count());
+            t_prev = t_now;
+        }
+        if (hc[C_DONE])
             break;
-        cur = far;
-        ++bucket_moves;
     }
-    if (getenv("GM_SSSP_STATS"))
-        fprintf(stderr, "sssp: %llu rounds, %llu bucket advances, last bucket %u\n", (unsigned long long)rounds,
-                (unsigned long long)bucket_moves, cur);
+    if (stats)
+        fprintf(stderr, "sssp: %u rounds, %u threshold advances, width %.6f\n", hctrl.as<uint32_t>()[C_ROUND],
+                hctrl.as<uint32_t>()[C_ADVANCES], width);
     GM_HIP(hipMemcpy(distances_out, dist.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return GM_OK;
 }
