@@ -49,6 +49,10 @@ def parse_args():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
                     "exercising the multi-rank path with several ranks on ONE device)")
     ap.add_argument("--single-device", type=int, default=0, help="debug: all ranks use cuda:0 (needs --backend gloo)")
+    ap.add_argument("--exchange-parts", type=int, default=0,
+                    help="N > 1: regions of the out_scores exchange that overlap with the work (1 = one blocking all-gather "
+                         "per sweep; 0 = automatic: 2 up to 4 ranks, 1 beyond, where the per-rank kernels (~0.35 ms at scale "
+                         "26) are too short to pay for being launched in pieces)")
     ap.add_argument("--emulate-parts", type=int, default=0, help="debug (1 process): time only the row slice that "
                     "rank --emulate-rank of an N-way partition would own, without the exchange")
     ap.add_argument("--emulate-rank", type=int, default=0)
@@ -112,11 +116,17 @@ def main():
     emu = args.emulate_parts if world == 1 else 0
     if emu:
         world, rank = emu, args.emulate_rank  # pretend; no process group exists
+    if args.exchange_parts == 0:
+        args.exchange_parts = 2 if world <= 4 else 1
+    piecewise = world > 1 and args.exchange_parts > 1 and args.engine != "pull"
+    ex = None
     if world == 1:
         local_csr, row_lo, n_local, stride = in_csr, 0, n, n
         out_deg_local = out_deg
+        x_len = n
     else:
-        from graph_amd.distributed import compact_exchange_layout, greedy_degree_partition, pad_bounds
+        from graph_amd.distributed import (PiecewiseExchange, compact_exchange_layout, greedy_degree_partition, pad_bounds,
+                                           split_exchange_layout)
 
         off_host = np.empty(n + 1, np.uint32)
         check(lib().gm_csr_download(in_csr.handle, off_host.ctypes.data_as(vp), None, None))
@@ -124,9 +134,14 @@ def main():
         row_lo, row_hi = int(bounds[rank]), int(bounds[rank + 1])
         n_local = row_hi - row_lo
         # exchange only the out_scores of nodes that have out-edges (the others are never gathered)
-        node_map, send_counts, stride, send_rows_all = compact_exchange_layout(out_deg, bounds)
-        send_rows = send_rows_all[rank]
-        del send_rows_all
+        if piecewise:
+            layout = split_exchange_layout(out_deg, bounds, parts=args.exchange_parts)
+            node_map, x_len, stride = layout["node_map"], layout["x_len"], sum(layout["strides"])
+        else:
+            node_map, send_counts, stride, send_rows_all = compact_exchange_layout(out_deg, bounds)
+            send_rows = send_rows_all[rank]
+            del send_rows_all
+            x_len = world * stride
         h = vp()
         check(lib().gm_csr_slice_rows_map(in_csr.handle, row_lo, row_hi, node_map.data_ptr(), C.byref(h)))
         del node_map
@@ -137,40 +152,51 @@ def main():
         del in_csr, off_host
         torch.cuda.empty_cache()
     m_local = local_csr.m
-    if emu:
-        x_len_emu = world * stride
 
-    engine = PageRankEngine(local_csr.handle, n, row_lo, out_deg_local, 0.85,
-                            x_len=world * stride if world > 1 else n,
-                            engine={"auto": 0, "pull": 1, "pb": 2}[args.engine])
-    x = [torch.zeros(world * stride if world > 1 else n, dtype=torch.float32, device=dev) for _ in range(2)]
-    x_loc = torch.zeros(max(n_local, 1), dtype=torch.float32, device=dev) if world > 1 else None
-    x_send = torch.zeros(stride, dtype=torch.float32, device=dev) if world > 1 else None
+    engine = PageRankEngine(local_csr.handle, n, row_lo, out_deg_local, 0.85, x_len=x_len,
+                            engine={"auto": 2 if piecewise else 0, "pull": 1, "pb": 2}[args.engine])
     scores = torch.zeros(max(n_local, 1), dtype=torch.float32, device=dev)
     err = torch.zeros(1, dtype=torch.float64, device=dev)
-
-    def exchange(dst_buf):
-        x_send[: send_rows.numel()] = x_loc[send_rows]  # compaction gather (33 MB -> ~12 MB per rank at scale 26)
-        if emu:  # stand-in: only this rank's slot is refreshed
-            dst_buf[rank * stride:(rank + 1) * stride] = x_send
-            return
-        dist.all_gather_into_tensor(dst_buf, x_send)
-
-    if world == 1:
-        engine.init(scores, x[0])
+    if piecewise:
+        gather = None
+        if emu:  # stand-in for the collective: only this rank's slot of the region is refreshed
+            def gather(dst_region, src, k):
+                st = layout["strides"][k]
+                dst_region[rank * st:(rank + 1) * st] = src
+        ex = PiecewiseExchange(engine, layout, rank, n_local, dev, gather=gather)
+        ex.start(scores)
     else:
-        engine.init(scores, x_loc)
-        exchange(x[0])
+        x = [torch.zeros(x_len, dtype=torch.float32, device=dev) for _ in range(2)]
+        x_loc = torch.zeros(max(n_local, 1), dtype=torch.float32, device=dev) if world > 1 else None
+        x_send = torch.zeros(stride, dtype=torch.float32, device=dev) if world > 1 else None
+
+        def exchange(dst_buf):
+            x_send[: send_rows.numel()] = x_loc[send_rows]  # compaction gather (33 MB -> ~12 MB per rank at scale 26)
+            if emu:  # stand-in: only this rank's slot is refreshed
+                dst_buf[rank * stride:(rank + 1) * stride] = x_send
+                return
+            dist.all_gather_into_tensor(dst_buf, x_send)
+
+        if world == 1:
+            engine.init(scores, x[0])
+        else:
+            engine.init(scores, x_loc)
+            exchange(x[0])
     cur = 0
 
     def step(timed_events=None):
+        """timed_events: list that receives (start, end) event pairs around the sweep's kernels"""
         nonlocal cur
+        if piecewise:
+            ex.sweep(scores, err, timed_events)
+            return
         out_local = x[1 - cur] if world == 1 else x_loc
         if timed_events is not None:
-            e0, e1 = timed_events
-            e0.record()
+            pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            pair[0].record()
             engine.sweep_tiles(x[cur], out_local, scores)
-            e1.record()
+            pair[1].record()
+            timed_events.append(pair)
         else:
             engine.sweep_tiles(x[cur], out_local, scores)
         engine.sweep_fixup(out_local, scores, err)
@@ -198,18 +224,19 @@ def main():
     for _ in range(args.warmup):
         step()
     sync_all()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    evs = []
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(evs[k])
+        step(evs)
     sync_all()
     seconds = time.perf_counter() - t0
+    if piecewise:
+        ex.finish()
     if world > 1 and not emu:
         tt = torch.tensor([seconds], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         seconds = float(tt.item())
-    tile_ms = [a.elapsed_time(b) for a, b in evs]
-    tile_ms_avg = sum(tile_ms) / max(len(tile_ms), 1)
+    tile_ms_avg = sum(a.elapsed_time(b) for a, b in evs) / max(args.steps, 1)  # kernel time per sweep
     if world > 1 and not emu:
         dist.all_reduce(err, op=dist.ReduceOp.SUM)
     final_err = float(err.item())
@@ -249,7 +276,8 @@ def main():
             "nodes": n, "edges": m, "step": "one sweep over all in-edges",
             "partition": "none" if world == 1 else
                          f"1-D vertex ranges (greedy in-degree), {world} ranks, all-gather of {stride * 4} B/rank/sweep "
-                         f"(only nodes with out-edges)",
+                         f"(only nodes with out-edges)" + (f" in {args.exchange_parts} regions overlapped with the work"
+                                                            if piecewise else ""),
             "csr_build_s": round(t_build, 3), "final_sweep_error": final_err, "workgroups_per_sweep": engine.tiles, "engine": engine.engine,
         },
         "roofline": {
@@ -289,6 +317,7 @@ def main():
         dist.destroy_process_group()
     # release every device object explicitly before interpreter shutdown (a HIP call from a
     # destructor during Python finalisation was seen to block forever under rocprofv3)
+    ex = None
     del engine, local_csr
     in_csr = None
     import gc

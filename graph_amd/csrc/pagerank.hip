@@ -524,6 +524,45 @@ GM_API int gm_pr_sweep_fixup(gm_pr *pr, uint64_t d_x_out_local, uint64_t d_score
     return GM_OK;
 }
 
+GM_API int gm_pr_part_geometry(const gm_pr *pr, uint64_t *rows_per_bin_out, uint64_t *source_tile_out)
+{
+    GM_CHECK(pr && rows_per_bin_out && source_tile_out, GM_ERR_INVALID, "gm_pr_part_geometry: null argument");
+    GM_CHECK(pr->engine == GM_PR_ENGINE_PB, GM_ERR_UNSUPPORTED, "gm_pr_part_geometry: not a propagation-blocking engine");
+    *rows_per_bin_out = gm::pb_rows_per_bin(pr->pb);
+    *source_tile_out = gm::pb_source_tile();
+    return GM_OK;
+}
+
+GM_API int gm_pr_set_parts(gm_pr *pr, const uint64_t *row_splits, uint64_t n_parts)
+{
+    GM_CHECK(pr && row_splits, GM_ERR_INVALID, "gm_pr_set_parts: null argument");
+    GM_CHECK(pr->engine == GM_PR_ENGINE_PB, GM_ERR_UNSUPPORTED, "gm_pr_set_parts: not a propagation-blocking engine");
+    GM_CHECK(n_parts >= 1 && n_parts <= 64, GM_ERR_INVALID, "gm_pr_set_parts: %llu parts", (unsigned long long)n_parts);
+    gm::DeviceGuard guard(pr->csr->device);
+    return gm::pb_set_parts(pr->pb, pr->pb_scratch, row_splits, (uint32_t)n_parts);
+}
+
+GM_API int gm_pr_sweep_bin(gm_pr *pr, uint64_t d_x_in_global, uint64_t tile_lo, uint64_t tile_hi, void *stream)
+{
+    GM_CHECK(pr && d_x_in_global, GM_ERR_INVALID, "gm_pr_sweep_bin: null argument");
+    GM_CHECK(pr->engine == GM_PR_ENGINE_PB, GM_ERR_UNSUPPORTED, "gm_pr_sweep_bin: not a propagation-blocking engine");
+    gm::DeviceGuard guard(pr->csr->device);
+    return gm::pb_sweep_bin_tiles(pr->pb, pr->pb_scratch, reinterpret_cast<const float *>(d_x_in_global), tile_lo, tile_hi,
+                                  (hipStream_t)stream);
+}
+
+GM_API int gm_pr_sweep_accum(gm_pr *pr, uint64_t d_x_in_global, uint64_t d_x_out_local, uint64_t d_scores_local,
+                             uint64_t part, void *stream)
+{
+    GM_CHECK(pr && d_x_in_global, GM_ERR_INVALID, "gm_pr_sweep_accum: null argument");
+    GM_CHECK(pr->engine == GM_PR_ENGINE_PB, GM_ERR_UNSUPPORTED, "gm_pr_sweep_accum: not a propagation-blocking engine");
+    GM_CHECK(part < 64, GM_ERR_INVALID, "gm_pr_sweep_accum: part %llu", (unsigned long long)part);
+    gm::DeviceGuard guard(pr->csr->device);
+    return gm::pb_sweep_accum_part(pr->pb, pr->pb_scratch, reinterpret_cast<const float *>(d_x_in_global),
+                                   reinterpret_cast<float *>(d_x_out_local), reinterpret_cast<float *>(d_scores_local),
+                                   pr->outdeg, pr->base, pr->damping, (uint32_t)part, (hipStream_t)stream);
+}
+
 GM_API int gm_pr_sweep(gm_pr *pr, uint64_t d_x_in_global, uint64_t d_x_out_local, uint64_t d_scores_local,
                        uint64_t d_error_out, void *stream)
 {

@@ -52,6 +52,10 @@ constexpr float PB_FIX_INV = 2.168404344971008868e-19f;    // 2^-62
 
 // mutable per-engine buffers: engines on one shared plan never touch each other's data
 struct PbScratch {
+    // row parts of a partitioned sweep (gm_pr_set_parts): the items of part k are
+    // part_items[part_off[k] .. part_off[k+1]), each part longest-first
+    DevBuf part_items;
+    std::vector<uint32_t> part_off;
     DevBuf vals_raw; // backing allocation of the value stream
     float *vals = nullptr; // f32[Mv] per-edge values, bin-major, segments padded to 4
     DevBuf partials; // u64[slots x R] partial LDS accumulators of split bins
@@ -98,6 +102,11 @@ struct PbPlan {
     DevBuf hot_ent;     // u32[Mh]  hot edges, bin-major: row_in_bin << 16 | hot index; 0xFFFFFFFF = padding
     DevBuf hbin_v;      // u32[B+1] hot-edge range of each bin (multiples of 4)
     uint64_t Mh = 0;
+    // host copies for launches over a range of source tiles / a group of bins (partitioned sweeps that
+    // overlap the exchange of one part of x with the work on another)
+    std::vector<uint32_t> wg_first_host; // u32[NT+1] first phase-1 workgroup of each tile
+    std::vector<PbItem> items_host;      // the accumulate items in dispatch order
+    int xcd_aware = 1;
 };
 
 namespace {
@@ -359,24 +368,13 @@ __global__ void pb_wg_count_kernel(const uint32_t *__restrict__ tile_p, uint32_t
         wg_cnt[t] = t == NT ? 0u : (tile_p[t + 1] - tile_p[t] + chunk - 1u) / chunk;
 }
 
-// Launch slot s runs on XCD s % 8 (observed dispatch rule; used for speed only).  With xcd_aware the
-// slots of one XCD take consecutive work items (tile-major order), so the cache lines shared by the
-// adjacent segments of consecutive tiles in the value stream are completed inside one L2 instead of
-// leaving two partial write-backs.  slot -> item is a bijection: item = base[s % 8] + s / 8.
+// work items in tile-major order: wg_tile[w] / wg_p0[w] of item w
 __global__ void pb_wg_fill_kernel(const uint32_t *__restrict__ tile_p, const uint32_t *__restrict__ wg_first, uint32_t NT,
-                                  uint32_t PB_BIN_CHUNK, uint32_t NW, int xcd_aware, uint32_t *__restrict__ wg_tile,
+                                  uint32_t PB_BIN_CHUNK, uint32_t NW, uint32_t *__restrict__ wg_tile,
                                   uint32_t *__restrict__ wg_p0)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < NW; s += stride) {
-        uint32_t w = s;
-        if (xcd_aware) {
-            const uint32_t x = s & 7u;
-            uint32_t base = 0;
-            for (uint32_t y = 0; y < x; ++y)
-                base += (NW - y + 7u) / 8u;
-            w = base + (s >> 3);
-        }
+    for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < NW; w += stride) {
         // tile of item w: last t with wg_first[t] <= w
         uint32_t lo = 0, hi = NT;
         while (hi - lo > 1) {
@@ -386,9 +384,22 @@ __global__ void pb_wg_fill_kernel(const uint32_t *__restrict__ tile_p, const uin
             else
                 hi = mid;
         }
-        wg_tile[s] = lo;
-        wg_p0[s] = tile_p[lo] + (w - wg_first[lo]) * PB_BIN_CHUNK;
+        wg_tile[w] = lo;
+        wg_p0[w] = tile_p[lo] + (w - wg_first[lo]) * PB_BIN_CHUNK;
     }
+}
+
+// Launch slot s runs on XCD s % 8 (observed dispatch rule; used for speed only).  The slots of one XCD
+// take consecutive work items (tile-major order), so the cache lines shared by the adjacent segments
+// of consecutive tiles in the value stream are completed inside one L2 instead of leaving two partial
+// write-backs.  slot -> item is a bijection on [0, count): item = base[s % 8] + s / 8.
+__device__ __forceinline__ uint32_t pb_xcd_item(uint32_t s, uint32_t count)
+{
+    const uint32_t x = s & 7u;
+    uint32_t base = 0;
+    for (uint32_t y = 0; y < x; ++y)
+        base += (count - y + 7u) / 8u;
+    return base + (s >> 3);
 }
 
 // chunk_seg[c] = number of segments with pstart < 256 c
@@ -440,13 +451,14 @@ __global__ __launch_bounds__(PB_BIN_BLOCK) void pb_bin_kernel(const float *__res
                                                               const uint16_t *__restrict__ p1_src,
                                                               const uint32_t *__restrict__ chunk_seg,
                                                               const uint32_t *__restrict__ delta, float *__restrict__ vals,
-                                                              uint32_t PB_BIN_CHUNK)
+                                                              uint32_t PB_BIN_CHUNK, uint32_t w_first, int xcd_aware)
 {
     extern __shared__ float xs[];                                   // PB_S floats ...
     uint32_t *dl = reinterpret_cast<uint32_t *>(xs + PB_S);         // ... + PB_DCACHE segment deltas
     const uint32_t tid = threadIdx.x;
-    const uint32_t t = wg_tile[blockIdx.x];
-    const uint32_t p_begin = wg_p0[blockIdx.x];
+    const uint32_t item = w_first + (xcd_aware ? pb_xcd_item(blockIdx.x, gridDim.x) : blockIdx.x);
+    const uint32_t t = wg_tile[item];
+    const uint32_t p_begin = wg_p0[item];
     const uint32_t tile_end = tile_p[t + 1];
     const uint32_t p_end = (tile_end - p_begin) < PB_BIN_CHUNK ? tile_end : p_begin + PB_BIN_CHUNK;
     const uint64_t x0 = (uint64_t)t * PB_S;
@@ -901,6 +913,7 @@ int pb_make_items(PbPlan *pl)
     pl->NI = (uint32_t)items.size();
     GM_TRY(pl->items.alloc(items.size() * sizeof(PbItem)));
     GM_HIP(hipMemcpy(pl->items.p, items.data(), items.size() * sizeof(PbItem), hipMemcpyHostToDevice));
+    pl->items_host = items;
     pl->slots = slots;
     return GM_OK;
 }
@@ -1209,8 +1222,10 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     GM_TRY(pl->wg_tile.alloc((size_t)NW * 4));
     GM_TRY(pl->wg_p0.alloc((size_t)NW * 4));
     hipLaunchKernelGGL(pb_wg_fill_kernel, dim3(pb_grid(NW)), dim3(256), 0, 0, pl->tile_p.as<uint32_t>(),
-                       wg_first.as<uint32_t>(), pl->NT, pl->chunk, NW, pb_env("GM_PB_XCD", 1), pl->wg_tile.as<uint32_t>(),
-                       pl->wg_p0.as<uint32_t>());
+                       wg_first.as<uint32_t>(), pl->NT, pl->chunk, NW, pl->wg_tile.as<uint32_t>(), pl->wg_p0.as<uint32_t>());
+    pl->xcd_aware = pb_env("GM_PB_XCD", 1);
+    pl->wg_first_host.resize((size_t)pl->NT + 1);
+    GM_HIP(hipMemcpy(pl->wg_first_host.data(), wg_first.p, ((size_t)pl->NT + 1) * 4, hipMemcpyDeviceToHost));
     GM_HIP(hipGetLastError());
     GM_HIP(hipDeviceSynchronize());
     return GM_OK;
@@ -1310,48 +1325,130 @@ void pb_scratch_destroy(PbScratch *scratch) { delete scratch; }
 
 uint64_t pb_work_items(const PbPlan *plan) { return plan ? (uint64_t)plan->NW + plan->NI : 0; }
 
-template <int ABL> void pb_launch_bin(const PbPlan *pl, PbScratch *sc, const float *x_in, hipStream_t st)
+template <int ABL>
+void pb_launch_bin(const PbPlan *pl, PbScratch *sc, const float *x_in, uint32_t w_first, uint32_t w_count, hipStream_t st)
 {
-    hipLaunchKernelGGL(pb_bin_kernel<ABL>, dim3(pl->NW), dim3(PB_BIN_BLOCK), PB_S * 4 + PB_DCACHE * 4, st, x_in, pl->x_len,
+    hipLaunchKernelGGL(pb_bin_kernel<ABL>, dim3(w_count), dim3(PB_BIN_BLOCK), PB_S * 4 + PB_DCACHE * 4, st, x_in, pl->x_len,
                        pl->tile_p.as<uint32_t>(), pl->wg_tile.as<uint32_t>(), pl->wg_p0.as<uint32_t>(),
                        pl->p1_src.as<uint16_t>(), pl->chunk_seg.as<uint32_t>(), pl->delta.as<uint32_t>(), sc->vals,
-                       pl->chunk);
+                       pl->chunk, w_first, pl->xcd_aware);
 }
 
 template <int ABL>
-void pb_launch_accum(const PbPlan *pl, PbScratch *sc, float *x_out, float *scores, const uint32_t *outdeg, float base,
-                     float damping, hipStream_t st)
+void pb_launch_accum(const PbPlan *pl, PbScratch *sc, const PbItem *items, uint32_t count, float *x_out, float *scores,
+                     const uint32_t *outdeg, float base, float damping, hipStream_t st)
 {
-    hipLaunchKernelGGL(pb_accum_kernel<ABL>, dim3(pl->NI), dim3(PB_ACC_BLOCK), (size_t)pl->Racc * 8 + (((size_t)pl->H + 3) & ~(size_t)3) * 4, st,
-                       sc->vals, pl->p2_dst.as<uint16_t>(), pl->items.as<PbItem>(), pl->hot_ent.as<uint32_t>(),
-                       sc->hot_x.as<float>(), pl->H, sc->partials.as<unsigned long long>(), sc->tickets.as<uint32_t>(),
-                       pl->cidx.as<uint16_t>(), outdeg, scores, x_out, sc->bin_err.as<double>(), pl->n_local, pl->R,
-                       pl->Racc, base, damping);
+    hipLaunchKernelGGL(pb_accum_kernel<ABL>, dim3(count), dim3(PB_ACC_BLOCK),
+                       (size_t)pl->Racc * 8 + (((size_t)pl->H + 3) & ~(size_t)3) * 4, st, sc->vals, pl->p2_dst.as<uint16_t>(),
+                       items, pl->hot_ent.as<uint32_t>(), sc->hot_x.as<float>(), pl->H,
+                       sc->partials.as<unsigned long long>(), sc->tickets.as<uint32_t>(), pl->cidx.as<uint16_t>(), outdeg,
+                       scores, x_out, sc->bin_err.as<double>(), pl->n_local, pl->R, pl->Racc, base, damping);
+}
+
+// GM_PB_ABLATE = 10*accumulate variant + bin variant; 0 = the product kernels (re-read per call so that
+// tools/ablate.py can switch variants on one resident graph)
+static void pb_bin_dispatch(const PbPlan *pl, PbScratch *sc, const float *x_in, uint32_t w_first, uint32_t w_count,
+                            hipStream_t st)
+{
+    if (w_count == 0)
+        return;
+    switch (pb_env("GM_PB_ABLATE", 0) % 10) {
+    case 1: pb_launch_bin<1>(pl, sc, x_in, w_first, w_count, st); break;
+    case 3: pb_launch_bin<3>(pl, sc, x_in, w_first, w_count, st); break;
+    case 4: pb_launch_bin<4>(pl, sc, x_in, w_first, w_count, st); break;
+    case 5: pb_launch_bin<5>(pl, sc, x_in, w_first, w_count, st); break;
+    default: pb_launch_bin<0>(pl, sc, x_in, w_first, w_count, st); break;
+    }
+}
+
+static void pb_accum_dispatch(const PbPlan *pl, PbScratch *sc, const PbItem *items, uint32_t count, float *x_out,
+                              float *scores, const uint32_t *outdeg, float base, float damping, hipStream_t st)
+{
+    if (count == 0)
+        return;
+    switch (pb_env("GM_PB_ABLATE", 0) / 10) {
+    case 3: pb_launch_accum<3>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
+    case 4: pb_launch_accum<4>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
+    default: pb_launch_accum<0>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
+    }
+}
+
+static void pb_hot_dispatch(const PbPlan *pl, PbScratch *sc, const float *x_in, hipStream_t st)
+{
+    if (pl->H)
+        hipLaunchKernelGGL(pb_hot_gather_kernel, dim3(div_up(pl->H, 256)), dim3(256), 0, st, x_in,
+                           pl->hot_ids.as<uint32_t>(), pl->H, sc->hot_x.as<float>());
 }
 
 int pb_sweep_main(const PbPlan *pl, PbScratch *sc, const float *x_in, float *x_out, float *scores,
                   const uint32_t *outdeg, float base, float damping, hipStream_t st)
 {
-    // GM_PB_ABLATE = 10*accumulate variant + bin variant; 0 = the product kernels (re-read per call so
-    // that tools/ablate.py can switch variants on one resident graph)
-    const int ablate = pb_env("GM_PB_ABLATE", 0);
-    if (pl->H)
-        hipLaunchKernelGGL(pb_hot_gather_kernel, dim3(div_up(pl->H, 256)), dim3(256), 0, st, x_in,
-                           pl->hot_ids.as<uint32_t>(), pl->H, sc->hot_x.as<float>());
-    if (pl->NW) {
-        switch (ablate % 10) {
-        case 1: pb_launch_bin<1>(pl, sc, x_in, st); break;
-        case 3: pb_launch_bin<3>(pl, sc, x_in, st); break;
-        case 4: pb_launch_bin<4>(pl, sc, x_in, st); break;
-        case 5: pb_launch_bin<5>(pl, sc, x_in, st); break;
-        default: pb_launch_bin<0>(pl, sc, x_in, st); break;
-        }
+    pb_hot_dispatch(pl, sc, x_in, st);
+    pb_bin_dispatch(pl, sc, x_in, 0, pl->NW, st);
+    pb_accum_dispatch(pl, sc, pl->items.as<PbItem>(), pl->NI, x_out, scores, outdeg, base, damping, st);
+    GM_HIP(hipGetLastError());
+    return GM_OK;
+}
+
+// ---- partitioned sweeps in pieces (overlap of the exchange with the work) ----------
+uint32_t pb_rows_per_bin(const PbPlan *pl) { return pl->R; }
+uint32_t pb_source_tile() { return PB_S; }
+
+// bins [row_splits[k] / R, row_splits[k+1] / R) form part k; row_splits[0] = 0, the last one = n_local,
+// the inner ones multiples of R
+int pb_set_parts(const PbPlan *pl, PbScratch *sc, const uint64_t *row_splits, uint32_t n_parts)
+{
+    GM_CHECK(n_parts >= 1 && row_splits && row_splits[0] == 0 && row_splits[n_parts] == pl->n_local, GM_ERR_INVALID,
+             "gm_pr_set_parts: the splits must start at 0 and end at the %u local rows", pl->n_local);
+    std::vector<uint32_t> first_bin(n_parts + 1);
+    for (uint32_t k = 0; k <= n_parts; ++k) {
+        GM_CHECK(k == 0 || row_splits[k] >= row_splits[k - 1], GM_ERR_INVALID, "gm_pr_set_parts: splits must ascend");
+        GM_CHECK(k == n_parts || row_splits[k] % pl->R == 0, GM_ERR_INVALID,
+                 "gm_pr_set_parts: split %llu is not a multiple of the %u rows of a bin",
+                 (unsigned long long)row_splits[k], pl->R);
+        first_bin[k] = k == n_parts ? pl->B : (uint32_t)(row_splits[k] / pl->R);
     }
-    switch (ablate / 10) {
-    case 3: pb_launch_accum<3>(pl, sc, x_out, scores, outdeg, base, damping, st); break;
-    case 4: pb_launch_accum<4>(pl, sc, x_out, scores, outdeg, base, damping, st); break;
-    default: pb_launch_accum<0>(pl, sc, x_out, scores, outdeg, base, damping, st); break;
+    std::vector<PbItem> ordered;
+    ordered.reserve(pl->items_host.size());
+    sc->part_off.assign(n_parts + 1, 0);
+    for (uint32_t k = 0; k < n_parts; ++k) {
+        sc->part_off[k] = (uint32_t)ordered.size();
+        for (const PbItem &it : pl->items_host) // keeps the longest-first order inside the part
+            if (it.bin >= first_bin[k] && it.bin < first_bin[k + 1])
+                ordered.push_back(it);
     }
+    sc->part_off[n_parts] = (uint32_t)ordered.size();
+    GM_CHECK(ordered.size() == pl->items_host.size(), GM_ERR_INVALID, "gm_pr_set_parts: the parts do not cover every bin");
+    GM_TRY(sc->part_items.alloc(ordered.size() * sizeof(PbItem)));
+    GM_HIP(hipMemcpy(sc->part_items.p, ordered.data(), ordered.size() * sizeof(PbItem), hipMemcpyHostToDevice));
+    return GM_OK;
+}
+
+// propagates the x values of source tiles [tile_lo, tile_hi) into the value stream
+int pb_sweep_bin_tiles(const PbPlan *pl, PbScratch *sc, const float *x_in, uint64_t tile_lo, uint64_t tile_hi, hipStream_t st)
+{
+    if (tile_hi > pl->NT)
+        tile_hi = pl->NT;
+    if (pl->NW == 0 || tile_lo >= tile_hi)
+        return GM_OK;
+    const uint32_t w0 = pl->wg_first_host[tile_lo], w1 = pl->wg_first_host[tile_hi];
+    pb_bin_dispatch(pl, sc, x_in, w0, w1 - w0, st);
+    GM_HIP(hipGetLastError());
+    return GM_OK;
+}
+
+// accumulates and finishes the rows of part `part`; part 0 also stages the hot sources' values, so the
+// parts run in ascending order, after every tile of x has been propagated
+int pb_sweep_accum_part(const PbPlan *pl, PbScratch *sc, const float *x_in, float *x_out, float *scores,
+                        const uint32_t *outdeg, float base, float damping, uint32_t part, hipStream_t st)
+{
+    GM_CHECK(sc->part_off.size() >= 2 && part + 1 < sc->part_off.size(), GM_ERR_INVALID,
+             "gm_pr_sweep_accum: part %u of %zu (call gm_pr_set_parts first)", part,
+             sc->part_off.empty() ? (size_t)0 : sc->part_off.size() - 1);
+    if (part == 0)
+        pb_hot_dispatch(pl, sc, x_in, st);
+    const uint32_t i0 = sc->part_off[part], i1 = sc->part_off[part + 1];
+    pb_accum_dispatch(pl, sc, sc->part_items.as<PbItem>() + i0, i1 - i0, x_out, scores, outdeg, base, damping, st);
     GM_HIP(hipGetLastError());
     return GM_OK;
 }

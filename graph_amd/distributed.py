@@ -81,6 +81,149 @@ def compact_exchange_layout(out_degree, bounds):
     return node_map, counts, stride, send_rows
 
 
+ROW_ALIGN = 16384  # row splits of a sweep in pieces: a multiple of the rows per bin of any plan (<= 16384)
+SOURCE_TILE = 16384  # x regions of a sweep in pieces: a multiple of the source tile (gm_pr_part_geometry)
+
+
+def split_exchange_layout(out_degree, bounds, parts: int = 2, row_align: int = ROW_ALIGN, tile: int = SOURCE_TILE):
+    """compact_exchange_layout for a sweep in pieces: every rank cuts its rows into `parts` groups (at
+    multiples of row_align) and the exchanged vector into as many regions, region k holding group k of
+    every rank (rank-major, `strides[k]` floats per rank, a multiple of `tile`), so that region k can be
+    all-gathered while the ranks still work on group k+1 and be consumed (source tiles
+    [tile_ranges[k][0], tile_ranges[k][1])) while region k+1 is still in flight.
+    Returns a dict: node_map int32[n] (-1: never a source), x_len, strides[k], region_off[k],
+    tile_ranges[k], row_splits[rank] (parts+1 local row indices), send_rows[rank][k] (local rows, slot order)."""
+    has_out = out_degree > 0
+    world = len(bounds) - 1
+    n = out_degree.numel()
+    dev = out_degree.device
+    node_map = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    row_splits, send_rows = [], []
+    for p in range(world):
+        lo, hi = int(bounds[p]), int(bounds[p + 1])
+        n_loc = hi - lo
+        sp = [min(n_loc, -(-(n_loc * k // parts) // row_align) * row_align) for k in range(parts)] + [n_loc]
+        row_splits.append(sp)
+        send_rows.append([sp[k] + torch.nonzero(has_out[lo + sp[k]:lo + sp[k + 1]], as_tuple=False).flatten()
+                          for k in range(parts)])
+    strides, region_off, tile_ranges, off = [], [], [], 0
+    for k in range(parts):
+        most = max(int(send_rows[p][k].numel()) for p in range(world))
+        stride = max(tile, -(-most // tile) * tile)
+        strides.append(stride)
+        region_off.append(off)
+        tile_ranges.append((off // tile, (off + world * stride) // tile))
+        off += world * stride
+    for p in range(world):
+        lo = int(bounds[p])
+        for k in range(parts):
+            rows = send_rows[p][k]
+            node_map[lo + rows] = (region_off[k] + p * strides[k] + torch.arange(rows.numel(), device=dev)).to(torch.int32)
+    return {"node_map": node_map, "x_len": off, "strides": strides, "region_off": region_off, "tile_ranges": tile_ranges,
+            "row_splits": row_splits, "send_rows": send_rows, "parts": parts}
+
+
+class PiecewiseExchange:
+    """The per-sweep schedule of a partitioned PageRank whose exchange overlaps the work:
+
+        wait region 0 -> propagate its tiles -> wait region 1 -> propagate its tiles -> ...
+        rows of group 0 -> start all-gather of region 0 -> rows of group 1 -> start all-gather of region 1 ...
+
+    so the all-gather of region k runs (RCCL, its own stream) under the accumulate of group k+1 and under
+    the propagation of regions < k of the next sweep.  engine: sweep_bin / sweep_accum / sweep_fixup /
+    set_parts (graph_amd.engine.PageRankEngine, or a stand-in with the same methods)."""
+
+    def __init__(self, engine, layout, rank: int, n_local: int, device, group=None, gather=None):
+        self.engine, self.layout, self.rank, self.group = engine, layout, rank, group
+        world = len(layout["row_splits"])
+        self.parts = layout["parts"]
+        self.x = [torch.zeros(layout["x_len"], dtype=torch.float32, device=device) for _ in range(2)]
+        self.x_loc = torch.zeros(max(n_local, 1), dtype=torch.float32, device=device)
+        self.x_send = [torch.zeros(s, dtype=torch.float32, device=device) for s in layout["strides"]]
+        self.send_rows = [r.to(device) for r in layout["send_rows"][rank]]
+        self.regions = [(layout["region_off"][k], layout["region_off"][k] + world * layout["strides"][k])
+                        for k in range(self.parts)]
+        self.cur = 0
+        self.works = [None] * self.parts
+        # gather(dst_region, src, k): stand-in for the collective (single-process emulation); default RCCL/gloo
+        self._gather = gather
+        engine.set_parts(layout["row_splits"][rank])
+
+    def _start_gather(self, buf: int, k: int):
+        rows = self.send_rows[k]
+        self.x_send[k][: rows.numel()] = self.x_loc[rows]  # compaction: only nodes with out-edges travel
+        lo, hi = self.regions[k]
+        dst = self.x[buf][lo:hi]
+        if self._gather is not None:
+            self._gather(dst, self.x_send[k], k)
+            self.works[k] = None
+        else:
+            self.works[k] = dist.all_gather_into_tensor(dst, self.x_send[k], group=self.group, async_op=True)
+
+    def start(self, scores: torch.Tensor):
+        """page_rank.rs:70-81 initial values, then the first exchange"""
+        self.engine.init(scores, self.x_loc)
+        for k in range(self.parts):
+            self._start_gather(self.cur, k)
+
+    def sweep(self, scores: torch.Tensor, err: torch.Tensor, events=None):
+        """events: optional list receiving a (start, end) torch.cuda.Event pair around every kernel piece
+        (bench.py: kernel time without the waits for the collectives)"""
+        e, x_in = self.engine, self.x[self.cur]
+
+        def timed(fn, *a):
+            if events is None:
+                return fn(*a)
+            pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            pair[0].record()
+            fn(*a)
+            pair[1].record()
+            events.append(pair)
+
+        for k in range(self.parts):
+            if self.works[k] is not None:
+                self.works[k].wait()  # orders the current stream behind the collective; the host does not block
+            lo, hi = self.layout["tile_ranges"][k]
+            timed(e.sweep_bin, x_in, lo, hi)
+        for k in range(self.parts):
+            timed(e.sweep_accum, x_in, self.x_loc, scores, k)
+            self._start_gather(1 - self.cur, k)
+        e.sweep_fixup(self.x_loc, scores, err)
+        self.cur = 1 - self.cur
+
+    def finish(self):
+        for k in range(self.parts):
+            if self.works[k] is not None:
+                self.works[k].wait()
+                self.works[k] = None
+
+
+def page_rank_partitioned_overlapped(engine, layout, rank: int, n_local: int, max_iterations: int, tolerance: float,
+                                     device, group=None):
+    """page_rank (page_rank.rs:88-110) across the ranks of `group` with the exchange overlapped
+    (PiecewiseExchange).  Same results as page_rank_partitioned, bit for bit.
+    Returns (scores_local, iterations, error)."""
+    if max_iterations == 0 and not tolerance > 0.0:
+        raise ValueError("max_iterations == 0 with tolerance <= 0 never terminates (reference: infinite loop)")
+    scores = torch.zeros(max(n_local, 1), dtype=torch.float32, device=device)
+    err = torch.zeros(1, dtype=torch.float64, device=device)
+    ex = PiecewiseExchange(engine, layout, rank, n_local, device, group)
+    ex.start(scores)
+    iteration, error = 0, 0.0
+    can_stop_early = tolerance > 0.0
+    while True:
+        ex.sweep(scores, err)
+        iteration += 1
+        last = iteration == max_iterations
+        if can_stop_early or last:
+            dist.all_reduce(err, op=dist.ReduceOp.SUM, group=group)
+            error = float(err.item())
+            if error < tolerance or last:
+                break
+    ex.finish()
+    return scores[:n_local], iteration, error
+
+
 def page_rank_partitioned(engine, n_global: int, n_local: int, stride: int, max_iterations: int, tolerance: float,
                           device, group=None, send_rows=None):
     """Runs the sweeps of page_rank (page_rank.rs:88-110) across the ranks of `group`.

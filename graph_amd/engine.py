@@ -66,3 +66,21 @@ class PageRankEngine:
     def sweep_fixup(self, x_out_local, scores_local, err_out):
         check(lib().gm_pr_sweep_fixup(self._h, x_out_local.data_ptr(), scores_local.data_ptr(), err_out.data_ptr(),
                                       current_stream_ptr()))
+
+    # ---- a sweep in pieces (propagation-blocking engines): see include/graph_mi355x.h ------------------
+    def part_geometry(self):
+        """(rows per bin, source tile): row splits must be multiples of the first, x regions of the second"""
+        r, t = C.c_uint64(0), C.c_uint64(0)
+        check(lib().gm_pr_part_geometry(self._h, C.byref(r), C.byref(t)))
+        return int(r.value), int(t.value)
+
+    def set_parts(self, row_splits):
+        arr = (C.c_uint64 * len(row_splits))(*[int(v) for v in row_splits])
+        check(lib().gm_pr_set_parts(self._h, arr, len(row_splits) - 1))
+
+    def sweep_bin(self, x_in: torch.Tensor, tile_lo: int, tile_hi: int):
+        check(lib().gm_pr_sweep_bin(self._h, x_in.data_ptr(), tile_lo, tile_hi, current_stream_ptr()))
+
+    def sweep_accum(self, x_in: torch.Tensor, x_out_local: torch.Tensor, scores_local: torch.Tensor, part: int):
+        check(lib().gm_pr_sweep_accum(self._h, x_in.data_ptr(), x_out_local.data_ptr(), scores_local.data_ptr(), part,
+                                      current_stream_ptr()))

@@ -79,6 +79,103 @@ def _worker(rank, world, port, scale, max_iter, tol, q, compact=False):
     dist.destroy_process_group()
 
 
+class _OraclePiecewiseEngine(_OracleRankEngine):
+    """The same rows in pieces: sweep_bin captures the tiles it is handed (so a region consumed before its
+    all-gather had landed would show up as wrong scores), sweep_accum finishes one row group."""
+
+    def set_parts(self, row_splits):
+        self.splits = [int(v) for v in row_splits]
+        self.tile = None
+
+    def sweep_bin(self, x_in, tile_lo, tile_hi):
+        if getattr(self, "seen", None) is None or self.seen.numel() != x_in.numel():
+            self.seen = torch.full_like(x_in, float("nan"))
+        self.seen[tile_lo * self.TILE: tile_hi * self.TILE] = x_in[tile_lo * self.TILE: tile_hi * self.TILE]
+
+    def sweep_accum(self, x_in, x_out_local, scores, part):
+        if part == 0:
+            self.err_parts = []
+        lo, hi = self.splits[part], self.splits[part + 1]
+        base = (np.float32(1.0) - np.float32(self.damping)) / np.float32(self.n)
+        xin, sc, e = self.seen.numpy(), scores.numpy(), 0.0
+        for u in range(lo, hi):
+            ssum = np.float32(0)
+            for i in range(self.off[u], self.off[u + 1]):
+                ssum = np.float32(ssum + xin[self.tgt[i]])
+            assert not np.isnan(ssum)
+            nw = np.float32(base + np.float32(np.float32(self.damping) * ssum))
+            e += abs(float(np.float32(nw - sc[u])))
+            sc[u] = nw
+            with np.errstate(divide="ignore"):
+                x_out_local[u] = float(np.float32(nw) / np.float32(self.od[u]))
+        self.err_parts.append(e)
+
+    def sweep_fixup(self, x_out_local, scores, err):
+        err[0] = sum(self.err_parts)
+        self.seen = None  # the next sweep must propagate every region again
+
+
+def _overlap_worker(rank, world, port, scale, max_iter, tol, parts, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    from graph_amd.distributed import (greedy_degree_partition, pad_bounds, page_rank_partitioned_overlapped,
+                                       split_exchange_layout)
+
+    s, d = O.rmat_edges(scale, seed=3)
+    n = 1 << scale
+    ioff, itgt = O.csr_build(n, s, d, O.INCOMING, O.SORTED)
+    od = O.out_degrees_from(n, s)
+    bounds, _ = pad_bounds(greedy_degree_partition(ioff, world), world, n)
+    lay = split_exchange_layout(torch.from_numpy(od.astype(np.int64)), bounds, parts=parts, row_align=8, tile=16)
+    nm = lay["node_map"].numpy()
+    assert int((nm >= 0).sum()) == int((od > 0).sum()) and len(set(nm[nm >= 0].tolist())) == int((nm >= 0).sum())
+    for k in range(parts):  # regions are whole tiles and every slot of region k lies inside it
+        assert lay["region_off"][k] % 16 == 0 and lay["strides"][k] % 16 == 0
+    eng = _OraclePiecewiseEngine(O, ioff, itgt, od, bounds, 0, rank, 0.85, nm)
+    eng.TILE = 16
+    scores, it, err = page_rank_partitioned_overlapped(eng, lay, rank, int(bounds[rank + 1] - bounds[rank]), max_iter, tol,
+                                                       torch.device("cpu"))
+    q.put((rank, int(bounds[rank]), scores.numpy().copy(), it, err))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,max_iter,tol,parts", [(2, 5, 0.0, 2), (3, 20, 1e-3, 2), (2, 4, 0.0, 3)])
+def test_partitioned_page_rank_overlapped_exchange_matches_single_rank(oracle, world, max_iter, tol, parts):
+    scale = 7
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, scale, max_iter, tol, parts, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n = 1 << scale
+    s, d = oracle.rmat_edges(scale, seed=3)
+    ioff, itgt = oracle.csr_build(n, s, d, oracle.INCOMING, oracle.SORTED)
+    od = oracle.out_degrees_from(n, s)
+    init = np.float32(1.0) / np.float32(n)
+    scores = np.full(n, init, np.float32)
+    with np.errstate(divide="ignore"):
+        outs = (init / od.astype(np.float32)).astype(np.float32)
+    it = 0
+    while True:
+        outs, err = oracle.page_rank_jacobi_sweep(ioff, itgt, od, 0.85, scores, outs)
+        it += 1
+        if err < tol or it == max_iter:
+            break
+    got = np.zeros(n, np.float32)
+    for rank, lo, sc, it_r, err_r in results:
+        got[lo:lo + sc.size] = sc
+        assert it_r == it
+        assert abs(err_r - err) <= 1e-9 * max(err, 1e-30) + 1e-15
+    assert np.array_equal(got, scores)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

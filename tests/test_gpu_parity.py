@@ -522,6 +522,78 @@ def test_partitioned_engines_on_one_device_match_single_engine(P, oracle):
         assert torch.equal(got_c, got)
 
 
+def test_page_rank_sweep_in_pieces_matches_whole_sweep(P, oracle):
+    """The overlapped multi-GPU schedule (split exchange layout, tile-range propagation, row-group
+    accumulation: graph_amd.distributed.PiecewiseExchange) with 3 virtual ranks on one GPU, a copy into
+    the shared vector standing in for the all-gather: bit-identical to one engine sweeping the whole graph."""
+    import ctypes as C
+
+    import torch
+
+    from graph_amd._lib import GraphMI355XError, check, lib, vp
+    from graph_amd.distributed import PiecewiseExchange, greedy_degree_partition, pad_bounds, split_exchange_layout
+    from graph_amd.engine import PageRankEngine
+
+    scale, world, sweeps = 17, 3, 4
+    n = 1 << scale
+    s, d = oracle.rmat_edges(scale, seed=11)
+    inc = P.DeviceCsr.from_edges(n, s, d, None, P.Direction.Incoming, P.CsrLayout.Sorted)
+    ioff = inc.host()[0]
+    od = torch.from_numpy(oracle.out_degrees_from(n, s).astype(np.int32)).cuda()
+    bounds, _ = pad_bounds(greedy_degree_partition(ioff, world), world, n)
+    dev = torch.device("cuda", 0)
+    eng = PageRankEngine(inc.handle, n, 0, od, 0.85, engine=PageRankEngine.PB)
+    x = [torch.zeros(n, device=dev), torch.zeros(n, device=dev)]
+    sc = torch.zeros(n, device=dev)
+    err = torch.zeros(1, dtype=torch.float64, device=dev)
+    eng.init(sc, x[0])
+    errs = []
+    for k in range(sweeps):
+        eng.sweep(x[k % 2], x[1 - k % 2], sc, err)
+        errs.append(float(err.item()))
+    for parts in (2, 3):
+        lay = split_exchange_layout(od, bounds, parts=parts)
+        assert lay["x_len"] % 16384 == 0
+        shared = [torch.zeros(lay["x_len"], device=dev) for _ in range(2)]
+        ranks = []
+        for r in range(world):
+            lo, hi = int(bounds[r]), int(bounds[r + 1])
+            h = vp()
+            check(lib().gm_csr_slice_rows_map(inc.handle, lo, hi, lay["node_map"].data_ptr(), C.byref(h)))
+            csr = P.DeviceCsr(h)
+            odl = od[lo:hi].contiguous()
+            e = PageRankEngine(csr.handle, n, lo, odl, 0.85, x_len=lay["x_len"], engine=PageRankEngine.PB)
+            rows_per_bin, tile = e.part_geometry()
+            assert tile == 16384 and 16384 % rows_per_bin == 0
+
+            def gather(dst_region, src, k, r=r):  # this rank's slot of region k
+                st = lay["strides"][k]
+                dst_region[r * st:(r + 1) * st] = src
+
+            ex = PiecewiseExchange(e, lay, r, hi - lo, dev, gather=gather)
+            ex.x = shared
+            ranks.append((csr, odl, e, ex, torch.zeros(hi - lo, device=dev), torch.zeros(1, dtype=torch.float64, device=dev)))
+        for (_, _, _, ex, scl, _) in ranks:
+            ex.start(scl)
+        for k in range(sweeps):
+            tot = 0.0
+            for (_, _, _, ex, scl, el) in ranks:
+                ex.sweep(scl, el)
+                tot += float(el.item())
+            assert abs(tot - errs[k]) <= 1e-11 * errs[k] + 1e-15
+        got = torch.cat([rk[4] for rk in ranks])
+        assert torch.equal(got, sc)
+    # argument checks: splits that are not bin-aligned, parts out of range, non-PB engines
+    e = ranks[0][2]
+    with pytest.raises(GraphMI355XError):
+        e.set_parts([0, 5, e.n_local])
+    with pytest.raises(GraphMI355XError):
+        e.sweep_accum(shared[0], ranks[0][3].x_loc, ranks[0][4], 7)
+    pull = PageRankEngine(inc.handle, n, 0, od, 0.85, engine=PageRankEngine.PULL)
+    with pytest.raises(GraphMI355XError):
+        pull.part_geometry()
+
+
 def test_page_rank_pb_split_bins(P, oracle, monkeypatch):
     """Over-long destination bins (ids sorted by in-degree put all hubs into bin 0) are accumulated by
     several workgroups whose integer partial sums are merged by the last arrival: same exact result."""
