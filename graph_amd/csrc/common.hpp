@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdlib>
@@ -180,7 +181,7 @@ struct gm_csr {
     // once"): PageRank's propagation-blocking plan, keyed by the length of the x vector it was built for.
     mutable std::mutex cache_mu;
     mutable std::map<uint64_t, gm::PbPlan *> pb_plans;
-    mutable uint64_t page_rank_calls = 0; // gm_page_rank calls seen by this handle (engine choice, below)
+    mutable std::atomic<uint64_t> page_rank_calls{0}; // gm_page_rank calls seen by this handle (engine choice); calls may run concurrently
     ~gm_csr()
     {
         for (auto &kv : pb_plans)

@@ -844,3 +844,53 @@ def test_sssp_partitioned_virtual_ranks(P, oracle):
     assert np.array_equal(got, expect)
     with pytest.raises(Exception):
         check(lib().gm_sssp_init_distances(n, n, dist[0].data_ptr(), 0, None))
+
+
+# ------------------------------------------------------------------------------------------------
+# Re-entrancy: the reference's functions take &G and run concurrently on one graph (the server holds
+# a read lock across spawn_blocking, server.rs:418-421; mate releases the GIL, mate/src/page_rank.rs:21)
+# ------------------------------------------------------------------------------------------------
+def test_concurrent_calls_on_shared_graphs(P, oracle):
+    import threading
+
+    scale = 14
+    n = 1 << scale
+    s, d = oracle.rmat_edges(scale, seed=21)
+    w = oracle.rmat_weights(s.size, seed=22)
+    g = _directed(P, n, s, d, P.CsrLayout.Sorted)
+    gw = _directed(P, n, s, d, P.CsrLayout.Sorted, w)
+    ug = P.UndirectedCsrGraph(P.DeviceCsr.from_edges(n, s, d, None, 2, P.CsrLayout.Deduplicated), P.CsrLayout.Deduplicated)
+    start = int(np.flatnonzero(np.bincount(s, minlength=n) > 0)[0])
+    jobs = {
+        "pr_pb": lambda: P.page_rank(g, P.PageRankConfig(6, 0.0, 0.85), P.PageRankMode.JacobiPB),
+        "pr_pull": lambda: P.page_rank(g, P.PageRankConfig(6, 0.0, 0.85), P.PageRankMode.JacobiPull),
+        "wcc": lambda: P.wcc_afforest(g, P.WccConfig()).to_vec(),
+        "sssp": lambda: P.delta_stepping(gw, P.DeltaSteppingConfig(start, 0.25)),
+        "tc": lambda: P.global_triangle_count(ug),
+    }
+
+    def same(a, b):
+        if isinstance(a, tuple):
+            return all(same(x, y) for x, y in zip(a, b))
+        return np.array_equal(np.asarray(a), np.asarray(b))
+
+    expected = {k: f() for k, f in jobs.items()}  # sequential answers (each path is deterministic)
+    failures = []
+
+    def worker(names):
+        try:
+            for _ in range(3):
+                for k in names:
+                    if not same(jobs[k](), expected[k]):
+                        failures.append(k)
+        except Exception as exc:  # noqa: BLE001 - reported below
+            failures.append(repr(exc))
+
+    names = list(jobs)
+    threads = [threading.Thread(target=worker, args=(names[i:] + names[:i],)) for i in range(len(names))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in threads)
+    assert failures == []
