@@ -84,3 +84,15 @@ def test_config_defaults():
     w = P.WccConfig()
     assert (w.chunk_size, w.neighbor_rounds, w.sampling_size) == (16384, 2, 1024)  # wcc.rs:69-71
     assert int(P.CsrLayout.Unsorted) == 0 and int(P.CsrLayout.Deduplicated) == 2
+
+
+def test_header_is_plain_c99(tmp_path):
+    """The boundary is a C ABI: the header must compile as C (what a cgo / bindgen / ctypes user feeds it to)."""
+    import subprocess
+
+    src = tmp_path / "hc.c"
+    header = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "graph_mi355x.h")
+    src.write_text('#include "%s"\nint main(void) { return gm_abi_version() > 0 ? 0 : 1; }\n' % header)
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
