@@ -1403,10 +1403,11 @@ int pb_set_parts(const PbPlan *pl, PbScratch *sc, const uint64_t *row_splits, ui
     std::vector<uint32_t> first_bin(n_parts + 1);
     for (uint32_t k = 0; k <= n_parts; ++k) {
         GM_CHECK(k == 0 || row_splits[k] >= row_splits[k - 1], GM_ERR_INVALID, "gm_pr_set_parts: splits must ascend");
-        GM_CHECK(k == n_parts || row_splits[k] % pl->R == 0, GM_ERR_INVALID,
+        const bool at_end = row_splits[k] == pl->n_local; // trailing groups may be empty
+        GM_CHECK(at_end || (row_splits[k] < pl->n_local && row_splits[k] % pl->R == 0), GM_ERR_INVALID,
                  "gm_pr_set_parts: split %llu is not a multiple of the %u rows of a bin",
                  (unsigned long long)row_splits[k], pl->R);
-        first_bin[k] = k == n_parts ? pl->B : (uint32_t)(row_splits[k] / pl->R);
+        first_bin[k] = at_end ? pl->B : (uint32_t)(row_splits[k] / pl->R);
     }
     std::vector<PbItem> ordered;
     ordered.reserve(pl->items_host.size());
