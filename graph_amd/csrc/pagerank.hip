@@ -529,7 +529,7 @@ GM_API int gm_pr_part_geometry(const gm_pr *pr, uint64_t *rows_per_bin_out, uint
     GM_CHECK(pr && rows_per_bin_out && source_tile_out, GM_ERR_INVALID, "gm_pr_part_geometry: null argument");
     GM_CHECK(pr->engine == GM_PR_ENGINE_PB, GM_ERR_UNSUPPORTED, "gm_pr_part_geometry: not a propagation-blocking engine");
     *rows_per_bin_out = gm::pb_rows_per_bin(pr->pb);
-    *source_tile_out = gm::pb_source_tile();
+    *source_tile_out = gm::pb_source_tile(pr->pb);
     return GM_OK;
 }
 
@@ -542,12 +542,12 @@ GM_API int gm_pr_set_parts(gm_pr *pr, const uint64_t *row_splits, uint64_t n_par
     return gm::pb_set_parts(pr->pb, pr->pb_scratch, row_splits, (uint32_t)n_parts);
 }
 
-GM_API int gm_pr_sweep_bin(gm_pr *pr, uint64_t d_x_in_global, uint64_t tile_lo, uint64_t tile_hi, void *stream)
+GM_API int gm_pr_sweep_bin(gm_pr *pr, uint64_t d_x_in_global, uint64_t x_lo, uint64_t x_hi, void *stream)
 {
     GM_CHECK(pr && d_x_in_global, GM_ERR_INVALID, "gm_pr_sweep_bin: null argument");
     GM_CHECK(pr->engine == GM_PR_ENGINE_PB, GM_ERR_UNSUPPORTED, "gm_pr_sweep_bin: not a propagation-blocking engine");
     gm::DeviceGuard guard(pr->csr->device);
-    return gm::pb_sweep_bin_tiles(pr->pb, pr->pb_scratch, reinterpret_cast<const float *>(d_x_in_global), tile_lo, tile_hi,
+    return gm::pb_sweep_bin_range(pr->pb, pr->pb_scratch, reinterpret_cast<const float *>(d_x_in_global), x_lo, x_hi,
                                   (hipStream_t)stream);
 }
 

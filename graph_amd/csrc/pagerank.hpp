@@ -34,9 +34,9 @@ int pb_sweep_main(const PbPlan *plan, PbScratch *scratch, const float *x_in, flo
 int pb_sweep_error(const PbPlan *plan, PbScratch *scratch, double *err_out, hipStream_t st);
 // a sweep in pieces, for partitioned runs that overlap the exchange of x with the work (pagerank_pb.hip)
 uint32_t pb_rows_per_bin(const PbPlan *plan);
-uint32_t pb_source_tile();
+uint32_t pb_source_tile(const PbPlan *plan);
 int pb_set_parts(const PbPlan *plan, PbScratch *scratch, const uint64_t *row_splits, uint32_t n_parts);
-int pb_sweep_bin_tiles(const PbPlan *plan, PbScratch *scratch, const float *x_in, uint64_t tile_lo, uint64_t tile_hi,
+int pb_sweep_bin_range(const PbPlan *plan, PbScratch *scratch, const float *x_in, uint64_t x_lo, uint64_t x_hi,
                        hipStream_t st);
 int pb_sweep_accum_part(const PbPlan *plan, PbScratch *scratch, const float *x_in, float *x_out, float *scores,
                         const uint32_t *outdeg, float base, float damping, uint32_t part, hipStream_t st);

@@ -37,8 +37,7 @@ namespace gm {
 
 namespace {
 
-constexpr int PB_S_LOG = 14;
-constexpr uint32_t PB_S = 1u << PB_S_LOG; // sources per tile (x tile = 64 KiB of LDS)
+constexpr int PB_S_LOG_MAX = 15;     // sources per tile = 2^s_log, s_log 14 (x tile = 64 KiB of LDS) or 15 (128 KiB)
 constexpr int PB_BIN_BLOCK = 1024;
 constexpr int PB_ACC_BLOCK = 1024;
 constexpr uint32_t PB_VEC = 4;                  // segments are padded to multiples of 4 entries in both streams
@@ -74,6 +73,7 @@ struct PbPlan {
     uint32_t n_local = 0, m = 0;
     uint64_t x_len = 0;
     int rb = 0;            // log2(rows per bin)
+    int s_log = 14;        // log2(sources per tile)
     uint32_t R = 0, B = 0; // rows per bin, bins
     uint32_t Racc = 0;     // accumulators per bin = max number of rows with in-edges in one bin (<= R)
     DevBuf cidx;           // u16[n]  accumulator slot of each row inside its bin, PB_NULL = no in-edges
@@ -84,7 +84,8 @@ struct PbPlan {
     uint32_t NW = 0;       // phase-1 workgroups
     uint32_t chunk = 0;    // phase-1 entries per workgroup (multiple of 256)
     int device = 0;
-    DevBuf p1_src;      // u16[Mp]   local source id | PB_FLAG on the first entry of a segment, PB_NULL = padding
+    DevBuf p1_src;      // u16[Mp]   local source id | PB_FLAG on the first entry of a segment; padding entries are
+                        //           unflagged ids: they belong to the segment before them and land in its padding slots
     DevBuf chunk_seg;   // u32[Mp/256] segments started before each 256-entry wavefront block
     DevBuf delta;       // u32[NS]   slot = p + delta[segment]   (mod 2^32, a multiple of 4)
     DevBuf tile_p;      // u32[NT+1] phase-1 range of each tile (multiples of 256)
@@ -244,26 +245,27 @@ __global__ __launch_bounds__(256) void pb_keys_kernel(const uint32_t *__restrict
     }
 }
 
-__device__ __forceinline__ uint64_t pb_seg_of_key(uint64_t k, int rb, int sb)
+__device__ __forceinline__ uint64_t pb_seg_of_key(uint64_t k, int rb, int sb, int s_log)
 {
     // (bin, tile) as one comparable integer: bin << 32 | tile
     const uint64_t bin = k >> (sb + rb);
     const uint64_t src = (k >> rb) & ((1ull << sb) - 1ull);
-    return (bin << 32) | (src >> PB_S_LOG);
+    return (bin << 32) | (src >> s_log);
 }
 
-__global__ void pb_flags_kernel(const uint64_t *__restrict__ keys, uint32_t m, int rb, int sb, uint32_t *__restrict__ flag)
+__global__ void pb_flags_kernel(const uint64_t *__restrict__ keys, uint32_t m, int rb, int sb, int s_log,
+                                uint32_t *__restrict__ flag)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < m; q += stride) {
         const uint64_t k = keys[q];
-        flag[q] = (q == 0 || pb_seg_of_key(keys[q - 1], rb, sb) != pb_seg_of_key(k, rb, sb)) ? 1u : 0u;
+        flag[q] = (q == 0 || pb_seg_of_key(keys[q - 1], rb, sb, s_log) != pb_seg_of_key(k, rb, sb, s_log)) ? 1u : 0u;
     }
 }
 
 // segid = inclusive_scan(flag); for every segment start: vstart[j] = q, segkey[j] = tile << 32 | bin, segval[j] = j
 __global__ void pb_segments_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ flag,
-                                   const uint32_t *__restrict__ segid_incl, uint32_t m, int rb, int sb,
+                                   const uint32_t *__restrict__ segid_incl, uint32_t m, int rb, int sb, int s_log,
                                    uint32_t *__restrict__ vstart, uint64_t *__restrict__ segkey,
                                    uint32_t *__restrict__ segval, uint64_t *__restrict__ segbin)
 {
@@ -271,7 +273,7 @@ __global__ void pb_segments_kernel(const uint64_t *__restrict__ keys, const uint
     for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < m; q += stride)
         if (flag[q]) {
             const uint32_t j = segid_incl[q] - 1;
-            const uint64_t bt = pb_seg_of_key(keys[q], rb, sb);
+            const uint64_t bt = pb_seg_of_key(keys[q], rb, sb, s_log);
             vstart[j] = q;
             segkey[j] = ((bt & 0xFFFFFFFFull) << 32) | (bt >> 32);
             segval[j] = j;
@@ -314,6 +316,21 @@ __global__ void pb_tile_sizes_kernel(const uint32_t *__restrict__ tile_seg, cons
     }
 }
 
+// A tile's phase-1 range is rounded up to 256 entries; the entries behind its last segment count as
+// padding of that segment (the bin kernel has no "nothing here" marker), so the segment's slice of the
+// value stream grows by the same amount.
+__global__ void pb_tile_tail_kernel(const uint32_t *__restrict__ tile_seg, const uint32_t *__restrict__ cs,
+                                    const uint32_t *__restrict__ tile_pad, const uint32_t *__restrict__ segval_sorted,
+                                    uint32_t NT, uint32_t *__restrict__ cnt_v)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < NT; t += stride) {
+        const uint32_t r0 = tile_seg[t], r1 = tile_seg[t + 1];
+        if (r1 > r0)
+            cnt_v[segval_sorted[r1 - 1]] += tile_pad[t] - (cs[r1] - cs[r0]);
+    }
+}
+
 // per phase-1 segment r: pstart, delta; and the inverse permutation rank_of[j] = r
 __global__ void pb_seg_layout_kernel(const uint64_t *__restrict__ segkey_sorted, const uint32_t *__restrict__ segval_sorted,
                                      const uint32_t *__restrict__ vstart4, const uint32_t *__restrict__ cs,
@@ -335,7 +352,7 @@ __global__ void pb_seg_layout_kernel(const uint64_t *__restrict__ segkey_sorted,
 __global__ void pb_fill_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ segid_incl,
                                const uint32_t *__restrict__ vstart, const uint32_t *__restrict__ vstart4,
                                const uint32_t *__restrict__ rank_of, const uint32_t *__restrict__ pstart, uint32_t m,
-                               int rb, int sb, uint16_t *__restrict__ p1_src, uint16_t *__restrict__ p2_dst)
+                               int rb, int sb, int s_log, uint16_t *__restrict__ p1_src, uint16_t *__restrict__ p2_dst)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t rmask = (1u << rb) - 1u;
@@ -345,7 +362,7 @@ __global__ void pb_fill_kernel(const uint64_t *__restrict__ keys, const uint32_t
         const uint64_t k = keys[q];
         const uint32_t p = pstart[rank_of[j]] + (q - vs);
         const uint32_t src = (uint32_t)((k >> rb) & ((1ull << sb) - 1ull));
-        p1_src[p] = (uint16_t)((src & (PB_S - 1u)) | (q == vs ? PB_FLAG : 0));
+        p1_src[p] = (uint16_t)((src & ((1u << s_log) - 1u)) | (q == vs ? PB_FLAG : 0));
         p2_dst[vstart4[j] + (q - vs)] = (uint16_t)((uint32_t)k & rmask);
     }
 }
@@ -443,7 +460,7 @@ constexpr uint32_t PB_DCACHE = 4096; // segment deltas cached in LDS per workgro
 // ingredient at a time to show what bounds the kernel.  bin: 1 = no LDS gather, 3 = no stores.  accumulate: 3 = no epilogue, 4 = no streaming loops
 // (removing the LDS atomics or making them conflict-free changed nothing: measured, then deleted).  bin: 4 = no x tile load,
 // 5 = x tile load only.
-template <int ABL>
+template <int ABL, int S_LOG>
 __global__ __launch_bounds__(PB_BIN_BLOCK) void pb_bin_kernel(const float *__restrict__ x_in, uint64_t x_len,
                                                               const uint32_t *__restrict__ tile_p,
                                                               const uint32_t *__restrict__ wg_tile,
@@ -453,6 +470,7 @@ __global__ __launch_bounds__(PB_BIN_BLOCK) void pb_bin_kernel(const float *__res
                                                               const uint32_t *__restrict__ delta, float *__restrict__ vals,
                                                               uint32_t PB_BIN_CHUNK, uint32_t w_first, int xcd_aware)
 {
+    constexpr uint32_t PB_S = 1u << S_LOG;                          // sources per tile
     extern __shared__ float xs[];                                   // PB_S floats ...
     uint32_t *dl = reinterpret_cast<uint32_t *>(xs + PB_S);         // ... + PB_DCACHE segment deltas
     const uint32_t tid = threadIdx.x;
@@ -482,7 +500,7 @@ __global__ __launch_bounds__(PB_BIN_BLOCK) void pb_bin_kernel(const float *__res
                 const u32x2 raw = *reinterpret_cast<const u32x2 *>(p1_src + p);
                 vv[k] = U16x4{(uint16_t)raw.x, (uint16_t)(raw.x >> 16), (uint16_t)raw.y, (uint16_t)(raw.y >> 16)};
             } else {
-                vv[k] = U16x4{PB_NULL, PB_NULL, PB_NULL, PB_NULL};
+                vv[k] = U16x4{0, 0, 0, 0};
             }
             cc[k] = in ? chunk_seg[p / PB_WBLK] : 0u;
         }
@@ -519,7 +537,7 @@ __global__ __launch_bounds__(PB_BIN_BLOCK) void pb_bin_kernel(const float *__res
 #pragma unroll
         for (int k = 0; k < U; ++k) {
             const uint32_t p = p0 + k * STEP;
-            const bool valid = v[k].a != PB_NULL; // a segment's first entry is never padding
+            const bool valid = p < p_end; // every entry of the range belongs to a segment (padding included)
             const uint64_t starts = __ballot(valid && (v[k].a & PB_FLAG));
             if (valid) {
                 const uint32_t rank = cs[k] + (uint32_t)__popcll(starts & le_mask) - 1u;
@@ -926,6 +944,9 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     pl->m = m_all;
     pl->x_len = x_len;
     pl->device = csr->device;
+    // 16384-source tiles up to 2^26 sources; 32768 beyond, where the (tile, bin) segments of the smaller
+    // tile drop below ~128 bytes (measured: scale 26 2.63 vs 2.71 ms for 14 vs 15, scale 27 5.90 vs 5.73 ms)
+    pl->s_log = pb_env("GM_PB_SLOG", x_len > (1ull << 26) ? 15 : 14) >= PB_S_LOG_MAX ? PB_S_LOG_MAX : 14;
     // rows per bin: keep >= ~2048 bins so the accumulate kernel fills the chip, cap the LDS slice at 128 KiB
     int rb = bits_for(n) - 11;
     if (rb < 8)
@@ -934,7 +955,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     // m * S / x_len edges to this rank's rows, so at most that / 64 bins (matters for row slices of a
     // partitioned graph, where every source tile holds only 1/P of its edges)
     {
-        const uint64_t per_tile = x_len ? (uint64_t)m_all * PB_S / x_len : 0;
+        const uint64_t per_tile = x_len ? ((uint64_t)m_all << pl->s_log) / x_len : 0;
         const uint64_t max_bins = per_tile / 64 > 1 ? per_tile / 64 : 1;
         while (rb < 14 && (((uint64_t)n + (1ull << rb) - 1) >> rb) > max_bins)
             ++rb;
@@ -948,7 +969,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     pl->B = (uint32_t)(((uint64_t)n + pl->R - 1) >> rb);
     if (pl->B == 0)
         pl->B = 1;
-    pl->NT = (uint32_t)((x_len + PB_S - 1) >> PB_S_LOG);
+    pl->NT = (uint32_t)((x_len + (1ull << pl->s_log) - 1) >> pl->s_log);
     if (pl->NT == 0)
         pl->NT = 1;
     const int sb = bits_for(x_len) < 1 ? 1 : bits_for(x_len);
@@ -1118,7 +1139,8 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     DevBuf flag, segid;
     GM_TRY(flag.alloc((size_t)m * 4));
     GM_TRY(segid.alloc((size_t)m * 4));
-    hipLaunchKernelGGL(pb_flags_kernel, dim3(gm_), dim3(256), 0, 0, keys.as<uint64_t>(), m, rb, sb, flag.as<uint32_t>());
+    hipLaunchKernelGGL(pb_flags_kernel, dim3(gm_), dim3(256), 0, 0, keys.as<uint64_t>(), m, rb, sb, pl->s_log,
+                       flag.as<uint32_t>());
     GM_HIP(hipGetLastError());
     GM_TRY(scan_inclusive_u32(flag.as<uint32_t>(), segid.as<uint32_t>(), m));
     uint32_t NS = 0;
@@ -1135,7 +1157,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     GM_TRY(segvalt.alloc((size_t)NS * 4));
     GM_TRY(segbin.alloc((size_t)NS * 8));
     hipLaunchKernelGGL(pb_segments_kernel, dim3(gm_), dim3(256), 0, 0, keys.as<uint64_t>(), flag.as<uint32_t>(),
-                       segid.as<uint32_t>(), m, rb, sb, vstart.as<uint32_t>(), segkey.as<uint64_t>(),
+                       segid.as<uint32_t>(), m, rb, sb, pl->s_log, vstart.as<uint32_t>(), segkey.as<uint64_t>(),
                        segval.as<uint32_t>(), segbin.as<uint64_t>());
     GM_HIP(hipGetLastError());
     GM_HIP(hipDeviceSynchronize());
@@ -1168,16 +1190,19 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
                        m, cnt.as<uint32_t>(), cntv.as<uint32_t>());
     GM_HIP(hipGetLastError());
     GM_TRY(scan_exclusive<uint32_t>(cnt.as<uint32_t>(), cs.as<uint32_t>(), (uint64_t)NS + 1));
+    hipLaunchKernelGGL(pb_bounds_kernel, dim3(gs), dim3(256), 0, 0, segkey.as<uint64_t>(), NS, 32, pl->NT,
+                       tile_seg.as<uint32_t>());
+    hipLaunchKernelGGL(pb_tile_sizes_kernel, dim3(pb_grid((uint64_t)pl->NT + 1)), dim3(256), 0, 0,
+                       tile_seg.as<uint32_t>(), cs.as<uint32_t>(), pl->NT, tile_pad.as<uint32_t>());
+    hipLaunchKernelGGL(pb_tile_tail_kernel, dim3(pb_grid(pl->NT)), dim3(256), 0, 0, tile_seg.as<uint32_t>(),
+                       cs.as<uint32_t>(), tile_pad.as<uint32_t>(), segval.as<uint32_t>(), pl->NT, cntv.as<uint32_t>());
+    GM_HIP(hipGetLastError());
     GM_TRY(scan_exclusive<uint32_t>(cntv.as<uint32_t>(), vstart4.as<uint32_t>(), (uint64_t)NS + 1));
     uint32_t Mv = 0;
     GM_HIP(hipMemcpy(&Mv, vstart4.as<uint32_t>() + NS, 4, hipMemcpyDeviceToHost));
     pl->Mv = Mv;
     hipLaunchKernelGGL(pb_bin_ranges_kernel, dim3(pb_grid((uint64_t)pl->B + 1)), dim3(256), 0, 0, bin_seg.as<uint32_t>(),
                        vstart4.as<uint32_t>(), pl->B, pl->bin_v.as<uint32_t>());
-    hipLaunchKernelGGL(pb_bounds_kernel, dim3(gs), dim3(256), 0, 0, segkey.as<uint64_t>(), NS, 32, pl->NT,
-                       tile_seg.as<uint32_t>());
-    hipLaunchKernelGGL(pb_tile_sizes_kernel, dim3(pb_grid((uint64_t)pl->NT + 1)), dim3(256), 0, 0,
-                       tile_seg.as<uint32_t>(), cs.as<uint32_t>(), pl->NT, tile_pad.as<uint32_t>());
     GM_HIP(hipGetLastError());
     GM_TRY(scan_exclusive<uint32_t>(tile_pad.as<uint32_t>(), pl->tile_p.as<uint32_t>(), (uint64_t)pl->NT + 1));
     uint32_t Mp = 0;
@@ -1191,11 +1216,11 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     GM_TRY(pl->p2_dst.alloc((size_t)Mv * 2));
     GM_TRY(pl->p1_src.alloc((size_t)Mp * 2));
     GM_TRY(pl->chunk_seg.alloc(((size_t)Mp / PB_WBLK + 1) * 4));
-    GM_HIP(hipMemset(pl->p1_src.p, 0xFF, (size_t)Mp * 2));
+    GM_HIP(hipMemset(pl->p1_src.p, 0x7F, (size_t)Mp * 2)); // padding: an unflagged id (any source of the tile will do)
     GM_HIP(hipMemset(pl->p2_dst.p, 0xFF, (size_t)Mv * 2));
     hipLaunchKernelGGL(pb_fill_kernel, dim3(gm_), dim3(256), 0, 0, keys.as<uint64_t>(), segid.as<uint32_t>(),
                        vstart.as<uint32_t>(), vstart4.as<uint32_t>(), rank_of.as<uint32_t>(), pstart.as<uint32_t>(), m, rb,
-                       sb, pl->p1_src.as<uint16_t>(), pl->p2_dst.as<uint16_t>());
+                       sb, pl->s_log, pl->p1_src.as<uint16_t>(), pl->p2_dst.as<uint16_t>());
     hipLaunchKernelGGL(pb_chunk_seg_kernel, dim3(pb_grid(Mp / PB_WBLK + 1)), dim3(256), 0, 0, pstart.as<uint32_t>(), NS,
                        Mp / PB_WBLK + 1, pl->chunk_seg.as<uint32_t>());
     GM_HIP(hipGetLastError());
@@ -1235,16 +1260,18 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
 
 static hipError_t pb_set_kernel_attributes()
 {
-    const void *bin_fns[] = {reinterpret_cast<const void *>(&pb_bin_kernel<0>), reinterpret_cast<const void *>(&pb_bin_kernel<1>),
-                             reinterpret_cast<const void *>(&pb_bin_kernel<3>), reinterpret_cast<const void *>(&pb_bin_kernel<4>),
-                             reinterpret_cast<const void *>(&pb_bin_kernel<5>)};
+    const void *bin_fns[] = {
+        reinterpret_cast<const void *>(&pb_bin_kernel<0, 14>), reinterpret_cast<const void *>(&pb_bin_kernel<1, 14>),
+        reinterpret_cast<const void *>(&pb_bin_kernel<3, 14>), reinterpret_cast<const void *>(&pb_bin_kernel<4, 14>),
+        reinterpret_cast<const void *>(&pb_bin_kernel<5, 14>), reinterpret_cast<const void *>(&pb_bin_kernel<0, 15>),
+        reinterpret_cast<const void *>(&pb_bin_kernel<3, 15>), reinterpret_cast<const void *>(&pb_bin_kernel<5, 15>)};
     const void *acc_fns[] = {reinterpret_cast<const void *>(&pb_accum_kernel<0>),
                              reinterpret_cast<const void *>(&pb_accum_kernel<3>),
                              reinterpret_cast<const void *>(&pb_accum_kernel<4>)};
     hipError_t e = hipSuccess;
     for (const void *f : bin_fns)
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, PB_S * 4 + PB_DCACHE * 4);
+            e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (4u << PB_S_LOG_MAX) + PB_DCACHE * 4);
     for (const void *f : acc_fns)
         if (e == hipSuccess)
             e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 163840 - 512);
@@ -1325,11 +1352,11 @@ void pb_scratch_destroy(PbScratch *scratch) { delete scratch; }
 
 uint64_t pb_work_items(const PbPlan *plan) { return plan ? (uint64_t)plan->NW + plan->NI : 0; }
 
-template <int ABL>
+template <int ABL, int S_LOG>
 void pb_launch_bin(const PbPlan *pl, PbScratch *sc, const float *x_in, uint32_t w_first, uint32_t w_count, hipStream_t st)
 {
-    hipLaunchKernelGGL(pb_bin_kernel<ABL>, dim3(w_count), dim3(PB_BIN_BLOCK), PB_S * 4 + PB_DCACHE * 4, st, x_in, pl->x_len,
-                       pl->tile_p.as<uint32_t>(), pl->wg_tile.as<uint32_t>(), pl->wg_p0.as<uint32_t>(),
+    hipLaunchKernelGGL((pb_bin_kernel<ABL, S_LOG>), dim3(w_count), dim3(PB_BIN_BLOCK), (4u << S_LOG) + PB_DCACHE * 4, st, x_in,
+                       pl->x_len, pl->tile_p.as<uint32_t>(), pl->wg_tile.as<uint32_t>(), pl->wg_p0.as<uint32_t>(),
                        pl->p1_src.as<uint16_t>(), pl->chunk_seg.as<uint32_t>(), pl->delta.as<uint32_t>(), sc->vals,
                        pl->chunk, w_first, pl->xcd_aware);
 }
@@ -1352,12 +1379,21 @@ static void pb_bin_dispatch(const PbPlan *pl, PbScratch *sc, const float *x_in, 
 {
     if (w_count == 0)
         return;
-    switch (pb_env("GM_PB_ABLATE", 0) % 10) {
-    case 1: pb_launch_bin<1>(pl, sc, x_in, w_first, w_count, st); break;
-    case 3: pb_launch_bin<3>(pl, sc, x_in, w_first, w_count, st); break;
-    case 4: pb_launch_bin<4>(pl, sc, x_in, w_first, w_count, st); break;
-    case 5: pb_launch_bin<5>(pl, sc, x_in, w_first, w_count, st); break;
-    default: pb_launch_bin<0>(pl, sc, x_in, w_first, w_count, st); break;
+    const int abl = pb_env("GM_PB_ABLATE", 0) % 10;
+    if (pl->s_log == 15) {
+        switch (abl) {
+        case 3: pb_launch_bin<3, 15>(pl, sc, x_in, w_first, w_count, st); break;
+        case 5: pb_launch_bin<5, 15>(pl, sc, x_in, w_first, w_count, st); break;
+        default: pb_launch_bin<0, 15>(pl, sc, x_in, w_first, w_count, st); break;
+        }
+        return;
+    }
+    switch (abl) {
+    case 1: pb_launch_bin<1, 14>(pl, sc, x_in, w_first, w_count, st); break;
+    case 3: pb_launch_bin<3, 14>(pl, sc, x_in, w_first, w_count, st); break;
+    case 4: pb_launch_bin<4, 14>(pl, sc, x_in, w_first, w_count, st); break;
+    case 5: pb_launch_bin<5, 14>(pl, sc, x_in, w_first, w_count, st); break;
+    default: pb_launch_bin<0, 14>(pl, sc, x_in, w_first, w_count, st); break;
     }
 }
 
@@ -1392,7 +1428,7 @@ int pb_sweep_main(const PbPlan *pl, PbScratch *sc, const float *x_in, float *x_o
 
 // ---- partitioned sweeps in pieces (overlap of the exchange with the work) ----------
 uint32_t pb_rows_per_bin(const PbPlan *pl) { return pl->R; }
-uint32_t pb_source_tile() { return PB_S; }
+uint32_t pb_source_tile(const PbPlan *pl) { return 1u << pl->s_log; }
 
 // bins [row_splits[k] / R, row_splits[k+1] / R) form part k; row_splits[0] = 0, the last one = n_local,
 // the inner ones multiples of R
@@ -1425,14 +1461,19 @@ int pb_set_parts(const PbPlan *pl, PbScratch *sc, const uint64_t *row_splits, ui
     return GM_OK;
 }
 
-// propagates the x values of source tiles [tile_lo, tile_hi) into the value stream
-int pb_sweep_bin_tiles(const PbPlan *pl, PbScratch *sc, const float *x_in, uint64_t tile_lo, uint64_t tile_hi, hipStream_t st)
+// propagates x[x_lo, x_hi) (whole source tiles; x_hi may also be the end of the vector) into the value stream
+int pb_sweep_bin_range(const PbPlan *pl, PbScratch *sc, const float *x_in, uint64_t x_lo, uint64_t x_hi, hipStream_t st)
 {
-    if (tile_hi > pl->NT)
-        tile_hi = pl->NT;
+    const uint64_t S = 1ull << pl->s_log;
+    if (x_hi > pl->x_len)
+        x_hi = pl->x_len;
+    GM_CHECK(x_lo % S == 0 && (x_hi % S == 0 || x_hi == pl->x_len), GM_ERR_INVALID,
+             "gm_pr_sweep_bin: [%llu, %llu) is not a range of whole source tiles (%llu)", (unsigned long long)x_lo,
+             (unsigned long long)x_hi, (unsigned long long)S);
+    const uint64_t tile_lo = x_lo >> pl->s_log, tile_hi = (x_hi + S - 1) >> pl->s_log;
     if (pl->NW == 0 || tile_lo >= tile_hi)
         return GM_OK;
-    const uint32_t w0 = pl->wg_first_host[tile_lo], w1 = pl->wg_first_host[tile_hi];
+    const uint32_t w0 = pl->wg_first_host[tile_lo], w1 = pl->wg_first_host[tile_hi > pl->NT ? pl->NT : tile_hi];
     pb_bin_dispatch(pl, sc, x_in, w0, w1 - w0, st);
     GM_HIP(hipGetLastError());
     return GM_OK;

@@ -82,17 +82,17 @@ def compact_exchange_layout(out_degree, bounds):
 
 
 ROW_ALIGN = 16384  # row splits of a sweep in pieces: a multiple of the rows per bin of any plan (<= 16384)
-SOURCE_TILE = 16384  # x regions of a sweep in pieces: a multiple of the source tile (gm_pr_part_geometry)
+SOURCE_TILE = 32768  # x regions of a sweep in pieces: a multiple of any plan's source tile (gm_pr_part_geometry)
 
 
 def split_exchange_layout(out_degree, bounds, parts: int = 2, row_align: int = ROW_ALIGN, tile: int = SOURCE_TILE):
     """compact_exchange_layout for a sweep in pieces: every rank cuts its rows into `parts` groups (at
     multiples of row_align) and the exchanged vector into as many regions, region k holding group k of
     every rank (rank-major, `strides[k]` floats per rank, a multiple of `tile`), so that region k can be
-    all-gathered while the ranks still work on group k+1 and be consumed (source tiles
-    [tile_ranges[k][0], tile_ranges[k][1])) while region k+1 is still in flight.
+    all-gathered while the ranks still work on group k+1 and be consumed (elements
+    [region_off[k], region_off[k] + world * strides[k]) of x) while region k+1 is still in flight.
     Returns a dict: node_map int32[n] (-1: never a source), x_len, strides[k], region_off[k],
-    tile_ranges[k], row_splits[rank] (parts+1 local row indices), send_rows[rank][k] (local rows, slot order)."""
+    row_splits[rank] (parts+1 local row indices), send_rows[rank][k] (local rows, slot order)."""
     has_out = out_degree > 0
     world = len(bounds) - 1
     n = out_degree.numel()
@@ -106,20 +106,19 @@ def split_exchange_layout(out_degree, bounds, parts: int = 2, row_align: int = R
         row_splits.append(sp)
         send_rows.append([sp[k] + torch.nonzero(has_out[lo + sp[k]:lo + sp[k + 1]], as_tuple=False).flatten()
                           for k in range(parts)])
-    strides, region_off, tile_ranges, off = [], [], [], 0
+    strides, region_off, off = [], [], 0
     for k in range(parts):
         most = max(int(send_rows[p][k].numel()) for p in range(world))
         stride = max(tile, -(-most // tile) * tile)
         strides.append(stride)
         region_off.append(off)
-        tile_ranges.append((off // tile, (off + world * stride) // tile))
         off += world * stride
     for p in range(world):
         lo = int(bounds[p])
         for k in range(parts):
             rows = send_rows[p][k]
             node_map[lo + rows] = (region_off[k] + p * strides[k] + torch.arange(rows.numel(), device=dev)).to(torch.int32)
-    return {"node_map": node_map, "x_len": off, "strides": strides, "region_off": region_off, "tile_ranges": tile_ranges,
+    return {"node_map": node_map, "x_len": off, "strides": strides, "region_off": region_off,
             "row_splits": row_splits, "send_rows": send_rows, "parts": parts}
 
 
@@ -183,7 +182,7 @@ class PiecewiseExchange:
         for k in range(self.parts):
             if self.works[k] is not None:
                 self.works[k].wait()  # orders the current stream behind the collective; the host does not block
-            lo, hi = self.layout["tile_ranges"][k]
+            lo, hi = self.regions[k]
             timed(e.sweep_bin, x_in, lo, hi)
         for k in range(self.parts):
             timed(e.sweep_accum, x_in, self.x_loc, scores, k)

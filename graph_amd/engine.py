@@ -78,8 +78,9 @@ class PageRankEngine:
         arr = (C.c_uint64 * len(row_splits))(*[int(v) for v in row_splits])
         check(lib().gm_pr_set_parts(self._h, arr, len(row_splits) - 1))
 
-    def sweep_bin(self, x_in: torch.Tensor, tile_lo: int, tile_hi: int):
-        check(lib().gm_pr_sweep_bin(self._h, x_in.data_ptr(), tile_lo, tile_hi, current_stream_ptr()))
+    def sweep_bin(self, x_in: torch.Tensor, x_lo: int, x_hi: int):
+        # propagate x_in[x_lo:x_hi] (whole source tiles) into the value stream
+        check(lib().gm_pr_sweep_bin(self._h, x_in.data_ptr(), x_lo, x_hi, current_stream_ptr()))
 
     def sweep_accum(self, x_in: torch.Tensor, x_out_local: torch.Tensor, scores_local: torch.Tensor, part: int):
         check(lib().gm_pr_sweep_accum(self._h, x_in.data_ptr(), x_out_local.data_ptr(), scores_local.data_ptr(), part,

@@ -87,10 +87,11 @@ class _OraclePiecewiseEngine(_OracleRankEngine):
         self.splits = [int(v) for v in row_splits]
         self.tile = None
 
-    def sweep_bin(self, x_in, tile_lo, tile_hi):
+    def sweep_bin(self, x_in, x_lo, x_hi):
+        assert x_lo % self.TILE == 0 and x_hi % self.TILE == 0
         if getattr(self, "seen", None) is None or self.seen.numel() != x_in.numel():
             self.seen = torch.full_like(x_in, float("nan"))
-        self.seen[tile_lo * self.TILE: tile_hi * self.TILE] = x_in[tile_lo * self.TILE: tile_hi * self.TILE]
+        self.seen[x_lo:x_hi] = x_in[x_lo:x_hi]
 
     def sweep_accum(self, x_in, x_out_local, scores, part):
         if part == 0:

@@ -19,7 +19,7 @@ del src, dst
 torch.cuda.empty_cache()
 x = [torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")]
 sc = torch.zeros(n, device="cuda")
-KNOBS = ["GM_PB_WGS", "GM_PB_RB", "GM_PB_HOT", "GM_PB_CHUNK", "GM_PB_XCD", "GM_PB_SPLIT", "GM_PB_ORDER"]
+KNOBS = ["GM_PB_SLOG", "GM_PB_WGS", "GM_PB_RB", "GM_PB_HOT", "GM_PB_CHUNK", "GM_PB_XCD", "GM_PB_SPLIT", "GM_PB_ORDER"]
 res = {c: [] for c in configs}
 for r in range(rounds):
     for c in configs:
