@@ -12,6 +12,9 @@
 #pragma once
 
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -130,7 +133,106 @@ template <class NI> template <class U> auto DirectedCsrGraph<NI>::to_undirected(
     return UndirectedCsrGraph<U>(detail::CsrPtr(c), layout);
 }
 
-// GraphBuilder::new().csr_layout(..).edges(..).build()   (crates/builder/src/builder.rs:123-540)
+// ---- on-disk inputs (host-side parsing; the CSR is then built on the device) --------------------------
+// What a file holds: edges as u64 ids (narrowed to the u32 device id type at build time), optional f32
+// values, and the node count the reference derives for that format.
+struct EdgeData {
+    std::vector<uint64_t> src, dst;
+    std::vector<float> values; // empty unless the format carries them
+    uint64_t node_count = 0;
+};
+
+namespace detail {
+inline std::vector<char> read_file(const std::string &path)
+{
+    std::FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f)
+        throw Error(GM_ERR_INVALID, "cannot open " + path);
+    std::vector<char> buf;
+    char chunk[1 << 16];
+    size_t got;
+    while ((got = std::fread(chunk, 1, sizeof(chunk), f)) > 0)
+        buf.insert(buf.end(), chunk, chunk + got);
+    std::fclose(f);
+    return buf;
+}
+} // namespace detail
+
+// `source target[ value]` per line, \n or \r\n (crates/builder/src/input/edgelist.rs:181-265);
+// node_count = largest id + 1 (csr.rs:530)
+struct EdgeListInput {
+    bool weighted = false;
+    EdgeData read(const std::string &path) const
+    {
+        std::vector<char> buf = detail::read_file(path);
+        buf.push_back('\0');
+        EdgeData out;
+        const char *p = buf.data();
+        const char *end = buf.data() + buf.size() - 1;
+        auto skip_ws = [&] {
+            while (p < end && (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n'))
+                ++p;
+        };
+        for (;;) {
+            skip_ws();
+            if (p >= end)
+                break;
+            char *q = nullptr;
+            const unsigned long long s = std::strtoull(p, &q, 10);
+            if (q == p)
+                throw Error(GM_ERR_INVALID, path + ": malformed edge list");
+            p = q;
+            skip_ws();
+            const unsigned long long t = std::strtoull(p, &q, 10);
+            if (q == p)
+                throw Error(GM_ERR_INVALID, path + ": malformed edge list");
+            p = q;
+            out.src.push_back(s);
+            out.dst.push_back(t);
+            if (weighted) {
+                skip_ws();
+                const float v = std::strtof(p, &q);
+                if (q == p)
+                    throw Error(GM_ERR_INVALID, path + ": edge without a value");
+                p = q;
+                out.values.push_back(v);
+            }
+            if (s + 1 > out.node_count) out.node_count = s + 1;
+            if (t + 1 > out.node_count) out.node_count = t + 1;
+        }
+        return out;
+    }
+};
+
+// 12-byte packed edges {v0_low: u32, v1_low: u32, high: u32}: source = v0_low | (high & 0xFFFF) << 32,
+// target = v1_low | (high >> 16) << 32 (crates/builder/src/input/graph500.rs:111-127);
+// node_count = edge_count / 16 (:74)
+struct Graph500Input {
+    EdgeData read(const std::string &path) const
+    {
+        const std::vector<char> buf = detail::read_file(path);
+        if (buf.size() % 12)
+            throw Error(GM_ERR_INVALID, path + ": size is not a multiple of 12 bytes");
+        EdgeData out;
+        const size_t m = buf.size() / 12;
+        out.src.resize(m);
+        out.dst.resize(m);
+        const unsigned char *b = reinterpret_cast<const unsigned char *>(buf.data());
+        auto u32le = [](const unsigned char *x) {
+            return (uint64_t)x[0] | (uint64_t)x[1] << 8 | (uint64_t)x[2] << 16 | (uint64_t)x[3] << 24;
+        };
+        for (size_t i = 0; i < m; ++i) {
+            const uint64_t lo0 = u32le(b + 12 * i), lo1 = u32le(b + 12 * i + 4), hi = u32le(b + 12 * i + 8);
+            out.src[i] = lo0 | (hi & 0xFFFFull) << 32;
+            out.dst[i] = lo1 | (hi >> 16) << 32;
+        }
+        out.node_count = m / 16;
+        return out;
+    }
+};
+
+// GraphBuilder::new().csr_layout(..).edges(..) | .file_format(..).path(..) -> build()
+// (crates/builder/src/builder.rs:123-540)
 class GraphBuilder {
 public:
     GraphBuilder &csr_layout(CsrLayout l) { layout_ = l; return *this; }
@@ -145,6 +247,26 @@ public:
     {
         src_.clear(); dst_.clear(); w_.clear(); weighted_ = true;
         for (auto &t : e) { push(std::get<0>(t), std::get<1>(t)); w_.push_back(std::get<2>(t)); }
+        return *this;
+    }
+    // .file_format(EdgeListInput{..} | Graph500Input{}).path("...")   (builder.rs:330-420)
+    template <class Format> GraphBuilder &file_format(const Format &f)
+    {
+        reader_ = [f](const std::string &path) { return f.read(path); };
+        return *this;
+    }
+    GraphBuilder &path(const std::string &file)
+    {
+        if (!reader_)
+            throw Error(GM_ERR_INVALID, "GraphBuilder::path before file_format");
+        const EdgeData data = reader_(file);
+        src_.clear(); dst_.clear(); w_.clear();
+        weighted_ = !data.values.empty();
+        n_ = 0;
+        for (size_t i = 0; i < data.src.size(); ++i)
+            push(data.src[i], data.dst[i]);
+        w_ = data.values;
+        n_ = data.node_count; // the format's own rule (Graph500: edge_count / 16)
         return *this;
     }
     template <class G> G build() const { return build_impl(static_cast<G *>(nullptr)); }
@@ -179,6 +301,7 @@ private:
     bool weighted_ = false;
     std::vector<uint32_t> src_, dst_;
     std::vector<float> w_;
+    std::function<EdgeData(const std::string &)> reader_;
 };
 
 // ---- algorithms ------------------------------------------------------------------------------------
@@ -267,7 +390,9 @@ using graph::CsrLayout;
 using graph::delta_stepping;
 using graph::DeltaSteppingConfig;
 using graph::DirectedCsrGraph;
+using graph::EdgeListInput;
 using graph::global_triangle_count;
+using graph::Graph500Input;
 using graph::GraphBuilder;
 using graph::page_rank;
 using graph::PageRankConfig;

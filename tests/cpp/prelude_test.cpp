@@ -23,8 +23,9 @@ static bool bits_equal(const std::vector<float> &a, const std::vector<float> &b)
     return a.size() == b.size() && std::memcmp(a.data(), b.data(), a.size() * sizeof(float)) == 0;
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    const std::string golden = argc > 1 ? argv[1] : "";
     try {
         { // crates/algos/src/lib.rs:92-141 (README doc-test): bit-exact scores, 10 iterations
             auto g = GraphBuilder()
@@ -88,6 +89,26 @@ int main()
             relabel_graph(g);
             EXPECT(global_triangle_count(g) == 2);
             EXPECT(g.edge_count() == 6 && g.degree(0) == 2);
+        }
+        if (!golden.empty()) { // crates/builder/tests/builder.rs:448-491: the Graph500 fixture through the file reader
+            auto g = GraphBuilder()
+                         .csr_layout(CsrLayout::Sorted)
+                         .file_format(Graph500Input{})
+                         .path(golden + "/scale_8.graph500")
+                         .build<DirectedCsrGraph<uint32_t>>();
+            EXPECT(g.node_count() == 256 && g.edge_count() == 4096);
+            auto o = g.out_neighbors(0);
+            EXPECT(o.size() == 2 && o[0] == 37 && o[1] == 157);
+            EXPECT(g.in_neighbors(0).size() == 14);
+            auto ug = g.to_undirected<uint32_t>(CsrLayout::Sorted);
+            relabel_graph(ug);
+            EXPECT(global_triangle_count(ug) == 227874); // mate/tests/triangle_count_test.py:5-9 (after relabel)
+            auto gw = GraphBuilder()
+                          .csr_layout(CsrLayout::Deduplicated)
+                          .file_format(EdgeListInput{true})
+                          .path(golden + "/example.wel")
+                          .build<DirectedCsrGraph<uint32_t>>();
+            EXPECT(gw.node_count() == 4 && gw.edge_count() == 5);
         }
     } catch (const std::exception &e) {
         std::printf("EXCEPTION %s\n", e.what());

@@ -12,7 +12,7 @@ EXE = os.path.join(ROOT, "tests", "cpp", "prelude_test")
 @pytest.mark.gpu
 def test_cpp_prelude_mirror_passes_reference_unit_tests():
     assert os.path.exists(EXE), "tests/cpp/prelude_test missing: run __graft_entry__.build()"
-    r = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([EXE, os.path.join(ROOT, "tests", "golden")], capture_output=True, text=True, timeout=300)
     print(r.stdout, r.stderr)
     assert r.returncode == 0 and "ALL PASSED" in r.stdout
 

@@ -62,3 +62,36 @@ def test_serialize_round_trip_on_device(tmp_path, golden_dir):
     io.serialize(ug, path)
     uh = io.deserialize(path, P.UndirectedCsrGraph, layout=P.CsrLayout.Deduplicated)
     assert P.global_triangle_count(uh) == 10508
+
+
+def test_cpp_prelude_file_readers_match_python_readers(golden_dir):
+    """include/graph_prelude.hpp's EdgeListInput / Graph500Input (host-only parsing) against the Python
+    readers on the reference's fixture files; the program makes no library call, so this runs without a GPU."""
+    import subprocess
+
+    from graph_amd import prelude as P
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "tests", "cpp"), "loaders_test"])
+    out = subprocess.run([os.path.join(root, "tests", "cpp", "loaders_test"), golden_dir], capture_output=True, text=True,
+                         check=True).stdout.strip().splitlines()
+    got = {ln.split()[0]: dict(kv.split("=") for kv in ln.split()[1:]) for ln in out if " " in ln}
+    assert out[-1] == "missing-file-throws=1"
+
+    def fnv(src, dst):
+        h = 1469598103934665603
+        for s, d in zip(src.tolist(), dst.tolist()):
+            h = ((h ^ s) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+            h = ((h ^ d) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return h
+
+    cases = {"example.el": P.EdgeListInput(), "example.wel": P.EdgeListInput(weighted=True),
+             "windows.el": P.EdgeListInput(), "scale_8.graph500": P.Graph500Input()}
+    for name, reader in cases.items():
+        src, dst, w, n = reader.read(os.path.join(golden_dir, name))
+        rec = got[name]
+        assert int(rec["nodes"]) == n and int(rec["edges"]) == src.size
+        assert int(rec["hash"]) == fnv(src, dst)
+        assert int(rec["values"]) == (0 if w is None else w.size)
+        if w is not None:
+            assert abs(float(rec["wsum"]) - float(w.astype(np.float64).sum())) < 1e-6
