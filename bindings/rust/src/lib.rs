@@ -25,6 +25,9 @@ extern "C" {
     fn gm_page_rank(in_csr: *const GmCsr, out_degree: *const u32, max_iterations: u64, tolerance: f64,
                     damping_factor: f32, mode: c_int, scores_out: *mut f32, iterations_out: *mut u64,
                     error_out: *mut f64) -> c_int;
+    fn gm_page_rank_directed(out_csr: *const GmCsr, in_csr: *const GmCsr, max_iterations: u64, tolerance: f64,
+                             damping_factor: f32, mode: c_int, scores_out: *mut f32, iterations_out: *mut u64,
+                             error_out: *mut f64) -> c_int;
     fn gm_wcc_afforest(out_csr: *const GmCsr, in_csr: *const GmCsr, neighbor_rounds: u64, sampling_size: u64,
                        components_out: *mut u32) -> c_int;
     fn gm_sssp_delta_stepping(out_csr: *const GmCsr, start_node: u64, delta: f32, distances_out: *mut f32) -> c_int;
@@ -88,8 +91,9 @@ pub fn page_rank(g: &DeviceDirected, max_iterations: usize, tolerance: f64, damp
     let mut scores = vec![0f32; g.node_count as usize];
     let (mut iterations, mut error) = (0u64, 0f64);
     check(unsafe {
-        gm_page_rank(g.inc.0, g.out_degree.as_ptr(), max_iterations as u64, tolerance, damping_factor, 0,
-                     scores.as_mut_ptr(), &mut iterations, &mut error)
+        // both CSRs are resident: out-degrees come from the out-CSR's offsets on the device
+        gm_page_rank_directed(g.out.0, g.inc.0, max_iterations as u64, tolerance, damping_factor, 0,
+                              scores.as_mut_ptr(), &mut iterations, &mut error)
     });
     (scores, iterations as usize, error)
 }

@@ -44,6 +44,7 @@ SIGNATURES = {
     "gm_csr_to_undirected": (i32, [vp, i32, PP]),
     "gm_csr_relabel_by_degree": (i32, [vp, PP, vp]),
     "gm_page_rank": (i32, [vp, vp, u64, f64, f32, i32, vp, C.POINTER(u64), C.POINTER(f64)]),
+    "gm_page_rank_directed": (i32, [vp, vp, u64, f64, f32, i32, vp, C.POINTER(u64), C.POINTER(f64)]),
     "gm_pr_create": (i32, [vp, u64, u64, u64, f32, PP]),
     "gm_pr_create_with": (i32, [vp, u64, u64, u64, u64, f32, i32, PP]),
     "gm_pr_engine": (i32, [vp]),

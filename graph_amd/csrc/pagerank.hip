@@ -69,6 +69,13 @@ __global__ void pr_init_kernel(uint32_t n_local, float init, const uint32_t *__r
 }
 
 // out_degree[v] = number of occurrences of v in the in-lists
+__global__ void pr_degrees_from_offsets_kernel(const uint32_t *__restrict__ off, uint32_t n, uint32_t *__restrict__ deg)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += stride)
+        deg[u] = off[u + 1] - off[u];
+}
+
 __global__ void pr_count_outdeg_kernel(const uint32_t *__restrict__ tgt, uint64_t m, uint32_t *__restrict__ outdeg)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -576,10 +583,20 @@ GM_API int gm_pr_sweep(gm_pr *pr, uint64_t d_x_in_global, uint64_t d_x_out_local
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-int pr_out_degrees(const gm_csr *csr, const uint32_t *host_outdeg, gm::DevBuf &buf, hipStream_t st)
+// out-degrees on the device: from the out-CSR's offsets when the caller has one (no PCIe traffic), else
+// the caller's host array, else counted from the in-CSR's targets
+int pr_out_degrees(const gm_csr *csr, const uint32_t *host_outdeg, const gm_csr *out_csr, gm::DevBuf &buf, hipStream_t st)
 {
     GM_TRY(buf.alloc((size_t)csr->n * 4));
-    if (host_outdeg) {
+    if (out_csr) {
+        unsigned grid = gm::div_up(csr->n, 256);
+        if (grid > 256 * 16)
+            grid = 256 * 16;
+        if (csr->n)
+            hipLaunchKernelGGL(pr_degrees_from_offsets_kernel, dim3(grid), dim3(256), 0, st, out_csr->offsets, (uint32_t)csr->n,
+                               buf.as<uint32_t>());
+        GM_HIP(hipGetLastError());
+    } else if (host_outdeg) {
         GM_HIP(hipMemcpyAsync(buf.p, host_outdeg, (size_t)csr->n * 4, hipMemcpyHostToDevice, st));
     } else {
         GM_HIP(hipMemsetAsync(buf.p, 0, (size_t)csr->n * 4, st));
@@ -611,11 +628,13 @@ struct PrHolder {
 
 } // namespace
 
-GM_API int gm_page_rank(const gm_csr *in_csr, const uint32_t *out_degree, uint64_t max_iterations, double tolerance,
-                        float damping_factor, int mode, float *scores_out, uint64_t *iterations_out,
-                        double *error_out)
+static int page_rank_impl(const gm_csr *in_csr, const uint32_t *out_degree, const gm_csr *out_csr, uint64_t max_iterations,
+                          double tolerance, float damping_factor, int mode, float *scores_out, uint64_t *iterations_out,
+                          double *error_out)
 {
     GM_CHECK(in_csr && iterations_out && error_out, GM_ERR_INVALID, "gm_page_rank: null argument");
+    GM_CHECK(!out_csr || (out_csr->n == in_csr->n && out_csr->m == in_csr->m && out_csr->device == in_csr->device),
+             GM_ERR_INVALID, "gm_page_rank_directed: the two CSRs are not the out- and in-lists of one graph on one device");
     GM_CHECK(mode >= GM_PR_AUTO && mode <= GM_PR_JACOBI_REFORDER, GM_ERR_INVALID, "gm_page_rank: unknown mode %d", mode);
     // page_rank.rs:105-109: the loop only ends on error < tolerance or iteration == max_iterations
     GM_CHECK(max_iterations != 0 || tolerance > 0.0, GM_ERR_INVALID,
@@ -639,7 +658,7 @@ GM_API int gm_page_rank(const gm_csr *in_csr, const uint32_t *out_degree, uint64
 
     gm::DevBuf outdeg, scores, x0, x1, dres;
     gm::PinnedBuf hres;
-    GM_TRY(pr_out_degrees(in_csr, out_degree, outdeg, st));
+    GM_TRY(pr_out_degrees(in_csr, out_degree, out_csr, outdeg, st));
     GM_TRY(scores.alloc(n * 4));
     GM_TRY(dres.alloc(16));
     GM_TRY(hres.alloc(16));
@@ -726,4 +745,21 @@ GM_API int gm_page_rank(const gm_csr *in_csr, const uint32_t *out_degree, uint64
     *iterations_out = iter;
     *error_out = err;
     return GM_OK;
+}
+
+GM_API int gm_page_rank(const gm_csr *in_csr, const uint32_t *out_degree, uint64_t max_iterations, double tolerance,
+                        float damping_factor, int mode, float *scores_out, uint64_t *iterations_out,
+                        double *error_out)
+{
+    return page_rank_impl(in_csr, out_degree, nullptr, max_iterations, tolerance, damping_factor, mode, scores_out,
+                          iterations_out, error_out);
+}
+
+GM_API int gm_page_rank_directed(const gm_csr *out_csr, const gm_csr *in_csr, uint64_t max_iterations, double tolerance,
+                                 float damping_factor, int mode, float *scores_out, uint64_t *iterations_out,
+                                 double *error_out)
+{
+    GM_CHECK(out_csr, GM_ERR_INVALID, "gm_page_rank_directed: null out-CSR");
+    return page_rank_impl(in_csr, nullptr, out_csr, max_iterations, tolerance, damping_factor, mode, scores_out,
+                          iterations_out, error_out);
 }

@@ -341,12 +341,12 @@ def page_rank(graph: DirectedCsrGraph, config: PageRankConfig | None = None, mod
     """page_rank(&graph, config) -> (scores, iterations, error) — crates/algos/src/page_rank.rs:58-111."""
     config = config or PageRankConfig()
     n = graph.node_count()
-    out_deg = graph.csr_out.degrees()
     scores = np.empty(n, np.float32)
     it, err = u64(0), f64(0.0)
-    check(lib().gm_page_rank(graph.csr_inc.handle, _ptr(out_deg) if n else None, int(config.max_iterations),
-                             float(config.tolerance), float(config.damping_factor), int(mode),
-                             _ptr(scores) if n else None, C.byref(it), C.byref(err)))
+    # both CSRs are resident: out-degrees are taken from the out-CSR's offsets on the device
+    check(lib().gm_page_rank_directed(graph.csr_out.handle, graph.csr_inc.handle, int(config.max_iterations),
+                                      float(config.tolerance), float(config.damping_factor), int(mode),
+                                      _ptr(scores) if n else None, C.byref(it), C.byref(err)))
     return scores, int(it.value), float(err.value)
 
 

@@ -139,6 +139,11 @@ typedef enum gm_pr_mode {
 int gm_page_rank(const gm_csr *in_csr, const uint32_t *out_degree, uint64_t max_iterations, double tolerance,
                  float damping_factor, int mode, float *scores_out /* n, host */, uint64_t *iterations_out,
                  double *error_out);
+/* The same for a caller that holds both CSRs of a DirectedCsrGraph on the device (the shape of the
+ * reference's graph type, csr.rs:364-389): out-degrees come from out_csr's offsets on the device, so
+ * nothing but the scores crosses PCIe (gm_page_rank uploads n * 4 bytes of out-degrees per call). */
+int gm_page_rank_directed(const gm_csr *out_csr, const gm_csr *in_csr, uint64_t max_iterations, double tolerance,
+                          float damping_factor, int mode, float *scores_out, uint64_t *iterations_out, double *error_out);
 
 /* Resident PageRank engine: the per-sweep hot loop (page_rank_iteration, page_rank.rs:113-168)
  * over rows [row_begin, row_begin + n_local) of a graph with n_global nodes.  One engine per

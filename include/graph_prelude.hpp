@@ -318,13 +318,12 @@ std::tuple<std::vector<float>, size_t, double> page_rank(const DirectedCsrGraph<
                                                          int mode = GM_PR_AUTO)
 {
     const uint64_t n = gm_csr_node_count(g.csr_inc());
-    std::vector<uint32_t> out_deg(n);
-    detail::check(gm_csr_degrees(g.csr_out(), out_deg.data()));
     std::vector<float> scores(n);
     uint64_t iterations = 0;
     double error = 0.0;
-    detail::check(gm_page_rank(g.csr_inc(), out_deg.data(), config.max_iterations, config.tolerance, config.damping_factor,
-                               mode, scores.data(), &iterations, &error));
+    // both CSRs are resident: out-degrees come from the out-CSR's offsets on the device
+    detail::check(gm_page_rank_directed(g.csr_out(), g.csr_inc(), config.max_iterations, config.tolerance,
+                                        config.damping_factor, mode, scores.data(), &iterations, &error));
     return {std::move(scores), (size_t)iterations, error};
 }
 

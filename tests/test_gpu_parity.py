@@ -895,3 +895,36 @@ def test_concurrent_calls_on_shared_graphs(P, oracle):
         t.join(timeout=300)
     assert not any(t.is_alive() for t in threads)
     assert failures == []
+
+
+def test_page_rank_out_degree_sources_agree(P, oracle):
+    """gm_page_rank_directed (degrees from the resident out-CSR), gm_page_rank with the caller's host
+    array, and gm_page_rank with NULL (degrees counted from the in-lists) are the same computation."""
+    import ctypes as C
+
+    from graph_amd._lib import GraphMI355XError, check, lib, vp
+
+    n = 1 << 15
+    s, d = oracle.rmat_edges(15, seed=33)
+    g = _directed(P, n, s, d, P.CsrLayout.Sorted)
+    od = oracle.out_degrees_from(n, s).astype(np.uint32)
+    res = []
+    for variant in ("directed", "host", "null"):
+        scores = np.empty(n, np.float32)
+        it, err = C.c_uint64(0), C.c_double(0.0)
+        sp = scores.ctypes.data_as(vp)
+        if variant == "directed":
+            check(lib().gm_page_rank_directed(g.csr_out.handle, g.csr_inc.handle, 7, 0.0, 0.85, int(P.PageRankMode.JacobiPB), sp,
+                                              C.byref(it), C.byref(err)))
+        else:
+            check(lib().gm_page_rank(g.csr_inc.handle, od.ctypes.data_as(vp) if variant == "host" else None, 7, 0.0, 0.85,
+                                     int(P.PageRankMode.JacobiPB), sp, C.byref(it), C.byref(err)))
+        res.append((scores, it.value, err.value))
+    for r in res[1:]:
+        assert np.array_equal(r[0], res[0][0]) and r[1] == res[0][1] == 7 and r[2] == res[0][2]
+    other = _directed(P, 1 << 14, *oracle.rmat_edges(14, seed=34), P.CsrLayout.Sorted)
+    with pytest.raises(GraphMI355XError):  # not the two CSRs of one graph
+        scores = np.empty(n, np.float32)
+        it, err = C.c_uint64(0), C.c_double(0.0)
+        check(lib().gm_page_rank_directed(other.csr_out.handle, g.csr_inc.handle, 3, 0.0, 0.85, 0, scores.ctypes.data_as(vp),
+                                          C.byref(it), C.byref(err)))
