@@ -297,15 +297,13 @@ def main():
         tgt_h = np.empty(m, np.uint32)
         check(lib().gm_csr_download(in_csr.handle, off_h.ctypes.data_as(vp), tgt_h.ctypes.data_as(vp), None))
         od_h = out_deg.cpu().numpy().astype(np.uint32)
-        cores = args.cpu_threads or (os.cpu_count() or 4)
-        O.page_rank_chunked(off_h, tgt_h, od_h, 1, 0.0, 0.85, cores)  # warm-up (page cache, thread pool)
-        t1 = time.perf_counter()
-        O.page_rank_chunked(off_h, tgt_h, od_h, args.cpu_sweeps, 0.0, 0.85, cores)
-        cpu_s = time.perf_counter() - t1
+        cores = args.cpu_threads or O.effective_cores()  # affinity mask capped by the cgroup CPU quota, as Rust's available_parallelism()
+        cpu_s, _ = O.page_rank_chunked_timed(off_h, tgt_h, od_h, args.cpu_sweeps, 0.85, cores, spread=True)
         result["cpu_baseline"] = {
             "value": round(m * args.cpu_sweeps / cpu_s / 1e9, 4), "unit": "GTEPS", "cores": cores, "kind": "port",
             "sample": f"{args.cpu_sweeps} sweeps of the same scale-{scale} graph (after 1 warm-up sweep), "
-                      f"orc_page_rank_chunked: 16384-node dynamic chunks, threads re-spawned per sweep",
+                      f"orc_page_rank_chunked_timed: 16384-node dynamic chunks, threads re-spawned per sweep, inputs "
+                      f"first-touched by all threads (NUMA spread)",
             "ms_per_step": round(cpu_s * 1e3 / args.cpu_sweeps, 3),
         }
     if emu:

@@ -29,6 +29,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <time.h>
 #include <float.h>
 
 #define ORC_EXPORT __attribute__((visibility("default")))
@@ -417,6 +419,115 @@ ORC_EXPORT int orc_page_rank_chunked(uint32_t n, const uint32_t *in_off, const u
     free(jobs);
     *iterations_out = iter;
     *error_out = err;
+    return 0;
+}
+
+/* ---- timed CPU baseline (bench.py's cpu_baseline leg) ------------------------------------------------
+ * The same sweeps as orc_page_rank_chunked on private copies of the inputs whose pages were first
+ * touched in 2 MiB stripes by all worker threads.  The reference builds its CSR with the rayon pool
+ * (csr.rs:124-221), so its pages are spread over the NUMA nodes of a many-socket host; arrays handed
+ * over from numpy were touched by one thread and would make every core pull from one memory
+ * controller.  spread = 0 runs on the caller's arrays as they are.  Returns the wall time of `sweeps`
+ * sweeps after one untimed sweep; thread creation per sweep is inside the time, as in the reference
+ * (page_rank.rs:127-131). */
+typedef struct {
+    char *dst;
+    const char *src; /* NULL: fill with zero bytes */
+    size_t bytes;
+    uint32_t t, T;
+} orc_spread_job;
+
+static void *orc_spread_worker(void *p)
+{
+    orc_spread_job *j = (orc_spread_job *)p;
+    const size_t stripe = (size_t)2 << 20;
+    for (size_t o = (size_t)j->t * stripe; o < j->bytes; o += (size_t)j->T * stripe) {
+        const size_t len = j->bytes - o < stripe ? j->bytes - o : stripe;
+        if (j->src)
+            memcpy(j->dst + o, j->src + o, len);
+        else
+            memset(j->dst + o, 0, len);
+    }
+    return NULL;
+}
+
+static void *orc_spread_copy(const void *src, size_t bytes, uint32_t threads)
+{
+    /* 2 MiB-aligned and advised as huge pages: the gathered vector spans 65536 4-KiB pages at scale 26,
+     * far beyond the TLB reach (a system with transparent_hugepage=always gives the reference the same) */
+    void *mem = NULL;
+    if (posix_memalign(&mem, (size_t)2 << 20, bytes ? bytes : 1) != 0)
+        return NULL;
+    (void)madvise(mem, bytes, MADV_HUGEPAGE);
+    char *dst = (char *)mem;
+    pthread_t *tid = (pthread_t *)malloc(threads * sizeof(pthread_t));
+    orc_spread_job *jobs = (orc_spread_job *)malloc(threads * sizeof(orc_spread_job));
+    for (uint32_t t = 0; t < threads; ++t) {
+        jobs[t] = (orc_spread_job){dst, (const char *)src, bytes, t, threads};
+        pthread_create(&tid[t], NULL, orc_spread_worker, &jobs[t]);
+    }
+    for (uint32_t t = 0; t < threads; ++t)
+        pthread_join(tid[t], NULL);
+    free(tid);
+    free(jobs);
+    return dst;
+}
+
+ORC_EXPORT int orc_page_rank_chunked_timed(uint32_t n, const uint32_t *in_off, const uint32_t *in_tgt,
+                                           const uint32_t *out_deg, uint64_t sweeps, float damping, uint32_t threads,
+                                           int spread, double *seconds_out, double *error_out)
+{
+    if (threads == 0)
+        threads = 4;
+    const uint64_t m = in_off[n];
+    const uint32_t *off = in_off, *tgt = in_tgt, *od = out_deg;
+    void *c_off = NULL, *c_tgt = NULL, *c_od = NULL;
+    if (spread) {
+        c_off = orc_spread_copy(in_off, ((size_t)n + 1) * 4, threads);
+        c_tgt = orc_spread_copy(in_tgt, (size_t)m * 4, threads);
+        c_od = orc_spread_copy(out_deg, (size_t)n * 4, threads);
+        if (!c_off || !c_tgt || !c_od)
+            return -1;
+        off = (const uint32_t *)c_off, tgt = (const uint32_t *)c_tgt, od = (const uint32_t *)c_od;
+    }
+    float *scores = (float *)(spread ? orc_spread_copy(NULL, (size_t)n * 4, threads) : malloc((size_t)(n ? n : 1) * 4));
+    float *outs = (float *)(spread ? orc_spread_copy(NULL, (size_t)n * 4, threads) : malloc((size_t)(n ? n : 1) * 4));
+    pthread_t *tid = (pthread_t *)malloc(threads * sizeof(pthread_t));
+    orc_pr_job *jobs = (orc_pr_job *)malloc(threads * sizeof(orc_pr_job));
+    if (!scores || !outs || !tid || !jobs)
+        return -1;
+    const float init = 1.0f / (float)n, base = (1.0f - damping) / (float)n;
+    for (uint32_t u = 0; u < n; ++u) {
+        scores[u] = init;
+        outs[u] = init / (float)od[u];
+    }
+    struct timespec t0, t1;
+    double err = 0.0;
+    for (uint64_t it = 0; it <= sweeps; ++it) {
+        if (it == 1)
+            clock_gettime(CLOCK_MONOTONIC, &t0);
+        atomic_uint_fast64_t next;
+        atomic_init(&next, 0);
+        for (uint32_t t = 0; t < threads; ++t) {
+            jobs[t] = (orc_pr_job){n, off, tgt, od, base, damping, scores, outs, &next, 0.0};
+            pthread_create(&tid[t], NULL, orc_pr_worker, &jobs[t]);
+        }
+        err = 0.0;
+        for (uint32_t t = 0; t < threads; ++t) {
+            pthread_join(tid[t], NULL);
+            err += jobs[t].err;
+        }
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    *seconds_out = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    *error_out = err;
+    free(scores);
+    free(outs);
+    free(tid);
+    free(jobs);
+    free(c_off);
+    free(c_tgt);
+    free(c_od);
     return 0;
 }
 

@@ -55,6 +55,9 @@ def lib():
         L.orc_page_rank_chunked.argtypes = [C.c_uint32, _u32p, _u32p, _u32p, C.c_uint64, C.c_double, C.c_float,
                                             C.c_uint32, _f32p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
         L.orc_page_rank_chunked.restype = C.c_int
+        L.orc_page_rank_chunked_timed.argtypes = [C.c_uint32, _u32p, _u32p, _u32p, C.c_uint64, C.c_float, C.c_uint32, C.c_int,
+                                                  C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.orc_page_rank_chunked_timed.restype = C.c_int
         L.orc_page_rank_f64.argtypes = [C.c_uint32, _u32p, _u32p, _u32p, C.c_uint64, C.c_double, C.c_double,
                                         _f64p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
         L.orc_page_rank_f64.restype = None
@@ -175,9 +178,29 @@ def page_rank_seq(in_off, in_tgt, out_deg, max_iterations=20, tolerance=1e-4, da
     return scores[:n], it.value, err.value
 
 
+def effective_cores() -> int:
+    """What Rust's available_parallelism() (page_rank.rs:128) would report: the affinity mask capped by the
+    cgroup CPU quota (a container with cpu.max = 16 CPUs on a 256-thread host runs 16 workers)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 4)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2: "<quota> <period>" or "max <period>"
+            quota, period = f.read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                quota, period = int(fq.read()), int(fp.read())
+                if quota > 0:
+                    n = min(n, max(1, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def page_rank_chunked(in_off, in_tgt, out_deg, max_iterations=20, tolerance=1e-4, damping=0.85, threads=0):
     n = in_off.size - 1
-    threads = threads or (os.cpu_count() or 4)
+    threads = threads or effective_cores()
     scores = np.empty(max(n, 1), np.float32)
     it, err = C.c_uint64(), C.c_double()
     rc = lib().orc_page_rank_chunked(n, in_off, _tgt(in_tgt), np.ascontiguousarray(out_deg, np.uint32),
@@ -185,6 +208,18 @@ def page_rank_chunked(in_off, in_tgt, out_deg, max_iterations=20, tolerance=1e-4
                                      C.byref(err))
     assert rc == 0
     return scores[:n], it.value, err.value
+
+
+def page_rank_chunked_timed(in_off, in_tgt, out_deg, sweeps, damping=0.85, threads=0, spread=True):
+    """bench.py's CPU baseline: seconds for `sweeps` sweeps of the threaded path after one untimed sweep, on
+    copies whose pages were first touched by all threads (spread) -> (seconds, last error)"""
+    n = in_off.size - 1
+    threads = threads or effective_cores()
+    sec, err = C.c_double(), C.c_double()
+    rc = lib().orc_page_rank_chunked_timed(n, in_off, _tgt(in_tgt), np.ascontiguousarray(out_deg, np.uint32), sweeps,
+                                           damping, threads, 1 if spread else 0, C.byref(sec), C.byref(err))
+    assert rc == 0
+    return sec.value, err.value
 
 
 def page_rank_f64(in_off, in_tgt, out_deg, max_iterations=500, tolerance=1e-14, damping=0.85):
