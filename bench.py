@@ -40,7 +40,7 @@ def parse_args():
     ap.add_argument("--scale", type=int, default=26)   # BASELINE.json metric: RMAT scale-26
     ap.add_argument("--edge-factor", type=int, default=16)
     ap.add_argument("--seed", type=int, default=42)
-    ap.add_argument("--cpu-sweeps", type=int, default=8, help="sweeps of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sweeps", type=int, default=20, help="sweeps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores (available_parallelism)")
     ap.add_argument("--relabel", type=int, default=0, help="(experimental) internal degree-ordered layout")
     ap.add_argument("--engine", choices=["auto", "pull", "pb"], default="auto")
