@@ -7,23 +7,27 @@
 // random 4-byte accesses fast enough, so the sweep is restructured so that every random access
 // lands in LDS and everything that touches HBM is a sequential stream:
 //
-//   pb_bin_kernel    one workgroup per SOURCE TILE (S = 16384 consecutive node ids): the tile's
-//                    out_scores are loaded into LDS (64 KiB, coalesced); the tile's edges — stored
-//                    once, at plan creation, as 2-byte local source ids grouped by destination bin
-//                    — are streamed and each edge's value xs[src] is appended to its bin's slice of
-//                    the `vals` stream (4-byte coalesced writes, runs of (tile, bin) segments).
-//   pb_accum_kernel  one workgroup per DESTINATION BIN (R <= 16384 consecutive rows): streams the
-//                    bin's values and 2-byte local row ids and accumulates into an LDS array of
-//                    64-bit fixed-point sums (ds_add_u64, scale 2^62: exact, order-independent), then
-//                    the fused epilogue of the reference (new score, |delta|, out_score) for its rows.
+//   pb_bin_kernel    one workgroup per chunk (32768 entries) of a SOURCE TILE (2^s_log = 16384 or 32768
+//                    consecutive ids of x): the tile's out_scores are loaded into LDS (64 / 128 KiB,
+//                    coalesced); the tile's edges — stored once, at plan creation, as 2-byte local source
+//                    ids grouped by destination bin — are streamed and each edge's value xs[src] is
+//                    appended to its bin's slice of the `vals` stream (float4 writes, runs of (tile, bin)
+//                    segments).  Software-pipelined: ids of the next step are requested before the stores
+//                    of this one.
+//   pb_accum_kernel  one workgroup per DESTINATION BIN (R <= 16384 consecutive rows; over-long bins are
+//                    sliced): streams the bin's values and 2-byte accumulator slots and accumulates into
+//                    an LDS array of 64-bit fixed-point sums (ds_add_u64, scale 2^62: exact,
+//                    order-independent); edges of the H most frequent ("hot") sources skip the value
+//                    stream — 4-byte (slot, hot index) records read against an LDS table of their
+//                    out_scores; then the fused epilogue of the reference (new score, |delta|, out_score).
 //   pb_err_kernel    sums the per-bin f64 errors in index order.
 //
 // The row sum is therefore the exactly rounded sum of the f32 out_scores: deterministic, identical
 // for any partition of the rows over GPUs, and closer to the real-number fixed point than any f32
 // summation order (the reference's left-to-right order drifts by ~sqrt(in-degree) * 2^-24).
 //
-// HBM traffic per edge and sweep: 2 B (source id) + 4 B (value write) + 4 B (value read) + 2 B (row id)
-// = 12 B, all streaming, against 8 B "algorithmic" of which 4 B are a random gather.
+// HBM traffic per edge and sweep: cold 2 B (source id) + 4 B (value write) + 4 B (value read) + 2 B (slot)
+// = 12 B, hot 4 B, all streaming, against 8 B "algorithmic" of which 4 B are a random gather.
 #include "pagerank.hpp"
 
 #include <rocprim/rocprim.hpp>
