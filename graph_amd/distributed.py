@@ -132,7 +132,11 @@ class PiecewiseExchange:
     the propagation of regions < k of the next sweep.  engine: sweep_bin / sweep_accum / sweep_fixup /
     set_parts (graph_amd.engine.PageRankEngine, or a stand-in with the same methods)."""
 
-    def __init__(self, engine, layout, rank: int, n_local: int, device, group=None, gather=None):
+    def __init__(self, engine, layout, rank: int, n_local: int, device, group=None, gather=None, split_bin=True):
+        # split_bin=False: one propagation launch after every region has landed (only the accumulate is cut into
+        # row groups) — region k still travels under the accumulate of the later groups, and the short kernels
+        # of a many-rank run are not cut in four
+        self.split_bin = split_bin
         self.engine, self.layout, self.rank, self.group = engine, layout, rank, group
         world = len(layout["row_splits"])
         self.parts = layout["parts"]
@@ -183,7 +187,10 @@ class PiecewiseExchange:
             if self.works[k] is not None:
                 self.works[k].wait()  # orders the current stream behind the collective; the host does not block
             lo, hi = self.regions[k]
-            timed(e.sweep_bin, x_in, lo, hi)
+            if self.split_bin:
+                timed(e.sweep_bin, x_in, lo, hi)
+        if not self.split_bin:
+            timed(e.sweep_bin, x_in, 0, x_in.numel())
         for k in range(self.parts):
             timed(e.sweep_accum, x_in, self.x_loc, scores, k)
             self._start_gather(1 - self.cur, k)
