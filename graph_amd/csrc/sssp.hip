@@ -6,12 +6,13 @@
 // reference although its buckets are organised differently:
 //   * distances are kept as u32 bit patterns (non-negative f32 order == unsigned order) and
 //     relaxed with atomicMin — the reference's CAS-min loop (sssp.rs:180-202) in one instruction;
-//   * instead of per-thread bins copied into a shared frontier (sssp.rs:85-94) there are two
-//     byte-flag arrays (double-buffered per round, so no in-round ordering is needed): a node is
-//     flagged when its distance improved since its edges were last relaxed; a round relaxes every
-//     flagged node whose distance is <= the current threshold and carries the others over,
-//     tracking the minimum pending distance — the role of the reference's min_non_empty_bin
-//     (sssp.rs:159-168).  The threshold advances to (minimum pending distance + width) when a round
+//   * instead of per-thread bins copied into a shared frontier (sssp.rs:85-94) there is one bit per
+//     node: set when the node's distance improved since its edges were last relaxed.  A round clears
+//     and relaxes every flagged node whose distance is <= the current threshold; the others simply
+//     stay flagged (nothing is rewritten for them), and the minimum pending distance is tracked — the
+//     role of the reference's min_non_empty_bin (sssp.rs:159-168).  No fences: "distance improved,
+//     then flag set" and "flag cleared, then distance read" are each ordered by the returned value of
+//     the first atomic, so an improvement is never lost;  The threshold advances to (minimum pending distance + width) when a round
 //     leaves nothing below it; width = delta * GM_SSSP_WIDTH (default 1): `delta` only shapes the
 //     schedule, never the result (measured at RMAT scale 24, delta 0.1: widths from delta/16 to pure
 //     Bellman-Ford all take 74-98 ms — the small-world graph needs ~7 near-full passes over the edges
@@ -42,13 +43,15 @@ struct RelaxOut {
 // thr: bit pattern of the current distance threshold (non-negative f32 order == unsigned order).
 // `pre` is dist[t] as read by the caller's batched pre-check (several independent random reads in
 // flight per lane); the atomic only runs when the candidate still looks like an improvement.
-__device__ __forceinline__ void relax_checked(uint32_t *dist, uint8_t *__restrict__ flag_next, uint32_t nb, uint32_t pre,
+__device__ __forceinline__ void relax_checked(uint32_t *dist, uint32_t *flags, uint32_t *wmin, uint32_t nb, uint32_t pre,
                                               uint32_t t, uint32_t thr, RelaxOut &ro)
 {
     if (nb < pre) {
         const uint32_t old = atomicMin(&dist[t], nb);
-        if (nb < old) {
-            flag_next[t] = 1;
+        if (nb < old) { // issued only once the atomicMin has returned: distance, then flag, then word summary
+            uint32_t zero = atomicOr(&flags[t >> 5], 1u << (t & 31u));
+            asm volatile("v_and_b32 %0, 0, %0" : "+v"(zero)); // 0, but only known once the atomicOr has returned
+            atomicMin(&wmin[(t >> 5) + zero], nb);
             if (nb <= thr)
                 ro.again = 1;
             else
@@ -60,7 +63,7 @@ __device__ __forceinline__ void relax_checked(uint32_t *dist, uint8_t *__restric
 // relaxes edges i = first, first + step, ... < end of one source at distance du, SSSP_MLP at a time
 constexpr int SSSP_MLP = 4;
 __device__ __forceinline__ void relax_range(const uint32_t *__restrict__ tgt, const float *__restrict__ w, uint32_t *dist,
-                                            uint8_t *__restrict__ flag_next, float du, uint32_t first, uint32_t end,
+                                            uint32_t *flags, uint32_t *wmin, float du, uint32_t first, uint32_t end,
                                             uint32_t step, uint32_t thr, RelaxOut &ro)
 {
     for (uint32_t i = first; i < end; i += step * SSSP_MLP) {
@@ -77,68 +80,175 @@ __device__ __forceinline__ void relax_range(const uint32_t *__restrict__ tgt, co
             pre[k] = nb[k] != 0xFFFFFFFFu ? ld_agent(&dist[t[k]]) : 0u;
 #pragma unroll
         for (int k = 0; k < SSSP_MLP; ++k)
-            relax_checked(dist, flag_next, nb[k], pre[k], t[k], thr, ro);
+            relax_checked(dist, flags, wmin, nb[k], pre[k], t[k], thr, ro);
     }
 }
 
 // ctrl words shared by the round and advance kernels
-enum : uint32_t { C_AGAIN = 0, C_FAR = 1, C_BAD = 2, C_THR = 3, C_DONE = 4, C_ROUND = 5, C_ADVANCES = 6 };
+enum : uint32_t { C_AGAIN = 0, C_FAR = 1, C_BAD = 2, C_THR = 3, C_DONE = 4, C_ROUND = 5, C_ADVANCES = 6,
+                  C_WORK = 7 /* relaxed edges / 64, statistics */, C_CHUNKS = 8 /* deferred edge chunks of this round */ };
 
-// One round.  A wavefront takes 256 consecutive nodes at a time: a 4-byte flag load per lane decides
-// whether anything in the group is flagged (in the long tail of rounds almost nothing is), then each
-// 64-node quarter is relaxed one lane per node.
-__global__ __launch_bounds__(SSSP_BLOCK) void sssp_round_kernel(
-    const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, const float *__restrict__ w, uint32_t *dist,
-    uint8_t *__restrict__ flags, size_t n_flags, uint32_t n, uint32_t *ctrl)
+// One round.  wmin[i] is a lower bound of the distances of the flagged nodes of flag word i (32 nodes):
+// whoever flags a node lowers it, the scanner resets it and puts back what it leaves flagged.  A
+// wavefront takes 64 words (2048 consecutive nodes) at a time with one coalesced wmin load; only words
+// that can hold a node at or below the threshold are opened (two at a time, one per half wavefront),
+// their near nodes cleared and collected in an LDS list, then relaxed one lane per node (lists longer
+// than 32 edges by the whole wavefront).  Nodes above the threshold cost nothing per round.
+constexpr uint32_t SSSP_GROUP = 64u * 32u; // nodes per wavefront step
+constexpr uint32_t SSSP_BIG = 2048;        // adjacency lists longer than this are cut into chunks for the whole grid
+constexpr uint32_t SSSP_CHUNK = 1024;      // edges per deferred chunk
+
+__device__ __forceinline__ void sssp_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__global__ __launch_bounds__(SSSP_BLOCK) void sssp_round_kernel(const uint32_t *__restrict__ off,
+                                                                const uint32_t *__restrict__ tgt,
+                                                                const float *__restrict__ w, uint32_t *dist,
+                                                                uint32_t *flags, uint32_t *wmin, uint32_t nwords,
+                                                                uint2 *__restrict__ chunks, uint32_t *ctrl)
 {
+    __shared__ uint32_t list[SSSP_BLOCK / kWave][SSSP_GROUP];
     if (ld_agent(&ctrl[C_DONE]))
         return; // a round enqueued behind the last one of its batch
     const uint32_t thr = ld_agent(&ctrl[C_THR]);
-    const uint32_t parity = ld_agent(&ctrl[C_ROUND]) & 1u;
-    uint8_t *__restrict__ flag_cur = flags + (parity ? n_flags : 0);
-    uint8_t *__restrict__ flag_next = flags + (parity ? 0 : n_flags);
     const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t half = lane & 32u, sub = lane & 31u;
+    const uint32_t wv = threadIdx.x >> 6;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-    const uint32_t ngroups = (n + 255u) >> 8; // the flag arrays are padded to a multiple of 256 bytes
-    const uint32_t *flag_words = reinterpret_cast<const uint32_t *>(flag_cur);
+    const uint32_t ngroups = (nwords + kWave - 1) / kWave;
+    const uint64_t lt_mask = lane ? (~0ull >> (64u - lane)) : 0ull;
     RelaxOut ro{0u, NO_BUCKET};
+    uint32_t work = 0; // out-edges of the nodes this lane relaxed (statistics)
     for (uint32_t grp = wave; grp < ngroups; grp += nwaves) {
-        const uint32_t word = flag_words[grp * 64u + lane];
-        if (__ballot(word != 0u) == 0ull)
+        const uint32_t my_word = grp * kWave + lane;
+        const uint32_t lo = my_word < nwords ? ld_agent(&wmin[my_word]) : NO_BUCKET;
+        if (lo > thr && lo != NO_BUCKET)
+            ro.far = lo < ro.far ? lo : ro.far;
+        uint64_t cand = __ballot(lo <= thr);
+        uint32_t total = 0;
+        while (cand) {
+            // two words per step: the lower half of the wavefront opens the first, the upper half the second
+            const uint32_t i0 = (uint32_t)__ffsll((unsigned long long)cand) - 1u;
+            cand &= cand - 1;
+            uint32_t i1 = 64u;
+            if (cand) {
+                i1 = (uint32_t)__ffsll((unsigned long long)cand) - 1u;
+                cand &= cand - 1;
+            }
+            const uint32_t mine = half ? i1 : i0;
+            const bool open = mine < 64u;
+            const uint32_t widx = grp * kWave + (open ? mine : 0u);
+            if (open && sub == 0)
+                atomicExch(&wmin[widx], NO_BUCKET); // reset first, then look: a concurrent flagger re-arms the word
+            sssp_drain();
+            const uint32_t fw = open ? ld_agent(&flags[widx]) : 0u;
+            const bool bit = (fw >> sub) & 1u;
+            const uint32_t u = widx * 32u + sub;
+            const uint32_t db = bit ? ld_agent(&dist[u]) : NO_BUCKET;
+            const bool is_near = bit && db <= thr;
+            uint32_t keep_far = bit && !is_near ? db : NO_BUCKET; // what stays flagged goes back into the summary
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) {
+                const uint32_t other = __shfl_xor(keep_far, o, kWave);
+                keep_far = other < keep_far ? other : keep_far;
+            }
+            if (keep_far != NO_BUCKET) {
+                if (sub == 0)
+                    atomicMin(&wmin[widx], keep_far);
+                ro.far = keep_far < ro.far ? keep_far : ro.far;
+            }
+            const uint64_t near_b = __ballot(is_near);
+            const uint32_t clear = half ? (uint32_t)(near_b >> 32) : (uint32_t)near_b;
+            if (clear && sub == 0)
+                atomicAnd(&flags[widx], ~clear);
+            sssp_drain(); // cleared before anyone reads the distances the relaxation uses
+            if (is_near)
+                list[wv][total + (uint32_t)__popcll(near_b & lt_mask)] = u;
+            total += (uint32_t)__popcll(near_b);
+        }
+        if (total == 0)
             continue;
-        for (uint32_t quarter = 0; quarter < 4; ++quarter) {
-            // lanes whose word covers this quarter: bytes [quarter*64, quarter*64+64) = words quarter*16 .. +16
-            const uint32_t u = (grp << 8) + quarter * 64u + lane;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (uint32_t base = 0; base < total; base += kWave) {
             uint32_t s = 0, e = 0;
             float du = 0.0f;
-            if (u < n && flag_cur[u]) {
-                flag_cur[u] = 0; // this lane is the only reader/writer of flag_cur[u] in this round
-                const uint32_t db = ld_agent(&dist[u]);
-                du = __uint_as_float(db);
-                if (db <= thr) {
-                    s = off[u];
-                    e = off[u + 1];
-                } else { // not yet its turn: carry over
-                    flag_next[u] = 1;
-                    ro.far = db < ro.far ? db : ro.far;
-                }
+            if (base + lane < total) {
+                const uint32_t u = list[wv][base + lane];
+                du = __uint_as_float(ld_agent(&dist[u])); // <= thr: distances only decrease
+                s = off[u];
+                e = off[u + 1];
             }
             // short lists by their own lane, lists longer than 32 edges by the whole wavefront (measured:
             // an edge-balanced expansion with a shuffle search per edge was 25 % slower — the round is bound
             // by the random dist[] accesses, not by the target stream)
             const uint32_t len = e - s;
+            work += len;
             if (len <= SSSP_COOP)
-                relax_range(tgt, w, dist, flag_next, du, s, e, 1u, thr, ro);
-            uint64_t big = __ballot(len > SSSP_COOP);
+                relax_range(tgt, w, dist, flags, wmin, du, s, e, 1u, thr, ro);
+            uint64_t big = __ballot(len > SSSP_COOP && len <= SSSP_BIG);
             while (big) {
                 const int src = __ffsll((unsigned long long)big) - 1;
                 big &= big - 1;
                 const uint32_t bs = __shfl(s, src, kWave), be = __shfl(e, src, kWave);
                 const float bd = __shfl(du, src, kWave);
-                relax_range(tgt, w, dist, flag_next, bd, bs + lane, be, kWave, thr, ro);
+                relax_range(tgt, w, dist, flags, wmin, bd, bs + lane, be, kWave, thr, ro);
+            }
+            // hubs: one wavefront would be the round's critical path (a 300k-edge list = milliseconds);
+            // their edge ranges go to a chunk list that sssp_chunk_kernel spreads over the whole grid
+            uint64_t huge = __ballot(len > SSSP_BIG);
+            while (huge) {
+                const int src = __ffsll((unsigned long long)huge) - 1;
+                huge &= huge - 1;
+                const uint32_t hu = __shfl(base + lane < total ? list[wv][base + lane] : 0u, src, kWave);
+                const uint32_t hs = __shfl(s, src, kWave), he = __shfl(e, src, kWave);
+                const uint32_t nch = (he - hs + SSSP_CHUNK - 1u) / SSSP_CHUNK;
+                uint32_t first = 0;
+                if (lane == 0)
+                    first = atomicAdd(&ctrl[C_CHUNKS], nch);
+                first = __shfl(first, 0, kWave);
+                for (uint32_t c = lane; c < nch; c += kWave)
+                    chunks[first + c] = make_uint2(hu, hs + c * SSSP_CHUNK);
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // the list is rewritten by the next step
+    }
+    const uint32_t far = wave_min(ro.far);
+    const uint64_t any = __ballot(ro.again != 0);
+    const uint32_t wave_work = (uint32_t)wave_sum((uint64_t)work);
+    if (lane == 0) {
+        if (wave_work)
+            atomicAdd(&ctrl[C_WORK], (wave_work + 63u) >> 6);
+        if (any)
+            atomicOr(&ctrl[C_AGAIN], 1u);
+        if (far != NO_BUCKET)
+            atomicMin(&ctrl[C_FAR], far);
+    }
+}
+
+// The deferred hub edges of the round that just ran: chunk (u, first edge) -> up to SSSP_CHUNK edges of u,
+// one wavefront per chunk, any wavefront of the grid.
+__global__ __launch_bounds__(SSSP_BLOCK) void sssp_chunk_kernel(const uint32_t *__restrict__ off,
+                                                                const uint32_t *__restrict__ tgt,
+                                                                const float *__restrict__ w, uint32_t *dist,
+                                                                uint32_t *flags, uint32_t *wmin,
+                                                                const uint2 *__restrict__ chunks, uint32_t *ctrl)
+{
+    if (ld_agent(&ctrl[C_DONE]))
+        return;
+    const uint32_t nchunks = ld_agent(&ctrl[C_CHUNKS]);
+    if (nchunks == 0)
+        return;
+    const uint32_t thr = ld_agent(&ctrl[C_THR]);
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    RelaxOut ro{0u, NO_BUCKET};
+    for (uint32_t c = wave; c < nchunks; c += nwaves) {
+        const uint2 ch = chunks[c];
+        const float du = __uint_as_float(ld_agent(&dist[ch.x]));
+        const uint32_t end_u = off[ch.x + 1];
+        const uint32_t end = ch.y + SSSP_CHUNK < end_u ? ch.y + SSSP_CHUNK : end_u;
+        relax_range(tgt, w, dist, flags, wmin, du, ch.y + lane, end, kWave, thr, ro);
     }
     const uint32_t far = wave_min(ro.far);
     const uint64_t any = __ballot(ro.again != 0);
@@ -151,7 +261,7 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_round_kernel(
 }
 
 // Between two rounds (one thread): nothing left below the threshold -> move it to the minimum pending
-// distance + width, or finish; then swap the flag buffers (round parity) and clear the round's outputs.
+// distance + width, or finish; then clear the round's outputs.
 __global__ void sssp_advance_kernel(uint32_t *ctrl, float width)
 {
     if (ctrl[C_DONE])
@@ -168,6 +278,7 @@ __global__ void sssp_advance_kernel(uint32_t *ctrl, float width)
     }
     ctrl[C_AGAIN] = 0u;
     ctrl[C_FAR] = NO_BUCKET;
+    ctrl[C_CHUNKS] = 0u;
     ctrl[C_ROUND] += 1u;
 }
 
@@ -250,10 +361,14 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
     gm::DevBuf dist, flags, ctrl;
     gm::PinnedBuf hctrl;
     GM_TRY(dist.alloc((size_t)n * 4));
-    const size_t n_flags = ((size_t)n + 255) & ~(size_t)255; // the round kernel reads flags 4 bytes per lane
-    GM_TRY(flags.alloc(n_flags * 2));
-    GM_TRY(ctrl.alloc(32));
-    GM_TRY(hctrl.alloc(32));
+    const uint32_t nwords = (n + 31u) / 32u; // one flag bit per node, one distance summary per flag word
+    GM_TRY(flags.alloc(((size_t)nwords + kWave) * 4));
+    gm::DevBuf wmin;
+    GM_TRY(wmin.alloc(((size_t)nwords + kWave) * 4));
+    GM_TRY(ctrl.alloc(64));
+    GM_TRY(hctrl.alloc(64));
+    gm::DevBuf chunks; // (node, first edge) of deferred hub chunks: at most one per SSSP_CHUNK edges plus one per node
+    GM_TRY(chunks.alloc(((size_t)g->m / SSSP_CHUNK + (size_t)g->m / SSSP_BIG + 64) * sizeof(uint2)));
     hipStream_t st = 0;
     unsigned grid = gm::div_up(n, SSSP_BLOCK);
     if (grid > 256 * 8)
@@ -266,8 +381,8 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
     const float width = delta * frac;
 
     // ctrl: again 0, far NONE, bad 0, threshold 0.0 (only the start node qualifies), done 0, round 0, advances 0
-    const uint32_t init_ctrl[8] = {0u, NO_BUCKET, 0u, 0u, 0u, 0u, 0u, 0u};
-    GM_HIP(hipMemcpyAsync(ctrl.p, init_ctrl, 32, hipMemcpyHostToDevice, st));
+    const uint32_t init_ctrl[16] = {0u, NO_BUCKET, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    GM_HIP(hipMemcpyAsync(ctrl.p, init_ctrl, 64, hipMemcpyHostToDevice, st));
     if (g->m) {
         unsigned wg = gm::div_up(g->m, 256);
         hipLaunchKernelGGL(sssp_check_weights_kernel, dim3(wg > 8192 ? 8192 : wg), dim3(256), 0, st, g->weights, g->m,
@@ -275,9 +390,12 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
     }
     hipLaunchKernelGGL(sssp_init_kernel, dim3(grid), dim3(SSSP_BLOCK), 0, st, dist.as<uint32_t>(), n,
                        (uint32_t)start_node);
-    GM_HIP(hipMemsetAsync(flags.p, 0, n_flags * 2, st));
-    GM_HIP(hipMemsetAsync(flags.as<uint8_t>() + start_node, 1, 1, st));
-    GM_HIP(hipMemcpyAsync(hctrl.p, ctrl.p, 32, hipMemcpyDeviceToHost, st));
+    GM_HIP(hipMemsetAsync(flags.p, 0, flags.bytes, st));
+    const uint32_t start_bit = 1u << (start_node & 31u);
+    GM_HIP(hipMemcpyAsync(flags.as<uint32_t>() + (start_node >> 5), &start_bit, 4, hipMemcpyHostToDevice, st));
+    GM_HIP(hipMemsetAsync(wmin.p, 0xFF, wmin.bytes, st));
+    GM_HIP(hipMemsetAsync(wmin.as<uint32_t>() + (start_node >> 5), 0, 4, st)); // the start node's distance: 0.0
+    GM_HIP(hipMemcpyAsync(hctrl.p, ctrl.p, 64, hipMemcpyDeviceToHost, st));
     GM_HIP(hipStreamSynchronize(st));
     GM_CHECK(hctrl.as<uint32_t>()[C_BAD] == 0, GM_ERR_UNSUPPORTED,
              "gm_sssp_delta_stepping: negative or NaN edge weight (the reference assumes weights >= 0)");
@@ -288,11 +406,15 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
     for (;;) {
         for (int k = 0; k < batch; ++k) {
             hipLaunchKernelGGL(sssp_round_kernel, dim3(grid), dim3(SSSP_BLOCK), 0, st, g->offsets, g->targets, g->weights,
-                               dist.as<uint32_t>(), flags.as<uint8_t>(), n_flags, n, ctrl.as<uint32_t>());
+                               dist.as<uint32_t>(), flags.as<uint32_t>(), wmin.as<uint32_t>(), nwords, chunks.as<uint2>(),
+                               ctrl.as<uint32_t>());
+            hipLaunchKernelGGL(sssp_chunk_kernel, dim3(grid), dim3(SSSP_BLOCK), 0, st, g->offsets, g->targets, g->weights,
+                               dist.as<uint32_t>(), flags.as<uint32_t>(), wmin.as<uint32_t>(), chunks.as<uint2>(),
+                               ctrl.as<uint32_t>());
             hipLaunchKernelGGL(sssp_advance_kernel, dim3(1), dim3(1), 0, st, ctrl.as<uint32_t>(), width);
         }
         GM_HIP(hipGetLastError());
-        GM_HIP(hipMemcpyAsync(hctrl.p, ctrl.p, 32, hipMemcpyDeviceToHost, st));
+        GM_HIP(hipMemcpyAsync(hctrl.p, ctrl.p, 64, hipMemcpyDeviceToHost, st));
         GM_HIP(hipStreamSynchronize(st));
         const uint32_t *hc = hctrl.as<uint32_t>();
         if (stats) { // batch = 1: wall clock between synchronisations is the round time
@@ -305,8 +427,9 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
             break;
     }
     if (stats)
-        fprintf(stderr, "sssp: %u rounds, %u threshold advances, width %.6f\n", hctrl.as<uint32_t>()[C_ROUND],
-                hctrl.as<uint32_t>()[C_ADVANCES], width);
+        fprintf(stderr, "sssp: %u rounds, %u threshold advances, width %.6f, ~%.1f M edge relaxations (%.2f x m)\n",
+                hctrl.as<uint32_t>()[C_ROUND], hctrl.as<uint32_t>()[C_ADVANCES], width,
+                hctrl.as<uint32_t>()[C_WORK] * 64.0 / 1e6, g->m ? hctrl.as<uint32_t>()[C_WORK] * 64.0 / (double)g->m : 0.0);
     GM_HIP(hipMemcpy(distances_out, dist.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return GM_OK;
 }
