@@ -74,16 +74,26 @@ __global__ void wcc_sample_kernel(const uint32_t *__restrict__ off, const uint32
     }
 }
 
+// Hub lists are not linked by the wavefront that met them (a 300k-entry list would be the kernel's
+// critical path: measured 6.6 ms of a 7 ms pass at scale 22) but cut into WCC_CHUNK-entry pieces for
+// wcc_chunk_kernel, which spreads them over the whole grid.  The order of unions never matters.
+constexpr uint32_t WCC_BIG = 2048, WCC_CHUNK = 1024;
+struct WccChunks {
+    uint4 *items = nullptr;   // {u, first entry, end of the list, 0 = out-list / 1 = in-list}
+    uint32_t *count = nullptr; // null: no deferral (hubs are linked in place)
+};
+
 // Link u with list[s..e): short lists by the owning lane, long lists by the whole wavefront.
 // Must be called by all 64 lanes of a wavefront (lanes without work pass s == e).
 __device__ __forceinline__ void wcc_link_list(const uint32_t *__restrict__ tgt, uint32_t *parent, uint32_t u,
-                                              uint32_t s, uint32_t e)
+                                              uint32_t s, uint32_t e, WccChunks chunks, uint32_t which)
 {
     const uint32_t len = e - s;
     if (len <= WCC_COOP)
         for (uint32_t i = s; i < e; ++i)
             af_link(parent, u, tgt[i]);
-    uint64_t big = __ballot(len > WCC_COOP);
+    const bool defer = chunks.count != nullptr && len > WCC_BIG;
+    uint64_t big = __ballot(len > WCC_COOP && !defer);
     const uint32_t lane = threadIdx.x & (kWave - 1);
     while (big) {
         const int src = __ffsll((unsigned long long)big) - 1;
@@ -92,6 +102,36 @@ __device__ __forceinline__ void wcc_link_list(const uint32_t *__restrict__ tgt, 
         for (uint32_t i = bs + lane; i < be; i += kWave)
             af_link(parent, bu, tgt[i]);
     }
+    uint64_t huge = __ballot(defer);
+    while (huge) {
+        const int src = __ffsll((unsigned long long)huge) - 1;
+        huge &= huge - 1;
+        const uint32_t hu = __shfl(u, src, kWave), hs = __shfl(s, src, kWave), he = __shfl(e, src, kWave);
+        const uint32_t nch = (he - hs + WCC_CHUNK - 1u) / WCC_CHUNK;
+        uint32_t first = 0;
+        if (lane == 0)
+            first = atomicAdd(chunks.count, nch);
+        first = __shfl(first, 0, kWave);
+        for (uint32_t c = lane; c < nch; c += kWave)
+            chunks.items[first + c] = make_uint4(hu, hs + c * WCC_CHUNK, he, which);
+    }
+}
+
+__global__ __launch_bounds__(WCC_BLOCK) void wcc_chunk_kernel(const uint32_t *__restrict__ out_tgt,
+                                                              const uint32_t *__restrict__ in_tgt, uint32_t *parent,
+                                                              const uint4 *__restrict__ items, const uint32_t *count)
+{
+    const uint32_t nchunks = *count;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t c = wave; c < nchunks; c += nwaves) {
+        const uint4 ch = items[c];
+        const uint32_t *tgt = ch.w ? in_tgt : out_tgt;
+        const uint32_t end = ch.y + WCC_CHUNK < ch.z ? ch.y + WCC_CHUNK : ch.z;
+        for (uint32_t i = ch.y + lane; i < end; i += kWave)
+            af_link(parent, ch.x, tgt[i]);
+    }
 }
 
 // wcc.rs:274-301 (skip = UINT32_MAX never matches a parent: link everything, used by wcc_baseline
@@ -99,7 +139,7 @@ __device__ __forceinline__ void wcc_link_list(const uint32_t *__restrict__ tgt, 
 __global__ __launch_bounds__(WCC_BLOCK) void wcc_link_remaining_kernel(
     const uint32_t *__restrict__ out_off, const uint32_t *__restrict__ out_tgt, const uint32_t *__restrict__ in_off,
     const uint32_t *__restrict__ in_tgt, uint32_t *parent, uint32_t n, uint64_t rounds, const uint32_t *skip_ptr,
-    uint32_t row_base = 0 /* node id of CSR row 0 (row slices of a partitioned graph) */)
+    uint32_t row_base /* node id of CSR row 0 (row slices of a partitioned graph) */, WccChunks chunks)
 {
     const uint32_t skip = skip_ptr ? *skip_ptr : 0xFFFFFFFFu;
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -113,14 +153,14 @@ __global__ __launch_bounds__(WCC_BLOCK) void wcc_link_remaining_kernel(
             e = out_off[r + 1];
             s = (uint64_t)(e - s) > rounds ? s + (uint32_t)rounds : e;
         }
-        wcc_link_list(out_tgt, parent, u, s, e);
+        wcc_link_list(out_tgt, parent, u, s, e, chunks, 0u);
         if (in_off) {
             s = e = 0;
             if (active) {
                 s = in_off[r];
                 e = in_off[r + 1];
             }
-            wcc_link_list(in_tgt, parent, u, s, e);
+            wcc_link_list(in_tgt, parent, u, s, e, chunks, 1u);
         }
     }
 }
@@ -172,18 +212,28 @@ int wcc_device(const gm_csr *out_csr, const gm_csr *in_csr, uint64_t rounds, uin
 {
     const uint32_t n = (uint32_t)out_csr->n;
     const unsigned grid = wcc_grid(n);
+    // deferred hub chunks: at most one per WCC_CHUNK entries plus one per hub list, out- and in-lists together
+    const uint64_t entries = out_csr->m + (in_csr ? in_csr->m : 0);
+    // one allocation: [chunk count | pad] [chunk items] [sample buffer + skip id]
+    const size_t items_bytes = (size_t)(entries / WCC_CHUNK + entries / WCC_BIG + 64) * sizeof(uint4);
+    gm::DevBuf buf;
+    GM_TRY(buf.alloc(16 + items_bytes + (size_t)(sampling + 1) * 4));
+    GM_HIP(hipMemsetAsync(buf.p, 0, 16, st));
+    const WccChunks chunks{reinterpret_cast<uint4 *>(buf.as<char>() + 16), buf.as<uint32_t>()};
+    uint32_t *sample_buf = reinterpret_cast<uint32_t *>(buf.as<char>() + 16 + items_bytes);
     hipLaunchKernelGGL(wcc_init_kernel, dim3(grid), dim3(WCC_BLOCK), 0, st, d_parent, n);
     if (!afforest) { // wcc.rs:103-122: union every out-edge
         hipLaunchKernelGGL(wcc_link_remaining_kernel, dim3(grid), dim3(WCC_BLOCK), 0, st, out_csr->offsets,
                            out_csr->targets, (const uint32_t *)nullptr, (const uint32_t *)nullptr, d_parent, n,
-                           (uint64_t)0, (const uint32_t *)nullptr);
+                           (uint64_t)0, (const uint32_t *)nullptr, 0u, chunks);
+        hipLaunchKernelGGL(wcc_chunk_kernel, dim3(grid), dim3(WCC_BLOCK), 0, st, out_csr->targets,
+                           (const uint32_t *)nullptr, d_parent, chunks.items, chunks.count);
         hipLaunchKernelGGL(wcc_compress_kernel, dim3(grid), dim3(WCC_BLOCK), 0, st, d_parent, n);
         GM_HIP(hipGetLastError());
+        GM_HIP(hipStreamSynchronize(st)); // the work buffer is freed on return
         return GM_OK;
     }
-    gm::DevBuf scratch;
-    GM_TRY(scratch.alloc((sampling + 1) * 4));
-    uint32_t *d_skip = scratch.as<uint32_t>() + sampling;
+    uint32_t *d_skip = sample_buf + sampling;
     gm::PhaseTimer timer(st); // phase names as logged by the reference, wcc.rs:164-182
     hipLaunchKernelGGL(wcc_sample_kernel, dim3(grid), dim3(WCC_BLOCK), 0, st, out_csr->offsets, out_csr->targets,
                        d_parent, n, rounds);
@@ -191,16 +241,18 @@ int wcc_device(const gm_csr *out_csr, const gm_csr *in_csr, uint64_t rounds, uin
     hipLaunchKernelGGL(wcc_compress_kernel, dim3(grid), dim3(WCC_BLOCK), 0, st, d_parent, n);
     timer.done("Sample compress");
     hipLaunchKernelGGL(wcc_sample_mode_kernel, dim3(1), dim3(WCC_BLOCK), 0, st, d_parent, n, (uint32_t)sampling,
-                       (uint64_t)0x2545F4914F6CDD1Dull, scratch.as<uint32_t>(), d_skip);
+                       (uint64_t)0x2545F4914F6CDD1Dull, sample_buf, d_skip);
     timer.done("Get component");
     hipLaunchKernelGGL(wcc_link_remaining_kernel, dim3(grid), dim3(WCC_BLOCK), 0, st, out_csr->offsets,
                        out_csr->targets, in_csr->offsets, in_csr->targets, d_parent, n, rounds,
-                       (const uint32_t *)d_skip);
+                       (const uint32_t *)d_skip, 0u, chunks);
+    hipLaunchKernelGGL(wcc_chunk_kernel, dim3(grid), dim3(WCC_BLOCK), 0, st, out_csr->targets, in_csr->targets, d_parent,
+                       chunks.items, chunks.count);
     timer.done("Link remaining");
     hipLaunchKernelGGL(wcc_compress_kernel, dim3(grid), dim3(WCC_BLOCK), 0, st, d_parent, n);
     timer.done("Final compress");
     GM_HIP(hipGetLastError());
-    GM_HIP(hipStreamSynchronize(st)); // scratch is freed on return
+    GM_HIP(hipStreamSynchronize(st)); // the work buffer is freed on return
     return GM_OK;
 }
 } // namespace gm
@@ -276,7 +328,7 @@ GM_API int gm_wcc_link_rows(const gm_csr *out_rows, const gm_csr *in_rows, uint6
         hipLaunchKernelGGL(wcc_link_remaining_kernel, dim3(wcc_grid(out_rows->n)), dim3(WCC_BLOCK), 0, st,
                            out_rows->offsets, out_rows->targets, in_rows ? in_rows->offsets : (const uint32_t *)nullptr,
                            in_rows ? in_rows->targets : (const uint32_t *)nullptr, parent, (uint32_t)out_rows->n,
-                           (uint64_t)0, (const uint32_t *)nullptr, (uint32_t)row_begin);
+                           (uint64_t)0, (const uint32_t *)nullptr, (uint32_t)row_begin, WccChunks{});
     hipLaunchKernelGGL(wcc_compress_kernel, dim3(wcc_grid(n_global)), dim3(WCC_BLOCK), 0, st, parent, (uint32_t)n_global);
     GM_HIP(hipGetLastError());
     return GM_OK;
