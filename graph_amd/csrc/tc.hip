@@ -10,7 +10,7 @@
 // self-loops kept: 227874 on the reference's scale_8 fixture after relabelling) and
 // Deduplicated layouts alike.
 //
-// Kernels: tc_low_len (per node: |L(u)| by binary search, sortedness / strictness check),
+// Kernels: tc_low_len (per node: |L(u)| by binary search), tc_order (per entry: sortedness / strictness check),
 // tc_dag_src (row id of every DAG entry, filled per node with wavefront help for long lists),
 // tc_count (one lane per DAG entry: walk one prefix, binary-search the other; on strictly
 // increasing lists the shorter prefix is walked).  Integer work, HBM/latency bound: no MFMA.
@@ -28,52 +28,48 @@ using namespace gm;
 constexpr int TC_BLOCK = 256;
 constexpr int TC_WAVES = TC_BLOCK / kWave;
 
-// flags[0] |= 1 if some list is not sorted ascending, |= 2 if some list has equal neighbours.
-// One lane per node; the order check of lists longer than 32 entries is spread over the wavefront.
+// Per node: |L(u)| by binary search, and a mark on the first entry of its list (row_start bitmap) so
+// that the order check below can run one lane per ENTRY: checking a 600k-entry hub list with the one
+// wavefront that owns the node was 24 ms of critical path at scale 24.
 __global__ __launch_bounds__(TC_BLOCK) void tc_low_len_kernel(const uint32_t *__restrict__ off,
                                                               const uint32_t *__restrict__ tgt, uint32_t n,
                                                               uint32_t *__restrict__ low_len /* n+1 */,
-                                                              uint32_t *__restrict__ flags)
+                                                              uint32_t *__restrict__ row_start /* bit per entry */)
 {
-    const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t n_pad = (n + 1 + kWave - 1) / kWave * kWave;
-    uint32_t f = 0;
-    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n_pad; u += stride) {
-        uint32_t s = 0, e = 0;
-        if (u < n) {
-            s = off[u];
-            e = off[u + 1];
-            uint32_t lo = s, hi = e; // first position with tgt > u
-            while (lo < hi) {
-                const uint32_t mid = lo + ((hi - lo) >> 1);
-                if (tgt[mid] <= u)
-                    lo = mid + 1;
-                else
-                    hi = mid;
-            }
-            low_len[u] = lo - s;
-        } else if (u == n) {
+    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u <= n; u += stride) {
+        if (u == n) {
             low_len[u] = 0;
+            continue;
         }
-        const uint32_t len = e - s;
-        if (len <= 32)
-            for (uint32_t i = s + 1; i < e; ++i) {
-                const uint32_t a = tgt[i - 1], b = tgt[i];
-                f |= (a > b) ? 1u : 0u;
-                f |= (a == b) ? 2u : 0u;
-            }
-        uint64_t big = __ballot(len > 32);
-        while (big) {
-            const int src = __ffsll((unsigned long long)big) - 1;
-            big &= big - 1;
-            const uint32_t bs = __shfl(s, src, kWave), be = __shfl(e, src, kWave);
-            for (uint32_t i = bs + 1 + lane; i < be; i += kWave) {
-                const uint32_t a = tgt[i - 1], b = tgt[i];
-                f |= (a > b) ? 1u : 0u;
-                f |= (a == b) ? 2u : 0u;
-            }
+        const uint32_t s = off[u], e = off[u + 1];
+        uint32_t lo = s, hi = e; // first position with tgt > u
+        while (lo < hi) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (tgt[mid] <= u)
+                lo = mid + 1;
+            else
+                hi = mid;
         }
+        low_len[u] = lo - s;
+        if (e > s)
+            atomicOr(&row_start[s >> 5], 1u << (s & 31u));
+    }
+}
+
+// flags[0] |= 1 if some list is not sorted ascending, |= 2 if some list has equal neighbours.
+__global__ __launch_bounds__(TC_BLOCK) void tc_order_kernel(const uint32_t *__restrict__ tgt, uint64_t m,
+                                                            const uint32_t *__restrict__ row_start,
+                                                            uint32_t *__restrict__ flags)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint32_t f = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + 1; i < m; i += stride) {
+        if ((row_start[i >> 5] >> (i & 31u)) & 1u)
+            continue; // tgt[i - 1] belongs to the previous list
+        const uint32_t a = tgt[i - 1], b = tgt[i];
+        f |= (a > b) ? 1u : 0u;
+        f |= (a == b) ? 2u : 0u;
     }
     if (f)
         atomicOr(flags, f);
@@ -235,9 +231,20 @@ GM_API int gm_triangle_count(const gm_csr *g, uint64_t *triangles_out)
     unsigned grid = gm::div_up((uint64_t)n + 1, TC_BLOCK);
     if (grid > 256 * 8)
         grid = 256 * 8;
-    hipLaunchKernelGGL(tc_low_len_kernel, dim3(grid), dim3(TC_BLOCK), 0, 0, g->offsets, g->targets, n,
-                       low_len.as<uint32_t>(), ctrl.as<uint32_t>() + 2);
-    GM_HIP(hipGetLastError());
+    {
+        gm::DevBuf row_start;
+        GM_TRY(row_start.alloc(((size_t)g->m / 32 + 1) * 4));
+        GM_HIP(hipMemset(row_start.p, 0, row_start.bytes));
+        hipLaunchKernelGGL(tc_low_len_kernel, dim3(grid), dim3(TC_BLOCK), 0, 0, g->offsets, g->targets, n,
+                           low_len.as<uint32_t>(), row_start.as<uint32_t>());
+        unsigned egrid = gm::div_up(g->m, TC_BLOCK);
+        if (egrid > 256 * 32)
+            egrid = 256 * 32;
+        hipLaunchKernelGGL(tc_order_kernel, dim3(egrid), dim3(TC_BLOCK), 0, 0, g->targets, g->m, row_start.as<uint32_t>(),
+                           ctrl.as<uint32_t>() + 2);
+        GM_HIP(hipGetLastError());
+        GM_HIP(hipDeviceSynchronize()); // row_start is released on scope exit
+    }
     {
         size_t tmp_bytes = 0;
         GM_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, low_len.as<uint32_t>(), loff.as<uint32_t>(), 0u,
