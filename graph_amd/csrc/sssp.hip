@@ -13,10 +13,8 @@
 //     role of the reference's min_non_empty_bin (sssp.rs:159-168).  No fences: "distance improved,
 //     then flag set" and "flag cleared, then distance read" are each ordered by the returned value of
 //     the first atomic, so an improvement is never lost;  The threshold advances to (minimum pending distance + width) when a round
-//     leaves nothing below it; width = delta * GM_SSSP_WIDTH (default 1): `delta` only shapes the
-//     schedule, never the result (measured at RMAT scale 24, delta 0.1: widths from delta/16 to pure
-//     Bellman-Ford all take 74-98 ms — the small-world graph needs ~7 near-full passes over the edges
-//     whatever the order, and finer steps only add rounds);
+//     leaves nothing below it; `delta` only seeds the schedule (first step delta/32, then adapted to
+//     the work of each phase, see gm_sssp_delta_stepping) and never changes the result;
 //   * the bucket bookkeeping lives on the device (sssp_advance_kernel): the host enqueues rounds in
 //     batches and reads one flag per batch instead of synchronising after every round;
 //   * INF = f32::MAX (sssp.rs:12), never +inf.
@@ -86,7 +84,8 @@ __device__ __forceinline__ void relax_range(const uint32_t *__restrict__ tgt, co
 
 // ctrl words shared by the round and advance kernels
 enum : uint32_t { C_AGAIN = 0, C_FAR = 1, C_BAD = 2, C_THR = 3, C_DONE = 4, C_ROUND = 5, C_ADVANCES = 6,
-                  C_WORK = 7 /* relaxed edges / 64, statistics */, C_CHUNKS = 8 /* deferred edge chunks of this round */ };
+                  C_WORK = 7 /* relaxed edges / 64, statistics */, C_CHUNKS = 8 /* deferred edge chunks of this round */,
+                  C_WIDTH = 9 /* f32 bits: current threshold step */, C_MARK = 10 /* C_WORK at the last advance */ };
 
 // One round.  wmin[i] is a lower bound of the distances of the flagged nodes of flag word i (32 nodes):
 // whoever flags a node lowers it, the scanner resets it and puts back what it leaves flagged.  A
@@ -262,7 +261,10 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_chunk_kernel(const uint32_t *
 
 // Between two rounds (one thread): nothing left below the threshold -> move it to the minimum pending
 // distance + width, or finish; then clear the round's outputs.
-__global__ void sssp_advance_kernel(uint32_t *ctrl, float width)
+// adapt_lo / adapt_hi (units of 64 relaxed edges; 0 = fixed width): the step halves when the phase that
+// just ended relaxed more than adapt_hi and doubles when it relaxed less than adapt_lo, within
+// [width_min, width_max] — coarse steps re-relax every edge ~6 times, fine steps leave the chip idle.
+__global__ void sssp_advance_kernel(uint32_t *ctrl, uint32_t adapt_lo, uint32_t adapt_hi, float width_min, float width_max)
 {
     if (ctrl[C_DONE])
         return;
@@ -270,6 +272,16 @@ __global__ void sssp_advance_kernel(uint32_t *ctrl, float width)
         if (ctrl[C_FAR] == NO_BUCKET) {
             ctrl[C_DONE] = 1u;
         } else {
+            float width = __uint_as_float(ctrl[C_WIDTH]);
+            if (adapt_hi) {
+                const uint32_t phase = ctrl[C_WORK] - ctrl[C_MARK];
+                if (phase > adapt_hi)
+                    width = fmaxf(width * 0.5f, width_min);
+                else if (phase < adapt_lo)
+                    width = fminf(width * 2.0f, width_max);
+                ctrl[C_WIDTH] = __float_as_uint(width);
+                ctrl[C_MARK] = ctrl[C_WORK];
+            }
             const float next = __fadd_rn(__uint_as_float(ctrl[C_FAR]), width);
             const uint32_t nb = __float_as_uint(next);
             ctrl[C_THR] = nb > ctrl[C_FAR] && next < 3.0e38f ? nb : ctrl[C_FAR]; // always covers the pending minimum
@@ -373,15 +385,29 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
     unsigned grid = gm::div_up(n, SSSP_BLOCK);
     if (grid > 256 * 8)
         grid = 256 * 8;
-    float frac = 1.0f;
+    // Threshold step: starts at delta/32 and adapts to the work of each phase (sssp_advance_kernel): it doubles
+    // while a phase relaxes fewer than m/5 edges and halves beyond 3m/4.  Measured at RMAT scale 24, delta 0.1:
+    // 2.0 x m relaxations in ~60 rounds, 32 ms; a fixed step of delta: 6.4 x m, 53 ms; fixed delta/16: 2.2 x m but
+    // 500 rounds, 101 ms.  GM_SSSP_WIDTH=<fraction of delta> sets the first step, GM_SSSP_ADAPT="lo,hi" the band
+    // in millions of edges ("0,0": fixed step).
+    float frac = 1.0f / 32.0f;
     if (const char *v = getenv("GM_SSSP_WIDTH"))
         frac = (float)atof(v);
     if (!(frac > 0.0f))
-        frac = 1.0f;
+        frac = 1.0f / 32.0f;
     const float width = delta * frac;
+    uint32_t adapt_lo = (uint32_t)(g->m / 5 / 64), adapt_hi = (uint32_t)(g->m / 4 * 3 / 64) + 1u;
+    if (const char *v = getenv("GM_SSSP_ADAPT")) {
+        double lo = 0, hi = 0;
+        if (sscanf(v, "%lf,%lf", &lo, &hi) == 2 && lo >= 0) {
+            adapt_lo = hi > lo ? (uint32_t)(lo * 1e6 / 64.0) : 0u;
+            adapt_hi = hi > lo ? (uint32_t)(hi * 1e6 / 64.0) : 0u;
+        }
+    }
 
     // ctrl: again 0, far NONE, bad 0, threshold 0.0 (only the start node qualifies), done 0, round 0, advances 0
-    const uint32_t init_ctrl[16] = {0u, NO_BUCKET, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    uint32_t init_ctrl[16] = {0u, NO_BUCKET, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    memcpy(&init_ctrl[C_WIDTH], &width, 4);
     GM_HIP(hipMemcpyAsync(ctrl.p, init_ctrl, 64, hipMemcpyHostToDevice, st));
     if (g->m) {
         unsigned wg = gm::div_up(g->m, 256);
@@ -411,7 +437,8 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
             hipLaunchKernelGGL(sssp_chunk_kernel, dim3(grid), dim3(SSSP_BLOCK), 0, st, g->offsets, g->targets, g->weights,
                                dist.as<uint32_t>(), flags.as<uint32_t>(), wmin.as<uint32_t>(), chunks.as<uint2>(),
                                ctrl.as<uint32_t>());
-            hipLaunchKernelGGL(sssp_advance_kernel, dim3(1), dim3(1), 0, st, ctrl.as<uint32_t>(), width);
+            hipLaunchKernelGGL(sssp_advance_kernel, dim3(1), dim3(1), 0, st, ctrl.as<uint32_t>(), adapt_lo, adapt_hi,
+                               delta / 1024.0f, delta * 16.0f);
         }
         GM_HIP(hipGetLastError());
         GM_HIP(hipMemcpyAsync(hctrl.p, ctrl.p, 64, hipMemcpyDeviceToHost, st));
@@ -427,8 +454,9 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
             break;
     }
     if (stats)
-        fprintf(stderr, "sssp: %u rounds, %u threshold advances, width %.6f, ~%.1f M edge relaxations (%.2f x m)\n",
+        fprintf(stderr, "sssp: %u rounds, %u threshold advances, width %.6f (last %.6f), ~%.1f M edge relaxations (%.2f x m)\n",
                 hctrl.as<uint32_t>()[C_ROUND], hctrl.as<uint32_t>()[C_ADVANCES], width,
+                __builtin_bit_cast(float, hctrl.as<uint32_t>()[C_WIDTH]),
                 hctrl.as<uint32_t>()[C_WORK] * 64.0 / 1e6, g->m ? hctrl.as<uint32_t>()[C_WORK] * 64.0 / (double)g->m : 0.0);
     GM_HIP(hipMemcpy(distances_out, dist.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return GM_OK;
