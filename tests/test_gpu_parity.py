@@ -348,6 +348,27 @@ def test_sssp_bit_exact_vs_oracle(P, oracle, scale, delta):
     assert (got == F32_MAX).any() and not np.isinf(got).any()
 
 
+@pytest.mark.parametrize("width,adapt", [("1", "0,0"), ("0.03125", "0,0"), ("1000", "0,0"), ("0.001", "0.001,0.01"),
+                                         ("0.25", "1,4")])
+def test_sssp_result_does_not_depend_on_the_schedule(P, oracle, monkeypatch, width, adapt):
+    """The reference's result is the least fixed point (sssp.rs: any relaxation order converges to it), so
+    every threshold schedule of the device path — fixed steps from delta/1000 to pure Bellman-Ford, adaptive
+    bands — must give the oracle's bits.  Includes hub lists long enough for the chunk kernel."""
+    scale = 16
+    s, d = oracle.rmat_edges(scale, seed=7)
+    w = oracle.rmat_weights(s.size, seed=8)
+    n = 1 << scale
+    g = _directed(P, n, s, d, P.CsrLayout.Sorted, w)
+    off, tgt, wv = oracle.csr_build(n, s, d, oracle.OUTGOING, oracle.SORTED, w)
+    assert int(np.diff(off).max()) > 2048  # a hub beyond SSSP_BIG
+    start = int(np.flatnonzero(np.diff(off) > 0)[0])
+    ref = oracle.delta_stepping(off, tgt, wv, start, 0.1)
+    monkeypatch.setenv("GM_SSSP_WIDTH", width)
+    monkeypatch.setenv("GM_SSSP_ADAPT", adapt)
+    got = P.delta_stepping(g, P.DeltaSteppingConfig(start, 0.1))
+    assert np.array_equal(got, ref)
+
+
 # ------------------------------------------------------------------------------------------------
 # triangle count
 # ------------------------------------------------------------------------------------------------
