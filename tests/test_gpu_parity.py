@@ -348,6 +348,26 @@ def test_sssp_bit_exact_vs_oracle(P, oracle, scale, delta):
     assert (got == F32_MAX).any() and not np.isinf(got).any()
 
 
+def test_sssp_zero_weights_self_loops_and_duplicates(P, oracle):
+    """Edge cases of the relaxation: zero-weight edges (a node can improve inside the current threshold),
+    self-loops, parallel edges with different weights, isolated and unreachable nodes, every start node."""
+    rng = np.random.default_rng(5)
+    n, m = 300, 1500
+    s = rng.integers(0, n - 20, m).astype(np.uint32)   # the last 20 nodes have no out-edges
+    d = rng.integers(0, n - 10, m).astype(np.uint32)   # the last 10 nodes are unreachable
+    w = rng.choice(np.array([0.0, 0.0, 0.25, 0.5, 1.0, 3.5], np.float32), m)
+    s[:40] = d[:40]                                      # self-loops
+    s[40:80], d[40:80] = s[80:120], d[80:120]            # parallel edges, other weights
+    g = _directed(P, n, s, d, P.CsrLayout.Sorted, w)
+    off, tgt, wv = oracle.csr_build(n, s, d, oracle.OUTGOING, oracle.SORTED, w)
+    for start in (0, 7, int(s[0]), n - 1):
+        for delta in (0.1, 3.0):
+            ref = oracle.delta_stepping(off, tgt, wv, start, delta)
+            got = P.delta_stepping(g, P.DeltaSteppingConfig(start, delta))
+            assert np.array_equal(got, ref)
+            assert got[start] == 0.0 and (got[n - 10:] == F32_MAX).sum() >= (9 if start >= n - 10 else 10)
+
+
 @pytest.mark.parametrize("width,adapt", [("1", "0,0"), ("0.03125", "0,0"), ("1000", "0,0"), ("0.001", "0.001,0.01"),
                                          ("0.25", "1,4")])
 def test_sssp_result_does_not_depend_on_the_schedule(P, oracle, monkeypatch, width, adapt):
