@@ -969,3 +969,18 @@ def test_page_rank_out_degree_sources_agree(P, oracle):
         it, err = C.c_uint64(0), C.c_double(0.0)
         check(lib().gm_page_rank_directed(other.csr_out.handle, g.csr_inc.handle, 3, 0.0, 0.85, 0, scores.ctypes.data_as(vp),
                                           C.byref(it), C.byref(err)))
+
+
+def test_page_rank_pb_source_tile_sizes_agree(P, oracle, monkeypatch):
+    """The 32768-source tile (automatic only beyond 2^26 sources) against the 16384-source tile on the same
+    graph: exact row sums make the two layouts produce identical bits."""
+    scale = 18
+    n = 1 << scale
+    s, d = oracle.rmat_edges(scale, seed=19)
+    res = []
+    for slog in ("14", "15"):
+        monkeypatch.setenv("GM_PB_SLOG", slog)
+        g = _directed(P, n, s, d, P.CsrLayout.Sorted)  # a fresh handle: the plan is cached per graph
+        res.append(P.page_rank(g, P.PageRankConfig(6, 0.0, 0.85), P.PageRankMode.JacobiPB))
+    assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1] == 6
+    assert abs(res[0][2] - res[1][2]) <= 1e-12 * res[0][2]
