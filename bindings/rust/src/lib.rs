@@ -72,7 +72,6 @@ impl DeviceCsr {
 pub struct DeviceDirected {
     pub out: DeviceCsr,
     pub inc: DeviceCsr,
-    pub out_degree: Vec<u32>,
     pub node_count: u32,
 }
 
@@ -81,8 +80,7 @@ impl DeviceDirected {
         let n = g.node_count();
         let out = DeviceCsr::upload(n, |u| g.out_degree(u), g.out_neighbors(0).as_slice().as_ptr());
         let inc = DeviceCsr::upload(n, |u| g.in_degree(u), g.in_neighbors(0).as_slice().as_ptr());
-        let out_degree = (0..n).map(|u| g.out_degree(u)).collect();
-        Self { out, inc, out_degree, node_count: n }
+        Self { out, inc, node_count: n }
     }
 }
 
