@@ -51,11 +51,15 @@ def parse_args():
     ap.add_argument("--single-device", type=int, default=0, help="debug: all ranks use cuda:0 (needs --backend gloo)")
     ap.add_argument("--exchange-parts", type=int, default=0,
                     help="N > 1: regions of the out_scores exchange that overlap with the work (1 = one blocking all-gather "
-                         "per sweep; 0 = automatic: 2 up to 4 ranks, 1 beyond, where the per-rank kernels (~0.35 ms at scale "
-                         "26) are too short to pay for being launched in pieces)")
+                         "per sweep; 0 = automatic: 2)")
     ap.add_argument("--bin-pieces", type=int, default=-1,
                     help="overlapped exchange: 1 = propagate every region as it lands, 0 = one propagation launch per sweep "
                          "(only the accumulate is cut; measured no cheaper: P = 8 kernels 0.41 -> 0.48 / 0.46-0.49 ms), -1 = 1")
+    ap.add_argument("--piece-streams", type=int, default=-1,
+                    help="overlapped exchange: 1 = one HIP stream per part (the pieces of a phase overlap each other's tails: "
+                         "cutting the sweep in two costs +0.04 ms of kernels at P = 8 instead of +0.11; at P = 2 the long "
+                         "kernels only get in each other's way: 1.31 / 1.38 / 1.57 ms for one launch / pieces / pieces on "
+                         "streams), 0 = one stream, -1 = automatic: from 4 ranks up")
     ap.add_argument("--emulate-parts", type=int, default=0, help="debug (1 process): time only the row slice that "
                     "rank --emulate-rank of an N-way partition would own, without the exchange")
     ap.add_argument("--emulate-rank", type=int, default=0)
@@ -120,9 +124,11 @@ def main():
     if emu:
         world, rank = emu, args.emulate_rank  # pretend; no process group exists
     if args.exchange_parts == 0:
-        args.exchange_parts = 2 if world <= 4 else 1
+        args.exchange_parts = 2
     if args.bin_pieces < 0:
         args.bin_pieces = 1
+    if args.piece_streams < 0:
+        args.piece_streams = 1 if world >= 4 else 0
     piecewise = world > 1 and args.exchange_parts > 1 and args.engine != "pull"
     ex = None
     if world == 1:
@@ -168,7 +174,8 @@ def main():
             def gather(dst_region, src, k):
                 st = layout["strides"][k]
                 dst_region[rank * st:(rank + 1) * st] = src
-        ex = PiecewiseExchange(engine, layout, rank, n_local, dev, gather=gather, split_bin=bool(args.bin_pieces))
+        ex = PiecewiseExchange(engine, layout, rank, n_local, dev, gather=gather, split_bin=bool(args.bin_pieces),
+                               streams=bool(args.piece_streams))
         ex.start(scores)
     else:
         x = [torch.zeros(x_len, dtype=torch.float32, device=dev) for _ in range(2)]
@@ -293,6 +300,9 @@ def main():
             "edges_per_launch": m_local, "rows_per_launch": n_local,
         },
     }
+    if piecewise and args.piece_streams:
+        result["roofline"]["note"] = ("avg_launch_ms spans the rank's whole sweep (its pieces overlap on several streams), "
+                                      "waits for regions of out_scores still in flight included")
 
     # ---- CPU baseline on rank 0 at N = 1 (bounded sample: a few sweeps of the same graph) -----
     if world == 1 and args.cpu_sweeps > 0:

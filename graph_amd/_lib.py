@@ -58,7 +58,8 @@ SIGNATURES = {
     "gm_pr_part_geometry": (i32, [vp, vp, vp]),
     "gm_pr_set_parts": (i32, [vp, vp, u64]),
     "gm_pr_sweep_bin": (i32, [vp, u64, u64, u64, vp]),
-    "gm_pr_sweep_accum": (i32, [vp, u64, u64, u64, u64, vp]),
+    "gm_pr_sweep_hot": (i32, [vp, u64, vp]),
+    "gm_pr_sweep_accum": (i32, [vp, u64, u64, u64, u64, i32, vp]),
     "gm_wcc_afforest": (i32, [vp, vp, u64, u64, vp]),
     "gm_wcc_baseline": (i32, [vp, vp]),
     "gm_wcc_init_labels": (i32, [u64, u64, i32, vp]),

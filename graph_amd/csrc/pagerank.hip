@@ -558,8 +558,16 @@ GM_API int gm_pr_sweep_bin(gm_pr *pr, uint64_t d_x_in_global, uint64_t x_lo, uin
                                   (hipStream_t)stream);
 }
 
+GM_API int gm_pr_sweep_hot(gm_pr *pr, uint64_t d_x_in_global, void *stream)
+{
+    GM_CHECK(pr && d_x_in_global, GM_ERR_INVALID, "gm_pr_sweep_hot: null argument");
+    GM_CHECK(pr->engine == GM_PR_ENGINE_PB, GM_ERR_UNSUPPORTED, "gm_pr_sweep_hot: not a propagation-blocking engine");
+    gm::DeviceGuard guard(pr->csr->device);
+    return gm::pb_sweep_hot(pr->pb, pr->pb_scratch, reinterpret_cast<const float *>(d_x_in_global), (hipStream_t)stream);
+}
+
 GM_API int gm_pr_sweep_accum(gm_pr *pr, uint64_t d_x_in_global, uint64_t d_x_out_local, uint64_t d_scores_local,
-                             uint64_t part, void *stream)
+                             uint64_t part, int stage_hot, void *stream)
 {
     GM_CHECK(pr && d_x_in_global, GM_ERR_INVALID, "gm_pr_sweep_accum: null argument");
     GM_CHECK(pr->engine == GM_PR_ENGINE_PB, GM_ERR_UNSUPPORTED, "gm_pr_sweep_accum: not a propagation-blocking engine");
@@ -567,7 +575,7 @@ GM_API int gm_pr_sweep_accum(gm_pr *pr, uint64_t d_x_in_global, uint64_t d_x_out
     gm::DeviceGuard guard(pr->csr->device);
     return gm::pb_sweep_accum_part(pr->pb, pr->pb_scratch, reinterpret_cast<const float *>(d_x_in_global),
                                    reinterpret_cast<float *>(d_x_out_local), reinterpret_cast<float *>(d_scores_local),
-                                   pr->outdeg, pr->base, pr->damping, (uint32_t)part, (hipStream_t)stream);
+                                   pr->outdeg, pr->base, pr->damping, (uint32_t)part, stage_hot, (hipStream_t)stream);
 }
 
 GM_API int gm_pr_sweep(gm_pr *pr, uint64_t d_x_in_global, uint64_t d_x_out_local, uint64_t d_scores_local,

@@ -1483,15 +1483,23 @@ int pb_sweep_bin_range(const PbPlan *pl, PbScratch *sc, const float *x_in, uint6
     return GM_OK;
 }
 
-// accumulates and finishes the rows of part `part`; part 0 also stages the hot sources' values, so the
-// parts run in ascending order, after every tile of x has been propagated
+// stages the hot sources' values of x_in for the accumulate launches of this sweep (needs the whole vector)
+int pb_sweep_hot(const PbPlan *pl, PbScratch *sc, const float *x_in, hipStream_t st)
+{
+    pb_hot_dispatch(pl, sc, x_in, st);
+    GM_HIP(hipGetLastError());
+    return GM_OK;
+}
+
+// accumulates and finishes the rows of part `part`, after every tile of x has been propagated and the hot
+// sources staged (stage_hot != 0: stage them here first — the simple in-order schedule does that on part 0)
 int pb_sweep_accum_part(const PbPlan *pl, PbScratch *sc, const float *x_in, float *x_out, float *scores,
-                        const uint32_t *outdeg, float base, float damping, uint32_t part, hipStream_t st)
+                        const uint32_t *outdeg, float base, float damping, uint32_t part, int stage_hot, hipStream_t st)
 {
     GM_CHECK(sc->part_off.size() >= 2 && part + 1 < sc->part_off.size(), GM_ERR_INVALID,
              "gm_pr_sweep_accum: part %u of %zu (call gm_pr_set_parts first)", part,
              sc->part_off.empty() ? (size_t)0 : sc->part_off.size() - 1);
-    if (part == 0)
+    if (stage_hot)
         pb_hot_dispatch(pl, sc, x_in, st);
     const uint32_t i0 = sc->part_off[part], i1 = sc->part_off[part + 1];
     pb_accum_dispatch(pl, sc, sc->part_items.as<PbItem>() + i0, i1 - i0, x_out, scores, outdeg, base, damping, st);

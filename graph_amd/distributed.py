@@ -132,11 +132,15 @@ class PiecewiseExchange:
     the propagation of regions < k of the next sweep.  engine: sweep_bin / sweep_accum / sweep_fixup /
     set_parts (graph_amd.engine.PageRankEngine, or a stand-in with the same methods)."""
 
-    def __init__(self, engine, layout, rank: int, n_local: int, device, group=None, gather=None, split_bin=True):
+    def __init__(self, engine, layout, rank: int, n_local: int, device, group=None, gather=None, split_bin=True,
+                 streams=False):
         # split_bin=False: one propagation launch after every region has landed (only the accumulate is cut into
         # row groups) — region k still travels under the accumulate of the later groups, and the short kernels
         # of a many-rank run are not cut in four
         self.split_bin = split_bin
+        # streams=True: part k runs on its own HIP stream (events order them), so that the pieces of one phase
+        # overlap each other's tails instead of running back to back — what cutting a short kernel in two costs
+        self.streams = None
         self.engine, self.layout, self.rank, self.group = engine, layout, rank, group
         world = len(layout["row_splits"])
         self.parts = layout["parts"]
@@ -151,6 +155,9 @@ class PiecewiseExchange:
         # gather(dst_region, src, k): stand-in for the collective (single-process emulation); default RCCL/gloo
         self._gather = gather
         engine.set_parts(layout["row_splits"][rank])
+        if streams and self.parts > 1 and torch.cuda.is_available():
+            self.streams = [None] + [torch.cuda.Stream(device=device) for _ in range(self.parts - 1)]
+            self._ev_acc = None
 
     def _start_gather(self, buf: int, k: int):
         rows = self.send_rows[k]
@@ -172,6 +179,8 @@ class PiecewiseExchange:
     def sweep(self, scores: torch.Tensor, err: torch.Tensor, events=None):
         """events: optional list receiving a (start, end) torch.cuda.Event pair around every kernel piece
         (bench.py: kernel time without the waits for the collectives)"""
+        if self.streams is not None:
+            return self._sweep_streams(scores, err, events)
         e, x_in = self.engine, self.x[self.cur]
 
         def timed(fn, *a):
@@ -194,6 +203,55 @@ class PiecewiseExchange:
         for k in range(self.parts):
             timed(e.sweep_accum, x_in, self.x_loc, scores, k)
             self._start_gather(1 - self.cur, k)
+        e.sweep_fixup(self.x_loc, scores, err)
+        self.cur = 1 - self.cur
+
+    def _sweep_streams(self, scores: torch.Tensor, err: torch.Tensor, events=None):
+        """the same sweep with part k on stream k (stream 0 = the caller's current stream); events receives one
+        (start, end) pair around the whole sweep — with overlapping pieces that span, waits for regions still in
+        flight included, is the only well-defined time"""
+        e, x_in = self.engine, self.x[self.cur]
+        main = torch.cuda.current_stream()
+        strs = [main] + self.streams[1:]
+        start = torch.cuda.Event(enable_timing=events is not None)
+        start.record(main)  # everything the caller enqueued so far (the previous sweep's fixup included)
+        ev_bin = []
+        for k, st in enumerate(strs):
+            with torch.cuda.stream(st):
+                st.wait_event(start)
+                if self._ev_acc is not None:  # the value stream is rewritten: every accumulate of the last sweep is done
+                    for ev in self._ev_acc:
+                        st.wait_event(ev)
+                if self.works[k] is not None:
+                    self.works[k].wait()
+                lo, hi = self.regions[k]
+                e.sweep_bin(x_in, lo, hi)
+                ev = torch.cuda.Event()
+                ev.record(st)
+                ev_bin.append(ev)
+        for ev in ev_bin:
+            main.wait_event(ev)
+        e.sweep_hot(x_in)
+        ev_hot = torch.cuda.Event()
+        ev_hot.record(main)
+        ev_acc = []
+        for k, st in enumerate(strs):
+            with torch.cuda.stream(st):
+                for ev in ev_bin:
+                    st.wait_event(ev)
+                st.wait_event(ev_hot)
+                e.sweep_accum(x_in, self.x_loc, scores, k, stage_hot=False)
+                self._start_gather(1 - self.cur, k)
+                ev = torch.cuda.Event()
+                ev.record(st)
+                ev_acc.append(ev)
+        for ev in ev_acc:
+            main.wait_event(ev)
+        self._ev_acc = ev_acc
+        if events is not None:
+            end = torch.cuda.Event(enable_timing=True)
+            end.record(main)
+            events.append((start, end))
         e.sweep_fixup(self.x_loc, scores, err)
         self.cur = 1 - self.cur
 

@@ -82,6 +82,12 @@ class PageRankEngine:
         # propagate x_in[x_lo:x_hi] (whole source tiles) into the value stream
         check(lib().gm_pr_sweep_bin(self._h, x_in.data_ptr(), x_lo, x_hi, current_stream_ptr()))
 
-    def sweep_accum(self, x_in: torch.Tensor, x_out_local: torch.Tensor, scores_local: torch.Tensor, part: int):
+    def sweep_hot(self, x_in: torch.Tensor):
+        check(lib().gm_pr_sweep_hot(self._h, x_in.data_ptr(), current_stream_ptr()))
+
+    def sweep_accum(self, x_in: torch.Tensor, x_out_local: torch.Tensor, scores_local: torch.Tensor, part: int,
+                    stage_hot: bool | None = None):
+        """stage_hot None: on part 0 (the in-order, single-stream schedule)"""
+        hot = (part == 0) if stage_hot is None else bool(stage_hot)
         check(lib().gm_pr_sweep_accum(self._h, x_in.data_ptr(), x_out_local.data_ptr(), scores_local.data_ptr(), part,
-                                      current_stream_ptr()))
+                                      1 if hot else 0, current_stream_ptr()))

@@ -187,14 +187,16 @@ int gm_pr_sweep_fixup(gm_pr *pr, uint64_t d_x_out_local, uint64_t d_scores_local
  * work on another (propagation-blocking engines only, GM_ERR_UNSUPPORTED otherwise; SURVEY §8e "must be
  * overlapped").  The caller lays the global vector out in regions that are multiples of the source tile
  * (gm_pr_part_geometry) and splits its rows at multiples of rows_per_bin; then per sweep:
- * gm_pr_sweep_bin for every region [x_lo, x_hi) of the vector as it arrives, gm_pr_sweep_accum for parts 0, 1, ... in
- * ascending order (part 0 needs the whole vector: it stages the hot sources), gm_pr_sweep_fixup for the
+ * gm_pr_sweep_bin for every region [x_lo, x_hi) of the vector as it arrives; once all of it is there the hot
+ * sources are staged (gm_pr_sweep_hot, or stage_hot = 1 on the first accumulate) and gm_pr_sweep_accum runs
+ * for every part — on one stream in order, or on several streams ordered by events; gm_pr_sweep_fixup for the
  * error.  Together they do exactly what gm_pr_sweep_tiles does: same kernels, same bits. */
 int gm_pr_part_geometry(const gm_pr *pr, uint64_t *rows_per_bin_out, uint64_t *source_tile_out);
 int gm_pr_set_parts(gm_pr *pr, const uint64_t *row_splits /* n_parts + 1 values: 0 .. n_local */, uint64_t n_parts);
 int gm_pr_sweep_bin(gm_pr *pr, uint64_t d_x_in_global, uint64_t x_lo, uint64_t x_hi /* elements of x_in */, void *stream);
+int gm_pr_sweep_hot(gm_pr *pr, uint64_t d_x_in_global, void *stream); /* stage the hot sources (whole vector needed) */
 int gm_pr_sweep_accum(gm_pr *pr, uint64_t d_x_in_global, uint64_t d_x_out_local, uint64_t d_scores_local,
-                      uint64_t part, void *stream);
+                      uint64_t part, int stage_hot /* 1: gm_pr_sweep_hot first, on this stream */, void *stream);
 /* algorithmic HBM bytes of one sweep, SURVEY §8(d): 8*m_local + 20*n_local + 4 */
 uint64_t gm_pr_algorithmic_bytes(const gm_pr *pr);
 uint64_t gm_pr_tile_count(const gm_pr *pr); /* workgroups per sweep (diagnostics) */

@@ -593,7 +593,7 @@ def test_page_rank_sweep_in_pieces_matches_whole_sweep(P, oracle, scale):
     for k in range(sweeps):
         eng.sweep(x[k % 2], x[1 - k % 2], sc, err)
         errs.append(float(err.item()))
-    for parts in (2, 3):
+    for parts, streams in ((2, False), (3, False), (2, True), (3, True)):
         lay = split_exchange_layout(od, bounds, parts=parts)
         assert lay["x_len"] % 32768 == 0
         shared = [torch.zeros(lay["x_len"], device=dev) for _ in range(2)]
@@ -612,7 +612,7 @@ def test_page_rank_sweep_in_pieces_matches_whole_sweep(P, oracle, scale):
                 st = lay["strides"][k]
                 dst_region[r * st:(r + 1) * st] = src
 
-            ex = PiecewiseExchange(e, lay, r, hi - lo, dev, gather=gather)
+            ex = PiecewiseExchange(e, lay, r, hi - lo, dev, gather=gather, streams=streams)
             ex.x = shared
             ranks.append((csr, odl, e, ex, torch.zeros(hi - lo, device=dev), torch.zeros(1, dtype=torch.float64, device=dev)))
         for (_, _, _, ex, scl, _) in ranks:
@@ -622,6 +622,8 @@ def test_page_rank_sweep_in_pieces_matches_whole_sweep(P, oracle, scale):
             for (_, _, _, ex, scl, el) in ranks:
                 ex.sweep(scl, el)
                 tot += float(el.item())
+                if streams:  # the virtual ranks share one vector: a real rank's side streams are its own device's
+                    torch.cuda.synchronize()
             assert abs(tot - errs[k]) <= 1e-11 * errs[k] + 1e-15
         got = torch.cat([rk[4] for rk in ranks])
         assert torch.equal(got, sc)
