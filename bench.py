@@ -66,6 +66,19 @@ def parse_args():
     return ap.parse_args()
 
 
+def _device_note(torch, dev):
+    """what the run landed on (sweep times differ by up to 20 % between boxes of the same model)"""
+    try:
+        p = torch.cuda.get_device_properties(dev)
+        note = f"{p.name}, {p.multi_processor_count} CUs, {p.total_memory >> 30} GiB"
+        for attr in ("clock_rate", "memory_clock_rate"):
+            if hasattr(p, attr):
+                note += f", {attr} {getattr(p, attr) // 1000} MHz"
+        return note
+    except Exception as exc:  # informational only
+        return f"unknown ({exc})"
+
+
 def main():
     args = parse_args()
     import numpy as np
@@ -290,6 +303,7 @@ def main():
                          f"1-D vertex ranges (greedy in-degree), {world} ranks, all-gather of {stride * 4} B/rank/sweep "
                          f"(only nodes with out-edges)" + (f" in {args.exchange_parts} regions overlapped with the work"
                                                             if piecewise else ""),
+            "device": _device_note(torch, dev),
             "csr_build_s": round(t_build, 3), "final_sweep_error": final_err, "workgroups_per_sweep": engine.tiles, "engine": engine.engine,
         },
         "roofline": {
