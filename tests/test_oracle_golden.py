@@ -255,3 +255,21 @@ def test_rmat_generator_properties(oracle):
     assert deg[:41].sum() > 0.2 * s.size
     w = oracle.rmat_weights(1000)
     assert w.min() > 0 and w.max() <= 1
+
+
+def test_timed_cpu_baseline_runs_the_same_sweeps(oracle):
+    """bench.py's cpu_baseline leg (private NUMA-spread copies, timed inside the oracle) does the work it claims:
+    after k sweeps its error matches the threaded restatement's (the in-place order is racy beyond one chunk, so
+    only to a tolerance), with and without the spread copies; effective_cores() is a positive count."""
+    s, d = oracle.rmat_edges(12, seed=4)
+    n = 1 << 12
+    ioff, itgt = oracle.csr_build(n, s, d, oracle.INCOMING, oracle.SORTED)
+    od = oracle.out_degrees_from(n, s)
+    _, it, err = oracle.page_rank_chunked(ioff, itgt, od, 6, 0.0, 0.85, threads=1)
+    assert it == 6
+    for spread in (False, True):
+        sec, e = oracle.page_rank_chunked_timed(ioff, itgt, od, 5, 0.85, threads=1, spread=spread)  # 1 untimed + 5 timed
+        assert sec > 0.0 and e == err  # one chunk, one thread: the sequential order, bit for bit
+    sec, e = oracle.page_rank_chunked_timed(ioff, itgt, od, 5, 0.85, threads=4, spread=True)
+    assert abs(e - err) <= 0.2 * err
+    assert oracle.effective_cores() >= 1
