@@ -1,9 +1,12 @@
 // sssp.hip — delta-stepping single-source shortest paths on a device-resident weighted out-CSR.
 //
-// Replaces crates/algos/src/sssp.rs:38-204.  The reference's result is the least fixed point of
+// Replaces crates/algos/src/sssp.rs:38-204.  The reference's intended result is the least fixed point of
 // d[v] = min(d[u] (+) w(u,v)) under f32 round-to-nearest addition, which is monotone — so the
-// distances do not depend on the relaxation schedule and this kernel is bit-exact with the
-// reference although its buckets are organised differently:
+// distances do not depend on the relaxation schedule and this kernel returns exactly that fixed point,
+// bit for bit, although its buckets are organised differently.  (The reference itself misses the fixed
+// point on inputs where its stale-entry test `d >= delta * bin` (:126) disagrees in f32 with the bin it
+// chose as (d/delta) as usize (:192), e.g. d = 13.5, delta = 0.3: the node is skipped and its edges are
+// never relaxed.  There is no such test here)
 //   * distances are kept as u32 bit patterns (non-negative f32 order == unsigned order) and
 //     relaxed with atomicMin — the reference's CAS-min loop (sssp.rs:180-202) in one instruction;
 //   * instead of per-thread bins copied into a shared frontier (sssp.rs:85-94) there is one bit per

@@ -860,6 +860,74 @@ ORC_EXPORT int orc_delta_stepping(uint32_t n, const uint32_t *off, const uint32_
     return 0;
 }
 
+/* The least fixed point of d[v] = min(d[u] (+) w(u,v)) under f32 addition (f32 Dijkstra with a binary
+ * heap): what delta-stepping computes under ANY schedule as long as no improvement is dropped.  The
+ * reference does drop some: a node whose new distance d lands in bin (usize)(d/delta) (sssp.rs:192) is
+ * skipped as "stale" when its turn comes if d < delta * bin (sssp.rs:126), and f32 rounding makes that
+ * happen for real distances (d = 13.5, delta = 0.3f: 13.5/0.3f rounds up to 45.0, 0.3f*45 = 13.500001):
+ * the node's edges are then never relaxed and everything behind it keeps a longer distance or f32::MAX.
+ * orc_delta_stepping above restates that faithfully; this function is the intended result. */
+typedef struct {
+    float d;
+    uint32_t v;
+} orc_heap_item;
+
+ORC_EXPORT int orc_sssp_fixed_point(uint32_t n, const uint32_t *off, const uint32_t *tgt, const float *w,
+                                    uint64_t start_node, float *dist)
+{
+    if (start_node >= n)
+        return -1;
+    for (uint32_t u = 0; u < n; ++u)
+        dist[u] = FLT_MAX;
+    dist[start_node] = 0.0f;
+    size_t cap = 1024, len = 0;
+    orc_heap_item *heap = (orc_heap_item *)malloc(cap * sizeof(orc_heap_item));
+    if (!heap)
+        return -2;
+    heap[len++] = (orc_heap_item){0.0f, (uint32_t)start_node};
+    while (len) {
+        const orc_heap_item top = heap[0];
+        heap[0] = heap[--len];
+        for (size_t i = 0;;) { /* sift down */
+            size_t l = 2 * i + 1, r = l + 1, m = i;
+            if (l < len && heap[l].d < heap[m].d)
+                m = l;
+            if (r < len && heap[r].d < heap[m].d)
+                m = r;
+            if (m == i)
+                break;
+            const orc_heap_item t = heap[i];
+            heap[i] = heap[m];
+            heap[m] = t;
+            i = m;
+        }
+        if (top.d > dist[top.v])
+            continue;
+        for (uint32_t e = off[top.v]; e < off[top.v + 1]; ++e) {
+            const float nd = top.d + w[e];
+            if (nd < dist[tgt[e]]) {
+                dist[tgt[e]] = nd;
+                if (len == cap) {
+                    cap *= 2;
+                    heap = (orc_heap_item *)realloc(heap, cap * sizeof(orc_heap_item));
+                    if (!heap)
+                        return -2;
+                }
+                size_t i = len++;
+                heap[i] = (orc_heap_item){nd, tgt[e]};
+                while (i && heap[(i - 1) / 2].d > heap[i].d) { /* sift up */
+                    const orc_heap_item t = heap[i];
+                    heap[i] = heap[(i - 1) / 2];
+                    heap[(i - 1) / 2] = t;
+                    i = (i - 1) / 2;
+                }
+            }
+        }
+    }
+    free(heap);
+    return 0;
+}
+
 /* ------------------------------------------------------------------------------------------
  * Global triangle count — crates/algos/src/triangle_count.rs:47-70 with the put-back iterator
  * of crates/algos/src/utils.rs:8-101: for u; for v in N(u) while v <= u; cursor over N(u)

@@ -260,6 +260,34 @@ def delta_stepping(off, tgt, w, start_node: int, delta: float):
     return dist[:n]
 
 
+def sssp_fixed_point(off, tgt, w, start_node: int):
+    """the least fixed point of d[v] = min(d[u] + w) in f32 (Dijkstra): the intended result of delta-stepping"""
+    n = off.size - 1
+    dist = np.empty(max(n, 1), np.float32)
+    wv = np.ascontiguousarray(w, np.float32)
+    L = lib()
+    L.orc_sssp_fixed_point.argtypes = [C.c_uint32, _u32p, _u32p, np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS"),
+                                       C.c_uint64, np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")]
+    L.orc_sssp_fixed_point.restype = C.c_int
+    rc = L.orc_sssp_fixed_point(n, off, _tgt(tgt), wv if wv.size else np.zeros(1, np.float32), start_node, dist)
+    if rc != 0:
+        raise IndexError(f"orc_sssp_fixed_point rc={rc}")
+    return dist[:n]
+
+
+def stale_check_misfires(dist, delta: float):
+    """Reached nodes whose final distance d satisfies d < delta * (usize)(d / delta) in f32: the reference files
+    them in a bin it then refuses to process (sssp.rs:126 vs :192), so its result is not the fixed point there."""
+    d = np.asarray(dist, np.float32)
+    fin = d < np.float32(3.0e38)
+    dl = np.float32(delta)
+    b = (d[fin] / dl).astype(np.int64)
+    bad = d[fin] < (dl * b.astype(np.float32)).astype(np.float32)
+    out = np.zeros(d.size, bool)
+    out[np.flatnonzero(fin)[bad]] = True
+    return out
+
+
 def triangle_count(off, tgt, threads: int = 1) -> int:
     return int(lib().orc_triangle_count(off.size - 1, off, _tgt(tgt), threads))
 

@@ -348,6 +348,36 @@ def test_sssp_bit_exact_vs_oracle(P, oracle, scale, delta):
     assert (got == F32_MAX).any() and not np.isinf(got).any()
 
 
+def test_sssp_is_the_least_fixed_point_where_the_reference_drops_updates(P, oracle):
+    """The reference skips a node as stale when d < delta * (usize)(d/delta) in f32 (sssp.rs:126 vs :192; e.g.
+    d = 13.5, delta = 0.3) and then never relaxes its edges: its own result is not the fixed point there
+    (oracle restatement: node 2 unreachable).  The device path has no such check: it returns the least fixed
+    point on every input, and equals the reference wherever the reference's check does not misfire."""
+    s, d = np.array([0, 1], np.uint32), np.array([1, 2], np.uint32)
+    w = np.array([13.5, 1.0], np.float32)
+    g = _directed(P, 3, s, d, P.CsrLayout.Sorted, w)
+    off, tgt, wv = oracle.csr_build(3, s, d, oracle.OUTGOING, oracle.SORTED, w)
+    assert list(oracle.delta_stepping(off, tgt, wv, 0, 0.3)) == [0.0, 13.5, F32_MAX]      # the reference's answer
+    assert list(P.delta_stepping(g, P.DeltaSteppingConfig(0, 0.3))) == [0.0, 13.5, 14.5]  # the fixed point
+    rng = np.random.default_rng(11)
+    quirky = 0
+    for _ in range(40):
+        n, m = int(rng.integers(2, 2000)), int(rng.integers(1, 12000))
+        s, d = rng.integers(0, n, m).astype(np.uint32), rng.integers(0, n, m).astype(np.uint32)
+        w = rng.choice(np.array([0.0, 0.125, 0.5, 1.0, 2.75], np.float32), m)
+        g = _directed(P, n, s, d, P.CsrLayout.Sorted, w)
+        off, tgt, wv = oracle.csr_build(n, s, d, oracle.OUTGOING, oracle.SORTED, w)
+        start, delta = int(rng.integers(0, n)), float(rng.choice([0.3, 0.7]))
+        got = P.delta_stepping(g, P.DeltaSteppingConfig(start, delta))
+        fp = oracle.sssp_fixed_point(off, tgt, wv, start)
+        assert np.array_equal(got, fp)
+        if oracle.stale_check_misfires(fp, delta).any():
+            quirky += 1
+        else:
+            assert np.array_equal(got, oracle.delta_stepping(off, tgt, wv, start, delta))
+    assert quirky < 40
+
+
 def test_sssp_zero_weights_self_loops_and_duplicates(P, oracle):
     """Edge cases of the relaxation: zero-weight edges (a node can improve inside the current threshold),
     self-loops, parallel edges with different weights, isolated and unreachable nodes, every start node."""

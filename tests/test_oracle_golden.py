@@ -273,3 +273,39 @@ def test_timed_cpu_baseline_runs_the_same_sweeps(oracle):
     sec, e = oracle.page_rank_chunked_timed(ioff, itgt, od, 5, 0.85, threads=4, spread=True)
     assert abs(e - err) <= 0.2 * err
     assert oracle.effective_cores() >= 1
+
+
+def test_sssp_reference_stale_check_quirk(oracle):
+    """Derived, not reference-published: the reference files a node whose new distance d falls in bin
+    (usize)(d/delta) (sssp.rs:192) and later skips it as stale unless d >= delta * bin (sssp.rs:126).  In f32
+    13.5 / 0.3 rounds up to 45.0 while 0.3 * 45 = 13.500001, so the node at 13.5 is never relaxed and node 2
+    stays at f32::MAX.  The restatement reproduces that; sssp_fixed_point is the intended answer."""
+    s, d = np.array([0, 1], np.uint32), np.array([1, 2], np.uint32)
+    w = np.array([13.5, 1.0], np.float32)
+    off, tgt, wv = oracle.csr_build(3, s, d, oracle.OUTGOING, oracle.SORTED, w)
+    fmax = np.finfo(np.float32).max
+    assert list(oracle.delta_stepping(off, tgt, wv, 0, 0.3)) == [0.0, 13.5, fmax]
+    assert list(oracle.delta_stepping(off, tgt, wv, 0, 0.25)) == [0.0, 13.5, 14.5]
+    fp = oracle.sssp_fixed_point(off, tgt, wv, 0)
+    assert list(fp) == [0.0, 13.5, 14.5]
+    assert list(oracle.stale_check_misfires(fp, 0.3)) == [False, True, False]
+    assert not oracle.stale_check_misfires(fp, 0.25).any()
+    # wherever the check does not misfire the two agree (random graphs, several deltas)
+    rng = np.random.default_rng(3)
+    agree = quirky = 0
+    for _ in range(60):
+        n, m = int(rng.integers(2, 400)), int(rng.integers(1, 3000))
+        s, d = rng.integers(0, n, m).astype(np.uint32), rng.integers(0, n, m).astype(np.uint32)
+        w = rng.choice(np.array([0.0, 0.125, 0.5, 1.0, 2.75], np.float32), m)
+        off, tgt, wv = oracle.csr_build(n, s, d, oracle.OUTGOING, oracle.SORTED, w)
+        for delta in (0.05, 0.3, 3.0):
+            start = int(rng.integers(0, n))
+            fp = oracle.sssp_fixed_point(off, tgt, wv, start)
+            ds = oracle.delta_stepping(off, tgt, wv, start, delta)
+            if oracle.stale_check_misfires(fp, delta).any():
+                quirky += 1
+                assert (ds >= fp).all()  # the reference can only lose improvements
+            else:
+                agree += 1
+                assert np.array_equal(ds, fp)
+    assert agree > 100
