@@ -2,7 +2,8 @@
 """Differential fuzz of the HIP path against the oracle on random small graphs of awkward shapes (duplicates,
 self-loops, isolated nodes, hubs, empty graphs): CSR build in every direction and layout, PageRank (sequential
 mode bit-exact; PB and pull engines against exact row sums), WCC ids, SSSP distances (zero weights included),
-triangle counts with and without relabelling.  usage: fuzz_parity.py [cases] [seed]; exit status 1 on a mismatch."""
+triangle counts with and without relabelling.  usage: fuzz_parity.py [cases] [seed] [max nodes] [max edges];
+exit status 1 on a mismatch."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np
@@ -11,6 +12,8 @@ from oracle import oracle as O
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+max_n = int(sys.argv[3]) if len(sys.argv) > 3 else 3000
+max_m = int(sys.argv[4]) if len(sys.argv) > 4 else 20000
 rng = np.random.default_rng(seed)
 bad = 0
 quirks = 0
@@ -41,8 +44,8 @@ def exact_sweeps(ioff, itgt, od, sweeps, damping=0.85):
 
 for case in range(cases):
     shape = rng.integers(0, 5)
-    n = int(rng.integers(1, 3000))
-    m = int(rng.integers(0, 20000)) if shape else 0
+    n = int(rng.integers(1, max_n))
+    m = int(rng.integers(0, max_m)) if shape else 0
     s = rng.integers(0, n, m).astype(np.uint32)
     d = rng.integers(0, n, m).astype(np.uint32)
     if shape == 2 and m:  # a hub on each side
@@ -71,7 +74,7 @@ for case in range(cases):
     od = np.diff(ooff).astype(np.uint32)
     # PageRank: Auto = the reference's sequential order for n <= 16384, bit for bit
     ref = O.page_rank_seq(ioff, itgt, od, 20, 1e-4, 0.85)
-    got = P.page_rank(g, P.PageRankConfig(20, 1e-4, 0.85))
+    got = P.page_rank(g, P.PageRankConfig(20, 1e-4, 0.85), P.PageRankMode.Sequential)
     if not (np.array_equal(got[0], ref[0]) and got[1] == ref[1] and got[2] == ref[2]):
         fail(case, f"page_rank sequential {tag}")
     ex = exact_sweeps(ioff, itgt, od, 3)
