@@ -52,6 +52,10 @@ def parse_args():
     ap.add_argument("--exchange-parts", type=int, default=0,
                     help="N > 1: regions of the out_scores exchange that overlap with the work (1 = one blocking all-gather "
                          "per sweep; 0 = automatic: 2)")
+    ap.add_argument("--exchange", choices=["allgather", "sparse"], default="allgather",
+                    help="N > 1: allgather = every rank receives every source's out_score (in regions overlapped with the "
+                         "work); sparse = every pair of ranks exchanges only what the receiver's rows read (blocking; covered "
+                         "by gloo tests with a stand-in engine, not yet run on RCCL)")
     ap.add_argument("--bin-pieces", type=int, default=-1,
                     help="overlapped exchange: 1 = propagate every region as it lands, 0 = one propagation launch per sweep "
                          "(only the accumulate is cut; measured no cheaper: P = 8 kernels 0.41 -> 0.48 / 0.46-0.49 ms), -1 = 1")
@@ -128,6 +132,8 @@ def main():
         del deg, order, new_id
     out_deg = torch.bincount(src, minlength=n).to(torch.int32)
     in_csr = synth.build_csr(n, src, dst, Direction.Incoming, CsrLayout.Sorted, None, local_rank)
+    sparse = world > 1 and args.exchange == "sparse"
+    edges = (src, dst) if sparse else None
     del src, dst
     torch.cuda.empty_cache()
     t_build = time.time() - t_build
@@ -142,7 +148,7 @@ def main():
         args.bin_pieces = 1
     if args.piece_streams < 0:
         args.piece_streams = 1 if world >= 4 else 0
-    piecewise = world > 1 and args.exchange_parts > 1 and args.engine != "pull"
+    piecewise = world > 1 and args.exchange_parts > 1 and args.engine != "pull" and args.exchange != "sparse"
     ex = None
     if world == 1:
         local_csr, row_lo, n_local, stride = in_csr, 0, n, n
@@ -161,6 +167,13 @@ def main():
         if piecewise:
             layout = split_exchange_layout(out_deg, bounds, parts=args.exchange_parts)
             node_map, x_len, stride = layout["node_map"], layout["x_len"], sum(layout["strides"])
+        elif args.exchange == "sparse" and not emu:
+            from graph_amd.distributed import SparseExchange, sparse_exchange_layout
+
+            layout = sparse_exchange_layout(None, None, bounds, rank, edges=edges)
+            edges = None
+            node_map, x_len = layout["node_map"], layout["x_len"]
+            stride = sum(c for q, c in enumerate(layout["recv_cnt"]) if q != rank)  # floats received per sweep
         else:
             node_map, send_counts, stride, send_rows_all = compact_exchange_layout(out_deg, bounds)
             send_rows = send_rows_all[rank]
@@ -190,6 +203,15 @@ def main():
         ex = PiecewiseExchange(engine, layout, rank, n_local, dev, gather=gather, split_bin=bool(args.bin_pieces),
                                streams=bool(args.piece_streams))
         ex.start(scores)
+    elif sparse and not emu:
+        sx = SparseExchange(layout, n_local, dev)
+        x, x_loc = sx.x, sx.x_loc
+
+        def exchange(dst_buf):
+            sx.exchange(0 if dst_buf is x[0] else 1)
+
+        engine.init(scores, x_loc)
+        exchange(x[0])
     else:
         x = [torch.zeros(x_len, dtype=torch.float32, device=dev) for _ in range(2)]
         x_loc = torch.zeros(max(n_local, 1), dtype=torch.float32, device=dev) if world > 1 else None
@@ -302,7 +324,9 @@ def main():
             "partition": "none" if world == 1 else
                          f"1-D vertex ranges (greedy in-degree), {world} ranks, all-gather of {stride * 4} B/rank/sweep "
                          f"(only nodes with out-edges)" + (f" in {args.exchange_parts} regions overlapped with the work"
-                                                            if piecewise else ""),
+                                                            if piecewise else "") if not sparse else
+                         f"1-D vertex ranges (greedy in-degree), {world} ranks, sparse pairwise exchange: this rank receives "
+                         f"{stride * 4} B/sweep (the out_scores its rows read)",
             "device": _device_note(torch, dev),
             "csr_build_s": round(t_build, 3), "final_sweep_error": final_err, "workgroups_per_sweep": engine.tiles, "engine": engine.engine,
         },

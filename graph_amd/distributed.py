@@ -81,6 +81,104 @@ def compact_exchange_layout(out_degree, bounds):
     return node_map, counts, stride, send_rows
 
 
+def sparse_exchange_layout(in_offsets, in_targets, bounds, rank: int, edges=None):
+    """Layout of the *sparse* exchange for rank `rank` (opt-in): a rank only needs the
+    out_scores of the sources that actually occur in its rows' in-lists — on RMAT about 0.82 / 0.64 / 0.49 of what
+    the all-gather delivers at 2 / 4 / 8 ranks — so every pair of ranks exchanges exactly that list.
+    in_offsets / in_targets: the whole in-CSR as 1-D integer torch tensors (any device), or edges=(src, dst) edge
+    tensors and in_offsets = in_targets = None with n = bounds[-1]; bounds: world+1 node ids.
+    Returns a dict for this rank: node_map int32[n] (slot in this rank's x vector, -1 = not needed here), x_len,
+    recv_off[q] / recv_cnt[q] (region of x filled by rank q; q == rank: filled locally), send_rows[q] (local rows
+    whose values rank q needs, in q's slot order), own_rows (local rows this rank needs itself)."""
+    world = len(bounds) - 1
+    n = int(bounds[-1]) if edges is not None else in_offsets.numel() - 1
+    dev = edges[0].device if edges is not None else in_targets.device
+    b = torch.as_tensor(np.asarray(bounds, np.int64), device=dev)
+    needs = []  # needs[r]: sorted ids of the sources rank r reads
+    for r in range(world):
+        lo, hi = int(bounds[r]), int(bounds[r + 1])
+        if edges is not None:
+            src, dst = edges
+            needs.append(torch.unique(src[(dst >= lo) & (dst < hi)].to(torch.int64)))
+        else:
+            e0, e1 = int(in_offsets[lo]), int(in_offsets[hi])
+            needs.append(torch.unique(in_targets[e0:e1].to(torch.int64)))
+    mine = needs[rank]
+    owner = torch.bucketize(mine, b[1:], right=True)  # rank that owns each needed source
+    recv_cnt = torch.bincount(owner, minlength=world).tolist()
+    recv_off = [0] * world
+    for q in range(1, world):
+        recv_off[q] = recv_off[q - 1] + recv_cnt[q - 1]
+    node_map = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    node_map[mine] = torch.arange(mine.numel(), dtype=torch.int32, device=dev)  # sorted ids: regions are owner-major
+    lo_r, hi_r = int(bounds[rank]), int(bounds[rank + 1])
+    send_rows = []
+    for q in range(world):
+        nq = needs[q]
+        send_rows.append((nq[(nq >= lo_r) & (nq < hi_r)] - lo_r))
+    return {"node_map": node_map, "x_len": max(int(mine.numel()), 1), "recv_off": recv_off, "recv_cnt": recv_cnt,
+            "send_rows": send_rows, "own_rows": send_rows[rank], "world": world, "rank": rank}
+
+
+class SparseExchange:
+    """Blocking pairwise exchange of exactly the out_scores each rank needs (sparse_exchange_layout): one
+    compaction gather, world-1 sends and world-1 receives per sweep (batch_isend_irecv: grouped send/recv on
+    RCCL, plain isend/irecv on gloo), own values copied locally."""
+
+    def __init__(self, layout, n_local: int, device, group=None):
+        self.lay, self.group, self.rank, self.world = layout, group, layout["rank"], layout["world"]
+        self.x = [torch.zeros(layout["x_len"], dtype=torch.float32, device=device) for _ in range(2)]
+        self.x_loc = torch.zeros(max(n_local, 1), dtype=torch.float32, device=device)
+        self.rows = [r.to(device) for r in layout["send_rows"]]
+        self.peers = [q for q in range(self.world) if q != self.rank]
+        self.send = {q: torch.zeros(max(int(self.rows[q].numel()), 1), dtype=torch.float32, device=device) for q in self.peers}
+        self.cur = 0
+
+    def exchange(self, buf: int):
+        lay, x = self.lay, self.x[buf]
+        o, c = lay["recv_off"][self.rank], lay["recv_cnt"][self.rank]
+        x[o:o + c] = self.x_loc[self.rows[self.rank]]
+        ops = []
+        for q in self.peers:
+            k = int(self.rows[q].numel())
+            if k:
+                self.send[q][:k] = self.x_loc[self.rows[q]]
+                ops.append(dist.P2POp(dist.isend, self.send[q][:k], q, self.group))
+            o, c = lay["recv_off"][q], lay["recv_cnt"][q]
+            if c:
+                ops.append(dist.P2POp(dist.irecv, x[o:o + c], q, self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+
+
+def page_rank_partitioned_sparse(engine, layout, n_local: int, max_iterations: int, tolerance: float, device,
+                                 group=None):
+    """page_rank (page_rank.rs:88-110) across the ranks of `group` with the sparse exchange; engine.sweep(x_in,
+    x_out_local, scores_local, err) reads x through layout["node_map"].  Same results as the other drivers."""
+    if max_iterations == 0 and not tolerance > 0.0:
+        raise ValueError("max_iterations == 0 with tolerance <= 0 never terminates (reference: infinite loop)")
+    scores = torch.zeros(max(n_local, 1), dtype=torch.float32, device=device)
+    err = torch.zeros(1, dtype=torch.float64, device=device)
+    ex = SparseExchange(layout, n_local, device, group)
+    engine.init(scores, ex.x_loc)
+    ex.exchange(0)
+    iteration, error, cur = 0, 0.0, 0
+    can_stop_early = tolerance > 0.0
+    while True:
+        engine.sweep(ex.x[cur], ex.x_loc, scores, err)
+        ex.exchange(1 - cur)
+        cur = 1 - cur
+        iteration += 1
+        last = iteration == max_iterations
+        if can_stop_early or last:
+            dist.all_reduce(err, op=dist.ReduceOp.SUM, group=group)
+            error = float(err.item())
+            if error < tolerance or last:
+                break
+    return scores[:n_local], iteration, error
+
+
 ROW_ALIGN = 16384  # row splits of a sweep in pieces: a multiple of the rows per bin of any plan (<= 16384)
 SOURCE_TILE = 32768  # x regions of a sweep in pieces: a multiple of any plan's source tile (gm_pr_part_geometry)
 

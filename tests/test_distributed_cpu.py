@@ -177,6 +177,67 @@ def test_partitioned_page_rank_overlapped_exchange_matches_single_rank(oracle, w
     assert np.array_equal(got, scores)
 
 
+def _sparse_worker(rank, world, port, scale, max_iter, tol, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    from graph_amd.distributed import (greedy_degree_partition, pad_bounds, page_rank_partitioned_sparse,
+                                       sparse_exchange_layout)
+
+    s, d = O.rmat_edges(scale, seed=3)
+    n = 1 << scale
+    ioff, itgt = O.csr_build(n, s, d, O.INCOMING, O.SORTED)
+    od = O.out_degrees_from(n, s)
+    bounds, _ = pad_bounds(greedy_degree_partition(ioff, world), world, n)
+    lay = sparse_exchange_layout(torch.from_numpy(ioff.astype(np.int64)), torch.from_numpy(itgt.astype(np.int64)), bounds, rank)
+    nm = lay["node_map"].numpy()
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    needed = np.unique(itgt[ioff[lo]:ioff[hi]])
+    assert lay["x_len"] == max(needed.size, 1) and np.array_equal(np.flatnonzero(nm >= 0), needed)
+    assert sum(lay["recv_cnt"]) == needed.size and lay["x_len"] <= int((od > 0).sum())  # never more than the all-gather
+    eng = _OracleRankEngine(O, ioff, itgt, od, bounds, 0, rank, 0.85, nm)
+    scores, it, err = page_rank_partitioned_sparse(eng, lay, hi - lo, max_iter, tol, torch.device("cpu"))
+    q.put((rank, lo, scores.numpy().copy(), it, err, lay["x_len"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,max_iter,tol", [(2, 5, 0.0), (3, 20, 1e-3), (4, 3, 0.0)])
+def test_partitioned_page_rank_sparse_exchange_matches_single_rank(oracle, world, max_iter, tol):
+    """The opt-in sparse exchange: every pair of ranks exchanges only the out_scores the receiver's rows read."""
+    scale = 7
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sparse_worker, args=(r, world, port, scale, max_iter, tol, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n = 1 << scale
+    s, d = oracle.rmat_edges(scale, seed=3)
+    ioff, itgt = oracle.csr_build(n, s, d, oracle.INCOMING, oracle.SORTED)
+    od = oracle.out_degrees_from(n, s)
+    init = np.float32(1.0) / np.float32(n)
+    scores = np.full(n, init, np.float32)
+    with np.errstate(divide="ignore"):
+        outs = (init / od.astype(np.float32)).astype(np.float32)
+    it = 0
+    while True:
+        outs, err = oracle.page_rank_jacobi_sweep(ioff, itgt, od, 0.85, scores, outs)
+        it += 1
+        if err < tol or it == max_iter:
+            break
+    got = np.zeros(n, np.float32)
+    for rank, lo, sc, it_r, err_r, x_len in results:
+        got[lo:lo + sc.size] = sc
+        assert it_r == it
+        assert abs(err_r - err) <= 1e-9 * max(err, 1e-30) + 1e-15
+    assert np.array_equal(got, scores)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
