@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """bench.py — PageRank pull sweeps on synthetic R-MAT, the metric of BASELINE.json.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 runs one process per GPU over RCCL.  Started under torch.distributed.run (WORLD_SIZE set) it is one
+rank of the job; started plainly (`python bench.py --gpus 8`) it launches its own N ranks through
+torch.distributed.run on 127.0.0.1 and relays rank 0's JSON line.
 
 A *step* is one PageRank sweep (page_rank_iteration, crates/algos/src/page_rank.rs:113-168) over the
 whole graph: K timed sweeps after W warm-up sweeps, bracketed by barrier + synchronize, MAX over
@@ -67,7 +71,27 @@ def parse_args():
     ap.add_argument("--emulate-parts", type=int, default=0, help="debug (1 process): time only the row slice that "
                     "rank --emulate-rank of an N-way partition would own, without the exchange")
     ap.add_argument("--emulate-rank", type=int, default=0)
+    ap.add_argument("--launch-check", type=int, default=0, help="debug: every rank reports its rendezvous and exits "
+                    "before touching a GPU (tests/test_bench_launch_cpu.py)")
     return ap.parse_args()
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one process per GPU, the
+    way the driver would (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py ...`).  Rank 0 prints the JSON line; it passes through unchanged."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
 
 
 def _device_note(torch, dev):
@@ -85,6 +109,13 @@ def _device_note(torch, dev):
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.emulate_parts:
+        raise SystemExit(self_launch(args))
+    if args.launch_check:
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": int(os.environ.get("WORLD_SIZE", "1")),
+                              "master": os.environ.get("MASTER_ADDR"), "backend": args.backend}), flush=True)
+        return
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -106,6 +137,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback")
     if args.single_device:
         local_rank = 0
+    elif world > 1 and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} needs {world} visible GPUs, this node shows {torch.cuda.device_count()} "
+                         f"(one process per GPU; --single-device 1 --backend gloo exercises the path on one)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
