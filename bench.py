@@ -392,6 +392,7 @@ def main():
                       f"orc_page_rank_chunked_timed: 16384-node dynamic chunks, threads re-spawned per sweep, inputs "
                       f"first-touched by all threads (NUMA spread)",
             "ms_per_step": round(cpu_s * 1e3 / args.cpu_sweeps, 3),
+            "build": O.timed_build_flags(),
         }
     if emu:
         result["config"]["emulated"] = f"rank {rank} of {world} on one device, exchange replaced by a local copy"

@@ -93,6 +93,45 @@ int check_device(int device)
 
 } // namespace
 
+namespace {
+
+// bit 0: offsets not monotone / beyond m; bit 1: a target >= n
+__global__ void csr_validate_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt, uint64_t n, uint64_t m,
+                                    uint32_t *__restrict__ bad)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint32_t b = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        if (off[i] > off[i + 1] || off[i + 1] > m)
+            b |= 1u;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride)
+        if (tgt[i] >= n)
+            b |= 2u;
+    if (b)
+        atomicOr(bad, b);
+}
+
+// every kernel indexes x / dist / parent by target and walks [off[u], off[u+1]): a CSR that came from a
+// file or a foreign buffer is checked once, on the device (one streaming pass), before anything trusts it
+int validate_csr_arrays(const uint32_t *d_off, const uint32_t *d_tgt, uint64_t n, uint64_t m, const char *who)
+{
+    gm::DevBuf bad;
+    GM_TRY(bad.alloc(4));
+    GM_HIP(hipMemset(bad.p, 0, 4));
+    uint64_t work = n > m ? n : m;
+    unsigned grid = (unsigned)((work + 255) / 256);
+    grid = grid > 8192 ? 8192 : (grid ? grid : 1);
+    hipLaunchKernelGGL(csr_validate_kernel, dim3(grid), dim3(256), 0, 0, d_off, d_tgt, n, m, bad.as<uint32_t>());
+    GM_HIP(hipGetLastError());
+    uint32_t h = 0;
+    GM_HIP(hipMemcpy(&h, bad.p, 4, hipMemcpyDeviceToHost));
+    GM_CHECK(!(h & 1u), GM_ERR_INVALID, "%s: offsets are not ascending within [0, m]", who);
+    GM_CHECK(!(h & 2u), GM_ERR_RANGE, "%s: a target id is >= node_count (%llu)", who, (unsigned long long)n);
+    return GM_OK;
+}
+
+} // namespace
+
 GM_API int gm_csr_upload_u32(const uint32_t *offsets, const uint32_t *targets, const float *weights, uint64_t n,
                              uint64_t m, int device, gm_csr **out)
 {
@@ -114,6 +153,11 @@ GM_API int gm_csr_upload_u32(const uint32_t *offsets, const uint32_t *targets, c
         gm::set_error("gm_csr_upload_u32: %s", hipGetErrorString(e));
         delete c;
         return GM_ERR_HIP;
+    }
+    const int rc = validate_csr_arrays(c->offsets, c->targets, n, m, "gm_csr_upload_u32");
+    if (rc != GM_OK) {
+        delete c;
+        return rc;
     }
     *out = c;
     return GM_OK;
@@ -150,6 +194,12 @@ GM_API int gm_csr_wrap_device(uint64_t d_offsets, uint64_t d_targets, uint64_t d
 {
     GM_CHECK(d_offsets && out && (d_targets || m == 0), GM_ERR_INVALID, "gm_csr_wrap_device: null argument");
     GM_CHECK(n < (1ull << 32) && m < (1ull << 32), GM_ERR_RANGE, "gm_csr_wrap_device: n or m exceed u32");
+    GM_TRY(check_device(device));
+    {
+        gm::DeviceGuard guard(device);
+        GM_TRY(validate_csr_arrays(reinterpret_cast<const uint32_t *>(d_offsets), reinterpret_cast<const uint32_t *>(d_targets),
+                                   n, m, "gm_csr_wrap_device"));
+    }
     gm_csr *c = new (std::nothrow) gm_csr();
     GM_CHECK(c, GM_ERR_NOMEM, "out of host memory");
     c->n = n;
@@ -656,6 +706,15 @@ GM_API int gm_csr_build_device(uint64_t n, uint64_t m, uint64_t d_src, uint64_t 
     }
 
     auto fail = [&](int rc) { return rc; }; // `hold` frees the handle
+    // An endpoint >= node_count must stop the build BEFORE the sort: the radix sort covers only
+    // ceil_log2(n) row bits, so an oversized row id would survive in the keys and send
+    // offsets_from_sorted_kernel far past the n + 1 offsets (heap corruption / a near-endless loop).
+    auto endpoints_ok = [&]() -> int {
+        uint32_t hbad = 0;
+        GM_HIP(hipMemcpy(&hbad, bad.p, 4, hipMemcpyDeviceToHost)); // orders after the key kernel (null stream)
+        GM_CHECK(!hbad, GM_ERR_RANGE, "gm_csr_build_device: an edge endpoint is >= node_count (%llu)", (unsigned long long)n);
+        return GM_OK;
+    };
 
     if (layout == GM_LAYOUT_UNSORTED) {
         gm::DevBuf keys, kalt, idx, ialt;
@@ -666,6 +725,7 @@ GM_API int gm_csr_build_device(uint64_t n, uint64_t m, uint64_t d_src, uint64_t 
         hipLaunchKernelGGL(make_keys32_kernel, dim3(grid), dim3(256), 0, 0, total, m, direction, src, dst,
                            keys.as<uint32_t>(), idx.as<uint32_t>(), (uint32_t)n, bad.as<uint32_t>());
         GM_HIP(hipGetLastError());
+        GM_TRY(endpoints_ok());
         GM_TRY(radix_sort_pairs_inplace<uint32_t>(keys, kalt, idx, ialt, total, 0, row_bits));
         GM_TRY(new_owned_csr(n, total, weighted, device, &c));
         hipLaunchKernelGGL((offsets_from_sorted_kernel<uint32_t, 0>), dim3(grid), dim3(256), 0, 0, keys.as<uint32_t>(),
@@ -687,6 +747,7 @@ GM_API int gm_csr_build_device(uint64_t n, uint64_t m, uint64_t d_src, uint64_t 
         hipLaunchKernelGGL(make_keys64_kernel, dim3(grid), dim3(256), 0, 0, total, m, direction, src, dst,
                            keys.as<uint64_t>(), weighted ? idx.as<uint32_t>() : nullptr, (uint32_t)n, bad.as<uint32_t>());
         GM_HIP(hipGetLastError());
+        GM_TRY(endpoints_ok());
         if (weighted)
             GM_TRY(radix_sort_pairs_inplace<uint64_t>(keys, kalt, idx, ialt, total, 0, 32 + row_bits));
         else
@@ -737,15 +798,6 @@ GM_API int gm_csr_build_device(uint64_t n, uint64_t m, uint64_t d_src, uint64_t 
                 return fail(GM_ERR_HIP);
             }
         }
-    }
-    uint32_t hbad = 0;
-    if (hipMemcpy(&hbad, bad.p, 4, hipMemcpyDeviceToHost) != hipSuccess) {
-        gm::set_error("gm_csr_build_device: read-back failed");
-        return fail(GM_ERR_HIP);
-    }
-    if (hbad) {
-        gm::set_error("gm_csr_build_device: an edge endpoint is >= node_count (%llu)", (unsigned long long)n);
-        return fail(GM_ERR_RANGE);
     }
     *out = hold.release();
     return GM_OK;

@@ -34,7 +34,8 @@ constexpr int TC_WAVES = TC_BLOCK / kWave;
 __global__ __launch_bounds__(TC_BLOCK) void tc_low_len_kernel(const uint32_t *__restrict__ off,
                                                               const uint32_t *__restrict__ tgt, uint32_t n,
                                                               uint32_t *__restrict__ low_len /* n+1 */,
-                                                              uint32_t *__restrict__ row_start /* bit per entry */)
+                                                              uint32_t *__restrict__ row_start /* bit per entry */,
+                                                              uint32_t *__restrict__ flags)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u <= n; u += stride) {
@@ -52,6 +53,11 @@ __global__ __launch_bounds__(TC_BLOCK) void tc_low_len_kernel(const uint32_t *__
                 hi = mid;
         }
         low_len[u] = lo - s;
+        // a self-loop entry (u in N(u)) takes part in the put-back walk as v == u and as w == v; the bitmap
+        // path counts only w < v < u, so lists with a self-loop take the general path (flag 2), like lists
+        // with duplicates (an undirected build doubles self-loops; an uploaded CSR may hold a single one)
+        if (lo > s && tgt[lo - 1] == u)
+            atomicOr(flags, 2u);
         if (e > s)
             atomicOr(&row_start[s >> 5], 1u << (s & 31u));
     }
@@ -236,7 +242,7 @@ GM_API int gm_triangle_count(const gm_csr *g, uint64_t *triangles_out)
         GM_TRY(row_start.alloc(((size_t)g->m / 32 + 1) * 4));
         GM_HIP(hipMemset(row_start.p, 0, row_start.bytes));
         hipLaunchKernelGGL(tc_low_len_kernel, dim3(grid), dim3(TC_BLOCK), 0, 0, g->offsets, g->targets, n,
-                           low_len.as<uint32_t>(), row_start.as<uint32_t>());
+                           low_len.as<uint32_t>(), row_start.as<uint32_t>(), ctrl.as<uint32_t>() + 2);
         unsigned egrid = gm::div_up(g->m, TC_BLOCK);
         if (egrid > 256 * 32)
             egrid = 256 * 32;
@@ -282,10 +288,18 @@ GM_API int gm_triangle_count(const gm_csr *g, uint64_t *triangles_out)
         if (const char *e = getenv("GM_TC_K"))
             K = (uint32_t)atoll(e) < n ? (uint32_t)atoll(e) : n;
         gm::DevBuf bits;
+        // the bitmap is an accelerator, not a requirement: when HBM is short (a graph that already fills the
+        // card, a shared node) halve K until it fits, down to the search-only path
+        while (K >= 2) {
+            const uint64_t nbits = (uint64_t)K * (K - 1) / 2;
+            if (bits.alloc((size_t)((nbits + 31) / 32 + 1) * 4) == GM_OK)
+                break;
+            (void)hipGetLastError();
+            K /= 2;
+        }
         if (K >= 2) {
             const uint64_t nbits = (uint64_t)K * (K - 1) / 2;
             const size_t words = (size_t)((nbits + 31) / 32) + 1;
-            GM_TRY(bits.alloc(words * 4));
             GM_HIP(hipMemset(bits.p, 0, words * 4));
             hipLaunchKernelGGL(tc_bitmap_fill_kernel, dim3(cgrid), dim3(TC_BLOCK), 0, 0, dag_src.as<uint32_t>(),
                                dag_tgt.as<uint32_t>(), (uint64_t)dag_m, K, bits.as<uint32_t>());

@@ -47,17 +47,27 @@ def _write_csr(f, offsets, targets, weights):
         f.write(rec.tobytes())
 
 
+def _read_exact(f, count, what):
+    """a truncated dump must fail here, not as a short array handed to the device"""
+    buf = f.read(count)
+    if len(buf) != count:
+        raise ValueError(f"truncated graph file: {what} needs {count} bytes, {len(buf)} left")
+    return buf
+
+
 def _read_csr(f, weighted):
-    (name_len,) = struct.unpack("<Q", f.read(8))
-    name = f.read(name_len)
+    (name_len,) = struct.unpack("<Q", _read_exact(f, 8, "type-name length"))
+    if name_len > 64:
+        raise ValueError(f"invalid id type: a type name of {name_len} bytes")
+    name = _read_exact(f, name_len, "type name")
     if name != _TYPE_NAME:  # Error::InvalidIdType (csr.rs:284-289)
         raise ValueError(f"invalid id type: expected {_TYPE_NAME.decode()}, got {name.decode(errors='replace')}")
-    n, m = struct.unpack("<II", f.read(8))
-    offsets = np.frombuffer(f.read(4 * (n + 1)), "<u4").copy()
+    n, m = struct.unpack("<II", _read_exact(f, 8, "node and edge count"))
+    offsets = np.frombuffer(_read_exact(f, 4 * (n + 1), "offsets"), "<u4").copy()
     if weighted:
-        rec = np.frombuffer(f.read(8 * m), dtype=[("target", "<u4"), ("value", "<f4")])
+        rec = np.frombuffer(_read_exact(f, 8 * m, "targets"), dtype=[("target", "<u4"), ("value", "<f4")])
         return offsets, rec["target"].copy(), rec["value"].copy()
-    return offsets, np.frombuffer(f.read(4 * m), "<u4").copy(), None
+    return offsets, np.frombuffer(_read_exact(f, 4 * m, "targets"), "<u4").copy(), None
 
 
 def serialize(graph, path):
@@ -74,7 +84,7 @@ def serialize(graph, path):
 def deserialize(path, kind=P.DirectedCsrGraph, weighted=False, layout=P.CsrLayout.Unsorted, device=0):
     """DeserializeGraphOp::deserialize; uploads the CSR(s) to the device."""
     with open(path, "rb") as f:
-        (node_values,) = struct.unpack("<Q", f.read(8))
+        (node_values,) = struct.unpack("<Q", _read_exact(f, 8, "node-value count"))
         if kind is P.DirectedCsrGraph:
             out = P.DeviceCsr.from_arrays(*_read_csr(f, weighted), device=device)
             inc = P.DeviceCsr.from_arrays(*_read_csr(f, weighted), device=device)

@@ -63,7 +63,8 @@ int gm_csr_upload_u32(const uint32_t *offsets /* n+1 */, const uint32_t *targets
 int gm_csr_upload_u64(const uint64_t *offsets, const uint64_t *targets, const float *weights, uint64_t n,
                       uint64_t m, int device, gm_csr **out);
 /* Borrow arrays that already live in HBM (u32 offsets n+1, u32 targets m, f32 weights or 0).
- * The caller keeps them alive for the lifetime of the handle. */
+ * The caller keeps them alive for the lifetime of the handle.  Like the uploads, the arrays are checked once
+ * on the device (offsets ascending within [0, m] -> GM_ERR_INVALID, targets < n -> GM_ERR_RANGE). */
 int gm_csr_wrap_device(uint64_t d_offsets, uint64_t d_targets, uint64_t d_weights, uint64_t n, uint64_t m,
                        int device, gm_csr **out);
 void gm_csr_free(gm_csr *csr);

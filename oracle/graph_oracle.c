@@ -377,6 +377,39 @@ static void *orc_pr_worker(void *arg)
     return NULL;
 }
 
+/* The same loop for the TIMED baseline only (orc_page_rank_chunked_timed): plain loads and stores of
+ * out_scores, as the reference's raw-pointer SharedMut accesses compile to (page_rank.rs:143-159) —
+ * the checker above keeps `volatile` so that the racing in-place updates it models are really re-read. */
+static void *orc_pr_worker_timed(void *arg)
+{
+    orc_pr_job *j = (orc_pr_job *)arg;
+    const uint32_t *restrict in_off = j->in_off, *restrict in_tgt = j->in_tgt, *restrict out_deg = j->out_deg;
+    float *outs = j->outs, *scores = j->scores;
+    const float base = j->base, damping = j->damping;
+    double err = 0.0;
+    for (;;) {
+        uint64_t start = atomic_fetch_add(j->next_chunk, ORC_PR_CHUNK);
+        if (start >= j->n)
+            break;
+        uint64_t end = start + ORC_PR_CHUNK;
+        if (end > j->n)
+            end = j->n;
+        for (uint32_t u = (uint32_t)start; u < (uint32_t)end; ++u) {
+            float s = 0.0f;
+            for (uint32_t i = in_off[u]; i < in_off[u + 1]; ++i)
+                s = s + outs[in_tgt[i]];
+            const float old = scores[u];
+            const float prod = damping * s;
+            const float nw = base + prod;
+            scores[u] = nw;
+            err += fabs((double)(nw - old));
+            outs[u] = nw / (float)out_deg[u];
+        }
+    }
+    j->err = err;
+    return NULL;
+}
+
 /* seconds_per_iter_out (optional, may be NULL): wall time of every sweep, length max_iterations */
 ORC_EXPORT int orc_page_rank_chunked(uint32_t n, const uint32_t *in_off, const uint32_t *in_tgt,
                                      const uint32_t *out_deg, uint64_t max_iterations, double tolerance,
@@ -510,7 +543,7 @@ ORC_EXPORT int orc_page_rank_chunked_timed(uint32_t n, const uint32_t *in_off, c
         atomic_init(&next, 0);
         for (uint32_t t = 0; t < threads; ++t) {
             jobs[t] = (orc_pr_job){n, off, tgt, od, base, damping, scores, outs, &next, 0.0};
-            pthread_create(&tid[t], NULL, orc_pr_worker, &jobs[t]);
+            pthread_create(&tid[t], NULL, orc_pr_worker_timed, &jobs[t]);
         }
         err = 0.0;
         for (uint32_t t = 0; t < threads; ++t) {

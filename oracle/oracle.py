@@ -32,6 +32,31 @@ def build(force: bool = False) -> str:
 
 
 _lib = None
+_native = None
+_native_flags = None
+
+
+def native_lib():
+    """The build used by the TIMED cpu_baseline legs only: `-O3 -march=native`, compiled on the
+    box whose cores are timed (oracle/Makefile: liborc_native.so; never shipped).  Falls back to liborc.so
+    (-O3, generic x86-64) when no compiler is there; timed_build_flags() says which one ran."""
+    global _native, _native_flags
+    if _native is None:
+        path = os.path.join(_HERE, "liborc_native.so")
+        try:
+            subprocess.check_call(["make", "-C", _HERE, "-B", "liborc_native.so"], stdout=subprocess.DEVNULL,
+                                  stderr=subprocess.DEVNULL)
+            _native = _bind(C.CDLL(path))
+            _native_flags = "gcc -O3 -march=native -ffp-contract=off"
+        except (OSError, subprocess.CalledProcessError):
+            _native = lib()
+            _native_flags = "gcc -O3 -ffp-contract=off (generic x86-64: native build failed)"
+    return _native
+
+
+def timed_build_flags() -> str:
+    native_lib()
+    return _native_flags
 
 
 def lib():
@@ -39,46 +64,49 @@ def lib():
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
             build()
-        L = C.CDLL(_LIB_PATH)
-        L.orc_rmat_edges.argtypes = [C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, _u32p, _u32p]
-        L.orc_rmat_edges.restype = None
-        L.orc_rmat_weights.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, _f32p]
-        L.orc_rmat_weights.restype = None
-        L.orc_csr_build.argtypes = [C.c_uint32, C.c_uint64, _u32p, _u32p, C.c_void_p, C.c_int, C.c_int,
-                                    _u32p, _u32p, C.c_void_p]
-        L.orc_csr_build.restype = C.c_uint64
-        L.orc_relabel_by_degree.argtypes = [C.c_uint32, _u32p, _u32p, _u32p, _u32p, _u32p]
-        L.orc_relabel_by_degree.restype = C.c_int
-        L.orc_page_rank_seq.argtypes = [C.c_uint32, _u32p, _u32p, _u32p, C.c_uint64, C.c_double, C.c_float,
-                                        _f32p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
-        L.orc_page_rank_seq.restype = None
-        L.orc_page_rank_chunked.argtypes = [C.c_uint32, _u32p, _u32p, _u32p, C.c_uint64, C.c_double, C.c_float,
-                                            C.c_uint32, _f32p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
-        L.orc_page_rank_chunked.restype = C.c_int
-        L.orc_page_rank_chunked_timed.argtypes = [C.c_uint32, _u32p, _u32p, _u32p, C.c_uint64, C.c_float, C.c_uint32, C.c_int,
-                                                  C.POINTER(C.c_double), C.POINTER(C.c_double)]
-        L.orc_page_rank_chunked_timed.restype = C.c_int
-        L.orc_page_rank_f64.argtypes = [C.c_uint32, _u32p, _u32p, _u32p, C.c_uint64, C.c_double, C.c_double,
-                                        _f64p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
-        L.orc_page_rank_f64.restype = None
-        L.orc_page_rank_jacobi_sweep.argtypes = [C.c_uint32, _u32p, _u32p, _u32p, C.c_float, _f32p, _f32p, _f32p]
-        L.orc_page_rank_jacobi_sweep.restype = C.c_double
-        L.orc_uf_new.argtypes = [C.c_uint32, _u32p]
-        L.orc_uf_union.argtypes = [C.c_int, _u32p, C.c_uint32, C.c_uint32]
-        L.orc_uf_find.argtypes = [C.c_int, _u32p, C.c_uint32]
-        L.orc_uf_find.restype = C.c_uint32
-        L.orc_uf_compress.argtypes = [C.c_int, _u32p, C.c_uint32]
-        L.orc_wcc.argtypes = [C.c_int, C.c_uint32, _u32p, _u32p, _u32p, _u32p, C.c_uint64, C.c_uint64,
-                              C.c_uint64, _u32p]
-        L.orc_wcc.restype = C.c_int
-        L.orc_delta_stepping.argtypes = [C.c_uint32, _u32p, _u32p, _f32p, C.c_uint64, C.c_float, _f32p]
-        L.orc_delta_stepping.restype = C.c_int
-        L.orc_triangle_count.argtypes = [C.c_uint32, _u32p, _u32p, C.c_uint32]
-        L.orc_triangle_count.restype = C.c_uint64
-        L.orc_greedy_degree_partition.argtypes = [C.c_uint32, _u32p, C.c_uint32, _u32p]
-        L.orc_greedy_degree_partition.restype = C.c_uint32
-        _lib = L
+        _lib = _bind(C.CDLL(_LIB_PATH))
     return _lib
+
+
+def _bind(L):
+    L.orc_rmat_edges.argtypes = [C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, _u32p, _u32p]
+    L.orc_rmat_edges.restype = None
+    L.orc_rmat_weights.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, _f32p]
+    L.orc_rmat_weights.restype = None
+    L.orc_csr_build.argtypes = [C.c_uint32, C.c_uint64, _u32p, _u32p, C.c_void_p, C.c_int, C.c_int,
+                                _u32p, _u32p, C.c_void_p]
+    L.orc_csr_build.restype = C.c_uint64
+    L.orc_relabel_by_degree.argtypes = [C.c_uint32, _u32p, _u32p, _u32p, _u32p, _u32p]
+    L.orc_relabel_by_degree.restype = C.c_int
+    L.orc_page_rank_seq.argtypes = [C.c_uint32, _u32p, _u32p, _u32p, C.c_uint64, C.c_double, C.c_float,
+                                    _f32p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+    L.orc_page_rank_seq.restype = None
+    L.orc_page_rank_chunked.argtypes = [C.c_uint32, _u32p, _u32p, _u32p, C.c_uint64, C.c_double, C.c_float,
+                                        C.c_uint32, _f32p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+    L.orc_page_rank_chunked.restype = C.c_int
+    L.orc_page_rank_chunked_timed.argtypes = [C.c_uint32, _u32p, _u32p, _u32p, C.c_uint64, C.c_float, C.c_uint32, C.c_int,
+                                              C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.orc_page_rank_chunked_timed.restype = C.c_int
+    L.orc_page_rank_f64.argtypes = [C.c_uint32, _u32p, _u32p, _u32p, C.c_uint64, C.c_double, C.c_double,
+                                    _f64p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+    L.orc_page_rank_f64.restype = None
+    L.orc_page_rank_jacobi_sweep.argtypes = [C.c_uint32, _u32p, _u32p, _u32p, C.c_float, _f32p, _f32p, _f32p]
+    L.orc_page_rank_jacobi_sweep.restype = C.c_double
+    L.orc_uf_new.argtypes = [C.c_uint32, _u32p]
+    L.orc_uf_union.argtypes = [C.c_int, _u32p, C.c_uint32, C.c_uint32]
+    L.orc_uf_find.argtypes = [C.c_int, _u32p, C.c_uint32]
+    L.orc_uf_find.restype = C.c_uint32
+    L.orc_uf_compress.argtypes = [C.c_int, _u32p, C.c_uint32]
+    L.orc_wcc.argtypes = [C.c_int, C.c_uint32, _u32p, _u32p, _u32p, _u32p, C.c_uint64, C.c_uint64,
+                          C.c_uint64, _u32p]
+    L.orc_wcc.restype = C.c_int
+    L.orc_delta_stepping.argtypes = [C.c_uint32, _u32p, _u32p, _f32p, C.c_uint64, C.c_float, _f32p]
+    L.orc_delta_stepping.restype = C.c_int
+    L.orc_triangle_count.argtypes = [C.c_uint32, _u32p, _u32p, C.c_uint32]
+    L.orc_triangle_count.restype = C.c_uint64
+    L.orc_greedy_degree_partition.argtypes = [C.c_uint32, _u32p, C.c_uint32, _u32p]
+    L.orc_greedy_degree_partition.restype = C.c_uint32
+    return L
 
 
 # ----------------------------------------------------------------------------------------------
@@ -216,7 +244,7 @@ def page_rank_chunked_timed(in_off, in_tgt, out_deg, sweeps, damping=0.85, threa
     n = in_off.size - 1
     threads = threads or effective_cores()
     sec, err = C.c_double(), C.c_double()
-    rc = lib().orc_page_rank_chunked_timed(n, in_off, _tgt(in_tgt), np.ascontiguousarray(out_deg, np.uint32), sweeps,
+    rc = native_lib().orc_page_rank_chunked_timed(n, in_off, _tgt(in_tgt), np.ascontiguousarray(out_deg, np.uint32), sweeps,
                                            damping, threads, 1 if spread else 0, C.byref(sec), C.byref(err))
     assert rc == 0
     return sec.value, err.value
@@ -239,21 +267,22 @@ def page_rank_jacobi_sweep(in_off, in_tgt, out_deg, damping, scores, outs_in):
     return outs_out, err
 
 
-def wcc(out_off, out_tgt, in_off, in_tgt, algo=AFFOREST, neighbor_rounds=2, sampling_size=1024, seed=1):
+def wcc(out_off, out_tgt, in_off, in_tgt, algo=AFFOREST, neighbor_rounds=2, sampling_size=1024, seed=1, native=False):
+    """native=True: the -march=native build (timed cpu_baseline legs; same results)"""
     n = out_off.size - 1
     comp = np.empty(max(n, 1), np.uint32)
-    rc = lib().orc_wcc(algo, n, out_off, _tgt(out_tgt), in_off, _tgt(in_tgt), neighbor_rounds, sampling_size,
+    rc = (native_lib() if native else lib()).orc_wcc(algo, n, out_off, _tgt(out_tgt), in_off, _tgt(in_tgt), neighbor_rounds, sampling_size,
                        seed, comp)
     if rc != 0:
         raise ValueError(f"orc_wcc rc={rc}")
     return comp[:n]
 
 
-def delta_stepping(off, tgt, w, start_node: int, delta: float):
+def delta_stepping(off, tgt, w, start_node: int, delta: float, native=False):
     n = off.size - 1
     dist = np.empty(max(n, 1), np.float32)
     wv = np.ascontiguousarray(w, np.float32)
-    rc = lib().orc_delta_stepping(n, off, _tgt(tgt), wv if wv.size else np.zeros(1, np.float32), start_node,
+    rc = (native_lib() if native else lib()).orc_delta_stepping(n, off, _tgt(tgt), wv if wv.size else np.zeros(1, np.float32), start_node,
                                   delta, dist)
     if rc != 0:
         raise IndexError(f"orc_delta_stepping rc={rc}")
@@ -288,8 +317,8 @@ def stale_check_misfires(dist, delta: float):
     return out
 
 
-def triangle_count(off, tgt, threads: int = 1) -> int:
-    return int(lib().orc_triangle_count(off.size - 1, off, _tgt(tgt), threads))
+def triangle_count(off, tgt, threads: int = 1, native=False) -> int:
+    return int((native_lib() if native else lib()).orc_triangle_count(off.size - 1, off, _tgt(tgt), threads))
 
 
 def greedy_degree_partition(off, concurrency: int):

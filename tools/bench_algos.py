@@ -1,8 +1,19 @@
 #!/usr/bin/env python3
-"""Timing + full-size property checks of the non-headline algorithms at BASELINE.json's configs:
-   RMAT scale-22 WCC (bit-exact vs the oracle), RMAT scale-24 weighted SSSP and triangle count."""
+"""WCC / SSSP / triangle count at BASELINE.json's configs (RMAT scale-22 WCC, scale-24 weighted SSSP and
+triangle count): device time, parity against the oracle AT FULL SIZE, SURVEY §8(d)'s byte model -> roofline
+fraction, and the oracle's time on this box's host cores as cpu_baseline.  One JSON object on stdout.
+
+    python tools/bench_algos.py                    everything (the oracle runs take a few minutes of CPU)
+    python tools/bench_algos.py --profile 1        one device call per algorithm, no oracle (for rocprofv3 passes)
+
+Byte models (u32 ids, f32 weights / distances):
+    WCC   4(n+1) + 4(m_out + m_in) + 8n                 both CSRs once + parent init / write-back
+    SSSP  12 B x relaxed edges + 4 B x reached nodes    relaxed edges = out-edges of reached nodes, each counted once
+    TC    4 B x sum over DAG entries (u, v), v < u, of (rank of v in L(u) + |L(v)|)   the merge streams
+`roofline.frac` uses the wall time of the whole call (allocation, scheduling and the result download
+included) — the kernel-only sums are in profiles/r02_algos_kernel_stats.txt.
+"""
 import argparse
-import ctypes as C
 import json
 import os
 import sys
@@ -10,6 +21,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+HBM_PEAK = 8.0e12
 
 
 def main():
@@ -18,22 +30,31 @@ def main():
     ap.add_argument("--sssp-scale", type=int, default=24)
     ap.add_argument("--tc-scale", type=int, default=24)
     ap.add_argument("--oracle", type=int, default=1)
+    ap.add_argument("--profile", type=int, default=0)
     ap.add_argument("--skip", default="")
+    ap.add_argument("--reps", type=int, default=3)
     args = ap.parse_args()
+    if args.profile:
+        args.oracle, args.reps = 0, 1
+        args.skip += ",prapi"
     import numpy as np
     import torch
 
     from graph_amd import synth
     from graph_amd import prelude as P
-    from graph_amd._lib import check, lib, vp, u64
 
-    out = {}
-    dev = 0
+    O = None
+    cores = 0
+    if args.oracle:
+        from oracle import oracle as O  # checker + timed CPU baseline (oracle/graph_oracle.c header)
 
-    def timed(fn, reps=3):
-        best = None
-        res = None
-        for _ in range(reps):
+        cores = O.effective_cores()
+    out = {"tool": "bench_algos", "device": torch.cuda.get_device_properties(0).name,
+           "cpu_build": O.timed_build_flags() if O is not None else None}
+
+    def timed(fn, reps=None):
+        best, res = None, None
+        for _ in range(reps or args.reps):
             torch.cuda.synchronize()
             t = time.perf_counter()
             res = fn()
@@ -41,6 +62,11 @@ def main():
             dt = time.perf_counter() - t
             best = dt if best is None else min(best, dt)
         return best, res
+
+    def roofline(alg_bytes, seconds):
+        ach = alg_bytes / seconds
+        return {"bound": "hbm", "algorithmic_bytes": int(alg_bytes), "achieved": round(ach / 1e9, 2), "peak": HBM_PEAK / 1e9,
+                "unit": "GB/s", "frac": round(ach / HBM_PEAK, 5), "timed": "wall time of the whole API call"}
 
     if "prapi" not in args.skip:
         # the drop-in call page_rank(&graph, config) with host result buffers: first call builds the
@@ -65,55 +91,65 @@ def main():
         sc = args.wcc_scale
         n = 1 << sc
         src, dst = synth.rmat_edges(sc, 42)
+        m = int(src.numel())
         g_out = synth.build_csr(n, src, dst, P.Direction.Outgoing, P.CsrLayout.Sorted)
         g_in = synth.build_csr(n, src, dst, P.Direction.Incoming, P.CsrLayout.Sorted)
         g = P.DirectedCsrGraph(g_out, g_in, P.CsrLayout.Sorted)
+        del src, dst
         t_aff, comp = timed(lambda: P.wcc_afforest(g, P.WccConfig()).to_vec())
-        t_base, comp_b = timed(lambda: P.wcc_baseline(g).to_vec())
-        rec = {"scale": sc, "edges": int(src.numel()), "afforest_ms": t_aff * 1e3, "baseline_ms": t_base * 1e3,
-               "components": int(np.unique(comp).size), "afforest_eq_baseline": bool(np.array_equal(comp, comp_b)),
-               "edges_per_s_afforest": src.numel() / t_aff}
-        if args.oracle:
-            from oracle import oracle as O
-
+        rec = {"config": f"RMAT scale-{sc} DirectedCsrGraph<u32> wcc_afforest (labels = min id, what UndirectedCsrGraph "
+                         f"wcc means, SURVEY a-5)", "nodes": n, "edges": m, "ms": t_aff * 1e3,
+               "edges_per_s": m / t_aff, "components": int(np.unique(comp).size)}
+        rec["roofline"] = roofline(4 * (n + 1) + 4 * (2 * m) + 8 * n, t_aff)
+        if not args.profile:
+            t_base, comp_b = timed(lambda: P.wcc_baseline(g).to_vec())
+            rec["baseline_ms"] = t_base * 1e3
+            rec["afforest_eq_baseline"] = bool(np.array_equal(comp, comp_b))
+        if O is not None:
             ooff, otgt, _ = g_out.host()
             ioff, itgt, _ = g_in.host()
             t = time.perf_counter()
-            ref = O.wcc(ooff, otgt, ioff, itgt, O.AFFOREST)
-            rec["oracle_s"] = time.perf_counter() - t
-            rec["bit_exact_vs_oracle"] = bool(np.array_equal(ref, comp))
+            ref = O.wcc(ooff, otgt, ioff, itgt, O.AFFOREST, native=True)
+            cpu_s = time.perf_counter() - t
+            rec["parity"] = {"bit_exact_vs_oracle": bool(np.array_equal(ref, comp)), "oracle": "orc_wcc AFFOREST (wcc.rs:158-301)"}
+            rec["cpu_baseline"] = {"value": m / cpu_s, "unit": "edges/s", "seconds": cpu_s, "cores": 1, "kind": "port",
+                                   "sample": "one full sequential run of orc_wcc on the same graph"}
         out["wcc"] = rec
-        del g, g_out, g_in, src, dst
+        del g, g_out, g_in
         torch.cuda.empty_cache()
 
     if "sssp" not in args.skip:
         sc = args.sssp_scale
         n = 1 << sc
         src, dst = synth.rmat_edges(sc, 42)
-        w = synth.rmat_weights(src.numel(), 44)
+        m = int(src.numel())
+        w = synth.rmat_weights(m, 44)
         g_out = synth.build_csr(n, src, dst, P.Direction.Outgoing, P.CsrLayout.Sorted, w)
+        del src, dst, w
         g = P.DirectedCsrGraph(g_out, g_out, P.CsrLayout.Sorted)
         deg = g_out.degrees()
         start = int(np.flatnonzero(deg > 0)[0])
-        t_s, dist = timed(lambda: P.delta_stepping(g, P.DeltaSteppingConfig(start, 0.1)), reps=2)
-        # fixed-point property on the device: d[v] <= d[u] (+) w for every edge, equality attained for every reached v
-        d = torch.from_numpy(dist).cuda()
-        off = torch.from_numpy(g_out.host()[0].astype(np.int64)).cuda()
-        tg = torch.from_numpy(g_out.host()[1].astype(np.int64)).cuda()
-        wv = torch.from_numpy(g_out.host()[2]).cuda()
-        su = torch.repeat_interleave(torch.arange(n, device="cuda"), off[1:] - off[:-1])
-        cand = d[su] + wv
-        reach = d[su] < 3.0e38
-        ok_le = bool((d[tg][reach] <= cand[reach]).all())
-        best = torch.full((n,), float("inf"), device="cuda")
-        best.scatter_reduce_(0, tg[reach], cand[reach], reduce="amin")
-        reached = (d < 3.0e38)
-        reached[start] = False
-        ok_eq = bool((best[reached] == d[reached]).all())
-        out["sssp"] = {"scale": sc, "edges": int(src.numel()), "ms": t_s * 1e3, "delta": 0.1, "start": start,
-                       "reached": int((dist < 3.0e38).sum()), "relaxed_edges_per_s": int(reach.sum()) / t_s,
-                       "fixed_point_le": ok_le, "fixed_point_attained": ok_eq}
-        del g, g_out, src, dst, w, d, off, tg, wv, su, cand, best
+        t_s, dist = timed(lambda: P.delta_stepping(g, P.DeltaSteppingConfig(start, 0.1)), reps=min(args.reps, 2))
+        reached = dist < np.float32(3.0e38)
+        relaxed = int(deg[reached].astype(np.int64).sum())
+        rec = {"config": f"RMAT scale-{sc}, f32 weights uniform (0,1] seed 44, delta 0.1, start node {start}", "nodes": n,
+               "edges": m, "ms": t_s * 1e3, "reached": int(reached.sum()), "relaxed_edges": relaxed,
+               "relaxed_edges_per_s": relaxed / t_s}
+        rec["roofline"] = roofline(12 * relaxed + 4 * int(reached.sum()), t_s)
+        if O is not None:
+            off, tgt, wv = g_out.host()
+            t = time.perf_counter()
+            ref = O.delta_stepping(off, tgt, wv, start, 0.1, native=True)
+            cpu_s = time.perf_counter() - t
+            mis = O.stale_check_misfires(ref, 0.1)
+            neq = int((ref.view(np.uint32) != dist.view(np.uint32)).sum())
+            rec["parity"] = {"bit_exact_vs_oracle": neq == 0, "nodes_differing": neq,
+                             "stale_check_misfire_candidates": int(mis.sum()),
+                             "oracle": "orc_delta_stepping (sssp.rs:38-204)"}
+            rec["cpu_baseline"] = {"value": relaxed / cpu_s, "unit": "relaxed edges/s", "seconds": cpu_s, "cores": 1,
+                                   "kind": "port", "sample": "one full sequential run of orc_delta_stepping on the same graph"}
+        out["sssp"] = rec
+        del g, g_out
         torch.cuda.empty_cache()
 
     if "tc" not in args.skip:
@@ -125,19 +161,37 @@ def main():
                                   P.CsrLayout.Deduplicated)
         t_build = time.perf_counter() - t0
         del src, dst
-        t_plain, tri_plain = (None, None)
-        if sc <= 22:
-            t_plain, tri_plain = timed(lambda: P.global_triangle_count(ug), reps=1)
         t0 = time.perf_counter()
         P.relabel_graph(ug)
         torch.cuda.synchronize()
         t_relabel = time.perf_counter() - t0
-        t_tc, tri = timed(lambda: P.global_triangle_count(ug), reps=2)
-        out["tc"] = {"scale": sc, "undirected_entries": ug.csr.m, "build_s": t_build, "relabel_s": t_relabel,
-                     "tc_ms": t_tc * 1e3, "triangles": tri, "edges_per_s": ug.csr.m / 2 / t_tc,
-                     "tc_unrelabelled_ms": None if t_plain is None else t_plain * 1e3,
-                     "relabel_invariant": None if tri_plain is None else bool(tri_plain == tri)}
-    print(json.dumps(out))
+        t_tc, tri = timed(lambda: P.global_triangle_count(ug), reps=min(args.reps, 2))
+        rec = {"config": f"RMAT scale-{sc} to_undirected(Deduplicated) + make_degree_ordered (the --relabel path)",
+               "nodes": n, "undirected_entries": ug.csr.m, "build_s": t_build, "relabel_s": t_relabel, "ms": t_tc * 1e3,
+               "triangles": tri, "edges_per_s": ug.csr.m / 2 / t_tc, "triangles_per_s": tri / t_tc}
+        off, tgt, _ = ug.csr.host()
+        # merge-stream bytes: for every entry v < u of N(u): rank of v in N(u) + |{w in N(v): w < v}|
+        d_off = torch.from_numpy(off.astype(np.int64)).cuda()
+        d_tgt = torch.from_numpy(tgt.astype(np.int64)).cuda()
+        rows = torch.repeat_interleave(torch.arange(n, device="cuda"), d_off[1:] - d_off[:-1])
+        lower = d_tgt < rows
+        low_len = torch.zeros(n, dtype=torch.int64, device="cuda").index_add_(0, rows[lower], torch.ones_like(rows[lower]))
+        pos = torch.arange(d_tgt.numel(), device="cuda") - d_off[rows]
+        stream = int((pos[lower] + low_len[d_tgt[lower]]).sum().item())
+        del d_off, d_tgt, rows, lower, low_len, pos
+        torch.cuda.empty_cache()
+        rec["roofline"] = roofline(4 * stream, t_tc)
+        if O is not None:
+            t = time.perf_counter()
+            ref = O.triangle_count(off, tgt, cores, native=True)
+            cpu_s = time.perf_counter() - t
+            rec["parity"] = {"bit_exact_vs_oracle": bool(ref == tri), "oracle_triangles": int(ref),
+                             "oracle": "orc_triangle_count (triangle_count.rs:47-70)"}
+            rec["cpu_baseline"] = {"value": ug.csr.m / 2 / cpu_s, "unit": "edges/s", "seconds": cpu_s, "cores": cores,
+                                   "kind": "port", "sample": "one full run of orc_triangle_count (64-node dynamic chunks) "
+                                                             "on the same relabelled graph"}
+        out["tc"] = rec
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
