@@ -1,17 +1,44 @@
-//! Drop-in for the hot path of `graph::prelude` (crates/algos/src/prelude.rs:1-7) on MI355X.
+//! `graph::prelude` algorithms on MI355X: the same public names, generic bounds, config structs and
+//! return types as `crates/algos` (prelude.rs:1-7), with bodies that call the C ABI of
+//! `include/graph_mi355x.h`.  A caller swaps `use graph::prelude::*` for `use graph_mi355x::prelude::*`.
 //!
-//! NOT COMPILED HERE: the build image has no Rust toolchain.  This file is the binding a
-//! maintainer adds; every `extern "C"` item is declared in include/graph_mi355x.h.
+//! NOT COMPILED IN THIS REPOSITORY'S ENVIRONMENT (no rustc / cargo in the image).  The same mirror exists,
+//! compiled and tested on the GPU, as C++ (`include/graph_prelude.hpp`) and Python (`graph_amd/prelude.py`).
 //!
-//! The CSR arrays of the upstream `DirectedCsrGraph<u32>` are reachable from outside the crate
-//! because the neighbour lists are laid out back to back (csr.rs:87-92,146-172):
-//! `g.in_neighbors(0).as_slice().as_ptr()` is the base of `targets`, offsets are the prefix sum
-//! of the degrees.  Inside the upstream workspace one would read `Csr::offsets/targets` directly.
-use std::ffi::{c_char, c_int, c_void, CStr};
+//! Signatures replaced (reference file:line):
+//!   page_rank<NI, G>(&G, PageRankConfig) -> (Vec<f32>, usize, f64)        crates/algos/src/page_rank.rs:58-62
+//!   wcc_afforest / wcc_afforest_dss / wcc_baseline -> impl Components<NI>  crates/algos/src/wcc.rs:103,127,144
+//!   delta_stepping<NI, G>(&G, DeltaSteppingConfig) -> Vec<AtomicF32>       crates/algos/src/sssp.rs:38-42
+//!   global_triangle_count<NI, G>(&G) -> u64                                crates/algos/src/triangle_count.rs:22-26
+//!
+//! How the graph reaches the GPU.  The traits only promise iterators (`NeighborsIterator<'a>: Iterator<Item =
+//! &'a NI>`, crates/builder/src/lib.rs:336-412), so the generic path walks them once — O(n + m) on the host —
+//! into u32 (NI up to 32 bits) or u64 (`u64` / `usize`, narrowed with a range check by `gm_csr_upload_u64`)
+//! arrays, splits `Target<NI, f32>` (AoS, crates/builder/src/graph/mod.rs:5-10) into targets + weights, and
+//! uploads them.  The resulting handles are cached in a process-wide map keyed by (address of the graph,
+//! node_count, edge_count, which CSRs), so every later call on the same graph object starts on resident data:
+//! "offsets/targets uploaded once to HBM".  `forget(&graph)` drops the entry when a graph is mutated in place
+//! (`make_degree_ordered`) or freed.
+use std::any::TypeId;
+use std::collections::HashMap;
+use std::ffi::{c_char, c_int, CStr};
+use std::hash::Hash;
+use std::sync::{Arc, Mutex, OnceLock};
 
 use atomic_float::AtomicF32;
 use graph_builder::prelude::*;
 
+pub mod prelude {
+    pub use super::{
+        delta_stepping, forget, global_triangle_count, page_rank, relabel_graph, wcc_afforest, wcc_afforest_dss,
+        wcc_baseline, Components, DeltaSteppingConfig, PageRankConfig, WccConfig,
+    };
+    pub use graph_builder::prelude::*;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI (include/graph_mi355x.h)
+// ------------------------------------------------------------------------------------------------
 #[repr(C)]
 pub struct GmCsr {
     _private: [u8; 0],
@@ -21,102 +48,344 @@ extern "C" {
     fn gm_last_error() -> *const c_char;
     fn gm_csr_upload_u32(offsets: *const u32, targets: *const u32, weights: *const f32, n: u64, m: u64,
                          device: c_int, out: *mut *mut GmCsr) -> c_int;
+    fn gm_csr_upload_u64(offsets: *const u64, targets: *const u64, weights: *const f32, n: u64, m: u64,
+                         device: c_int, out: *mut *mut GmCsr) -> c_int;
     fn gm_csr_free(csr: *mut GmCsr);
-    fn gm_page_rank(in_csr: *const GmCsr, out_degree: *const u32, max_iterations: u64, tolerance: f64,
-                    damping_factor: f32, mode: c_int, scores_out: *mut f32, iterations_out: *mut u64,
-                    error_out: *mut f64) -> c_int;
     fn gm_page_rank_directed(out_csr: *const GmCsr, in_csr: *const GmCsr, max_iterations: u64, tolerance: f64,
                              damping_factor: f32, mode: c_int, scores_out: *mut f32, iterations_out: *mut u64,
                              error_out: *mut f64) -> c_int;
+    fn gm_page_rank_multi(out_csr: *const GmCsr, in_csr: *const GmCsr, devices: *const c_int, n_devices: u32,
+                          max_iterations: u64, tolerance: f64, damping_factor: f32, scores_out: *mut f32,
+                          iterations_out: *mut u64, error_out: *mut f64) -> c_int;
     fn gm_wcc_afforest(out_csr: *const GmCsr, in_csr: *const GmCsr, neighbor_rounds: u64, sampling_size: u64,
                        components_out: *mut u32) -> c_int;
+    fn gm_wcc_baseline(out_csr: *const GmCsr, components_out: *mut u32) -> c_int;
     fn gm_sssp_delta_stepping(out_csr: *const GmCsr, start_node: u64, delta: f32, distances_out: *mut f32) -> c_int;
     fn gm_triangle_count(undirected_csr: *const GmCsr, triangles_out: *mut u64) -> c_int;
 }
 
+/// The reference's functions are infallible and panic on bad input (start node out of range, empty sample
+/// set, ...): the shim keeps that contract and carries the library's message into the panic.
 fn check(status: c_int) {
     if status != 0 {
-        // the reference's functions are infallible and panic on bad input; keep that contract
         let msg = unsafe { CStr::from_ptr(gm_last_error()) }.to_string_lossy().into_owned();
         panic!("graph_mi355x status {status}: {msg}");
     }
 }
 
-/// One device-resident CSR, uploaded once and cached by the caller next to the graph.
-pub struct DeviceCsr(*mut GmCsr);
+struct DeviceCsr(*mut GmCsr);
 unsafe impl Send for DeviceCsr {}
-unsafe impl Sync for DeviceCsr {}
+unsafe impl Sync for DeviceCsr {} // a gm_csr is immutable after creation (header: "may be used from several host threads")
 impl Drop for DeviceCsr {
     fn drop(&mut self) {
         unsafe { gm_csr_free(self.0) }
     }
 }
 
-impl DeviceCsr {
-    /// `degree(u)` and `neighbors(u)` are the graph's accessors for one direction.
-    pub fn upload(n: u32, degree: impl Fn(u32) -> u32, first_list: *const u32) -> Self {
-        let mut offsets = Vec::with_capacity(n as usize + 1);
-        let mut acc = 0u32;
-        offsets.push(0);
-        for u in 0..n {
-            acc += degree(u);
-            offsets.push(acc);
+/// One neighbour list walked into flat arrays; `wide` = ids do not fit u32 by type (u64 / usize / i64 ...).
+fn upload<NI: Idx>(node_count: usize, lists: impl Fn(NI, &mut dyn FnMut(NI, Option<f32>))) -> DeviceCsr {
+    let wide = std::mem::size_of::<NI>() > 4;
+    let mut weights: Vec<f32> = Vec::new();
+    let mut weighted = false;
+    let mut out = std::ptr::null_mut();
+    if wide {
+        let (mut off, mut tgt) = (Vec::<u64>::with_capacity(node_count + 1), Vec::<u64>::new());
+        off.push(0);
+        for u in 0..node_count {
+            lists(NI::new(u), &mut |v, w| {
+                tgt.push(v.index() as u64);
+                if let Some(w) = w {
+                    weighted = true;
+                    weights.push(w);
+                }
+            });
+            off.push(tgt.len() as u64); // u64: no overflow; gm_csr_upload_u64 rejects n or m >= 2^32 (GM_ERR_RANGE)
         }
-        let mut out = std::ptr::null_mut();
-        check(unsafe { gm_csr_upload_u32(offsets.as_ptr(), first_list, std::ptr::null(), n as u64, acc as u64, 0, &mut out) });
-        DeviceCsr(out)
+        let wp = if weighted { weights.as_ptr() } else { std::ptr::null() };
+        check(unsafe { gm_csr_upload_u64(off.as_ptr(), tgt.as_ptr(), wp, node_count as u64, tgt.len() as u64, 0, &mut out) });
+    } else {
+        let (mut off, mut tgt) = (Vec::<u32>::with_capacity(node_count + 1), Vec::<u32>::new());
+        off.push(0);
+        for u in 0..node_count {
+            lists(NI::new(u), &mut |v, w| {
+                tgt.push(v.index() as u32);
+                if let Some(w) = w {
+                    weighted = true;
+                    weights.push(w);
+                }
+            });
+            assert!(tgt.len() < u32::MAX as usize, "more than 2^32 - 1 target entries: beyond the device id type");
+            off.push(tgt.len() as u32);
+        }
+        let wp = if weighted { weights.as_ptr() } else { std::ptr::null() };
+        check(unsafe { gm_csr_upload_u32(off.as_ptr(), tgt.as_ptr(), wp, node_count as u64, tgt.len() as u64, 0, &mut out) });
+    }
+    DeviceCsr(out)
+}
+
+// ------------------------------------------------------------------------------------------------
+// handle cache: "upload once", next to the graph
+// ------------------------------------------------------------------------------------------------
+#[derive(Clone, Copy, PartialEq, Eq, Hash)]
+enum Kind {
+    Directed,         // out + in lists
+    DirectedWeighted, // out lists with f32 values
+    OutOnly,          // wcc_baseline needs nothing else
+    Undirected,
+}
+
+#[derive(Clone, Copy, PartialEq, Eq, Hash)]
+struct Key {
+    graph: usize, // address of the graph object
+    ty: TypeId,   // its node id type
+    nodes: usize,
+    edges: usize,
+    kind: Kind,
+}
+
+struct Resident {
+    out: Option<DeviceCsr>,
+    inc: Option<DeviceCsr>,
+}
+
+fn cache() -> &'static Mutex<HashMap<Key, Arc<Resident>>> {
+    static CACHE: OnceLock<Mutex<HashMap<Key, Arc<Resident>>>> = OnceLock::new();
+    CACHE.get_or_init(|| Mutex::new(HashMap::new()))
+}
+
+fn resident<NI: Idx, G: Graph<NI>>(graph: &G, kind: Kind, build: impl FnOnce() -> Resident) -> Arc<Resident> {
+    let key = Key {
+        graph: graph as *const G as *const u8 as usize,
+        ty: TypeId::of::<NI>(),
+        nodes: graph.node_count().index(),
+        edges: graph.edge_count().index(),
+        kind,
+    };
+    if let Some(r) = cache().lock().unwrap().get(&key) {
+        return r.clone();
+    }
+    let r = Arc::new(build()); // outside the lock: uploads of different graphs may overlap
+    cache().lock().unwrap().entry(key).or_insert(r).clone()
+}
+
+/// Drops every device copy made for `graph` (call before mutating a graph in place or after freeing it:
+/// the cache is keyed by address + counts and cannot see a content change).
+pub fn forget<G>(graph: &G) {
+    let addr = graph as *const G as *const u8 as usize;
+    cache().lock().unwrap().retain(|k, _| k.graph != addr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// PageRank — crates/algos/src/page_rank.rs:14-111
+// ------------------------------------------------------------------------------------------------
+#[derive(Copy, Clone, Debug)]
+pub struct PageRankConfig {
+    pub max_iterations: usize,
+    pub tolerance: f64,
+    pub damping_factor: f32,
+}
+
+impl PageRankConfig {
+    pub const DEFAULT_MAX_ITERATIONS: usize = 20;
+    pub const DEFAULT_TOLERANCE: f64 = 1E-4;
+    pub const DEFAULT_DAMPING_FACTOR: f32 = 0.85;
+
+    pub fn new(max_iterations: usize, tolerance: f64, damping_factor: f32) -> Self {
+        Self { max_iterations, tolerance, damping_factor }
     }
 }
 
-/// Device mirror of a `DirectedCsrGraph<u32>` (build once, reuse for every algorithm call).
-pub struct DeviceDirected {
-    pub out: DeviceCsr,
-    pub inc: DeviceCsr,
-    pub node_count: u32,
-}
-
-impl DeviceDirected {
-    pub fn new(g: &DirectedCsrGraph<u32>) -> Self {
-        let n = g.node_count();
-        let out = DeviceCsr::upload(n, |u| g.out_degree(u), g.out_neighbors(0).as_slice().as_ptr());
-        let inc = DeviceCsr::upload(n, |u| g.in_degree(u), g.in_neighbors(0).as_slice().as_ptr());
-        Self { out, inc, node_count: n }
+impl Default for PageRankConfig {
+    fn default() -> Self {
+        Self::new(Self::DEFAULT_MAX_ITERATIONS, Self::DEFAULT_TOLERANCE, Self::DEFAULT_DAMPING_FACTOR)
     }
 }
 
-/// `page_rank(&graph, config) -> (Vec<f32>, usize, f64)` — crates/algos/src/page_rank.rs:58-62
-pub fn page_rank(g: &DeviceDirected, max_iterations: usize, tolerance: f64, damping_factor: f32) -> (Vec<f32>, usize, f64) {
-    let mut scores = vec![0f32; g.node_count as usize];
+fn directed<NI, G>(graph: &G) -> Arc<Resident>
+where
+    NI: Idx,
+    G: Graph<NI> + DirectedNeighbors<NI> + Sync,
+{
+    let n = graph.node_count().index();
+    resident(graph, Kind::Directed, || Resident {
+        out: Some(upload::<NI>(n, |u, push| graph.out_neighbors(u).for_each(|v| push(*v, None)))),
+        inc: Some(upload::<NI>(n, |u, push| graph.in_neighbors(u).for_each(|v| push(*v, None)))),
+    })
+}
+
+/// Same signature as the reference.  `GM_DEVICES=k` (k > 1) runs the call 1-D partitioned over the first k
+/// GPUs of the node (`gm_page_rank_multi`: RCCL all-gather of out_scores per sweep); default: one GPU.
+pub fn page_rank<NI, G>(graph: &G, config: PageRankConfig) -> (Vec<f32>, usize, f64)
+where
+    NI: Idx,
+    G: Graph<NI> + DirectedDegrees<NI> + DirectedNeighbors<NI> + Sync,
+{
+    let PageRankConfig { max_iterations, tolerance, damping_factor } = config;
+    let g = directed(graph);
+    let mut scores = vec![0f32; graph.node_count().index()];
     let (mut iterations, mut error) = (0u64, 0f64);
+    let (out, inc) = (g.out.as_ref().unwrap().0, g.inc.as_ref().unwrap().0);
+    let devices: u32 = std::env::var("GM_DEVICES").ok().and_then(|v| v.parse().ok()).unwrap_or(1);
     check(unsafe {
-        // both CSRs are resident: out-degrees come from the out-CSR's offsets on the device
-        gm_page_rank_directed(g.out.0, g.inc.0, max_iterations as u64, tolerance, damping_factor, 0,
-                              scores.as_mut_ptr(), &mut iterations, &mut error)
+        if devices > 1 {
+            gm_page_rank_multi(out, inc, std::ptr::null(), devices, max_iterations as u64, tolerance, damping_factor,
+                               scores.as_mut_ptr(), &mut iterations, &mut error)
+        } else {
+            // mode 0 = GM_PR_AUTO: n <= 16384 runs the reference's exact in-place order, else synchronous sweeps
+            gm_page_rank_directed(out, inc, max_iterations as u64, tolerance, damping_factor, 0, scores.as_mut_ptr(),
+                                  &mut iterations, &mut error)
+        }
     });
     (scores, iterations as usize, error)
 }
 
-/// `wcc_afforest(&graph, config) -> impl Components<u32>` — crates/algos/src/wcc.rs:127-141
-pub fn wcc_afforest(g: &DeviceDirected, neighbor_rounds: usize, sampling_size: usize) -> Vec<u32> {
-    let mut comp = vec![0u32; g.node_count as usize];
-    check(unsafe { gm_wcc_afforest(g.out.0, g.inc.0, neighbor_rounds as u64, sampling_size as u64, comp.as_mut_ptr()) });
-    comp
+// ------------------------------------------------------------------------------------------------
+// WCC — crates/algos/src/wcc.rs:43-156
+// ------------------------------------------------------------------------------------------------
+#[derive(Copy, Clone, Debug)]
+pub struct WccConfig {
+    pub chunk_size: usize, // a CPU scheduling knob (rayon chunks): no meaning on the device
+    pub neighbor_rounds: usize,
+    pub sampling_size: usize,
 }
 
-/// `delta_stepping(&graph, config) -> Vec<AtomicF32>` — crates/algos/src/sssp.rs:38-42
-/// (`out_weighted` uploaded with the f32 values of `out_neighbors_with_values`).
-pub fn delta_stepping(out_weighted: &DeviceCsr, node_count: usize, start_node: usize, delta: f32) -> Vec<AtomicF32> {
-    let mut dist = vec![0f32; node_count];
-    check(unsafe { gm_sssp_delta_stepping(out_weighted.0, start_node as u64, delta, dist.as_mut_ptr()) });
+impl WccConfig {
+    pub const DEFAULT_CHUNK_SIZE: usize = 16384;
+    pub const DEFAULT_NEIGHBOR_ROUNDS: usize = 2;
+    pub const DEFAULT_SAMPLING_SIZE: usize = 1024;
+
+    pub fn new(chunk_size: usize, neighbor_rounds: usize, sampling_size: usize) -> Self {
+        Self { chunk_size, neighbor_rounds, sampling_size }
+    }
+}
+
+impl Default for WccConfig {
+    fn default() -> Self {
+        Self::new(Self::DEFAULT_CHUNK_SIZE, Self::DEFAULT_NEIGHBOR_ROUNDS, Self::DEFAULT_SAMPLING_SIZE)
+    }
+}
+
+pub trait Components<NI> {
+    fn component(&self, node: NI) -> NI;
+
+    fn to_vec(self) -> Vec<NI>;
+}
+
+/// component(u) = minimum node id of u's weakly connected component — what `Afforest::find` /
+/// `DisjointSetStruct::find` return after the final compress (afforest.rs:22-56, dss.rs:38-116).
+struct DeviceComponents(Vec<u32>);
+
+impl<NI: Idx> Components<NI> for DeviceComponents {
+    fn component(&self, node: NI) -> NI {
+        NI::new(self.0[node.index()] as usize)
+    }
+
+    fn to_vec(self) -> Vec<NI> {
+        self.0.into_iter().map(|c| NI::new(c as usize)).collect()
+    }
+}
+
+pub fn wcc_afforest<NI, G>(graph: &G, config: WccConfig) -> impl Components<NI>
+where
+    NI: Idx + Hash,
+    G: Graph<NI> + DirectedDegrees<NI> + DirectedNeighbors<NI> + Sync,
+{
+    let g = directed(graph);
+    let mut comp = vec![0u32; graph.node_count().index()];
+    check(unsafe {
+        gm_wcc_afforest(g.out.as_ref().unwrap().0, g.inc.as_ref().unwrap().0, config.neighbor_rounds as u64,
+                        config.sampling_size as u64, comp.as_mut_ptr())
+    });
+    DeviceComponents(comp)
+}
+
+/// The union-find backend is a CPU data-structure choice; `component()` is the same minimum id.
+pub fn wcc_afforest_dss<NI, G>(graph: &G, config: WccConfig) -> impl Components<NI>
+where
+    NI: Idx + Hash,
+    G: Graph<NI> + DirectedDegrees<NI> + DirectedNeighbors<NI> + Sync,
+{
+    wcc_afforest(graph, config)
+}
+
+pub fn wcc_baseline<NI, G>(graph: &G, _config: WccConfig) -> impl Components<NI>
+where
+    NI: Idx,
+    G: Graph<NI> + DirectedNeighbors<NI> + Sync,
+{
+    let n = graph.node_count().index();
+    let g = resident(graph, Kind::OutOnly, || Resident {
+        out: Some(upload::<NI>(n, |u, push| graph.out_neighbors(u).for_each(|v| push(*v, None)))),
+        inc: None,
+    });
+    let mut comp = vec![0u32; n];
+    check(unsafe { gm_wcc_baseline(g.out.as_ref().unwrap().0, comp.as_mut_ptr()) });
+    DeviceComponents(comp)
+}
+
+// ------------------------------------------------------------------------------------------------
+// SSSP — crates/algos/src/sssp.rs:18-102
+// ------------------------------------------------------------------------------------------------
+#[derive(Copy, Clone, Debug)]
+pub struct DeltaSteppingConfig {
+    pub start_node: usize,
+    pub delta: f32,
+}
+
+impl DeltaSteppingConfig {
+    pub fn new(start_node: usize, delta: f32) -> Self {
+        Self { start_node, delta }
+    }
+}
+
+/// Unreachable nodes hold `f32::MAX` (sssp.rs:12), not infinity; an out-of-range start node panics (:52).
+pub fn delta_stepping<NI, G>(graph: &G, config: DeltaSteppingConfig) -> Vec<AtomicF32>
+where
+    NI: Idx,
+    G: Graph<NI> + DirectedNeighborsWithValues<NI, f32> + Sync,
+{
+    let n = graph.node_count().index();
+    let g = resident(graph, Kind::DirectedWeighted, || Resident {
+        // Target<NI, f32> is an 8-byte AoS record on the host; the device streams targets and weights apart
+        out: Some(upload::<NI>(n, |u, push| {
+            graph.out_neighbors_with_values(u).for_each(|t| push(t.target, Some(t.value)))
+        })),
+        inc: None,
+    });
+    let mut dist = vec![0f32; n];
+    check(unsafe {
+        gm_sssp_delta_stepping(g.out.as_ref().unwrap().0, config.start_node as u64, config.delta, dist.as_mut_ptr())
+    });
     dist.into_iter().map(AtomicF32::new).collect()
 }
 
-/// `global_triangle_count(&graph) -> u64` — crates/algos/src/triangle_count.rs:22-26
-pub fn global_triangle_count(undirected: &DeviceCsr) -> u64 {
-    let mut t = 0u64;
-    check(unsafe { gm_triangle_count(undirected.0, &mut t) });
-    t
+// ------------------------------------------------------------------------------------------------
+// Triangle count — crates/algos/src/triangle_count.rs:12-86
+// ------------------------------------------------------------------------------------------------
+/// Lists must be sorted (`CsrLayout::Sorted` / `Deduplicated`); unsorted lists are rejected (status -5 ->
+/// panic) where the reference silently returns a meaningless number.
+pub fn global_triangle_count<NI, G>(graph: &G) -> u64
+where
+    NI: Idx,
+    G: Graph<NI> + UndirectedNeighbors<NI> + Sync,
+{
+    let n = graph.node_count().index();
+    let g = resident(graph, Kind::Undirected, || Resident {
+        out: Some(upload::<NI>(n, |u, push| graph.neighbors(u).for_each(|v| push(*v, None)))),
+        inc: None,
+    });
+    let mut triangles = 0u64;
+    check(unsafe { gm_triangle_count(g.out.as_ref().unwrap().0, &mut triangles) });
+    triangles
 }
 
-#[allow(dead_code)]
-fn _unused(_: *mut c_void) {}
+/// `make_degree_ordered` rewrites the host graph in place (graph_ops.rs:511-638), so any device copy of
+/// it is stale afterwards: drop it, the next algorithm call uploads the relabelled lists.
+pub fn relabel_graph<NI, G, EV>(graph: &mut G)
+where
+    NI: Idx,
+    G: RelabelByDegreeOp<NI, EV>,
+{
+    forget(graph);
+    graph.make_degree_ordered();
+}

@@ -1,0 +1,84 @@
+//! The reference's own unit tests for the hot path, restated against this crate's prelude (edge lists
+//! instead of GDL strings, which are out of scope): crates/algos/src/page_rank.rs:175-197, lib.rs:92-141,
+//! wcc.rs:307-329, sssp.rs:282-313, triangle_count.rs:93-130.  Needs an MI355X and libgraph_mi355x.so
+//! (`GRAPH_MI355X_LIB_DIR`, see build.rs); not run in this repository's build image (no rustc).
+use std::sync::atomic::Ordering;
+
+use graph_mi355x::prelude::*;
+
+#[test]
+fn pr_two_components() {
+    // "(a)-->()-->()<--(a),(b)-->()-->()<--(b)"
+    let graph: DirectedCsrGraph<usize> = GraphBuilder::new()
+        .csr_layout(CsrLayout::Sorted)
+        .edges(vec![(0, 1), (1, 2), (0, 2), (3, 4), (4, 5), (3, 5)])
+        .build();
+    let (scores, _, _) = page_rank(&graph, PageRankConfig::default());
+    let expected: Vec<f32> = vec![0.024999997, 0.035624996, 0.06590624, 0.024999997, 0.035624996, 0.06590624];
+    assert_eq!(scores, expected);
+}
+
+#[test]
+fn pr_readme_graph() {
+    let graph: DirectedCsrGraph<usize> = GraphBuilder::new()
+        .edges(vec![
+            (1, 2), (2, 1), (4, 0), (4, 1), (5, 4), (5, 1), (5, 6), (6, 1), (6, 5), (7, 1), (7, 5), (8, 1), (8, 5),
+            (9, 1), (9, 5), (10, 1), (10, 5), (11, 5), (12, 5),
+        ])
+        .build();
+    let (ranks, iterations, _) = page_rank(&graph, PageRankConfig::new(10, 1E-4, 0.85));
+    assert_eq!(iterations, 10);
+    let expected = vec![
+        0.024064068, 0.3145448, 0.27890152, 0.01153846, 0.029471997, 0.06329483, 0.029471997, 0.01153846, 0.01153846,
+        0.01153846, 0.01153846, 0.01153846, 0.01153846,
+    ];
+    assert_eq!(ranks, expected);
+}
+
+#[test]
+fn two_components_afforest_and_dss_and_baseline() {
+    let graph: DirectedCsrGraph<usize> = GraphBuilder::new().edges(vec![(0, 1), (2, 3)]).build();
+    let res = wcc_afforest_dss(&graph, WccConfig::default());
+    assert_eq!(res.component(0), res.component(1));
+    assert_eq!(res.component(2), res.component(3));
+    assert_ne!(res.component(1), res.component(2));
+    let res = wcc_afforest(&graph, WccConfig::default());
+    assert_eq!(res.component(0), res.component(1));
+    assert_eq!(res.component(2), res.component(3));
+    assert_ne!(res.component(1), res.component(2));
+    assert_eq!(wcc_baseline(&graph, WccConfig::default()).to_vec(), vec![0usize, 0, 2, 2]);
+}
+
+#[test]
+fn sssp_six_nodes() {
+    let graph: DirectedCsrGraph<usize, (), f32> = GraphBuilder::new()
+        .csr_layout(CsrLayout::Deduplicated)
+        .edges_with_values(vec![
+            (0, 1, 4.0), (0, 2, 2.0), (1, 2, 5.0), (1, 3, 10.0), (2, 4, 3.0), (3, 5, 11.0), (4, 3, 4.0),
+        ])
+        .build();
+    let actual: Vec<f32> =
+        delta_stepping(&graph, DeltaSteppingConfig::new(0, 3.0)).into_iter().map(|d| d.load(Ordering::Relaxed)).collect();
+    assert_eq!(actual, vec![0.0, 4.0, 2.0, 9.0, 5.0, 20.0]);
+}
+
+#[test]
+fn tc_three_shapes() {
+    for edges in [
+        vec![(0, 1), (1, 2), (0, 2), (3, 4), (4, 5), (3, 5)], // two components
+        vec![(0, 1), (1, 2), (0, 2), (0, 3), (3, 4), (0, 4)], // two triangles sharing a node
+        vec![(0, 1), (1, 2), (0, 2), (1, 3), (2, 3)],         // diamond
+    ] {
+        let graph: UndirectedCsrGraph<u32> = GraphBuilder::new().csr_layout(CsrLayout::Deduplicated).edges(edges).build();
+        assert_eq!(global_triangle_count(&graph), 2);
+    }
+}
+
+#[test]
+fn second_call_reuses_the_resident_graph() {
+    let graph: DirectedCsrGraph<u32> = GraphBuilder::new().csr_layout(CsrLayout::Sorted).edges(vec![(0, 1), (1, 2), (2, 0)]).build();
+    let a = page_rank(&graph, PageRankConfig::default());
+    let b = page_rank(&graph, PageRankConfig::default()); // no second upload: the handle cache is keyed by the graph
+    assert_eq!(a.0, b.0);
+    forget(&graph);
+}

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <new>
 
@@ -164,7 +165,6 @@ struct PhaseTimer { // wall clock around stream-ordered work; only active under 
 
 namespace gm {
 struct PbPlan; // propagation-blocking layout of a CSR (pagerank_pb.hip); immutable once built
-void pb_plan_destroy(PbPlan *plan);
 } // namespace gm
 
 // The opaque handle of include/graph_mi355x.h.
@@ -180,11 +180,6 @@ struct gm_csr {
     // Derived, immutable layouts built on first use and kept for the lifetime of the handle ("upload
     // once"): PageRank's propagation-blocking plan, keyed by the length of the x vector it was built for.
     mutable std::mutex cache_mu;
-    mutable std::map<uint64_t, gm::PbPlan *> pb_plans;
+    mutable std::map<uint64_t, std::shared_ptr<const gm::PbPlan>> pb_plans;
     mutable std::atomic<uint64_t> page_rank_calls{0}; // gm_page_rank calls seen by this handle (engine choice); calls may run concurrently
-    ~gm_csr()
-    {
-        for (auto &kv : pb_plans)
-            gm::pb_plan_destroy(kv.second);
-    }
 };

@@ -398,7 +398,8 @@ GM_API int gm_pr_create_with(const gm_csr *csr, uint64_t n_global, uint64_t row_
     pr->init = 1.0f / (float)n_global;
     pr->base = (1.0f - damping_factor) / (float)n_global;
     if (engine == GM_PR_ENGINE_PB) {
-        int rc = gm::pb_plan_get(csr, x_len, &pr->pb);
+        int rc = gm::pb_plan_get(csr, x_len, &pr->pb_keep);
+        pr->pb = pr->pb_keep.get();
         if (rc == GM_OK)
             rc = gm::pb_scratch_create(pr->pb, &pr->pb_scratch);
         if (rc != GM_OK) {
@@ -556,6 +557,14 @@ GM_API int gm_pr_sweep_bin(gm_pr *pr, uint64_t d_x_in_global, uint64_t x_lo, uin
     gm::DeviceGuard guard(pr->csr->device);
     return gm::pb_sweep_bin_range(pr->pb, pr->pb_scratch, reinterpret_cast<const float *>(d_x_in_global), x_lo, x_hi,
                                   (hipStream_t)stream);
+}
+
+GM_API int gm_pr_plan_info(const gm_pr *pr, uint64_t *info, uint32_t count)
+{
+    GM_CHECK(pr && info, GM_ERR_INVALID, "gm_pr_plan_info: null argument");
+    GM_CHECK(pr->engine == GM_PR_ENGINE_PB, GM_ERR_UNSUPPORTED, "gm_pr_plan_info: not a propagation-blocking engine");
+    gm::pb_plan_info(pr->pb, pr->pb_scratch, info, count);
+    return GM_OK;
 }
 
 GM_API int gm_pr_sweep_hot(gm_pr *pr, uint64_t d_x_in_global, void *stream)

@@ -26,7 +26,7 @@ __device__ __forceinline__ double pr_finalize(uint32_t r, float incoming, float 
 
 struct PbPlan;    // pagerank_pb.hip: immutable layout, cached in the gm_csr handle
 struct PbScratch; // per-engine mutable buffers (value stream, partial sums, tickets, errors, hot values)
-int pb_plan_get(const gm_csr *csr, uint64_t x_len, const PbPlan **out); // build on first use, then shared
+int pb_plan_get(const gm_csr *csr, uint64_t x_len, std::shared_ptr<const PbPlan> *out); // build on first use, then shared
 int pb_scratch_create(const PbPlan *plan, PbScratch **out);
 void pb_scratch_destroy(PbScratch *scratch);
 int pb_sweep_main(const PbPlan *plan, PbScratch *scratch, const float *x_in, float *x_out, float *scores,
@@ -42,6 +42,7 @@ int pb_sweep_hot(const PbPlan *plan, PbScratch *scratch, const float *x_in, hipS
 int pb_sweep_accum_part(const PbPlan *plan, PbScratch *scratch, const float *x_in, float *x_out, float *scores,
                         const uint32_t *outdeg, float base, float damping, uint32_t part, int stage_hot, hipStream_t st);
 uint64_t pb_work_items(const PbPlan *plan);
+void pb_plan_info(const PbPlan *plan, const PbScratch *scratch, uint64_t *info, uint32_t count);
 
 } // namespace gm
 
@@ -54,7 +55,8 @@ struct gm_pr {
     const uint32_t *outdeg = nullptr;
     float damping = 0.85f, base = 0.0f, init = 0.0f;
     gm::DevBuf tile_row, head, tail, tile_err, blk_err, ticket; // pull engine
-    const gm::PbPlan *pb = nullptr;                             // propagation-blocking engine (plan owned by csr)
+    std::shared_ptr<const gm::PbPlan> pb_keep;                  // propagation-blocking engine: shared plan (cached in the csr)
+    const gm::PbPlan *pb = nullptr;
     gm::PbScratch *pb_scratch = nullptr;
     ~gm_pr()
     {

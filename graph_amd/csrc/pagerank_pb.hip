@@ -24,7 +24,23 @@
 //
 // The row sum is therefore the exactly rounded sum of the f32 out_scores: deterministic, identical
 // for any partition of the rows over GPUs, and closer to the real-number fixed point than any f32
-// summation order (the reference's left-to-right order drifts by ~sqrt(in-degree) * 2^-24).
+// summation order.
+//
+// HUB ROWS.  The reference adds a row's in-neighbours left to right in f32 (page_rank.rs:143-146), and on a
+// long row that order has a SYSTEMATIC drift: thousands of in-neighbours carry the same out_score
+// ((1-d)/n / out_degree of nodes without in-edges), every one of them is rounded the same way against the
+// running sum, and the errors add up instead of cancelling (measured at RMAT scale 26: the reference's own
+// score of the 854,315-in-edge row is 8.5e-4 away from the exact row sum, and every node that row points to
+// inherits that).  Matching the reference within 1e-5 therefore means reproducing its rounding, not being
+// more exact.  Rows with at least `hub_deg` in-edges (default 4096, GM_PB_HUB_DEG) get the first accumulator
+// slots of their bin and never use the hot path, so all their terms arrive in the value stream in ascending
+// source order — the CSR order of the Sorted / Deduplicated layouts.  The accumulate kernel processes such a
+// bin one 4096-entry step at a time: a term v of a hub row is first rounded to the f32 grid of the row's
+// running sum S — rint(v / ulp(S)) * ulp(S), what fl(S + v) - S is while S stays in one binade, whatever the
+// order inside the step — and the step's rounded terms are added as exact integers.  Between steps (one
+// __syncthreads) S, its binade and ulp are updated; a step in which S crosses into the next binade is
+// resolved by interpolation between the step's sums rounded at ulp and at 2 ulp.  Deterministic (integer
+// sums, fixed step boundaries); measured against the left-to-right sum: DESIGN.md section 5.
 //
 // HBM traffic per edge and sweep: cold 2 B (source id) + 4 B (value write) + 4 B (value read) + 2 B (slot)
 // = 12 B, hot 4 B, all streaming, against 8 B "algorithmic" of which 4 B are a random gather.
@@ -34,6 +50,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <memory>
 #include <utility>
 #include <vector>
 
@@ -47,6 +64,13 @@ constexpr int PB_ACC_BLOCK = 1024;
 constexpr uint32_t PB_VEC = 4;                  // segments are padded to multiples of 4 entries in both streams
 constexpr uint32_t PB_WBLK = kWave * PB_VEC;    // entries one wavefront covers per step (256)
 constexpr uint16_t PB_NULL = 0xFFFFu;
+constexpr uint32_t PB_HUB_Q = 256;      // replicated step sums of the hub rows of a bin (hub slots x replicas)
+constexpr size_t PB_ACC_STATIC = 13824; // static LDS of pb_accum_kernel, rounded up
+struct HubUnit {
+    float iu; // 1 / ulp(S) of a hub row's running sum S
+    int sh;   // ulp(S) = 2^sh units of the 2^-62 fixed point; < 0: S has no binade yet
+};
+constexpr uint32_t PB_HUB_MAX = 64;  // hub rows per bin that are summed in the reference's order (one lane each)
 constexpr uint16_t PB_FLAG = 0x8000u;
 constexpr float PB_FIX_SCALE = 4611686018427387904.0f;     // 2^62
 constexpr float PB_FIX_INV = 2.168404344971008868e-19f;    // 2^-62
@@ -68,9 +92,11 @@ struct PbScratch {
 };
 
 struct PbItem {
-    uint32_t bin, q0, q1;          // value-stream range [q0, q1) of bin `bin`
+    uint32_t bin, q0, q1;          // value-stream range [q0, q1) of bin `bin`: ordinary rows in [q0, qh), hub rows in [qh, q1)
+    uint32_t qh;
     uint32_t h0, h1;               // hot-edge range of this item
     uint32_t nparts, slot0, part;  // slices of this bin, first partial-accumulator slot of the bin, this slice
+    uint32_t nh;                   // hub rows of this bin summed in the reference's order (accumulator slots [0, nh))
 };
 
 struct PbPlan {
@@ -81,6 +107,13 @@ struct PbPlan {
     uint32_t R = 0, B = 0; // rows per bin, bins
     uint32_t Racc = 0;     // accumulators per bin = max number of rows with in-edges in one bin (<= R)
     DevBuf cidx;           // u16[n]  accumulator slot of each row inside its bin, PB_NULL = no in-edges
+    int vs = 0;            // 1: the streams are laid out over 2 * B virtual bins (ordinary rows / hub rows of a bin)
+    uint32_t hub_deg = 0;  // rows with >= hub_deg in-edges are summed in the reference's order (0 = feature off)
+    uint32_t n_hub = 0;    // such rows (at most PB_HUB_MAX per bin take part)
+    uint64_t hub_edges = 0, hub_edges_unsplit = 0; // their in-edges; those in bins that are not sliced
+    DevBuf bin_nh;         // u32[B]  hub slots of each bin
+    std::vector<uint32_t> bin_nh_host;
+    double build_ms = 0.0; // wall time of pb_build (device work included)
     uint32_t NT = 0;       // source tiles
     uint32_t NS = 0;       // non-empty (tile, bin) segments
     uint64_t Mp = 0;       // padded length of the phase-1 stream
@@ -118,38 +151,70 @@ namespace {
 
 // ---- plan construction ---------------------------------------------------------------------------
 // key = bin << (sb + rb) | src << rb | row_in_bin      (sorted ascending = bin-major, then source, then row)
+// When the graph has hub rows (vs = 1) the bin field holds a VIRTUAL bin 2 * bin + (1 for a hub row): the value
+// stream of a bin is then [terms of its ordinary rows][terms of its hub rows], each part tile-major — the second
+// part is what the accumulate kernel walks step by step.  Everything below simply sees twice as many bins.
 // cold key: bin << (sb+rb) | src << rb | slot.   hot key: 1 << (bin_bits+sb+rb) | bin << (sb+rb) | hot index << rb
 // | slot (the hot index is < x_len, so it fits the source field) — the flag bit sits just above the cold key, so
 // hot keys sort behind every cold key, bin-major; only bits [0, bin_bits+sb+rb] take part in the sort.
 __device__ __forceinline__ uint64_t pb_make_key(uint64_t hi_cold, uint32_t r, uint32_t slot, uint32_t src, int rb, int sb,
-                                                int hot_bit, const uint16_t *__restrict__ hot_rank)
+                                                int hot_bit, int vs, const uint16_t *__restrict__ hot_rank)
 {
-    if (hot_rank) {
+    if (hot_rank) { // (null for hub rows: every term of theirs must pass the value stream in source order)
         const uint16_t h = hot_rank[src];
         if (h != PB_NULL)
-            return (1ull << hot_bit) | ((uint64_t)(r >> rb) << (sb + rb)) | ((uint64_t)h << rb) | slot;
+            return (1ull << hot_bit) | ((uint64_t)((r >> rb) << vs) << (sb + rb)) | ((uint64_t)h << rb) | slot;
     }
     return hi_cold | ((uint64_t)src << rb);
 }
 
-// accumulator slots: rows with in-edges are numbered consecutively inside their bin
-__global__ void pb_rowflag_kernel(const uint32_t *__restrict__ off, uint32_t n, uint32_t *__restrict__ flag)
+// accumulator slots: rows with in-edges are numbered consecutively inside their bin, hub rows (>= hub_deg
+// in-edges, at most PB_HUB_MAX per bin) first, so that `slot < nh` identifies them in the accumulate kernel
+__global__ void pb_hubflag_kernel(const uint32_t *__restrict__ off, uint32_t n, uint32_t hub_deg, uint32_t *__restrict__ flag)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r <= n; r += stride)
-        flag[r] = (r < n && off[r + 1] > off[r]) ? 1u : 0u;
+        flag[r] = (r < n && hub_deg && off[r + 1] - off[r] >= hub_deg) ? 1u : 0u;
 }
 
-__global__ void pb_cidx_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ pos, uint32_t n, int rb,
-                               uint16_t *__restrict__ cidx, uint32_t *__restrict__ bin_rows, uint32_t B)
+__device__ __forceinline__ bool pb_is_hub_row(const uint32_t *__restrict__ off, const uint32_t *__restrict__ pos_h, uint32_t r,
+                                              int rb, uint32_t hub_deg)
+{
+    return hub_deg && off[r + 1] - off[r] >= hub_deg && pos_h[r] - pos_h[(r >> rb) << rb] < PB_HUB_MAX;
+}
+
+__global__ void pb_rowflag_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ pos_h, uint32_t n, int rb,
+                                  uint32_t hub_deg, uint32_t *__restrict__ flag)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r <= n; r += stride)
+        flag[r] = (r < n && off[r + 1] > off[r] && !pb_is_hub_row(off, pos_h, r, rb, hub_deg)) ? 1u : 0u;
+}
+
+__global__ void pb_cidx_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ pos_h,
+                               const uint32_t *__restrict__ pos, uint32_t n, int rb, uint32_t hub_deg,
+                               uint16_t *__restrict__ cidx, uint32_t *__restrict__ bin_rows, uint32_t *__restrict__ bin_nh,
+                               unsigned long long *__restrict__ hub_edges)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
-        const uint32_t base = pos[(r >> rb) << rb];
-        cidx[r] = off[r + 1] > off[r] ? (uint16_t)(pos[r] - base) : PB_NULL;
-        if ((r & ((1u << rb) - 1u)) == 0) {
-            const uint64_t end = ((uint64_t)((r >> rb) + 1) << rb);
-            bin_rows[r >> rb] = pos[end < n ? end : n] - base;
+        const uint32_t bs = (r >> rb) << rb;
+        const uint64_t end = (uint64_t)bs + (1ull << rb);
+        const uint32_t be = end < n ? (uint32_t)end : n;
+        const uint32_t hubs = pos_h[be] - pos_h[bs];
+        const uint32_t nh = hubs < PB_HUB_MAX ? hubs : PB_HUB_MAX;
+        const uint32_t deg = off[r + 1] - off[r];
+        uint16_t c = PB_NULL; // rows without in-edges own no accumulator
+        if (pb_is_hub_row(off, pos_h, r, rb, hub_deg)) {
+            c = (uint16_t)(pos_h[r] - pos_h[bs]);
+            atomicAdd(hub_edges, (unsigned long long)deg);
+        } else if (deg) {
+            c = (uint16_t)(nh + pos[r] - pos[bs]);
+        }
+        cidx[r] = c;
+        if (r == bs) {
+            bin_rows[r >> rb] = nh + pos[be] - pos[bs];
+            bin_nh[r >> rb] = nh;
         }
     }
 }
@@ -216,9 +281,10 @@ __global__ void pb_hot_gather_kernel(const float *__restrict__ x_in, const uint3
 }
 
 __global__ __launch_bounds__(256) void pb_keys_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt,
-                                                      uint32_t n, int rb, int sb, int hot_bit,
+                                                      uint32_t n, int rb, int sb, int hot_bit, int vs,
                                                       const uint16_t *__restrict__ hot_rank,
-                                                      const uint16_t *__restrict__ cidx, uint64_t *__restrict__ keys)
+                                                      const uint16_t *__restrict__ cidx,
+                                                      const uint32_t *__restrict__ bin_nh, uint64_t *__restrict__ keys)
 {
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -231,11 +297,12 @@ __global__ __launch_bounds__(256) void pb_keys_kernel(const uint32_t *__restrict
             e = off[r + 1];
         }
         const uint32_t slot = r < n ? cidx[r] : 0u; // rows with edges always own a slot
-        const uint64_t hi = ((uint64_t)(r >> rb) << (sb + rb)) | (slot & rmask);
         const uint32_t len = e - s;
+        const bool hub = r < n && len && slot < bin_nh[r >> rb];
+        const uint64_t hi = ((uint64_t)(((r >> rb) << vs) | (hub ? 1u : 0u)) << (sb + rb)) | (slot & rmask);
         if (len <= 32)
             for (uint32_t i = s; i < e; ++i)
-                keys[i] = pb_make_key(hi, r, slot, tgt[i], rb, sb, hot_bit, hot_rank);
+                keys[i] = pb_make_key(hi, r, slot, tgt[i], rb, sb, hot_bit, vs, hub ? nullptr : hot_rank);
         uint64_t big = __ballot(len > 32);
         while (big) {
             const int src = __ffsll((unsigned long long)big) - 1;
@@ -243,8 +310,9 @@ __global__ __launch_bounds__(256) void pb_keys_kernel(const uint32_t *__restrict
             const uint32_t bs = __shfl(s, src, kWave), be = __shfl(e, src, kWave);
             const uint64_t bhi = __shfl(hi, src, kWave);
             const uint32_t br = __shfl(r, src, kWave), bslot = __shfl(slot, src, kWave);
+            const bool bhub = __shfl((int)hub, src, kWave) != 0;
             for (uint32_t i = bs + lane; i < be; i += kWave)
-                keys[i] = pb_make_key(bhi, br, bslot, tgt[i], rb, sb, hot_bit, hot_rank);
+                keys[i] = pb_make_key(bhi, br, bslot, tgt[i], rb, sb, hot_bit, vs, bhub ? nullptr : hot_rank);
         }
     }
 }
@@ -582,7 +650,8 @@ __device__ __forceinline__ unsigned long long pb_to_fix(float x)
     return (unsigned long long)(x * PB_FIX_SCALE); // exact scaling by 2^62, truncation below 2^-62
 }
 
-template <int ABL>
+// HUB = false: the plan has no hub rows — the step-by-step loop over [qh, q1) is compiled out.
+template <int ABL, bool HUB>
 __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__restrict__ vals,
                                                                 const uint16_t *__restrict__ p2_dst,
                                                                 const PbItem *__restrict__ items,
@@ -598,10 +667,18 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
     extern __shared__ unsigned long long acc[]; // Racc fixed-point sums (one per row WITH in-edges)
     __shared__ double red[PB_ACC_BLOCK / kWave];
     __shared__ bool is_last;
+    // hub rows (header): per step and hub slot, the sum of the step's terms rounded at ulp(S) [0] and at
+    // 2 ulp(S) [1], three steps in rotation (filled / read / cleared); (1 / ulp, ulp) of every hub slot
+    __shared__ unsigned long long hub_q[3][2][PB_HUB_Q];
+    __shared__ HubUnit hub_unit[PB_HUB_MAX];
+    static_assert(sizeof(double) * (PB_ACC_BLOCK / kWave) + 3 * 2 * PB_HUB_Q * 8 + PB_HUB_MAX * 8 + 64 <= PB_ACC_STATIC,
+                  "static LDS of pb_accum_kernel exceeds what the plan reserves");
     const PbItem item = items[blockIdx.x]; // longest items are dispatched first
     const uint32_t b = item.bin, tid = threadIdx.x;
+    const uint32_t nh = HUB ? item.nh : 0u; // hub slots of this bin: accumulator slots [0, nh)
     float *hot = reinterpret_cast<float *>(acc + Racc); // H out_scores of the hot sources
-    const uint32_t qb = item.q0, qe = (ABL == 4 ? item.q0 : item.q1); // multiples of 4
+    // the terms of the bin's ordinary rows are [q0, qh), those of its hub rows [qh, q1) (multiples of 4)
+    const uint32_t qb = item.q0, qe = (ABL == 4 ? item.q0 : (HUB ? item.qh : item.q1));
     constexpr int U = PB_ACC_U;
     constexpr uint32_t STEP = PB_ACC_BLOCK * PB_VEC;
     // Every phase keeps several independent loads per lane in flight and the first group of the value
@@ -624,10 +701,19 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
         }
     };
     const uint32_t q_first = qb + tid * PB_VEC;
+#pragma unroll
+    for (int k = 0; k < U; ++k) // (the hub loop walks every lane through every step)
+        d[k] = U16x4{PB_NULL, PB_NULL, PB_NULL, PB_NULL};
     if (q_first < qe)
         fetch(q_first, v, d);
     for (uint32_t i = tid; i < Racc; i += PB_ACC_BLOCK)
         acc[i] = 0ull;
+    if (nh) {
+        for (uint32_t i = tid; i < 3 * 2 * PB_HUB_Q; i += PB_ACC_BLOCK)
+            (&hub_q[0][0][0])[i] = 0ull;
+        if (tid < PB_HUB_MAX)
+            hub_unit[tid] = HubUnit{PB_FIX_SCALE, -1}; // "no rounding" until the sum has a binade
+    }
     if (item.h1 > item.h0) { // hot_x and the LDS table are 16-byte aligned and padded to a multiple of 4
         constexpr int HB = 4;
         const uint32_t H4 = (H + 3u) / 4u;
@@ -668,6 +754,120 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
                 d[k] = dn[k];
             }
         }
+    }
+    if (nh && ABL != 4) {
+        // The terms of the bin's hub rows, [qh, q1): one 4096-entry step at a time, a barrier between steps.
+        // Lane g < nh of EVERY wavefront carries the running sum S of hub slot g (scale 2^62) and its binade e
+        // — identical copies, computed from the same LDS sums, so no second barrier is needed to publish them.
+        // A long row sends most of a step's terms to ONE slot: its step sums are kept in R replicas (lane mod R)
+        // so that the LDS atomics of a wavefront spread over R addresses instead of serialising on one.
+        const uint32_t lane = tid & (kWave - 1);
+        const uint32_t rlog = nh <= 16 ? 4u : nh <= 32 ? 3u : 2u; // replicas: nh << rlog <= PB_HUB_Q
+        const uint32_t rep = lane & ((1u << rlog) - 1u);
+        const uint32_t hb = item.qh, he = item.q1;
+        unsigned long long S = 0ull;
+        int e = -1;
+        uint32_t buf = 0;
+        auto add_term = [&](uint32_t slot, float val) {
+            if (slot >= nh) // padding (PB_NULL); only hub rows have terms here
+                return;
+            const HubUnit un = hub_unit[slot]; // 1 / ulp(S) and log2 of ulp(S) in fixed-point units
+            const uint32_t qi = (slot << rlog) | rep;
+            const float t = val * un.iu; // a power-of-two scaling: exact
+            unsigned long long fa, fb;
+            if (un.sh >= 0 && t < 2147483648.0f) {
+                // the term rounded to the grid of S (and to the twice coarser grid), as an integer count of ulps
+                fa = (unsigned long long)(uint32_t)__builtin_rintf(t) << un.sh;
+                fb = (unsigned long long)(uint32_t)__builtin_rintf(t * 0.5f) << (un.sh + 1);
+            } else if (un.sh >= 0) { // a term far above the sum so far
+                const float u = __uint_as_float((uint32_t)(127 + un.sh - 62) << 23);
+                fa = pb_to_fix(__builtin_rintf(t) * u);
+                fb = pb_to_fix(__builtin_rintf(t * 0.5f) * (u * 2.0f));
+            } else {
+                fa = fb = pb_to_fix(val); // the sum has no binade yet: nothing to round against
+            }
+            atomicAdd(&hub_q[buf][0][qi], fa);
+            atomicAdd(&hub_q[buf][1][qi], fb);
+        };
+        auto load_step = [&](uint32_t q, f32x4 &vv, U16x4 &dd) {
+            dd = U16x4{PB_NULL, PB_NULL, PB_NULL, PB_NULL};
+            if (q < he) {
+                vv = *reinterpret_cast<const f32x4 *>(vals + q);
+                const u32x2 raw = *reinterpret_cast<const u32x2 *>(p2_dst + q);
+                dd = U16x4{(uint16_t)raw.x, (uint16_t)(raw.x >> 16), (uint16_t)raw.y, (uint16_t)(raw.y >> 16)};
+            }
+        };
+        // one workgroup walks the hub rows of a bin alone (the bin of a long row is the kernel's critical
+        // path): four steps in flight
+        constexpr int HS = 4;
+        f32x4 hv[HS];
+        U16x4 hd[HS];
+        const uint32_t h_first = hb + tid * PB_VEC;
+#pragma unroll
+        for (int k = 0; k < HS; ++k)
+            load_step(h_first + (uint32_t)k * STEP, hv[k], hd[k]);
+        auto hub_step = [&](f32x4 &vv, U16x4 &dd, uint32_t q) {
+            const f32x4 cv = vv;
+            const U16x4 cd = dd;
+            load_step(q + HS * STEP, vv, dd); // requested before the LDS work of this step
+            add_term(cd.a, cv.x);
+            add_term(cd.b, cv.y);
+            add_term(cd.c, cv.z);
+            add_term(cd.d, cv.w);
+            __syncthreads(); // every term of this step is in hub_q[buf]
+            if (lane < nh) {
+                unsigned long long A = 0ull, B = 0ull;
+                const uint32_t q0i = lane << rlog;
+                for (uint32_t r = 0; r < (1u << rlog); ++r) {
+                    A += hub_q[buf][0][q0i + r];
+                    B += hub_q[buf][1][q0i + r];
+                }
+                if (e < 24) {
+                    S += A; // no binade yet (the row's first terms): A was added without rounding
+                } else {
+                    const unsigned long long top = 1ull << (e + 1);
+                    if (S + A < top) {
+                        S += A; // S stayed in its binade: exactly what the left-to-right f32 sum does
+                    } else {
+                        // S crossed into the next binade inside this step: the terms behind the crossing are
+                        // rounded at 2 ulp.  Terms arrive in source order, a homogeneous sequence, so the share
+                        // of the step behind the crossing is the share of A beyond `top`.
+                        const unsigned long long rem = S + A - top;
+                        S = top + __double2ull_rn((double)B * ((double)rem / (double)A));
+                    }
+                }
+                HubUnit un{PB_FIX_SCALE, -1};
+                e = -1;
+                if (S) {
+                    int ee = 63 - __clzll((long long)S);
+                    if (ee >= 24) { // keep S on the f32 grid of its binade (round to nearest even, as fl() does)
+                        const int sh = ee - 23;
+                        const unsigned long long half = 1ull << (sh - 1), r = S & ((1ull << sh) - 1ull);
+                        unsigned long long qv = S >> sh;
+                        qv += (r > half || (r == half && (qv & 1ull))) ? 1ull : 0ull;
+                        S = qv << sh;
+                        ee = 63 - __clzll((long long)S);
+                        un = HubUnit{__uint_as_float((uint32_t)(127 + 85 - ee) << 23), ee - 23};
+                    }
+                    e = ee;
+                }
+                hub_unit[lane] = un; // every wavefront writes the same value
+            }
+            if (tid < PB_HUB_Q) { // cleared two steps before it is filled again
+                hub_q[(buf + 2u) % 3u][0][tid] = 0ull;
+                hub_q[(buf + 2u) % 3u][1][tid] = 0ull;
+            }
+            buf = (buf + 1u) % 3u;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wavefront's unit writes before its next reads
+        };
+        for (uint32_t qs = hb, q0 = h_first; qs < he; qs += HS * STEP, q0 += HS * STEP) {
+#pragma unroll
+            for (int k = 0; k < HS; ++k)
+                if (qs + (uint32_t)k * STEP < he) // uniform over the workgroup
+                    hub_step(hv[k], hd[k], q0 + (uint32_t)k * STEP);
+        }
+        if (tid < nh)
+            acc[tid] = S; // on the f32 grid: the epilogue's conversion is exact
     }
     // hot edges: 4 bytes each (row_in_bin << 16 | hot index), the value comes from the LDS table
     {
@@ -893,11 +1093,12 @@ int sort_pairs_u64_u32(DevBuf &keys, DevBuf &kalt, DevBuf &vals, DevBuf &valt, u
 // boundaries (a few KiB).
 int pb_make_items(PbPlan *pl)
 {
-    std::vector<uint32_t> bv((size_t)pl->B + 1), hv((size_t)pl->B + 1, 0u);
+    const uint32_t Bv = pl->B << pl->vs; // virtual bins of the streams
+    std::vector<uint32_t> bv((size_t)Bv + 1), hv((size_t)Bv + 1, 0u);
     GM_HIP(hipMemcpy(bv.data(), pl->bin_v.p, bv.size() * 4, hipMemcpyDeviceToHost));
     if (pl->H)
         GM_HIP(hipMemcpy(hv.data(), pl->hbin_v.p, hv.size() * 4, hipMemcpyDeviceToHost));
-    const uint64_t total = (uint64_t)bv[pl->B] + hv[pl->B];
+    const uint64_t total = (uint64_t)bv[Bv] + hv[Bv];
     uint64_t limit = 2 * (total / pl->B + 1);
     if (limit < 65536)
         limit = 65536;
@@ -906,12 +1107,27 @@ int pb_make_items(PbPlan *pl)
     limit = (limit + 3) & ~3ull;
     std::vector<PbItem> items;
     uint32_t slots = 0;
+    // A bin with hub rows is streamed by ONE workgroup, in order (the running sums of its hub rows are a
+    // sequence); it is dispatched first (longest first) and at ~4 G entries/s per workgroup even the bin of the
+    // largest RMAT scale-26 row (1.1 M entries) ends well inside the kernel.  Beyond GM_PB_HUB_SERIAL entries
+    // (default 8 M: ids sorted by degree, one giant bin) the bin is sliced like any other and its rows fall back
+    // to exactly rounded sums.
+    const uint64_t hub_serial = (uint64_t)pb_env("GM_PB_HUB_SERIAL", 8 << 20);
+    pl->hub_edges_unsplit = pl->hub_edges;
     for (uint32_t b = 0; b < pl->B; ++b) {
-        const uint32_t q0 = bv[b], q1 = bv[b + 1], g0 = hv[b], g1 = hv[b + 1];
+        const uint32_t q0 = bv[b << pl->vs], q1 = bv[(b + 1) << pl->vs], g0 = hv[b << pl->vs], g1 = hv[(b + 1) << pl->vs];
+        const uint32_t qh = pl->vs ? bv[(b << 1) + 1] : q1; // the terms of the bin's hub rows are [qh, q1)
         const uint64_t len = (uint64_t)(q1 - q0) + (g1 - g0);
-        const uint32_t parts = len > limit ? (uint32_t)((len + limit - 1) / limit) : 1u;
+        uint32_t nh = pl->bin_nh_host.empty() ? 0u : pl->bin_nh_host[b];
+        uint32_t parts = len > limit ? (uint32_t)((len + limit - 1) / limit) : 1u;
+        if (nh && parts > 1) {
+            if (len <= hub_serial)
+                parts = 1;
+            else
+                nh = 0, pl->hub_edges_unsplit = 0; // (not tracked per bin: reported as "none guaranteed")
+        }
         if (parts == 1) {
-            items.push_back(PbItem{b, q0, q1, g0, g1, 1u, 0u, 0u});
+            items.push_back(PbItem{b, q0, q1, nh ? qh : q1, g0, g1, 1u, 0u, 0u, nh});
             continue;
         }
         const uint32_t per = (((q1 - q0) + parts - 1) / parts + 3u) & ~3u;
@@ -923,7 +1139,7 @@ int pb_make_items(PbPlan *pl)
             e = e < q1 ? e : q1;
             hs = hs < g1 ? hs : g1;
             he = he < g1 ? he : g1;
-            items.push_back(PbItem{b, (uint32_t)s, (uint32_t)e, (uint32_t)hs, (uint32_t)he, parts, slots, k});
+            items.push_back(PbItem{b, (uint32_t)s, (uint32_t)e, (uint32_t)e, (uint32_t)hs, (uint32_t)he, parts, slots, k, 0u});
         }
         slots += parts;
     }
@@ -977,36 +1193,56 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     if (pl->NT == 0)
         pl->NT = 1;
     const int sb = bits_for(x_len) < 1 ? 1 : bits_for(x_len);
-    const int bin_bits = bits_for(pl->B) < 1 ? 1 : bits_for(pl->B);
-    GM_CHECK(bin_bits + sb + rb <= 63, GM_ERR_RANGE, "pb_build: key does not fit 63 bits");
+    GM_CHECK(bits_for(pl->B) + 1 + sb + rb <= 63, GM_ERR_RANGE, "pb_build: key does not fit 63 bits");
 
     gm::PhaseTimer timer((hipStream_t)0); // GM_LOG=1: where the plan construction time goes
-    // accumulator slots only for rows that have in-edges (RMAT: about half of the rows have none)
+    // accumulator slots only for rows that have in-edges (RMAT: about half of the rows have none); hub rows
+    // (summed in the reference's order, see the header) take the first slots of their bin
+    pl->hub_deg = (uint32_t)pb_env("GM_PB_HUB_DEG", 4096);
     GM_TRY(pl->cidx.alloc((size_t)(n ? n : 1) * 2));
+    GM_TRY(pl->bin_nh.alloc((size_t)pl->B * 4));
+    GM_HIP(hipMemset(pl->bin_nh.p, 0, (size_t)pl->B * 4));
+    pl->bin_nh_host.assign(pl->B, 0u);
     pl->Racc = 1;
     if (n) {
-        DevBuf flag, pos, bin_rows;
+        DevBuf flag, pos_h, pos, bin_rows, hub_edges;
         GM_TRY(flag.alloc(((size_t)n + 1) * 4));
+        GM_TRY(pos_h.alloc(((size_t)n + 1) * 4));
         GM_TRY(pos.alloc(((size_t)n + 1) * 4));
         GM_TRY(bin_rows.alloc((size_t)pl->B * 4));
-        hipLaunchKernelGGL(pb_rowflag_kernel, dim3(pb_grid((uint64_t)n + 1)), dim3(256), 0, 0, csr->offsets, n,
+        GM_TRY(hub_edges.alloc(8));
+        GM_HIP(hipMemset(hub_edges.p, 0, 8));
+        hipLaunchKernelGGL(pb_hubflag_kernel, dim3(pb_grid((uint64_t)n + 1)), dim3(256), 0, 0, csr->offsets, n, pl->hub_deg,
                            flag.as<uint32_t>());
         GM_HIP(hipGetLastError());
+        GM_TRY(scan_exclusive<uint32_t>(flag.as<uint32_t>(), pos_h.as<uint32_t>(), (uint64_t)n + 1));
+        hipLaunchKernelGGL(pb_rowflag_kernel, dim3(pb_grid((uint64_t)n + 1)), dim3(256), 0, 0, csr->offsets,
+                           pos_h.as<uint32_t>(), n, rb, pl->hub_deg, flag.as<uint32_t>());
+        GM_HIP(hipGetLastError());
         GM_TRY(scan_exclusive<uint32_t>(flag.as<uint32_t>(), pos.as<uint32_t>(), (uint64_t)n + 1));
-        hipLaunchKernelGGL(pb_cidx_kernel, dim3(pb_grid(n)), dim3(256), 0, 0, csr->offsets, pos.as<uint32_t>(), n, rb,
-                           pl->cidx.as<uint16_t>(), bin_rows.as<uint32_t>(), pl->B);
+        hipLaunchKernelGGL(pb_cidx_kernel, dim3(pb_grid(n)), dim3(256), 0, 0, csr->offsets, pos_h.as<uint32_t>(),
+                           pos.as<uint32_t>(), n, rb, pl->hub_deg, pl->cidx.as<uint16_t>(), bin_rows.as<uint32_t>(),
+                           pl->bin_nh.as<uint32_t>(), hub_edges.as<unsigned long long>());
         GM_HIP(hipGetLastError());
         std::vector<uint32_t> rows(pl->B);
         GM_HIP(hipMemcpy(rows.data(), bin_rows.p, (size_t)pl->B * 4, hipMemcpyDeviceToHost));
+        GM_HIP(hipMemcpy(pl->bin_nh_host.data(), pl->bin_nh.p, (size_t)pl->B * 4, hipMemcpyDeviceToHost));
+        GM_HIP(hipMemcpy(&pl->hub_edges, hub_edges.p, 8, hipMemcpyDeviceToHost));
         uint32_t mx = 1;
         for (uint32_t v : rows)
             mx = v > mx ? v : mx;
+        for (uint32_t v : pl->bin_nh_host)
+            pl->n_hub += v;
         pl->Racc = (mx + 63u) & ~63u;
         if (pl->Racc > pl->R)
             pl->Racc = pl->R;
         if (pb_env("GM_PB_COMPACT", 1) == 0)
             pl->Racc = pl->R; // keep the slot numbering, size the LDS as if every row had one
     }
+
+    pl->vs = pl->n_hub ? 1 : 0;
+    const uint32_t Bv = pl->B << pl->vs; // virtual bins: (ordinary rows, hub rows) of every bin when there are hub rows
+    const int bin_bits = bits_for(Bv) < 1 ? 1 : bits_for(Bv);
 
     // hot table size: what is left of the LDS beside the accumulators (2 workgroups per CU when the
     // accumulators are <= 64 KiB, else 1)
@@ -1016,7 +1252,8 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
         int wgs = acc_bytes > 65536 ? 1 : 2; // accumulate workgroups per CU the LDS request should allow
         if (pb_env("GM_PB_WGS", 0) == 1 || (pb_env("GM_PB_WGS", 0) == 0 && acc_bytes > 32768))
             wgs = 1;
-        const size_t budget = wgs == 1 ? (163840 - 512 - acc_bytes) : (81920 - 512 - acc_bytes);
+        // static LDS of the accumulate kernel (hub step sums + units + reduction scratch): PB_ACC_STATIC
+        const size_t budget = wgs == 1 ? (163840 - PB_ACC_STATIC - acc_bytes) : (81920 - PB_ACC_STATIC - acc_bytes);
         H = (uint32_t)(budget / 4) & ~63u;
         if (H > 32768)
             H = 32768;
@@ -1025,15 +1262,15 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
             H = (uint32_t)cap & ~63u;
     }
 
-    GM_TRY(pl->bin_v.alloc(((size_t)pl->B + 1) * 4));
-    GM_TRY(pl->hbin_v.alloc(((size_t)pl->B + 1) * 4));
+    GM_TRY(pl->bin_v.alloc(((size_t)Bv + 1) * 4));
+    GM_TRY(pl->hbin_v.alloc(((size_t)Bv + 1) * 4));
     GM_TRY(pl->tile_p.alloc(((size_t)pl->NT + 1) * 4));
-    GM_HIP(hipMemset(pl->hbin_v.p, 0, ((size_t)pl->B + 1) * 4));
+    GM_HIP(hipMemset(pl->hbin_v.p, 0, ((size_t)Bv + 1) * 4));
     GM_TRY(pl->hot_ent.alloc(16));
     GM_TRY(pl->hot_ids.alloc((size_t)(H ? H : 1) * 4));
     if (m_all == 0) {
         GM_TRY(pl->p2_dst.alloc(16));
-        GM_HIP(hipMemset(pl->bin_v.p, 0, ((size_t)pl->B + 1) * 4));
+        GM_HIP(hipMemset(pl->bin_v.p, 0, ((size_t)Bv + 1) * 4));
         GM_HIP(hipMemset(pl->tile_p.p, 0, ((size_t)pl->NT + 1) * 4));
         pl->H = 0;
         GM_TRY(pb_make_items(pl));
@@ -1087,8 +1324,8 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     GM_TRY(kalt.alloc((size_t)m_all * 8));
     const int hot_bit = bin_bits + sb + rb; // <= 63
     hipLaunchKernelGGL(pb_keys_kernel, dim3(pb_grid(n)), dim3(256), 0, 0, csr->offsets, csr->targets, n, rb, sb, hot_bit,
-                       H ? hot_rank.as<uint16_t>() : (const uint16_t *)nullptr, pl->cidx.as<uint16_t>(),
-                       keys.as<uint64_t>());
+                       pl->vs, H ? hot_rank.as<uint16_t>() : (const uint16_t *)nullptr, pl->cidx.as<uint16_t>(),
+                       pl->bin_nh.as<uint32_t>(), keys.as<uint64_t>());
     GM_HIP(hipGetLastError());
     // (sorting only bits [rb, ..) would do — the slot order inside a (bin, source) is irrelevant — but rocPRIM's
     // radix sort was measured 14x slower with a non-zero begin bit at this size)
@@ -1108,17 +1345,17 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
         if (mh) {
             const uint64_t *hkeys = keys.as<uint64_t>() + m;
             DevBuf hstart, hpad;
-            GM_TRY(hstart.alloc(((size_t)pl->B + 1) * 4));
-            GM_TRY(hpad.alloc(((size_t)pl->B + 1) * 4));
+            GM_TRY(hstart.alloc(((size_t)Bv + 1) * 4));
+            GM_TRY(hpad.alloc(((size_t)Bv + 1) * 4));
             const uint32_t bin_mask = (uint32_t)((1ull << bin_bits) - 1ull);
-            hipLaunchKernelGGL(pb_bounds_kernel, dim3(pb_grid(mh)), dim3(256), 0, 0, hkeys, mh, sb + rb, pl->B,
+            hipLaunchKernelGGL(pb_bounds_kernel, dim3(pb_grid(mh)), dim3(256), 0, 0, hkeys, mh, sb + rb, Bv,
                                hstart.as<uint32_t>(), bin_mask);
-            hipLaunchKernelGGL(pb_pad4_sizes_kernel, dim3(pb_grid((uint64_t)pl->B + 1)), dim3(256), 0, 0,
-                               hstart.as<uint32_t>(), pl->B, hpad.as<uint32_t>());
+            hipLaunchKernelGGL(pb_pad4_sizes_kernel, dim3(pb_grid((uint64_t)Bv + 1)), dim3(256), 0, 0,
+                               hstart.as<uint32_t>(), Bv, hpad.as<uint32_t>());
             GM_HIP(hipGetLastError());
-            GM_TRY(scan_exclusive<uint32_t>(hpad.as<uint32_t>(), pl->hbin_v.as<uint32_t>(), (uint64_t)pl->B + 1));
+            GM_TRY(scan_exclusive<uint32_t>(hpad.as<uint32_t>(), pl->hbin_v.as<uint32_t>(), (uint64_t)Bv + 1));
             uint32_t Mh = 0;
-            GM_HIP(hipMemcpy(&Mh, pl->hbin_v.as<uint32_t>() + pl->B, 4, hipMemcpyDeviceToHost));
+            GM_HIP(hipMemcpy(&Mh, pl->hbin_v.as<uint32_t>() + Bv, 4, hipMemcpyDeviceToHost));
             pl->Mh = Mh;
             GM_TRY(pl->hot_ent.alloc((size_t)Mh * 4));
             GM_HIP(hipMemset(pl->hot_ent.p, 0xFF, (size_t)Mh * 4));
@@ -1130,7 +1367,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     }
     if (m == 0) { // every edge is hot
         GM_TRY(pl->p2_dst.alloc(16));
-        GM_HIP(hipMemset(pl->bin_v.p, 0, ((size_t)pl->B + 1) * 4));
+        GM_HIP(hipMemset(pl->bin_v.p, 0, ((size_t)Bv + 1) * 4));
         GM_HIP(hipMemset(pl->tile_p.p, 0, ((size_t)pl->NT + 1) * 4));
         GM_TRY(pb_make_items(pl));
         pl->NW = 0;
@@ -1168,9 +1405,9 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     flag.release();
     // first segment of every bin (segments are bin-major already)
     DevBuf bin_seg;
-    GM_TRY(bin_seg.alloc(((size_t)pl->B + 1) * 4));
+    GM_TRY(bin_seg.alloc(((size_t)Bv + 1) * 4));
     const unsigned gs = pb_grid((uint64_t)NS + 1);
-    hipLaunchKernelGGL(pb_bounds_kernel, dim3(gs), dim3(256), 0, 0, segbin.as<uint64_t>(), NS, 0, pl->B,
+    hipLaunchKernelGGL(pb_bounds_kernel, dim3(gs), dim3(256), 0, 0, segbin.as<uint64_t>(), NS, 0, Bv,
                        bin_seg.as<uint32_t>());
     GM_HIP(hipGetLastError());
     timer.done("pb plan: segments");
@@ -1205,8 +1442,8 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     uint32_t Mv = 0;
     GM_HIP(hipMemcpy(&Mv, vstart4.as<uint32_t>() + NS, 4, hipMemcpyDeviceToHost));
     pl->Mv = Mv;
-    hipLaunchKernelGGL(pb_bin_ranges_kernel, dim3(pb_grid((uint64_t)pl->B + 1)), dim3(256), 0, 0, bin_seg.as<uint32_t>(),
-                       vstart4.as<uint32_t>(), pl->B, pl->bin_v.as<uint32_t>());
+    hipLaunchKernelGGL(pb_bin_ranges_kernel, dim3(pb_grid((uint64_t)Bv + 1)), dim3(256), 0, 0, bin_seg.as<uint32_t>(),
+                       vstart4.as<uint32_t>(), Bv, pl->bin_v.as<uint32_t>());
     GM_HIP(hipGetLastError());
     GM_TRY(scan_exclusive<uint32_t>(tile_pad.as<uint32_t>(), pl->tile_p.as<uint32_t>(), (uint64_t)pl->NT + 1));
     uint32_t Mp = 0;
@@ -1269,16 +1506,17 @@ static hipError_t pb_set_kernel_attributes()
         reinterpret_cast<const void *>(&pb_bin_kernel<3, 14>), reinterpret_cast<const void *>(&pb_bin_kernel<4, 14>),
         reinterpret_cast<const void *>(&pb_bin_kernel<5, 14>), reinterpret_cast<const void *>(&pb_bin_kernel<0, 15>),
         reinterpret_cast<const void *>(&pb_bin_kernel<3, 15>), reinterpret_cast<const void *>(&pb_bin_kernel<5, 15>)};
-    const void *acc_fns[] = {reinterpret_cast<const void *>(&pb_accum_kernel<0>),
-                             reinterpret_cast<const void *>(&pb_accum_kernel<3>),
-                             reinterpret_cast<const void *>(&pb_accum_kernel<4>)};
+    const void *acc_fns[] = {reinterpret_cast<const void *>(&pb_accum_kernel<0, false>),
+                             reinterpret_cast<const void *>(&pb_accum_kernel<0, true>),
+                             reinterpret_cast<const void *>(&pb_accum_kernel<3, true>),
+                             reinterpret_cast<const void *>(&pb_accum_kernel<4, true>)};
     hipError_t e = hipSuccess;
     for (const void *f : bin_fns)
         if (e == hipSuccess)
             e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (4u << PB_S_LOG_MAX) + PB_DCACHE * 4);
     for (const void *f : acc_fns)
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 163840 - 512);
+            e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 163840 - PB_ACC_STATIC);
     return e;
 }
 
@@ -1286,7 +1524,9 @@ int pb_plan_create(const gm_csr *csr, uint64_t x_len, PbPlan **out)
 {
     PbPlan *pl = new (std::nothrow) PbPlan();
     GM_CHECK(pl, GM_ERR_NOMEM, "pb_plan_create: out of host memory");
+    const auto t0 = std::chrono::steady_clock::now();
     const int rc = pb_build(csr, x_len, pl);
+    pl->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (rc != GM_OK) {
         delete pl;
         return rc;
@@ -1302,26 +1542,29 @@ int pb_plan_create(const gm_csr *csr, uint64_t x_len, PbPlan **out)
 }
 
 // The plan depends only on the CSR and on x_len: build it on first use and keep it in the handle, so
-// repeated page_rank() calls on one graph (the reference app's warm-up + timed runs) pay for it once.
-int pb_plan_get(const gm_csr *csr, uint64_t x_len, const PbPlan **out)
+// repeated page_rank() calls on one graph (the reference's app: warm-up + timed runs) pay for it once.
+// Plans are shared: an engine keeps its plan alive for as long as it lives, whatever happens to the cache.
+// GM_PB_NOCACHE=1 (measurement tools that switch plan knobs on one resident graph) builds a private plan
+// for the caller and leaves the cached one alone.
+int pb_plan_get(const gm_csr *csr, uint64_t x_len, std::shared_ptr<const PbPlan> *out)
 {
-    std::lock_guard<std::mutex> lock(csr->cache_mu);
-    auto it = csr->pb_plans.find(x_len);
-    if (it == csr->pb_plans.end() || pb_env("GM_PB_NOCACHE", 0)) {
+    if (pb_env("GM_PB_NOCACHE", 0)) {
         PbPlan *pl = nullptr;
         GM_TRY(pb_plan_create(csr, x_len, &pl));
-        if (it != csr->pb_plans.end()) {
-            delete it->second;
-            it->second = pl;
-        } else {
-            it = csr->pb_plans.emplace(x_len, pl).first;
-        }
+        out->reset(pl, [](const PbPlan *p) { delete p; });
+        return GM_OK;
+    }
+    std::lock_guard<std::mutex> lock(csr->cache_mu);
+    auto it = csr->pb_plans.find(x_len);
+    if (it == csr->pb_plans.end()) {
+        PbPlan *pl = nullptr;
+        GM_TRY(pb_plan_create(csr, x_len, &pl));
+        it = csr->pb_plans.emplace(x_len, std::shared_ptr<const PbPlan>(pl, [](const PbPlan *p) { delete p; })).first;
     }
     *out = it->second;
     return GM_OK;
 }
 
-void pb_plan_destroy(PbPlan *plan) { delete plan; }
 
 int pb_scratch_create(const PbPlan *pl, PbScratch **out)
 {
@@ -1356,6 +1599,22 @@ void pb_scratch_destroy(PbScratch *scratch) { delete scratch; }
 
 uint64_t pb_work_items(const PbPlan *plan) { return plan ? (uint64_t)plan->NW + plan->NI : 0; }
 
+// diagnostics (gm_pr_plan_info): what the plan costs and what it contains
+void pb_plan_info(const PbPlan *pl, const PbScratch *sc, uint64_t *info, uint32_t count)
+{
+    const DevBuf *bufs[] = {&pl->cidx, &pl->bin_nh, &pl->p1_src, &pl->chunk_seg, &pl->delta, &pl->tile_p, &pl->wg_tile,
+                            &pl->wg_p0,  &pl->p2_dst, &pl->bin_v,  &pl->items,     &pl->hot_ids, &pl->hot_ent, &pl->hbin_v};
+    uint64_t plan_bytes = 0;
+    for (const DevBuf *b : bufs)
+        plan_bytes += b->bytes;
+    const uint64_t scratch_bytes = sc ? sc->vals_raw.bytes + sc->partials.bytes + sc->tickets.bytes + sc->bin_err.bytes +
+                                            sc->hot_x.bytes : 0;
+    const uint64_t v[] = {plan_bytes, (uint64_t)(pl->build_ms * 1000.0), pl->n_hub, pl->hub_edges, pl->hub_deg, pl->H,
+                          pl->Mv, pl->Mh, scratch_bytes, pl->B, pl->NT, pl->NS, pl->hub_edges_unsplit};
+    for (uint32_t i = 0; i < count; ++i)
+        info[i] = i < sizeof(v) / sizeof(v[0]) ? v[i] : 0;
+}
+
 template <int ABL, int S_LOG>
 void pb_launch_bin(const PbPlan *pl, PbScratch *sc, const float *x_in, uint32_t w_first, uint32_t w_count, hipStream_t st)
 {
@@ -1365,11 +1624,11 @@ void pb_launch_bin(const PbPlan *pl, PbScratch *sc, const float *x_in, uint32_t 
                        pl->chunk, w_first, pl->xcd_aware);
 }
 
-template <int ABL>
+template <int ABL, bool HUB>
 void pb_launch_accum(const PbPlan *pl, PbScratch *sc, const PbItem *items, uint32_t count, float *x_out, float *scores,
                      const uint32_t *outdeg, float base, float damping, hipStream_t st)
 {
-    hipLaunchKernelGGL(pb_accum_kernel<ABL>, dim3(count), dim3(PB_ACC_BLOCK),
+    hipLaunchKernelGGL((pb_accum_kernel<ABL, HUB>), dim3(count), dim3(PB_ACC_BLOCK),
                        (size_t)pl->Racc * 8 + (((size_t)pl->H + 3) & ~(size_t)3) * 4, st, sc->vals, pl->p2_dst.as<uint16_t>(),
                        items, pl->hot_ent.as<uint32_t>(), sc->hot_x.as<float>(), pl->H,
                        sc->partials.as<unsigned long long>(), sc->tickets.as<uint32_t>(), pl->cidx.as<uint16_t>(), outdeg,
@@ -1407,9 +1666,14 @@ static void pb_accum_dispatch(const PbPlan *pl, PbScratch *sc, const PbItem *ite
     if (count == 0)
         return;
     switch (pb_env("GM_PB_ABLATE", 0) / 10) {
-    case 3: pb_launch_accum<3>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
-    case 4: pb_launch_accum<4>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
-    default: pb_launch_accum<0>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
+    case 3: pb_launch_accum<3, true>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
+    case 4: pb_launch_accum<4, true>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
+    default:
+        if (pl->n_hub)
+            pb_launch_accum<0, true>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st);
+        else
+            pb_launch_accum<0, false>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st);
+        break;
     }
 }
 

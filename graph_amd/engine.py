@@ -50,6 +50,16 @@ class PageRankEngine:
     def tiles(self) -> int:
         return int(lib().gm_pr_tile_count(self._h))
 
+    def plan_info(self) -> dict:
+        """what the propagation-blocking plan costs and contains (gm_pr_plan_info); {} for the other engines"""
+        if self.engine != "pb":
+            return {}
+        v = (C.c_uint64 * 13)()
+        check(lib().gm_pr_plan_info(self._h, v, 13))
+        keys = ("plan_bytes", "plan_build_us", "hub_rows", "hub_edges", "hub_in_degree", "hot_sources", "value_entries",
+                "hot_edges", "scratch_bytes", "bins", "source_tiles", "segments", "hub_edges_in_order")
+        return dict(zip(keys, (int(x) for x in v)))
+
     def init(self, scores_local: torch.Tensor, x_local: torch.Tensor):
         check(lib().gm_pr_init(self._h, scores_local.data_ptr(), x_local.data_ptr(), current_stream_ptr()))
 

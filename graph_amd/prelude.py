@@ -350,6 +350,25 @@ def page_rank(graph: DirectedCsrGraph, config: PageRankConfig | None = None, mod
     return scores, int(it.value), float(err.value)
 
 
+def page_rank_multi(graph: DirectedCsrGraph, config: PageRankConfig | None = None, devices=None, n_devices: int | None = None):
+    """page_rank over several GPUs of one node through the C ABI (gm_page_rank_multi: 1-D in-degree-balanced row
+    ranges, RCCL all-gather of out_scores per sweep, one host thread).  devices: list of device ordinals (a device
+    named twice = virtual ranks on one GPU), or n_devices for 0 .. n_devices-1."""
+    config = config or PageRankConfig()
+    n = graph.node_count()
+    scores = np.empty(n, np.float32)
+    it, err = u64(0), f64(0.0)
+    if devices is not None:
+        arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+        count = len(devices)
+    else:
+        arr, count = None, int(n_devices or 1)
+    check(lib().gm_page_rank_multi(graph.csr_out.handle, graph.csr_inc.handle, arr, count, int(config.max_iterations),
+                                   float(config.tolerance), float(config.damping_factor), _ptr(scores) if n else None,
+                                   C.byref(it), C.byref(err)))
+    return scores, int(it.value), float(err.value)
+
+
 @dataclass
 class WccConfig:
     """crates/algos/src/wcc.rs:43-79 (chunk_size is a CPU scheduling knob; ignored on the device)"""
@@ -424,7 +443,7 @@ def relabel_graph(graph: UndirectedCsrGraph):
 
 __all__ = [
     "CsrLayout", "Direction", "DeviceCsr", "DirectedCsrGraph", "UndirectedCsrGraph", "EdgeListInput",
-    "Graph500Input", "GraphBuilder", "PageRankConfig", "PageRankMode", "page_rank", "WccConfig", "Components",
+    "Graph500Input", "GraphBuilder", "PageRankConfig", "PageRankMode", "page_rank", "page_rank_multi", "WccConfig", "Components",
     "wcc_afforest", "wcc_afforest_dss", "wcc_baseline", "DeltaSteppingConfig", "delta_stepping",
     "global_triangle_count", "relabel_graph",
 ]

@@ -146,6 +146,20 @@ int gm_page_rank(const gm_csr *in_csr, const uint32_t *out_degree, uint64_t max_
 int gm_page_rank_directed(const gm_csr *out_csr, const gm_csr *in_csr, uint64_t max_iterations, double tolerance,
                           float damping_factor, int mode, float *scores_out, uint64_t *iterations_out, double *error_out);
 
+/* page_rank() on a graph split over the GPUs of one node (BASELINE north_star: 1-D vertex-range partition, RCCL
+ * exchange of the rank vector over xGMI every iteration), driven by ONE host thread — the entry a Rust / C++ host
+ * calls; nothing in it needs Python.  Rows are cut into n_devices contiguous ranges balanced by in-degree (the
+ * reference's greedy partitioner, crates/builder/src/graph_ops.rs:431-439,479-509); every device gets its rows of
+ * the in-CSR, a sweep engine and a replica of out_scores; per sweep: local sweep kernels -> ncclAllGather of the
+ * out_scores of the nodes that have out-edges -> the f64 error partials summed in rank order.  Same stop rule and
+ * results as gm_page_rank_directed (rows below the hub threshold bit-identical, hub rows to ~1e-6).
+ * devices: n_devices device ordinals, or NULL for 0 .. n_devices-1.  A device named more than once gives
+ * "virtual ranks" (the exchange then uses device-to-device copies instead of RCCL) — for exercising the
+ * partitioned path on a single GPU.  librccl.so is loaded on first use; GM_ERR_UNSUPPORTED if it is missing. */
+int gm_page_rank_multi(const gm_csr *out_csr, const gm_csr *in_csr, const int *devices, uint32_t n_devices,
+                       uint64_t max_iterations, double tolerance, float damping_factor, float *scores_out /* n, host */,
+                       uint64_t *iterations_out, double *error_out);
+
 /* Resident PageRank engine: the per-sweep hot loop (page_rank_iteration, page_rank.rs:113-168)
  * over rows [row_begin, row_begin + n_local) of a graph with n_global nodes.  One engine per
  * GPU; with n_local == n_global it is the single-GPU path.  All arrays are device pointers. */
@@ -201,6 +215,14 @@ int gm_pr_sweep_accum(gm_pr *pr, uint64_t d_x_in_global, uint64_t d_x_out_local,
 /* algorithmic HBM bytes of one sweep, SURVEY §8(d): 8*m_local + 20*n_local + 4 */
 uint64_t gm_pr_algorithmic_bytes(const gm_pr *pr);
 uint64_t gm_pr_tile_count(const gm_pr *pr); /* workgroups per sweep (diagnostics) */
+/* Diagnostics of the propagation-blocking plan behind an engine (GM_ERR_UNSUPPORTED for the other engines):
+ * info[0] bytes of plan data in HBM, [1] time the plan took to build (microseconds; it is built once per graph
+ * and cached in the gm_csr), [2] hub rows whose sums follow the reference's left-to-right f32 order
+ * (page_rank.rs:143-146), [3] their in-edges, [4] the in-degree threshold for that (GM_PB_HUB_DEG, default
+ * 4096, 0 = off), [5] hot sources, [6] entries of the value stream, [7] hot edges, [8] bytes of this engine's
+ * scratch (value stream etc.), [9] bins, [10] source tiles, [11] (tile, bin) segments, [12] hub in-edges in bins
+ * that one workgroup streams in order (= [3] unless a giant bin had to be sliced).  Further entries are 0. */
+int gm_pr_plan_info(const gm_pr *pr, uint64_t *info, uint32_t count);
 
 /* ---------------------------------------------------------------------------------------------
  * WCC — replaces wcc_afforest / wcc_afforest_dss / wcc_baseline(&G, WccConfig) -> impl
