@@ -338,6 +338,19 @@ def main():
         except Exception:
             traffic = None
 
+    plan = engine.plan_info()  # propagation-blocking engines: what the resident plan cost and holds
+    # parity of the timed engine at this scale against the reference's threaded path (tools/parity_pagerank.py,
+    # PageRankConfig::new(200, 1e-10, 0.85) on both sides), from the committed profile of this round
+    parity = None
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+        if name.endswith(f"parity_scale{scale}.json"):
+            try:
+                rec = json.load(open(os.path.join(ROOT, "profiles", name)))
+                parity = {"max_rel_vs_reference": rec["max_rel_vs_reference"], "rows_over_1e-5": rec["rows_over_1e-5"],
+                          "tolerance": 1e-5, "engine": rec["mode"], "source": f"profiles/{name}"}
+            except Exception:
+                parity = None
+            break
     result = {
         "metric": "pagerank_edges_per_sec",
         "value": round(gteps, 4),
@@ -363,9 +376,14 @@ def main():
                          f"{stride * 4} B/sweep (the out_scores its rows read)",
             "device": _device_note(torch, dev),
             "csr_build_s": round(t_build, 3), "final_sweep_error": final_err, "workgroups_per_sweep": engine.tiles, "engine": engine.engine,
+            "plan_build_ms": round(plan["plan_build_us"] / 1e3, 2) if plan else None,
+            "plan_bytes": plan.get("plan_bytes") if plan else None, "scratch_bytes": plan.get("scratch_bytes") if plan else None,
+            "hub_rows_in_reference_order": {k: plan[k] for k in ("hub_in_degree", "hub_rows", "hub_edges", "hub_groups")} if plan else None,
+            "hot_sources": plan.get("hot_sources") if plan else None, "value_entries": plan.get("value_entries") if plan else None,
+            "parity": parity,
         },
         "roofline": {
-            "kernel": "pr_tile_kernel" if engine.engine == "pull" else "pb_bin_kernel+pb_accum_kernel",
+            "kernel": "pr_tile_kernel" if engine.engine == "pull" else "pb_bin_kernel+pb_accum_kernel+pb_hub_kernel",
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(tile_ms_avg, 5),

@@ -76,6 +76,16 @@ __global__ void pr_degrees_from_offsets_kernel(const uint32_t *__restrict__ off,
         deg[u] = off[u + 1] - off[u];
 }
 
+__global__ void pr_long_row_kernel(const uint32_t *__restrict__ off, uint32_t n, uint32_t min_len, uint32_t *__restrict__ flag)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    bool any = false;
+    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += stride)
+        any = any || off[u + 1] - off[u] >= min_len;
+    if (any)
+        *flag = 1u;
+}
+
 __global__ void pr_count_outdeg_kernel(const uint32_t *__restrict__ tgt, uint64_t m, uint32_t *__restrict__ outdeg)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -365,6 +375,35 @@ __global__ __launch_bounds__(kWave) void pr_seq_kernel(const uint32_t *__restric
 
 } // namespace
 
+// Does some row have at least GM_PB_HUB_DEG (default 4096) in-edges?  Such rows need the propagation-blocking
+// engine, which sums them in the reference's left-to-right f32 order (pagerank_pb.hip): the pull tiles reduce a
+// long row as a tree, and on long rows the two differ by more than the 1e-5 the results must agree to
+// (measured 1.2e-5 at RMAT scale 18).  Looked at once per handle.
+static int pr_has_long_rows(const gm_csr *csr, bool *out)
+{
+    int state = csr->long_rows.load();
+    if (state < 0) {
+        const char *v = getenv("GM_PB_HUB_DEG");
+        const long thr = v && *v ? atol(v) : 4096;
+        state = 0;
+        if (thr > 0 && csr->n && csr->m >= (uint64_t)thr) {
+            gm::DevBuf flag;
+            GM_TRY(flag.alloc(4));
+            GM_HIP(hipMemset(flag.p, 0, 4));
+            unsigned grid = gm::div_up(csr->n, 256);
+            hipLaunchKernelGGL(pr_long_row_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0, 0, csr->offsets, (uint32_t)csr->n,
+                               (uint32_t)thr, flag.as<uint32_t>());
+            GM_HIP(hipGetLastError());
+            uint32_t h = 0;
+            GM_HIP(hipMemcpy(&h, flag.p, 4, hipMemcpyDeviceToHost));
+            state = h ? 1 : 0;
+        }
+        csr->long_rows.store(state);
+    }
+    *out = state == 1;
+    return GM_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 GM_API int gm_pr_create_with(const gm_csr *csr, uint64_t n_global, uint64_t row_begin, uint64_t x_len,
                              uint64_t d_out_degree_local, float damping_factor, int engine, gm_pr **out)
@@ -380,9 +419,12 @@ GM_API int gm_pr_create_with(const gm_csr *csr, uint64_t n_global, uint64_t row_
     GM_CHECK(x_len >= 1 && x_len < (1ull << 32), GM_ERR_RANGE, "gm_pr_create: x_len %llu out of range",
              (unsigned long long)x_len);
     GM_CHECK(engine >= GM_PR_ENGINE_AUTO && engine <= GM_PR_ENGINE_REFORDER, GM_ERR_INVALID, "gm_pr_create: unknown engine %d", engine);
-    if (engine == GM_PR_ENGINE_AUTO) // below ~16M edges the gathered vector is cache-resident: the pull tiles win
-        engine = csr->m >= (1ull << 24) ? GM_PR_ENGINE_PB : GM_PR_ENGINE_PULL;
     gm::DeviceGuard guard(csr->device);
+    if (engine == GM_PR_ENGINE_AUTO) { // below ~16M edges the gathered vector is cache-resident: the pull tiles win
+        bool long_rows = false;         // ... unless a long row needs the reference's summation order
+        GM_TRY(pr_has_long_rows(csr, &long_rows));
+        engine = (csr->m >= (1ull << 24) || long_rows) ? GM_PR_ENGINE_PB : GM_PR_ENGINE_PULL;
+    }
     gm_pr *pr = new (std::nothrow) gm_pr();
     GM_CHECK(pr, GM_ERR_NOMEM, "gm_pr_create: out of host memory");
     pr->csr = csr;
@@ -723,11 +765,13 @@ static int page_rank_impl(const gm_csr *in_csr, const uint32_t *out_degree, cons
         // plan if this handle already has one; build it straight away where ~20 sweeps repay it (>= 2^28 edges); otherwise
         // run this call on the pull tiles and build the plan on the second call of the same graph (the
         // reference's app runs 5 warm-ups + N timed runs on one graph, crates/app/src/app.rs:124-153).
+        bool long_rows = false; // rows that must be summed in the reference's order: only the PB engine does that
+        GM_TRY(pr_has_long_rows(in_csr, &long_rows));
         std::lock_guard<std::mutex> lock(in_csr->cache_mu);
         const uint64_t calls = ++in_csr->page_rank_calls;
         const bool cached = in_csr->pb_plans.count(n) != 0;
         const bool big = in_csr->m >= (1ull << 28), mid = in_csr->m >= (1ull << 24);
-        engine = (cached || big || (mid && calls >= 2)) ? GM_PR_ENGINE_PB : GM_PR_ENGINE_PULL;
+        engine = (cached || big || long_rows || (mid && calls >= 2)) ? GM_PR_ENGINE_PB : GM_PR_ENGINE_PULL;
     }
     GM_TRY(gm_pr_create_with(in_csr, n, 0, n, (uint64_t)outdeg.p, damping_factor, engine, &ph.p));
     GM_TRY(gm_pr_init(ph.p, (uint64_t)scores.p, (uint64_t)x0.p, st));

@@ -32,15 +32,17 @@
 // running sum, and the errors add up instead of cancelling (measured at RMAT scale 26: the reference's own
 // score of the 854,315-in-edge row is 8.5e-4 away from the exact row sum, and every node that row points to
 // inherits that).  Matching the reference within 1e-5 therefore means reproducing its rounding, not being
-// more exact.  Rows with at least `hub_deg` in-edges (default 4096, GM_PB_HUB_DEG) get the first accumulator
-// slots of their bin and never use the hot path, so all their terms arrive in the value stream in ascending
-// source order — the CSR order of the Sorted / Deduplicated layouts.  The accumulate kernel processes such a
-// bin one 4096-entry step at a time: a term v of a hub row is first rounded to the f32 grid of the row's
-// running sum S — rint(v / ulp(S)) * ulp(S), what fl(S + v) - S is while S stays in one binade, whatever the
-// order inside the step — and the step's rounded terms are added as exact integers.  Between steps (one
-// __syncthreads) S, its binade and ulp are updated; a step in which S crosses into the next binade is
-// resolved by interpolation between the step's sums rounded at ulp and at 2 ulp.  Deterministic (integer
-// sums, fixed step boundaries); measured against the left-to-right sum: DESIGN.md section 5.
+// more exact.  Rows with at least `hub_deg` in-edges (default 4096, GM_PB_HUB_DEG) are taken out of the
+// ordinary bins: consecutive hub rows form HUB GROUPS (<= 64 rows, about one ordinary bin's worth of terms),
+// every group is one more "bin" of the value stream (so (tile, group) segments are as long as (tile, bin)
+// ones), and no hub row uses the hot path — all its terms arrive in the stream in ascending source order, the
+// CSR order of the Sorted / Deduplicated layouts.  pb_hub_kernel walks a group one 4096-entry step at a time:
+// a term v is first rounded to the f32 grid of the row's running sum S — rint(v / ulp(S)) * ulp(S), what
+// fl(S + v) - S is while S stays in one binade, whatever the order inside the step — and the step's rounded
+// terms are added as exact integers.  Between steps (one __syncthreads) S, its binade and ulp are updated; a
+// step in which S crosses into the next binade is resolved by interpolation between the step's sums rounded
+// at ulp and at 2 ulp.  Deterministic (integer sums, fixed step boundaries).  The kernel needs 13 KiB of LDS,
+// so its workgroups run beside the accumulate workgroups of the ordinary bins (second stream).
 //
 // HBM traffic per edge and sweep: cold 2 B (source id) + 4 B (value write) + 4 B (value read) + 2 B (slot)
 // = 12 B, hot 4 B, all streaming, against 8 B "algorithmic" of which 4 B are a random gather.
@@ -51,6 +53,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <memory>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -65,12 +68,13 @@ constexpr uint32_t PB_VEC = 4;                  // segments are padded to multip
 constexpr uint32_t PB_WBLK = kWave * PB_VEC;    // entries one wavefront covers per step (256)
 constexpr uint16_t PB_NULL = 0xFFFFu;
 constexpr uint32_t PB_HUB_Q = 256;      // replicated step sums of the hub rows of a bin (hub slots x replicas)
-constexpr size_t PB_ACC_STATIC = 13824; // static LDS of pb_accum_kernel, rounded up
+constexpr size_t PB_ACC_STATIC = 512;  // static LDS of pb_accum_kernel, rounded up
 struct HubUnit {
     float iu; // 1 / ulp(S) of a hub row's running sum S
     int sh;   // ulp(S) = 2^sh units of the 2^-62 fixed point; < 0: S has no binade yet
 };
-constexpr uint32_t PB_HUB_MAX = 64;  // hub rows per bin that are summed in the reference's order (one lane each)
+constexpr uint32_t PB_HUB_MAX = 64;  // rows of a hub group (one lane of a wavefront each)
+constexpr uint16_t PB_HUBROW = 0xFFFEu; // cidx of a hub row: its sum is produced by pb_hub_kernel, not by its bin
 constexpr uint16_t PB_FLAG = 0x8000u;
 constexpr float PB_FIX_SCALE = 4611686018427387904.0f;     // 2^62
 constexpr float PB_FIX_INV = 2.168404344971008868e-19f;    // 2^-62
@@ -87,16 +91,32 @@ struct PbScratch {
     float *vals = nullptr; // f32[Mv] per-edge values, bin-major, segments padded to 4
     DevBuf partials; // u64[slots x R] partial LDS accumulators of split bins
     DevBuf tickets;  // u32[B]    arrival counters of split bins (self-resetting)
-    DevBuf bin_err;  // f64[B]
+    DevBuf bin_err;  // f64[B + G]
+    hipStream_t side = nullptr;           // the hub groups run beside the ordinary bins
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    ~PbScratch()
+    {
+        if (side)
+            (void)hipStreamDestroy(side);
+        if (ev_fork)
+            (void)hipEventDestroy(ev_fork);
+        if (ev_join)
+            (void)hipEventDestroy(ev_join);
+    }
     DevBuf hot_x;    // f32[H]    out_scores of the hot sources, refreshed every sweep
 };
 
 struct PbItem {
-    uint32_t bin, q0, q1;          // value-stream range [q0, q1) of bin `bin`: ordinary rows in [q0, qh), hub rows in [qh, q1)
-    uint32_t qh;
+    uint32_t bin, q0, q1;          // value-stream range [q0, q1) of bin `bin`
     uint32_t h0, h1;               // hot-edge range of this item
     uint32_t nparts, slot0, part;  // slices of this bin, first partial-accumulator slot of the bin, this slice
-    uint32_t nh;                   // hub rows of this bin summed in the reference's order (accumulator slots [0, nh))
+};
+
+struct PbHubItem {
+    uint32_t q0, q1; // value-stream range of the group (virtual bin B + group)
+    uint32_t nh;     // rows of the group: slots [0, nh)
+    uint32_t row0;   // their ids: hub_rows[row0 .. row0 + nh)
+    uint32_t group;
 };
 
 struct PbPlan {
@@ -107,12 +127,14 @@ struct PbPlan {
     uint32_t R = 0, B = 0; // rows per bin, bins
     uint32_t Racc = 0;     // accumulators per bin = max number of rows with in-edges in one bin (<= R)
     DevBuf cidx;           // u16[n]  accumulator slot of each row inside its bin, PB_NULL = no in-edges
-    int vs = 0;            // 1: the streams are laid out over 2 * B virtual bins (ordinary rows / hub rows of a bin)
     uint32_t hub_deg = 0;  // rows with >= hub_deg in-edges are summed in the reference's order (0 = feature off)
-    uint32_t n_hub = 0;    // such rows (at most PB_HUB_MAX per bin take part)
-    uint64_t hub_edges = 0, hub_edges_unsplit = 0; // their in-edges; those in bins that are not sliced
-    DevBuf bin_nh;         // u32[B]  hub slots of each bin
-    std::vector<uint32_t> bin_nh_host;
+    uint32_t n_hub = 0;    // such rows
+    uint32_t G = 0;        // hub groups: virtual bins B .. B + G - 1 of the streams
+    uint64_t hub_edges = 0;
+    DevBuf hub_rows;       // u32[n_hub] row id of every hub row, ascending
+    DevBuf hub_first;      // u32[G+1]   first hub row (index into hub_rows) of every group
+    DevBuf hub_items;      // PbHubItem[G] longest first
+    std::vector<uint32_t> hub_first_host;
     double build_ms = 0.0; // wall time of pb_build (device work included)
     uint32_t NT = 0;       // source tiles
     uint32_t NS = 0;       // non-empty (tile, bin) segments
@@ -151,25 +173,23 @@ namespace {
 
 // ---- plan construction ---------------------------------------------------------------------------
 // key = bin << (sb + rb) | src << rb | row_in_bin      (sorted ascending = bin-major, then source, then row)
-// When the graph has hub rows (vs = 1) the bin field holds a VIRTUAL bin 2 * bin + (1 for a hub row): the value
-// stream of a bin is then [terms of its ordinary rows][terms of its hub rows], each part tile-major — the second
-// part is what the accumulate kernel walks step by step.  Everything below simply sees twice as many bins.
+// A hub row (header) belongs to no ordinary bin: its bin field holds the VIRTUAL bin B + (its hub group) and its
+// slot is its position inside the group.  Everything below simply sees B + G bins.
 // cold key: bin << (sb+rb) | src << rb | slot.   hot key: 1 << (bin_bits+sb+rb) | bin << (sb+rb) | hot index << rb
 // | slot (the hot index is < x_len, so it fits the source field) — the flag bit sits just above the cold key, so
 // hot keys sort behind every cold key, bin-major; only bits [0, bin_bits+sb+rb] take part in the sort.
 __device__ __forceinline__ uint64_t pb_make_key(uint64_t hi_cold, uint32_t r, uint32_t slot, uint32_t src, int rb, int sb,
-                                                int hot_bit, int vs, const uint16_t *__restrict__ hot_rank)
+                                                int hot_bit, const uint16_t *__restrict__ hot_rank)
 {
     if (hot_rank) { // (null for hub rows: every term of theirs must pass the value stream in source order)
         const uint16_t h = hot_rank[src];
         if (h != PB_NULL)
-            return (1ull << hot_bit) | ((uint64_t)((r >> rb) << vs) << (sb + rb)) | ((uint64_t)h << rb) | slot;
+            return (1ull << hot_bit) | ((uint64_t)(r >> rb) << (sb + rb)) | ((uint64_t)h << rb) | slot;
     }
     return hi_cold | ((uint64_t)src << rb);
 }
 
-// accumulator slots: rows with in-edges are numbered consecutively inside their bin, hub rows (>= hub_deg
-// in-edges, at most PB_HUB_MAX per bin) first, so that `slot < nh` identifies them in the accumulate kernel
+// hub rows: >= hub_deg in-edges
 __global__ void pb_hubflag_kernel(const uint32_t *__restrict__ off, uint32_t n, uint32_t hub_deg, uint32_t *__restrict__ flag)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -177,44 +197,41 @@ __global__ void pb_hubflag_kernel(const uint32_t *__restrict__ off, uint32_t n, 
         flag[r] = (r < n && hub_deg && off[r + 1] - off[r] >= hub_deg) ? 1u : 0u;
 }
 
-__device__ __forceinline__ bool pb_is_hub_row(const uint32_t *__restrict__ off, const uint32_t *__restrict__ pos_h, uint32_t r,
-                                              int rb, uint32_t hub_deg)
-{
-    return hub_deg && off[r + 1] - off[r] >= hub_deg && pos_h[r] - pos_h[(r >> rb) << rb] < PB_HUB_MAX;
-}
-
-__global__ void pb_rowflag_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ pos_h, uint32_t n, int rb,
-                                  uint32_t hub_deg, uint32_t *__restrict__ flag)
-{
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r <= n; r += stride)
-        flag[r] = (r < n && off[r + 1] > off[r] && !pb_is_hub_row(off, pos_h, r, rb, hub_deg)) ? 1u : 0u;
-}
-
-__global__ void pb_cidx_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ pos_h,
-                               const uint32_t *__restrict__ pos, uint32_t n, int rb, uint32_t hub_deg,
-                               uint16_t *__restrict__ cidx, uint32_t *__restrict__ bin_rows, uint32_t *__restrict__ bin_nh,
-                               unsigned long long *__restrict__ hub_edges)
+// their ids and in-degrees in ascending row order (pos_h = exclusive scan of the hub flags)
+__global__ void pb_hub_rows_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ pos_h, uint32_t n,
+                                   uint32_t hub_deg, uint32_t *__restrict__ hub_rows, uint32_t *__restrict__ hub_degs)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
-        const uint32_t bs = (r >> rb) << rb;
-        const uint64_t end = (uint64_t)bs + (1ull << rb);
-        const uint32_t be = end < n ? (uint32_t)end : n;
-        const uint32_t hubs = pos_h[be] - pos_h[bs];
-        const uint32_t nh = hubs < PB_HUB_MAX ? hubs : PB_HUB_MAX;
         const uint32_t deg = off[r + 1] - off[r];
-        uint16_t c = PB_NULL; // rows without in-edges own no accumulator
-        if (pb_is_hub_row(off, pos_h, r, rb, hub_deg)) {
-            c = (uint16_t)(pos_h[r] - pos_h[bs]);
-            atomicAdd(hub_edges, (unsigned long long)deg);
-        } else if (deg) {
-            c = (uint16_t)(nh + pos[r] - pos[bs]);
+        if (hub_deg && deg >= hub_deg) {
+            hub_rows[pos_h[r]] = r;
+            hub_degs[pos_h[r]] = deg;
         }
-        cidx[r] = c;
-        if (r == bs) {
-            bin_rows[r >> rb] = nh + pos[be] - pos[bs];
-            bin_nh[r >> rb] = nh;
+    }
+}
+
+// accumulator slots of the ordinary bins: rows with in-edges that are not hub rows, numbered consecutively
+__global__ void pb_rowflag_kernel(const uint32_t *__restrict__ off, uint32_t n, uint32_t hub_deg, uint32_t *__restrict__ flag)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r <= n; r += stride) {
+        const uint32_t deg = r < n ? off[r + 1] - off[r] : 0u;
+        flag[r] = (deg && !(hub_deg && deg >= hub_deg)) ? 1u : 0u;
+    }
+}
+
+__global__ void pb_cidx_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ pos, uint32_t n, int rb,
+                               uint32_t hub_deg, uint16_t *__restrict__ cidx, uint32_t *__restrict__ bin_rows)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
+        const uint32_t base = pos[(r >> rb) << rb];
+        const uint32_t deg = off[r + 1] - off[r];
+        cidx[r] = !deg ? PB_NULL : (hub_deg && deg >= hub_deg) ? PB_HUBROW : (uint16_t)(pos[r] - base);
+        if ((r & ((1u << rb) - 1u)) == 0) {
+            const uint64_t end = ((uint64_t)((r >> rb) + 1) << rb);
+            bin_rows[r >> rb] = pos[end < n ? end : n] - base;
         }
     }
 }
@@ -281,10 +298,11 @@ __global__ void pb_hot_gather_kernel(const float *__restrict__ x_in, const uint3
 }
 
 __global__ __launch_bounds__(256) void pb_keys_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt,
-                                                      uint32_t n, int rb, int sb, int hot_bit, int vs,
+                                                      uint32_t n, int rb, int sb, int hot_bit,
                                                       const uint16_t *__restrict__ hot_rank,
-                                                      const uint16_t *__restrict__ cidx,
-                                                      const uint32_t *__restrict__ bin_nh, uint64_t *__restrict__ keys)
+                                                      const uint16_t *__restrict__ cidx, const uint32_t *__restrict__ pos_h,
+                                                      const uint32_t *__restrict__ hub_first, uint32_t B, uint32_t G,
+                                                      uint64_t *__restrict__ keys)
 {
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -296,13 +314,20 @@ __global__ __launch_bounds__(256) void pb_keys_kernel(const uint32_t *__restrict
             s = off[r];
             e = off[r + 1];
         }
-        const uint32_t slot = r < n ? cidx[r] : 0u; // rows with edges always own a slot
+        uint32_t slot = r < n ? cidx[r] : 0u; // rows with edges always own a slot
+        uint32_t vbin = r >> rb;
         const uint32_t len = e - s;
-        const bool hub = r < n && len && slot < bin_nh[r >> rb];
-        const uint64_t hi = ((uint64_t)(((r >> rb) << vs) | (hub ? 1u : 0u)) << (sb + rb)) | (slot & rmask);
+        const bool hub = r < n && len && slot == PB_HUBROW;
+        if (hub) { // virtual bin B + group, slot = position inside the group
+            const uint32_t i = pos_h[r];
+            const uint32_t g = (uint32_t)lower_bound_fn(0, G + 1, (uint64_t)i + 1, [&](uint64_t k) { return (uint64_t)hub_first[k]; }) - 1u;
+            vbin = B + g;
+            slot = i - hub_first[g];
+        }
+        const uint64_t hi = ((uint64_t)vbin << (sb + rb)) | (slot & rmask);
         if (len <= 32)
             for (uint32_t i = s; i < e; ++i)
-                keys[i] = pb_make_key(hi, r, slot, tgt[i], rb, sb, hot_bit, vs, hub ? nullptr : hot_rank);
+                keys[i] = pb_make_key(hi, r, slot, tgt[i], rb, sb, hot_bit, hub ? nullptr : hot_rank);
         uint64_t big = __ballot(len > 32);
         while (big) {
             const int src = __ffsll((unsigned long long)big) - 1;
@@ -312,7 +337,7 @@ __global__ __launch_bounds__(256) void pb_keys_kernel(const uint32_t *__restrict
             const uint32_t br = __shfl(r, src, kWave), bslot = __shfl(slot, src, kWave);
             const bool bhub = __shfl((int)hub, src, kWave) != 0;
             for (uint32_t i = bs + lane; i < be; i += kWave)
-                keys[i] = pb_make_key(bhi, br, bslot, tgt[i], rb, sb, hot_bit, vs, bhub ? nullptr : hot_rank);
+                keys[i] = pb_make_key(bhi, br, bslot, tgt[i], rb, sb, hot_bit, bhub ? nullptr : hot_rank);
         }
     }
 }
@@ -650,8 +675,7 @@ __device__ __forceinline__ unsigned long long pb_to_fix(float x)
     return (unsigned long long)(x * PB_FIX_SCALE); // exact scaling by 2^62, truncation below 2^-62
 }
 
-// HUB = false: the plan has no hub rows — the step-by-step loop over [qh, q1) is compiled out.
-template <int ABL, bool HUB>
+template <int ABL>
 __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__restrict__ vals,
                                                                 const uint16_t *__restrict__ p2_dst,
                                                                 const PbItem *__restrict__ items,
@@ -664,21 +688,13 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
                                                                 uint32_t n_local, uint32_t R, uint32_t Racc, float base,
                                                                 float damping)
 {
-    extern __shared__ unsigned long long acc[]; // Racc fixed-point sums (one per row WITH in-edges)
+    extern __shared__ unsigned long long acc[]; // Racc fixed-point sums (one per ordinary row WITH in-edges)
     __shared__ double red[PB_ACC_BLOCK / kWave];
     __shared__ bool is_last;
-    // hub rows (header): per step and hub slot, the sum of the step's terms rounded at ulp(S) [0] and at
-    // 2 ulp(S) [1], three steps in rotation (filled / read / cleared); (1 / ulp, ulp) of every hub slot
-    __shared__ unsigned long long hub_q[3][2][PB_HUB_Q];
-    __shared__ HubUnit hub_unit[PB_HUB_MAX];
-    static_assert(sizeof(double) * (PB_ACC_BLOCK / kWave) + 3 * 2 * PB_HUB_Q * 8 + PB_HUB_MAX * 8 + 64 <= PB_ACC_STATIC,
-                  "static LDS of pb_accum_kernel exceeds what the plan reserves");
     const PbItem item = items[blockIdx.x]; // longest items are dispatched first
     const uint32_t b = item.bin, tid = threadIdx.x;
-    const uint32_t nh = HUB ? item.nh : 0u; // hub slots of this bin: accumulator slots [0, nh)
     float *hot = reinterpret_cast<float *>(acc + Racc); // H out_scores of the hot sources
-    // the terms of the bin's ordinary rows are [q0, qh), those of its hub rows [qh, q1) (multiples of 4)
-    const uint32_t qb = item.q0, qe = (ABL == 4 ? item.q0 : (HUB ? item.qh : item.q1));
+    const uint32_t qb = item.q0, qe = (ABL == 4 ? item.q0 : item.q1); // multiples of 4
     constexpr int U = PB_ACC_U;
     constexpr uint32_t STEP = PB_ACC_BLOCK * PB_VEC;
     // Every phase keeps several independent loads per lane in flight and the first group of the value
@@ -701,19 +717,10 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
         }
     };
     const uint32_t q_first = qb + tid * PB_VEC;
-#pragma unroll
-    for (int k = 0; k < U; ++k) // (the hub loop walks every lane through every step)
-        d[k] = U16x4{PB_NULL, PB_NULL, PB_NULL, PB_NULL};
     if (q_first < qe)
         fetch(q_first, v, d);
     for (uint32_t i = tid; i < Racc; i += PB_ACC_BLOCK)
         acc[i] = 0ull;
-    if (nh) {
-        for (uint32_t i = tid; i < 3 * 2 * PB_HUB_Q; i += PB_ACC_BLOCK)
-            (&hub_q[0][0][0])[i] = 0ull;
-        if (tid < PB_HUB_MAX)
-            hub_unit[tid] = HubUnit{PB_FIX_SCALE, -1}; // "no rounding" until the sum has a binade
-    }
     if (item.h1 > item.h0) { // hot_x and the LDS table are 16-byte aligned and padded to a multiple of 4
         constexpr int HB = 4;
         const uint32_t H4 = (H + 3u) / 4u;
@@ -754,120 +761,6 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
                 d[k] = dn[k];
             }
         }
-    }
-    if (nh && ABL != 4) {
-        // The terms of the bin's hub rows, [qh, q1): one 4096-entry step at a time, a barrier between steps.
-        // Lane g < nh of EVERY wavefront carries the running sum S of hub slot g (scale 2^62) and its binade e
-        // — identical copies, computed from the same LDS sums, so no second barrier is needed to publish them.
-        // A long row sends most of a step's terms to ONE slot: its step sums are kept in R replicas (lane mod R)
-        // so that the LDS atomics of a wavefront spread over R addresses instead of serialising on one.
-        const uint32_t lane = tid & (kWave - 1);
-        const uint32_t rlog = nh <= 16 ? 4u : nh <= 32 ? 3u : 2u; // replicas: nh << rlog <= PB_HUB_Q
-        const uint32_t rep = lane & ((1u << rlog) - 1u);
-        const uint32_t hb = item.qh, he = item.q1;
-        unsigned long long S = 0ull;
-        int e = -1;
-        uint32_t buf = 0;
-        auto add_term = [&](uint32_t slot, float val) {
-            if (slot >= nh) // padding (PB_NULL); only hub rows have terms here
-                return;
-            const HubUnit un = hub_unit[slot]; // 1 / ulp(S) and log2 of ulp(S) in fixed-point units
-            const uint32_t qi = (slot << rlog) | rep;
-            const float t = val * un.iu; // a power-of-two scaling: exact
-            unsigned long long fa, fb;
-            if (un.sh >= 0 && t < 2147483648.0f) {
-                // the term rounded to the grid of S (and to the twice coarser grid), as an integer count of ulps
-                fa = (unsigned long long)(uint32_t)__builtin_rintf(t) << un.sh;
-                fb = (unsigned long long)(uint32_t)__builtin_rintf(t * 0.5f) << (un.sh + 1);
-            } else if (un.sh >= 0) { // a term far above the sum so far
-                const float u = __uint_as_float((uint32_t)(127 + un.sh - 62) << 23);
-                fa = pb_to_fix(__builtin_rintf(t) * u);
-                fb = pb_to_fix(__builtin_rintf(t * 0.5f) * (u * 2.0f));
-            } else {
-                fa = fb = pb_to_fix(val); // the sum has no binade yet: nothing to round against
-            }
-            atomicAdd(&hub_q[buf][0][qi], fa);
-            atomicAdd(&hub_q[buf][1][qi], fb);
-        };
-        auto load_step = [&](uint32_t q, f32x4 &vv, U16x4 &dd) {
-            dd = U16x4{PB_NULL, PB_NULL, PB_NULL, PB_NULL};
-            if (q < he) {
-                vv = *reinterpret_cast<const f32x4 *>(vals + q);
-                const u32x2 raw = *reinterpret_cast<const u32x2 *>(p2_dst + q);
-                dd = U16x4{(uint16_t)raw.x, (uint16_t)(raw.x >> 16), (uint16_t)raw.y, (uint16_t)(raw.y >> 16)};
-            }
-        };
-        // one workgroup walks the hub rows of a bin alone (the bin of a long row is the kernel's critical
-        // path): four steps in flight
-        constexpr int HS = 4;
-        f32x4 hv[HS];
-        U16x4 hd[HS];
-        const uint32_t h_first = hb + tid * PB_VEC;
-#pragma unroll
-        for (int k = 0; k < HS; ++k)
-            load_step(h_first + (uint32_t)k * STEP, hv[k], hd[k]);
-        auto hub_step = [&](f32x4 &vv, U16x4 &dd, uint32_t q) {
-            const f32x4 cv = vv;
-            const U16x4 cd = dd;
-            load_step(q + HS * STEP, vv, dd); // requested before the LDS work of this step
-            add_term(cd.a, cv.x);
-            add_term(cd.b, cv.y);
-            add_term(cd.c, cv.z);
-            add_term(cd.d, cv.w);
-            __syncthreads(); // every term of this step is in hub_q[buf]
-            if (lane < nh) {
-                unsigned long long A = 0ull, B = 0ull;
-                const uint32_t q0i = lane << rlog;
-                for (uint32_t r = 0; r < (1u << rlog); ++r) {
-                    A += hub_q[buf][0][q0i + r];
-                    B += hub_q[buf][1][q0i + r];
-                }
-                if (e < 24) {
-                    S += A; // no binade yet (the row's first terms): A was added without rounding
-                } else {
-                    const unsigned long long top = 1ull << (e + 1);
-                    if (S + A < top) {
-                        S += A; // S stayed in its binade: exactly what the left-to-right f32 sum does
-                    } else {
-                        // S crossed into the next binade inside this step: the terms behind the crossing are
-                        // rounded at 2 ulp.  Terms arrive in source order, a homogeneous sequence, so the share
-                        // of the step behind the crossing is the share of A beyond `top`.
-                        const unsigned long long rem = S + A - top;
-                        S = top + __double2ull_rn((double)B * ((double)rem / (double)A));
-                    }
-                }
-                HubUnit un{PB_FIX_SCALE, -1};
-                e = -1;
-                if (S) {
-                    int ee = 63 - __clzll((long long)S);
-                    if (ee >= 24) { // keep S on the f32 grid of its binade (round to nearest even, as fl() does)
-                        const int sh = ee - 23;
-                        const unsigned long long half = 1ull << (sh - 1), r = S & ((1ull << sh) - 1ull);
-                        unsigned long long qv = S >> sh;
-                        qv += (r > half || (r == half && (qv & 1ull))) ? 1ull : 0ull;
-                        S = qv << sh;
-                        ee = 63 - __clzll((long long)S);
-                        un = HubUnit{__uint_as_float((uint32_t)(127 + 85 - ee) << 23), ee - 23};
-                    }
-                    e = ee;
-                }
-                hub_unit[lane] = un; // every wavefront writes the same value
-            }
-            if (tid < PB_HUB_Q) { // cleared two steps before it is filled again
-                hub_q[(buf + 2u) % 3u][0][tid] = 0ull;
-                hub_q[(buf + 2u) % 3u][1][tid] = 0ull;
-            }
-            buf = (buf + 1u) % 3u;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wavefront's unit writes before its next reads
-        };
-        for (uint32_t qs = hb, q0 = h_first; qs < he; qs += HS * STEP, q0 += HS * STEP) {
-#pragma unroll
-            for (int k = 0; k < HS; ++k)
-                if (qs + (uint32_t)k * STEP < he) // uniform over the workgroup
-                    hub_step(hv[k], hd[k], q0 + (uint32_t)k * STEP);
-        }
-        if (tid < nh)
-            acc[tid] = S; // on the f32 grid: the epilogue's conversion is exact
     }
     // hot edges: 4 bytes each (row_in_bin << 16 | hot index), the value comes from the LDS table
     {
@@ -944,6 +837,10 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
                 if (full[k]) {
                     const u32x2 raw = *reinterpret_cast<const u32x2 *>(cidx + r);
                     c4[k] = U16x4{(uint16_t)raw.x, (uint16_t)(raw.x >> 16), (uint16_t)raw.y, (uint16_t)(raw.y >> 16)};
+                    // a hub row among the four is finished by pb_hub_kernel, possibly right now: no vector store
+                    full[k] = c4[k].a != PB_HUBROW && c4[k].b != PB_HUBROW && c4[k].c != PB_HUBROW && c4[k].d != PB_HUBROW;
+                }
+                if (full[k]) {
                     old4[k] = *reinterpret_cast<const f32x4 *>(scores + r);
                     od4[k] = *reinterpret_cast<const uint4 *>(outdeg + r);
                 }
@@ -970,9 +867,11 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
                     *reinterpret_cast<f32x4 *>(scores + r) = o;
                     o.x = xo[0], o.y = xo[1], o.z = xo[2], o.w = xo[3];
                     *reinterpret_cast<f32x4 *>(x_out + r) = o;
-                } else if (i < R) { // the last rows of the slice
+                } else if (i < R) { // the last rows of the slice, or four rows with a hub row among them
                     for (uint32_t rr = r; rr < n_local && rr < r + 4u; ++rr) {
                         const uint32_t c = cidx[rr];
+                        if (c == PB_HUBROW)
+                            continue;
                         const unsigned long long sum = c != PB_NULL ? acc[c] : 0ull;
                         err += pr_finalize(rr, (float)sum * PB_FIX_INV, base, damping, outdeg, scores, x_out);
                     }
@@ -984,6 +883,8 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
             const uint32_t r = r0 + i;
             if (r < n_local) {
                 const uint32_t c = cidx[r]; // rows without in-edges own no accumulator: incoming = 0
+                if (c == PB_HUBROW)
+                    continue; // finished by pb_hub_kernel
                 unsigned long long sum = 0ull;
                 if (c != PB_NULL) {
                     if (item.nparts > 1) { // slices of one bin own consecutive partial slots [slot0, slot0 + nparts)
@@ -1001,6 +902,229 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
     const double total = block_sum<double, PB_ACC_BLOCK / kWave>(err, red);
     if (tid == 0)
         bin_err[b] = total;
+}
+
+// The rows of one hub group, summed in the reference's left-to-right f32 order (header): one workgroup walks the
+// group's part of the value stream one 4096-entry step at a time.  Per step: every lane rounds its four terms to
+// the grid of their rows' running sums and adds them — as integer counts of ulps — to the step sums in LDS; barrier;
+// wavefront 0 (lane g = row g) moves the rows' running sums S (scale 2^62), binades and ulps on; barrier.
+// The kernel is bound by instruction issue, not by memory (measured: 16 wavefronts x ~300 instructions per step =
+// 2.7 us against 1.2 us for the step's 24 KiB at the sweep's memory rate), hence: no branches per term (padding
+// goes to a dummy row whose scale is 0), the rare general cases out of line, and the step's bookkeeping on one
+// wavefront instead of redundantly on all sixteen.
+__global__ __launch_bounds__(PB_ACC_BLOCK) void pb_hub_kernel(const float *__restrict__ vals,
+                                                              const uint16_t *__restrict__ p2_dst,
+                                                              const PbHubItem *__restrict__ items,
+                                                              const uint32_t *__restrict__ hub_rows,
+                                                              const uint32_t *__restrict__ outdeg, float *__restrict__ scores,
+                                                              float *__restrict__ x_out, double *__restrict__ group_err,
+                                                              float base, float damping)
+{
+    // per step and row: the sum of the step's terms rounded at ulp(S) [0] and at 2 ulp(S) [1], in R replicas
+    // (lane mod R) so that the LDS atomics of a wavefront spread over ~64 addresses; three steps in rotation
+    // (filled / read / cleared).  Row nh is the dummy row of the padding entries.
+    __shared__ unsigned long long hub_q[3][2][PB_HUB_Q];
+    __shared__ HubUnit hub_unit[PB_HUB_MAX + 1];
+    __shared__ double red[PB_ACC_BLOCK / kWave];
+    const PbHubItem item = items[blockIdx.x]; // longest groups are dispatched first
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), nh = item.nh;
+    constexpr uint32_t STEP = PB_ACC_BLOCK * PB_VEC;
+    const uint32_t hb = item.q0, he = item.q1;
+    auto load_step = [&](uint32_t q, f32x4 &vv, U16x4 &dd) {
+        dd = U16x4{PB_NULL, PB_NULL, PB_NULL, PB_NULL};
+        vv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (q < he) {
+            vv = *reinterpret_cast<const f32x4 *>(vals + q);
+            const u32x2 raw = *reinterpret_cast<const u32x2 *>(p2_dst + q);
+            dd = U16x4{(uint16_t)raw.x, (uint16_t)(raw.x >> 16), (uint16_t)raw.y, (uint16_t)(raw.y >> 16)};
+        }
+    };
+    constexpr int HS = 4; // blocks in flight
+    f32x4 hv[HS];
+    U16x4 hd[HS];
+    const uint32_t h_first = hb + tid * PB_VEC;
+#pragma unroll
+    for (int k = 0; k < HS; ++k)
+        load_step(h_first + (uint32_t)k * STEP, hv[k], hd[k]);
+    for (uint32_t i = tid; i < 3 * 2 * PB_HUB_Q; i += PB_ACC_BLOCK)
+        (&hub_q[0][0][0])[i] = 0ull;
+    if (tid <= PB_HUB_MAX)
+        hub_unit[tid] = tid < nh ? HubUnit{PB_FIX_SCALE, -1}  // "no rounding" until the sum has a binade
+                                 : HubUnit{0.0f, 0};          // the dummy row: every term counts 0 ulps
+    __syncthreads();
+    // Groups of one or two rows are the long chains (a 854,315-term row is a group of its own) and every lane's
+    // terms go to the same one or two sums: they are added up in registers first (`few`).  Otherwise
+    // R = 16 replicas for 3-4 rows ... 1 for more than 32.
+    const bool few = nh <= 2; // uniform over the group
+    const uint32_t rlog = few ? 0u : nh <= 4 ? 4u : nh <= 8 ? 3u : nh <= 16 ? 2u : nh <= 32 ? 1u : 0u;
+    const uint32_t rep = lane & ((1u << rlog) - 1u);
+    unsigned long long S = 0ull; // wavefront 0, lane g: the running sum of row g and its binade
+    int e = -1;
+    uint32_t buf = 0;
+    // The rare terms — the sum has no binade yet (sh < 0: nothing to round against), or a term far above the sum
+    // so far (more than 2^31 ulps) — go through ONE copy of the general code per step.
+    auto slow_term = [&](uint32_t slot, float val) {
+        const HubUnit un = hub_unit[slot];
+        unsigned long long fa, fb;
+        if (un.sh >= 0) {
+            const float t = val * un.iu, u = __uint_as_float((uint32_t)(127 + un.sh - 62) << 23);
+            fa = pb_to_fix(__builtin_rintf(t) * u);
+            fb = pb_to_fix(__builtin_rintf(t * 0.5f) * (u * 2.0f));
+        } else {
+            fa = fb = pb_to_fix(val);
+        }
+        atomicAdd(&hub_q[buf][0][(slot << rlog) | rep], fa);
+        atomicAdd(&hub_q[buf][1][(slot << rlog) | rep], fb);
+    };
+    auto slow_terms = [&](uint32_t slow, const f32x4 &cv, const uint32_t (&sl)[4]) {
+#pragma nounroll
+        for (uint32_t j = 0; j < 4 && slow; ++j, slow >>= 1)
+            if (slow & 1u)
+                slow_term(j == 0 ? sl[0] : j == 1 ? sl[1] : j == 2 ? sl[2] : sl[3],
+                          j == 0 ? cv.x : j == 1 ? cv.y : j == 2 ? cv.z : cv.w);
+    };
+    auto wave_sum32 = [&](uint32_t x) {
+#pragma unroll
+        for (int o = 32; o; o >>= 1)
+            x += (uint32_t)__shfl_xor((int)x, o, kWave);
+        return x;
+    };
+    // the terms of one 4096-entry block of the stream, rounded and added to the step sums hub_q[buf]
+    auto add_block = [&](auto few_tag, const f32x4 &cv, const U16x4 &cd) {
+        constexpr bool FEW = decltype(few_tag)::value;
+        const uint32_t sl[4] = {cd.a < nh ? cd.a : nh, cd.b < nh ? cd.b : nh, cd.c < nh ? cd.c : nh, cd.d < nh ? cd.d : nh};
+        const float vl[4] = {cv.x, cv.y, cv.z, cv.w};
+        uint32_t slow = 0;
+        if constexpr (FEW) {
+            // counts summed over the lane's terms and over the wavefront as two 32-bit halves (low 16 bits / the
+            // rest: neither sum can overflow); one lane per wavefront adds the wavefront's total to the step sum —
+            // 8192 LDS atomics on one address per step ran at the LDS's conflict rate (measured: 5 us per step)
+#pragma nounroll
+            for (uint32_t k = 0; k < nh; ++k) { // nh <= 2
+                const HubUnit un = hub_unit[k];
+                uint32_t a_lo = 0, a_hi = 0, b_lo = 0, b_hi = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float t = sl[j] == k ? vl[j] * un.iu : 0.0f;
+                    const bool ok = un.sh >= 0 && t < 2147483648.0f;
+                    const uint32_t ca = ok ? (uint32_t)__builtin_rintf(t) : 0u, cb = ok ? (uint32_t)__builtin_rintf(t * 0.5f) : 0u;
+                    a_lo += ca & 0xFFFFu, a_hi += ca >> 16;
+                    b_lo += cb & 0xFFFFu, b_hi += cb >> 16;
+                    slow |= (sl[j] == k && !ok) ? 1u << j : 0u;
+                }
+                a_lo = wave_sum32(a_lo), a_hi = wave_sum32(a_hi), b_lo = wave_sum32(b_lo), b_hi = wave_sum32(b_hi);
+                if (lane == 0 && un.sh >= 0) {
+                    atomicAdd(&hub_q[buf][0][k], (((unsigned long long)a_hi << 16) + a_lo) << un.sh);
+                    atomicAdd(&hub_q[buf][1][k], (((unsigned long long)b_hi << 16) + b_lo) << (un.sh + 1));
+                }
+            }
+        } else {
+            HubUnit un[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                un[j] = hub_unit[sl[j]]; // 1 / ulp(S) and log2 of ulp(S) in fixed-point units; four reads in flight
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float t = vl[j] * un[j].iu; // a power-of-two scaling: exact (0 for padding)
+                const bool ok = un[j].sh >= 0 && t < 2147483648.0f;
+                const uint32_t ca = ok ? (uint32_t)__builtin_rintf(t) : 0u, cb = ok ? (uint32_t)__builtin_rintf(t * 0.5f) : 0u;
+                const uint32_t qi = (sl[j] << rlog) | rep;
+                const int sh = un[j].sh & 63;
+                atomicAdd(&hub_q[buf][0][qi], (unsigned long long)ca << sh);
+                atomicAdd(&hub_q[buf][1][qi], (unsigned long long)cb << ((sh + 1) & 63));
+                slow |= ok ? 0u : 1u << j;
+            }
+        }
+        if (__ballot(slow != 0)) // almost never
+            slow_terms(slow, cv, sl);
+    };
+    // between two steps: lane g < nh of EVERY wavefront moves the running sum of row g on — identical copies,
+    // computed from the same LDS sums, so one barrier per step is enough
+    auto end_step = [&]() {
+        // every term of this step is in hub_q[buf] (LDS traffic only: the prefetched global loads stay in flight)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (lane < nh) {
+            unsigned long long A = 0ull, B = 0ull;
+            const uint32_t q0i = lane << rlog;
+            for (uint32_t r = 0; r < (1u << rlog); ++r) {
+                A += hub_q[buf][0][q0i + r];
+                B += hub_q[buf][1][q0i + r];
+            }
+            if (e < 24) {
+                S += A; // no binade yet (the row's first terms): A was added without rounding
+            } else {
+                const unsigned long long top = 1ull << (e + 1);
+                if (S + A < top) {
+                    S += A; // S stayed in its binade: exactly what the left-to-right f32 sum does
+                } else {
+                    // S crossed into the next binade inside this step: the terms behind the crossing are
+                    // rounded at 2 ulp.  Terms arrive in source order, a homogeneous sequence, so the share
+                    // of the step behind the crossing is the share of A beyond `top`.
+                    const unsigned long long rem = S + A - top;
+                    S = top + __double2ull_rn((double)B * ((double)rem / (double)A));
+                }
+            }
+            HubUnit un{PB_FIX_SCALE, -1};
+            e = -1;
+            if (S) {
+                int ee = 63 - __clzll((long long)S);
+                if (ee >= 24) { // keep S on the f32 grid of its binade (round to nearest even, as fl() does)
+                    const int sh = ee - 23;
+                    const unsigned long long half = 1ull << (sh - 1), r = S & ((1ull << sh) - 1ull);
+                    unsigned long long qv = S >> sh;
+                    qv += (r > half || (r == half && (qv & 1ull))) ? 1ull : 0ull;
+                    S = qv << sh;
+                    ee = 63 - __clzll((long long)S);
+                    un = HubUnit{__uint_as_float((uint32_t)(127 + 85 - ee) << 23), ee - 23};
+                }
+                e = ee;
+            }
+            hub_unit[lane] = un; // every wavefront writes the same value
+        }
+        if (tid < ((nh + 1u) << rlog)) { // cleared two steps before it is filled again
+            hub_q[(buf + 2u) % 3u][0][tid] = 0ull;
+            hub_q[(buf + 2u) % 3u][1][tid] = 0ull;
+        }
+        buf = (buf + 1u) % 3u;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wavefront's unit writes before its next reads
+    };
+    // A step is one block (4096 entries) for groups of one or two rows — their rows see thousands of terms per
+    // block — and two blocks for the others (a row of a 30-row group sees ~270 terms in 8192 entries): the
+    // barrier and the bookkeeping are paid half as often.  The kernel is bound by instruction issue (measured:
+    // ~570 wavefront instructions per block), not by memory.
+    auto walk = [&](auto few_tag) {
+        constexpr bool FEW = decltype(few_tag)::value;
+        for (uint32_t qs = hb, q0 = h_first; qs < he; qs += HS * STEP, q0 += HS * STEP) {
+#pragma unroll
+            for (int k = 0; k < HS; k += FEW ? 1 : 2) {
+                if (qs + (uint32_t)k * STEP >= he) // uniform over the workgroup
+                    break;
+                const f32x4 cv0 = hv[k];
+                const U16x4 cd0 = hd[k];
+                load_step(q0 + (uint32_t)(k + HS) * STEP, hv[k], hd[k]); // requested before the LDS work of this step
+                add_block(few_tag, cv0, cd0);
+                if constexpr (!FEW) {
+                    const f32x4 cv1 = hv[k + 1];
+                    const U16x4 cd1 = hd[k + 1];
+                    load_step(q0 + (uint32_t)(k + 1 + HS) * STEP, hv[k + 1], hd[k + 1]);
+                    add_block(few_tag, cv1, cd1);
+                }
+                end_step();
+            }
+        }
+    };
+    if (few)
+        walk(std::true_type{});
+    else
+        walk(std::false_type{});
+    // epilogue of the reference for the group's rows (page_rank.rs:149-159); S is on the f32 grid: the
+    // conversion is exact
+    double err = 0.0;
+    if (tid < nh)
+        err = pr_finalize(hub_rows[item.row0 + tid], (float)S * PB_FIX_INV, base, damping, outdeg, scores, x_out);
+    const double total = block_sum<double, PB_ACC_BLOCK / kWave>(err, red);
+    if (tid == 0)
+        group_err[item.group] = total;
 }
 
 __global__ __launch_bounds__(1024) void pb_err_kernel(const double *__restrict__ bin_err, uint32_t B, double *__restrict__ err_out)
@@ -1093,12 +1217,12 @@ int sort_pairs_u64_u32(DevBuf &keys, DevBuf &kalt, DevBuf &vals, DevBuf &valt, u
 // boundaries (a few KiB).
 int pb_make_items(PbPlan *pl)
 {
-    const uint32_t Bv = pl->B << pl->vs; // virtual bins of the streams
+    const uint32_t Bv = pl->B + pl->G; // virtual bins of the streams
     std::vector<uint32_t> bv((size_t)Bv + 1), hv((size_t)Bv + 1, 0u);
     GM_HIP(hipMemcpy(bv.data(), pl->bin_v.p, bv.size() * 4, hipMemcpyDeviceToHost));
     if (pl->H)
         GM_HIP(hipMemcpy(hv.data(), pl->hbin_v.p, hv.size() * 4, hipMemcpyDeviceToHost));
-    const uint64_t total = (uint64_t)bv[Bv] + hv[Bv];
+    const uint64_t total = (uint64_t)bv[pl->B] + hv[pl->B];
     uint64_t limit = 2 * (total / pl->B + 1);
     if (limit < 65536)
         limit = 65536;
@@ -1107,27 +1231,12 @@ int pb_make_items(PbPlan *pl)
     limit = (limit + 3) & ~3ull;
     std::vector<PbItem> items;
     uint32_t slots = 0;
-    // A bin with hub rows is streamed by ONE workgroup, in order (the running sums of its hub rows are a
-    // sequence); it is dispatched first (longest first) and at ~4 G entries/s per workgroup even the bin of the
-    // largest RMAT scale-26 row (1.1 M entries) ends well inside the kernel.  Beyond GM_PB_HUB_SERIAL entries
-    // (default 8 M: ids sorted by degree, one giant bin) the bin is sliced like any other and its rows fall back
-    // to exactly rounded sums.
-    const uint64_t hub_serial = (uint64_t)pb_env("GM_PB_HUB_SERIAL", 8 << 20);
-    pl->hub_edges_unsplit = pl->hub_edges;
     for (uint32_t b = 0; b < pl->B; ++b) {
-        const uint32_t q0 = bv[b << pl->vs], q1 = bv[(b + 1) << pl->vs], g0 = hv[b << pl->vs], g1 = hv[(b + 1) << pl->vs];
-        const uint32_t qh = pl->vs ? bv[(b << 1) + 1] : q1; // the terms of the bin's hub rows are [qh, q1)
+        const uint32_t q0 = bv[b], q1 = bv[b + 1], g0 = hv[b], g1 = hv[b + 1];
         const uint64_t len = (uint64_t)(q1 - q0) + (g1 - g0);
-        uint32_t nh = pl->bin_nh_host.empty() ? 0u : pl->bin_nh_host[b];
-        uint32_t parts = len > limit ? (uint32_t)((len + limit - 1) / limit) : 1u;
-        if (nh && parts > 1) {
-            if (len <= hub_serial)
-                parts = 1;
-            else
-                nh = 0, pl->hub_edges_unsplit = 0; // (not tracked per bin: reported as "none guaranteed")
-        }
+        const uint32_t parts = len > limit ? (uint32_t)((len + limit - 1) / limit) : 1u;
         if (parts == 1) {
-            items.push_back(PbItem{b, q0, q1, nh ? qh : q1, g0, g1, 1u, 0u, 0u, nh});
+            items.push_back(PbItem{b, q0, q1, g0, g1, 1u, 0u, 0u});
             continue;
         }
         const uint32_t per = (((q1 - q0) + parts - 1) / parts + 3u) & ~3u;
@@ -1139,7 +1248,7 @@ int pb_make_items(PbPlan *pl)
             e = e < q1 ? e : q1;
             hs = hs < g1 ? hs : g1;
             he = he < g1 ? he : g1;
-            items.push_back(PbItem{b, (uint32_t)s, (uint32_t)e, (uint32_t)e, (uint32_t)hs, (uint32_t)he, parts, slots, k, 0u});
+            items.push_back(PbItem{b, (uint32_t)s, (uint32_t)e, (uint32_t)hs, (uint32_t)he, parts, slots, k});
         }
         slots += parts;
     }
@@ -1153,6 +1262,15 @@ int pb_make_items(PbPlan *pl)
     GM_HIP(hipMemcpy(pl->items.p, items.data(), items.size() * sizeof(PbItem), hipMemcpyHostToDevice));
     pl->items_host = items;
     pl->slots = slots;
+    // hub groups: one workgroup walks a group in order (the running sums of its rows are a sequence); longest first
+    std::vector<PbHubItem> hubs;
+    for (uint32_t g = 0; g < pl->G; ++g)
+        hubs.push_back(PbHubItem{bv[pl->B + g], bv[pl->B + g + 1], pl->hub_first_host[g + 1] - pl->hub_first_host[g],
+                                 pl->hub_first_host[g], g});
+    std::stable_sort(hubs.begin(), hubs.end(), [](const PbHubItem &a, const PbHubItem &c) { return a.q1 - a.q0 > c.q1 - c.q0; });
+    GM_TRY(pl->hub_items.alloc((hubs.size() ? hubs.size() : 1) * sizeof(PbHubItem)));
+    if (!hubs.empty())
+        GM_HIP(hipMemcpy(pl->hub_items.p, hubs.data(), hubs.size() * sizeof(PbHubItem), hipMemcpyHostToDevice));
     return GM_OK;
 }
 
@@ -1193,56 +1311,83 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     if (pl->NT == 0)
         pl->NT = 1;
     const int sb = bits_for(x_len) < 1 ? 1 : bits_for(x_len);
-    GM_CHECK(bits_for(pl->B) + 1 + sb + rb <= 63, GM_ERR_RANGE, "pb_build: key does not fit 63 bits");
 
     gm::PhaseTimer timer((hipStream_t)0); // GM_LOG=1: where the plan construction time goes
     // accumulator slots only for rows that have in-edges (RMAT: about half of the rows have none); hub rows
-    // (summed in the reference's order, see the header) take the first slots of their bin
+    // (summed in the reference's order, see the header) leave the ordinary bins and form hub groups
     pl->hub_deg = (uint32_t)pb_env("GM_PB_HUB_DEG", 4096);
     GM_TRY(pl->cidx.alloc((size_t)(n ? n : 1) * 2));
-    GM_TRY(pl->bin_nh.alloc((size_t)pl->B * 4));
-    GM_HIP(hipMemset(pl->bin_nh.p, 0, (size_t)pl->B * 4));
-    pl->bin_nh_host.assign(pl->B, 0u);
     pl->Racc = 1;
+    DevBuf pos_h; // hub rows before each row (kept until the keys are built)
+    GM_TRY(pos_h.alloc(((size_t)n + 1) * 4));
+    pl->hub_first_host.assign(1, 0u);
     if (n) {
-        DevBuf flag, pos_h, pos, bin_rows, hub_edges;
+        DevBuf flag, pos, bin_rows;
         GM_TRY(flag.alloc(((size_t)n + 1) * 4));
-        GM_TRY(pos_h.alloc(((size_t)n + 1) * 4));
         GM_TRY(pos.alloc(((size_t)n + 1) * 4));
         GM_TRY(bin_rows.alloc((size_t)pl->B * 4));
-        GM_TRY(hub_edges.alloc(8));
-        GM_HIP(hipMemset(hub_edges.p, 0, 8));
         hipLaunchKernelGGL(pb_hubflag_kernel, dim3(pb_grid((uint64_t)n + 1)), dim3(256), 0, 0, csr->offsets, n, pl->hub_deg,
                            flag.as<uint32_t>());
         GM_HIP(hipGetLastError());
         GM_TRY(scan_exclusive<uint32_t>(flag.as<uint32_t>(), pos_h.as<uint32_t>(), (uint64_t)n + 1));
-        hipLaunchKernelGGL(pb_rowflag_kernel, dim3(pb_grid((uint64_t)n + 1)), dim3(256), 0, 0, csr->offsets,
-                           pos_h.as<uint32_t>(), n, rb, pl->hub_deg, flag.as<uint32_t>());
+        GM_HIP(hipMemcpy(&pl->n_hub, pos_h.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost));
+        if (pl->n_hub) {
+            // hub groups: consecutive hub rows, cut at PB_HUB_MAX rows or about one ordinary bin's worth of
+            // terms (so that a group's (tile, group) segments are as long as a bin's)
+            DevBuf hub_degs;
+            GM_TRY(pl->hub_rows.alloc((size_t)pl->n_hub * 4));
+            GM_TRY(hub_degs.alloc((size_t)pl->n_hub * 4));
+            hipLaunchKernelGGL(pb_hub_rows_kernel, dim3(pb_grid(n)), dim3(256), 0, 0, csr->offsets, pos_h.as<uint32_t>(), n,
+                               pl->hub_deg, pl->hub_rows.as<uint32_t>(), hub_degs.as<uint32_t>());
+            GM_HIP(hipGetLastError());
+            std::vector<uint32_t> degs(pl->n_hub);
+            GM_HIP(hipMemcpy(degs.data(), hub_degs.p, (size_t)pl->n_hub * 4, hipMemcpyDeviceToHost));
+            uint64_t target = (uint64_t)m_all / pl->B;
+            if (target < 65536)
+                target = 65536;
+            if (pb_env("GM_PB_HUB_GROUP", 0) > 0)
+                target = (uint64_t)pb_env("GM_PB_HUB_GROUP", 0);
+            uint64_t acc_edges = 0;
+            uint32_t count = 0;
+            for (uint32_t i = 0; i < pl->n_hub; ++i) {
+                pl->hub_edges += degs[i];
+                if (count && (count == PB_HUB_MAX || acc_edges + degs[i] > target)) {
+                    pl->hub_first_host.push_back(i);
+                    acc_edges = 0, count = 0;
+                }
+                acc_edges += degs[i];
+                ++count;
+            }
+            pl->hub_first_host.push_back(pl->n_hub);
+            pl->G = (uint32_t)pl->hub_first_host.size() - 1;
+        }
+        GM_TRY(pl->hub_first.alloc(pl->hub_first_host.size() * 4));
+        GM_HIP(hipMemcpy(pl->hub_first.p, pl->hub_first_host.data(), pl->hub_first_host.size() * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(pb_rowflag_kernel, dim3(pb_grid((uint64_t)n + 1)), dim3(256), 0, 0, csr->offsets, n, pl->hub_deg,
+                           flag.as<uint32_t>());
         GM_HIP(hipGetLastError());
         GM_TRY(scan_exclusive<uint32_t>(flag.as<uint32_t>(), pos.as<uint32_t>(), (uint64_t)n + 1));
-        hipLaunchKernelGGL(pb_cidx_kernel, dim3(pb_grid(n)), dim3(256), 0, 0, csr->offsets, pos_h.as<uint32_t>(),
-                           pos.as<uint32_t>(), n, rb, pl->hub_deg, pl->cidx.as<uint16_t>(), bin_rows.as<uint32_t>(),
-                           pl->bin_nh.as<uint32_t>(), hub_edges.as<unsigned long long>());
+        hipLaunchKernelGGL(pb_cidx_kernel, dim3(pb_grid(n)), dim3(256), 0, 0, csr->offsets, pos.as<uint32_t>(), n, rb,
+                           pl->hub_deg, pl->cidx.as<uint16_t>(), bin_rows.as<uint32_t>());
         GM_HIP(hipGetLastError());
         std::vector<uint32_t> rows(pl->B);
         GM_HIP(hipMemcpy(rows.data(), bin_rows.p, (size_t)pl->B * 4, hipMemcpyDeviceToHost));
-        GM_HIP(hipMemcpy(pl->bin_nh_host.data(), pl->bin_nh.p, (size_t)pl->B * 4, hipMemcpyDeviceToHost));
-        GM_HIP(hipMemcpy(&pl->hub_edges, hub_edges.p, 8, hipMemcpyDeviceToHost));
         uint32_t mx = 1;
         for (uint32_t v : rows)
             mx = v > mx ? v : mx;
-        for (uint32_t v : pl->bin_nh_host)
-            pl->n_hub += v;
         pl->Racc = (mx + 63u) & ~63u;
         if (pl->Racc > pl->R)
             pl->Racc = pl->R;
         if (pb_env("GM_PB_COMPACT", 1) == 0)
             pl->Racc = pl->R; // keep the slot numbering, size the LDS as if every row had one
+    } else {
+        GM_TRY(pl->hub_first.alloc(4));
+        GM_HIP(hipMemset(pl->hub_first.p, 0, 4));
     }
 
-    pl->vs = pl->n_hub ? 1 : 0;
-    const uint32_t Bv = pl->B << pl->vs; // virtual bins: (ordinary rows, hub rows) of every bin when there are hub rows
+    const uint32_t Bv = pl->B + pl->G; // virtual bins of the streams: the ordinary bins, then the hub groups
     const int bin_bits = bits_for(Bv) < 1 ? 1 : bits_for(Bv);
+    GM_CHECK(bin_bits + sb + rb <= 63, GM_ERR_RANGE, "pb_build: key does not fit 63 bits");
 
     // hot table size: what is left of the LDS beside the accumulators (2 workgroups per CU when the
     // accumulators are <= 64 KiB, else 1)
@@ -1252,8 +1397,11 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
         int wgs = acc_bytes > 65536 ? 1 : 2; // accumulate workgroups per CU the LDS request should allow
         if (pb_env("GM_PB_WGS", 0) == 1 || (pb_env("GM_PB_WGS", 0) == 0 && acc_bytes > 32768))
             wgs = 1;
-        // static LDS of the accumulate kernel (hub step sums + units + reduction scratch): PB_ACC_STATIC
-        const size_t budget = wgs == 1 ? (163840 - PB_ACC_STATIC - acc_bytes) : (81920 - PB_ACC_STATIC - acc_bytes);
+        // static LDS of the accumulate kernel: PB_ACC_STATIC; with hub groups, room for one pb_hub_kernel workgroup
+        // (13.5 KiB) beside the accumulate workgroup(s) of a CU
+        const size_t hub_room = (pl->G && pb_env("GM_PB_HUB_FORK", 0)) ? 14336 : 0;
+        const size_t budget = wgs == 1 ? (163840 - hub_room - PB_ACC_STATIC - acc_bytes)
+                                       : ((163840 - hub_room) / 2 - PB_ACC_STATIC - acc_bytes);
         H = (uint32_t)(budget / 4) & ~63u;
         if (H > 32768)
             H = 32768;
@@ -1324,14 +1472,15 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     GM_TRY(kalt.alloc((size_t)m_all * 8));
     const int hot_bit = bin_bits + sb + rb; // <= 63
     hipLaunchKernelGGL(pb_keys_kernel, dim3(pb_grid(n)), dim3(256), 0, 0, csr->offsets, csr->targets, n, rb, sb, hot_bit,
-                       pl->vs, H ? hot_rank.as<uint16_t>() : (const uint16_t *)nullptr, pl->cidx.as<uint16_t>(),
-                       pl->bin_nh.as<uint32_t>(), keys.as<uint64_t>());
+                       H ? hot_rank.as<uint16_t>() : (const uint16_t *)nullptr, pl->cidx.as<uint16_t>(),
+                       pos_h.as<uint32_t>(), pl->hub_first.as<uint32_t>(), pl->B, pl->G, keys.as<uint64_t>());
     GM_HIP(hipGetLastError());
     // (sorting only bits [rb, ..) would do — the slot order inside a (bin, source) is irrelevant — but rocPRIM's
     // radix sort was measured 14x slower with a non-zero begin bit at this size)
     GM_TRY(sort_keys_u64(keys, kalt, m_all, 0, H ? hot_bit + 1 : hot_bit));
     kalt.release();
     hot_rank.release();
+    pos_h.release();
     timer.done("pb plan: edge keys + sort");
 
     if (H) { // hot keys (top bit set) sit behind the cold ones, already ordered by (bin, hot index, row)
@@ -1506,10 +1655,9 @@ static hipError_t pb_set_kernel_attributes()
         reinterpret_cast<const void *>(&pb_bin_kernel<3, 14>), reinterpret_cast<const void *>(&pb_bin_kernel<4, 14>),
         reinterpret_cast<const void *>(&pb_bin_kernel<5, 14>), reinterpret_cast<const void *>(&pb_bin_kernel<0, 15>),
         reinterpret_cast<const void *>(&pb_bin_kernel<3, 15>), reinterpret_cast<const void *>(&pb_bin_kernel<5, 15>)};
-    const void *acc_fns[] = {reinterpret_cast<const void *>(&pb_accum_kernel<0, false>),
-                             reinterpret_cast<const void *>(&pb_accum_kernel<0, true>),
-                             reinterpret_cast<const void *>(&pb_accum_kernel<3, true>),
-                             reinterpret_cast<const void *>(&pb_accum_kernel<4, true>)};
+    const void *acc_fns[] = {reinterpret_cast<const void *>(&pb_accum_kernel<0>),
+                             reinterpret_cast<const void *>(&pb_accum_kernel<3>),
+                             reinterpret_cast<const void *>(&pb_accum_kernel<4>)};
     hipError_t e = hipSuccess;
     for (const void *f : bin_fns)
         if (e == hipSuccess)
@@ -1573,7 +1721,7 @@ int pb_scratch_create(const PbPlan *pl, PbScratch **out)
     int rc;
     if ((rc = sc->vals_raw.alloc((size_t)(pl->Mv ? pl->Mv : 4) * 4)) ||
         (rc = sc->partials.alloc((size_t)(pl->slots ? pl->slots : 1) * pl->Racc * 8)) ||
-        (rc = sc->tickets.alloc((size_t)pl->B * 4)) || (rc = sc->bin_err.alloc((size_t)pl->B * 8)) ||
+        (rc = sc->tickets.alloc((size_t)pl->B * 4)) || (rc = sc->bin_err.alloc(((size_t)pl->B + pl->G) * 8)) ||
         (rc = sc->hot_x.alloc(((size_t)pl->H + 4) * 4))) {
         delete sc;
         return rc;
@@ -1582,6 +1730,13 @@ int pb_scratch_create(const PbPlan *pl, PbScratch **out)
     hipError_t e = hipMemset(sc->tickets.p, 0, (size_t)pl->B * 4);
     if (e == hipSuccess)
         e = hipMemset(sc->vals_raw.p, 0, sc->vals_raw.bytes);
+    if (e == hipSuccess && pl->G) { // the hub groups' own stream
+        e = hipStreamCreateWithFlags(&sc->side, hipStreamNonBlocking);
+        if (e == hipSuccess)
+            e = hipEventCreateWithFlags(&sc->ev_fork, hipEventDisableTiming);
+        if (e == hipSuccess)
+            e = hipEventCreateWithFlags(&sc->ev_join, hipEventDisableTiming);
+    }
     // hipMemset on device memory returns before the fill has run, and the sweeps run on the caller's
     // (possibly non-blocking) stream, which the null stream does not order against
     if (e == hipSuccess)
@@ -1602,7 +1757,7 @@ uint64_t pb_work_items(const PbPlan *plan) { return plan ? (uint64_t)plan->NW + 
 // diagnostics (gm_pr_plan_info): what the plan costs and what it contains
 void pb_plan_info(const PbPlan *pl, const PbScratch *sc, uint64_t *info, uint32_t count)
 {
-    const DevBuf *bufs[] = {&pl->cidx, &pl->bin_nh, &pl->p1_src, &pl->chunk_seg, &pl->delta, &pl->tile_p, &pl->wg_tile,
+    const DevBuf *bufs[] = {&pl->cidx, &pl->hub_rows, &pl->p1_src, &pl->chunk_seg, &pl->delta, &pl->tile_p, &pl->wg_tile,
                             &pl->wg_p0,  &pl->p2_dst, &pl->bin_v,  &pl->items,     &pl->hot_ids, &pl->hot_ent, &pl->hbin_v};
     uint64_t plan_bytes = 0;
     for (const DevBuf *b : bufs)
@@ -1610,7 +1765,7 @@ void pb_plan_info(const PbPlan *pl, const PbScratch *sc, uint64_t *info, uint32_
     const uint64_t scratch_bytes = sc ? sc->vals_raw.bytes + sc->partials.bytes + sc->tickets.bytes + sc->bin_err.bytes +
                                             sc->hot_x.bytes : 0;
     const uint64_t v[] = {plan_bytes, (uint64_t)(pl->build_ms * 1000.0), pl->n_hub, pl->hub_edges, pl->hub_deg, pl->H,
-                          pl->Mv, pl->Mh, scratch_bytes, pl->B, pl->NT, pl->NS, pl->hub_edges_unsplit};
+                          pl->Mv, pl->Mh, scratch_bytes, pl->B, pl->NT, pl->NS, pl->G};
     for (uint32_t i = 0; i < count; ++i)
         info[i] = i < sizeof(v) / sizeof(v[0]) ? v[i] : 0;
 }
@@ -1624,11 +1779,11 @@ void pb_launch_bin(const PbPlan *pl, PbScratch *sc, const float *x_in, uint32_t 
                        pl->chunk, w_first, pl->xcd_aware);
 }
 
-template <int ABL, bool HUB>
+template <int ABL>
 void pb_launch_accum(const PbPlan *pl, PbScratch *sc, const PbItem *items, uint32_t count, float *x_out, float *scores,
                      const uint32_t *outdeg, float base, float damping, hipStream_t st)
 {
-    hipLaunchKernelGGL((pb_accum_kernel<ABL, HUB>), dim3(count), dim3(PB_ACC_BLOCK),
+    hipLaunchKernelGGL(pb_accum_kernel<ABL>, dim3(count), dim3(PB_ACC_BLOCK),
                        (size_t)pl->Racc * 8 + (((size_t)pl->H + 3) & ~(size_t)3) * 4, st, sc->vals, pl->p2_dst.as<uint16_t>(),
                        items, pl->hot_ent.as<uint32_t>(), sc->hot_x.as<float>(), pl->H,
                        sc->partials.as<unsigned long long>(), sc->tickets.as<uint32_t>(), pl->cidx.as<uint16_t>(), outdeg,
@@ -1666,15 +1821,20 @@ static void pb_accum_dispatch(const PbPlan *pl, PbScratch *sc, const PbItem *ite
     if (count == 0)
         return;
     switch (pb_env("GM_PB_ABLATE", 0) / 10) {
-    case 3: pb_launch_accum<3, true>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
-    case 4: pb_launch_accum<4, true>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
-    default:
-        if (pl->n_hub)
-            pb_launch_accum<0, true>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st);
-        else
-            pb_launch_accum<0, false>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st);
-        break;
+    case 3: pb_launch_accum<3>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
+    case 4: pb_launch_accum<4>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
+    default: pb_launch_accum<0>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
     }
+}
+
+// every hub group of the plan (its value-stream part must have been written: after the bin kernel)
+static void pb_hub_dispatch(const PbPlan *pl, PbScratch *sc, float *x_out, float *scores, const uint32_t *outdeg, float base,
+                            float damping, hipStream_t st)
+{
+    if (pl->G)
+        hipLaunchKernelGGL(pb_hub_kernel, dim3(pl->G), dim3(PB_ACC_BLOCK), 0, st, sc->vals, pl->p2_dst.as<uint16_t>(),
+                           pl->hub_items.as<PbHubItem>(), pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out,
+                           sc->bin_err.as<double>() + pl->B, base, damping);
 }
 
 static void pb_hot_dispatch(const PbPlan *pl, PbScratch *sc, const float *x_in, hipStream_t st)
@@ -1689,7 +1849,21 @@ int pb_sweep_main(const PbPlan *pl, PbScratch *sc, const float *x_in, float *x_o
 {
     pb_hot_dispatch(pl, sc, x_in, st);
     pb_bin_dispatch(pl, sc, x_in, 0, pl->NW, st);
+    // the hub groups need little LDS: on a second stream their workgroups run beside those of the ordinary bins
+    // (measured at scale 26 / 22: beside the accumulate kernel on a second stream the two only slow each other
+    // down — 3.23 vs 3.19 ms, 0.249 vs 0.275 ms — so the default is one stream; GM_PB_HUB_FORK=1 forks)
+    const bool fork = pl->G && sc->side && pl->hub_edges >= (1u << 20) && pb_env("GM_PB_HUB_FORK", 0);
+    if (fork) {
+        GM_HIP(hipEventRecord(sc->ev_fork, st));
+        GM_HIP(hipStreamWaitEvent(sc->side, sc->ev_fork, 0));
+        pb_hub_dispatch(pl, sc, x_out, scores, outdeg, base, damping, sc->side);
+        GM_HIP(hipEventRecord(sc->ev_join, sc->side));
+    } else {
+        pb_hub_dispatch(pl, sc, x_out, scores, outdeg, base, damping, st);
+    }
     pb_accum_dispatch(pl, sc, pl->items.as<PbItem>(), pl->NI, x_out, scores, outdeg, base, damping, st);
+    if (fork)
+        GM_HIP(hipStreamWaitEvent(st, sc->ev_join, 0));
     GM_HIP(hipGetLastError());
     return GM_OK;
 }
@@ -1765,6 +1939,8 @@ int pb_sweep_accum_part(const PbPlan *pl, PbScratch *sc, const float *x_in, floa
              sc->part_off.empty() ? (size_t)0 : sc->part_off.size() - 1);
     if (stage_hot)
         pb_hot_dispatch(pl, sc, x_in, st);
+    if (part == 0) // every hub row is finished with the first part: before any region of x_out is exchanged
+        pb_hub_dispatch(pl, sc, x_out, scores, outdeg, base, damping, st);
     const uint32_t i0 = sc->part_off[part], i1 = sc->part_off[part + 1];
     pb_accum_dispatch(pl, sc, sc->part_items.as<PbItem>() + i0, i1 - i0, x_out, scores, outdeg, base, damping, st);
     GM_HIP(hipGetLastError());
@@ -1773,7 +1949,7 @@ int pb_sweep_accum_part(const PbPlan *pl, PbScratch *sc, const float *x_in, floa
 
 int pb_sweep_error(const PbPlan *pl, PbScratch *sc, double *err_out, hipStream_t st)
 {
-    hipLaunchKernelGGL(pb_err_kernel, dim3(1), dim3(1024), 0, st, sc->bin_err.as<double>(), pl->B, err_out);
+    hipLaunchKernelGGL(pb_err_kernel, dim3(1), dim3(1024), 0, st, sc->bin_err.as<double>(), pl->B + pl->G, err_out);
     GM_HIP(hipGetLastError());
     return GM_OK;
 }

@@ -57,7 +57,7 @@ class PageRankEngine:
         v = (C.c_uint64 * 13)()
         check(lib().gm_pr_plan_info(self._h, v, 13))
         keys = ("plan_bytes", "plan_build_us", "hub_rows", "hub_edges", "hub_in_degree", "hot_sources", "value_entries",
-                "hot_edges", "scratch_bytes", "bins", "source_tiles", "segments", "hub_edges_in_order")
+                "hot_edges", "scratch_bytes", "bins", "source_tiles", "segments", "hub_groups")
         return dict(zip(keys, (int(x) for x in v)))
 
     def init(self, scores_local: torch.Tensor, x_local: torch.Tensor):

@@ -220,8 +220,8 @@ uint64_t gm_pr_tile_count(const gm_pr *pr); /* workgroups per sweep (diagnostics
  * and cached in the gm_csr), [2] hub rows whose sums follow the reference's left-to-right f32 order
  * (page_rank.rs:143-146), [3] their in-edges, [4] the in-degree threshold for that (GM_PB_HUB_DEG, default
  * 4096, 0 = off), [5] hot sources, [6] entries of the value stream, [7] hot edges, [8] bytes of this engine's
- * scratch (value stream etc.), [9] bins, [10] source tiles, [11] (tile, bin) segments, [12] hub in-edges in bins
- * that one workgroup streams in order (= [3] unless a giant bin had to be sliced).  Further entries are 0. */
+ * scratch (value stream etc.), [9] bins, [10] source tiles, [11] (tile, bin) segments, [12] hub groups (the hub
+ * rows are walked in groups of <= 64 rows, one workgroup each).  Further entries are 0. */
 int gm_pr_plan_info(const gm_pr *pr, uint64_t *info, uint32_t count);
 
 /* ---------------------------------------------------------------------------------------------

@@ -327,6 +327,21 @@ std::tuple<std::vector<float>, size_t, double> page_rank(const DirectedCsrGraph<
     return {std::move(scores), (size_t)iterations, error};
 }
 
+// The same call on a graph split over `devices` GPUs of this node (gm_page_rank_multi: 1-D in-degree-balanced row
+// ranges, RCCL all-gather of out_scores per sweep, one host thread).  An ordinal listed twice = virtual ranks.
+template <class NI>
+std::tuple<std::vector<float>, size_t, double> page_rank_multi(const DirectedCsrGraph<NI> &g, const std::vector<int> &devices,
+                                                               PageRankConfig config = {})
+{
+    const uint64_t n = gm_csr_node_count(g.csr_inc());
+    std::vector<float> scores(n);
+    uint64_t iterations = 0;
+    double error = 0.0;
+    detail::check(gm_page_rank_multi(g.csr_out(), g.csr_inc(), devices.data(), (uint32_t)devices.size(), config.max_iterations,
+                                     config.tolerance, config.damping_factor, scores.data(), &iterations, &error));
+    return {std::move(scores), (size_t)iterations, error};
+}
+
 // crates/algos/src/wcc.rs:43-79 (chunk_size is a CPU scheduling knob)
 struct WccConfig {
     size_t chunk_size = 16384, neighbor_rounds = 2, sampling_size = 1024;
@@ -394,6 +409,7 @@ using graph::global_triangle_count;
 using graph::Graph500Input;
 using graph::GraphBuilder;
 using graph::page_rank;
+using graph::page_rank_multi;
 using graph::PageRankConfig;
 using graph::relabel_graph;
 using graph::UndirectedCsrGraph;

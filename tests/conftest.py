@@ -12,6 +12,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu through gpurun)")
+    config.addinivalue_line("markers", "hub_order: runs with the default hub-row handling (reference summation order); "
+                            "unmarked tests of test_gpu_parity.py pin GM_PB_HUB_DEG=0, every row exactly rounded")
 
 
 @pytest.fixture(scope="session")

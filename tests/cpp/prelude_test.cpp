@@ -55,6 +55,22 @@ int main(int argc, char **argv)
             (void)iterations;
             (void)error;
         }
+        { // the same call split over GPUs through the C ABI (RCCL from the compiled host): a communicator of the
+          // size this box has, and three virtual ranks on device 0
+            auto g = GraphBuilder()
+                         .csr_layout(CsrLayout::Sorted)
+                         .edges({{0, 1}, {1, 2}, {0, 2}, {3, 4}, {4, 5}, {3, 5}, {5, 0}, {2, 3}})
+                         .build<DirectedCsrGraph<uint32_t>>();
+            auto [one, it1, e1] = page_rank(g, PageRankConfig{12, 0.0, 0.85f}, GM_PR_JACOBI);
+            for (const std::vector<int> &devs : {std::vector<int>{0}, std::vector<int>{0, 0, 0}}) {
+                auto [many, it, e] = page_rank_multi(g, devs, PageRankConfig{12, 0.0, 0.85f});
+                EXPECT(it == it1 && it == 12);
+                for (size_t i = 0; i < one.size(); ++i)
+                    EXPECT(std::fabs(many[i] - one[i]) <= 2e-7f * one[i]);
+                (void)e;
+            }
+            (void)e1;
+        }
         { // crates/algos/src/wcc.rs:307-329
             auto g = GraphBuilder().edges({{0, 1}, {2, 3}}).build<DirectedCsrGraph<uint32_t>>();
             for (int k = 0; k < 3; ++k) {

@@ -28,33 +28,40 @@ def rmat22(env):
     return g, src, dst, n
 
 
-def test_scale22_page_rank_engines_agree_and_match_reference_order(env, oracle, rmat22):
+def test_scale22_page_rank_engines_agree_and_match_reference_order(env, oracle, rmat22, monkeypatch):
     P, synth, torch = env
     g, src, dst, n = rmat22
     cfg = P.PageRankConfig(200, 1e-10, 0.85)
-    pb, it_pb, err_pb = P.page_rank(g, cfg, P.PageRankMode.JacobiPB)
-    pull, it_pull, err_pull = P.page_rank(g, cfg, P.PageRankMode.JacobiPull)
-    assert abs(it_pb - it_pull) <= 15  # near 1e-10 the stopping error is f32 rounding noise
-    np.testing.assert_allclose(pb, pull, rtol=2e-6, atol=0)           # exact row sums vs f32 tree sums
+    pb, it_pb, err_pb = P.page_rank(g, cfg, P.PageRankMode.JacobiPB)   # default: long rows in the reference's order
     again, _, err_again = P.page_rank(g, cfg, P.PageRankMode.JacobiPB)
     assert np.array_equal(pb, again) and err_pb == err_again           # bit-reproducible
     assert 0.0 < float(pb.astype(np.float64).sum()) <= 1.0 + 1e-6      # no dangling redistribution: mass only leaks
     assert np.all(pb >= (np.float32(1) - np.float32(0.85)) / np.float32(n))
-    # against the reference's threaded order at its fixed point (oracle: ~1 s on the box's host cores)
+    # against the reference's threaded order at its fixed point (oracle: ~1 s on the box's host cores): EVERY row
     ioff, itgt, _ = g.csr_inc.host()
     od = g.csr_out.degrees()
     ref, _, _ = oracle.page_rank_chunked(ioff, itgt, od, 200, 1e-10, 0.85)
     deg = np.diff(ioff).astype(np.float64)
     rel = np.abs(pb.astype(np.float64) - ref) / ref
-    assert rel[deg < 4096].max() <= 1e-5, rel[deg < 4096].max()
-    assert np.all(rel <= np.maximum(1e-5, deg * 2.0 ** -24))            # hubs: the reference order's own drift bound
-    print(f"scale 22: {it_pb} sweeps; vs reference order: max rel {rel.max():.2e} overall, "
-          f"{rel[deg < 4096].max():.2e} below in-degree 4096 (max in-degree {int(deg.max())})")
-    # the same sweeps with the reference's left-to-right f32 row sums meet 1e-5 on EVERY row, hubs included
+    print(f"scale 22: {it_pb} sweeps; vs the reference: max rel {rel.max():.2e} on every row, "
+          f"{rel[deg >= 4096].max():.2e} on rows with >= 4096 in-edges (max in-degree {int(deg.max())})")
+    assert rel.max() <= 1e-5, rel.max()
+    assert rel.max() <= 6e-6  # measured 2.9e-6: margin against the bar
+    # the sweep engines against each other with every row exactly rounded (a private plan: the cached one has hub groups)
+    monkeypatch.setenv("GM_PB_HUB_DEG", "0")
+    monkeypatch.setenv("GM_PB_NOCACHE", "1")
+    pbx, it_x, _ = P.page_rank(g, cfg, P.PageRankMode.JacobiPB)
+    pull, it_pull, err_pull = P.page_rank(g, cfg, P.PageRankMode.JacobiPull)
+    assert abs(it_x - it_pull) <= 15  # near 1e-10 the stopping error is f32 rounding noise
+    np.testing.assert_allclose(pbx, pull, rtol=2e-6, atol=0)           # exact row sums vs f32 tree sums
+    relx = np.abs(pbx.astype(np.float64) - ref) / ref
+    print(f"scale 22, every row exactly rounded: max rel vs the reference {relx.max():.2e} (the long rows of the reference drift)")
+    assert relx.max() > rel.max()
+    # the same sweeps with the reference's left-to-right f32 row sums (one lane per row) meet 1e-5 on every row too
     ro, it_ro, _ = P.page_rank(g, cfg, P.PageRankMode.JacobiRefOrder)
     rel_ro = np.abs(ro.astype(np.float64) - ref) / ref
     assert rel_ro.max() <= 1e-5, rel_ro.max()
-    print(f"scale 22, reference summation order: {it_ro} sweeps, max rel vs reference {rel_ro.max():.2e}")
+    print(f"scale 22, reference summation order on every row: {it_ro} sweeps, max rel vs reference {rel_ro.max():.2e}")
 
 
 def test_scale22_wcc_bit_exact(env, oracle, rmat22):

@@ -1,0 +1,71 @@
+"""gm_page_rank_multi: the 1-D partitioned page_rank behind the C ABI (graph_amd/csrc/multi.hip) — partition,
+index rewrite, sweep drivers and the exchange, with RCCL on the devices this box has (one: a communicator of
+size 1) and with virtual ranks (several ranks on device 0, copies standing in for the all-gather)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def P():
+    from graph_amd import prelude
+
+    return prelude
+
+
+def _graph(P, oracle, scale, seed=42):
+    s, d = oracle.rmat_edges(scale, seed=seed)
+    n = 1 << scale
+    out = P.DeviceCsr.from_edges(n, s, d, None, P.Direction.Outgoing, P.CsrLayout.Sorted)
+    inc = P.DeviceCsr.from_edges(n, s, d, None, P.Direction.Incoming, P.CsrLayout.Sorted)
+    return P.DirectedCsrGraph(out, inc, P.CsrLayout.Sorted), np.bincount(d, minlength=n)
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0, 0, 0]])
+def test_partitioned_page_rank_matches_the_single_gpu_engine(P, oracle, devices, monkeypatch):
+    monkeypatch.setenv("GM_MULTI_ENGINE", "pb")  # the same engine on both sides: exactly rounded row sums
+    g, indeg = _graph(P, oracle, 17)
+    cfg = P.PageRankConfig(7, 0.0, 0.85)
+    one, it1, err1 = P.page_rank(g, cfg, P.PageRankMode.JacobiPB)
+    got, it, err = P.page_rank_multi(g, cfg, devices=devices)
+    assert it == it1 == 7
+    # hub rows (>= 4096 in-edges) are summed step by step in the reference's order and the step boundaries move
+    # with the layout of a rank's slice; what they feed inherits that difference
+    np.testing.assert_allclose(got, one, rtol=4e-6, atol=0)
+    assert abs(err - err1) <= 1e-5 * max(err1, 1e-30)
+    again, _, err2 = P.page_rank_multi(g, cfg, devices=devices)
+    assert np.array_equal(got, again) and err == err2  # deterministic
+    # with every row exactly rounded (GM_PB_HUB_DEG=0) the row sums do not depend on the partition at all
+    monkeypatch.setenv("GM_PB_HUB_DEG", "0")
+    monkeypatch.setenv("GM_PB_NOCACHE", "1")
+    one0, _, _ = P.page_rank(g, cfg, P.PageRankMode.JacobiPB)
+    got0, _, _ = P.page_rank_multi(g, cfg, devices=devices)
+    assert np.array_equal(got0, one0)
+
+
+def test_partitioned_page_rank_stop_rule_and_default_engines(P, oracle):
+    g, _ = _graph(P, oracle, 15, seed=7)
+    ref, it_ref, err_ref = P.page_rank(g, P.PageRankConfig(), P.PageRankMode.Jacobi)
+    for devices in ([0], [0, 0, 0]):
+        got, it, err = P.page_rank_multi(g, P.PageRankConfig(), devices=devices)
+        assert it == it_ref and (err < 1e-4 or it == 20)
+        np.testing.assert_allclose(got, ref, rtol=4e-6, atol=0)
+    # n_devices beyond what the box shows is an error, not a crash
+    from graph_amd._lib import GraphMI355XError
+    import graph_amd
+
+    with pytest.raises(GraphMI355XError):
+        P.page_rank_multi(g, P.PageRankConfig(), n_devices=graph_amd.device_count() + 1)
+    # max_iterations = 1: one sweep
+    got, it, _ = P.page_rank_multi(g, P.PageRankConfig(1, 1e-4, 0.85), devices=[0, 0])
+    assert it == 1
+
+
+def test_partitioned_page_rank_more_ranks_than_rows_with_edges(P):
+    # 6 nodes, 3 virtual ranks, empty trailing ranges
+    g = P.GraphBuilder().csr_layout(P.CsrLayout.Sorted).edges([(0, 1), (1, 2), (0, 2), (3, 4), (4, 5), (3, 5)]).build(P.DirectedCsrGraph)
+    ref = P.page_rank(g, P.PageRankConfig(5, 0.0, 0.85), P.PageRankMode.Jacobi)
+    got = P.page_rank_multi(g, P.PageRankConfig(5, 0.0, 0.85), devices=[0, 0, 0])
+    np.testing.assert_allclose(got[0], ref[0], rtol=2e-7, atol=0)
+    assert got[1] == 5
