@@ -22,7 +22,7 @@ rec["_method"] = (
 entry = {}
 total = 0
 for name, c in d.items():
-    if "pb_bin_kernel" in name or "pb_accum_kernel" in name or "pr_tile_kernel" in name or "pb_hot_gather" in name:
+    if any(k in name for k in ("pb_bin_kernel", "pb_accum_kernel", "pb_hub_kernel", "pr_tile_kernel", "pb_hot_gather")):
         short = name.split("::")[-1].split("(")[0].split("<")[0]
         b = int(2 * c.get("FETCH_SIZE", 0) * KIB + c.get("WRITE_SIZE", 0) * KIB)
         entry[short] = {"FETCH_SIZE_KiB": c.get("FETCH_SIZE"), "WRITE_SIZE_KiB": c.get("WRITE_SIZE"), "hbm_bytes": b}
