@@ -912,7 +912,7 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
 // 2.7 us against 1.2 us for the step's 24 KiB at the sweep's memory rate), hence: no branches per term (padding
 // goes to a dummy row whose scale is 0), the rare general cases out of line, and the step's bookkeeping on one
 // wavefront instead of redundantly on all sixteen.
-__global__ __launch_bounds__(PB_ACC_BLOCK) void pb_hub_kernel(const float *__restrict__ vals,
+__global__ __launch_bounds__(PB_ACC_BLOCK, 8) void pb_hub_kernel(const float *__restrict__ vals,
                                                               const uint16_t *__restrict__ p2_dst,
                                                               const PbHubItem *__restrict__ items,
                                                               const uint32_t *__restrict__ hub_rows,
@@ -939,7 +939,7 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_hub_kernel(const float *__res
             dd = U16x4{(uint16_t)raw.x, (uint16_t)(raw.x >> 16), (uint16_t)raw.y, (uint16_t)(raw.y >> 16)};
         }
     };
-    constexpr int HS = 4; // blocks in flight
+    constexpr int HS = 2; // blocks in flight (64 VGPRs: the workgroup fits beside an accumulate workgroup on its CU)
     f32x4 hv[HS];
     U16x4 hd[HS];
     const uint32_t h_first = hb + tid * PB_VEC;
@@ -1399,7 +1399,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
             wgs = 1;
         // static LDS of the accumulate kernel: PB_ACC_STATIC; with hub groups, room for one pb_hub_kernel workgroup
         // (13.5 KiB) beside the accumulate workgroup(s) of a CU
-        const size_t hub_room = (pl->G && pb_env("GM_PB_HUB_FORK", 0)) ? 14336 : 0;
+        const size_t hub_room = (pl->G && pb_env("GM_PB_HUB_FORK", 1)) ? 14336 : 0;
         const size_t budget = wgs == 1 ? (163840 - hub_room - PB_ACC_STATIC - acc_bytes)
                                        : ((163840 - hub_room) / 2 - PB_ACC_STATIC - acc_bytes);
         H = (uint32_t)(budget / 4) & ~63u;
@@ -1850,9 +1850,9 @@ int pb_sweep_main(const PbPlan *pl, PbScratch *sc, const float *x_in, float *x_o
     pb_hot_dispatch(pl, sc, x_in, st);
     pb_bin_dispatch(pl, sc, x_in, 0, pl->NW, st);
     // the hub groups need little LDS: on a second stream their workgroups run beside those of the ordinary bins
-    // (measured at scale 26 / 22: beside the accumulate kernel on a second stream the two only slow each other
-    // down — 3.23 vs 3.19 ms, 0.249 vs 0.275 ms — so the default is one stream; GM_PB_HUB_FORK=1 forks)
-    const bool fork = pl->G && sc->side && pl->hub_edges >= (1u << 20) && pb_env("GM_PB_HUB_FORK", 0);
+    // (measured at scale 26 / 22 on one box: 3.12 / 3.24 ms forked vs 3.33 / 3.44 ms in line, 0.216 vs 0.252 ms;
+    // with the 85-VGPR version of the kernel the two could not share a CU and forking gained nothing)
+    const bool fork = pl->G && sc->side && pl->hub_edges >= (1u << 20) && pb_env("GM_PB_HUB_FORK", 1);
     if (fork) {
         GM_HIP(hipEventRecord(sc->ev_fork, st));
         GM_HIP(hipStreamWaitEvent(sc->side, sc->ev_fork, 0));
