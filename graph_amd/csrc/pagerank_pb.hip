@@ -172,21 +172,22 @@ struct PbPlan {
 namespace {
 
 // ---- plan construction ---------------------------------------------------------------------------
-// key = bin << (sb + rb) | src << rb | row_in_bin      (sorted ascending = bin-major, then source, then row)
+// key = slot << (sb + bb + 1) | hot << (sb + bb) | bin << sb | src      (sb = bits of a source id, bb = of a bin id)
+// Only the low sb + bb + 1 bits are sorted (LSD radix, stable): bin-major, then source, then CSR order — the
+// accumulator slot rides in the unsorted high bits (its order inside a (bin, source) is irrelevant), which saves
+// two of the seven 8-bit passes over the 8 GB of keys at scale 26.  A hot edge carries the hot index of its
+// source in the source field and the flag bit above the bin, so hot keys sort behind every cold key, bin-major.
 // A hub row (header) belongs to no ordinary bin: its bin field holds the VIRTUAL bin B + (its hub group) and its
 // slot is its position inside the group.  Everything below simply sees B + G bins.
-// cold key: bin << (sb+rb) | src << rb | slot.   hot key: 1 << (bin_bits+sb+rb) | bin << (sb+rb) | hot index << rb
-// | slot (the hot index is < x_len, so it fits the source field) — the flag bit sits just above the cold key, so
-// hot keys sort behind every cold key, bin-major; only bits [0, bin_bits+sb+rb] take part in the sort.
-__device__ __forceinline__ uint64_t pb_make_key(uint64_t hi_cold, uint32_t r, uint32_t slot, uint32_t src, int rb, int sb,
-                                                int hot_bit, const uint16_t *__restrict__ hot_rank)
+__device__ __forceinline__ uint64_t pb_make_key(uint64_t hi_cold, uint32_t src, int sb, int bb,
+                                                const uint16_t *__restrict__ hot_rank)
 {
     if (hot_rank) { // (null for hub rows: every term of theirs must pass the value stream in source order)
         const uint16_t h = hot_rank[src];
         if (h != PB_NULL)
-            return (1ull << hot_bit) | ((uint64_t)(r >> rb) << (sb + rb)) | ((uint64_t)h << rb) | slot;
+            return hi_cold | (1ull << (sb + bb)) | h;
     }
-    return hi_cold | ((uint64_t)src << rb);
+    return hi_cold | src;
 }
 
 // hub rows: >= hub_deg in-edges
@@ -269,15 +270,14 @@ __global__ void pb_hot_select_kernel(const uint64_t *__restrict__ sorted, uint32
 }
 
 __global__ void pb_hot_fill_kernel(const uint64_t *__restrict__ hkeys, uint32_t mh, const uint32_t *__restrict__ hstart,
-                                   const uint32_t *__restrict__ hbin_v, int bin_shift, uint32_t bin_mask, int rb,
-                                   uint32_t *__restrict__ hot_ent)
+                                   const uint32_t *__restrict__ hbin_v, int sb, int bb, uint32_t *__restrict__ hot_ent)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < mh; i += stride) {
         const uint64_t k = hkeys[i];
-        const uint32_t bin = (uint32_t)(k >> bin_shift) & bin_mask;
-        const uint32_t slot = (uint32_t)k & ((1u << rb) - 1u);
-        const uint32_t h = (uint32_t)((k >> rb) & ((1ull << (bin_shift - rb)) - 1ull));
+        const uint32_t bin = (uint32_t)(k >> sb) & (uint32_t)((1ull << bb) - 1ull);
+        const uint32_t slot = (uint32_t)(k >> (sb + bb + 1));
+        const uint32_t h = (uint32_t)(k & ((1ull << sb) - 1ull));
         hot_ent[hbin_v[bin] + (i - hstart[bin])] = (slot << 16) | h;
     }
 }
@@ -298,7 +298,7 @@ __global__ void pb_hot_gather_kernel(const float *__restrict__ x_in, const uint3
 }
 
 __global__ __launch_bounds__(256) void pb_keys_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt,
-                                                      uint32_t n, int rb, int sb, int hot_bit,
+                                                      uint32_t n, int rb, int sb, int bb,
                                                       const uint16_t *__restrict__ hot_rank,
                                                       const uint16_t *__restrict__ cidx, const uint32_t *__restrict__ pos_h,
                                                       const uint32_t *__restrict__ hub_first, uint32_t B, uint32_t G,
@@ -324,45 +324,44 @@ __global__ __launch_bounds__(256) void pb_keys_kernel(const uint32_t *__restrict
             vbin = B + g;
             slot = i - hub_first[g];
         }
-        const uint64_t hi = ((uint64_t)vbin << (sb + rb)) | (slot & rmask);
+        const uint64_t hi = ((uint64_t)(slot & rmask) << (sb + bb + 1)) | ((uint64_t)vbin << sb);
         if (len <= 32)
             for (uint32_t i = s; i < e; ++i)
-                keys[i] = pb_make_key(hi, r, slot, tgt[i], rb, sb, hot_bit, hub ? nullptr : hot_rank);
+                keys[i] = pb_make_key(hi, tgt[i], sb, bb, hub ? nullptr : hot_rank);
         uint64_t big = __ballot(len > 32);
         while (big) {
             const int src = __ffsll((unsigned long long)big) - 1;
             big &= big - 1;
             const uint32_t bs = __shfl(s, src, kWave), be = __shfl(e, src, kWave);
             const uint64_t bhi = __shfl(hi, src, kWave);
-            const uint32_t br = __shfl(r, src, kWave), bslot = __shfl(slot, src, kWave);
             const bool bhub = __shfl((int)hub, src, kWave) != 0;
             for (uint32_t i = bs + lane; i < be; i += kWave)
-                keys[i] = pb_make_key(bhi, br, bslot, tgt[i], rb, sb, hot_bit, bhub ? nullptr : hot_rank);
+                keys[i] = pb_make_key(bhi, tgt[i], sb, bb, bhub ? nullptr : hot_rank);
         }
     }
 }
 
-__device__ __forceinline__ uint64_t pb_seg_of_key(uint64_t k, int rb, int sb, int s_log)
+__device__ __forceinline__ uint64_t pb_seg_of_key(uint64_t k, int bb, int sb, int s_log)
 {
     // (bin, tile) as one comparable integer: bin << 32 | tile
-    const uint64_t bin = k >> (sb + rb);
-    const uint64_t src = (k >> rb) & ((1ull << sb) - 1ull);
+    const uint64_t bin = (k >> sb) & ((1ull << bb) - 1ull);
+    const uint64_t src = k & ((1ull << sb) - 1ull);
     return (bin << 32) | (src >> s_log);
 }
 
-__global__ void pb_flags_kernel(const uint64_t *__restrict__ keys, uint32_t m, int rb, int sb, int s_log,
+__global__ void pb_flags_kernel(const uint64_t *__restrict__ keys, uint32_t m, int bb, int sb, int s_log,
                                 uint32_t *__restrict__ flag)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < m; q += stride) {
         const uint64_t k = keys[q];
-        flag[q] = (q == 0 || pb_seg_of_key(keys[q - 1], rb, sb, s_log) != pb_seg_of_key(k, rb, sb, s_log)) ? 1u : 0u;
+        flag[q] = (q == 0 || pb_seg_of_key(keys[q - 1], bb, sb, s_log) != pb_seg_of_key(k, bb, sb, s_log)) ? 1u : 0u;
     }
 }
 
 // segid = inclusive_scan(flag); for every segment start: vstart[j] = q, segkey[j] = tile << 32 | bin, segval[j] = j
 __global__ void pb_segments_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ flag,
-                                   const uint32_t *__restrict__ segid_incl, uint32_t m, int rb, int sb, int s_log,
+                                   const uint32_t *__restrict__ segid_incl, uint32_t m, int bb, int sb, int s_log,
                                    uint32_t *__restrict__ vstart, uint64_t *__restrict__ segkey,
                                    uint32_t *__restrict__ segval, uint64_t *__restrict__ segbin)
 {
@@ -370,7 +369,7 @@ __global__ void pb_segments_kernel(const uint64_t *__restrict__ keys, const uint
     for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < m; q += stride)
         if (flag[q]) {
             const uint32_t j = segid_incl[q] - 1;
-            const uint64_t bt = pb_seg_of_key(keys[q], rb, sb, s_log);
+            const uint64_t bt = pb_seg_of_key(keys[q], bb, sb, s_log);
             vstart[j] = q;
             segkey[j] = ((bt & 0xFFFFFFFFull) << 32) | (bt >> 32);
             segval[j] = j;
@@ -449,18 +448,17 @@ __global__ void pb_seg_layout_kernel(const uint64_t *__restrict__ segkey_sorted,
 __global__ void pb_fill_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ segid_incl,
                                const uint32_t *__restrict__ vstart, const uint32_t *__restrict__ vstart4,
                                const uint32_t *__restrict__ rank_of, const uint32_t *__restrict__ pstart, uint32_t m,
-                               int rb, int sb, int s_log, uint16_t *__restrict__ p1_src, uint16_t *__restrict__ p2_dst)
+                               int bb, int sb, int s_log, uint16_t *__restrict__ p1_src, uint16_t *__restrict__ p2_dst)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t rmask = (1u << rb) - 1u;
     for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < m; q += stride) {
         const uint32_t j = segid_incl[q] - 1;
         const uint32_t vs = vstart[j];
         const uint64_t k = keys[q];
         const uint32_t p = pstart[rank_of[j]] + (q - vs);
-        const uint32_t src = (uint32_t)((k >> rb) & ((1ull << sb) - 1ull));
+        const uint32_t src = (uint32_t)(k & ((1ull << sb) - 1ull));
         p1_src[p] = (uint16_t)((src & ((1u << s_log) - 1u)) | (q == vs ? PB_FLAG : 0));
-        p2_dst[vstart4[j] + (q - vs)] = (uint16_t)((uint32_t)k & rmask);
+        p2_dst[vstart4[j] + (q - vs)] = (uint16_t)(k >> (sb + bb + 1));
     }
 }
 
@@ -1387,7 +1385,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
 
     const uint32_t Bv = pl->B + pl->G; // virtual bins of the streams: the ordinary bins, then the hub groups
     const int bin_bits = bits_for(Bv) < 1 ? 1 : bits_for(Bv);
-    GM_CHECK(bin_bits + sb + rb <= 63, GM_ERR_RANGE, "pb_build: key does not fit 63 bits");
+    GM_CHECK(bin_bits + sb + rb + 1 <= 64, GM_ERR_RANGE, "pb_build: key does not fit 64 bits");
 
     // hot table size: what is left of the LDS beside the accumulators (2 workgroups per CU when the
     // accumulators are <= 64 KiB, else 1)
@@ -1470,13 +1468,13 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     DevBuf keys, kalt;
     GM_TRY(keys.alloc((size_t)m_all * 8));
     GM_TRY(kalt.alloc((size_t)m_all * 8));
-    const int hot_bit = bin_bits + sb + rb; // <= 63
-    hipLaunchKernelGGL(pb_keys_kernel, dim3(pb_grid(n)), dim3(256), 0, 0, csr->offsets, csr->targets, n, rb, sb, hot_bit,
+    const int hot_bit = bin_bits + sb; // the flag bit of a hot edge: the highest sorted bit
+    hipLaunchKernelGGL(pb_keys_kernel, dim3(pb_grid(n)), dim3(256), 0, 0, csr->offsets, csr->targets, n, rb, sb, bin_bits,
                        H ? hot_rank.as<uint16_t>() : (const uint16_t *)nullptr, pl->cidx.as<uint16_t>(),
                        pos_h.as<uint32_t>(), pl->hub_first.as<uint32_t>(), pl->B, pl->G, keys.as<uint64_t>());
     GM_HIP(hipGetLastError());
-    // (sorting only bits [rb, ..) would do — the slot order inside a (bin, source) is irrelevant — but rocPRIM's
-    // radix sort was measured 14x slower with a non-zero begin bit at this size)
+    // the slot sits above the sorted bits (rocPRIM's radix sort was measured 14x slower with a non-zero BEGIN bit at
+    // this size, so the unsorted field is at the top, not at the bottom)
     GM_TRY(sort_keys_u64(keys, kalt, m_all, 0, H ? hot_bit + 1 : hot_bit));
     kalt.release();
     hot_rank.release();
@@ -1487,7 +1485,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
         DevBuf split;
         GM_TRY(split.alloc(3 * 4));
         hipLaunchKernelGGL(pb_bounds_kernel, dim3(pb_grid(m_all)), dim3(256), 0, 0, keys.as<uint64_t>(), m_all, hot_bit, 2u,
-                           split.as<uint32_t>(), 0xFFFFFFFFu);
+                           split.as<uint32_t>(), 1u);
         GM_HIP(hipGetLastError());
         GM_HIP(hipMemcpy(&m, split.as<uint32_t>() + 1, 4, hipMemcpyDeviceToHost));
         const uint32_t mh = m_all - m;
@@ -1497,7 +1495,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
             GM_TRY(hstart.alloc(((size_t)Bv + 1) * 4));
             GM_TRY(hpad.alloc(((size_t)Bv + 1) * 4));
             const uint32_t bin_mask = (uint32_t)((1ull << bin_bits) - 1ull);
-            hipLaunchKernelGGL(pb_bounds_kernel, dim3(pb_grid(mh)), dim3(256), 0, 0, hkeys, mh, sb + rb, Bv,
+            hipLaunchKernelGGL(pb_bounds_kernel, dim3(pb_grid(mh)), dim3(256), 0, 0, hkeys, mh, sb, Bv,
                                hstart.as<uint32_t>(), bin_mask);
             hipLaunchKernelGGL(pb_pad4_sizes_kernel, dim3(pb_grid((uint64_t)Bv + 1)), dim3(256), 0, 0,
                                hstart.as<uint32_t>(), Bv, hpad.as<uint32_t>());
@@ -1509,7 +1507,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
             GM_TRY(pl->hot_ent.alloc((size_t)Mh * 4));
             GM_HIP(hipMemset(pl->hot_ent.p, 0xFF, (size_t)Mh * 4));
             hipLaunchKernelGGL(pb_hot_fill_kernel, dim3(pb_grid(mh)), dim3(256), 0, 0, hkeys, mh, hstart.as<uint32_t>(),
-                               pl->hbin_v.as<uint32_t>(), sb + rb, bin_mask, rb, pl->hot_ent.as<uint32_t>());
+                               pl->hbin_v.as<uint32_t>(), sb, bin_bits, pl->hot_ent.as<uint32_t>());
             GM_HIP(hipGetLastError());
             GM_HIP(hipDeviceSynchronize());
         }
@@ -1529,7 +1527,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     DevBuf flag, segid;
     GM_TRY(flag.alloc((size_t)m * 4));
     GM_TRY(segid.alloc((size_t)m * 4));
-    hipLaunchKernelGGL(pb_flags_kernel, dim3(gm_), dim3(256), 0, 0, keys.as<uint64_t>(), m, rb, sb, pl->s_log,
+    hipLaunchKernelGGL(pb_flags_kernel, dim3(gm_), dim3(256), 0, 0, keys.as<uint64_t>(), m, bin_bits, sb, pl->s_log,
                        flag.as<uint32_t>());
     GM_HIP(hipGetLastError());
     GM_TRY(scan_inclusive_u32(flag.as<uint32_t>(), segid.as<uint32_t>(), m));
@@ -1547,7 +1545,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     GM_TRY(segvalt.alloc((size_t)NS * 4));
     GM_TRY(segbin.alloc((size_t)NS * 8));
     hipLaunchKernelGGL(pb_segments_kernel, dim3(gm_), dim3(256), 0, 0, keys.as<uint64_t>(), flag.as<uint32_t>(),
-                       segid.as<uint32_t>(), m, rb, sb, pl->s_log, vstart.as<uint32_t>(), segkey.as<uint64_t>(),
+                       segid.as<uint32_t>(), m, bin_bits, sb, pl->s_log, vstart.as<uint32_t>(), segkey.as<uint64_t>(),
                        segval.as<uint32_t>(), segbin.as<uint64_t>());
     GM_HIP(hipGetLastError());
     GM_HIP(hipDeviceSynchronize());
@@ -1609,8 +1607,8 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     GM_HIP(hipMemset(pl->p1_src.p, 0x7F, (size_t)Mp * 2)); // padding: an unflagged id (any source of the tile will do)
     GM_HIP(hipMemset(pl->p2_dst.p, 0xFF, (size_t)Mv * 2));
     hipLaunchKernelGGL(pb_fill_kernel, dim3(gm_), dim3(256), 0, 0, keys.as<uint64_t>(), segid.as<uint32_t>(),
-                       vstart.as<uint32_t>(), vstart4.as<uint32_t>(), rank_of.as<uint32_t>(), pstart.as<uint32_t>(), m, rb,
-                       sb, pl->s_log, pl->p1_src.as<uint16_t>(), pl->p2_dst.as<uint16_t>());
+                       vstart.as<uint32_t>(), vstart4.as<uint32_t>(), rank_of.as<uint32_t>(), pstart.as<uint32_t>(), m,
+                       bin_bits, sb, pl->s_log, pl->p1_src.as<uint16_t>(), pl->p2_dst.as<uint16_t>());
     hipLaunchKernelGGL(pb_chunk_seg_kernel, dim3(pb_grid(Mp / PB_WBLK + 1)), dim3(256), 0, 0, pstart.as<uint32_t>(), NS,
                        Mp / PB_WBLK + 1, pl->chunk_seg.as<uint32_t>());
     GM_HIP(hipGetLastError());
