@@ -2,7 +2,7 @@
 
 The reference's PyO3 module exposes `DiGraph` / `Graph` (32-bit node ids), `Layout`, `FileFormat` and
 result objects; this module mirrors that surface so the reference's own pytest suite
-(crates/mate/tests/*.py) runs nearly verbatim as an acceptance suite (tests/mate/).  Graph data lives
+(crates/mate/tests/*.py) runs nearly verbatim as an acceptance suite (tests/test_gpu_graph_mate.py).  Graph data lives
 in HBM (graph_amd.prelude.DeviceCsr); neighbour accessors return numpy views of a lazily downloaded
 host mirror, like the reference's zero-copy views (crates/mate/src/graphs/digraph.rs:126-160).
 """
