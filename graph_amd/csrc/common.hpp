@@ -165,6 +165,15 @@ struct PhaseTimer { // wall clock around stream-ordered work; only active under 
 
 namespace gm {
 struct PbPlan; // propagation-blocking layout of a CSR (pagerank_pb.hip); immutable once built
+
+// Working buffers of one gm_sssp_delta_stepping call (sssp.hip).  A call takes the set parked in the CSR handle (or
+// allocates one) and parks it again when it returns: hipMalloc / hipFree of ~200 MB cost more than a millisecond
+// each and a graph is usually queried from many start nodes.
+struct SsspScratch {
+    DevBuf dist, flags, wmin, ctrl, chunks;
+    PinnedBuf hctrl;
+    size_t items = 0; // capacity of `chunks` in work items; 0: not (completely) allocated
+};
 } // namespace gm
 
 // The opaque handle of include/graph_mi355x.h.
@@ -182,5 +191,6 @@ struct gm_csr {
     mutable std::mutex cache_mu;
     mutable std::map<uint64_t, std::shared_ptr<const gm::PbPlan>> pb_plans;
     mutable std::atomic<uint64_t> page_rank_calls{0}; // gm_page_rank calls seen by this handle (engine choice); calls may run concurrently
+    mutable std::unique_ptr<gm::SsspScratch> sssp_scratch; // parked between calls (under cache_mu)
     mutable std::atomic<int> long_rows{-1};           // 1: some row has >= GM_PB_HUB_DEG entries (-1: not looked at yet)
 };

@@ -37,8 +37,7 @@ constexpr uint32_t SSSP_INF_BITS = 0x7F7FFFFFu; // f32::MAX
 constexpr uint32_t NO_BUCKET = 0xFFFFFFFFu;
 
 struct RelaxOut {
-    uint32_t again;
-    uint32_t far;
+    uint32_t again; // some distance at or below the threshold improved: the phase has not run dry
 };
 
 // thr: bit pattern of the current distance threshold (non-negative f32 order == unsigned order).
@@ -55,8 +54,6 @@ __device__ __forceinline__ void relax_checked(uint32_t *dist, uint32_t *flags, u
             atomicMin(&wmin[(t >> 5) + zero], nb);
             if (nb <= thr)
                 ro.again = 1;
-            else
-                ro.far = nb < ro.far ? nb : ro.far;
         }
     }
 }
@@ -85,20 +82,22 @@ __device__ __forceinline__ void relax_range(const uint32_t *__restrict__ tgt, co
     }
 }
 
-// ctrl words shared by the round and advance kernels
+// ctrl words shared by the kernels of a round
 enum : uint32_t { C_AGAIN = 0, C_FAR = 1, C_BAD = 2, C_THR = 3, C_DONE = 4, C_ROUND = 5, C_ADVANCES = 6,
-                  C_WORK = 7 /* relaxed edges / 64, statistics */, C_CHUNKS = 8 /* deferred edge chunks of this round */,
-                  C_WIDTH = 9 /* f32 bits: current threshold step */, C_MARK = 10 /* C_WORK at the last advance */ };
+                  C_WORK = 7 /* relaxed edges / 64, statistics */, C_WIDTH = 9 /* f32 bits: current threshold step */,
+                  C_MARK = 10 /* C_WORK at the last advance */,
+                  C_ITEMS = 12 /* work items queued by this round; with C_RWORK one 64-bit counter */,
+                  C_RWORK = 13 /* out-edges of the nodes this round took up */ };
 
 // One round.  wmin[i] is a lower bound of the distances of the flagged nodes of flag word i (32 nodes):
 // whoever flags a node lowers it, the scanner resets it and puts back what it leaves flagged.  A
 // wavefront takes 64 words (2048 consecutive nodes) at a time with one coalesced wmin load; only words
-// that can hold a node at or below the threshold are opened (two at a time, one per half wavefront),
+// that can hold a node at or below the threshold are opened (all at once, one per lane),
 // their near nodes cleared and collected in an LDS list, then relaxed one lane per node (lists longer
 // than 32 edges by the whole wavefront).  Nodes above the threshold cost nothing per round.
 constexpr uint32_t SSSP_GROUP = 64u * 32u; // nodes per wavefront step
-constexpr uint32_t SSSP_BIG = 2048;        // adjacency lists longer than this are cut into chunks for the whole grid
-constexpr uint32_t SSSP_CHUNK = 1024;      // edges per deferred chunk
+constexpr uint32_t SSSP_BIG = 2048;        // the work items of a list longer than this are written by the whole wavefront
+constexpr uint32_t SSSP_CHUNK = 256;       // edges per work item (GM_SSSP_CHUNK overrides)
 
 __device__ __forceinline__ void sssp_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -106,125 +105,130 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_round_kernel(const uint32_t *
                                                                 const uint32_t *__restrict__ tgt,
                                                                 const float *__restrict__ w, uint32_t *dist,
                                                                 uint32_t *flags, uint32_t *wmin, uint32_t nwords,
-                                                                uint2 *__restrict__ chunks, uint32_t *ctrl)
+                                                                uint2 *__restrict__ chunks, uint32_t *ctrl,
+                                                                uint32_t chunk_edges, uint32_t coop)
 {
-    __shared__ uint32_t list[SSSP_BLOCK / kWave][SSSP_GROUP];
+    __shared__ uint16_t list[SSSP_BLOCK / kWave][SSSP_GROUP]; // node - first node of the group
     if (ld_agent(&ctrl[C_DONE]))
         return; // a round enqueued behind the last one of its batch
     const uint32_t thr = ld_agent(&ctrl[C_THR]);
     const uint32_t lane = threadIdx.x & (kWave - 1);
-    const uint32_t half = lane & 32u, sub = lane & 31u;
     const uint32_t wv = threadIdx.x >> 6;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t ngroups = (nwords + kWave - 1) / kWave;
-    const uint64_t lt_mask = lane ? (~0ull >> (64u - lane)) : 0ull;
-    RelaxOut ro{0u, NO_BUCKET};
-    uint32_t work = 0; // out-edges of the nodes this lane relaxed (statistics)
+    RelaxOut ro{0u};
     for (uint32_t grp = wave; grp < ngroups; grp += nwaves) {
         const uint32_t my_word = grp * kWave + lane;
         const uint32_t lo = my_word < nwords ? ld_agent(&wmin[my_word]) : NO_BUCKET;
-        if (lo > thr && lo != NO_BUCKET)
-            ro.far = lo < ro.far ? lo : ro.far;
-        uint64_t cand = __ballot(lo <= thr);
-        uint32_t total = 0;
-        while (cand) {
-            // two words per step: the lower half of the wavefront opens the first, the upper half the second
-            const uint32_t i0 = (uint32_t)__ffsll((unsigned long long)cand) - 1u;
-            cand &= cand - 1;
-            uint32_t i1 = 64u;
-            if (cand) {
-                i1 = (uint32_t)__ffsll((unsigned long long)cand) - 1u;
-                cand &= cand - 1;
-            }
-            const uint32_t mine = half ? i1 : i0;
-            const bool open = mine < 64u;
-            const uint32_t widx = grp * kWave + (open ? mine : 0u);
-            if (open && sub == 0)
-                atomicExch(&wmin[widx], NO_BUCKET); // reset first, then look: a concurrent flagger re-arms the word
-            sssp_drain();
-            const uint32_t fw = open ? ld_agent(&flags[widx]) : 0u;
-            const bool bit = (fw >> sub) & 1u;
-            const uint32_t u = widx * 32u + sub;
-            const uint32_t db = bit ? ld_agent(&dist[u]) : NO_BUCKET;
-            const bool is_near = bit && db <= thr;
-            uint32_t keep_far = bit && !is_near ? db : NO_BUCKET; // what stays flagged goes back into the summary
+        // Every lane opens ITS word (32 nodes) if the word can hold a node at or below the threshold: all candidate
+        // words of the group at once — five memory round trips per group whatever the density.  (Two words per
+        // step, one per half wavefront, was 32 steps of three round trips each for a dense group: with one group
+        // per resident wavefront that serial chain, not the probe rate, set the time of the dense rounds.)
+        const bool mine = lo <= thr;
+        if (!__ballot(mine))
+            continue;
+        if (mine)
+            atomicExch(&wmin[my_word], NO_BUCKET); // reset first, then look: a concurrent flagger re-arms the word
+        sssp_drain();
+        const uint32_t fw = mine ? ld_agent(&flags[my_word]) : 0u;
+        uint32_t near = 0u, keep_far = NO_BUCKET;
 #pragma unroll
-            for (int o = 16; o > 0; o >>= 1) {
-                const uint32_t other = __shfl_xor(keep_far, o, kWave);
-                keep_far = other < keep_far ? other : keep_far;
-            }
-            if (keep_far != NO_BUCKET) {
-                if (sub == 0)
-                    atomicMin(&wmin[widx], keep_far);
-                ro.far = keep_far < ro.far ? keep_far : ro.far;
-            }
-            const uint64_t near_b = __ballot(is_near);
-            const uint32_t clear = half ? (uint32_t)(near_b >> 32) : (uint32_t)near_b;
-            if (clear && sub == 0)
-                atomicAnd(&flags[widx], ~clear);
-            sssp_drain(); // cleared before anyone reads the distances the relaxation uses
-            if (is_near)
-                list[wv][total + (uint32_t)__popcll(near_b & lt_mask)] = u;
-            total += (uint32_t)__popcll(near_b);
+        for (uint32_t c = 0; c < 32u; c += 8u) { // the distances of the word's flagged nodes, eight loads in flight
+            uint32_t db[8];
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; ++j)
+                db[j] = ((fw >> (c + j)) & 1u) ? ld_agent(&dist[my_word * 32u + c + j]) : NO_BUCKET;
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; ++j)
+                if ((fw >> (c + j)) & 1u) {
+                    if (db[j] <= thr)
+                        near |= 1u << (c + j);
+                    else
+                        keep_far = db[j] < keep_far ? db[j] : keep_far; // what stays flagged goes back into the summary
+                }
         }
+        if (keep_far != NO_BUCKET)
+            atomicMin(&wmin[my_word], keep_far);
+        if (near)
+            atomicAnd(&flags[my_word], ~near);
+        sssp_drain(); // cleared before anyone reads the distances the relaxation uses
+        uint32_t cnt = (uint32_t)__popc(near), pre = cnt; // inclusive prefix of the lanes' counts
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            const uint32_t up = __shfl_up(pre, o, kWave);
+            if ((int)lane >= o)
+                pre += up;
+        }
+        const uint32_t total = __shfl(pre, kWave - 1, kWave);
+        for (uint32_t at = pre - cnt, bits = near; bits; bits &= bits - 1u)
+            list[wv][at++] = (uint16_t)(lane * 32u + (uint32_t)__ffs((int)bits) - 1u);
         if (total == 0)
             continue;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // Lists of up to `coop` edges are relaxed by their own lane.  Everything longer leaves the wavefront: one
+        // work item per chunk_edges edges in a queue that sssp_chunk_kernel spreads over the whole grid.  (Relaxing
+        // the 33..2048-edge lists here, one after the other by the whole wavefront, made the few node groups that
+        // hold the high-degree nodes — the low ids of an RMAT graph — the critical path of every round.)
+        // First the group's item count, so that ONE atomic reserves its stretch of the queue: thousands of
+        // wavefronts adding to the same counter once per 64 nodes were ~12 ns apiece, serialised — 0.1-0.4 ms of a
+        // dense round.  The same 64-bit add carries the round's work statistic in its upper half.
+        uint32_t my_items = 0, my_work = 0;
+        for (uint32_t base = lane; base < total; base += kWave) {
+            const uint32_t u = grp * SSSP_GROUP + list[wv][base];
+            const uint32_t len = off[u + 1] - off[u];
+            my_work += len;
+            my_items += len > coop ? (len + chunk_edges - 1u) / chunk_edges : 0u;
+        }
+        const uint32_t grp_items = (uint32_t)wave_sum((uint64_t)my_items);
+        const uint32_t grp_work = (uint32_t)wave_sum((uint64_t)my_work);
+        uint32_t cursor = 0;
+        if (lane == 0)
+            cursor = (uint32_t)atomicAdd(reinterpret_cast<unsigned long long *>(&ctrl[C_ITEMS]),
+                                         (unsigned long long)grp_items | ((unsigned long long)grp_work << 32));
+        cursor = __shfl(cursor, 0, kWave);
         for (uint32_t base = 0; base < total; base += kWave) {
-            uint32_t s = 0, e = 0;
+            uint32_t u = 0, s = 0, e = 0;
             float du = 0.0f;
             if (base + lane < total) {
-                const uint32_t u = list[wv][base + lane];
+                u = grp * SSSP_GROUP + list[wv][base + lane];
                 du = __uint_as_float(ld_agent(&dist[u])); // <= thr: distances only decrease
                 s = off[u];
                 e = off[u + 1];
             }
-            // short lists by their own lane, lists longer than 32 edges by the whole wavefront (measured:
-            // an edge-balanced expansion with a shuffle search per edge was 25 % slower — the round is bound
-            // by the random dist[] accesses, not by the target stream)
             const uint32_t len = e - s;
-            work += len;
-            if (len <= SSSP_COOP)
+            if (len <= coop)
                 relax_range(tgt, w, dist, flags, wmin, du, s, e, 1u, thr, ro);
-            uint64_t big = __ballot(len > SSSP_COOP && len <= SSSP_BIG);
-            while (big) {
-                const int src = __ffsll((unsigned long long)big) - 1;
-                big &= big - 1;
-                const uint32_t bs = __shfl(s, src, kWave), be = __shfl(e, src, kWave);
-                const float bd = __shfl(du, src, kWave);
-                relax_range(tgt, w, dist, flags, wmin, bd, bs + lane, be, kWave, thr, ro);
+            const uint32_t nch = len > coop ? (len + chunk_edges - 1u) / chunk_edges : 0u;
+            if (!__ballot(nch != 0u))
+                continue;
+            uint32_t incl = nch;
+#pragma unroll
+            for (int o = 1; o < kWave; o <<= 1) {
+                const uint32_t up = __shfl_up(incl, o, kWave);
+                if ((int)lane >= o)
+                    incl += up;
             }
-            // hubs: one wavefront would be the round's critical path (a 300k-edge list = milliseconds);
-            // their edge ranges go to a chunk list that sssp_chunk_kernel spreads over the whole grid
+            const uint32_t first = cursor + incl - nch;
+            cursor += __shfl(incl, kWave - 1, kWave);
+            if (len <= SSSP_BIG)
+                for (uint32_t c = 0; c < nch; ++c)
+                    chunks[first + c] = make_uint2(u, s + c * chunk_edges);
+            // hubs: the item list of one node written by the whole wavefront
             uint64_t huge = __ballot(len > SSSP_BIG);
             while (huge) {
                 const int src = __ffsll((unsigned long long)huge) - 1;
                 huge &= huge - 1;
-                const uint32_t hu = __shfl(base + lane < total ? list[wv][base + lane] : 0u, src, kWave);
-                const uint32_t hs = __shfl(s, src, kWave), he = __shfl(e, src, kWave);
-                const uint32_t nch = (he - hs + SSSP_CHUNK - 1u) / SSSP_CHUNK;
-                uint32_t first = 0;
-                if (lane == 0)
-                    first = atomicAdd(&ctrl[C_CHUNKS], nch);
-                first = __shfl(first, 0, kWave);
-                for (uint32_t c = lane; c < nch; c += kWave)
-                    chunks[first + c] = make_uint2(hu, hs + c * SSSP_CHUNK);
+                const uint32_t hu = __shfl(u, src, kWave), hs = __shfl(s, src, kWave);
+                const uint32_t hn = __shfl(nch, src, kWave), hfirst = __shfl(first, src, kWave);
+                for (uint32_t c = lane; c < hn; c += kWave)
+                    chunks[hfirst + c] = make_uint2(hu, hs + c * chunk_edges);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // the list is rewritten by the next step
     }
-    const uint32_t far = wave_min(ro.far);
-    const uint64_t any = __ballot(ro.again != 0);
-    const uint32_t wave_work = (uint32_t)wave_sum((uint64_t)work);
-    if (lane == 0) {
-        if (wave_work)
-            atomicAdd(&ctrl[C_WORK], (wave_work + 63u) >> 6);
-        if (any)
-            atomicOr(&ctrl[C_AGAIN], 1u);
-        if (far != NO_BUCKET)
-            atomicMin(&ctrl[C_FAR], far);
-    }
+    if (__ballot(ro.again != 0) && lane == 0 && !ld_agent(&ctrl[C_AGAIN]))
+        atomicOr(&ctrl[C_AGAIN], 1u);
 }
 
 // The deferred hub edges of the round that just ran: chunk (u, first edge) -> up to SSSP_CHUNK edges of u,
@@ -233,32 +237,55 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_chunk_kernel(const uint32_t *
                                                                 const uint32_t *__restrict__ tgt,
                                                                 const float *__restrict__ w, uint32_t *dist,
                                                                 uint32_t *flags, uint32_t *wmin,
-                                                                const uint2 *__restrict__ chunks, uint32_t *ctrl)
+                                                                const uint2 *__restrict__ chunks, uint32_t *ctrl,
+                                                                uint32_t chunk_edges)
 {
     if (ld_agent(&ctrl[C_DONE]))
         return;
-    const uint32_t nchunks = ld_agent(&ctrl[C_CHUNKS]);
+    const uint32_t nchunks = ld_agent(&ctrl[C_ITEMS]);
     if (nchunks == 0)
         return;
     const uint32_t thr = ld_agent(&ctrl[C_THR]);
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-    RelaxOut ro{0u, NO_BUCKET};
+    RelaxOut ro{0u};
     for (uint32_t c = wave; c < nchunks; c += nwaves) {
         const uint2 ch = chunks[c];
         const float du = __uint_as_float(ld_agent(&dist[ch.x]));
         const uint32_t end_u = off[ch.x + 1];
-        const uint32_t end = ch.y + SSSP_CHUNK < end_u ? ch.y + SSSP_CHUNK : end_u;
+        const uint32_t end = ch.y + chunk_edges < end_u ? ch.y + chunk_edges : end_u;
         relax_range(tgt, w, dist, flags, wmin, du, ch.y + lane, end, kWave, thr, ro);
     }
-    const uint32_t far = wave_min(ro.far);
-    const uint64_t any = __ballot(ro.again != 0);
-    if (lane == 0) {
-        if (any)
-            atomicOr(&ctrl[C_AGAIN], 1u);
-        if (far != NO_BUCKET)
-            atomicMin(&ctrl[C_FAR], far);
+    if (__ballot(ro.again != 0) && lane == 0 && !ld_agent(&ctrl[C_AGAIN]))
+        atomicOr(&ctrl[C_AGAIN], 1u);
+}
+
+// When the round left nothing at or below the threshold: the minimum pending distance = the minimum of the word
+// bounds (every flagged node has its word's bound at or below its distance once the round's atomics have landed;
+// a bound may be stale-low, the next round then opens that word and tightens it).  Thousands of wavefronts each
+// folding their own minimum into one ctrl word was ~0.1 ms of every round.
+__global__ __launch_bounds__(SSSP_BLOCK) void sssp_far_kernel(const uint32_t *__restrict__ wmin, uint32_t nwords,
+                                                              uint32_t *ctrl)
+{
+    __shared__ uint32_t part[SSSP_BLOCK / kWave];
+    if (ld_agent(&ctrl[C_DONE]) || ld_agent(&ctrl[C_AGAIN]))
+        return;
+    uint32_t lo = NO_BUCKET;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += stride) {
+        const uint32_t v = ld_agent(&wmin[i]);
+        lo = v < lo ? v : lo;
+    }
+    lo = wave_min(lo);
+    if ((threadIdx.x & (kWave - 1)) == 0)
+        part[threadIdx.x >> 6] = lo;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < SSSP_BLOCK / kWave; ++k)
+            lo = part[k] < lo ? part[k] : lo;
+        if (lo != NO_BUCKET)
+            atomicMin(&ctrl[C_FAR], lo);
     }
 }
 
@@ -271,6 +298,7 @@ __global__ void sssp_advance_kernel(uint32_t *ctrl, uint32_t adapt_lo, uint32_t 
 {
     if (ctrl[C_DONE])
         return;
+    ctrl[C_WORK] += (ctrl[C_RWORK] + 63u) >> 6;
     if (!ctrl[C_AGAIN]) {
         if (ctrl[C_FAR] == NO_BUCKET) {
             ctrl[C_DONE] = 1u;
@@ -286,14 +314,16 @@ __global__ void sssp_advance_kernel(uint32_t *ctrl, uint32_t adapt_lo, uint32_t 
                 ctrl[C_MARK] = ctrl[C_WORK];
             }
             const float next = __fadd_rn(__uint_as_float(ctrl[C_FAR]), width);
-            const uint32_t nb = __float_as_uint(next);
-            ctrl[C_THR] = nb > ctrl[C_FAR] && next < 3.0e38f ? nb : ctrl[C_FAR]; // always covers the pending minimum
+            uint32_t nb = __float_as_uint(next);
+            nb = nb > ctrl[C_FAR] && next < 3.0e38f ? nb : ctrl[C_FAR]; // always covers the pending minimum
+            ctrl[C_THR] = nb > ctrl[C_THR] ? nb : ctrl[C_THR];         // (a stale-low word bound never moves it back)
             ctrl[C_ADVANCES] += 1u;
         }
     }
     ctrl[C_AGAIN] = 0u;
     ctrl[C_FAR] = NO_BUCKET;
-    ctrl[C_CHUNKS] = 0u;
+    ctrl[C_ITEMS] = 0u;
+    ctrl[C_RWORK] = 0u;
     ctrl[C_ROUND] += 1u;
 }
 
@@ -372,18 +402,51 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
              "gm_sssp_delta_stepping: delta must be a positive finite f32 (reference: bin index overflow panic)");
     GM_CHECK(distances_out, GM_ERR_INVALID, "gm_sssp_delta_stepping: distances_out is null");
     gm::DeviceGuard guard(g->device);
+    const bool times = getenv("GM_SSSP_TIMES") != nullptr; // where the wall time of the call goes, on stderr
+    const auto t_call = std::chrono::steady_clock::now();
+    auto since = [](std::chrono::steady_clock::time_point t0) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    };
     const uint32_t n = (uint32_t)g->n;
-    gm::DevBuf dist, flags, ctrl;
-    gm::PinnedBuf hctrl;
-    GM_TRY(dist.alloc((size_t)n * 4));
     const uint32_t nwords = (n + 31u) / 32u; // one flag bit per node, one distance summary per flag word
-    GM_TRY(flags.alloc(((size_t)nwords + kWave) * 4));
-    gm::DevBuf wmin;
-    GM_TRY(wmin.alloc(((size_t)nwords + kWave) * 4));
-    GM_TRY(ctrl.alloc(64));
-    GM_TRY(hctrl.alloc(64));
-    gm::DevBuf chunks; // (node, first edge) of deferred hub chunks: at most one per SSSP_CHUNK edges plus one per node
-    GM_TRY(chunks.alloc(((size_t)g->m / SSSP_CHUNK + (size_t)g->m / SSSP_BIG + 64) * sizeof(uint2)));
+    uint32_t chunk_edges = SSSP_CHUNK;
+    if (const char *v = getenv("GM_SSSP_CHUNK"))
+        if (atoi(v) >= 64)
+            chunk_edges = (uint32_t)atoi(v);
+    uint32_t coop = SSSP_COOP;
+    if (const char *v = getenv("GM_SSSP_COOP"))
+        if (atoi(v) >= 1 && atoi(v) <= 64)
+            coop = (uint32_t)atoi(v);
+    std::unique_ptr<gm::SsspScratch> sc;
+    {
+        std::lock_guard<std::mutex> lock(g->cache_mu);
+        sc = std::move(g->sssp_scratch);
+    }
+    struct Park { // hand the buffers back to the handle on every way out
+        const gm_csr *g;
+        std::unique_ptr<gm::SsspScratch> &sc;
+        ~Park()
+        {
+            std::lock_guard<std::mutex> lock(g->cache_mu);
+            if (sc && sc->items && !g->sssp_scratch)
+                g->sssp_scratch = std::move(sc);
+        }
+    } park{g, sc};
+    // (node, first edge) work items of one round: a node is taken up at most once per round, so at most one item
+    // per chunk_edges edges plus one per list that is not relaxed by its own lane
+    const size_t items = (size_t)g->m / chunk_edges + (size_t)g->m / (coop + 1u) + 64;
+    if (!sc || sc->items < items) {
+        sc.reset(new gm::SsspScratch);
+        GM_TRY(sc->dist.alloc((size_t)n * 4));
+        GM_TRY(sc->flags.alloc(((size_t)nwords + kWave) * 4));
+        GM_TRY(sc->wmin.alloc(((size_t)nwords + kWave) * 4));
+        GM_TRY(sc->ctrl.alloc(64));
+        GM_TRY(sc->hctrl.alloc(64));
+        GM_TRY(sc->chunks.alloc(items * sizeof(uint2)));
+        sc->items = items;
+    }
+    gm::DevBuf &dist = sc->dist, &flags = sc->flags, &wmin = sc->wmin, &ctrl = sc->ctrl, &chunks = sc->chunks;
+    gm::PinnedBuf &hctrl = sc->hctrl;
     hipStream_t st = 0;
     unsigned grid = gm::div_up(n, SSSP_BLOCK);
     if (grid > 256 * 8)
@@ -429,6 +492,9 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
     GM_CHECK(hctrl.as<uint32_t>()[C_BAD] == 0, GM_ERR_UNSUPPORTED,
              "gm_sssp_delta_stepping: negative or NaN edge weight (the reference assumes weights >= 0)");
 
+    const double ms_setup = since(t_call);
+    unsigned far_grid = gm::div_up(nwords, SSSP_BLOCK * 8);
+    far_grid = far_grid > 256 ? 256 : far_grid;
     const bool stats = getenv("GM_SSSP_STATS") != nullptr;
     const int batch = stats ? 1 : 8; // rounds enqueued per host synchronisation
     auto t_prev = std::chrono::steady_clock::now();
@@ -436,9 +502,11 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
         for (int k = 0; k < batch; ++k) {
             hipLaunchKernelGGL(sssp_round_kernel, dim3(grid), dim3(SSSP_BLOCK), 0, st, g->offsets, g->targets, g->weights,
                                dist.as<uint32_t>(), flags.as<uint32_t>(), wmin.as<uint32_t>(), nwords, chunks.as<uint2>(),
-                               ctrl.as<uint32_t>());
+                               ctrl.as<uint32_t>(), chunk_edges, coop);
             hipLaunchKernelGGL(sssp_chunk_kernel, dim3(grid), dim3(SSSP_BLOCK), 0, st, g->offsets, g->targets, g->weights,
                                dist.as<uint32_t>(), flags.as<uint32_t>(), wmin.as<uint32_t>(), chunks.as<uint2>(),
+                               ctrl.as<uint32_t>(), chunk_edges);
+            hipLaunchKernelGGL(sssp_far_kernel, dim3(far_grid), dim3(SSSP_BLOCK), 0, st, wmin.as<uint32_t>(), nwords,
                                ctrl.as<uint32_t>());
             hipLaunchKernelGGL(sssp_advance_kernel, dim3(1), dim3(1), 0, st, ctrl.as<uint32_t>(), adapt_lo, adapt_hi,
                                delta / 1024.0f, delta * 16.0f);
@@ -461,7 +529,12 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
                 hctrl.as<uint32_t>()[C_ROUND], hctrl.as<uint32_t>()[C_ADVANCES], width,
                 __builtin_bit_cast(float, hctrl.as<uint32_t>()[C_WIDTH]),
                 hctrl.as<uint32_t>()[C_WORK] * 64.0 / 1e6, g->m ? hctrl.as<uint32_t>()[C_WORK] * 64.0 / (double)g->m : 0.0);
-    GM_HIP(hipMemcpy(distances_out, dist.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    const double ms_rounds = since(t_call) - ms_setup;
+    // distances_out: host memory (pinned memory takes the copy at link speed) or device memory
+    GM_HIP(hipMemcpy(distances_out, dist.p, (size_t)n * 4, hipMemcpyDefault));
+    if (times)
+        fprintf(stderr, "sssp: setup %.3f ms (buffers, weight check, init), rounds %.3f ms (%u rounds), result copy %.3f ms\n",
+                ms_setup, ms_rounds, hctrl.as<uint32_t>()[C_ROUND], since(t_call) - ms_setup - ms_rounds);
     return GM_OK;
 }
 
