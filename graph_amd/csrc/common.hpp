@@ -170,7 +170,7 @@ struct PbPlan; // propagation-blocking layout of a CSR (pagerank_pb.hip); immuta
 // allocates one) and parks it again when it returns: hipMalloc / hipFree of ~200 MB cost more than a millisecond
 // each and a graph is usually queried from many start nodes.
 struct SsspScratch {
-    DevBuf dist, flags, wmin, ctrl, chunks;
+    DevBuf dist, flags, wmin, hflags, ctrl, chunks, queues;
     PinnedBuf hctrl;
     size_t items = 0; // capacity of `chunks` in work items; 0: not (completely) allocated
 };

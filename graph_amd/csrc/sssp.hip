@@ -58,11 +58,16 @@ __device__ __forceinline__ void relax_checked(uint32_t *dist, uint32_t *flags, u
     }
 }
 
-// relaxes edges i = first, first + step, ... < end of one source at distance du, SSSP_MLP at a time
+// relaxes edges i = first, first + step, ... < end of one source at distance du, SSSP_MLP at a time.
+// `which` (uniform): R_LIGHT = only the edges whose candidate lands at or below the threshold (they can make a node
+// of the running phase move again), R_HEAVY = only the others (relaxed once per phase, when it has run dry, with the
+// source's final distance), R_ALL = every edge.  The targets and weights of the skipped edges are streamed, their
+// distances not probed.
+enum : int { R_ALL = 0, R_LIGHT = 1, R_HEAVY = 2 };
 constexpr int SSSP_MLP = 4;
 __device__ __forceinline__ void relax_range(const uint32_t *__restrict__ tgt, const float *__restrict__ w, uint32_t *dist,
                                             uint32_t *flags, uint32_t *wmin, float du, uint32_t first, uint32_t end,
-                                            uint32_t step, uint32_t thr, RelaxOut &ro)
+                                            uint32_t step, uint32_t thr, int which, RelaxOut &ro)
 {
     for (uint32_t i = first; i < end; i += step * SSSP_MLP) {
         uint32_t t[SSSP_MLP], nb[SSSP_MLP], pre[SSSP_MLP];
@@ -72,6 +77,8 @@ __device__ __forceinline__ void relax_range(const uint32_t *__restrict__ tgt, co
             const bool in = j < end;
             t[k] = in ? tgt[j] : 0u;
             nb[k] = in ? __float_as_uint(__fadd_rn(du, w[j])) : 0xFFFFFFFFu;
+            if (which == R_LIGHT ? nb[k] > thr : which == R_HEAVY ? nb[k] <= thr : false)
+                nb[k] = 0xFFFFFFFFu;
         }
 #pragma unroll
         for (int k = 0; k < SSSP_MLP; ++k)
@@ -84,75 +91,105 @@ __device__ __forceinline__ void relax_range(const uint32_t *__restrict__ tgt, co
 
 // ctrl words shared by the kernels of a round
 enum : uint32_t { C_AGAIN = 0, C_FAR = 1, C_BAD = 2, C_THR = 3, C_DONE = 4, C_ROUND = 5, C_ADVANCES = 6,
-                  C_WORK = 7 /* relaxed edges / 64, statistics */, C_WIDTH = 9 /* f32 bits: current threshold step */,
-                  C_MARK = 10 /* C_WORK at the last advance */,
-                  C_ITEMS = 12 /* work items queued by this round; with C_RWORK one 64-bit counter */,
-                  C_RWORK = 13 /* out-edges of the nodes this round took up */ };
+                  C_WORK = 7 /* relaxed edges / 64, statistics */, C_HEAVY = 8 /* 1: this round is a phase's heavy round */,
+                  C_WIDTH = 9 /* f32 bits: current threshold step */,
+                  C_MARK = 10 /* C_WORK at the last advance */ };
 
-// One round.  wmin[i] is a lower bound of the distances of the flagged nodes of flag word i (32 nodes):
-// whoever flags a node lowers it, the scanner resets it and puts back what it leaves flagged.  A
-// wavefront takes 64 words (2048 consecutive nodes) at a time with one coalesced wmin load; only words
-// that can hold a node at or below the threshold are opened (all at once, one per lane),
-// their near nodes cleared and collected in an LDS list, then relaxed one lane per node (lists longer
-// than 32 edges by the whole wavefront).  Nodes above the threshold cost nothing per round.
-constexpr uint32_t SSSP_GROUP = 64u * 32u; // nodes per wavefront step
-constexpr uint32_t SSSP_BIG = 2048;        // the work items of a list longer than this are written by the whole wavefront
-constexpr uint32_t SSSP_CHUNK = 256;       // edges per work item (GM_SSSP_CHUNK overrides)
+// The work-item queue of a round is SSSP_QUEUES sub-queues, node group g appending to sub-queue g % SSSP_QUEUES:
+// each has its own 64-bit counter (low half: items queued this round, high half: out-edges of the nodes taken up — the
+// work statistic rides on the reservation) in its own 128-byte line, and its own stretch of `chunks`, sized once per
+// call for the case that every node of its groups is taken up in the same round (sssp_caps_kernel).  One counter
+// for the whole grid cost ~15 ns per reservation, serialised: 0.1-0.25 ms of every dense round.
+constexpr uint32_t SSSP_QUEUES = 64;
+constexpr uint32_t SSSP_QSTRIDE = 16; // counters are 16 x 8 bytes apart
+struct QueueState {
+    unsigned long long ctr[SSSP_QUEUES * SSSP_QSTRIDE];
+    uint32_t start[SSSP_QUEUES]; // first slot of the sub-queue in `chunks`
+    uint32_t cap[SSSP_QUEUES];
+};
+
+// One round.  wmin[i] is a lower bound of the distances of the flagged nodes of flag word i (32 nodes): whoever
+// flags a node lowers it, the scanner resets it and puts back what it leaves flagged.  A wavefront takes 32 words
+// (1024 consecutive nodes, 16 per lane) at a time; only words that can hold a node at or below the threshold are
+// opened (all at once), their near nodes cleared and collected in an LDS list.  Lists of up to `coop` edges are
+// then relaxed by their own lane, all edges at once.  Everything longer leaves the wavefront: one work item per
+// chunk_edges edges in a queue that sssp_chunk_kernel spreads over the whole grid (relaxing the 33..2048-edge lists
+// here, one after the other by the whole wavefront, made the few node groups that hold the high-degree nodes — the
+// low ids of an RMAT graph — the critical path of every round), and those lists are relaxed in two parts: while
+// the phase is busy only the edges that land at or below the threshold, and once, in the phase's heavy round
+// (C_HEAVY, the nodes marked in hflags), the others — a hub whose distance improves in ten rounds of a phase has
+// its 300 000 targets probed once, not ten times.  Nodes above the threshold cost nothing per round.
+constexpr uint32_t SSSP_LANE_NODES = 16u;                // flag bits per lane
+constexpr uint32_t SSSP_GROUP = kWave * SSSP_LANE_NODES; // nodes per wavefront step
+constexpr uint32_t SSSP_BIG = 2048;  // the work items of a list longer than this are written by the whole wavefront
+constexpr uint32_t SSSP_CHUNK = 256; // edges per work item (GM_SSSP_CHUNK overrides)
 
 __device__ __forceinline__ void sssp_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 __global__ __launch_bounds__(SSSP_BLOCK) void sssp_round_kernel(const uint32_t *__restrict__ off,
                                                                 const uint32_t *__restrict__ tgt,
                                                                 const float *__restrict__ w, uint32_t *dist,
-                                                                uint32_t *flags, uint32_t *wmin, uint32_t nwords,
-                                                                uint2 *__restrict__ chunks, uint32_t *ctrl,
+                                                                uint32_t *flags, uint32_t *wmin, uint32_t *hflags,
+                                                                uint32_t nwords, uint2 *__restrict__ chunks,
+                                                                QueueState *__restrict__ qs, uint32_t *ctrl,
                                                                 uint32_t chunk_edges, uint32_t coop)
 {
-    __shared__ uint16_t list[SSSP_BLOCK / kWave][SSSP_GROUP]; // node - first node of the group
+    __shared__ uint16_t list[SSSP_BLOCK / kWave][SSSP_GROUP];          // node - first node of the group
+    __shared__ uint8_t owner[SSSP_BLOCK / kWave][kWave * SSSP_COOP];    // short-list edge slot -> lane holding its node
     if (ld_agent(&ctrl[C_DONE]))
         return; // a round enqueued behind the last one of its batch
     const uint32_t thr = ld_agent(&ctrl[C_THR]);
+    const bool heavy = ld_agent(&ctrl[C_HEAVY]) != 0u;
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wv = threadIdx.x >> 6;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-    const uint32_t ngroups = (nwords + kWave - 1) / kWave;
+    const uint32_t ngroups = (nwords * 2u + kWave - 1) / kWave;
+    const uint32_t sh = (lane & 1u) * 16u; // this lane's half of its flag word
     RelaxOut ro{0u};
     for (uint32_t grp = wave; grp < ngroups; grp += nwaves) {
-        const uint32_t my_word = grp * kWave + lane;
-        const uint32_t lo = my_word < nwords ? ld_agent(&wmin[my_word]) : NO_BUCKET;
-        // Every lane opens ITS word (32 nodes) if the word can hold a node at or below the threshold: all candidate
-        // words of the group at once — five memory round trips per group whatever the density.  (Two words per
-        // step, one per half wavefront, was 32 steps of three round trips each for a dense group: with one group
-        // per resident wavefront that serial chain, not the probe rate, set the time of the dense rounds.)
-        const bool mine = lo <= thr;
-        if (!__ballot(mine))
-            continue;
-        if (mine)
-            atomicExch(&wmin[my_word], NO_BUCKET); // reset first, then look: a concurrent flagger re-arms the word
-        sssp_drain();
-        const uint32_t fw = mine ? ld_agent(&flags[my_word]) : 0u;
-        uint32_t near = 0u, keep_far = NO_BUCKET;
+        const uint32_t my_word = (grp * kWave + lane) >> 1;
+        const bool valid = my_word < nwords;
+        uint32_t near = 0u; // 16 bits
+        if (heavy) {
+            near = valid ? (ld_agent(&hflags[my_word]) >> sh) & 0xFFFFu : 0u;
+            if (!__ballot(near != 0u))
+                continue;
+            if (near)
+                atomicAnd(&hflags[my_word], ~(near << sh));
+        } else {
+            const uint32_t lo = valid ? ld_agent(&wmin[my_word]) : NO_BUCKET;
+            // every lane opens its half word if the word can hold a node at or below the threshold: all candidate
+            // words of the group at once — four memory round trips per group whatever the density
+            const bool mine = lo <= thr;
+            if (!__ballot(mine))
+                continue;
+            if (mine && sh == 0u)
+                atomicExch(&wmin[my_word], NO_BUCKET); // reset first, then look: a concurrent flagger re-arms the word
+            sssp_drain();
+            const uint32_t fw = mine ? (ld_agent(&flags[my_word]) >> sh) & 0xFFFFu : 0u;
+            uint32_t keep_far = NO_BUCKET;
 #pragma unroll
-        for (uint32_t c = 0; c < 32u; c += 8u) { // the distances of the word's flagged nodes, eight loads in flight
-            uint32_t db[8];
+            for (uint32_t c = 0; c < SSSP_LANE_NODES; c += 8u) { // the distances of the flagged nodes, eight loads in flight
+                uint32_t db[8];
 #pragma unroll
-            for (uint32_t j = 0; j < 8u; ++j)
-                db[j] = ((fw >> (c + j)) & 1u) ? ld_agent(&dist[my_word * 32u + c + j]) : NO_BUCKET;
+                for (uint32_t j = 0; j < 8u; ++j)
+                    db[j] = ((fw >> (c + j)) & 1u) ? ld_agent(&dist[my_word * 32u + sh + c + j]) : NO_BUCKET;
 #pragma unroll
-            for (uint32_t j = 0; j < 8u; ++j)
-                if ((fw >> (c + j)) & 1u) {
-                    if (db[j] <= thr)
-                        near |= 1u << (c + j);
-                    else
-                        keep_far = db[j] < keep_far ? db[j] : keep_far; // what stays flagged goes back into the summary
-                }
+                for (uint32_t j = 0; j < 8u; ++j)
+                    if ((fw >> (c + j)) & 1u) {
+                        if (db[j] <= thr)
+                            near |= 1u << (c + j);
+                        else
+                            keep_far = db[j] < keep_far ? db[j] : keep_far; // what stays flagged goes back into the summary
+                    }
+            }
+            if (keep_far != NO_BUCKET)
+                atomicMin(&wmin[my_word], keep_far);
+            if (near)
+                atomicAnd(&flags[my_word], ~(near << sh));
+            sssp_drain(); // cleared before anyone reads the distances the relaxation uses
         }
-        if (keep_far != NO_BUCKET)
-            atomicMin(&wmin[my_word], keep_far);
-        if (near)
-            atomicAnd(&flags[my_word], ~near);
-        sssp_drain(); // cleared before anyone reads the distances the relaxation uses
         uint32_t cnt = (uint32_t)__popc(near), pre = cnt; // inclusive prefix of the lanes' counts
 #pragma unroll
         for (int o = 1; o < kWave; o <<= 1) {
@@ -162,18 +199,15 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_round_kernel(const uint32_t *
         }
         const uint32_t total = __shfl(pre, kWave - 1, kWave);
         for (uint32_t at = pre - cnt, bits = near; bits; bits &= bits - 1u)
-            list[wv][at++] = (uint16_t)(lane * 32u + (uint32_t)__ffs((int)bits) - 1u);
+            list[wv][at++] = (uint16_t)(lane * SSSP_LANE_NODES + (uint32_t)__ffs((int)bits) - 1u);
         if (total == 0)
             continue;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        // Lists of up to `coop` edges are relaxed by their own lane.  Everything longer leaves the wavefront: one
-        // work item per chunk_edges edges in a queue that sssp_chunk_kernel spreads over the whole grid.  (Relaxing
-        // the 33..2048-edge lists here, one after the other by the whole wavefront, made the few node groups that
-        // hold the high-degree nodes — the low ids of an RMAT graph — the critical path of every round.)
         // First the group's item count, so that ONE atomic reserves its stretch of the queue: thousands of
         // wavefronts adding to the same counter once per 64 nodes were ~12 ns apiece, serialised — 0.1-0.4 ms of a
         // dense round.  The same 64-bit add carries the round's work statistic in its upper half.
         uint32_t my_items = 0, my_work = 0;
+#pragma unroll 4
         for (uint32_t base = lane; base < total; base += kWave) {
             const uint32_t u = grp * SSSP_GROUP + list[wv][base];
             const uint32_t len = off[u + 1] - off[u];
@@ -184,7 +218,8 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_round_kernel(const uint32_t *
         const uint32_t grp_work = (uint32_t)wave_sum((uint64_t)my_work);
         uint32_t cursor = 0;
         if (lane == 0)
-            cursor = (uint32_t)atomicAdd(reinterpret_cast<unsigned long long *>(&ctrl[C_ITEMS]),
+            cursor = qs->start[grp % SSSP_QUEUES] +
+                     (uint32_t)atomicAdd(&qs->ctr[(grp % SSSP_QUEUES) * SSSP_QSTRIDE],
                                          (unsigned long long)grp_items | ((unsigned long long)grp_work << 32));
         cursor = __shfl(cursor, 0, kWave);
         for (uint32_t base = 0; base < total; base += kWave) {
@@ -197,11 +232,48 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_round_kernel(const uint32_t *
                 e = off[u + 1];
             }
             const uint32_t len = e - s;
-            if (len <= coop)
-                relax_range(tgt, w, dist, flags, wmin, du, s, e, 1u, thr, ro);
+            // The short lists of the 64 nodes, flattened over the lanes: edge slot f of their concatenation belongs
+            // to the node of lane owner[f].  (One lane walking its own list reads 64 different cache lines per load
+            // and takes len / 4 dependent steps; here consecutive lanes read consecutive edges.)
+            const uint32_t mine_len = len <= coop ? len : 0u;
+            uint32_t sincl = mine_len;
+#pragma unroll
+            for (int o = 1; o < kWave; o <<= 1) {
+                const uint32_t up = __shfl_up(sincl, o, kWave);
+                if ((int)lane >= o)
+                    sincl += up;
+            }
+            const uint32_t slots = __shfl(sincl, kWave - 1, kWave), sfirst = sincl - mine_len;
+            if (slots) {
+                for (uint32_t j = 0; j < mine_len; ++j)
+                    owner[wv][sfirst + j] = (uint8_t)lane;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                for (uint32_t f0 = 0; f0 < slots; f0 += kWave * SSSP_MLP) {
+                    uint32_t t[SSSP_MLP], nb[SSSP_MLP], pre[SSSP_MLP];
+#pragma unroll
+                    for (int k = 0; k < SSSP_MLP; ++k) {
+                        const uint32_t f = f0 + (uint32_t)k * kWave + lane;
+                        const bool in = f < slots;
+                        const int o = in ? (int)owner[wv][f] : 0;
+                        const uint32_t j = __shfl(s, o, kWave) + f - __shfl(sfirst, o, kWave);
+                        const float od = __shfl(du, o, kWave);
+                        t[k] = in ? tgt[j] : 0u;
+                        nb[k] = in ? __float_as_uint(__fadd_rn(od, w[j])) : 0xFFFFFFFFu;
+                    }
+#pragma unroll
+                    for (int k = 0; k < SSSP_MLP; ++k)
+                        pre[k] = nb[k] != 0xFFFFFFFFu ? ld_agent(&dist[t[k]]) : 0u;
+#pragma unroll
+                    for (int k = 0; k < SSSP_MLP; ++k)
+                        relax_checked(dist, flags, wmin, nb[k], pre[k], t[k], thr, ro);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // owner[] is rewritten by the next step
+            }
             const uint32_t nch = len > coop ? (len + chunk_edges - 1u) / chunk_edges : 0u;
             if (!__ballot(nch != 0u))
                 continue;
+            if (nch && !heavy)
+                atomicOr(&hflags[u >> 5], 1u << (u & 31u)); // owed a heavy round when the phase has run dry
             uint32_t incl = nch;
 #pragma unroll
             for (int o = 1; o < kWave; o <<= 1) {
@@ -237,25 +309,39 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_chunk_kernel(const uint32_t *
                                                                 const uint32_t *__restrict__ tgt,
                                                                 const float *__restrict__ w, uint32_t *dist,
                                                                 uint32_t *flags, uint32_t *wmin,
-                                                                const uint2 *__restrict__ chunks, uint32_t *ctrl,
+                                                                const uint2 *__restrict__ chunks,
+                                                                const QueueState *__restrict__ qs, uint32_t *ctrl,
                                                                 uint32_t chunk_edges)
 {
     if (ld_agent(&ctrl[C_DONE]))
         return;
-    const uint32_t nchunks = ld_agent(&ctrl[C_ITEMS]);
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    // lane q looks at sub-queue q: the wavefront walks the concatenation of the 64 sub-queues
+    static_assert(SSSP_QUEUES == kWave, "one sub-queue per lane");
+    const uint32_t q_items = (uint32_t)qs->ctr[lane * SSSP_QSTRIDE]; // written by the round kernel before this launch
+    uint32_t q_incl = q_items;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const uint32_t up = __shfl_up(q_incl, o, kWave);
+        if ((int)lane >= o)
+            q_incl += up;
+    }
+    const uint32_t nchunks = __shfl(q_incl, kWave - 1, kWave);
     if (nchunks == 0)
         return;
+    const uint32_t q_base = qs->start[lane] - (q_incl - q_items); // slot of item f of sub-queue q = q_base + f
     const uint32_t thr = ld_agent(&ctrl[C_THR]);
-    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const bool heavy = ld_agent(&ctrl[C_HEAVY]) != 0u;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     RelaxOut ro{0u};
     for (uint32_t c = wave; c < nchunks; c += nwaves) {
-        const uint2 ch = chunks[c];
+        const int q = __popcll(__ballot(q_incl <= c)); // sub-queues that end at or before item c
+        const uint2 ch = chunks[__shfl(q_base, q, kWave) + c];
         const float du = __uint_as_float(ld_agent(&dist[ch.x]));
         const uint32_t end_u = off[ch.x + 1];
         const uint32_t end = ch.y + chunk_edges < end_u ? ch.y + chunk_edges : end_u;
-        relax_range(tgt, w, dist, flags, wmin, du, ch.y + lane, end, kWave, thr, ro);
+        relax_range(tgt, w, dist, flags, wmin, du, ch.y + lane, end, kWave, thr, heavy ? R_HEAVY : R_LIGHT, ro);
     }
     if (__ballot(ro.again != 0) && lane == 0 && !ld_agent(&ctrl[C_AGAIN]))
         atomicOr(&ctrl[C_AGAIN], 1u);
@@ -269,7 +355,7 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_far_kernel(const uint32_t *__
                                                               uint32_t *ctrl)
 {
     __shared__ uint32_t part[SSSP_BLOCK / kWave];
-    if (ld_agent(&ctrl[C_DONE]) || ld_agent(&ctrl[C_AGAIN]))
+    if (ld_agent(&ctrl[C_DONE]) || !ld_agent(&ctrl[C_HEAVY]))
         return;
     uint32_t lo = NO_BUCKET;
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -289,18 +375,60 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_far_kernel(const uint32_t *__
     }
 }
 
-// Between two rounds (one thread): nothing left below the threshold -> move it to the minimum pending
+// Once per call: the capacity of every sub-queue = the items its node groups queue when all their nodes are taken
+// up in one round, then the sub-queues' first slots.
+__global__ __launch_bounds__(SSSP_BLOCK) void sssp_caps_kernel(const uint32_t *__restrict__ off, uint32_t n, uint32_t ngroups,
+                                                               QueueState *__restrict__ qs, uint32_t chunk_edges, uint32_t coop)
+{
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t grp = wave; grp < ngroups; grp += nwaves) {
+        uint32_t items = 0;
+        const uint32_t u0 = grp * SSSP_GROUP + lane * SSSP_LANE_NODES;
+        for (uint32_t u = u0; u < u0 + SSSP_LANE_NODES && u < n; ++u) {
+            const uint32_t len = off[u + 1] - off[u];
+            items += len > coop ? (len + chunk_edges - 1u) / chunk_edges : 0u;
+        }
+        items = (uint32_t)wave_sum((uint64_t)items);
+        if (lane == 0 && items)
+            atomicAdd(&qs->cap[grp % SSSP_QUEUES], items);
+    }
+}
+
+__global__ void sssp_qstart_kernel(QueueState *qs)
+{
+    uint32_t at = 0;
+    for (uint32_t q = 0; q < SSSP_QUEUES; ++q) {
+        qs->start[q] = at;
+        at += qs->cap[q];
+    }
+}
+
+// Between two rounds (one wavefront): nothing left below the threshold -> move it to the minimum pending
 // distance + width, or finish; then clear the round's outputs.
 // adapt_lo / adapt_hi (units of 64 relaxed edges; 0 = fixed width): the step halves when the phase that
 // just ended relaxed more than adapt_hi and doubles when it relaxed less than adapt_lo, within
 // [width_min, width_max] — coarse steps re-relax every edge ~6 times, fine steps leave the chip idle.
-__global__ void sssp_advance_kernel(uint32_t *ctrl, uint32_t adapt_lo, uint32_t adapt_hi, float width_min, float width_max)
+__global__ void sssp_advance_kernel(uint32_t *ctrl, QueueState *qs, uint32_t adapt_lo, uint32_t adapt_hi, float width_min,
+                                    float width_max)
 {
     if (ctrl[C_DONE])
         return;
-    ctrl[C_WORK] += (ctrl[C_RWORK] + 63u) >> 6;
-    if (!ctrl[C_AGAIN]) {
-        if (ctrl[C_FAR] == NO_BUCKET) {
+    // 64 threads: thread q reads and clears sub-queue q's counter; thread 0 does the rest
+    const uint64_t round_work = wave_sum((uint64_t)(qs->ctr[threadIdx.x * SSSP_QSTRIDE] >> 32));
+    qs->ctr[threadIdx.x * SSSP_QSTRIDE] = 0ull;
+    if (threadIdx.x != 0)
+        return;
+    ctrl[C_WORK] += (uint32_t)((round_work + 63u) >> 6);
+    if (!ctrl[C_HEAVY]) {
+        if (!ctrl[C_AGAIN])
+            ctrl[C_HEAVY] = 1u; // the phase has run dry: next, the heavy round of the nodes it took up
+    } else {
+        ctrl[C_HEAVY] = 0u;
+        if (ctrl[C_AGAIN]) {
+            // cannot happen (a heavy round only writes distances beyond the threshold); if it did, the phase goes on
+        } else if (ctrl[C_FAR] == NO_BUCKET) {
             ctrl[C_DONE] = 1u;
         } else {
             float width = __uint_as_float(ctrl[C_WIDTH]);
@@ -322,8 +450,6 @@ __global__ void sssp_advance_kernel(uint32_t *ctrl, uint32_t adapt_lo, uint32_t 
     }
     ctrl[C_AGAIN] = 0u;
     ctrl[C_FAR] = NO_BUCKET;
-    ctrl[C_ITEMS] = 0u;
-    ctrl[C_RWORK] = 0u;
     ctrl[C_ROUND] += 1u;
 }
 
@@ -415,7 +541,7 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
             chunk_edges = (uint32_t)atoi(v);
     uint32_t coop = SSSP_COOP;
     if (const char *v = getenv("GM_SSSP_COOP"))
-        if (atoi(v) >= 1 && atoi(v) <= 64)
+        if (atoi(v) >= 1 && atoi(v) <= (int)SSSP_COOP)
             coop = (uint32_t)atoi(v);
     std::unique_ptr<gm::SsspScratch> sc;
     {
@@ -440,17 +566,24 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
         GM_TRY(sc->dist.alloc((size_t)n * 4));
         GM_TRY(sc->flags.alloc(((size_t)nwords + kWave) * 4));
         GM_TRY(sc->wmin.alloc(((size_t)nwords + kWave) * 4));
+        GM_TRY(sc->hflags.alloc(((size_t)nwords + kWave) * 4));
         GM_TRY(sc->ctrl.alloc(64));
+        GM_TRY(sc->queues.alloc(sizeof(QueueState)));
         GM_TRY(sc->hctrl.alloc(64));
         GM_TRY(sc->chunks.alloc(items * sizeof(uint2)));
         sc->items = items;
     }
-    gm::DevBuf &dist = sc->dist, &flags = sc->flags, &wmin = sc->wmin, &ctrl = sc->ctrl, &chunks = sc->chunks;
+    gm::DevBuf &dist = sc->dist, &flags = sc->flags, &wmin = sc->wmin, &hflags = sc->hflags, &ctrl = sc->ctrl,
+               &chunks = sc->chunks;
+    QueueState *qs = sc->queues.as<QueueState>();
     gm::PinnedBuf &hctrl = sc->hctrl;
     hipStream_t st = 0;
     unsigned grid = gm::div_up(n, SSSP_BLOCK);
     if (grid > 256 * 8)
         grid = 256 * 8;
+    const uint32_t ngroups = gm::div_up((uint64_t)nwords * 2u, (uint64_t)kWave);
+    unsigned round_grid = gm::div_up(ngroups, SSSP_BLOCK / kWave); // one node group per wavefront
+    round_grid = round_grid > 256 * 16 ? 256 * 16 : round_grid;
     // Threshold step: starts at delta/32 and adapts to the work of each phase (sssp_advance_kernel): it doubles
     // while a phase relaxes fewer than m/5 edges and halves beyond 3m/4.  Measured at RMAT scale 24, delta 0.1:
     // 2.0 x m relaxations in ~60 rounds, 32 ms; a fixed step of delta: 6.4 x m, 53 ms; fixed delta/16: 2.2 x m but
@@ -483,6 +616,11 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
     hipLaunchKernelGGL(sssp_init_kernel, dim3(grid), dim3(SSSP_BLOCK), 0, st, dist.as<uint32_t>(), n,
                        (uint32_t)start_node);
     GM_HIP(hipMemsetAsync(flags.p, 0, flags.bytes, st));
+    GM_HIP(hipMemsetAsync(hflags.p, 0, hflags.bytes, st));
+    GM_HIP(hipMemsetAsync(qs, 0, sizeof(QueueState), st));
+    hipLaunchKernelGGL(sssp_caps_kernel, dim3(round_grid), dim3(SSSP_BLOCK), 0, st, g->offsets, n, ngroups, qs, chunk_edges,
+                       coop);
+    hipLaunchKernelGGL(sssp_qstart_kernel, dim3(1), dim3(1), 0, st, qs);
     const uint32_t start_bit = 1u << (start_node & 31u);
     GM_HIP(hipMemcpyAsync(flags.as<uint32_t>() + (start_node >> 5), &start_bit, 4, hipMemcpyHostToDevice, st));
     GM_HIP(hipMemsetAsync(wmin.p, 0xFF, wmin.bytes, st));
@@ -500,15 +638,16 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
     auto t_prev = std::chrono::steady_clock::now();
     for (;;) {
         for (int k = 0; k < batch; ++k) {
-            hipLaunchKernelGGL(sssp_round_kernel, dim3(grid), dim3(SSSP_BLOCK), 0, st, g->offsets, g->targets, g->weights,
-                               dist.as<uint32_t>(), flags.as<uint32_t>(), wmin.as<uint32_t>(), nwords, chunks.as<uint2>(),
+            hipLaunchKernelGGL(sssp_round_kernel, dim3(round_grid), dim3(SSSP_BLOCK), 0, st, g->offsets, g->targets, g->weights,
+                               dist.as<uint32_t>(), flags.as<uint32_t>(), wmin.as<uint32_t>(), hflags.as<uint32_t>(), nwords,
+                               chunks.as<uint2>(), qs,
                                ctrl.as<uint32_t>(), chunk_edges, coop);
             hipLaunchKernelGGL(sssp_chunk_kernel, dim3(grid), dim3(SSSP_BLOCK), 0, st, g->offsets, g->targets, g->weights,
-                               dist.as<uint32_t>(), flags.as<uint32_t>(), wmin.as<uint32_t>(), chunks.as<uint2>(),
+                               dist.as<uint32_t>(), flags.as<uint32_t>(), wmin.as<uint32_t>(), chunks.as<uint2>(), qs,
                                ctrl.as<uint32_t>(), chunk_edges);
             hipLaunchKernelGGL(sssp_far_kernel, dim3(far_grid), dim3(SSSP_BLOCK), 0, st, wmin.as<uint32_t>(), nwords,
                                ctrl.as<uint32_t>());
-            hipLaunchKernelGGL(sssp_advance_kernel, dim3(1), dim3(1), 0, st, ctrl.as<uint32_t>(), adapt_lo, adapt_hi,
+            hipLaunchKernelGGL(sssp_advance_kernel, dim3(1), dim3(kWave), 0, st, ctrl.as<uint32_t>(), qs, adapt_lo, adapt_hi,
                                delta / 1024.0f, delta * 16.0f);
         }
         GM_HIP(hipGetLastError());
