@@ -191,6 +191,7 @@ struct gm_csr {
     mutable std::mutex cache_mu;
     mutable std::map<uint64_t, std::shared_ptr<const gm::PbPlan>> pb_plans;
     mutable std::atomic<uint64_t> page_rank_calls{0}; // gm_page_rank calls seen by this handle (engine choice); calls may run concurrently
+    mutable std::atomic<int> weights_ok{0};                // 1: gm_sssp_delta_stepping has seen that no weight is negative or NaN
     mutable std::unique_ptr<gm::SsspScratch> sssp_scratch; // parked between calls (under cache_mu)
     mutable std::atomic<int> long_rows{-1};           // 1: some row has >= GM_PB_HUB_DEG entries (-1: not looked at yet)
 };

@@ -608,7 +608,9 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
     uint32_t init_ctrl[16] = {0u, NO_BUCKET, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     memcpy(&init_ctrl[C_WIDTH], &width, 4);
     GM_HIP(hipMemcpyAsync(ctrl.p, init_ctrl, 64, hipMemcpyHostToDevice, st));
-    if (g->m) {
+    // the weights of a handle do not change: one look per handle (0.3 ms of a 10 ms call at scale 24)
+    const bool check_weights = g->m && g->weights_ok.load(std::memory_order_relaxed) == 0;
+    if (check_weights) {
         unsigned wg = gm::div_up(g->m, 256);
         hipLaunchKernelGGL(sssp_check_weights_kernel, dim3(wg > 8192 ? 8192 : wg), dim3(256), 0, st, g->weights, g->m,
                            ctrl.as<uint32_t>() + C_BAD);
@@ -629,6 +631,8 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
     GM_HIP(hipStreamSynchronize(st));
     GM_CHECK(hctrl.as<uint32_t>()[C_BAD] == 0, GM_ERR_UNSUPPORTED,
              "gm_sssp_delta_stepping: negative or NaN edge weight (the reference assumes weights >= 0)");
+    if (check_weights)
+        g->weights_ok.store(1, std::memory_order_relaxed);
 
     const double ms_setup = since(t_call);
     unsigned far_grid = gm::div_up(nwords, SSSP_BLOCK * 8);

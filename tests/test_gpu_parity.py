@@ -422,6 +422,49 @@ def test_sssp_result_does_not_depend_on_the_schedule(P, oracle, monkeypatch, wid
     assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("chunk,coop", [("64", "1"), ("64", "32"), ("1024", "8"), ("4096", "32")])
+def test_sssp_result_does_not_depend_on_the_work_split(P, oracle, monkeypatch, chunk, coop):
+    """Edges per work item and the longest list a lane keeps for the wavefront's own flattened pass only move
+    work between the round and the chunk kernel (and change the sub-queue capacities): same bits."""
+    scale = 15
+    s, d = oracle.rmat_edges(scale, seed=17)
+    w = oracle.rmat_weights(s.size, seed=18)
+    n = 1 << scale
+    g = _directed(P, n, s, d, P.CsrLayout.Sorted, w)
+    off, tgt, wv = oracle.csr_build(n, s, d, oracle.OUTGOING, oracle.SORTED, w)
+    start = int(np.flatnonzero(np.diff(off) > 0)[0])
+    ref = oracle.delta_stepping(off, tgt, wv, start, 0.1)
+    monkeypatch.setenv("GM_SSSP_CHUNK", chunk)
+    monkeypatch.setenv("GM_SSSP_COOP", coop)
+    assert np.array_equal(P.delta_stepping(g, P.DeltaSteppingConfig(start, 0.1)), ref)
+
+
+def test_sssp_many_start_nodes_on_one_handle(P, oracle):
+    """The working buffers are parked in the CSR handle between calls and the weight check runs once per handle:
+    later calls (other start nodes, other deltas, an isolated start node) must not see anything of the earlier ones."""
+    scale = 13
+    s, d = oracle.rmat_edges(scale, seed=3)
+    w = oracle.rmat_weights(s.size, seed=4)
+    n = 1 << scale
+    g = _directed(P, n, s, d, P.CsrLayout.Sorted, w)
+    off, tgt, wv = oracle.csr_build(n, s, d, oracle.OUTGOING, oracle.SORTED, w)
+    deg = np.diff(off)
+    starts = [int(x) for x in np.flatnonzero(deg > 0)[[0, 5, 100, -1]]] + [int(np.flatnonzero(deg == 0)[0])]
+    for k, start in enumerate(starts * 2):
+        delta = (0.1, 0.7, 25.0)[k % 3]
+        got = P.delta_stepping(g, P.DeltaSteppingConfig(start, delta))
+        assert np.array_equal(got, oracle.delta_stepping(off, tgt, wv, start, delta)), (start, delta)
+
+
+def test_sssp_rejects_negative_and_nan_weights_every_time(P):
+    for bad in (-1.0, float("nan")):
+        g = (P.GraphBuilder().csr_layout(P.CsrLayout.Sorted)
+             .edges_with_values([(0, 1, 1.0), (1, 2, bad), (2, 3, 1.0)]).build(P.DirectedCsrGraph))
+        for _ in range(2):  # the verdict of the first look is not cached as "fine"
+            with pytest.raises(Exception, match="negative or NaN"):
+                P.delta_stepping(g, P.DeltaSteppingConfig(0, 1.0))
+
+
 # ------------------------------------------------------------------------------------------------
 # triangle count
 # ------------------------------------------------------------------------------------------------
