@@ -179,13 +179,21 @@ namespace {
 // source in the source field and the flag bit above the bin, so hot keys sort behind every cold key, bin-major.
 // A hub row (header) belongs to no ordinary bin: its bin field holds the VIRTUAL bin B + (its hub group) and its
 // slot is its position inside the group.  Everything below simply sees B + G bins.
+// `filter` (LDS; null for hub rows: every term of theirs must pass the value stream in source order): one bit per
+// 2^fshift consecutive sources, set when one of them is hot.  It answers "not hot" for most edges without leaving the
+// CU; only the rest look their source up in the rank table (134 MB at scale 26 — a random 2-byte gather per edge
+// from that table was most of this kernel's time).
 __device__ __forceinline__ uint64_t pb_make_key(uint64_t hi_cold, uint32_t src, int sb, int bb,
+                                                const uint32_t *filter, int fshift,
                                                 const uint16_t *__restrict__ hot_rank)
 {
-    if (hot_rank) { // (null for hub rows: every term of theirs must pass the value stream in source order)
-        const uint16_t h = hot_rank[src];
-        if (h != PB_NULL)
-            return hi_cold | (1ull << (sb + bb)) | h;
+    if (filter) {
+        const uint32_t blk = src >> fshift;
+        if ((filter[blk >> 5] >> (blk & 31u)) & 1u) {
+            const uint16_t h = hot_rank[src];
+            if (h != PB_NULL)
+                return hi_cold | (1ull << (sb + bb)) | h;
+        }
     }
     return hi_cold | src;
 }
@@ -247,26 +255,50 @@ __global__ void pb_count_sources_kernel(const uint32_t *__restrict__ tgt, uint32
         atomicAdd(&cnt[tgt[i]], 1u);
 }
 
-__global__ void pb_count_keys_kernel(const uint32_t *__restrict__ cnt, uint32_t x_len, uint64_t *__restrict__ keys)
+// candidates for the hot set: sources counted at least twice, as keys that sort ASCENDING into (count descending, id
+// ascending) — ~count << 32 | id — appended in any order (the keys are distinct, the sorted order does not depend on it)
+__global__ __launch_bounds__(256) void pb_count_keys_kernel(const uint32_t *__restrict__ cnt, uint32_t x_len,
+                                                            uint64_t *__restrict__ keys, uint32_t *__restrict__ n_keys)
 {
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < x_len; i += stride)
-        keys[i] = ((uint64_t)cnt[i] << 32) | i;
+    // every wavefront owns one contiguous stretch of the sources: count its candidates, reserve their places with
+    // ONE atomic (a million wavefront-level adds on the same counter serialise at ~12 ns each), then write them
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t per = ((x_len + nwaves - 1) / nwaves + kWave - 1) / kWave * kWave;
+    const uint64_t lo = (uint64_t)wave * per;
+    const uint64_t hi = lo + per < x_len ? lo + per : x_len;
+    uint32_t mine = 0;
+    for (uint64_t i = lo + lane; i < hi; i += kWave)
+        mine += cnt[i] >= 2u ? 1u : 0u;
+    const uint32_t total = (uint32_t)wave_sum((uint64_t)mine);
+    if (total == 0)
+        return;
+    uint32_t at = 0;
+    if (lane == 0)
+        at = atomicAdd(n_keys, total);
+    at = __shfl(at, 0, kWave);
+    for (uint64_t base = lo; base < hi; base += kWave) {
+        const uint64_t i = base + lane;
+        const uint32_t c = i < hi ? cnt[i] : 0u;
+        const uint64_t take = __ballot(c >= 2u);
+        if (c >= 2u)
+            keys[at + (uint32_t)__popcll(take & ((1ull << lane) - 1ull))] = ((uint64_t)(~c) << 32) | (uint32_t)i;
+        at += (uint32_t)__popcll(take);
+    }
 }
 
-// sorted descending by (count, id): the first H entries with count >= 2 become hot
+// the first H candidates become hot: rank table + the block filter pb_keys_kernel stages in LDS
 __global__ void pb_hot_select_kernel(const uint64_t *__restrict__ sorted, uint32_t H, uint32_t *__restrict__ hot_ids,
-                                     uint16_t *__restrict__ hot_rank, uint32_t *__restrict__ h_eff)
+                                     uint16_t *__restrict__ hot_rank, uint32_t *__restrict__ hot_blk, int fshift)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= H)
         return;
-    const uint64_t e = sorted[k];
-    if ((uint32_t)(e >> 32) >= 2u) {
-        hot_ids[k] = (uint32_t)e;
-        hot_rank[(uint32_t)e] = (uint16_t)k;
-        atomicMax(h_eff, k + 1u);
-    }
+    const uint32_t id = (uint32_t)sorted[k];
+    hot_ids[k] = id;
+    hot_rank[id] = (uint16_t)k;
+    atomicOr(&hot_blk[(id >> fshift) >> 5], 1u << ((id >> fshift) & 31u));
 }
 
 __global__ void pb_hot_fill_kernel(const uint64_t *__restrict__ hkeys, uint32_t mh, const uint32_t *__restrict__ hstart,
@@ -297,13 +329,23 @@ __global__ void pb_hot_gather_kernel(const float *__restrict__ x_in, const uint3
         hot_x[k] = x_in[hot_ids[k]];
 }
 
-__global__ __launch_bounds__(256) void pb_keys_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt,
-                                                      uint32_t n, int rb, int sb, int bb,
-                                                      const uint16_t *__restrict__ hot_rank,
-                                                      const uint16_t *__restrict__ cidx, const uint32_t *__restrict__ pos_h,
-                                                      const uint32_t *__restrict__ hub_first, uint32_t B, uint32_t G,
-                                                      uint64_t *__restrict__ keys)
+constexpr int PB_KEYS_BLOCK = 1024;
+constexpr int PB_FILTER_BITS = 20; // the hot-source block filter has at most 2^20 bits (128 KiB of LDS)
+
+__global__ __launch_bounds__(PB_KEYS_BLOCK) void pb_keys_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt,
+                                                               uint32_t n, int rb, int sb, int bb,
+                                                               const uint32_t *__restrict__ hot_blk, uint32_t filter_words,
+                                                               int fshift, const uint16_t *__restrict__ hot_rank,
+                                                               const uint16_t *__restrict__ cidx,
+                                                               const uint32_t *__restrict__ pos_h,
+                                                               const uint32_t *__restrict__ hub_first, uint32_t B, uint32_t G,
+                                                               uint64_t *__restrict__ keys)
 {
+    extern __shared__ uint32_t pb_filter[];
+    for (uint32_t i = threadIdx.x; i < filter_words; i += PB_KEYS_BLOCK)
+        pb_filter[i] = hot_blk[i];
+    __syncthreads();
+    const uint32_t *filter = hot_blk ? pb_filter : nullptr;
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t n_pad = (n + kWave - 1) / kWave * kWave;
@@ -327,7 +369,7 @@ __global__ __launch_bounds__(256) void pb_keys_kernel(const uint32_t *__restrict
         const uint64_t hi = ((uint64_t)(slot & rmask) << (sb + bb + 1)) | ((uint64_t)vbin << sb);
         if (len <= 32)
             for (uint32_t i = s; i < e; ++i)
-                keys[i] = pb_make_key(hi, tgt[i], sb, bb, hub ? nullptr : hot_rank);
+                keys[i] = pb_make_key(hi, tgt[i], sb, bb, hub ? nullptr : filter, fshift, hot_rank);
         uint64_t big = __ballot(len > 32);
         while (big) {
             const int src = __ffsll((unsigned long long)big) - 1;
@@ -336,7 +378,7 @@ __global__ __launch_bounds__(256) void pb_keys_kernel(const uint32_t *__restrict
             const uint64_t bhi = __shfl(hi, src, kWave);
             const bool bhub = __shfl((int)hub, src, kWave) != 0;
             for (uint32_t i = bs + lane; i < be; i += kWave)
-                keys[i] = pb_make_key(bhi, tgt[i], sb, bb, bhub ? nullptr : hot_rank);
+                keys[i] = pb_make_key(bhi, tgt[i], sb, bb, bhub ? nullptr : filter, fshift, hot_rank);
         }
     }
 }
@@ -359,11 +401,12 @@ __global__ void pb_flags_kernel(const uint64_t *__restrict__ keys, uint32_t m, i
     }
 }
 
-// segid = inclusive_scan(flag); for every segment start: vstart[j] = q, segkey[j] = tile << 32 | bin, segval[j] = j
+// segid = inclusive_scan(flag); for every segment start: vstart[j] = q, segbin[j] = bin, and the key that sorts the
+// segments into phase-1 order with their bin-major index as payload: tile << (bb + jb) | bin << jb | j
 __global__ void pb_segments_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ flag,
-                                   const uint32_t *__restrict__ segid_incl, uint32_t m, int bb, int sb, int s_log,
+                                   const uint32_t *__restrict__ segid_incl, uint32_t m, int bb, int sb, int s_log, int jb,
                                    uint32_t *__restrict__ vstart, uint64_t *__restrict__ segkey,
-                                   uint32_t *__restrict__ segval, uint64_t *__restrict__ segbin)
+                                   uint64_t *__restrict__ segbin)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < m; q += stride)
@@ -371,10 +414,17 @@ __global__ void pb_segments_kernel(const uint64_t *__restrict__ keys, const uint
             const uint32_t j = segid_incl[q] - 1;
             const uint64_t bt = pb_seg_of_key(keys[q], bb, sb, s_log);
             vstart[j] = q;
-            segkey[j] = ((bt & 0xFFFFFFFFull) << 32) | (bt >> 32);
-            segval[j] = j;
+            segkey[j] = ((bt & 0xFFFFFFFFull) << (bb + jb)) | ((bt >> 32) << jb) | j;
             segbin[j] = bt >> 32;
         }
+}
+
+// the payload of the sorted segment keys: segval[r] = bin-major index of the r-th segment in phase-1 order
+__global__ void pb_segval_kernel(const uint64_t *__restrict__ segkey_sorted, uint32_t NS, int jb, uint32_t *__restrict__ segval)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < NS; r += stride)
+        segval[r] = (uint32_t)(segkey_sorted[r] & ((1ull << jb) - 1ull));
 }
 
 // segments in phase-1 order (rank r): cnt[r]; tile_seg[t] = first rank of tile t
@@ -431,12 +481,12 @@ __global__ void pb_tile_tail_kernel(const uint32_t *__restrict__ tile_seg, const
 __global__ void pb_seg_layout_kernel(const uint64_t *__restrict__ segkey_sorted, const uint32_t *__restrict__ segval_sorted,
                                      const uint32_t *__restrict__ vstart4, const uint32_t *__restrict__ cs,
                                      const uint32_t *__restrict__ tile_seg, const uint32_t *__restrict__ tile_p,
-                                     uint32_t NS, uint32_t *__restrict__ pstart, uint32_t *__restrict__ delta,
-                                     uint32_t *__restrict__ rank_of)
+                                     uint32_t NS, int tile_shift, uint32_t *__restrict__ pstart,
+                                     uint32_t *__restrict__ delta, uint32_t *__restrict__ rank_of)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < NS; r += stride) {
-        const uint32_t t = (uint32_t)(segkey_sorted[r] >> 32);
+        const uint32_t t = (uint32_t)(segkey_sorted[r] >> tile_shift);
         const uint32_t j = segval_sorted[r];
         const uint32_t ps = tile_p[t] + (cs[r] - cs[tile_seg[t]]);
         pstart[r] = ps;
@@ -1192,23 +1242,6 @@ int sort_keys_u64(DevBuf &keys, DevBuf &alt, uint64_t count, int begin_bit, int 
     return GM_OK;
 }
 
-int sort_pairs_u64_u32(DevBuf &keys, DevBuf &kalt, DevBuf &vals, DevBuf &valt, uint64_t count, int end_bit)
-{
-    rocprim::double_buffer<uint64_t> dk(keys.as<uint64_t>(), kalt.as<uint64_t>());
-    rocprim::double_buffer<uint32_t> dv(vals.as<uint32_t>(), valt.as<uint32_t>());
-    size_t tmp_bytes = 0;
-    GM_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, dk, dv, count, 0u, (unsigned)end_bit, (hipStream_t)0));
-    DevBuf tmp;
-    GM_TRY(tmp.alloc(tmp_bytes));
-    GM_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, dk, dv, count, 0u, (unsigned)end_bit, (hipStream_t)0));
-    GM_HIP(hipDeviceSynchronize());
-    if (dk.current() != keys.as<uint64_t>())
-        std::swap(keys, kalt);
-    if (dv.current() != vals.as<uint32_t>())
-        std::swap(vals, valt);
-    return GM_OK;
-}
-
 // Accumulate work items: one per bin, except that a bin more than twice the average size (a range of
 // rows that attracts a large share of the edges, e.g. degree-sorted ids) is cut into slices so that no
 // workgroup streams more than ~2x the average; longest first.  Built on the host from the B+1 bin
@@ -1329,6 +1362,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
         GM_HIP(hipGetLastError());
         GM_TRY(scan_exclusive<uint32_t>(flag.as<uint32_t>(), pos_h.as<uint32_t>(), (uint64_t)n + 1));
         GM_HIP(hipMemcpy(&pl->n_hub, pos_h.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost));
+        timer.done("pb plan: - hub flags + scan");
         if (pl->n_hub) {
             // hub groups: consecutive hub rows, cut at PB_HUB_MAX rows or about one ordinary bin's worth of
             // terms (so that a group's (tile, group) segments are as long as a bin's)
@@ -1361,6 +1395,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
         }
         GM_TRY(pl->hub_first.alloc(pl->hub_first_host.size() * 4));
         GM_HIP(hipMemcpy(pl->hub_first.p, pl->hub_first_host.data(), pl->hub_first_host.size() * 4, hipMemcpyHostToDevice));
+        timer.done("pb plan: - hub groups");
         hipLaunchKernelGGL(pb_rowflag_kernel, dim3(pb_grid((uint64_t)n + 1)), dim3(256), 0, 0, csr->offsets, n, pl->hub_deg,
                            flag.as<uint32_t>());
         GM_HIP(hipGetLastError());
@@ -1370,6 +1405,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
         GM_HIP(hipGetLastError());
         std::vector<uint32_t> rows(pl->B);
         GM_HIP(hipMemcpy(rows.data(), bin_rows.p, (size_t)pl->B * 4, hipMemcpyDeviceToHost));
+        timer.done("pb plan: - row flags + scan + slots");
         uint32_t mx = 1;
         for (uint32_t v : rows)
             mx = v > mx ? v : mx;
@@ -1426,41 +1462,41 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
 
     timer.done("pb plan: accumulator slots");
     // ---- hot sources: the H most frequent source ids (>= 2 edges) of this rank's edges ----------------
-    DevBuf hot_rank;
+    DevBuf hot_rank, hot_blk;
+    const int fshift = sb > PB_FILTER_BITS ? sb - PB_FILTER_BITS : 0;
+    const uint32_t filter_words = (uint32_t)(((x_len >> fshift) + 32) / 32);
     if (H) {
-        DevBuf cnt, ckeys, calt, heff;
+        DevBuf cnt, ckeys, calt, n_keys;
         GM_TRY(cnt.alloc((size_t)x_len * 4));
         GM_TRY(ckeys.alloc((size_t)x_len * 8));
         GM_TRY(calt.alloc((size_t)x_len * 8));
-        GM_TRY(heff.alloc(4));
+        GM_TRY(n_keys.alloc(4));
         GM_TRY(hot_rank.alloc((size_t)x_len * 2));
+        GM_TRY(hot_blk.alloc((size_t)filter_words * 4));
         GM_HIP(hipMemset(cnt.p, 0, (size_t)x_len * 4));
-        GM_HIP(hipMemset(heff.p, 0, 4));
+        GM_HIP(hipMemset(n_keys.p, 0, 4));
+        GM_HIP(hipMemset(hot_blk.p, 0, hot_blk.bytes));
         GM_HIP(hipMemset(hot_rank.p, 0xFF, (size_t)x_len * 2));
         const uint32_t sample_step = m_all > (1u << 26) ? 8u : 1u;
         hipLaunchKernelGGL(pb_count_sources_kernel, dim3(pb_grid(m_all / sample_step + 1)), dim3(256), 0, 0, csr->targets,
                            m_all, sample_step, cnt.as<uint32_t>());
         hipLaunchKernelGGL(pb_count_keys_kernel, dim3(pb_grid(x_len)), dim3(256), 0, 0, cnt.as<uint32_t>(), (uint32_t)x_len,
-                           ckeys.as<uint64_t>());
+                           ckeys.as<uint64_t>(), n_keys.as<uint32_t>());
         GM_HIP(hipGetLastError());
-        {
-            rocprim::double_buffer<uint64_t> db(ckeys.as<uint64_t>(), calt.as<uint64_t>());
-            size_t tmp_bytes = 0;
-            GM_HIP(rocprim::radix_sort_keys_desc(nullptr, tmp_bytes, db, x_len, 0u, 64u, (hipStream_t)0));
-            DevBuf tmp;
-            GM_TRY(tmp.alloc(tmp_bytes));
-            GM_HIP(rocprim::radix_sort_keys_desc(tmp.p, tmp_bytes, db, x_len, 0u, 64u, (hipStream_t)0));
-            GM_HIP(hipDeviceSynchronize());
-            if (db.current() != ckeys.as<uint64_t>())
-                std::swap(ckeys, calt);
-        }
-        const uint32_t h_try = H < x_len ? H : (uint32_t)x_len;
-        hipLaunchKernelGGL(pb_hot_select_kernel, dim3(div_up(h_try, 256)), dim3(256), 0, 0, ckeys.as<uint64_t>(), h_try,
-                           pl->hot_ids.as<uint32_t>(), hot_rank.as<uint16_t>(), heff.as<uint32_t>());
+        uint32_t candidates = 0;
+        GM_HIP(hipMemcpy(&candidates, n_keys.p, 4, hipMemcpyDeviceToHost));
+        if (candidates)
+            GM_TRY(sort_keys_u64(ckeys, calt, candidates, 0, 64)); // a few million keys of the 67 M sources at scale 26
+        H = H < candidates ? H : candidates;
+        if (H)
+            hipLaunchKernelGGL(pb_hot_select_kernel, dim3(div_up(H, 256)), dim3(256), 0, 0, ckeys.as<uint64_t>(), H,
+                               pl->hot_ids.as<uint32_t>(), hot_rank.as<uint16_t>(), hot_blk.as<uint32_t>(), fshift);
         GM_HIP(hipGetLastError());
-        GM_HIP(hipMemcpy(&H, heff.p, 4, hipMemcpyDeviceToHost));
-        if (H == 0)
+        GM_HIP(hipDeviceSynchronize());
+        if (H == 0) {
             hot_rank.release();
+            hot_blk.release();
+        }
     }
     pl->H = H;
     timer.done("pb plan: hot source selection");
@@ -1469,15 +1505,24 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     GM_TRY(keys.alloc((size_t)m_all * 8));
     GM_TRY(kalt.alloc((size_t)m_all * 8));
     const int hot_bit = bin_bits + sb; // the flag bit of a hot edge: the highest sorted bit
-    hipLaunchKernelGGL(pb_keys_kernel, dim3(pb_grid(n)), dim3(256), 0, 0, csr->offsets, csr->targets, n, rb, sb, bin_bits,
-                       H ? hot_rank.as<uint16_t>() : (const uint16_t *)nullptr, pl->cidx.as<uint16_t>(),
-                       pos_h.as<uint32_t>(), pl->hub_first.as<uint32_t>(), pl->B, pl->G, keys.as<uint64_t>());
+    {
+        const size_t lds = H ? (size_t)filter_words * 4 : 0;
+        GM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pb_keys_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)((4u << PB_FILTER_BITS) / 32 + 64)));
+        unsigned kg = div_up(n, PB_KEYS_BLOCK);
+        kg = kg > 512 ? 512 : (kg ? kg : 1); // persistent workgroups: each stages the filter once
+        hipLaunchKernelGGL(pb_keys_kernel, dim3(kg), dim3(PB_KEYS_BLOCK), lds, 0, csr->offsets, csr->targets, n, rb, sb, bin_bits,
+                           H ? hot_blk.as<uint32_t>() : (const uint32_t *)nullptr, H ? filter_words : 0u, fshift,
+                           hot_rank.as<uint16_t>(), pl->cidx.as<uint16_t>(), pos_h.as<uint32_t>(), pl->hub_first.as<uint32_t>(),
+                           pl->B, pl->G, keys.as<uint64_t>());
+    }
     GM_HIP(hipGetLastError());
     // the slot sits above the sorted bits (rocPRIM's radix sort was measured 14x slower with a non-zero BEGIN bit at
     // this size, so the unsorted field is at the top, not at the bottom)
     GM_TRY(sort_keys_u64(keys, kalt, m_all, 0, H ? hot_bit + 1 : hot_bit));
     kalt.release();
     hot_rank.release();
+    hot_blk.release();
     pos_h.release();
     timer.done("pb plan: edge keys + sort");
 
@@ -1537,16 +1582,19 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     GM_CHECK((uint64_t)m + 3ull * NS + (uint64_t)pl->NT * PB_WBLK < (1ull << 32), GM_ERR_RANGE,
              "pb_build: padded streams exceed 2^32 entries");
 
-    DevBuf vstart, segkey, segkalt, segval, segvalt, segbin;
+    DevBuf vstart, segkey, segkalt, segval, segbin;
+    const int jb = bits_for(NS) < 1 ? 1 : bits_for(NS), tile_bits = bits_for(pl->NT) < 1 ? 1 : bits_for(pl->NT);
+    const int tile_shift = bin_bits + jb;
+    GM_CHECK(tile_bits + tile_shift <= 64, GM_ERR_RANGE, "pb_build: %u tiles x %u bins x %u segments do not fit a 64-bit key",
+             pl->NT, Bv, NS);
     GM_TRY(vstart.alloc((size_t)NS * 4));
     GM_TRY(segkey.alloc((size_t)NS * 8));
     GM_TRY(segkalt.alloc((size_t)NS * 8));
     GM_TRY(segval.alloc((size_t)NS * 4));
-    GM_TRY(segvalt.alloc((size_t)NS * 4));
     GM_TRY(segbin.alloc((size_t)NS * 8));
     hipLaunchKernelGGL(pb_segments_kernel, dim3(gm_), dim3(256), 0, 0, keys.as<uint64_t>(), flag.as<uint32_t>(),
-                       segid.as<uint32_t>(), m, bin_bits, sb, pl->s_log, vstart.as<uint32_t>(), segkey.as<uint64_t>(),
-                       segval.as<uint32_t>(), segbin.as<uint64_t>());
+                       segid.as<uint32_t>(), m, bin_bits, sb, pl->s_log, jb, vstart.as<uint32_t>(), segkey.as<uint64_t>(),
+                       segbin.as<uint64_t>());
     GM_HIP(hipGetLastError());
     GM_HIP(hipDeviceSynchronize());
     flag.release();
@@ -1558,11 +1606,13 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
                        bin_seg.as<uint32_t>());
     GM_HIP(hipGetLastError());
     timer.done("pb plan: segments");
-    // phase-1 order of the segments: by (tile, bin)
-    GM_TRY(sort_pairs_u64_u32(segkey, segkalt, segval, segvalt, NS, 64));
+    // phase-1 order of the segments: by (tile, bin); the bin-major index rides in the low bits of the key (the same
+    // keys-only radix sort as the edges: one instantiation of rocPRIM's sort in the code object instead of three)
+    GM_TRY(sort_keys_u64(segkey, segkalt, NS, 0, tile_bits + tile_shift));
     segkalt.release();
-    segvalt.release();
     segbin.release();
+    hipLaunchKernelGGL(pb_segval_kernel, dim3(gs), dim3(256), 0, 0, segkey.as<uint64_t>(), NS, jb, segval.as<uint32_t>());
+    GM_HIP(hipGetLastError());
 
     DevBuf cnt, cs, cntv, vstart4, tile_seg, tile_pad, pstart, rank_of;
     GM_TRY(cnt.alloc(((size_t)NS + 1) * 4));
@@ -1578,7 +1628,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
                        m, cnt.as<uint32_t>(), cntv.as<uint32_t>());
     GM_HIP(hipGetLastError());
     GM_TRY(scan_exclusive<uint32_t>(cnt.as<uint32_t>(), cs.as<uint32_t>(), (uint64_t)NS + 1));
-    hipLaunchKernelGGL(pb_bounds_kernel, dim3(gs), dim3(256), 0, 0, segkey.as<uint64_t>(), NS, 32, pl->NT,
+    hipLaunchKernelGGL(pb_bounds_kernel, dim3(gs), dim3(256), 0, 0, segkey.as<uint64_t>(), NS, tile_shift, pl->NT,
                        tile_seg.as<uint32_t>());
     hipLaunchKernelGGL(pb_tile_sizes_kernel, dim3(pb_grid((uint64_t)pl->NT + 1)), dim3(256), 0, 0,
                        tile_seg.as<uint32_t>(), cs.as<uint32_t>(), pl->NT, tile_pad.as<uint32_t>());
@@ -1598,7 +1648,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     pl->Mp = Mp;
     hipLaunchKernelGGL(pb_seg_layout_kernel, dim3(gs), dim3(256), 0, 0, segkey.as<uint64_t>(), segval.as<uint32_t>(),
                        vstart4.as<uint32_t>(), cs.as<uint32_t>(), tile_seg.as<uint32_t>(), pl->tile_p.as<uint32_t>(), NS,
-                       pstart.as<uint32_t>(), pl->delta.as<uint32_t>(), rank_of.as<uint32_t>());
+                       tile_shift, pstart.as<uint32_t>(), pl->delta.as<uint32_t>(), rank_of.as<uint32_t>());
     GM_HIP(hipGetLastError());
 
     GM_TRY(pl->p2_dst.alloc((size_t)Mv * 2));

@@ -353,7 +353,7 @@ def page_rank(graph: DirectedCsrGraph, config: PageRankConfig | None = None, mod
     """page_rank(&graph, config) -> (scores, iterations, error) — crates/algos/src/page_rank.rs:58-111."""
     config = config or PageRankConfig()
     n = graph.node_count()
-    scores = np.empty(n, np.float32)
+    scores = _result_buffer(n, np.float32)
     it, err = u64(0), f64(0.0)
     # both CSRs are resident: out-degrees are taken from the out-CSR's offsets on the device
     check(lib().gm_page_rank_directed(graph.csr_out.handle, graph.csr_inc.handle, int(config.max_iterations),
@@ -368,7 +368,7 @@ def page_rank_multi(graph: DirectedCsrGraph, config: PageRankConfig | None = Non
     named twice = virtual ranks on one GPU), or n_devices for 0 .. n_devices-1."""
     config = config or PageRankConfig()
     n = graph.node_count()
-    scores = np.empty(n, np.float32)
+    scores = _result_buffer(n, np.float32)
     it, err = u64(0), f64(0.0)
     if devices is not None:
         arr = (C.c_int * len(devices))(*[int(d) for d in devices])
@@ -405,7 +405,7 @@ class Components:
 def wcc_afforest(graph: DirectedCsrGraph, config: WccConfig | None = None) -> Components:
     """wcc_afforest — crates/algos/src/wcc.rs:127-141"""
     config = config or WccConfig()
-    labels = np.empty(graph.node_count(), np.uint32)
+    labels = _result_buffer(graph.node_count(), np.uint32)
     check(lib().gm_wcc_afforest(graph.csr_out.handle, graph.csr_inc.handle, int(config.neighbor_rounds),
                                 int(config.sampling_size), _ptr(labels) if labels.size else None))
     return Components(labels)
@@ -419,7 +419,7 @@ def wcc_afforest_dss(graph: DirectedCsrGraph, config: WccConfig | None = None) -
 
 def wcc_baseline(graph: DirectedCsrGraph, config: WccConfig | None = None) -> Components:
     """wcc_baseline — crates/algos/src/wcc.rs:103-122"""
-    labels = np.empty(graph.node_count(), np.uint32)
+    labels = _result_buffer(graph.node_count(), np.uint32)
     check(lib().gm_wcc_baseline(graph.csr_out.handle, _ptr(labels) if labels.size else None))
     return Components(labels)
 
