@@ -11,9 +11,10 @@
 // Deduplicated layouts alike.
 //
 // Kernels: tc_low_len (per node: |L(u)| by binary search), tc_order (per entry: sortedness / strictness check),
-// tc_dag_src (row id of every DAG entry, filled per node with wavefront help for long lists),
-// tc_count (one lane per DAG entry: walk one prefix, binary-search the other; on strictly
-// increasing lists the shorter prefix is walked).  Integer work, HBM/latency bound: no MFMA.
+// tc_dag (row id and target of every DAG entry, filled per node with wavefront help for long lists),
+// tc_rows (strictly increasing lists: the bit row of L(v) in LDS, the fronts of L(u) of v's upper neighbours
+// streamed against it), tc_count (everything else: a 16-lane group per DAG entry walks one prefix and
+// binary-searches the other).  Integer work, HBM bound: no MFMA.
 #include "common.hpp"
 #include "device_utils.hpp"
 
@@ -131,88 +132,154 @@ __device__ __forceinline__ bool tc_contains(const uint32_t *__restrict__ list, u
     return lo < len && list[lo] == x;
 }
 
-// Triangular adjacency bitmap of the K smallest ids (after make_degree_ordered: the K highest
-// degrees): bit (x, y), y < x < K, is set iff y is in L(x).  Row x starts at bit x(x-1)/2.
-__device__ __forceinline__ uint64_t tc_bit_index(uint32_t x, uint32_t y) { return (uint64_t)x * (x - 1) / 2 + y; }
+// ---- strictly increasing lists: the rows of the adjacency bitmap, one at a time, in LDS ---------------------------
+// triangles = sum over DAG entries (u, v) of |L(u) ∩ L(v)|, and on sets |L(u) ∩ L(v)| = the number of w in L(u),
+// w < v, with w in L(v).  A work item is a node v < K and a stretch of its UPPER neighbours u (the entries of N(v)
+// behind its lower prefix — the undirected CSR is its own transpose): the workgroup builds the bit row of L(v) in LDS
+// (v bits), then 16-lane groups take one u each and stream the front of L(u), 64 entries per step, testing every
+// w < v against the row, until the list passes v.  Every probe lands in LDS and the lists are read as whole 64-byte
+// lines.  (Round 1 probed a 4.3 GB triangular bitmap in HBM, one lane per DAG entry: 43 G probes at scale 24 fetched
+// 761 GB in 32-byte sectors — 150 ms at 5 TB/s.)
+constexpr int TCR_BLOCK = 1024;
+constexpr int TCR_WAVES = TCR_BLOCK / kWave;
+constexpr uint32_t TCR_GROUP = 16;       // lanes per u (general path; tc_rows_kernel: template parameter)
+constexpr uint32_t TCR_K_MAX = 1u << 20; // rows up to 128 KiB of LDS
 
-__global__ void tc_bitmap_fill_kernel(const uint32_t *__restrict__ dag_src, const uint32_t *__restrict__ dag_tgt,
-                                      uint64_t dag_m, uint32_t K, uint32_t *__restrict__ bits)
+// items of row v: ceil(|U(v)| / per_item) when L(v) is not empty (an empty row has no bits to hit)
+__global__ void tc_item_count_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ low_len, uint32_t K,
+                                     uint32_t per_item, uint32_t *__restrict__ items /* K+1 */)
 {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < dag_m; k += stride) {
-        const uint32_t x = dag_src[k], y = dag_tgt[k];
-        if (x < K && y < x) {
-            const uint64_t b = tc_bit_index(x, y);
-            atomicOr(&bits[b >> 5], 1u << (b & 31));
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v <= K; v += stride) {
+        uint32_t c = 0;
+        if (v < K && low_len[v]) {
+            const uint32_t upper = off[v + 1] - off[v] - low_len[v];
+            c = (upper + per_item - 1) / per_item;
         }
+        items[v] = c;
     }
 }
 
-// one lane per DAG entry (u, v): count entries w of L(v) that occur in L(u)
+template <uint32_t GROUP /* lanes per u */, uint32_t MLP /* loads a lane has in flight per step */>
+__global__ __launch_bounds__(TCR_BLOCK) void tc_rows_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt,
+                                                            const uint32_t *__restrict__ low_len,
+                                                            const uint32_t *__restrict__ loff,
+                                                            const uint32_t *__restrict__ dag_tgt,
+                                                            const uint32_t *__restrict__ item_first /* K+1, exclusive scan */,
+                                                            uint32_t K, uint32_t per_item,
+                                                            unsigned long long *__restrict__ total)
+{
+    extern __shared__ uint32_t tc_row[];
+    __shared__ uint64_t red[TCR_WAVES];
+    // the row of this item: the last v with item_first[v] <= item
+    const uint32_t item = blockIdx.x;
+    uint32_t lo = 0, hi = K;
+    while (hi - lo > 1) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (item_first[mid] <= item)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const uint32_t v = lo;
+    const uint32_t words = (v + 31u) >> 5;
+    for (uint32_t i = threadIdx.x; i < words; i += TCR_BLOCK)
+        tc_row[i] = 0u;
+    __syncthreads();
+    const uint32_t lv = loff[v], nv = loff[v + 1] - lv;
+    for (uint32_t i = threadIdx.x; i < nv; i += TCR_BLOCK) {
+        const uint32_t w = dag_tgt[lv + i]; // < v: lists are strictly increasing and hold no self-loop on this path
+        atomicOr(&tc_row[w >> 5], 1u << (w & 31u));
+    }
+    __syncthreads();
+    const uint32_t ubeg = off[v] + low_len[v] + (item - item_first[v]) * per_item;
+    const uint32_t uend = ubeg + per_item < off[v + 1] ? ubeg + per_item : off[v + 1];
+    constexpr uint32_t GROUPS = TCR_BLOCK / GROUP; // u's in flight per workgroup
+    constexpr uint64_t GMASK = GROUP == 64 ? ~0ull : ((1ull << (GROUP & 63)) - 1ull);
+    const uint32_t g = threadIdx.x / GROUP, l = threadIdx.x % GROUP;
+    const uint32_t gshift = (threadIdx.x & (kWave - 1)) / GROUP * GROUP; // this group's bits of a wavefront ballot
+    uint32_t count = 0;
+    for (uint32_t j0 = ubeg; j0 < uend; j0 += GROUPS) {
+        const uint32_t j = j0 + g;
+        uint32_t lu = 0, ne = 0;
+        if (j < uend) {
+            const uint32_t u = tgt[j];
+            lu = loff[u];
+            ne = loff[u + 1] - lu;
+            ne = ne < v ? ne : v; // at most v entries of a strictly increasing list are below v
+        }
+        uint32_t cur = 0;
+        bool go = ne != 0;
+        while (__ballot(go)) {
+            uint32_t w[MLP];
+#pragma unroll
+            for (uint32_t q = 0; q < MLP; ++q) {
+                const uint32_t i = cur + q * GROUP + l;
+                w[q] = (go && i < ne) ? dag_tgt[lu + i] : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (uint32_t q = 0; q < MLP; ++q)
+                if (w[q] < v)
+                    count += (tc_row[w[q] >> 5] >> (w[q] & 31u)) & 1u;
+            // ascending lists: once the last entry of the step is >= v (or past the end) the list is done
+            const uint64_t past = __ballot(w[MLP - 1] >= v);
+            go = go && ((past >> gshift) & GMASK) == 0;
+            cur += MLP * GROUP;
+        }
+    }
+    const uint64_t block_total = block_sum<uint64_t, TCR_WAVES>((uint64_t)count, red);
+    if (threadIdx.x == 0 && block_total)
+        atomicAdd(total, (unsigned long long)block_total);
+}
+
+// The general path: count the entries w of L(v) that occur in L(u), by binary search.  A wavefront looks at 64 DAG
+// entries at a time and hands the ones it has to do (all of them; on strictly increasing lists only those with
+// v >= skip_below, the rest belong to tc_rows_kernel) to its four 16-lane groups: every lane takes one element of
+// the walked prefix and searches the other prefix.  (One lane per entry walking its prefix alone was nwalk x log2
+// dependent loads per entry: 50 ms for the 8 % of the scale-24 entries beyond the bitmap rows.)  On sets the
+// intersection is symmetric and the shorter prefix is walked.
 template <bool STRICT>
 __global__ __launch_bounds__(TC_BLOCK) void tc_count_kernel(const uint32_t *__restrict__ loff,
                                                             const uint32_t *__restrict__ dag_src,
                                                             const uint32_t *__restrict__ dag_tgt, uint64_t dag_m,
-                                                            const uint32_t *__restrict__ bits, uint32_t K,
-                                                            unsigned long long *__restrict__ total)
+                                                            uint32_t skip_below, unsigned long long *__restrict__ total)
 {
     __shared__ uint64_t red[TC_WAVES];
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t gi = lane / TCR_GROUP, l = lane % TCR_GROUP;
     const uint64_t dag_pad = (dag_m + kWave - 1) / kWave * kWave; // whole wavefronts iterate together
     uint64_t count = 0;
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < dag_pad; k += stride) {
         const bool live = k < dag_m;
-        const uint32_t u = live ? dag_src[k] : 0u, v = live ? dag_tgt[k] : 0u;
-        bool handled = !live;
-        if (STRICT) {
-            // lists are sets: |L(u) ∩ L(v)| = number of w in L(u), w < v, with bit (v, w) set; the w < v are
-            // exactly the entries of L(u) in front of this one — one load per candidate, no search.
-            // Short prefixes by the owning lane, long ones spread over the wavefront.
-            const bool bitmap = live && v < K && v < u;
-            const uint32_t lo_u = bitmap ? loff[u] : 0u;
-            const uint32_t rank = bitmap ? (uint32_t)(k - lo_u) : 0u;
-            const uint64_t row = (uint64_t)v * (v ? v - 1 : 0) / 2;
-            if (bitmap && rank <= 64) {
-                const uint32_t *lu = dag_tgt + lo_u;
-                uint32_t c = 0;
-                for (uint32_t i = 0; i < rank; ++i) {
-                    const uint64_t b = row + lu[i];
-                    c += (bits[b >> 5] >> (b & 31)) & 1u;
-                }
-                count += c;
+        const uint32_t v = live ? dag_tgt[k] : 0u;
+        uint64_t todo = __ballot(live && !(STRICT && v < skip_below));
+        while (todo) {
+            // the (gi+1)-th entry still to do is this group's
+            uint64_t rest = todo;
+            for (uint32_t t = 0; t < gi; ++t)
+                rest &= rest - 1;
+            const int src = rest ? __ffsll((unsigned long long)rest) - 1 : -1;
+            for (int t = 0; t < 4 && todo; ++t)
+                todo &= todo - 1;
+            const uint32_t ev = __shfl(v, src < 0 ? 0 : src, kWave);
+            if (src < 0)
+                continue;
+            const uint32_t eu = dag_src[k - lane + (uint32_t)src];
+            const uint32_t *lu = dag_tgt + loff[eu];
+            const uint32_t *lv = dag_tgt + loff[ev];
+            const uint32_t nu = loff[eu + 1] - loff[eu], nv = loff[ev + 1] - loff[ev];
+            const uint32_t *walk = lv, *probe = lu;
+            uint32_t nwalk = nv, nprobe = nu;
+            if (STRICT && nu < nv) {
+                walk = lu;
+                probe = lv;
+                nwalk = nu;
+                nprobe = nv;
             }
-            uint64_t big = __ballot(bitmap && rank > 64);
-            while (big) {
-                const int src = __ffsll((unsigned long long)big) - 1;
-                big &= big - 1;
-                const uint32_t b_lo = __shfl(lo_u, src, kWave), b_rank = __shfl(rank, src, kWave);
-                const uint64_t b_row = __shfl(row, src, kWave);
-                const uint32_t *lu = dag_tgt + b_lo;
-                uint32_t c = 0;
-                for (uint32_t i = lane; i < b_rank; i += kWave) {
-                    const uint64_t b = b_row + lu[i];
-                    c += (bits[b >> 5] >> (b & 31)) & 1u;
-                }
-                count += c; // the total is a plain sum: any lane may carry any part of it
-            }
-            handled = handled || bitmap;
+            for (uint32_t i = l; i < nwalk; i += TCR_GROUP)
+                count += tc_contains(probe, nprobe, walk[i]) ? 1u : 0u;
         }
-        if (handled)
-            continue;
-        const uint32_t *lu = dag_tgt + loff[u];
-        const uint32_t *lv = dag_tgt + loff[v];
-        uint32_t nu = loff[u + 1] - loff[u], nv = loff[v + 1] - loff[v];
-        const uint32_t *walk = lv, *probe = lu;
-        uint32_t nwalk = nv, nprobe = nu;
-        if (STRICT && nu < nv) { // both are sets: the intersection is symmetric, walk the shorter
-            walk = lu;
-            probe = lv;
-            nwalk = nu;
-            nprobe = nv;
-        }
-        for (uint32_t i = 0; i < nwalk; ++i)
-            count += tc_contains(probe, nprobe, walk[i]) ? 1u : 0u;
     }
     const uint64_t block_total = block_sum<uint64_t, TC_WAVES>(count, red);
     if (threadIdx.x == 0 && block_total)
@@ -279,38 +346,70 @@ GM_API int gm_triangle_count(const gm_csr *g, uint64_t *triangles_out)
     unsigned long long *d_total = reinterpret_cast<unsigned long long *>(ctrl.p);
     if (flags & 2u) {
         hipLaunchKernelGGL(tc_count_kernel<false>, dim3(cgrid), dim3(TC_BLOCK), 0, 0, loff.as<uint32_t>(),
-                           dag_src.as<uint32_t>(), dag_tgt.as<uint32_t>(), (uint64_t)dag_m, (const uint32_t *)nullptr, 0u,
-                           d_total);
+                           dag_src.as<uint32_t>(), dag_tgt.as<uint32_t>(), (uint64_t)dag_m, 0u, d_total);
     } else {
-        // strictly increasing lists: membership in the prefix lists of the K smallest ids through a
-        // triangular bitmap (K = 262144 -> 4.3 GB of the 288 GB; GM_TC_K overrides, 0 disables)
-        uint32_t K = n < (1u << 18) ? n : (1u << 18);
-        if (const char *e = getenv("GM_TC_K"))
-            K = (uint32_t)atoll(e) < n ? (uint32_t)atoll(e) : n;
-        gm::DevBuf bits;
-        // the bitmap is an accelerator, not a requirement: when HBM is short (a graph that already fills the
-        // card, a shared node) halve K until it fits, down to the search-only path
-        while (K >= 2) {
-            const uint64_t nbits = (uint64_t)K * (K - 1) / 2;
-            if (bits.alloc((size_t)((nbits + 31) / 32 + 1) * 4) == GM_OK)
-                break;
-            (void)hipGetLastError();
-            K /= 2;
+        // strictly increasing lists: rows v < K by tc_rows_kernel (bit row of L(v) in LDS), the rest by search.
+        // GM_TC_K overrides K (0: search only), GM_TC_ITEM the upper neighbours per work item.
+        // K = 2^19: 64 KiB rows, two workgroups = 32 wavefronts per CU (2^20 halves the occupancy: 100 vs 54 ms at scale 24)
+        uint32_t K = n < (1u << 19) ? n : (1u << 19);
+        if (const char *e = getenv("GM_TC_K")) {
+            const uint32_t cap = n < TCR_K_MAX ? n : TCR_K_MAX;
+            K = (uint32_t)atoll(e) < cap ? (uint32_t)atoll(e) : cap;
         }
-        if (K >= 2) {
-            const uint64_t nbits = (uint64_t)K * (K - 1) / 2;
-            const size_t words = (size_t)((nbits + 31) / 32) + 1;
-            GM_HIP(hipMemset(bits.p, 0, words * 4));
-            hipLaunchKernelGGL(tc_bitmap_fill_kernel, dim3(cgrid), dim3(TC_BLOCK), 0, 0, dag_src.as<uint32_t>(),
-                               dag_tgt.as<uint32_t>(), (uint64_t)dag_m, K, bits.as<uint32_t>());
-        } else {
-            K = 0;
+        uint32_t per_item = 4096;
+        if (const char *e = getenv("GM_TC_ITEM"))
+            if (atoll(e) >= 64)
+                per_item = (uint32_t)atoll(e);
+        uint32_t n_items = 0;
+        gm::DevBuf items, item_first;
+        if (K) {
+            GM_TRY(items.alloc(((size_t)K + 1) * 4));
+            GM_TRY(item_first.alloc(((size_t)K + 1) * 4));
+            hipLaunchKernelGGL(tc_item_count_kernel, dim3(gm::div_up((uint64_t)K + 1, 256)), dim3(256), 0, 0, g->offsets,
+                               low_len.as<uint32_t>(), K, per_item, items.as<uint32_t>());
+            size_t tmp_bytes = 0;
+            GM_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, items.as<uint32_t>(), item_first.as<uint32_t>(), 0u,
+                                           (size_t)K + 1, rocprim::plus<uint32_t>(), (hipStream_t)0));
+            gm::DevBuf tmp;
+            GM_TRY(tmp.alloc(tmp_bytes));
+            GM_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, items.as<uint32_t>(), item_first.as<uint32_t>(), 0u,
+                                           (size_t)K + 1, rocprim::plus<uint32_t>(), (hipStream_t)0));
+            GM_HIP(hipMemcpy(&n_items, item_first.as<uint32_t>() + K, 4, hipMemcpyDeviceToHost));
+        }
+        if (n_items) {
+            // GM_TC_SHAPE="<lanes per u>,<loads in flight>" picks another instantiation (measurements)
+            int shape_g = 16, shape_m = 4;
+            if (const char *e = getenv("GM_TC_SHAPE"))
+                (void)sscanf(e, "%d,%d", &shape_g, &shape_m);
+            const size_t lds = (size_t)((K + 31u) / 32u) * 4;
+#define GM_TC_ROWS(G_, M_)                                                                                              \
+    do {                                                                                                                \
+        GM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tc_rows_kernel<G_, M_>),                             \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, TCR_K_MAX / 8));                         \
+        hipLaunchKernelGGL((tc_rows_kernel<G_, M_>), dim3(n_items), dim3(TCR_BLOCK), lds, 0, g->offsets, g->targets,    \
+                           low_len.as<uint32_t>(), loff.as<uint32_t>(), dag_tgt.as<uint32_t>(),                         \
+                           item_first.as<uint32_t>(), K, per_item, d_total);                                            \
+    } while (0)
+            if (shape_g == 8 && shape_m == 4)
+                GM_TC_ROWS(8, 4);
+            else if (shape_g == 16 && shape_m == 2)
+                GM_TC_ROWS(16, 2);
+            else if (shape_g == 16 && shape_m == 8)
+                GM_TC_ROWS(16, 8);
+            else if (shape_g == 32 && shape_m == 2)
+                GM_TC_ROWS(32, 2);
+            else if (shape_g == 32 && shape_m == 4)
+                GM_TC_ROWS(32, 4);
+            else if (shape_g == 64 && shape_m == 2)
+                GM_TC_ROWS(64, 2);
+            else
+                GM_TC_ROWS(16, 4);
+#undef GM_TC_ROWS
         }
         hipLaunchKernelGGL(tc_count_kernel<true>, dim3(cgrid), dim3(TC_BLOCK), 0, 0, loff.as<uint32_t>(),
-                           dag_src.as<uint32_t>(), dag_tgt.as<uint32_t>(), (uint64_t)dag_m,
-                           K ? bits.as<uint32_t>() : (const uint32_t *)nullptr, K, d_total);
+                           dag_src.as<uint32_t>(), dag_tgt.as<uint32_t>(), (uint64_t)dag_m, K, d_total);
         GM_HIP(hipGetLastError());
-        GM_HIP(hipDeviceSynchronize()); // bits is released on scope exit
+        GM_HIP(hipDeviceSynchronize()); // the item tables are released on scope exit
     }
     GM_HIP(hipGetLastError());
     unsigned long long total = 0;

@@ -509,6 +509,28 @@ def test_triangle_count_vs_oracle(P, oracle, layout, relabel):
     assert P.global_triangle_count(ug) == oracle.triangle_count(off, tgt, threads=8)
 
 
+@pytest.mark.parametrize("knobs", [{"GM_TC_K": "0"}, {"GM_TC_K": "1"}, {"GM_TC_K": "100"}, {"GM_TC_K": "5000", "GM_TC_ITEM": "64"},
+                                   {"GM_TC_ITEM": "100000"}, {"GM_TC_SHAPE": "8,4"}, {"GM_TC_SHAPE": "16,8"},
+                                   {"GM_TC_SHAPE": "32,2", "GM_TC_K": "3000"}, {"GM_TC_SHAPE": "64,2", "GM_TC_ITEM": "256"}])
+@pytest.mark.parametrize("relabel", [False, True])
+def test_triangle_count_row_kernel_knobs(P, oracle, monkeypatch, knobs, relabel):
+    """Strictly increasing lists: rows v < K are counted against their bit row in LDS by 16-lane groups, the rest by
+    cooperative binary search.  The split (K), the upper neighbours per work item and the group shape only move
+    work around: the count is the oracle's, relabelled or not (un-relabelled, hub ids are anywhere: long lists on
+    both sides of K)."""
+    s, d = oracle.rmat_edges(14, seed=9)
+    n = 1 << 14
+    off, tgt = oracle.csr_build(n, s, d, oracle.UNDIRECTED, oracle.DEDUPLICATED)
+    ug = P.UndirectedCsrGraph(P.DeviceCsr.from_edges(n, s, d, None, 2, 2), 2)
+    if relabel:
+        off, tgt, _ = oracle.relabel_by_degree(off, tgt)
+        P.relabel_graph(ug)
+    want = oracle.triangle_count(off, tgt, threads=8)
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    assert P.global_triangle_count(ug) == want
+
+
 # ------------------------------------------------------------------------------------------------
 # PageRank: propagation-blocking engine (exact fixed-point row sums) and the partitioned path
 # ------------------------------------------------------------------------------------------------

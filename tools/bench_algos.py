@@ -9,7 +9,8 @@ fraction, and the oracle's time on this box's host cores as cpu_baseline.  One J
 Byte models (u32 ids, f32 weights / distances):
     WCC   4(n+1) + 4(m_out + m_in) + 8n                 both CSRs once + parent init / write-back
     SSSP  12 B x relaxed edges + 4 B x reached nodes    relaxed edges = out-edges of reached nodes, each counted once
-    TC    4 B x sum over DAG entries (u, v), v < u, of (rank of v in L(u) + |L(v)|)   the merge streams
+    TC    4 B x wedges + 4 B x CSR entries + 8n   wedges = sum over DAG entries (u, v), v < u, of the rank of v in L(u);
+          SURVEY 8(d)'s merge model (rank + |L(v)| per entry) is reported beside it
 `roofline.frac` uses the wall time of the whole call (allocation, scheduling and the result download
 included) — the kernel-only sums are in profiles/r02_algos_kernel_stats.txt.
 """
@@ -172,17 +173,29 @@ def main():
                "nodes": n, "undirected_entries": ug.csr.m, "build_s": t_build, "relabel_s": t_relabel, "ms": t_tc * 1e3,
                "triangles": tri, "edges_per_s": ug.csr.m / 2 / t_tc, "triangles_per_s": tri / t_tc}
         off, tgt, _ = ug.csr.host()
-        # merge-stream bytes: for every entry v < u of N(u): rank of v in N(u) + |{w in N(v): w < v}|
+        # SURVEY 8(d)'s merge-stream model: for every entry v < u of N(u): (rank of v in L(u)) + |L(v)| elements.
+        # The device algorithm (bit row of L(v) in LDS, fronts of L(u) streamed) only needs the first term — the
+        # wedges — plus one pass over the lists that name the pairs.
         d_off = torch.from_numpy(off.astype(np.int64)).cuda()
         d_tgt = torch.from_numpy(tgt.astype(np.int64)).cuda()
         rows = torch.repeat_interleave(torch.arange(n, device="cuda"), d_off[1:] - d_off[:-1])
         lower = d_tgt < rows
         low_len = torch.zeros(n, dtype=torch.int64, device="cuda").index_add_(0, rows[lower], torch.ones_like(rows[lower]))
         pos = torch.arange(d_tgt.numel(), device="cuda") - d_off[rows]
-        stream = int((pos[lower] + low_len[d_tgt[lower]]).sum().item())
+        wedges = int(pos[lower].sum().item())
+        other = int(low_len[d_tgt[lower]].sum().item())
+        dag_entries = int(lower.sum().item())
         del d_off, d_tgt, rows, lower, low_len, pos
         torch.cuda.empty_cache()
-        rec["roofline"] = roofline(4 * stream, t_tc)
+        rec["wedges"] = wedges
+        rec["roofline"] = roofline(4 * wedges + 4 * ug.csr.m + 8 * n, t_tc)
+        rec["roofline"]["bytes_model"] = ("4 B x wedges (sum over DAG entries (u, v) of the rank of v in L(u): the fronts of L(u) "
+                                          "streamed against the bit row of L(v)) + 4 B x CSR entries + 8 B x nodes")
+        rec["roofline"]["survey_merge_model"] = {"bytes": 4 * (wedges + other),
+                                                 "achieved_GBps": round(4 * (wedges + other) / t_tc / 1e9, 1),
+                                                 "note": "SURVEY 8(d): 4 B x sum (rank of v in L(u) + |L(v)|), the two streams of "
+                                                         "the reference's sorted merge; the second term is not read here"}
+        rec["dag_entries"] = dag_entries
         if O is not None:
             t = time.perf_counter()
             ref = O.triangle_count(off, tgt, cores, native=True)
