@@ -247,6 +247,10 @@ int gm_wcc_link_rows(const gm_csr *out_rows, const gm_csr *in_rows, uint64_t row
  * SSSP — replaces delta_stepping(&G, DeltaSteppingConfig{start_node, delta}) -> Vec<AtomicF32>,
  * crates/algos/src/sssp.rs:38-102.  `out_csr` must carry weights (>= 0).  Unreachable nodes get
  * f32::MAX (sssp.rs:12), not inf.  start_node >= n -> GM_ERR_RANGE (the reference panics, :52).
+ * distances_out: n floats in host memory (page-locked memory takes the copy at link speed) or in device
+ * memory.  The handle keeps the call's working buffers (~9 bytes per node + 0.3 bytes per edge) for the
+ * next call and remembers that its weights passed the >= 0 / not-NaN check; the arrays of a wrapped CSR
+ * must not change while the handle lives (the same rule as for PageRank's cached plan).
  * ------------------------------------------------------------------------------------------- */
 int gm_sssp_delta_stepping(const gm_csr *out_csr, uint64_t start_node, float delta, float *distances_out);
 /* Partitioned run (distances replicated on every GPU as u32 bit patterns of non-negative f32, so an
