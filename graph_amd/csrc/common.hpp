@@ -169,6 +169,10 @@ struct PbPlan; // propagation-blocking layout of a CSR (pagerank_pb.hip); immuta
 // Working buffers of one gm_sssp_delta_stepping call (sssp.hip).  A call takes the set parked in the CSR handle (or
 // allocates one) and parks it again when it returns: hipMalloc / hipFree of ~200 MB cost more than a millisecond
 // each and a graph is usually queried from many start nodes.
+struct WccScratch {
+    DevBuf work;   // chunk count + chunk items + sample buffer (wcc.hip:wcc_device)
+    DevBuf labels; // u32[n] of gm_wcc_afforest / gm_wcc_baseline
+};
 struct SsspScratch {
     DevBuf dist, flags, wmin, hflags, ctrl, chunks, queues;
     PinnedBuf hctrl;
@@ -193,5 +197,6 @@ struct gm_csr {
     mutable std::atomic<uint64_t> page_rank_calls{0}; // gm_page_rank calls seen by this handle (engine choice); calls may run concurrently
     mutable std::atomic<int> weights_ok{0};                // 1: gm_sssp_delta_stepping has seen that no weight is negative or NaN
     mutable std::unique_ptr<gm::SsspScratch> sssp_scratch; // parked between calls (under cache_mu)
+    mutable std::unique_ptr<gm::WccScratch> wcc_scratch;   // likewise
     mutable std::atomic<int> long_rows{-1};           // 1: some row has >= GM_PB_HUB_DEG entries (-1: not looked at yet)
 };

@@ -21,6 +21,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include <cstdlib>
+#include <vector>
 
 namespace {
 
@@ -28,6 +29,8 @@ using namespace gm;
 
 constexpr int TC_BLOCK = 256;
 constexpr int TC_WAVES = TC_BLOCK / kWave;
+constexpr uint32_t TC_SHORT_IDS = 65536; // ids below this are also stored in two bytes (dag16)
+constexpr uint32_t TC_SHORT_PAD = 4;     // every list's 2-byte front starts on an 8-byte boundary
 
 // Per node: |L(u)| by binary search, and a mark on the first entry of its list (row_start bitmap) so
 // that the order check below can run one lane per ENTRY: checking a 600k-entry hub list with the one
@@ -35,6 +38,7 @@ constexpr int TC_WAVES = TC_BLOCK / kWave;
 __global__ __launch_bounds__(TC_BLOCK) void tc_low_len_kernel(const uint32_t *__restrict__ off,
                                                               const uint32_t *__restrict__ tgt, uint32_t n,
                                                               uint32_t *__restrict__ low_len /* n+1 */,
+                                                              uint32_t *__restrict__ short_len /* n+1 */,
                                                               uint32_t *__restrict__ row_start /* bit per entry */,
                                                               uint32_t *__restrict__ flags)
 {
@@ -42,6 +46,7 @@ __global__ __launch_bounds__(TC_BLOCK) void tc_low_len_kernel(const uint32_t *__
     for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u <= n; u += stride) {
         if (u == n) {
             low_len[u] = 0;
+            short_len[u] = 0;
             continue;
         }
         const uint32_t s = off[u], e = off[u + 1];
@@ -54,6 +59,20 @@ __global__ __launch_bounds__(TC_BLOCK) void tc_low_len_kernel(const uint32_t *__
                 hi = mid;
         }
         low_len[u] = lo - s;
+        // how many of them are below TC_SHORT_IDS (a front of the list): those are also kept as 2-byte ids
+        uint32_t lo16 = lo;
+        if (u >= TC_SHORT_IDS) {
+            uint32_t a = s, b = lo; // first position with tgt >= TC_SHORT_IDS
+            while (a < b) {
+                const uint32_t mid = a + ((b - a) >> 1);
+                if (tgt[mid] < TC_SHORT_IDS)
+                    a = mid + 1;
+                else
+                    b = mid;
+            }
+            lo16 = a;
+        }
+        short_len[u] = lo16 - s;
         // a self-loop entry (u in N(u)) takes part in the put-back walk as v == u and as w == v; the bitmap
         // path counts only w < v < u, so lists with a self-loop take the general path (flag 2), like lists
         // with duplicates (an undirected build doubles self-loops; an uploaded CSR may hold a single one)
@@ -82,38 +101,77 @@ __global__ __launch_bounds__(TC_BLOCK) void tc_order_kernel(const uint32_t *__re
         atomicOr(flags, f);
 }
 
-// dag_src[k] = u for k in [loff[u], loff[u+1]); dag_tgt[k] = the k-th lower-prefix entry
+__global__ void tc_short_pad_kernel(const uint32_t *__restrict__ short_len, uint32_t n, uint32_t *__restrict__ padded)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u <= n; u += stride)
+        padded[u] = u == n ? 0u : ((short_len[u] + TC_SHORT_PAD - 1u) & ~(TC_SHORT_PAD - 1u));
+}
+
+// everything tc_rows_kernel needs to know about L(u) in one 16-byte load:
+// {first DAG entry, |L(u)|, first 2-byte entry, number of entries below TC_SHORT_IDS}
+__global__ void tc_meta_kernel(const uint32_t *__restrict__ loff, const uint32_t *__restrict__ low_len,
+                               const uint32_t *__restrict__ loff16, const uint32_t *__restrict__ short_len, uint32_t n,
+                               uint4 *__restrict__ meta)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += stride)
+        meta[u] = make_uint4(loff[u], low_len[u], loff16[u], short_len[u]);
+}
+
+// dag_src[k] = u for k in [loff[u], loff[u+1]); dag_tgt[k] = the k-th lower-prefix entry; dag16 = the entries below
+// TC_SHORT_IDS once more, as 2-byte ids (padding: 0xFFFF, never counted — the reader knows the length)
 __global__ __launch_bounds__(TC_BLOCK) void tc_dag_kernel(const uint32_t *__restrict__ off,
                                                           const uint32_t *__restrict__ tgt,
-                                                          const uint32_t *__restrict__ loff, uint32_t n,
-                                                          uint32_t *__restrict__ dag_src, uint32_t *__restrict__ dag_tgt)
+                                                          const uint32_t *__restrict__ loff,
+                                                          const uint32_t *__restrict__ loff16,
+                                                          const uint32_t *__restrict__ short_len, uint32_t n,
+                                                          uint32_t *__restrict__ dag_src, uint32_t *__restrict__ dag_tgt,
+                                                          uint16_t *__restrict__ dag16)
 {
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t n_pad = (n + kWave - 1) / kWave * kWave;
     for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n_pad; u += stride) {
-        uint32_t ls = 0, le = 0, s = 0;
+        uint32_t ls = 0, le = 0, s = 0, s16 = 0, n16 = 0, p16 = 0;
         if (u < n) {
             ls = loff[u];
             le = loff[u + 1];
             s = off[u];
+            if (dag16) {
+                s16 = loff16[u];
+                n16 = short_len[u];
+                p16 = loff16[u + 1] - s16;
+            }
         }
         const uint32_t len = le - ls;
-        if (len <= 32)
+        if (len <= 32) {
             for (uint32_t i = 0; i < len; ++i) {
+                const uint32_t t = tgt[s + i];
                 dag_src[ls + i] = u;
-                dag_tgt[ls + i] = tgt[s + i];
+                dag_tgt[ls + i] = t;
+                if (i < n16)
+                    dag16[s16 + i] = (uint16_t)t;
             }
+            for (uint32_t i = n16; i < p16; ++i)
+                dag16[s16 + i] = 0xFFFFu;
+        }
         uint64_t big = __ballot(len > 32);
         while (big) {
             const int src = __ffsll((unsigned long long)big) - 1;
             big &= big - 1;
             const uint32_t bu = __shfl(u, src, kWave), bls = __shfl(ls, src, kWave), ble = __shfl(le, src, kWave),
-                           bs = __shfl(s, src, kWave);
+                           bs = __shfl(s, src, kWave), b16 = __shfl(s16, src, kWave), bn16 = __shfl(n16, src, kWave),
+                           bp16 = __shfl(p16, src, kWave);
             for (uint32_t i = lane; i < ble - bls; i += kWave) {
+                const uint32_t t = tgt[bs + i];
                 dag_src[bls + i] = bu;
-                dag_tgt[bls + i] = tgt[bs + i];
+                dag_tgt[bls + i] = t;
+                if (i < bn16)
+                    dag16[b16 + i] = (uint16_t)t;
             }
+            for (uint32_t i = bn16 + lane; i < bp16; i += kWave)
+                dag16[b16 + i] = 0xFFFFu;
         }
     }
 }
@@ -140,8 +198,6 @@ __device__ __forceinline__ bool tc_contains(const uint32_t *__restrict__ list, u
 // w < v against the row, until the list passes v.  Every probe lands in LDS and the lists are read as whole 64-byte
 // lines.  (Round 1 probed a 4.3 GB triangular bitmap in HBM, one lane per DAG entry: 43 G probes at scale 24 fetched
 // 761 GB in 32-byte sectors — 150 ms at 5 TB/s.)
-constexpr int TCR_BLOCK = 1024;
-constexpr int TCR_WAVES = TCR_BLOCK / kWave;
 constexpr uint32_t TCR_GROUP = 16;       // lanes per u (general path; tc_rows_kernel: template parameter)
 constexpr uint32_t TCR_K_MAX = 1u << 20; // rows up to 128 KiB of LDS
 
@@ -160,20 +216,23 @@ __global__ void tc_item_count_kernel(const uint32_t *__restrict__ off, const uin
     }
 }
 
-template <uint32_t GROUP /* lanes per u */, uint32_t MLP /* loads a lane has in flight per step */>
-__global__ __launch_bounds__(TCR_BLOCK) void tc_rows_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt,
+template <int BLOCK /* threads per work item */, uint32_t GROUP /* lanes per u */, uint32_t MLP /* loads in flight per lane */>
+__global__ __launch_bounds__(BLOCK) void tc_rows_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt,
                                                             const uint32_t *__restrict__ low_len,
                                                             const uint32_t *__restrict__ loff,
+                                                            const uint4 *__restrict__ meta,
                                                             const uint32_t *__restrict__ dag_tgt,
+                                                            const uint16_t *__restrict__ dag16,
                                                             const uint32_t *__restrict__ item_first /* K+1, exclusive scan */,
-                                                            uint32_t K, uint32_t per_item,
-                                                            unsigned long long *__restrict__ total)
+                                                            uint32_t v_lo, uint32_t v_hi /* rows of this launch */,
+                                                            uint32_t per_item, unsigned long long *__restrict__ total)
 {
     extern __shared__ uint32_t tc_row[];
-    __shared__ uint64_t red[TCR_WAVES];
+    __shared__ uint64_t red[BLOCK / kWave];
+    constexpr int TCR_BLOCK = BLOCK;
     // the row of this item: the last v with item_first[v] <= item
-    const uint32_t item = blockIdx.x;
-    uint32_t lo = 0, hi = K;
+    const uint32_t item = item_first[v_lo] + blockIdx.x;
+    uint32_t lo = v_lo, hi = v_hi;
     while (hi - lo > 1) {
         const uint32_t mid = lo + ((hi - lo) >> 1);
         if (item_first[mid] <= item)
@@ -196,38 +255,92 @@ __global__ __launch_bounds__(TCR_BLOCK) void tc_rows_kernel(const uint32_t *__re
     const uint32_t uend = ubeg + per_item < off[v + 1] ? ubeg + per_item : off[v + 1];
     constexpr uint32_t GROUPS = TCR_BLOCK / GROUP; // u's in flight per workgroup
     constexpr uint64_t GMASK = GROUP == 64 ? ~0ull : ((1ull << (GROUP & 63)) - 1ull);
+    constexpr uint32_t MLP16 = MLP > 1 ? MLP / 2 : 1; // 8-byte loads of four 2-byte ids
     const uint32_t g = threadIdx.x / GROUP, l = threadIdx.x % GROUP;
     const uint32_t gshift = (threadIdx.x & (kWave - 1)) / GROUP * GROUP; // this group's bits of a wavefront ballot
     uint32_t count = 0;
-    for (uint32_t j0 = ubeg; j0 < uend; j0 += GROUPS) {
-        const uint32_t j = j0 + g;
-        uint32_t lu = 0, ne = 0;
-        if (j < uend) {
-            const uint32_t u = tgt[j];
-            lu = loff[u];
-            ne = loff[u + 1] - lu;
-            ne = ne < v ? ne : v; // at most v entries of a strictly increasing list are below v
-        }
-        uint32_t cur = 0;
-        bool go = ne != 0;
-        while (__ballot(go)) {
-            uint32_t w[MLP];
+    // four bits of a packed load against the row: entries base .. base + 3 of a 2-byte front of `lim` entries
+    auto probe4 = [&](unsigned long long pk, uint32_t base, uint32_t lim, bool &over) {
 #pragma unroll
-            for (uint32_t q = 0; q < MLP; ++q) {
-                const uint32_t i = cur + q * GROUP + l;
-                w[q] = (go && i < ne) ? dag_tgt[lu + i] : 0xFFFFFFFFu;
+        for (uint32_t e = 0; e < 4u; ++e) {
+            const uint32_t w = (uint32_t)(pk >> (16u * e)) & 0xFFFFu;
+            if (base + e < lim) {
+                if (w < v)
+                    count += (tc_row[w >> 5] >> (w & 31u)) & 1u;
+                else
+                    over = true;
             }
+        }
+    };
+    constexpr uint32_t UB = 4; // u's a group has in flight: id -> list header -> first line are three dependent round
+                               // trips, and one u at a time left the kernel waiting on them (4.5 us per u and group)
+    for (uint32_t j0 = ubeg; j0 < uend; j0 += GROUPS * UB) {
+        uint32_t uid[UB];
+        uint4 mt[UB]; // {first DAG entry, |L(u)|, first 2-byte entry, entries below TC_SHORT_IDS}
+        unsigned long long first[UB];
 #pragma unroll
-            for (uint32_t q = 0; q < MLP; ++q)
-                if (w[q] < v)
-                    count += (tc_row[w[q] >> 5] >> (w[q] & 31u)) & 1u;
-            // ascending lists: once the last entry of the step is >= v (or past the end) the list is done
-            const uint64_t past = __ballot(w[MLP - 1] >= v);
-            go = go && ((past >> gshift) & GMASK) == 0;
-            cur += MLP * GROUP;
+        for (uint32_t t = 0; t < UB; ++t) {
+            const uint32_t j = j0 + t * GROUPS + g;
+            uid[t] = j < uend ? tgt[j] : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (uint32_t t = 0; t < UB; ++t)
+            mt[t] = uid[t] != 0xFFFFFFFFu ? meta[uid[t]] : make_uint4(0u, 0u, 0u, 0u);
+        // the front of a list as 2-byte ids: half the bytes for the entries that are streamed most often (ids below
+        // 65536 are 94 % of the stream at scale 24 after make_degree_ordered); the first 128-byte line of each list
+#pragma unroll
+        for (uint32_t t = 0; t < UB; ++t) {
+            const uint32_t lim16 = mt[t].w < v ? mt[t].w : v; // at most v entries of an increasing list are below v
+            first[t] = l * 4u < lim16 ? *reinterpret_cast<const unsigned long long *>(dag16 + mt[t].z + l * 4u) : ~0ull;
+        }
+#pragma unroll
+        for (uint32_t t = 0; t < UB; ++t) {
+            const uint32_t lim16 = mt[t].w < v ? mt[t].w : v;
+            bool over = false;
+            probe4(first[t], l * 4u, lim16, over);
+            bool passed = ((__ballot(over) >> gshift) & GMASK) != 0; // an entry >= v was seen: the list is done
+            uint32_t cur = GROUP * 4u;
+            bool go = !passed && cur < lim16;
+            while (__ballot(go)) { // the rest of a long front, MLP16 lines per step
+                unsigned long long pk[MLP16];
+#pragma unroll
+                for (uint32_t q = 0; q < MLP16; ++q) {
+                    const uint32_t base = cur + (q * GROUP + l) * 4u;
+                    pk[q] = (go && base < lim16) ? *reinterpret_cast<const unsigned long long *>(dag16 + mt[t].z + base) : ~0ull;
+                }
+                bool more_over = false;
+#pragma unroll
+                for (uint32_t q = 0; q < MLP16; ++q)
+                    if (go)
+                        probe4(pk[q], cur + (q * GROUP + l) * 4u, lim16, more_over);
+                const bool grp_over = ((__ballot(more_over) >> gshift) & GMASK) != 0;
+                passed = passed || grp_over;
+                cur += MLP16 * GROUP * 4u;
+                go = go && !grp_over && cur < lim16;
+            }
+            // what is left of the list: the entries from TC_SHORT_IDS up, 4-byte ids — only rows beyond TC_SHORT_IDS get here
+            const uint32_t ne = mt[t].y < v ? mt[t].y : v;
+            cur = mt[t].w;
+            go = !passed && v > TC_SHORT_IDS && lim16 == mt[t].w && cur < ne;
+            while (__ballot(go)) {
+                uint32_t w[MLP];
+#pragma unroll
+                for (uint32_t q = 0; q < MLP; ++q) {
+                    const uint32_t i = cur + q * GROUP + l;
+                    w[q] = (go && i < ne) ? dag_tgt[mt[t].x + i] : 0xFFFFFFFFu;
+                }
+#pragma unroll
+                for (uint32_t q = 0; q < MLP; ++q)
+                    if (w[q] < v)
+                        count += (tc_row[w[q] >> 5] >> (w[q] & 31u)) & 1u;
+                // ascending lists: once the last entry of the step is >= v (or past the end) the list is done
+                const uint64_t past = __ballot(w[MLP - 1] >= v);
+                go = go && ((past >> gshift) & GMASK) == 0;
+                cur += MLP * GROUP;
+            }
         }
     }
-    const uint64_t block_total = block_sum<uint64_t, TCR_WAVES>((uint64_t)count, red);
+    const uint64_t block_total = block_sum<uint64_t, BLOCK / kWave>((uint64_t)count, red);
     if (threadIdx.x == 0 && block_total)
         atomicAdd(total, (unsigned long long)block_total);
 }
@@ -296,9 +409,11 @@ GM_API int gm_triangle_count(const gm_csr *g, uint64_t *triangles_out)
     if (n == 0 || g->m == 0)
         return GM_OK;
     gm::DeviceGuard guard(g->device);
-    gm::DevBuf low_len, loff, ctrl;
+    gm::DevBuf low_len, loff, short_len, loff16, ctrl;
     GM_TRY(low_len.alloc(((size_t)n + 1) * 4));
     GM_TRY(loff.alloc(((size_t)n + 1) * 4));
+    GM_TRY(short_len.alloc(((size_t)n + 1) * 4));
+    GM_TRY(loff16.alloc(((size_t)n + 1) * 4));
     GM_TRY(ctrl.alloc(16));
     GM_HIP(hipMemset(ctrl.p, 0, 16));
     unsigned grid = gm::div_up((uint64_t)n + 1, TC_BLOCK);
@@ -309,7 +424,8 @@ GM_API int gm_triangle_count(const gm_csr *g, uint64_t *triangles_out)
         GM_TRY(row_start.alloc(((size_t)g->m / 32 + 1) * 4));
         GM_HIP(hipMemset(row_start.p, 0, row_start.bytes));
         hipLaunchKernelGGL(tc_low_len_kernel, dim3(grid), dim3(TC_BLOCK), 0, 0, g->offsets, g->targets, n,
-                           low_len.as<uint32_t>(), row_start.as<uint32_t>(), ctrl.as<uint32_t>() + 2);
+                           low_len.as<uint32_t>(), short_len.as<uint32_t>(), row_start.as<uint32_t>(),
+                           ctrl.as<uint32_t>() + 2);
         unsigned egrid = gm::div_up(g->m, TC_BLOCK);
         if (egrid > 256 * 32)
             egrid = 256 * 32;
@@ -322,24 +438,39 @@ GM_API int gm_triangle_count(const gm_csr *g, uint64_t *triangles_out)
         size_t tmp_bytes = 0;
         GM_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, low_len.as<uint32_t>(), loff.as<uint32_t>(), 0u,
                                        (size_t)n + 1, rocprim::plus<uint32_t>(), (hipStream_t)0));
-        gm::DevBuf tmp;
+        gm::DevBuf tmp, padded;
         GM_TRY(tmp.alloc(tmp_bytes));
+        GM_TRY(padded.alloc(((size_t)n + 1) * 4));
         GM_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, low_len.as<uint32_t>(), loff.as<uint32_t>(), 0u,
+                                       (size_t)n + 1, rocprim::plus<uint32_t>(), (hipStream_t)0));
+        hipLaunchKernelGGL(tc_short_pad_kernel, dim3(grid), dim3(TC_BLOCK), 0, 0, short_len.as<uint32_t>(), n,
+                           padded.as<uint32_t>());
+        GM_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, padded.as<uint32_t>(), loff16.as<uint32_t>(), 0u,
                                        (size_t)n + 1, rocprim::plus<uint32_t>(), (hipStream_t)0));
         GM_HIP(hipDeviceSynchronize());
     }
-    uint32_t flags = 0, dag_m = 0;
+    uint32_t flags = 0, dag_m = 0, short_m = 0;
     GM_HIP(hipMemcpy(&flags, ctrl.as<uint32_t>() + 2, 4, hipMemcpyDeviceToHost));
     GM_CHECK((flags & 1u) == 0, GM_ERR_UNSUPPORTED,
              "gm_triangle_count: neighbour lists are not sorted (use CsrLayout::Sorted or Deduplicated)");
     GM_HIP(hipMemcpy(&dag_m, loff.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost));
     if (dag_m == 0)
         return GM_OK;
-    gm::DevBuf dag_src, dag_tgt;
+    // the 2-byte fronts are only read by tc_rows_kernel (strictly increasing lists)
+    const bool strict = (flags & 2u) == 0;
+    GM_HIP(hipMemcpy(&short_m, loff16.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost));
+    gm::DevBuf dag_src, dag_tgt, dag16, meta;
     GM_TRY(dag_src.alloc((size_t)dag_m * 4));
     GM_TRY(dag_tgt.alloc((size_t)dag_m * 4));
-    hipLaunchKernelGGL(tc_dag_kernel, dim3(grid), dim3(TC_BLOCK), 0, 0, g->offsets, g->targets, loff.as<uint32_t>(), n,
-                       dag_src.as<uint32_t>(), dag_tgt.as<uint32_t>());
+    if (strict) {
+        GM_TRY(dag16.alloc((size_t)short_m * 2 + 16));
+        GM_TRY(meta.alloc((size_t)n * sizeof(uint4)));
+        hipLaunchKernelGGL(tc_meta_kernel, dim3(grid), dim3(TC_BLOCK), 0, 0, loff.as<uint32_t>(), low_len.as<uint32_t>(),
+                           loff16.as<uint32_t>(), short_len.as<uint32_t>(), n, meta.as<uint4>());
+    }
+    hipLaunchKernelGGL(tc_dag_kernel, dim3(grid), dim3(TC_BLOCK), 0, 0, g->offsets, g->targets, loff.as<uint32_t>(),
+                       loff16.as<uint32_t>(), short_len.as<uint32_t>(), n, dag_src.as<uint32_t>(), dag_tgt.as<uint32_t>(),
+                       strict ? dag16.as<uint16_t>() : (uint16_t *)nullptr);
     unsigned cgrid = gm::div_up(dag_m, TC_BLOCK);
     if (cgrid > 256 * 16)
         cgrid = 256 * 16;
@@ -356,12 +487,12 @@ GM_API int gm_triangle_count(const gm_csr *g, uint64_t *triangles_out)
             const uint32_t cap = n < TCR_K_MAX ? n : TCR_K_MAX;
             K = (uint32_t)atoll(e) < cap ? (uint32_t)atoll(e) : cap;
         }
-        uint32_t per_item = 4096;
+        uint32_t per_item = 1024;
         if (const char *e = getenv("GM_TC_ITEM"))
             if (atoll(e) >= 64)
                 per_item = (uint32_t)atoll(e);
-        uint32_t n_items = 0;
         gm::DevBuf items, item_first;
+        std::vector<uint32_t> first_host;
         if (K) {
             GM_TRY(items.alloc(((size_t)K + 1) * 4));
             GM_TRY(item_first.alloc(((size_t)K + 1) * 4));
@@ -374,37 +505,48 @@ GM_API int gm_triangle_count(const gm_csr *g, uint64_t *triangles_out)
             GM_TRY(tmp.alloc(tmp_bytes));
             GM_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, items.as<uint32_t>(), item_first.as<uint32_t>(), 0u,
                                            (size_t)K + 1, rocprim::plus<uint32_t>(), (hipStream_t)0));
-            GM_HIP(hipMemcpy(&n_items, item_first.as<uint32_t>() + K, 4, hipMemcpyDeviceToHost));
+            first_host.resize((size_t)K + 1);
+            GM_HIP(hipMemcpy(first_host.data(), item_first.p, ((size_t)K + 1) * 4, hipMemcpyDeviceToHost));
         }
-        if (n_items) {
-            // GM_TC_SHAPE="<lanes per u>,<loads in flight>" picks another instantiation (measurements)
-            int shape_g = 16, shape_m = 4;
-            if (const char *e = getenv("GM_TC_SHAPE"))
-                (void)sscanf(e, "%d,%d", &shape_g, &shape_m);
-            const size_t lds = (size_t)((K + 31u) / 32u) * 4;
-#define GM_TC_ROWS(G_, M_)                                                                                              \
+        // One launch per power-of-two range of rows, with the LDS its longest row needs: the hub rows (short rows,
+        // most of the work) are not held to the occupancy of the 64 KiB rows at the far end.
+        // GM_TC_SHAPE="<threads per item>,<lanes per u>,<loads in flight>" picks another instantiation (measurements)
+        int shape_b = 512, shape_g = 8, shape_m = 4; // measured best at scale 24: 44.3 ms (1024 x 16: 49.6, 256 x 16: 49.3)
+        if (const char *e = getenv("GM_TC_SHAPE"))
+            (void)sscanf(e, "%d,%d,%d", &shape_b, &shape_g, &shape_m);
+        for (uint32_t v_lo = 0; v_lo < K;) {
+            uint32_t v_hi = v_lo < (1u << 14) ? (1u << 14) : v_lo * 2u;
+            v_hi = v_hi < K ? v_hi : K;
+            const uint32_t n_items = first_host[v_hi] - first_host[v_lo];
+            const size_t lds = (size_t)((v_hi + 31u) / 32u) * 4;
+            if (n_items) {
+#define GM_TC_ROWS(B_, G_, M_)                                                                                          \
     do {                                                                                                                \
-        GM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tc_rows_kernel<G_, M_>),                             \
+        GM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tc_rows_kernel<B_, G_, M_>),                         \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, TCR_K_MAX / 8));                         \
-        hipLaunchKernelGGL((tc_rows_kernel<G_, M_>), dim3(n_items), dim3(TCR_BLOCK), lds, 0, g->offsets, g->targets,    \
-                           low_len.as<uint32_t>(), loff.as<uint32_t>(), dag_tgt.as<uint32_t>(),                         \
-                           item_first.as<uint32_t>(), K, per_item, d_total);                                            \
+        hipLaunchKernelGGL((tc_rows_kernel<B_, G_, M_>), dim3(n_items), dim3(B_), lds, 0, g->offsets, g->targets,       \
+                           low_len.as<uint32_t>(), loff.as<uint32_t>(), meta.as<uint4>(), dag_tgt.as<uint32_t>(),      \
+                           dag16.as<uint16_t>(), item_first.as<uint32_t>(), v_lo, v_hi, per_item, d_total);            \
     } while (0)
-            if (shape_g == 8 && shape_m == 4)
-                GM_TC_ROWS(8, 4);
-            else if (shape_g == 16 && shape_m == 2)
-                GM_TC_ROWS(16, 2);
-            else if (shape_g == 16 && shape_m == 8)
-                GM_TC_ROWS(16, 8);
-            else if (shape_g == 32 && shape_m == 2)
-                GM_TC_ROWS(32, 2);
-            else if (shape_g == 32 && shape_m == 4)
-                GM_TC_ROWS(32, 4);
-            else if (shape_g == 64 && shape_m == 2)
-                GM_TC_ROWS(64, 2);
-            else
-                GM_TC_ROWS(16, 4);
+                if (shape_b == 1024 && shape_g == 16)
+                    GM_TC_ROWS(1024, 16, 4);
+                else if (shape_b == 1024 && shape_g == 8)
+                    GM_TC_ROWS(1024, 8, 4);
+                else if (shape_b == 512 && shape_g == 16)
+                    GM_TC_ROWS(512, 16, 4);
+                else if (shape_b == 256 && shape_g == 16)
+                    GM_TC_ROWS(256, 16, 4);
+                else if (shape_b == 256 && shape_g == 8)
+                    GM_TC_ROWS(256, 8, 4);
+                else if (shape_b == 128 && shape_g == 8)
+                    GM_TC_ROWS(128, 8, 4);
+                else if (shape_b == 128 && shape_g == 16)
+                    GM_TC_ROWS(128, 16, 4);
+                else
+                    GM_TC_ROWS(512, 8, 4);
 #undef GM_TC_ROWS
+            }
+            v_lo = v_hi;
         }
         hipLaunchKernelGGL(tc_count_kernel<true>, dim3(cgrid), dim3(TC_BLOCK), 0, 0, loff.as<uint32_t>(),
                            dag_src.as<uint32_t>(), dag_tgt.as<uint32_t>(), (uint64_t)dag_m, K, d_total);

@@ -165,6 +165,8 @@ __global__ __launch_bounds__(WCC_BLOCK) void wcc_link_remaining_kernel(
     }
 }
 
+constexpr uint32_t WCC_MODE_LDS = 4096;
+
 // wcc.rs:245-271: most frequent component among `samples` random nodes.  The reference draws from
 // an unseeded WyRand; the choice only decides which component link_remaining skips and never
 // changes the result.  One workgroup; ties -> smallest id.
@@ -174,22 +176,36 @@ __global__ __launch_bounds__(WCC_BLOCK) void wcc_sample_mode_kernel(const uint32
                                                                      uint32_t *__restrict__ skip_out)
 {
     __shared__ unsigned long long best; // (count << 32) | ~id  -> max picks highest count, then smallest id
+    __shared__ uint32_t staged[WCC_MODE_LDS]; // the samples, when they fit: the count below is samples^2 compares
     if (threadIdx.x == 0)
         best = 0ull;
+    const bool in_lds = samples <= WCC_MODE_LDS;
     for (uint32_t k = threadIdx.x; k < samples; k += WCC_BLOCK) {
         uint64_t x = seed + k;
         x += 0x9E3779B97F4A7C15ull;
         x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
         x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
         x ^= x >> 31;
-        sample_buf[k] = ld_agent(&parent[(uint32_t)(x % n)]);
+        const uint32_t c = ld_agent(&parent[(uint32_t)(x % n)]);
+        if (in_lds)
+            staged[k] = c;
+        else
+            sample_buf[k] = c;
     }
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < samples; k += WCC_BLOCK) {
-        const uint32_t c = sample_buf[k];
         uint32_t cnt = 0;
-        for (uint32_t j = 0; j < samples; ++j)
-            cnt += sample_buf[j] == c;
+        uint32_t c;
+        if (in_lds) { // every lane reads the same word per step: an LDS broadcast (1024 samples from global memory
+                      // were 0.18 ms of a 0.6 ms pipeline at scale 22)
+            c = staged[k];
+            for (uint32_t j = 0; j < samples; ++j)
+                cnt += staged[j] == c;
+        } else {
+            c = sample_buf[k];
+            for (uint32_t j = 0; j < samples; ++j)
+                cnt += sample_buf[j] == c;
+        }
         atomicMax(&best, ((unsigned long long)cnt << 32) | (uint32_t)~c);
     }
     __syncthreads();
@@ -206,9 +222,31 @@ unsigned wcc_grid(uint64_t n)
 } // namespace
 
 namespace gm {
+// The buffers of a call, taken from the out-CSR's handle and parked there again on every way out (hipMalloc /
+// hipFree of the two were a quarter of a scale-22 call).
+struct WccScratchLease {
+    const gm_csr *g;
+    std::unique_ptr<WccScratch> sc;
+    explicit WccScratchLease(const gm_csr *csr) : g(csr)
+    {
+        {
+            std::lock_guard<std::mutex> lock(g->cache_mu);
+            sc = std::move(g->wcc_scratch);
+        }
+        if (!sc)
+            sc.reset(new (std::nothrow) WccScratch);
+    }
+    ~WccScratchLease()
+    {
+        std::lock_guard<std::mutex> lock(g->cache_mu);
+        if (sc && !g->wcc_scratch)
+            g->wcc_scratch = std::move(sc);
+    }
+};
+
 // Shared by gm_wcc_afforest / gm_wcc_baseline; leaves the labels in d_parent (u32[n]).
 int wcc_device(const gm_csr *out_csr, const gm_csr *in_csr, uint64_t rounds, uint64_t sampling, bool afforest,
-               uint32_t *d_parent, hipStream_t st)
+               uint32_t *d_parent, hipStream_t st, DevBuf &buf /* work space, grown when too small */)
 {
     const uint32_t n = (uint32_t)out_csr->n;
     const unsigned grid = wcc_grid(n);
@@ -216,8 +254,9 @@ int wcc_device(const gm_csr *out_csr, const gm_csr *in_csr, uint64_t rounds, uin
     const uint64_t entries = out_csr->m + (in_csr ? in_csr->m : 0);
     // one allocation: [chunk count | pad] [chunk items] [sample buffer + skip id]
     const size_t items_bytes = (size_t)(entries / WCC_CHUNK + entries / WCC_BIG + 64) * sizeof(uint4);
-    gm::DevBuf buf;
-    GM_TRY(buf.alloc(16 + items_bytes + (size_t)(sampling + 1) * 4));
+    const size_t need = 16 + items_bytes + (size_t)(sampling + 1) * 4;
+    if (buf.bytes < need)
+        GM_TRY(buf.alloc(need));
     GM_HIP(hipMemsetAsync(buf.p, 0, 16, st));
     const WccChunks chunks{reinterpret_cast<uint4 *>(buf.as<char>() + 16), buf.as<uint32_t>()};
     uint32_t *sample_buf = reinterpret_cast<uint32_t *>(buf.as<char>() + 16 + items_bytes);
@@ -273,10 +312,13 @@ GM_API int gm_wcc_afforest(const gm_csr *out_csr, const gm_csr *in_csr, uint64_t
     GM_CHECK(n > 0, GM_ERR_INVALID, "gm_wcc_afforest: empty graph (reference panics when sampling)");
     GM_CHECK(components_out, GM_ERR_INVALID, "gm_wcc_afforest: components_out is null");
     gm::DeviceGuard guard(out_csr->device);
-    gm::DevBuf parent;
-    GM_TRY(parent.alloc(n * 4));
-    GM_TRY(gm::wcc_device(out_csr, in_csr, neighbor_rounds, sampling_size, true, parent.as<uint32_t>(), 0));
-    GM_HIP(hipMemcpy(components_out, parent.p, n * 4, hipMemcpyDeviceToHost));
+    gm::WccScratchLease lease(out_csr);
+    GM_CHECK(lease.sc, GM_ERR_NOMEM, "gm_wcc_afforest: out of host memory");
+    gm::DevBuf &parent = lease.sc->labels;
+    if (parent.bytes < n * 4)
+        GM_TRY(parent.alloc(n * 4));
+    GM_TRY(gm::wcc_device(out_csr, in_csr, neighbor_rounds, sampling_size, true, parent.as<uint32_t>(), 0, lease.sc->work));
+    GM_HIP(hipMemcpy(components_out, parent.p, n * 4, hipMemcpyDefault)); // host (page-locked: link speed) or device memory
     return GM_OK;
 }
 
@@ -288,10 +330,13 @@ GM_API int gm_wcc_baseline(const gm_csr *out_csr, uint32_t *components_out)
         return GM_OK;
     GM_CHECK(components_out, GM_ERR_INVALID, "gm_wcc_baseline: components_out is null");
     gm::DeviceGuard guard(out_csr->device);
-    gm::DevBuf parent;
-    GM_TRY(parent.alloc(n * 4));
-    GM_TRY(gm::wcc_device(out_csr, nullptr, 0, 0, false, parent.as<uint32_t>(), 0));
-    GM_HIP(hipMemcpy(components_out, parent.p, n * 4, hipMemcpyDeviceToHost));
+    gm::WccScratchLease lease(out_csr);
+    GM_CHECK(lease.sc, GM_ERR_NOMEM, "gm_wcc_baseline: out of host memory");
+    gm::DevBuf &parent = lease.sc->labels;
+    if (parent.bytes < n * 4)
+        GM_TRY(parent.alloc(n * 4));
+    GM_TRY(gm::wcc_device(out_csr, nullptr, 0, 0, false, parent.as<uint32_t>(), 0, lease.sc->work));
+    GM_HIP(hipMemcpy(components_out, parent.p, n * 4, hipMemcpyDefault));
     return GM_OK;
 }
 
