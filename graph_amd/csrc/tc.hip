@@ -108,15 +108,38 @@ __global__ void tc_short_pad_kernel(const uint32_t *__restrict__ short_len, uint
         padded[u] = u == n ? 0u : ((short_len[u] + TC_SHORT_PAD - 1u) & ~(TC_SHORT_PAD - 1u));
 }
 
-// everything tc_rows_kernel needs to know about L(u) in one 16-byte load:
-// {first DAG entry, |L(u)|, first 2-byte entry, number of entries below TC_SHORT_IDS}
-__global__ void tc_meta_kernel(const uint32_t *__restrict__ loff, const uint32_t *__restrict__ low_len,
-                               const uint32_t *__restrict__ loff16, const uint32_t *__restrict__ short_len, uint32_t n,
-                               uint4 *__restrict__ meta)
+// Everything tc_rows_kernel needs of most lists in ONE 128-byte line: the header
+// {first DAG entry, |L(u)|, first 2-byte entry, number of entries below TC_SHORT_IDS} and the first TC_REC_IDS
+// 2-byte ids of the front (0xFFFF beyond its end).  A visit of a short list costs one random line instead of two
+// (header, then the first line of the front).  Eight lanes per node, 16 bytes each.
+constexpr uint32_t TC_REC_IDS = 56;
+__global__ __launch_bounds__(TC_BLOCK) void tc_record_kernel(const uint32_t *__restrict__ loff,
+                                                             const uint32_t *__restrict__ low_len,
+                                                             const uint32_t *__restrict__ loff16,
+                                                             const uint32_t *__restrict__ short_len,
+                                                             const uint16_t *__restrict__ dag16, uint32_t n,
+                                                             uint4 *__restrict__ rec /* 8 per node */)
 {
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += stride)
-        meta[u] = make_uint4(loff[u], low_len[u], loff16[u], short_len[u]);
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < (uint64_t)n * 8u; t += stride) {
+        const uint32_t u = (uint32_t)(t >> 3), k = (uint32_t)(t & 7u);
+        const uint32_t s16 = loff16[u], n16 = short_len[u];
+        uint4 out;
+        if (k == 0) {
+            out = make_uint4(loff[u], low_len[u], s16, n16);
+        } else {
+            uint32_t w[4];
+#pragma unroll
+            for (uint32_t e = 0; e < 4u; ++e) {
+                const uint32_t i = (k - 1u) * 8u + 2u * e;
+                const uint32_t lo = i < n16 ? dag16[s16 + i] : 0xFFFFu;
+                const uint32_t hi = i + 1u < n16 ? dag16[s16 + i + 1u] : 0xFFFFu;
+                w[e] = lo | (hi << 16);
+            }
+            out = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        rec[t] = out;
+    }
 }
 
 // dag_src[k] = u for k in [loff[u], loff[u+1]); dag_tgt[k] = the k-th lower-prefix entry; dag16 = the entries below
@@ -216,31 +239,34 @@ __global__ void tc_item_count_kernel(const uint32_t *__restrict__ off, const uin
     }
 }
 
+// item -> its row (a 19-step binary search over item_first at the head of every workgroup was ~10 us of dependent loads)
+__global__ void tc_item_rows_kernel(const uint32_t *__restrict__ item_first, uint32_t K, uint32_t *__restrict__ item_row)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < K; v += stride)
+        for (uint32_t i = item_first[v]; i < item_first[v + 1]; ++i)
+            item_row[i] = v;
+}
+
 template <int BLOCK /* threads per work item */, uint32_t GROUP /* lanes per u */, uint32_t MLP /* loads in flight per lane */>
 __global__ __launch_bounds__(BLOCK) void tc_rows_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt,
                                                             const uint32_t *__restrict__ low_len,
                                                             const uint32_t *__restrict__ loff,
-                                                            const uint4 *__restrict__ meta,
+                                                            const uint4 *__restrict__ rec /* tc_record_kernel */,
                                                             const uint32_t *__restrict__ dag_tgt,
                                                             const uint16_t *__restrict__ dag16,
                                                             const uint32_t *__restrict__ item_first /* K+1, exclusive scan */,
-                                                            uint32_t v_lo, uint32_t v_hi /* rows of this launch */,
-                                                            uint32_t per_item, unsigned long long *__restrict__ total)
+                                                            const uint32_t *__restrict__ item_row,
+                                                            uint32_t item_base /* first item of this launch */,
+                                                            uint32_t per_item, uint32_t dyn,
+                                                            unsigned long long *__restrict__ total)
 {
     extern __shared__ uint32_t tc_row[];
     __shared__ uint64_t red[BLOCK / kWave];
+    __shared__ uint32_t next_u;
     constexpr int TCR_BLOCK = BLOCK;
-    // the row of this item: the last v with item_first[v] <= item
-    const uint32_t item = item_first[v_lo] + blockIdx.x;
-    uint32_t lo = v_lo, hi = v_hi;
-    while (hi - lo > 1) {
-        const uint32_t mid = lo + ((hi - lo) >> 1);
-        if (item_first[mid] <= item)
-            lo = mid;
-        else
-            hi = mid;
-    }
-    const uint32_t v = lo;
+    const uint32_t item = item_base + blockIdx.x;
+    const uint32_t v = item_row[item];
     const uint32_t words = (v + 31u) >> 5;
     for (uint32_t i = threadIdx.x; i < words; i += TCR_BLOCK)
         tc_row[i] = 0u;
@@ -250,13 +276,14 @@ __global__ __launch_bounds__(BLOCK) void tc_rows_kernel(const uint32_t *__restri
         const uint32_t w = dag_tgt[lv + i]; // < v: lists are strictly increasing and hold no self-loop on this path
         atomicOr(&tc_row[w >> 5], 1u << (w & 31u));
     }
-    __syncthreads();
     const uint32_t ubeg = off[v] + low_len[v] + (item - item_first[v]) * per_item;
     const uint32_t uend = ubeg + per_item < off[v + 1] ? ubeg + per_item : off[v + 1];
-    constexpr uint32_t GROUPS = TCR_BLOCK / GROUP; // u's in flight per workgroup
+    if (threadIdx.x == 0)
+        next_u = ubeg;
+    __syncthreads();
     constexpr uint64_t GMASK = GROUP == 64 ? ~0ull : ((1ull << (GROUP & 63)) - 1ull);
     constexpr uint32_t MLP16 = MLP > 1 ? MLP / 2 : 1; // 8-byte loads of four 2-byte ids
-    const uint32_t g = threadIdx.x / GROUP, l = threadIdx.x % GROUP;
+    const uint32_t l = threadIdx.x % GROUP;
     const uint32_t gshift = (threadIdx.x & (kWave - 1)) / GROUP * GROUP; // this group's bits of a wavefront ballot
     uint32_t count = 0;
     // four bits of a packed load against the row: entries base .. base + 3 of a 2-byte front of `lim` entries
@@ -274,39 +301,79 @@ __global__ __launch_bounds__(BLOCK) void tc_rows_kernel(const uint32_t *__restri
     };
     constexpr uint32_t UB = 4; // u's a group has in flight: id -> list header -> first line are three dependent round
                                // trips, and one u at a time left the kernel waiting on them (4.5 us per u and group)
-    for (uint32_t j0 = ubeg; j0 < uend; j0 += GROUPS * UB) {
+    static_assert(GROUP == 8 || GROUP == 16 || GROUP == 32, "a record is 128 bytes: 16, 8 or 4 per lane");
+    constexpr uint32_t RW = 32u / GROUP;  // 4-byte words of a record per lane
+    constexpr uint32_t IPL = 64u / GROUP; // 2-byte positions per lane; the first 8 positions are the header
+    // The groups of the workgroup draw their next UB upper neighbours from a counter in LDS: list fronts are anything
+    // from empty to 1700 entries, and with a fixed assignment a workgroup (and its LDS, and its wavefront slots) stayed
+    // resident until its unluckiest group was done.
+    uint32_t j_static = ubeg + threadIdx.x / GROUP * UB; // dyn == 0 (measurements): a fixed share per group
+    for (;;) {
+        uint32_t j0 = j_static;
+        if (dyn) {
+            if (l == 0)
+                j0 = atomicAdd(&next_u, UB);
+            j0 = __shfl(j0, (int)gshift, kWave);
+        }
+        j_static += TCR_BLOCK / GROUP * UB;
+        if (j0 >= uend)
+            break;
         uint32_t uid[UB];
-        uint4 mt[UB]; // {first DAG entry, |L(u)|, first 2-byte entry, entries below TC_SHORT_IDS}
-        unsigned long long first[UB];
+        uint32_t rw[UB][RW];
 #pragma unroll
         for (uint32_t t = 0; t < UB; ++t) {
-            const uint32_t j = j0 + t * GROUPS + g;
+            const uint32_t j = j0 + t;
             uid[t] = j < uend ? tgt[j] : 0xFFFFFFFFu;
         }
 #pragma unroll
-        for (uint32_t t = 0; t < UB; ++t)
-            mt[t] = uid[t] != 0xFFFFFFFFu ? meta[uid[t]] : make_uint4(0u, 0u, 0u, 0u);
-        // the front of a list as 2-byte ids: half the bytes for the entries that are streamed most often (ids below
-        // 65536 are 94 % of the stream at scale 24 after make_degree_ordered); the first 128-byte line of each list
-#pragma unroll
         for (uint32_t t = 0; t < UB; ++t) {
-            const uint32_t lim16 = mt[t].w < v ? mt[t].w : v; // at most v entries of an increasing list are below v
-            first[t] = l * 4u < lim16 ? *reinterpret_cast<const unsigned long long *>(dag16 + mt[t].z + l * 4u) : ~0ull;
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(rec + (size_t)uid[t] * 8u) + l * RW;
+            if (uid[t] == 0xFFFFFFFFu) {
+#pragma unroll
+                for (uint32_t k = 0; k < RW; ++k)
+                    rw[t][k] = 0u;
+            } else if (RW == 4) {
+                const uint4 x = *reinterpret_cast<const uint4 *>(p);
+                rw[t][0] = x.x, rw[t][1] = x.y, rw[t][2 % RW] = x.z, rw[t][3 % RW] = x.w;
+            } else if (RW == 2) {
+                const uint2 x = *reinterpret_cast<const uint2 *>(p);
+                rw[t][0] = x.x, rw[t][1 % RW] = x.y;
+            } else {
+                rw[t][0] = *p;
+            }
         }
 #pragma unroll
         for (uint32_t t = 0; t < UB; ++t) {
-            const uint32_t lim16 = mt[t].w < v ? mt[t].w : v;
+            // {first DAG entry, |L(u)|, first 2-byte entry, entries below TC_SHORT_IDS}: header word k sits in lane k / RW
+            uint4 mt;
+            mt.x = __shfl(rw[t][0 % RW], (int)(gshift + 0u / RW), kWave);
+            mt.y = __shfl(rw[t][1 % RW], (int)(gshift + 1u / RW), kWave);
+            mt.z = __shfl(rw[t][2 % RW], (int)(gshift + 2u / RW), kWave);
+            mt.w = __shfl(rw[t][3 % RW], (int)(gshift + 3u / RW), kWave);
+            // the front of a list as 2-byte ids: half the bytes for the entries that are streamed most often (ids below
+            // 65536 are 94 % of the stream at scale 24 after make_degree_ordered)
+            const uint32_t lim16 = mt.w < v ? mt.w : v; // at most v entries of an increasing list are below v
             bool over = false;
-            probe4(first[t], l * 4u, lim16, over);
+#pragma unroll
+            for (uint32_t e = 0; e < IPL; ++e) {
+                const uint32_t pos = l * IPL + e; // 2-byte position inside the record
+                const uint32_t w = (rw[t][(e / 2u) % RW] >> (16u * (e & 1u))) & 0xFFFFu;
+                if (pos >= 8u && pos - 8u < lim16) {
+                    if (w < v)
+                        count += (tc_row[w >> 5] >> (w & 31u)) & 1u;
+                    else
+                        over = true;
+                }
+            }
             bool passed = ((__ballot(over) >> gshift) & GMASK) != 0; // an entry >= v was seen: the list is done
-            uint32_t cur = GROUP * 4u;
+            uint32_t cur = TC_REC_IDS;
             bool go = !passed && cur < lim16;
             while (__ballot(go)) { // the rest of a long front, MLP16 lines per step
                 unsigned long long pk[MLP16];
 #pragma unroll
                 for (uint32_t q = 0; q < MLP16; ++q) {
                     const uint32_t base = cur + (q * GROUP + l) * 4u;
-                    pk[q] = (go && base < lim16) ? *reinterpret_cast<const unsigned long long *>(dag16 + mt[t].z + base) : ~0ull;
+                    pk[q] = (go && base < lim16) ? *reinterpret_cast<const unsigned long long *>(dag16 + mt.z + base) : ~0ull;
                 }
                 bool more_over = false;
 #pragma unroll
@@ -319,15 +386,15 @@ __global__ __launch_bounds__(BLOCK) void tc_rows_kernel(const uint32_t *__restri
                 go = go && !grp_over && cur < lim16;
             }
             // what is left of the list: the entries from TC_SHORT_IDS up, 4-byte ids — only rows beyond TC_SHORT_IDS get here
-            const uint32_t ne = mt[t].y < v ? mt[t].y : v;
-            cur = mt[t].w;
-            go = !passed && v > TC_SHORT_IDS && lim16 == mt[t].w && cur < ne;
+            const uint32_t ne = mt.y < v ? mt.y : v;
+            cur = mt.w;
+            go = !passed && v > TC_SHORT_IDS && lim16 == mt.w && cur < ne;
             while (__ballot(go)) {
                 uint32_t w[MLP];
 #pragma unroll
                 for (uint32_t q = 0; q < MLP; ++q) {
                     const uint32_t i = cur + q * GROUP + l;
-                    w[q] = (go && i < ne) ? dag_tgt[mt[t].x + i] : 0xFFFFFFFFu;
+                    w[q] = (go && i < ne) ? dag_tgt[mt.x + i] : 0xFFFFFFFFu;
                 }
 #pragma unroll
                 for (uint32_t q = 0; q < MLP; ++q)
@@ -459,18 +526,22 @@ GM_API int gm_triangle_count(const gm_csr *g, uint64_t *triangles_out)
     // the 2-byte fronts are only read by tc_rows_kernel (strictly increasing lists)
     const bool strict = (flags & 2u) == 0;
     GM_HIP(hipMemcpy(&short_m, loff16.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost));
-    gm::DevBuf dag_src, dag_tgt, dag16, meta;
+    gm::DevBuf dag_src, dag_tgt, dag16, rec;
     GM_TRY(dag_src.alloc((size_t)dag_m * 4));
     GM_TRY(dag_tgt.alloc((size_t)dag_m * 4));
     if (strict) {
         GM_TRY(dag16.alloc((size_t)short_m * 2 + 16));
-        GM_TRY(meta.alloc((size_t)n * sizeof(uint4)));
-        hipLaunchKernelGGL(tc_meta_kernel, dim3(grid), dim3(TC_BLOCK), 0, 0, loff.as<uint32_t>(), low_len.as<uint32_t>(),
-                           loff16.as<uint32_t>(), short_len.as<uint32_t>(), n, meta.as<uint4>());
+        GM_TRY(rec.alloc((size_t)n * 8 * sizeof(uint4)));
     }
     hipLaunchKernelGGL(tc_dag_kernel, dim3(grid), dim3(TC_BLOCK), 0, 0, g->offsets, g->targets, loff.as<uint32_t>(),
                        loff16.as<uint32_t>(), short_len.as<uint32_t>(), n, dag_src.as<uint32_t>(), dag_tgt.as<uint32_t>(),
                        strict ? dag16.as<uint16_t>() : (uint16_t *)nullptr);
+    if (strict) {
+        unsigned rgrid = gm::div_up((uint64_t)n * 8, TC_BLOCK);
+        rgrid = rgrid > 256 * 64 ? 256 * 64 : rgrid;
+        hipLaunchKernelGGL(tc_record_kernel, dim3(rgrid), dim3(TC_BLOCK), 0, 0, loff.as<uint32_t>(), low_len.as<uint32_t>(),
+                           loff16.as<uint32_t>(), short_len.as<uint32_t>(), dag16.as<uint16_t>(), n, rec.as<uint4>());
+    }
     unsigned cgrid = gm::div_up(dag_m, TC_BLOCK);
     if (cgrid > 256 * 16)
         cgrid = 256 * 16;
@@ -487,11 +558,11 @@ GM_API int gm_triangle_count(const gm_csr *g, uint64_t *triangles_out)
             const uint32_t cap = n < TCR_K_MAX ? n : TCR_K_MAX;
             K = (uint32_t)atoll(e) < cap ? (uint32_t)atoll(e) : cap;
         }
-        uint32_t per_item = 1024;
+        uint32_t per_item = 2048;
         if (const char *e = getenv("GM_TC_ITEM"))
             if (atoll(e) >= 64)
                 per_item = (uint32_t)atoll(e);
-        gm::DevBuf items, item_first;
+        gm::DevBuf items, item_first, item_row;
         std::vector<uint32_t> first_host;
         if (K) {
             GM_TRY(items.alloc(((size_t)K + 1) * 4));
@@ -507,10 +578,14 @@ GM_API int gm_triangle_count(const gm_csr *g, uint64_t *triangles_out)
                                            (size_t)K + 1, rocprim::plus<uint32_t>(), (hipStream_t)0));
             first_host.resize((size_t)K + 1);
             GM_HIP(hipMemcpy(first_host.data(), item_first.p, ((size_t)K + 1) * 4, hipMemcpyDeviceToHost));
+            GM_TRY(item_row.alloc(((size_t)first_host[K] + 1) * 4));
+            hipLaunchKernelGGL(tc_item_rows_kernel, dim3(gm::div_up(K, 256)), dim3(256), 0, 0, item_first.as<uint32_t>(), K,
+                               item_row.as<uint32_t>());
         }
         // One launch per power-of-two range of rows, with the LDS its longest row needs: the hub rows (short rows,
         // most of the work) are not held to the occupancy of the 64 KiB rows at the far end.
         // GM_TC_SHAPE="<threads per item>,<lanes per u>,<loads in flight>" picks another instantiation (measurements)
+        const uint32_t dyn = getenv("GM_TC_DYN") ? (uint32_t)atoi(getenv("GM_TC_DYN")) : 1u;
         int shape_b = 512, shape_g = 8, shape_m = 4; // measured best at scale 24: 44.3 ms (1024 x 16: 49.6, 256 x 16: 49.3)
         if (const char *e = getenv("GM_TC_SHAPE"))
             (void)sscanf(e, "%d,%d,%d", &shape_b, &shape_g, &shape_m);
@@ -525,8 +600,9 @@ GM_API int gm_triangle_count(const gm_csr *g, uint64_t *triangles_out)
         GM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tc_rows_kernel<B_, G_, M_>),                         \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, TCR_K_MAX / 8));                         \
         hipLaunchKernelGGL((tc_rows_kernel<B_, G_, M_>), dim3(n_items), dim3(B_), lds, 0, g->offsets, g->targets,       \
-                           low_len.as<uint32_t>(), loff.as<uint32_t>(), meta.as<uint4>(), dag_tgt.as<uint32_t>(),      \
-                           dag16.as<uint16_t>(), item_first.as<uint32_t>(), v_lo, v_hi, per_item, d_total);            \
+                           low_len.as<uint32_t>(), loff.as<uint32_t>(), rec.as<uint4>(), dag_tgt.as<uint32_t>(),       \
+                           dag16.as<uint16_t>(), item_first.as<uint32_t>(), item_row.as<uint32_t>(), first_host[v_lo],  \
+                           per_item, dyn, d_total);                                                                     \
     } while (0)
                 if (shape_b == 1024 && shape_g == 16)
                     GM_TC_ROWS(1024, 16, 4);
