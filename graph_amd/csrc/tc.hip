@@ -525,18 +525,22 @@ GM_API int gm_triangle_count(const gm_csr *g, uint64_t *triangles_out)
         return GM_OK;
     // the 2-byte fronts are only read by tc_rows_kernel (strictly increasing lists)
     const bool strict = (flags & 2u) == 0;
+    bool rows_ok = strict; // the row kernel needs 2 B x short entries + 128 B x nodes beside the DAG
     GM_HIP(hipMemcpy(&short_m, loff16.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost));
     gm::DevBuf dag_src, dag_tgt, dag16, rec;
     GM_TRY(dag_src.alloc((size_t)dag_m * 4));
     GM_TRY(dag_tgt.alloc((size_t)dag_m * 4));
-    if (strict) {
-        GM_TRY(dag16.alloc((size_t)short_m * 2 + 16));
-        GM_TRY(rec.alloc((size_t)n * 8 * sizeof(uint4)));
+    if (rows_ok && (dag16.alloc((size_t)short_m * 2 + 16) != GM_OK || rec.alloc((size_t)n * 8 * sizeof(uint4)) != GM_OK)) {
+        // an accelerator, not a requirement: when HBM is short the whole count takes the search path
+        (void)hipGetLastError();
+        dag16.release();
+        rec.release();
+        rows_ok = false;
     }
     hipLaunchKernelGGL(tc_dag_kernel, dim3(grid), dim3(TC_BLOCK), 0, 0, g->offsets, g->targets, loff.as<uint32_t>(),
                        loff16.as<uint32_t>(), short_len.as<uint32_t>(), n, dag_src.as<uint32_t>(), dag_tgt.as<uint32_t>(),
-                       strict ? dag16.as<uint16_t>() : (uint16_t *)nullptr);
-    if (strict) {
+                       rows_ok ? dag16.as<uint16_t>() : (uint16_t *)nullptr);
+    if (rows_ok) {
         unsigned rgrid = gm::div_up((uint64_t)n * 8, TC_BLOCK);
         rgrid = rgrid > 256 * 64 ? 256 * 64 : rgrid;
         hipLaunchKernelGGL(tc_record_kernel, dim3(rgrid), dim3(TC_BLOCK), 0, 0, loff.as<uint32_t>(), low_len.as<uint32_t>(),
@@ -558,6 +562,8 @@ GM_API int gm_triangle_count(const gm_csr *g, uint64_t *triangles_out)
             const uint32_t cap = n < TCR_K_MAX ? n : TCR_K_MAX;
             K = (uint32_t)atoll(e) < cap ? (uint32_t)atoll(e) : cap;
         }
+        if (!rows_ok)
+            K = 0;
         uint32_t per_item = 2048;
         if (const char *e = getenv("GM_TC_ITEM"))
             if (atoll(e) >= 64)

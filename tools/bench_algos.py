@@ -28,6 +28,7 @@ HBM_PEAK = 8.0e12
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--wcc-scale", type=int, default=22)
+    ap.add_argument("--prapi-scale", type=int, default=0, help="scale of the page_rank() drop-in call timing (0: --wcc-scale)")
     ap.add_argument("--sssp-scale", type=int, default=24)
     ap.add_argument("--tc-scale", type=int, default=24)
     ap.add_argument("--oracle", type=int, default=1)
@@ -73,7 +74,7 @@ def main():
     if "prapi" not in args.skip:
         # the drop-in call page_rank(&graph, config) with host result buffers: first call builds the
         # propagation-blocking plan (cached in the CSR handle), later calls reuse it
-        sc = args.wcc_scale
+        sc = args.prapi_scale or args.wcc_scale
         n = 1 << sc
         src, dst = synth.rmat_edges(sc, 42)
         g = P.DirectedCsrGraph(synth.build_csr(n, src, dst, P.Direction.Outgoing, P.CsrLayout.Sorted),
