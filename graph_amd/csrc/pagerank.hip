@@ -646,7 +646,8 @@ namespace {
 // the caller's host array, else counted from the in-CSR's targets
 int pr_out_degrees(const gm_csr *csr, const uint32_t *host_outdeg, const gm_csr *out_csr, gm::DevBuf &buf, hipStream_t st)
 {
-    GM_TRY(buf.alloc((size_t)csr->n * 4));
+    if (buf.bytes < (size_t)csr->n * 4 || !buf.p)
+        GM_TRY(buf.alloc((size_t)csr->n * 4));
     if (out_csr) {
         unsigned grid = gm::div_up(csr->n, 256);
         if (grid > 256 * 16)
@@ -671,21 +672,25 @@ int pr_out_degrees(const gm_csr *csr, const uint32_t *host_outdeg, const gm_csr 
     return GM_OK;
 }
 
-struct StreamHolder {
-    hipStream_t s = nullptr;
-    ~StreamHolder()
+} // namespace
+
+// Everything a gm_page_rank call allocates: its stream, the out-degree / score / x vectors, the read-back words and
+// the engine (with the propagation-blocking scratch: 3.6 GB at scale 26).  A call takes the set parked in the in-CSR's
+// handle, grows what is too small, rebuilds the engine if the call wants another one, and parks the set again:
+// a dozen hipFree + hipMalloc pairs were ~2 ms of every call (a third of a 20-sweep call at scale 22), and the
+// reference's app calls page_rank(&graph, config) in a loop on one graph (crates/app/src/app.rs:124-153).
+struct gm::PrCallState {
+    hipStream_t stream = nullptr;
+    gm::DevBuf outdeg, scores, x0, x1, dres;
+    gm::PinnedBuf hres;
+    gm_pr *engine = nullptr;
+    ~PrCallState()
     {
-        if (s)
-            (void)hipStreamDestroy(s);
+        delete engine;
+        if (stream)
+            (void)hipStreamDestroy(stream);
     }
 };
-
-struct PrHolder {
-    gm_pr *p = nullptr;
-    ~PrHolder() { delete p; }
-};
-
-} // namespace
 
 static int page_rank_impl(const gm_csr *in_csr, const uint32_t *out_degree, const gm_csr *out_csr, uint64_t max_iterations,
                           double tolerance, float damping_factor, int mode, float *scores_out, uint64_t *iterations_out,
@@ -711,23 +716,49 @@ static int page_rank_impl(const gm_csr *in_csr, const uint32_t *out_degree, cons
         mode = n <= 16384 ? GM_PR_SEQUENTIAL : GM_PR_JACOBI;
 
     gm::DeviceGuard guard(in_csr->device);
-    StreamHolder sh;
-    GM_HIP(hipStreamCreateWithFlags(&sh.s, hipStreamNonBlocking));
-    hipStream_t st = sh.s;
+    // GM_PB_NOCACHE (measurement tools that switch plan knobs between calls): nothing is carried over
+    const bool carry = getenv("GM_PB_NOCACHE") == nullptr || atoi(getenv("GM_PB_NOCACHE")) == 0;
+    std::shared_ptr<gm::PrCallState> cs;
+    if (carry) {
+        std::lock_guard<std::mutex> lock(in_csr->cache_mu);
+        cs = std::move(in_csr->pr_call);
+        in_csr->pr_call.reset();
+    }
+    struct Park { // back into the handle on every way out
+        const gm_csr *g;
+        std::shared_ptr<gm::PrCallState> &cs;
+        bool carry;
+        ~Park()
+        {
+            if (!carry || !cs)
+                return;
+            std::lock_guard<std::mutex> lock(g->cache_mu);
+            if (!g->pr_call)
+                g->pr_call = std::move(cs);
+        }
+    } park{in_csr, cs, carry};
+    if (!cs)
+        cs = std::make_shared<gm::PrCallState>();
+    if (!cs->stream)
+        GM_HIP(hipStreamCreateWithFlags(&cs->stream, hipStreamNonBlocking));
+    hipStream_t st = cs->stream;
 
-    gm::DevBuf outdeg, scores, x0, x1, dres;
-    gm::PinnedBuf hres;
+    gm::DevBuf &outdeg = cs->outdeg, &scores = cs->scores, &x0 = cs->x0, &x1 = cs->x1, &dres = cs->dres;
+    gm::PinnedBuf &hres = cs->hres;
     GM_TRY(pr_out_degrees(in_csr, out_degree, out_csr, outdeg, st));
-    GM_TRY(scores.alloc(n * 4));
-    GM_TRY(dres.alloc(16));
-    GM_TRY(hres.alloc(16));
+    if (scores.bytes < n * 4)
+        GM_TRY(scores.alloc(n * 4));
+    if (!dres.p)
+        GM_TRY(dres.alloc(16));
+    if (!hres.p)
+        GM_TRY(hres.alloc(16));
 
     const float init = 1.0f / (float)n;
     const float base = (1.0f - damping_factor) / (float)n;
 
     if (mode == GM_PR_SEQUENTIAL) {
         const bool lds = n <= 16384;
-        if (!lds)
+        if (!lds && x0.bytes < n * 4)
             GM_TRY(x0.alloc(n * 4));
         uint64_t *d_iter = dres.as<uint64_t>();
         double *d_err = reinterpret_cast<double *>(dres.as<char>() + 8);
@@ -752,9 +783,11 @@ static int page_rank_impl(const gm_csr *in_csr, const uint32_t *out_degree, cons
     }
 
     // synchronous sweeps
-    GM_TRY(x0.alloc(n * 4));
-    GM_TRY(x1.alloc(n * 4));
-    PrHolder ph;
+    if (x0.bytes < n * 4)
+        GM_TRY(x0.alloc(n * 4));
+    if (x1.bytes < n * 4)
+        GM_TRY(x1.alloc(n * 4));
+    struct { gm_pr *p; } ph{nullptr};
     int engine = mode == GM_PR_JACOBI_PULL       ? GM_PR_ENGINE_PULL
                  : mode == GM_PR_JACOBI_PB       ? GM_PR_ENGINE_PB
                  : mode == GM_PR_JACOBI_REFORDER ? GM_PR_ENGINE_REFORDER
@@ -773,7 +806,15 @@ static int page_rank_impl(const gm_csr *in_csr, const uint32_t *out_degree, cons
         const bool big = in_csr->m >= (1ull << 28), mid = in_csr->m >= (1ull << 24);
         engine = (cached || big || long_rows || (mid && calls >= 2)) ? GM_PR_ENGINE_PB : GM_PR_ENGINE_PULL;
     }
-    GM_TRY(gm_pr_create_with(in_csr, n, 0, n, (uint64_t)outdeg.p, damping_factor, engine, &ph.p));
+    // the parked engine serves this call if it is the same kind over the same vectors
+    if (cs->engine && (cs->engine->engine != engine || cs->engine->damping != damping_factor || cs->engine->n_global != n ||
+                       cs->engine->outdeg != outdeg.as<uint32_t>())) {
+        delete cs->engine;
+        cs->engine = nullptr;
+    }
+    if (!cs->engine)
+        GM_TRY(gm_pr_create_with(in_csr, n, 0, n, (uint64_t)outdeg.p, damping_factor, engine, &cs->engine));
+    ph.p = cs->engine;
     GM_TRY(gm_pr_init(ph.p, (uint64_t)scores.p, (uint64_t)x0.p, st));
     uint64_t iter = 0;
     double err = 0.0;

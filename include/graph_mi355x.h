@@ -125,6 +125,9 @@ int gm_csr_slice_rows_map(const gm_csr *full, uint64_t row_lo, uint64_t row_hi, 
  *                     deterministic (n <= CHUNK_SIZE = 16384, page_rank.rs:12,135)
  * Stop rule as page_rank.rs:105-109: iteration += 1; stop if error < tolerance ||
  * iteration == max_iterations (so at least one sweep always runs).
+ * The in-CSR's handle keeps what a call builds and allocates for the next call on the same graph (the
+ * propagation-blocking plan, the call's stream, vectors and engine: ~9 GB beside a 4.3 GB CSR at scale 26);
+ * gm_csr_free releases it.
  * ------------------------------------------------------------------------------------------- */
 typedef enum gm_pr_mode {
     GM_PR_AUTO = 0,
