@@ -277,6 +277,28 @@ def test_page_rank_converged_matches_reference_order(P, oracle, scale):
     assert 1 <= it_d <= 20 and (err_d < 1e-4 or it_d == 20)
 
 
+def test_page_rank_calls_on_one_handle_do_not_see_each_other(P, oracle):
+    """gm_page_rank parks its stream, vectors and engine in the in-CSR's handle.  A sequence of calls that changes
+    the mode (another engine), the damping factor, the iteration count and the tolerance on ONE graph object must
+    give, call by call, the bits a fresh graph object gives."""
+    s, d = oracle.rmat_edges(15, seed=21)
+    n = 1 << 15
+    kept = _directed(P, n, s, d, P.CsrLayout.Sorted)
+    calls = [(P.PageRankMode.JacobiPB, 5, 0.0, 0.85), (P.PageRankMode.JacobiPB, 3, 0.0, 0.5),
+             (P.PageRankMode.JacobiPull, 4, 0.0, 0.5), (P.PageRankMode.JacobiPB, 20, 1e-4, 0.85),
+             (P.PageRankMode.Sequential, 6, 0.0, 0.85), (P.PageRankMode.JacobiRefOrder, 2, 0.0, 0.9),
+             (P.PageRankMode.JacobiPB, 5, 0.0, 0.85)]  # (Auto picks its engine by the handle's history: not comparable)
+    first = None
+    for mode, iters, tol, damp in calls:
+        cfg = P.PageRankConfig(iters, tol, damp)
+        got = P.page_rank(kept, cfg, mode)
+        fresh = P.page_rank(_directed(P, n, s, d, P.CsrLayout.Sorted), cfg, mode)
+        assert np.array_equal(got[0], fresh[0]) and got[1:] == fresh[1:], (mode, iters, tol, damp)
+        if first is None:
+            first = got
+    assert np.array_equal(got[0], first[0])  # the last call repeats the first
+
+
 def test_page_rank_argument_errors(P, scale8):
     s, d, n = scale8
     g = _directed(P, n, s, d, P.CsrLayout.Sorted)
