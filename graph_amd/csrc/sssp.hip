@@ -12,16 +12,19 @@
 //   * instead of per-thread bins copied into a shared frontier (sssp.rs:85-94) there is one bit per
 //     node: set when the node's distance improved since its edges were last relaxed.  A round clears
 //     and relaxes every flagged node whose distance is <= the current threshold; the others simply
-//     stay flagged (nothing is rewritten for them), and the minimum pending distance is tracked — the
-//     role of the reference's min_non_empty_bin (sssp.rs:159-168).  No fences: "distance improved,
-//     then flag set" and "flag cleared, then distance read" are each ordered by the returned value of
-//     the first atomic, so an improvement is never lost;  The threshold advances to (minimum pending distance + width) when a round
-//     leaves nothing below it; `delta` only seeds the schedule (first step delta/32, then adapted to
-//     the work of each phase, see gm_sssp_delta_stepping) and never changes the result;
+//     stay flagged (nothing is rewritten for them).  No fences: "distance improved, then flag set" and
+//     "flag cleared, then distance read" are each ordered by the returned value of the first atomic, so
+//     an improvement is never lost.  When a phase has run dry the threshold advances to (minimum pending
+//     distance + width) — the role of the reference's min_non_empty_bin (sssp.rs:159-168); `delta` only
+//     seeds the schedule (first step delta/32, then adapted to the work of each phase, see
+//     gm_sssp_delta_stepping) and never changes the result;
 //   * the bucket bookkeeping lives on the device (sssp_advance_kernel): the host enqueues rounds in
 //     batches and reads one flag per batch instead of synchronising after every round;
 //   * INF = f32::MAX (sssp.rs:12), never +inf.
-// One lane per node; adjacency lists longer than 32 edges are relaxed by the whole wavefront.
+// Kernels of a round: sssp_round_kernel (a wavefront per 1024 nodes: opens the flag words that can hold a near node,
+// relaxes lists of <= 32 edges flattened over its lanes, queues work items for the longer ones), sssp_chunk_kernel
+// (one wavefront per 256-edge item, whole grid; light / heavy split), sssp_far_kernel (the pending minimum, after a
+// phase's heavy round), sssp_advance_kernel.
 #include "common.hpp"
 #include "device_utils.hpp"
 
@@ -303,8 +306,9 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_round_kernel(const uint32_t *
         atomicOr(&ctrl[C_AGAIN], 1u);
 }
 
-// The deferred hub edges of the round that just ran: chunk (u, first edge) -> up to SSSP_CHUNK edges of u,
-// one wavefront per chunk, any wavefront of the grid.
+// The work items of the round that just ran: item (u, first edge) -> up to chunk_edges edges of u, one wavefront per
+// item, any wavefront of the grid; in a light round only the edges that land at or below the threshold are probed,
+// in a heavy round only the others.
 __global__ __launch_bounds__(SSSP_BLOCK) void sssp_chunk_kernel(const uint32_t *__restrict__ off,
                                                                 const uint32_t *__restrict__ tgt,
                                                                 const float *__restrict__ w, uint32_t *dist,
