@@ -589,7 +589,8 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
     unsigned round_grid = gm::div_up(ngroups, SSSP_BLOCK / kWave); // one node group per wavefront
     round_grid = round_grid > 256 * 16 ? 256 * 16 : round_grid;
     // Threshold step: starts at delta/32 and adapts to the work of each phase (sssp_advance_kernel): it doubles
-    // while a phase relaxes fewer than m/5 edges and halves beyond 3m/4.  Measured at RMAT scale 24, delta 0.1:
+    // while a phase relaxes fewer than m/5 edges (without an upper limit: on a long path with weights far above
+    // delta a capped step would move the threshold one node at a time) and halves beyond 3m/4.  Measured at RMAT scale 24, delta 0.1:
     // 2.0 x m relaxations in ~60 rounds, 32 ms; a fixed step of delta: 6.4 x m, 53 ms; fixed delta/16: 2.2 x m but
     // 500 rounds, 101 ms.  GM_SSSP_WIDTH=<fraction of delta> sets the first step, GM_SSSP_ADAPT="lo,hi" the band
     // in millions of edges ("0,0": fixed step).
@@ -656,7 +657,7 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
             hipLaunchKernelGGL(sssp_far_kernel, dim3(far_grid), dim3(SSSP_BLOCK), 0, st, wmin.as<uint32_t>(), nwords,
                                ctrl.as<uint32_t>());
             hipLaunchKernelGGL(sssp_advance_kernel, dim3(1), dim3(kWave), 0, st, ctrl.as<uint32_t>(), qs, adapt_lo, adapt_hi,
-                               delta / 1024.0f, delta * 16.0f);
+                               delta / 1024.0f, 1.0e30f);
         }
         GM_HIP(hipGetLastError());
         GM_HIP(hipMemcpyAsync(hctrl.p, ctrl.p, 64, hipMemcpyDeviceToHost, st));

@@ -478,6 +478,21 @@ def test_sssp_many_start_nodes_on_one_handle(P, oracle):
         assert np.array_equal(got, oracle.delta_stepping(off, tgt, wv, start, delta)), (start, delta)
 
 
+def test_sssp_long_path_with_weights_far_above_delta(P):
+    """A path whose edge weights are 10^4 x delta: the threshold step has to grow to the scale of the weights (it
+    doubles while phases stay small, without an upper limit) — a step capped near delta would move the threshold one
+    node per phase.  Distances are exact in f32 (multiples of 1000 below 2^24)."""
+    import time
+    n = 16000
+    edges = [(i, i + 1, 1000.0) for i in range(n - 1)] + [(0, n // 2, 1.0e7)]  # and one shortcut that never wins
+    g = P.GraphBuilder().csr_layout(P.CsrLayout.Sorted).edges_with_values(edges).build(P.DirectedCsrGraph)
+    t = time.perf_counter()
+    dist = P.delta_stepping(g, P.DeltaSteppingConfig(0, 0.1))
+    seconds = time.perf_counter() - t
+    assert np.array_equal(dist, (np.arange(n, dtype=np.float64) * 1000.0).astype(np.float32))
+    assert seconds < 5.0, seconds  # a few hundred rounds, not 16000 phases
+
+
 def test_sssp_rejects_negative_and_nan_weights_every_time(P):
     for bad in (-1.0, float("nan")):
         g = (P.GraphBuilder().csr_layout(P.CsrLayout.Sorted)
