@@ -1504,6 +1504,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     DevBuf keys, kalt;
     GM_TRY(keys.alloc((size_t)m_all * 8));
     GM_TRY(kalt.alloc((size_t)m_all * 8));
+    timer.done("pb plan: - key buffers (2 x %.1f GB)", (double)m_all * 8 / 1e9);
     const int hot_bit = bin_bits + sb; // the flag bit of a hot edge: the highest sorted bit
     {
         const size_t lds = H ? (size_t)filter_words * 4 : 0;
@@ -1517,6 +1518,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
                            pl->B, pl->G, keys.as<uint64_t>());
     }
     GM_HIP(hipGetLastError());
+    timer.done("pb plan: - edge keys");
     // the slot sits above the sorted bits (rocPRIM's radix sort was measured 14x slower with a non-zero BEGIN bit at
     // this size, so the unsorted field is at the top, not at the bottom)
     GM_TRY(sort_keys_u64(keys, kalt, m_all, 0, H ? hot_bit + 1 : hot_bit));
