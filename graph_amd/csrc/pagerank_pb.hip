@@ -331,6 +331,7 @@ __global__ void pb_hot_gather_kernel(const float *__restrict__ x_in, const uint3
 
 constexpr int PB_KEYS_BLOCK = 1024;
 constexpr int PB_FILTER_BITS = 20; // the hot-source block filter has at most 2^20 bits (128 KiB of LDS)
+constexpr int PB_FILTER_DEFAULT = 18; // measured at scale 26: 2^20 bits 14.2 ms, 2^19 12.1, 2^18 11.8, 2^17 12.4, 2^16 13.1
 
 __global__ __launch_bounds__(PB_KEYS_BLOCK) void pb_keys_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt,
                                                                uint32_t n, int rb, int sb, int bb,
@@ -377,8 +378,17 @@ __global__ __launch_bounds__(PB_KEYS_BLOCK) void pb_keys_kernel(const uint32_t *
             const uint32_t bs = __shfl(s, src, kWave), be = __shfl(e, src, kWave);
             const uint64_t bhi = __shfl(hi, src, kWave);
             const bool bhub = __shfl((int)hub, src, kWave) != 0;
-            for (uint32_t i = bs + lane; i < be; i += kWave)
-                keys[i] = pb_make_key(bhi, tgt[i], sb, bb, bhub ? nullptr : filter, fshift, hot_rank);
+            // four loads in flight per lane: one at a time left the long rows (most of the edges) waiting on each
+            for (uint32_t i = bs + lane; i < be; i += kWave * 4u) {
+                uint32_t t4[4];
+#pragma unroll
+                for (uint32_t q = 0; q < 4u; ++q)
+                    t4[q] = i + q * kWave < be ? tgt[i + q * kWave] : 0u;
+#pragma unroll
+                for (uint32_t q = 0; q < 4u; ++q)
+                    if (i + q * kWave < be)
+                        keys[i + q * kWave] = pb_make_key(bhi, t4[q], sb, bb, bhub ? nullptr : filter, fshift, hot_rank);
+            }
         }
     }
 }
@@ -1463,7 +1473,9 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     timer.done("pb plan: accumulator slots");
     // ---- hot sources: the H most frequent source ids (>= 2 edges) of this rank's edges ----------------
     DevBuf hot_rank, hot_blk;
-    const int fshift = sb > PB_FILTER_BITS ? sb - PB_FILTER_BITS : 0;
+    int filter_bits = pb_env("GM_PB_FILTER_BITS", PB_FILTER_DEFAULT); // log2 of the block filter's size in bits
+    filter_bits = filter_bits < 10 ? 10 : (filter_bits > PB_FILTER_BITS ? PB_FILTER_BITS : filter_bits);
+    const int fshift = sb > filter_bits ? sb - filter_bits : 0;
     const uint32_t filter_words = (uint32_t)(((x_len >> fshift) + 32) / 32);
     if (H) {
         DevBuf cnt, ckeys, calt, n_keys;
@@ -1477,7 +1489,9 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
         GM_HIP(hipMemset(n_keys.p, 0, 4));
         GM_HIP(hipMemset(hot_blk.p, 0, hot_blk.bytes));
         GM_HIP(hipMemset(hot_rank.p, 0xFF, (size_t)x_len * 2));
-        const uint32_t sample_step = m_all > (1u << 26) ? 8u : 1u;
+        // one edge in 32 beyond 2^28 edges (one in 8 beyond 2^26): a source of the hot set has thousands of edges, and
+        // the 134 M random atomics of a 1/8 sample were 6 ms of the plan at scale 26
+        const uint32_t sample_step = m_all > (1u << 28) ? 32u : m_all > (1u << 26) ? 8u : 1u;
         hipLaunchKernelGGL(pb_count_sources_kernel, dim3(pb_grid(m_all / sample_step + 1)), dim3(256), 0, 0, csr->targets,
                            m_all, sample_step, cnt.as<uint32_t>());
         hipLaunchKernelGGL(pb_count_keys_kernel, dim3(pb_grid(x_len)), dim3(256), 0, 0, cnt.as<uint32_t>(), (uint32_t)x_len,
