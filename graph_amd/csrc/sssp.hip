@@ -70,7 +70,8 @@ enum : int { R_ALL = 0, R_LIGHT = 1, R_HEAVY = 2 };
 constexpr int SSSP_MLP = 4;
 __device__ __forceinline__ void relax_range(const uint32_t *__restrict__ tgt, const float *__restrict__ w, uint32_t *dist,
                                             uint32_t *flags, uint32_t *wmin, float du, uint32_t first, uint32_t end,
-                                            uint32_t step, uint32_t thr, int which, RelaxOut &ro)
+                                            uint32_t step, uint32_t thr, int which, const uint32_t *__restrict__ settled,
+                                            RelaxOut &ro)
 {
     for (uint32_t i = first; i < end; i += step * SSSP_MLP) {
         uint32_t t[SSSP_MLP], nb[SSSP_MLP], pre[SSSP_MLP];
@@ -82,6 +83,19 @@ __device__ __forceinline__ void relax_range(const uint32_t *__restrict__ tgt, co
             nb[k] = in ? __float_as_uint(__fadd_rn(du, w[j])) : 0xFFFFFFFFu;
             if (which == R_LIGHT ? nb[k] > thr : which == R_HEAVY ? nb[k] <= thr : false)
                 nb[k] = 0xFFFFFFFFu;
+        }
+        if (which == R_HEAVY && settled) {
+            // a heavy candidate is beyond the threshold, and a target that was ever taken up had a distance at or below
+            // it: nothing to improve.  One bit per node (2 MB at scale 24: it stays in L2) instead of a probe of the
+            // 64 MB distance vector — after the phase that takes up most of the graph nearly every target is settled.
+            uint32_t bits[SSSP_MLP];
+#pragma unroll
+            for (int k = 0; k < SSSP_MLP; ++k)
+                bits[k] = nb[k] != 0xFFFFFFFFu ? settled[t[k] >> 5] : 0u;
+#pragma unroll
+            for (int k = 0; k < SSSP_MLP; ++k)
+                if ((bits[k] >> (t[k] & 31u)) & 1u)
+                    nb[k] = 0xFFFFFFFFu;
         }
 #pragma unroll
         for (int k = 0; k < SSSP_MLP; ++k)
@@ -133,9 +147,9 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_round_kernel(const uint32_t *
                                                                 const uint32_t *__restrict__ tgt,
                                                                 const float *__restrict__ w, uint32_t *dist,
                                                                 uint32_t *flags, uint32_t *wmin, uint32_t *hflags,
-                                                                uint32_t nwords, uint2 *__restrict__ chunks,
-                                                                QueueState *__restrict__ qs, uint32_t *ctrl,
-                                                                uint32_t chunk_edges, uint32_t coop)
+                                                                uint32_t *settled, uint32_t nwords,
+                                                                uint2 *__restrict__ chunks, QueueState *__restrict__ qs,
+                                                                uint32_t *ctrl, uint32_t chunk_edges, uint32_t coop)
 {
     __shared__ uint16_t list[SSSP_BLOCK / kWave][SSSP_GROUP];          // node - first node of the group
     __shared__ uint8_t owner[SSSP_BLOCK / kWave][kWave * SSSP_COOP];    // short-list edge slot -> lane holding its node
@@ -189,8 +203,11 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_round_kernel(const uint32_t *
             }
             if (keep_far != NO_BUCKET)
                 atomicMin(&wmin[my_word], keep_far);
-            if (near)
+            if (near) {
                 atomicAnd(&flags[my_word], ~(near << sh));
+                if ((ld_agent(&settled[my_word]) & (near << sh)) != (near << sh))
+                    atomicOr(&settled[my_word], near << sh); // taken up = at or below the threshold, now and for ever
+            }
             sssp_drain(); // cleared before anyone reads the distances the relaxation uses
         }
         uint32_t cnt = (uint32_t)__popc(near), pre = cnt; // inclusive prefix of the lanes' counts
@@ -313,6 +330,7 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_chunk_kernel(const uint32_t *
                                                                 const uint32_t *__restrict__ tgt,
                                                                 const float *__restrict__ w, uint32_t *dist,
                                                                 uint32_t *flags, uint32_t *wmin,
+                                                                const uint32_t *__restrict__ settled,
                                                                 const uint2 *__restrict__ chunks,
                                                                 const QueueState *__restrict__ qs, uint32_t *ctrl,
                                                                 uint32_t chunk_edges)
@@ -345,7 +363,7 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_chunk_kernel(const uint32_t *
         const float du = __uint_as_float(ld_agent(&dist[ch.x]));
         const uint32_t end_u = off[ch.x + 1];
         const uint32_t end = ch.y + chunk_edges < end_u ? ch.y + chunk_edges : end_u;
-        relax_range(tgt, w, dist, flags, wmin, du, ch.y + lane, end, kWave, thr, heavy ? R_HEAVY : R_LIGHT, ro);
+        relax_range(tgt, w, dist, flags, wmin, du, ch.y + lane, end, kWave, thr, heavy ? R_HEAVY : R_LIGHT, settled, ro);
     }
     if (__ballot(ro.again != 0) && lane == 0 && !ld_agent(&ctrl[C_AGAIN]))
         atomicOr(&ctrl[C_AGAIN], 1u);
@@ -571,13 +589,15 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
         GM_TRY(sc->flags.alloc(((size_t)nwords + kWave) * 4));
         GM_TRY(sc->wmin.alloc(((size_t)nwords + kWave) * 4));
         GM_TRY(sc->hflags.alloc(((size_t)nwords + kWave) * 4));
+        GM_TRY(sc->settled.alloc(((size_t)nwords + kWave) * 4));
         GM_TRY(sc->ctrl.alloc(64));
         GM_TRY(sc->queues.alloc(sizeof(QueueState)));
         GM_TRY(sc->hctrl.alloc(64));
         GM_TRY(sc->chunks.alloc(items * sizeof(uint2)));
         sc->items = items;
     }
-    gm::DevBuf &dist = sc->dist, &flags = sc->flags, &wmin = sc->wmin, &hflags = sc->hflags, &ctrl = sc->ctrl,
+    gm::DevBuf &dist = sc->dist, &flags = sc->flags, &wmin = sc->wmin, &hflags = sc->hflags, &settled = sc->settled,
+               &ctrl = sc->ctrl,
                &chunks = sc->chunks;
     QueueState *qs = sc->queues.as<QueueState>();
     gm::PinnedBuf &hctrl = sc->hctrl;
@@ -624,6 +644,7 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
                        (uint32_t)start_node);
     GM_HIP(hipMemsetAsync(flags.p, 0, flags.bytes, st));
     GM_HIP(hipMemsetAsync(hflags.p, 0, hflags.bytes, st));
+    GM_HIP(hipMemsetAsync(settled.p, 0, settled.bytes, st));
     GM_HIP(hipMemsetAsync(qs, 0, sizeof(QueueState), st));
     hipLaunchKernelGGL(sssp_caps_kernel, dim3(round_grid), dim3(SSSP_BLOCK), 0, st, g->offsets, n, ngroups, qs, chunk_edges,
                        coop);
@@ -642,18 +663,20 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
     const double ms_setup = since(t_call);
     unsigned far_grid = gm::div_up(nwords, SSSP_BLOCK * 8);
     far_grid = far_grid > 256 ? 256 : far_grid;
+    const bool use_settled = getenv("GM_SSSP_SETTLED") == nullptr || atoi(getenv("GM_SSSP_SETTLED")) != 0;
     const bool stats = getenv("GM_SSSP_STATS") != nullptr;
     const int batch = stats ? 1 : 8; // rounds enqueued per host synchronisation
     auto t_prev = std::chrono::steady_clock::now();
     for (;;) {
         for (int k = 0; k < batch; ++k) {
             hipLaunchKernelGGL(sssp_round_kernel, dim3(round_grid), dim3(SSSP_BLOCK), 0, st, g->offsets, g->targets, g->weights,
-                               dist.as<uint32_t>(), flags.as<uint32_t>(), wmin.as<uint32_t>(), hflags.as<uint32_t>(), nwords,
+                               dist.as<uint32_t>(), flags.as<uint32_t>(), wmin.as<uint32_t>(), hflags.as<uint32_t>(),
+                               settled.as<uint32_t>(), nwords,
                                chunks.as<uint2>(), qs,
                                ctrl.as<uint32_t>(), chunk_edges, coop);
             hipLaunchKernelGGL(sssp_chunk_kernel, dim3(grid), dim3(SSSP_BLOCK), 0, st, g->offsets, g->targets, g->weights,
-                               dist.as<uint32_t>(), flags.as<uint32_t>(), wmin.as<uint32_t>(), chunks.as<uint2>(), qs,
-                               ctrl.as<uint32_t>(), chunk_edges);
+                               dist.as<uint32_t>(), flags.as<uint32_t>(), wmin.as<uint32_t>(), use_settled ? settled.as<uint32_t>() : (const uint32_t *)nullptr,
+                               chunks.as<uint2>(), qs, ctrl.as<uint32_t>(), chunk_edges);
             hipLaunchKernelGGL(sssp_far_kernel, dim3(far_grid), dim3(SSSP_BLOCK), 0, st, wmin.as<uint32_t>(), nwords,
                                ctrl.as<uint32_t>());
             hipLaunchKernelGGL(sssp_advance_kernel, dim3(1), dim3(kWave), 0, st, ctrl.as<uint32_t>(), qs, adapt_lo, adapt_hi,
