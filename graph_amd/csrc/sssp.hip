@@ -18,13 +18,13 @@
 //     distance + width) — the role of the reference's min_non_empty_bin (sssp.rs:159-168); `delta` only
 //     seeds the schedule (first step delta/32, then adapted to the work of each phase, see
 //     gm_sssp_delta_stepping) and never changes the result;
-//   * the bucket bookkeeping lives on the device (sssp_advance_kernel): the host enqueues rounds in
+//   * the bucket bookkeeping lives on the device (sssp_finish_kernel): the host enqueues rounds in
 //     batches and reads one flag per batch instead of synchronising after every round;
 //   * INF = f32::MAX (sssp.rs:12), never +inf.
 // Kernels of a round: sssp_round_kernel (a wavefront per 1024 nodes: opens the flag words that can hold a near node,
 // relaxes lists of <= 32 edges flattened over its lanes, queues work items for the longer ones), sssp_chunk_kernel
-// (one wavefront per 256-edge item, whole grid; light / heavy split), sssp_far_kernel (the pending minimum, after a
-// phase's heavy round), sssp_advance_kernel.
+// (one wavefront per 256-edge item, whole grid; light / heavy split), sssp_finish_kernel (the pending minimum after a
+// phase's heavy round, then the threshold bookkeeping).
 #include "common.hpp"
 #include "device_utils.hpp"
 
@@ -110,7 +110,7 @@ __device__ __forceinline__ void relax_range(const uint32_t *__restrict__ tgt, co
 enum : uint32_t { C_AGAIN = 0, C_FAR = 1, C_BAD = 2, C_THR = 3, C_DONE = 4, C_ROUND = 5, C_ADVANCES = 6,
                   C_WORK = 7 /* relaxed edges / 64, statistics */, C_HEAVY = 8 /* 1: this round is a phase's heavy round */,
                   C_WIDTH = 9 /* f32 bits: current threshold step */,
-                  C_MARK = 10 /* C_WORK at the last advance */ };
+                  C_MARK = 10 /* C_WORK at the last advance */, C_TICKET = 11 /* workgroups of sssp_finish_kernel done */ };
 
 // The work-item queue of a round is SSSP_QUEUES sub-queues, node group g appending to sub-queue g % SSSP_QUEUES:
 // each has its own 64-bit counter (low half: items queued this round, high half: out-edges of the nodes taken up — the
@@ -369,34 +369,6 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_chunk_kernel(const uint32_t *
         atomicOr(&ctrl[C_AGAIN], 1u);
 }
 
-// When the round left nothing at or below the threshold: the minimum pending distance = the minimum of the word
-// bounds (every flagged node has its word's bound at or below its distance once the round's atomics have landed;
-// a bound may be stale-low, the next round then opens that word and tightens it).  Thousands of wavefronts each
-// folding their own minimum into one ctrl word was ~0.1 ms of every round.
-__global__ __launch_bounds__(SSSP_BLOCK) void sssp_far_kernel(const uint32_t *__restrict__ wmin, uint32_t nwords,
-                                                              uint32_t *ctrl)
-{
-    __shared__ uint32_t part[SSSP_BLOCK / kWave];
-    if (ld_agent(&ctrl[C_DONE]) || !ld_agent(&ctrl[C_HEAVY]))
-        return;
-    uint32_t lo = NO_BUCKET;
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += stride) {
-        const uint32_t v = ld_agent(&wmin[i]);
-        lo = v < lo ? v : lo;
-    }
-    lo = wave_min(lo);
-    if ((threadIdx.x & (kWave - 1)) == 0)
-        part[threadIdx.x >> 6] = lo;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int k = 1; k < SSSP_BLOCK / kWave; ++k)
-            lo = part[k] < lo ? part[k] : lo;
-        if (lo != NO_BUCKET)
-            atomicMin(&ctrl[C_FAR], lo);
-    }
-}
-
 // Once per call: the capacity of every sub-queue = the items its node groups queue when all their nodes are taken
 // up in one round, then the sub-queues' first slots.
 __global__ __launch_bounds__(SSSP_BLOCK) void sssp_caps_kernel(const uint32_t *__restrict__ off, uint32_t n, uint32_t ngroups,
@@ -432,17 +404,16 @@ __global__ void sssp_qstart_kernel(QueueState *qs)
 // adapt_lo / adapt_hi (units of 64 relaxed edges; 0 = fixed width): the step halves when the phase that
 // just ended relaxed more than adapt_hi and doubles when it relaxed less than adapt_lo, within
 // [width_min, width_max] — coarse steps re-relax every edge ~6 times, fine steps leave the chip idle.
-__global__ void sssp_advance_kernel(uint32_t *ctrl, QueueState *qs, uint32_t adapt_lo, uint32_t adapt_hi, float width_min,
-                                    float width_max)
+__device__ void sssp_advance(uint32_t *ctrl, QueueState *qs, uint32_t adapt_lo, uint32_t adapt_hi, float width_min,
+                             float width_max)
 {
-    if (ctrl[C_DONE])
-        return;
     // 64 threads: thread q reads and clears sub-queue q's counter; thread 0 does the rest
     const uint64_t round_work = wave_sum((uint64_t)(qs->ctr[threadIdx.x * SSSP_QSTRIDE] >> 32));
     qs->ctr[threadIdx.x * SSSP_QSTRIDE] = 0ull;
     if (threadIdx.x != 0)
         return;
     ctrl[C_WORK] += (uint32_t)((round_work + 63u) >> 6);
+    const uint32_t far = ld_agent(&ctrl[C_FAR]); // folded in by other workgroups of this launch: not through L1
     if (!ctrl[C_HEAVY]) {
         if (!ctrl[C_AGAIN])
             ctrl[C_HEAVY] = 1u; // the phase has run dry: next, the heavy round of the nodes it took up
@@ -450,7 +421,7 @@ __global__ void sssp_advance_kernel(uint32_t *ctrl, QueueState *qs, uint32_t ada
         ctrl[C_HEAVY] = 0u;
         if (ctrl[C_AGAIN]) {
             // cannot happen (a heavy round only writes distances beyond the threshold); if it did, the phase goes on
-        } else if (ctrl[C_FAR] == NO_BUCKET) {
+        } else if (far == NO_BUCKET) {
             ctrl[C_DONE] = 1u;
         } else {
             float width = __uint_as_float(ctrl[C_WIDTH]);
@@ -463,9 +434,9 @@ __global__ void sssp_advance_kernel(uint32_t *ctrl, QueueState *qs, uint32_t ada
                 ctrl[C_WIDTH] = __float_as_uint(width);
                 ctrl[C_MARK] = ctrl[C_WORK];
             }
-            const float next = __fadd_rn(__uint_as_float(ctrl[C_FAR]), width);
+            const float next = __fadd_rn(__uint_as_float(far), width);
             uint32_t nb = __float_as_uint(next);
-            nb = nb > ctrl[C_FAR] && next < 3.0e38f ? nb : ctrl[C_FAR]; // always covers the pending minimum
+            nb = nb > far && next < 3.0e38f ? nb : far; // always covers the pending minimum
             ctrl[C_THR] = nb > ctrl[C_THR] ? nb : ctrl[C_THR];         // (a stale-low word bound never moves it back)
             ctrl[C_ADVANCES] += 1u;
         }
@@ -473,6 +444,52 @@ __global__ void sssp_advance_kernel(uint32_t *ctrl, QueueState *qs, uint32_t ada
     ctrl[C_AGAIN] = 0u;
     ctrl[C_FAR] = NO_BUCKET;
     ctrl[C_ROUND] += 1u;
+}
+
+// The tail of a round, one launch: after a phase's heavy round every workgroup folds its share of the word bounds into
+// the pending minimum (every flagged node has its word's bound at or below its distance once the round's atomics have
+// landed; a bound may be stale-low, the next round then opens that word and tightens it) and the last one to finish
+// moves the threshold; after a light round workgroup 0 does the bookkeeping alone.  (Thousands of wavefronts each
+// folding their own minimum into one ctrl word was ~0.1 ms of every round; a separate launch for the bookkeeping ~4 us.)
+__global__ __launch_bounds__(SSSP_BLOCK) void sssp_finish_kernel(const uint32_t *__restrict__ wmin, uint32_t nwords,
+                                                                 uint32_t *ctrl, QueueState *qs, uint32_t adapt_lo,
+                                                                 uint32_t adapt_hi, float width_min, float width_max)
+{
+    __shared__ uint32_t part[SSSP_BLOCK / kWave];
+    __shared__ uint32_t last;
+    if (ld_agent(&ctrl[C_DONE]))
+        return;
+    if (!ld_agent(&ctrl[C_HEAVY])) {
+        if (blockIdx.x == 0 && threadIdx.x < kWave)
+            sssp_advance(ctrl, qs, adapt_lo, adapt_hi, width_min, width_max);
+        return;
+    }
+    uint32_t lo = NO_BUCKET;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += stride) {
+        const uint32_t v = ld_agent(&wmin[i]);
+        lo = v < lo ? v : lo;
+    }
+    lo = wave_min(lo);
+    if ((threadIdx.x & (kWave - 1)) == 0)
+        part[threadIdx.x >> 6] = lo;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < SSSP_BLOCK / kWave; ++k)
+            lo = part[k] < lo ? part[k] : lo;
+        if (lo != NO_BUCKET)
+            atomicMin(&ctrl[C_FAR], lo);
+        __threadfence();
+        last = atomicAdd(&ctrl[C_TICKET], 1u) == gridDim.x - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!last)
+        return;
+    if (threadIdx.x == 0)
+        st_agent(&ctrl[C_TICKET], 0u);
+    __threadfence();
+    if (threadIdx.x < kWave)
+        sssp_advance(ctrl, qs, adapt_lo, adapt_hi, width_min, width_max);
 }
 
 // Partitioned building block: relax every out-edge of the slice's rows whose distance is finite
@@ -608,7 +625,7 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
     const uint32_t ngroups = gm::div_up((uint64_t)nwords * 2u, (uint64_t)kWave);
     unsigned round_grid = gm::div_up(ngroups, SSSP_BLOCK / kWave); // one node group per wavefront
     round_grid = round_grid > 256 * 16 ? 256 * 16 : round_grid;
-    // Threshold step: starts at delta/32 and adapts to the work of each phase (sssp_advance_kernel): it doubles
+    // Threshold step: starts at delta/32 and adapts to the work of each phase (sssp_advance): it doubles
     // while a phase relaxes fewer than m/5 edges (without an upper limit: on a long path with weights far above
     // delta a capped step would move the threshold one node at a time) and halves beyond 3m/4.  Measured at RMAT scale 24, delta 0.1:
     // 2.0 x m relaxations in ~60 rounds, 32 ms; a fixed step of delta: 6.4 x m, 53 ms; fixed delta/16: 2.2 x m but
@@ -677,10 +694,8 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
             hipLaunchKernelGGL(sssp_chunk_kernel, dim3(grid), dim3(SSSP_BLOCK), 0, st, g->offsets, g->targets, g->weights,
                                dist.as<uint32_t>(), flags.as<uint32_t>(), wmin.as<uint32_t>(), use_settled ? settled.as<uint32_t>() : (const uint32_t *)nullptr,
                                chunks.as<uint2>(), qs, ctrl.as<uint32_t>(), chunk_edges);
-            hipLaunchKernelGGL(sssp_far_kernel, dim3(far_grid), dim3(SSSP_BLOCK), 0, st, wmin.as<uint32_t>(), nwords,
-                               ctrl.as<uint32_t>());
-            hipLaunchKernelGGL(sssp_advance_kernel, dim3(1), dim3(kWave), 0, st, ctrl.as<uint32_t>(), qs, adapt_lo, adapt_hi,
-                               delta / 1024.0f, 1.0e30f);
+            hipLaunchKernelGGL(sssp_finish_kernel, dim3(far_grid), dim3(SSSP_BLOCK), 0, st, wmin.as<uint32_t>(), nwords,
+                               ctrl.as<uint32_t>(), qs, adapt_lo, adapt_hi, delta / 1024.0f, 1.0e30f);
         }
         GM_HIP(hipGetLastError());
         GM_HIP(hipMemcpyAsync(hctrl.p, ctrl.p, 64, hipMemcpyDeviceToHost, st));
