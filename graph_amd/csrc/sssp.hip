@@ -626,8 +626,8 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
     unsigned round_grid = gm::div_up(ngroups, SSSP_BLOCK / kWave); // one node group per wavefront
     round_grid = round_grid > 256 * 16 ? 256 * 16 : round_grid;
     // Threshold step: starts at delta/32 and adapts to the work of each phase (sssp_advance): it doubles
-    // while a phase relaxes fewer than m/5 edges (without an upper limit: on a long path with weights far above
-    // delta a capped step would move the threshold one node at a time) and halves beyond 3m/4.  Measured at RMAT scale 24, delta 0.1:
+    // while a phase streams fewer than 3m/4 edges (without an upper limit: on a long path with weights far above
+    // delta a capped step would move the threshold one node at a time) and halves beyond 3m.  Measured at RMAT scale 24, delta 0.1:
     // 2.0 x m relaxations in ~60 rounds, 32 ms; a fixed step of delta: 6.4 x m, 53 ms; fixed delta/16: 2.2 x m but
     // 500 rounds, 101 ms.  GM_SSSP_WIDTH=<fraction of delta> sets the first step, GM_SSSP_ADAPT="lo,hi" the band
     // in millions of edges ("0,0": fixed step).
@@ -637,7 +637,9 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
     if (!(frac > 0.0f))
         frac = 1.0f / 32.0f;
     const float width = delta * frac;
-    uint32_t adapt_lo = (uint32_t)(g->m / 5 / 64), adapt_hi = (uint32_t)(g->m / 4 * 3 / 64) + 1u;
+    // (work = edges streamed by the phase, light re-streams included: 0.75 m .. 3 m measured best at scale 24,
+    //  9.2 vs 9.4 ms for m/5 .. 3m/4, the band of the round kernels that probed every streamed edge)
+    uint32_t adapt_lo = (uint32_t)(g->m / 4 * 3 / 64), adapt_hi = (uint32_t)((g->m / 64) * 3) + 1u;
     if (const char *v = getenv("GM_SSSP_ADAPT")) {
         double lo = 0, hi = 0;
         if (sscanf(v, "%lf,%lf", &lo, &hi) == 2 && lo >= 0) {
