@@ -248,7 +248,8 @@ __global__ void tc_item_rows_kernel(const uint32_t *__restrict__ item_first, uin
             item_row[i] = v;
 }
 
-template <int BLOCK /* threads per work item */, uint32_t GROUP /* lanes per u */, uint32_t MLP /* loads in flight per lane */>
+template <int BLOCK /* threads per work item */, uint32_t GROUP /* lanes per u */, uint32_t MLP /* loads in flight per lane */,
+          uint32_t UB /* lists a group has in flight */>
 __global__ __launch_bounds__(BLOCK) void tc_rows_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt,
                                                             const uint32_t *__restrict__ low_len,
                                                             const uint32_t *__restrict__ loff,
@@ -299,8 +300,8 @@ __global__ __launch_bounds__(BLOCK) void tc_rows_kernel(const uint32_t *__restri
             }
         }
     };
-    constexpr uint32_t UB = 4; // u's a group has in flight: id -> list header -> first line are three dependent round
-                               // trips, and one u at a time left the kernel waiting on them (4.5 us per u and group)
+    // UB lists per group in flight: id -> list record -> rest of the list are dependent round trips, and one u at a
+    // time left the kernel waiting on them (4.5 us per u and group)
     static_assert(GROUP == 8 || GROUP == 16 || GROUP == 32, "a record is 128 bytes: 16, 8 or 4 per lane");
     constexpr uint32_t RW = 32u / GROUP;  // 4-byte words of a record per lane
     constexpr uint32_t IPL = 64u / GROUP; // 2-byte positions per lane; the first 8 positions are the header
@@ -592,40 +593,60 @@ GM_API int gm_triangle_count(const gm_csr *g, uint64_t *triangles_out)
         // most of the work) are not held to the occupancy of the 64 KiB rows at the far end.
         // GM_TC_SHAPE="<threads per item>,<lanes per u>,<loads in flight>" picks another instantiation (measurements)
         const uint32_t dyn = getenv("GM_TC_DYN") ? (uint32_t)atoi(getenv("GM_TC_DYN")) : 1u;
-        int shape_b = 512, shape_g = 8, shape_m = 4; // measured best at scale 24: 44.3 ms (1024 x 16: 49.6, 256 x 16: 49.3)
+        // measured best at scale 24 (1024 x 16: +12 %, 256 x 16: +11 %; four lists per draw: 45.9 ms against 39.3 for one —
+        // with the lists drawn from the counter the balance is worth more than the overlap of the dependent loads)
+        int shape_b = 512, shape_g = 8, shape_m = 4, shape_u = 1;
         if (const char *e = getenv("GM_TC_SHAPE"))
-            (void)sscanf(e, "%d,%d,%d", &shape_b, &shape_g, &shape_m);
+            (void)sscanf(e, "%d,%d,%d,%d", &shape_b, &shape_g, &shape_m, &shape_u);
         for (uint32_t v_lo = 0; v_lo < K;) {
             uint32_t v_hi = v_lo < (1u << 14) ? (1u << 14) : v_lo * 2u;
             v_hi = v_hi < K ? v_hi : K;
             const uint32_t n_items = first_host[v_hi] - first_host[v_lo];
             const size_t lds = (size_t)((v_hi + 31u) / 32u) * 4;
             if (n_items) {
-#define GM_TC_ROWS(B_, G_, M_)                                                                                          \
+#define GM_TC_ROWS(B_, G_, M_, U_)                                                                                      \
     do {                                                                                                                \
-        GM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tc_rows_kernel<B_, G_, M_>),                         \
+        GM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tc_rows_kernel<B_, G_, M_, U_>),                     \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, TCR_K_MAX / 8));                         \
-        hipLaunchKernelGGL((tc_rows_kernel<B_, G_, M_>), dim3(n_items), dim3(B_), lds, 0, g->offsets, g->targets,       \
+        hipLaunchKernelGGL((tc_rows_kernel<B_, G_, M_, U_>), dim3(n_items), dim3(B_), lds, 0, g->offsets, g->targets,   \
                            low_len.as<uint32_t>(), loff.as<uint32_t>(), rec.as<uint4>(), dag_tgt.as<uint32_t>(),       \
                            dag16.as<uint16_t>(), item_first.as<uint32_t>(), item_row.as<uint32_t>(), first_host[v_lo],  \
                            per_item, dyn, d_total);                                                                     \
     } while (0)
                 if (shape_b == 1024 && shape_g == 16)
-                    GM_TC_ROWS(1024, 16, 4);
-                else if (shape_b == 1024 && shape_g == 8)
-                    GM_TC_ROWS(1024, 8, 4);
-                else if (shape_b == 512 && shape_g == 16)
-                    GM_TC_ROWS(512, 16, 4);
+                    GM_TC_ROWS(1024, 16, 4, 4);
+                else if (shape_b == 1024 && shape_g == 8 && shape_u == 4)
+                    GM_TC_ROWS(1024, 8, 4, 4);
+                else if (shape_b == 512 && shape_g == 16 && shape_u == 4)
+                    GM_TC_ROWS(512, 16, 4, 4);
                 else if (shape_b == 256 && shape_g == 16)
-                    GM_TC_ROWS(256, 16, 4);
-                else if (shape_b == 256 && shape_g == 8)
-                    GM_TC_ROWS(256, 8, 4);
+                    GM_TC_ROWS(256, 16, 4, 4);
+                else if (shape_b == 256 && shape_g == 8 && shape_u == 4)
+                    GM_TC_ROWS(256, 8, 4, 4);
                 else if (shape_b == 128 && shape_g == 8)
-                    GM_TC_ROWS(128, 8, 4);
-                else if (shape_b == 128 && shape_g == 16)
-                    GM_TC_ROWS(128, 16, 4);
+                    GM_TC_ROWS(128, 8, 4, 4);
+                else if (shape_b == 512 && shape_g == 8 && shape_m == 4 && shape_u == 8)
+                    GM_TC_ROWS(512, 8, 4, 8);
+                else if (shape_b == 512 && shape_g == 8 && shape_m == 8 && shape_u == 4)
+                    GM_TC_ROWS(512, 8, 8, 4);
+                else if (shape_b == 512 && shape_g == 8 && shape_m == 8 && shape_u == 8)
+                    GM_TC_ROWS(512, 8, 8, 8);
+                else if (shape_b == 512 && shape_g == 8 && shape_m == 4 && shape_u == 2)
+                    GM_TC_ROWS(512, 8, 4, 2);
+                else if (shape_b == 512 && shape_g == 8 && shape_m == 4 && shape_u == 1)
+                    GM_TC_ROWS(512, 8, 4, 1);
+                else if (shape_b == 512 && shape_g == 8 && shape_m == 4 && shape_u == 3)
+                    GM_TC_ROWS(512, 8, 4, 3);
+                else if (shape_b == 512 && shape_g == 16 && shape_u == 2)
+                    GM_TC_ROWS(512, 16, 4, 2);
+                else if (shape_b == 1024 && shape_g == 8 && shape_u == 2)
+                    GM_TC_ROWS(1024, 8, 4, 2);
+                else if (shape_b == 256 && shape_g == 8 && shape_u == 2)
+                    GM_TC_ROWS(256, 8, 4, 2);
+                else if (shape_b == 512 && shape_g == 8 && shape_m == 4 && shape_u == 4)
+                    GM_TC_ROWS(512, 8, 4, 4);
                 else
-                    GM_TC_ROWS(512, 8, 4);
+                    GM_TC_ROWS(512, 8, 4, 1);
 #undef GM_TC_ROWS
             }
             v_lo = v_hi;

@@ -547,7 +547,8 @@ def test_triangle_count_vs_oracle(P, oracle, layout, relabel):
 
 
 @pytest.mark.parametrize("knobs", [{"GM_TC_K": "0"}, {"GM_TC_K": "1"}, {"GM_TC_K": "100"}, {"GM_TC_K": "5000", "GM_TC_ITEM": "64"},
-                                   {"GM_TC_ITEM": "100000"}, {"GM_TC_SHAPE": "256,8,4"}, {"GM_TC_SHAPE": "1024,16,4"},
+                                   {"GM_TC_ITEM": "100000"}, {"GM_TC_SHAPE": "256,8,4,4"}, {"GM_TC_SHAPE": "1024,16,4,4"}, {"GM_TC_SHAPE": "512,8,4,4"},
+                                   {"GM_TC_SHAPE": "512,8,8,8"}, {"GM_TC_SHAPE": "512,16,4,2"},
                                    {"GM_TC_SHAPE": "128,8,4", "GM_TC_K": "3000"}, {"GM_TC_SHAPE": "256,16,4", "GM_TC_ITEM": "256"}, {"GM_TC_DYN": "0"},
                                    {"GM_TC_DYN": "0", "GM_TC_SHAPE": "1024,8,4", "GM_TC_ITEM": "64"}])
 @pytest.mark.parametrize("relabel", [False, True])
