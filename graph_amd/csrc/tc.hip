@@ -645,6 +645,14 @@ GM_API int gm_triangle_count(const gm_csr *g, uint64_t *triangles_out)
                     GM_TC_ROWS(256, 8, 4, 2);
                 else if (shape_b == 512 && shape_g == 8 && shape_m == 4 && shape_u == 4)
                     GM_TC_ROWS(512, 8, 4, 4);
+                else if (shape_b == 256 && shape_g == 8 && shape_u == 1)
+                    GM_TC_ROWS(256, 8, 4, 1);
+                else if (shape_b == 1024 && shape_g == 8 && shape_u == 1)
+                    GM_TC_ROWS(1024, 8, 4, 1);
+                else if (shape_b == 512 && shape_g == 16 && shape_u == 1)
+                    GM_TC_ROWS(512, 16, 4, 1);
+                else if (shape_b == 512 && shape_g == 8 && shape_m == 8 && shape_u == 1)
+                    GM_TC_ROWS(512, 8, 8, 1);
                 else
                     GM_TC_ROWS(512, 8, 4, 1);
 #undef GM_TC_ROWS
