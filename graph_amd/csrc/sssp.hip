@@ -108,7 +108,7 @@ __device__ __forceinline__ void relax_range(const uint32_t *__restrict__ tgt, co
 
 // ctrl words shared by the kernels of a round
 enum : uint32_t { C_AGAIN = 0, C_FAR = 1, C_BAD = 2, C_THR = 3, C_DONE = 4, C_ROUND = 5, C_ADVANCES = 6,
-                  C_WORK = 7 /* relaxed edges / 64, statistics */, C_HEAVY = 8 /* 1: this round is a phase's heavy round */,
+                  C_WORK = 7 /* edges streamed so far / 64: drives the schedule */, C_HEAVY = 8 /* 1: this round is a phase's heavy round */,
                   C_WIDTH = 9 /* f32 bits: current threshold step */,
                   C_MARK = 10 /* C_WORK at the last advance */, C_TICKET = 11 /* workgroups of sssp_finish_kernel done */ };
 
@@ -129,7 +129,7 @@ struct QueueState {
 // flags a node lowers it, the scanner resets it and puts back what it leaves flagged.  A wavefront takes 32 words
 // (1024 consecutive nodes, 16 per lane) at a time; only words that can hold a node at or below the threshold are
 // opened (all at once), their near nodes cleared and collected in an LDS list.  Lists of up to `coop` edges are
-// then relaxed by their own lane, all edges at once.  Everything longer leaves the wavefront: one work item per
+// then relaxed inside the wavefront, all their edges, flattened over its lanes.  Everything longer leaves the wavefront: one work item per
 // chunk_edges edges in a queue that sssp_chunk_kernel spreads over the whole grid (relaxing the 33..2048-edge lists
 // here, one after the other by the whole wavefront, made the few node groups that hold the high-degree nodes — the
 // low ids of an RMAT graph — the critical path of every round), and those lists are relaxed in two parts: while
