@@ -1,6 +1,6 @@
 #!/bin/bash
-# round 2, GPU call 53: timeline of the kernels of a few PageRank sweeps (gaps between bin / accumulate / hub)
-OUT=gpurun_out/r02az; mkdir -p $OUT; export TMPDIR=/tmp
+# round 2, GPU call 67 (scale 22): timeline of the kernels of a few PageRank sweeps (gaps between bin / accumulate / hub)
+OUT=gpurun_out/r02bn; mkdir -p $OUT; export TMPDIR=/tmp
 timeout -s KILL 300 rocprofv3 --kernel-trace -d $OUT/kt -o kt -f csv -- python bench.py --cpu-sweeps 0 --steps 6 --warmup 3 ${BENCH_ARGS} > $OUT/kt.log 2>&1
 grep -a '^{' $OUT/kt.log | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('ms_per_step', d['ms_per_step'])"
 python - <<PY
