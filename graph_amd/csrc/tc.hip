@@ -596,6 +596,14 @@ GM_API int gm_triangle_count(const gm_csr *g, uint64_t *triangles_out)
         // measured best at scale 24 (1024 x 16: +12 %, 256 x 16: +11 %; four lists per draw: 45.9 ms against 39.3 for one —
         // with the lists drawn from the counter the balance is worth more than the overlap of the dependent loads)
         int shape_b = 512, shape_g = 8, shape_m = 4, shape_u = 1;
+        // GM_TC_HUB="<rows>,<lists per draw>": the launches of rows below <rows> draw that many lists at a time (their
+        // fronts are all short, so there is nothing to balance; measured at scale 24: 2, 4 or 8 lists per draw for the
+        // rows below 16384 or 65536 change nothing, 39.7-40.7 ms against 40.1: those 143 M visits are not waiting on
+        // their own dependent loads either)
+        uint32_t hub_rows_hi = 0;
+        int hub_ub = 1;
+        if (const char *e = getenv("GM_TC_HUB"))
+            (void)sscanf(e, "%u,%d", &hub_rows_hi, &hub_ub);
         if (const char *e = getenv("GM_TC_SHAPE"))
             (void)sscanf(e, "%d,%d,%d,%d", &shape_b, &shape_g, &shape_m, &shape_u);
         for (uint32_t v_lo = 0; v_lo < K;) {
@@ -653,6 +661,12 @@ GM_API int gm_triangle_count(const gm_csr *g, uint64_t *triangles_out)
                     GM_TC_ROWS(512, 16, 4, 1);
                 else if (shape_b == 512 && shape_g == 8 && shape_m == 8 && shape_u == 1)
                     GM_TC_ROWS(512, 8, 8, 1);
+                else if (v_hi <= hub_rows_hi && hub_ub == 4)
+                    GM_TC_ROWS(512, 8, 4, 4); // hub rows: every front is short, nothing to balance, overlap the loads
+                else if (v_hi <= hub_rows_hi && hub_ub == 2)
+                    GM_TC_ROWS(512, 8, 4, 2);
+                else if (v_hi <= hub_rows_hi && hub_ub == 8)
+                    GM_TC_ROWS(512, 8, 4, 8);
                 else
                     GM_TC_ROWS(512, 8, 4, 1);
 #undef GM_TC_ROWS
