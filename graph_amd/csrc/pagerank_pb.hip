@@ -976,7 +976,7 @@ __global__ __launch_bounds__(PB_ACC_BLOCK, 8) void pb_hub_kernel(const float *__
                                                               const uint32_t *__restrict__ hub_rows,
                                                               const uint32_t *__restrict__ outdeg, float *__restrict__ scores,
                                                               float *__restrict__ x_out, double *__restrict__ group_err,
-                                                              float base, float damping)
+                                                              float base, float damping, uint32_t long2, uint32_t long4)
 {
     // per step and row: the sum of the step's terms rounded at ulp(S) [0] and at 2 ulp(S) [1], in R replicas
     // (lane mod R) so that the LDS atomics of a wavefront spread over ~64 addresses; three steps in rotation
@@ -1149,9 +1149,16 @@ __global__ __launch_bounds__(PB_ACC_BLOCK, 8) void pb_hub_kernel(const float *__
     // A step is one block (4096 entries) for groups of one or two rows — their rows see thousands of terms per
     // block — and two blocks for the others (a row of a 30-row group sees ~270 terms in 8192 entries): the
     // barrier and the bookkeeping are paid half as often.  The kernel is bound by instruction issue (measured:
-    // ~570 wavefront instructions per block), not by memory.
+    // ~570 wavefront instructions per block), not by memory.  Chains of at least long2 / long4 terms can take two / four
+    // blocks per step (GM_PB_HUB_LONG2 / GM_PB_HUB_LONG4; off by default).  The walk of the longest row is a sequence
+    // nothing else can shorten — 0.62 ms for the 854,315-term row of scale 26, hidden under the accumulate kernel on
+    // one GPU but the critical path of the rank that owns the row in an 8-way split (1.02 ms against 0.55-0.70 for the
+    // other seven).  Measured with 65536 / 262144: that rank 1.02 -> 0.95 ms, scale 22 on one GPU 0.210 -> 0.204 ms, but
+    // the 400,000-term row of scale 24 moves from 3.0e-6 to 6.5e-6 of the reference (limit 1e-5): not worth the margin.
+    const uint32_t per_step = !few ? 1u : (he - hb) >= long4 ? 4u : (he - hb) >= long2 ? 2u : 1u; // FEW: blocks per step
     auto walk = [&](auto few_tag) {
         constexpr bool FEW = decltype(few_tag)::value;
+        uint32_t since = 0; // FEW: blocks added since the last end_step
         for (uint32_t qs = hb, q0 = h_first; qs < he; qs += HS * STEP, q0 += HS * STEP) {
 #pragma unroll
             for (int k = 0; k < HS; k += FEW ? 1 : 2) {
@@ -1166,10 +1173,15 @@ __global__ __launch_bounds__(PB_ACC_BLOCK, 8) void pb_hub_kernel(const float *__
                     const U16x4 cd1 = hd[k + 1];
                     load_step(q0 + (uint32_t)(k + 1 + HS) * STEP, hv[k + 1], hd[k + 1]);
                     add_block(few_tag, cv1, cd1);
+                    end_step();
+                } else if (++since == per_step) {
+                    end_step();
+                    since = 0;
                 }
-                end_step();
             }
         }
+        if (since) // the last, shorter step of a long chain
+            end_step();
     };
     if (few)
         walk(std::true_type{});
@@ -1898,7 +1910,8 @@ static void pb_hub_dispatch(const PbPlan *pl, PbScratch *sc, float *x_out, float
     if (pl->G)
         hipLaunchKernelGGL(pb_hub_kernel, dim3(pl->G), dim3(PB_ACC_BLOCK), 0, st, sc->vals, pl->p2_dst.as<uint16_t>(),
                            pl->hub_items.as<PbHubItem>(), pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out,
-                           sc->bin_err.as<double>() + pl->B, base, damping);
+                           sc->bin_err.as<double>() + pl->B, base, damping, (uint32_t)pb_env("GM_PB_HUB_LONG2", 0x7FFFFFFF),
+                           (uint32_t)pb_env("GM_PB_HUB_LONG4", 0x7FFFFFFF));
 }
 
 static void pb_hot_dispatch(const PbPlan *pl, PbScratch *sc, const float *x_in, hipStream_t st)

@@ -80,3 +80,23 @@ def test_fixed_point_within_1e5_of_the_reference_on_every_row(P, oracle, scale):
     print(f"scale {scale}: {it} sweeps, max rel vs the reference on every row {rel.max():.2e} "
           f"(rows with >= 4096 in-edges: {rel[deg >= 4096].max() if (deg >= 4096).any() else 0:.2e})")
     assert rel.max() <= 1e-5
+
+
+@pytest.mark.parametrize("long2,long4", [("4096", "1000000000"), ("4096", "16384"), ("1", "1")])
+def test_long_chains_with_two_and_four_blocks_per_step(P, oracle, monkeypatch, long2, long4):
+    """Long chains can be walked two or four 4096-term blocks per step (GM_PB_HUB_LONG2 / GM_PB_HUB_LONG4, off by
+    default: at scale 24 the four-block walk of the 400,000-term row costs parity margin).  With the thresholds lowered
+    every hub row of a scale-20 graph takes those paths: the fixed point must stay within the guard of the reference on
+    every row, and within 2e-6 of the one-block walk."""
+    n, g, ioff, itgt, od = _graph(P, oracle, 20)
+    ref, _, _ = oracle.page_rank_chunked(ioff, itgt, od, 200, 1e-10, 0.85)
+    base, _, _ = P.page_rank(g, P.PageRankConfig(200, 1e-10, 0.85), P.PageRankMode.JacobiPB)
+    monkeypatch.setenv("GM_PB_HUB_LONG2", long2)
+    monkeypatch.setenv("GM_PB_HUB_LONG4", long4)
+    got, _, _ = P.page_rank(g, P.PageRankConfig(200, 1e-10, 0.85), P.PageRankMode.JacobiPB)
+    rel = np.abs(got.astype(np.float64) - ref) / ref
+    deg = np.diff(ioff.astype(np.int64))
+    print(f"long2 {long2} long4 {long4}: max rel vs the reference {rel.max():.2e} (hub rows {rel[deg >= 4096].max():.2e}), "
+          f"vs the one-block walk {np.abs(got.astype(np.float64) - base).max() / base.max():.2e}")
+    assert rel.max() <= 6e-6
+    assert (np.abs(got.astype(np.float64) - base) / base).max() <= 2e-6
