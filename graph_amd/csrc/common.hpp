@@ -169,6 +169,7 @@ struct PbPlan; // propagation-blocking layout of a CSR (pagerank_pb.hip); immuta
 // Working buffers of one gm_sssp_delta_stepping call (sssp.hip).  A call takes the set parked in the CSR handle (or
 // allocates one) and parks it again when it returns: hipMalloc / hipFree of ~200 MB cost more than a millisecond
 // each and a graph is usually queried from many start nodes.
+struct TcDag;       // what gm_triangle_count derives from the graph alone (tc.hip); immutable once built
 struct PrCallState; // what one gm_page_rank call allocates (pagerank.hip), parked in the handle between calls
 struct WccScratch {
     DevBuf work;   // chunk count + chunk items + sample buffer (wcc.hip:wcc_device)
@@ -200,5 +201,6 @@ struct gm_csr {
     mutable std::unique_ptr<gm::SsspScratch> sssp_scratch; // parked between calls (under cache_mu)
     mutable std::unique_ptr<gm::WccScratch> wcc_scratch;   // likewise
     mutable std::shared_ptr<gm::PrCallState> pr_call;      // likewise (stream, vectors, engine + its scratch)
+    mutable std::shared_ptr<const gm::TcDag> tc_dag;       // the DAG of lower prefixes + list records of gm_triangle_count
     mutable std::atomic<int> long_rows{-1};           // 1: some row has >= GM_PB_HUB_DEG entries (-1: not looked at yet)
 };

@@ -271,6 +271,8 @@ int gm_sssp_relax_rows(const gm_csr *out_rows, uint64_t row_begin, uint64_t n_gl
  * including its put-back-iterator semantics on lists with duplicates / self-loops
  * (crates/algos/src/utils.rs:8-101).  Lists must be sorted (layout Sorted or Deduplicated);
  * unsorted lists are rejected with GM_ERR_UNSUPPORTED (the reference returns garbage silently).
+ * The handle keeps what the count derives from the graph alone (the lower-prefix DAG and its list records, ~9 bytes
+ * per undirected entry + 128 bytes per node) for the next count on the same graph.
  * ------------------------------------------------------------------------------------------- */
 int gm_triangle_count(const gm_csr *undirected_csr, uint64_t *triangles_out);
 

@@ -546,6 +546,26 @@ def test_triangle_count_vs_oracle(P, oracle, layout, relabel):
     assert P.global_triangle_count(ug) == oracle.triangle_count(off, tgt, threads=8)
 
 
+def test_triangle_count_twice_on_one_handle(P, oracle, monkeypatch):
+    """The DAG of lower prefixes and the list records stay in the CSR handle: later counts (other K, other item sizes,
+    a private rebuild with GM_TC_NOCACHE) must equal the first and the oracle's; relabelling makes a new handle."""
+    s, d = oracle.rmat_edges(13, seed=31)
+    n = 1 << 13
+    off, tgt = oracle.csr_build(n, s, d, oracle.UNDIRECTED, oracle.DEDUPLICATED)
+    ug = P.UndirectedCsrGraph(P.DeviceCsr.from_edges(n, s, d, None, 2, 2), 2)
+    want = oracle.triangle_count(off, tgt, threads=8)
+    assert P.global_triangle_count(ug) == want
+    monkeypatch.setenv("GM_TC_K", "200")
+    monkeypatch.setenv("GM_TC_ITEM", "64")
+    assert P.global_triangle_count(ug) == want
+    monkeypatch.setenv("GM_TC_NOCACHE", "1")
+    assert P.global_triangle_count(ug) == want
+    monkeypatch.delenv("GM_TC_NOCACHE"), monkeypatch.delenv("GM_TC_K"), monkeypatch.delenv("GM_TC_ITEM")
+    off2, tgt2, _ = oracle.relabel_by_degree(off, tgt)
+    P.relabel_graph(ug)
+    assert P.global_triangle_count(ug) == oracle.triangle_count(off2, tgt2, threads=8) == P.global_triangle_count(ug)
+
+
 @pytest.mark.parametrize("knobs", [{"GM_TC_K": "0"}, {"GM_TC_K": "1"}, {"GM_TC_K": "100"}, {"GM_TC_K": "5000", "GM_TC_ITEM": "64"},
                                    {"GM_TC_ITEM": "100000"}, {"GM_TC_SHAPE": "256,8,4,4"}, {"GM_TC_SHAPE": "1024,16,4,4"}, {"GM_TC_SHAPE": "512,8,4,4"},
                                    {"GM_TC_SHAPE": "512,8,8,8"}, {"GM_TC_SHAPE": "512,16,4,2"},

@@ -169,9 +169,12 @@ def main():
         P.relabel_graph(ug)
         torch.cuda.synchronize()
         t_relabel = time.perf_counter() - t0
-        t_tc, tri = timed(lambda: P.global_triangle_count(ug), reps=min(args.reps, 2))
+        t_tc_first, tri_first = timed(lambda: P.global_triangle_count(ug), reps=1)  # builds the DAG + list records, kept in the handle
+        t_tc, tri = timed(lambda: P.global_triangle_count(ug), reps=max(args.reps, 1))
+        assert tri == tri_first
         rec = {"config": f"RMAT scale-{sc} to_undirected(Deduplicated) + make_degree_ordered (the --relabel path)",
                "nodes": n, "undirected_entries": ug.csr.m, "build_s": t_build, "relabel_s": t_relabel, "ms": t_tc * 1e3,
+               "first_call_ms": t_tc_first * 1e3,
                "triangles": tri, "edges_per_s": ug.csr.m / 2 / t_tc, "triangles_per_s": tri / t_tc}
         off, tgt, _ = ug.csr.host()
         # SURVEY 8(d)'s merge-stream model: for every entry v < u of N(u): (rank of v in L(u)) + |L(v)| elements.
