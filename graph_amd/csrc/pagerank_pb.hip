@@ -1795,7 +1795,10 @@ int pb_scratch_create(const PbPlan *pl, PbScratch **out)
     PbScratch *sc = new (std::nothrow) PbScratch();
     GM_CHECK(sc, GM_ERR_NOMEM, "pb_scratch_create: out of host memory");
     int rc;
-    if ((rc = sc->vals_raw.alloc((size_t)(pl->Mv ? pl->Mv : 4) * 4)) ||
+    // GM_PB_VALS_SLACK=<MiB> (measurements): room behind the value stream so that GM_PB_VALS_OFFSET=<KiB>, read at
+    // every sweep, can move it inside one allocation — does the sweep time depend on the offset or on the pages?
+    const size_t slack = (size_t)pb_env("GM_PB_VALS_SLACK", 0) << 20;
+    if ((rc = sc->vals_raw.alloc((size_t)(pl->Mv ? pl->Mv : 4) * 4 + slack)) ||
         (rc = sc->partials.alloc((size_t)(pl->slots ? pl->slots : 1) * pl->Racc * 8)) ||
         (rc = sc->tickets.alloc((size_t)pl->B * 4)) || (rc = sc->bin_err.alloc(((size_t)pl->B + pl->G) * 8)) ||
         (rc = sc->hot_x.alloc(((size_t)pl->H + 4) * 4))) {
@@ -1924,6 +1927,11 @@ static void pb_hot_dispatch(const PbPlan *pl, PbScratch *sc, const float *x_in, 
 int pb_sweep_main(const PbPlan *pl, PbScratch *sc, const float *x_in, float *x_out, float *scores,
                   const uint32_t *outdeg, float base, float damping, hipStream_t st)
 {
+    if (const char *off = getenv("GM_PB_VALS_OFFSET")) { // measurements only (needs GM_PB_VALS_SLACK at creation)
+        const size_t bytes = (size_t)atoll(off) << 10;
+        if (bytes + (size_t)pl->Mv * 4 <= sc->vals_raw.bytes)
+            sc->vals = reinterpret_cast<float *>(sc->vals_raw.as<char>() + bytes);
+    }
     pb_hot_dispatch(pl, sc, x_in, st);
     pb_bin_dispatch(pl, sc, x_in, 0, pl->NW, st);
     // the hub groups need little LDS: on a second stream their workgroups run beside those of the ordinary bins
