@@ -440,10 +440,15 @@ GM_API int gm_pr_create_with(const gm_csr *csr, uint64_t n_global, uint64_t row_
     pr->init = 1.0f / (float)n_global;
     pr->base = (1.0f - damping_factor) / (float)n_global;
     if (engine == GM_PR_ENGINE_PB) {
+        // GM_PB_EARLY_VALS=1 (measurement): reserve the value stream before the plan is built — its pages decide 15 % of
+        // the sweep time; does it matter whether they are drawn before or after the build's 30 GB of churn?
+        gm::DevBuf early;
+        if (getenv("GM_PB_EARLY_VALS") && atoi(getenv("GM_PB_EARLY_VALS")) == 1)
+            (void)early.alloc((size_t)csr->m * 4 + ((size_t)csr->m >> 3) + (64u << 20));
         int rc = gm::pb_plan_get(csr, x_len, &pr->pb_keep);
         pr->pb = pr->pb_keep.get();
         if (rc == GM_OK)
-            rc = gm::pb_scratch_create(pr->pb, &pr->pb_scratch);
+            rc = gm::pb_scratch_create(pr->pb, &pr->pb_scratch, &early);
         if (rc != GM_OK) {
             delete pr;
             return rc;

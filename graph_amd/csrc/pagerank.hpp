@@ -27,7 +27,8 @@ __device__ __forceinline__ double pr_finalize(uint32_t r, float incoming, float 
 struct PbPlan;    // pagerank_pb.hip: immutable layout, cached in the gm_csr handle
 struct PbScratch; // per-engine mutable buffers (value stream, partial sums, tickets, errors, hot values)
 int pb_plan_get(const gm_csr *csr, uint64_t x_len, std::shared_ptr<const PbPlan> *out); // build on first use, then shared
-int pb_scratch_create(const PbPlan *plan, PbScratch **out);
+// `early`: a buffer allocated before the plan was built (may be null or too small): it becomes the value stream
+int pb_scratch_create(const PbPlan *plan, PbScratch **out, DevBuf *early = nullptr);
 void pb_scratch_destroy(PbScratch *scratch);
 int pb_sweep_main(const PbPlan *plan, PbScratch *scratch, const float *x_in, float *x_out, float *scores,
                   const uint32_t *outdeg, float base, float damping, hipStream_t st);

@@ -1790,15 +1790,17 @@ int pb_plan_get(const gm_csr *csr, uint64_t x_len, std::shared_ptr<const PbPlan>
 }
 
 
-int pb_scratch_create(const PbPlan *pl, PbScratch **out)
+int pb_scratch_create(const PbPlan *pl, PbScratch **out, DevBuf *early)
 {
     PbScratch *sc = new (std::nothrow) PbScratch();
     GM_CHECK(sc, GM_ERR_NOMEM, "pb_scratch_create: out of host memory");
     int rc;
+    if (early && early->p && early->bytes >= (size_t)(pl->Mv ? pl->Mv : 4) * 4)
+        sc->vals_raw = std::move(*early);
     // GM_PB_VALS_SLACK=<MiB> (measurements): room behind the value stream so that GM_PB_VALS_OFFSET=<KiB>, read at
     // every sweep, can move it inside one allocation — does the sweep time depend on the offset or on the pages?
     const size_t slack = (size_t)pb_env("GM_PB_VALS_SLACK", 0) << 20;
-    if ((rc = sc->vals_raw.alloc((size_t)(pl->Mv ? pl->Mv : 4) * 4 + slack)) ||
+    if ((rc = sc->vals_raw.p ? GM_OK : sc->vals_raw.alloc((size_t)(pl->Mv ? pl->Mv : 4) * 4 + slack)) ||
         (rc = sc->partials.alloc((size_t)(pl->slots ? pl->slots : 1) * pl->Racc * 8)) ||
         (rc = sc->tickets.alloc((size_t)pl->B * 4)) || (rc = sc->bin_err.alloc(((size_t)pl->B + pl->G) * 8)) ||
         (rc = sc->hot_x.alloc(((size_t)pl->H + 4) * 4))) {
