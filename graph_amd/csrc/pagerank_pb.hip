@@ -522,6 +522,17 @@ __global__ void pb_fill_kernel(const uint64_t *__restrict__ keys, const uint32_t
     }
 }
 
+// GM_PB_BIN_GAP (measurement): a pseudo-random run of unused entries (multiple of 4, below `max_gap`) behind every bin's
+// last segment, so that the bins' areas of the value stream do not start at regular address intervals
+__global__ void pb_bin_gap_kernel(const uint32_t *__restrict__ bin_seg, uint32_t B, uint32_t max_gap,
+                                  uint32_t *__restrict__ cnt_v)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += stride)
+        if (bin_seg[b + 1] > bin_seg[b])
+            cnt_v[bin_seg[b + 1] - 1u] += ((b * 2654435761u) >> 12) % max_gap & ~3u;
+}
+
 // bin_v[b] = padded value-stream position of the first segment of a bin >= b
 __global__ void pb_bin_ranges_kernel(const uint32_t *__restrict__ bin_seg, const uint32_t *__restrict__ vstart4, uint32_t B,
                                      uint32_t *__restrict__ bin_v)
@@ -1662,6 +1673,9 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
                        tile_seg.as<uint32_t>(), cs.as<uint32_t>(), pl->NT, tile_pad.as<uint32_t>());
     hipLaunchKernelGGL(pb_tile_tail_kernel, dim3(pb_grid(pl->NT)), dim3(256), 0, 0, tile_seg.as<uint32_t>(),
                        cs.as<uint32_t>(), tile_pad.as<uint32_t>(), segval.as<uint32_t>(), pl->NT, cntv.as<uint32_t>());
+    if (pb_env("GM_PB_BIN_GAP", 0) >= 8)
+        hipLaunchKernelGGL(pb_bin_gap_kernel, dim3(pb_grid(Bv)), dim3(256), 0, 0, bin_seg.as<uint32_t>(), Bv,
+                           (uint32_t)pb_env("GM_PB_BIN_GAP", 0), cntv.as<uint32_t>());
     GM_HIP(hipGetLastError());
     GM_TRY(scan_exclusive<uint32_t>(cntv.as<uint32_t>(), vstart4.as<uint32_t>(), (uint64_t)NS + 1));
     uint32_t Mv = 0;
@@ -1800,6 +1814,16 @@ int pb_scratch_create(const PbPlan *pl, PbScratch **out, DevBuf *early)
     // GM_PB_VALS_SLACK=<MiB> (measurements): room behind the value stream so that GM_PB_VALS_OFFSET=<KiB>, read at
     // every sweep, can move it inside one allocation — does the sweep time depend on the offset or on the pages?
     const size_t slack = (size_t)pb_env("GM_PB_VALS_SLACK", 0) << 20;
+    if (!sc->vals_raw.p && pb_env("GM_PB_VALS_CONTIG", 0)) { // measurement: physically contiguous pages
+        void *p = nullptr;
+        const size_t bytes = (size_t)(pl->Mv ? pl->Mv : 4) * 4 + slack;
+        if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocContiguous) == hipSuccess) {
+            sc->vals_raw.p = p;
+            sc->vals_raw.bytes = bytes;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     if ((rc = sc->vals_raw.p ? GM_OK : sc->vals_raw.alloc((size_t)(pl->Mv ? pl->Mv : 4) * 4 + slack)) ||
         (rc = sc->partials.alloc((size_t)(pl->slots ? pl->slots : 1) * pl->Racc * 8)) ||
         (rc = sc->tickets.alloc((size_t)pl->B * 4)) || (rc = sc->bin_err.alloc(((size_t)pl->B + pl->G) * 8)) ||
