@@ -46,6 +46,8 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--cpu-sweeps", type=int, default=20, help="sweeps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores (available_parallelism)")
+    ap.add_argument("--parity", type=int, default=1, help="N = 1, inside the cpu_baseline leg: run the timed engine and the CPU "
+                    "path to their fixed points and compare every row (about 20 s of host time at scale 26; 0 = skip)")
     ap.add_argument("--relabel", type=int, default=0, help="(experimental) internal degree-ordered layout")
     ap.add_argument("--engine", choices=["auto", "pull", "pb"], default="auto")
     ap.add_argument("--prewarm-ms", type=float, default=400.0, help="untimed sweeps before the W warm-up steps so "
@@ -354,18 +356,9 @@ def main():
             plan_rebuild_ms = None
         finally:
             del os.environ["GM_PB_NOCACHE"]
-    # parity of the timed engine at this scale against the reference's threaded path (tools/parity_pagerank.py,
-    # PageRankConfig::new(200, 1e-10, 0.85) on both sides), from the committed profile of this round
+    # parity of the timed engine is MEASURED below, in the cpu_baseline leg (the same CPU path run to its fixed point is
+    # the checker of the engine that was just timed): null when that leg is skipped — nothing is quoted from a file
     parity = None
-    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
-        if name.endswith(f"parity_scale{scale}.json"):
-            try:
-                rec = json.load(open(os.path.join(ROOT, "profiles", name)))
-                parity = {"max_rel_vs_reference": rec["max_rel_vs_reference"], "rows_over_1e-5": rec["rows_over_1e-5"],
-                          "tolerance": 1e-5, "engine": rec["mode"], "source": f"profiles/{name}"}
-            except Exception:
-                parity = None
-            break
     result = {
         "metric": "pagerank_edges_per_sec",
         "value": round(gteps, 4),
@@ -427,6 +420,32 @@ def main():
             "ms_per_step": round(cpu_s * 1e3 / args.cpu_sweeps, 3),
             "build": O.timed_build_flags(),
         }
+        if args.parity and not piecewise and not sparse:
+            # The same CPU path run to its fixed point checks THE ENGINE THAT WAS TIMED (this process, this library, this
+            # plan): PageRankConfig::new(200, 1e-10, 0.85) on both sides, every row compared (north_star: <= 1e-5 relative).
+            engine.init(scores, x[0])
+            sweeps_dev = 0
+            for it in range(200):
+                engine.sweep(x[it % 2], x[1 - it % 2], scores, err)
+                sweeps_dev += 1
+                if float(err.item()) < 1e-10:
+                    break
+            got = scores.cpu().numpy().astype(np.float64)
+            t_ref = time.perf_counter()
+            ref, it_ref, _ = O.page_rank_chunked(off_h, tgt_h, od_h, 200, 1e-10, 0.85, cores)
+            t_ref = time.perf_counter() - t_ref
+            ref = ref.astype(np.float64)
+            rel = np.abs(got - ref) / ref
+            deg_h = np.diff(off_h.astype(np.int64))
+            hub = deg_h >= 4096
+            result["config"]["parity"] = {
+                "max_rel_vs_reference": float(rel.max()), "rows_over_1e-5": int((rel > 1e-5).sum()), "tolerance": 1e-5,
+                "max_rel_rows_with_4096_or_more_in_edges": float(rel[hub].max()) if hub.any() else None,
+                "max_in_degree": int(deg_h.max()), "device_sweeps": sweeps_dev, "reference_iterations": int(it_ref),
+                "reference_seconds": round(t_ref, 2),
+                "source": "measured in this run: the timed engine run on to its fixed point against oracle "
+                          "orc_page_rank_chunked (page_rank.rs:113-168) on the host cores, PageRankConfig::new(200, 1e-10, 0.85)",
+            }
     if emu:
         result["config"]["emulated"] = f"rank {rank} of {world} on one device, exchange replaced by a local copy"
     if rank == 0 or emu:

@@ -29,6 +29,9 @@ SIGNATURES = {
     "gm_csr_upload_u64": (i32, [vp, vp, vp, u64, u64, i32, PP]),
     "gm_csr_wrap_device": (i32, [u64, u64, u64, u64, u64, i32, PP]),
     "gm_csr_free": (None, [vp]),
+    "gm_csr_trim": (i32, [vp]),
+    "gm_trim": (i32, [i32]),
+    "gm_arena_info": (i32, [i32, vp]),
     "gm_csr_node_count": (u64, [vp]),
     "gm_csr_edge_count": (u64, [vp]),
     "gm_csr_device": (i32, [vp]),

@@ -1,0 +1,188 @@
+// arena.hip — the library's own supply of physical device memory for its LARGE buffers (gfx950 / MI355X only).
+//
+// Why (measured in round 3, profiles/r03_placement_*.txt):
+//  * Where a buffer's pages lie decides up to 35 % of a streaming kernel's time.  The value stream of the PageRank
+//    sweep (3.6 GB at RMAT scale 26, written in 8 M scattered runs) takes 1.66 ms to write when it sits in ONE
+//    stretch of physical memory — what a fresh hipMalloc returns — 1.31 ms when it straddles two, and 1.23-1.30 ms
+//    when it is mapped from 64 MiB pieces drawn from all over a few dozen GiB: the DRAM banks a stretch of physical
+//    memory can use are chosen by high address bits, and scattered row activations need all of them.
+//  * hipMalloc after large hipFree calls stalls for seconds (the driver hands freed VRAM back only after clearing it):
+//    memory that never goes back to the driver is never waited for.
+// So large buffers are mapped (HIP virtual-memory API) from 64 MiB physical pieces that the arena creates on demand
+// and keeps when a buffer is released (up to GM_ARENA_KEEP_GIB, default 32; gm_trim() releases them).  A buffer asks
+// either for any pieces or for a SPREAD subset: one pseudo-random piece out of every stratum of the free list in
+// creation order — consecutive creations are mostly neighbours in physical memory, so the subset samples the whole
+// stretch the arena has seen.
+#include "common.hpp"
+
+#include <algorithm>
+
+namespace gm {
+
+namespace {
+
+struct Arena {
+    std::mutex mu;
+    std::vector<ArenaPiece> free_list; // ascending serial = creation order
+    uint64_t next_serial = 0;
+    uint64_t alive = 0; // pieces created and not released to the driver
+    uint64_t created = 0, reused = 0;
+};
+
+Arena &arena_of(int dev)
+{
+    static std::mutex mu;
+    static std::map<int, std::unique_ptr<Arena>> arenas;
+    std::lock_guard<std::mutex> lock(mu);
+    std::unique_ptr<Arena> &a = arenas[dev];
+    if (!a)
+        a.reset(new Arena());
+    return *a;
+}
+
+uint64_t mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+int create_pieces(Arena &a, int dev, size_t count)
+{
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    for (size_t i = 0; i < count; ++i) {
+        hipMemGenericAllocationHandle_t h;
+        hipError_t e = hipMemCreate(&h, ARENA_PIECE, &prop, 0);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("arena: hipMemCreate(64 MiB) failed after %llu pieces: %s", (unsigned long long)a.alive, hipGetErrorString(e));
+            return e == hipErrorOutOfMemory ? GM_ERR_NOMEM : GM_ERR_HIP;
+        }
+        a.free_list.push_back(ArenaPiece{h, a.next_serial++});
+        ++a.alive;
+        ++a.created;
+    }
+    return GM_OK;
+}
+
+} // namespace
+
+bool arena_enabled()
+{
+    static const bool on = [] {
+        const char *v = getenv("GM_ARENA");
+        return !(v && *v == '0');
+    }();
+    return on;
+}
+
+size_t arena_keep_bytes()
+{
+    const char *v = getenv("GM_ARENA_KEEP_GIB");
+    const long gib = v && *v ? atol(v) : 32;
+    return (size_t)(gib < 0 ? 0 : gib) << 30;
+}
+
+int arena_take(int dev, size_t count, uint64_t spread_seed, size_t spread_factor, std::vector<ArenaPiece> &out)
+{
+    Arena &a = arena_of(dev);
+    std::lock_guard<std::mutex> lock(a.mu);
+    out.clear();
+    const size_t want_free = spread_seed ? count * (spread_factor ? spread_factor : 1) : count;
+    if (a.free_list.size() < want_free) {
+        const int rc = create_pieces(a, dev, want_free - a.free_list.size());
+        if (rc != GM_OK && a.free_list.size() < count)
+            return rc; // a smaller pool than asked for still serves the request
+    }
+    a.reused += count;
+    if (!spread_seed) { // any pieces: the most recently returned ones
+        out.assign(a.free_list.end() - (ptrdiff_t)count, a.free_list.end());
+        a.free_list.resize(a.free_list.size() - count);
+        return GM_OK;
+    }
+    // one pseudo-random piece from every stratum of the free list (kept in creation order)
+    std::sort(a.free_list.begin(), a.free_list.end(), [](const ArenaPiece &x, const ArenaPiece &y) { return x.serial < y.serial; });
+    const size_t F = a.free_list.size();
+    std::vector<bool> taken(F, false);
+    for (size_t i = 0; i < count; ++i) {
+        const size_t lo = i * F / count, hi = (i + 1) * F / count; // hi > lo: F >= count
+        const size_t k = lo + (size_t)(mix64(spread_seed * 0x9E3779B97F4A7C15ull + i) % (hi - lo));
+        taken[k] = true;
+        out.push_back(a.free_list[k]);
+    }
+    // the stream's consecutive pieces should not be physical neighbours either: shuffle the order they are mapped in
+    for (size_t i = count; i > 1; --i)
+        std::swap(out[i - 1], out[mix64(spread_seed ^ (0xD1B54A32D192ED03ull * i)) % i]);
+    size_t w = 0;
+    for (size_t k = 0; k < F; ++k)
+        if (!taken[k])
+            a.free_list[w++] = a.free_list[k];
+    a.free_list.resize(w);
+    return GM_OK;
+}
+
+static void trim_locked(Arena &a, size_t keep_bytes)
+{
+    const size_t keep = keep_bytes / ARENA_PIECE;
+    while (a.free_list.size() > keep) { // the oldest returns go first
+        (void)hipMemRelease(a.free_list.front().handle);
+        a.free_list.erase(a.free_list.begin());
+        --a.alive;
+    }
+}
+
+void arena_give(int dev, std::vector<ArenaPiece> &pieces)
+{
+    Arena &a = arena_of(dev);
+    std::lock_guard<std::mutex> lock(a.mu);
+    a.free_list.insert(a.free_list.end(), pieces.begin(), pieces.end());
+    pieces.clear();
+    if (a.free_list.size() * ARENA_PIECE > arena_keep_bytes() + (arena_keep_bytes() >> 2)) // hysteresis: trim in batches
+        trim_locked(a, arena_keep_bytes());
+}
+
+void arena_trim(int dev, size_t keep_bytes)
+{
+    Arena &a = arena_of(dev);
+    std::lock_guard<std::mutex> lock(a.mu);
+    trim_locked(a, keep_bytes);
+}
+
+void arena_stats(int dev, uint64_t *out4)
+{
+    Arena &a = arena_of(dev);
+    std::lock_guard<std::mutex> lock(a.mu);
+    out4[0] = a.alive * ARENA_PIECE;
+    out4[1] = a.free_list.size() * ARENA_PIECE;
+    out4[2] = a.created;
+    out4[3] = a.reused;
+}
+
+} // namespace gm
+
+// Releases what the library holds in reserve on `device` (-1: the current device): the arena's free pieces.  Buffers in
+// use (graphs, plans, parked scratch: see gm_csr_trim) are not touched.
+GM_API int gm_trim(int device)
+{
+    int dev = device;
+    if (dev < 0)
+        GM_HIP(hipGetDevice(&dev));
+    gm::DeviceGuard guard(dev);
+    GM_HIP(hipDeviceSynchronize());
+    gm::arena_trim(dev, 0);
+    return GM_OK;
+}
+
+// bytes_out[4]: bytes of device memory the arena holds, bytes of it not in use, pieces created, pieces handed out
+GM_API int gm_arena_info(int device, uint64_t *bytes_out)
+{
+    GM_CHECK(bytes_out, GM_ERR_INVALID, "gm_arena_info: null argument");
+    int dev = device;
+    if (dev < 0)
+        GM_HIP(hipGetDevice(&dev));
+    gm::arena_stats(dev, bytes_out);
+    return GM_OK;
+}

@@ -14,6 +14,7 @@
 #include <memory>
 #include <mutex>
 #include <new>
+#include <vector>
 
 #include "../../include/graph_mi355x.h"
 
@@ -52,30 +53,92 @@ struct HipFail {
             return gm_s_;                                                                         \
     } while (0)
 
-// RAII device allocation (hipMalloc / hipFree); movable, not copyable.
+struct DeviceSwitch { // sets the current device for a scope (DeviceGuard below also reports failure)
+    int prev = -1;
+    explicit DeviceSwitch(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess)
+            prev = -1;
+        if (prev != dev)
+            (void)hipSetDevice(dev);
+        else
+            prev = -1;
+    }
+    ~DeviceSwitch()
+    {
+        if (prev >= 0)
+            (void)hipSetDevice(prev);
+    }
+};
+
+// arena.hip: the library's own supply of 64 MiB physical pieces for its large buffers
+constexpr size_t ARENA_PIECE = (size_t)64 << 20;
+constexpr size_t ARENA_MIN = (size_t)128 << 20; // smaller buffers stay with hipMalloc
+struct ArenaPiece {
+    hipMemGenericAllocationHandle_t handle;
+    uint64_t serial; // creation order
+};
+bool arena_enabled(); // GM_ARENA=0: every buffer from hipMalloc
+// `count` pieces; spread_seed != 0: a stratified pseudo-random subset of a free list of >= count x spread_factor pieces
+int arena_take(int dev, size_t count, uint64_t spread_seed, size_t spread_factor, std::vector<ArenaPiece> &out);
+void arena_give(int dev, std::vector<ArenaPiece> &pieces);
+void arena_trim(int dev, size_t keep_bytes);
+void arena_stats(int dev, uint64_t *out4);
+
+// RAII device allocation; movable, not copyable.  Two backings: hipMalloc / hipFree, or (alloc_vmm) a reserved
+// virtual range mapped chunk by chunk from physical allocations of the HIP virtual-memory API — the caller decides
+// the size of the physical pieces and the order in which they appear in the range (pagerank_pb.hip: the value
+// stream's sweep time depends on the pages it lands on).
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
+    std::vector<hipMemGenericAllocationHandle_t> vmm; // physical pieces of a mapped range (empty: hipMalloc backing)
+    size_t vmm_chunk = 0, vmm_span = 0;                // bytes per piece, bytes reserved
+    std::vector<ArenaPiece> arena;                     // pieces borrowed from the arena (alloc_big); returned on release
+    int arena_dev = 0;
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    DevBuf(DevBuf &&o) noexcept { take(o); }
     DevBuf &operator=(DevBuf &&o) noexcept
     {
         if (this != &o) {
             release();
-            p = o.p;
-            bytes = o.bytes;
-            o.p = nullptr;
-            o.bytes = 0;
+            take(o);
         }
         return *this;
     }
     ~DevBuf() { release(); }
+    void take(DevBuf &o)
+    {
+        p = o.p, bytes = o.bytes, vmm = std::move(o.vmm), vmm_chunk = o.vmm_chunk, vmm_span = o.vmm_span;
+        arena = std::move(o.arena), arena_dev = o.arena_dev;
+        o.p = nullptr, o.bytes = 0, o.vmm.clear(), o.vmm_chunk = o.vmm_span = 0, o.arena.clear();
+    }
     void release()
     {
-        if (p)
+        if (!arena.empty()) {
+            // hipFree waits for the device; so does this (a kernel may still be reading the buffer)
+            DeviceSwitch sw(arena_dev);
+            (void)hipDeviceSynchronize();
+            if (p) {
+                (void)hipMemUnmap(p, vmm_span);
+                (void)hipMemAddressFree(p, vmm_span);
+            }
+            arena_give(arena_dev, arena);
+            vmm_chunk = vmm_span = 0;
+        } else if (vmm_span) {
+            if (p) {
+                (void)hipMemUnmap(p, vmm_span);
+                (void)hipMemAddressFree(p, vmm_span);
+            }
+            for (hipMemGenericAllocationHandle_t h : vmm)
+                (void)hipMemRelease(h);
+            vmm.clear();
+            vmm_chunk = vmm_span = 0;
+        } else if (p) {
             (void)hipFree(p);
+        }
         p = nullptr;
         bytes = 0;
     }
@@ -87,6 +150,223 @@ struct DevBuf {
         GM_HIP(hipMalloc(&p, nbytes));
         bytes = nbytes;
         return GM_OK;
+    }
+    // A large buffer from the arena's 64 MiB pieces (arena.hip); spread_seed != 0: pieces sampled from all over the
+    // arena's free list, which is grown to spread_factor times the request first.  Small requests, and every request
+    // under GM_ARENA=0, take the hipMalloc path.  Contents are NOT zero (hipMalloc does not promise that either).
+    int alloc_big(size_t nbytes, uint64_t spread_seed = 0, size_t spread_factor = 4)
+    {
+        if (!arena_enabled() || nbytes < ARENA_MIN)
+            return alloc(nbytes);
+        release();
+        int dev = 0;
+        GM_HIP(hipGetDevice(&dev));
+        const size_t count = (nbytes + ARENA_PIECE - 1) / ARENA_PIECE, span = count * ARENA_PIECE;
+        GM_TRY(arena_take(dev, count, spread_seed, spread_factor, arena));
+        arena_dev = dev;
+        void *base = nullptr;
+        hipError_t e = hipMemAddressReserve(&base, span, ARENA_PIECE, nullptr, 0);
+        for (size_t i = 0; i < count && e == hipSuccess; ++i) {
+            e = hipMemMap(static_cast<char *>(base) + i * ARENA_PIECE, ARENA_PIECE, 0, arena[i].handle, 0);
+            if (e != hipSuccess && i)
+                (void)hipMemUnmap(base, i * ARENA_PIECE);
+        }
+        if (e == hipSuccess) {
+            hipMemAccessDesc desc{};
+            desc.location.type = hipMemLocationTypeDevice;
+            desc.location.id = dev;
+            desc.flags = hipMemAccessFlagsProtReadWrite;
+            e = hipMemSetAccess(base, span, &desc, 1);
+            if (e != hipSuccess)
+                (void)hipMemUnmap(base, span);
+        }
+        if (e != hipSuccess) {
+            gm::set_error("alloc_big(%zu bytes): %s", nbytes, hipGetErrorString(e));
+            if (base)
+                (void)hipMemAddressFree(base, span);
+            arena_give(dev, arena);
+            return e == hipErrorOutOfMemory ? GM_ERR_NOMEM : GM_ERR_HIP;
+        }
+        p = base, bytes = span, vmm_span = span, vmm_chunk = ARENA_PIECE;
+        return GM_OK;
+    }
+    // `nbytes` as pieces of `chunk` bytes (rounded up to the allocation granularity; 0: one piece), the range
+    // aligned to `va_align` bytes (0: the granularity), pieces mapped in the order order[i] (null: ascending)
+    int alloc_vmm(size_t nbytes, size_t chunk, size_t va_align, const uint32_t *order = nullptr)
+    {
+        release();
+        int dev = 0;
+        GM_HIP(hipGetDevice(&dev));
+        hipMemAllocationProp prop{};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = dev;
+        size_t gran = 0;
+        GM_HIP(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+        if (gran == 0)
+            gran = 2u << 20;
+        if (nbytes == 0)
+            nbytes = 16;
+        if (chunk == 0 || chunk > nbytes)
+            chunk = nbytes;
+        chunk = (chunk + gran - 1) / gran * gran;
+        const size_t count = (nbytes + chunk - 1) / chunk;
+        const size_t span = count * chunk;
+        if (va_align < gran)
+            va_align = gran;
+        void *base = nullptr;
+        GM_HIP(hipMemAddressReserve(&base, span, va_align, nullptr, 0));
+        p = base, vmm_span = span, vmm_chunk = chunk; // from here on release() undoes what has been done
+        vmm.reserve(count);
+        for (size_t i = 0; i < count; ++i) {
+            hipMemGenericAllocationHandle_t h;
+            hipError_t e = hipMemCreate(&h, chunk, &prop, 0);
+            if (e != hipSuccess) {
+                gm::set_error("hipMemCreate(%zu bytes, piece %zu of %zu) failed: %s", chunk, i, count, hipGetErrorString(e));
+                (void)hipMemAddressFree(base, span);
+                p = nullptr, vmm_span = 0;
+                release_handles();
+                return e == hipErrorOutOfMemory ? GM_ERR_NOMEM : GM_ERR_HIP;
+            }
+            vmm.push_back(h);
+        }
+        for (size_t i = 0; i < count; ++i) {
+            hipError_t e = hipMemMap(static_cast<char *>(base) + i * chunk, chunk, 0, vmm[order ? order[i] : i], 0);
+            if (e != hipSuccess) {
+                gm::set_error("hipMemMap failed: %s", hipGetErrorString(e));
+                if (i)
+                    (void)hipMemUnmap(base, i * chunk);
+                (void)hipMemAddressFree(base, span);
+                p = nullptr, vmm_span = 0;
+                release_handles();
+                return GM_ERR_HIP;
+            }
+        }
+        hipMemAccessDesc desc{};
+        desc.location = prop.location;
+        desc.flags = hipMemAccessFlagsProtReadWrite;
+        hipError_t e = hipMemSetAccess(base, span, &desc, 1);
+        if (e != hipSuccess) {
+            gm::set_error("hipMemSetAccess failed: %s", hipGetErrorString(e));
+            release();
+            return GM_ERR_HIP;
+        }
+        bytes = span;
+        return GM_OK;
+    }
+    // `pool` physical pieces of `chunk` bytes are created one after the other — consecutive allocations of a device
+    // are mostly neighbours in physical memory — and the range is mapped from the pieces pick[0], pick[1], ... of that
+    // sequence; the others are released again.  What it is for: DESIGN 4.1 ("where the pages are").
+    int alloc_vmm_pool(size_t nbytes, size_t chunk, size_t pool, const std::vector<size_t> &pick)
+    {
+        release();
+        int dev = 0;
+        GM_HIP(hipGetDevice(&dev));
+        hipMemAllocationProp prop{};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = dev;
+        const size_t count = pick.size(), span = count * chunk;
+        std::vector<hipMemGenericAllocationHandle_t> all;
+        all.reserve(pool);
+        hipError_t e = hipSuccess;
+        for (size_t i = 0; i < pool && e == hipSuccess; ++i) {
+            hipMemGenericAllocationHandle_t h;
+            e = hipMemCreate(&h, chunk, &prop, 0);
+            if (e == hipSuccess)
+                all.push_back(h);
+        }
+        void *base = nullptr;
+        if (e == hipSuccess)
+            e = hipMemAddressReserve(&base, span, chunk < ((size_t)1 << 30) ? chunk : ((size_t)1 << 30), nullptr, 0);
+        if (e != hipSuccess) {
+            gm::set_error("alloc_vmm_pool: %s (%zu pieces of %zu bytes for %zu bytes)", hipGetErrorString(e), pool, chunk, nbytes);
+            for (hipMemGenericAllocationHandle_t h : all)
+                (void)hipMemRelease(h);
+            return e == hipErrorOutOfMemory ? GM_ERR_NOMEM : GM_ERR_HIP;
+        }
+        p = base, vmm_span = span, vmm_chunk = chunk;
+        std::vector<bool> used(all.size(), false);
+        for (size_t i = 0; i < count; ++i) {
+            used[pick[i]] = true;
+            vmm.push_back(all[pick[i]]);
+        }
+        for (size_t k = 0; k < all.size(); ++k)
+            if (!used[k])
+                (void)hipMemRelease(all[k]);
+        for (size_t i = 0; i < count && e == hipSuccess; ++i)
+            e = hipMemMap(static_cast<char *>(base) + i * chunk, chunk, 0, vmm[i], 0);
+        hipMemAccessDesc desc{};
+        desc.location = prop.location;
+        desc.flags = hipMemAccessFlagsProtReadWrite;
+        if (e == hipSuccess)
+            e = hipMemSetAccess(base, span, &desc, 1);
+        if (e != hipSuccess) {
+            gm::set_error("alloc_vmm_pool: map failed: %s", hipGetErrorString(e));
+            release();
+            return GM_ERR_HIP;
+        }
+        bytes = span;
+        return GM_OK;
+    }
+    static size_t vmm_granularity()
+    {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        hipMemAllocationProp prop{};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = dev;
+        size_t gran = 0;
+        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0)
+            gran = 2u << 20;
+        return gran;
+    }
+    // pieces first, first + stride, first + 2 stride, ... (measurement)
+    int alloc_vmm_strided(size_t nbytes, size_t chunk, size_t pool, size_t first, size_t stride)
+    {
+        const size_t gran = vmm_granularity();
+        chunk = (chunk + gran - 1) / gran * gran;
+        const size_t count = (nbytes + chunk - 1) / chunk;
+        if (stride == 0)
+            stride = 1;
+        if (pool < first + (count - 1) * stride + 1)
+            pool = first + (count - 1) * stride + 1;
+        std::vector<size_t> pick(count);
+        for (size_t i = 0; i < count; ++i)
+            pick[i] = first + i * stride;
+        return alloc_vmm_pool(nbytes, chunk, pool, pick);
+    }
+    // a pseudo-random subset of `factor` times as many pieces as the range needs
+    int alloc_spread(size_t nbytes, size_t chunk, size_t factor, uint64_t seed)
+    {
+        const size_t gran = vmm_granularity();
+        chunk = (chunk + gran - 1) / gran * gran;
+        if (nbytes == 0)
+            nbytes = 16;
+        const size_t count = (nbytes + chunk - 1) / chunk;
+        const size_t pool = count * (factor ? factor : 1);
+        std::vector<size_t> idx(pool);
+        for (size_t i = 0; i < pool; ++i)
+            idx[i] = i;
+        uint64_t state = seed * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+        for (size_t i = 0; i < count; ++i) { // partial Fisher-Yates: the first `count` entries are the subset
+            state += 0x9E3779B97F4A7C15ull;
+            uint64_t z = state;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            z ^= z >> 31;
+            std::swap(idx[i], idx[i + z % (pool - i)]);
+        }
+        idx.resize(count);
+        return alloc_vmm_pool(nbytes, chunk, pool, idx);
+    }
+    void release_handles()
+    {
+        for (hipMemGenericAllocationHandle_t h : vmm)
+            (void)hipMemRelease(h);
+        vmm.clear();
+        vmm_chunk = 0;
     }
     template <class T> T *as() const { return static_cast<T *>(p); }
 };

@@ -220,6 +220,27 @@ GM_API void gm_csr_free(gm_csr *csr)
     delete csr;
 }
 
+GM_API int gm_csr_trim(const gm_csr *csr)
+{
+    GM_CHECK(csr, GM_ERR_INVALID, "gm_csr_trim: null handle");
+    gm::DeviceGuard guard(csr->device);
+    // taken out under the lock, destroyed outside it (a destructor may synchronise the device)
+    std::map<uint64_t, std::shared_ptr<const gm::PbPlan>> plans;
+    std::unique_ptr<gm::SsspScratch> sssp;
+    std::unique_ptr<gm::WccScratch> wcc;
+    std::shared_ptr<gm::PrCallState> pr;
+    std::shared_ptr<const gm::TcDag> dag;
+    {
+        std::lock_guard<std::mutex> lock(csr->cache_mu);
+        plans.swap(csr->pb_plans);
+        sssp = std::move(csr->sssp_scratch);
+        wcc = std::move(csr->wcc_scratch);
+        pr = std::move(csr->pr_call);
+        dag = std::move(csr->tc_dag);
+    }
+    return GM_OK;
+}
+
 GM_API uint64_t gm_csr_node_count(const gm_csr *csr) { return csr ? csr->n : 0; }
 GM_API uint64_t gm_csr_edge_count(const gm_csr *csr) { return csr ? csr->m : 0; }
 GM_API int gm_csr_device(const gm_csr *csr) { return csr ? csr->device : -1; }
@@ -718,10 +739,10 @@ GM_API int gm_csr_build_device(uint64_t n, uint64_t m, uint64_t d_src, uint64_t 
 
     if (layout == GM_LAYOUT_UNSORTED) {
         gm::DevBuf keys, kalt, idx, ialt;
-        GM_TRY(keys.alloc(total * 4));
-        GM_TRY(kalt.alloc(total * 4));
-        GM_TRY(idx.alloc(total * 4));
-        GM_TRY(ialt.alloc(total * 4));
+        GM_TRY(keys.alloc_big(total * 4));
+        GM_TRY(kalt.alloc_big(total * 4));
+        GM_TRY(idx.alloc_big(total * 4));
+        GM_TRY(ialt.alloc_big(total * 4));
         hipLaunchKernelGGL(make_keys32_kernel, dim3(grid), dim3(256), 0, 0, total, m, direction, src, dst,
                            keys.as<uint32_t>(), idx.as<uint32_t>(), (uint32_t)n, bad.as<uint32_t>());
         GM_HIP(hipGetLastError());
@@ -738,11 +759,11 @@ GM_API int gm_csr_build_device(uint64_t n, uint64_t m, uint64_t d_src, uint64_t 
         }
     } else {
         gm::DevBuf keys, kalt, idx, ialt, wsorted;
-        GM_TRY(keys.alloc(total * 8));
-        GM_TRY(kalt.alloc(total * 8));
+        GM_TRY(keys.alloc_big(total * 8));
+        GM_TRY(kalt.alloc_big(total * 8));
         if (weighted) {
-            GM_TRY(idx.alloc(total * 4));
-            GM_TRY(ialt.alloc(total * 4));
+            GM_TRY(idx.alloc_big(total * 4));
+            GM_TRY(ialt.alloc_big(total * 4));
         }
         hipLaunchKernelGGL(make_keys64_kernel, dim3(grid), dim3(256), 0, 0, total, m, direction, src, dst,
                            keys.as<uint64_t>(), weighted ? idx.as<uint32_t>() : nullptr, (uint32_t)n, bad.as<uint32_t>());
@@ -770,11 +791,11 @@ GM_API int gm_csr_build_device(uint64_t n, uint64_t m, uint64_t d_src, uint64_t 
             }
         } else { // Deduplicated
             gm::DevBuf keep, pos, old_off;
-            GM_TRY(keep.alloc((total + 1) * 4));
-            GM_TRY(pos.alloc((total + 1) * 4));
+            GM_TRY(keep.alloc_big((total + 1) * 4));
+            GM_TRY(pos.alloc_big((total + 1) * 4));
             GM_TRY(old_off.alloc((n + 1) * 4));
             if (weighted) {
-                GM_TRY(wsorted.alloc(total * 4));
+                GM_TRY(wsorted.alloc_big(total * 4));
                 hipLaunchKernelGGL(gather_by_idx_kernel, dim3(grid), dim3(256), 0, 0, idx.as<uint32_t>(), total, m,
                                    direction, src, dst, w, (uint32_t *)nullptr, wsorted.as<float>());
             }
@@ -961,7 +982,7 @@ GM_API int gm_csr_relabel_by_degree(const gm_csr *g, gm_csr **out, uint32_t *new
         return fail(rc);
     if (m) {
         gm::DevBuf keys, kalt;
-        if ((rc = keys.alloc(m * 8)) || (rc = kalt.alloc(m * 8)))
+        if ((rc = keys.alloc_big(m * 8)) || (rc = kalt.alloc_big(m * 8)))
             return fail(rc);
         hipLaunchKernelGGL(relabel_keys_kernel, dim3(stream_grid(m)), dim3(256), 0, 0, g->offsets, g->targets,
                            (uint32_t)n, m, new_id.as<uint32_t>(), keys.as<uint64_t>());

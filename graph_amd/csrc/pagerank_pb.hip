@@ -88,6 +88,7 @@ struct PbScratch {
     DevBuf part_items;
     std::vector<uint32_t> part_off;
     DevBuf vals_raw; // backing allocation of the value stream
+    std::shared_ptr<DevBuf> vals_shared; // GM_PB_VALS_SHARE (measurement): one allocation behind the streams of several engines
     float *vals = nullptr; // f32[Mv] per-edge values, bin-major, segments padded to 4
     DevBuf partials; // u64[slots x R] partial LDS accumulators of split bins
     DevBuf tickets;  // u32[B]    arrival counters of split bins (self-resetting)
@@ -96,6 +97,8 @@ struct PbScratch {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     ~PbScratch()
     {
+        if (vals_shared)
+            vals_raw.p = nullptr, vals_raw.bytes = 0;
         if (side)
             (void)hipStreamDestroy(side);
         if (ev_fork)
@@ -150,6 +153,7 @@ struct PbPlan {
     DevBuf tile_p;      // u32[NT+1] phase-1 range of each tile (multiples of 256)
     DevBuf wg_tile;     // u32[NW]   tile of each phase-1 workgroup
     DevBuf wg_p0;       // u32[NW]   first phase-1 entry of each workgroup
+    DevBuf wg_tile_g, wg_p0_g; // GM_PB_WG_GROUP=G (measurement): the same items in (tile / G, chunk, tile % G) order, whole sweeps only
     DevBuf p2_dst;      // u16[Mv]   local row id inside the bin, PB_NULL = padding
     DevBuf bin_v;       // u32[B+1]  value range of each bin (multiples of 4)
     DevBuf items;       // PbItem[NI] accumulate work items (a bin, or a slice of an over-long bin), longest first
@@ -1502,11 +1506,11 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     const uint32_t filter_words = (uint32_t)(((x_len >> fshift) + 32) / 32);
     if (H) {
         DevBuf cnt, ckeys, calt, n_keys;
-        GM_TRY(cnt.alloc((size_t)x_len * 4));
-        GM_TRY(ckeys.alloc((size_t)x_len * 8));
-        GM_TRY(calt.alloc((size_t)x_len * 8));
+        GM_TRY(cnt.alloc_big((size_t)x_len * 4));
+        GM_TRY(ckeys.alloc_big((size_t)x_len * 8));
+        GM_TRY(calt.alloc_big((size_t)x_len * 8));
         GM_TRY(n_keys.alloc(4));
-        GM_TRY(hot_rank.alloc((size_t)x_len * 2));
+        GM_TRY(hot_rank.alloc_big((size_t)x_len * 2));
         GM_TRY(hot_blk.alloc((size_t)filter_words * 4));
         GM_HIP(hipMemset(cnt.p, 0, (size_t)x_len * 4));
         GM_HIP(hipMemset(n_keys.p, 0, 4));
@@ -1539,8 +1543,8 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     timer.done("pb plan: hot source selection");
 
     DevBuf keys, kalt;
-    GM_TRY(keys.alloc((size_t)m_all * 8));
-    GM_TRY(kalt.alloc((size_t)m_all * 8));
+    GM_TRY(keys.alloc_big((size_t)m_all * 8)); // arena.hip: large buffers never go back to the driver while the
+    GM_TRY(kalt.alloc_big((size_t)m_all * 8)); // process may need them again (no hipMalloc stall after large frees)
     timer.done("pb plan: - key buffers (2 x %.1f GB)", (double)m_all * 8 / 1e9);
     const int hot_bit = bin_bits + sb; // the flag bit of a hot edge: the highest sorted bit
     {
@@ -1588,7 +1592,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
             uint32_t Mh = 0;
             GM_HIP(hipMemcpy(&Mh, pl->hbin_v.as<uint32_t>() + Bv, 4, hipMemcpyDeviceToHost));
             pl->Mh = Mh;
-            GM_TRY(pl->hot_ent.alloc((size_t)Mh * 4));
+            GM_TRY(pl->hot_ent.alloc_big((size_t)Mh * 4, 0x407E));
             GM_HIP(hipMemset(pl->hot_ent.p, 0xFF, (size_t)Mh * 4));
             hipLaunchKernelGGL(pb_hot_fill_kernel, dim3(pb_grid(mh)), dim3(256), 0, 0, hkeys, mh, hstart.as<uint32_t>(),
                                pl->hbin_v.as<uint32_t>(), sb, bin_bits, pl->hot_ent.as<uint32_t>());
@@ -1609,8 +1613,8 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     timer.done("pb plan: hot edge stream");
     // (bin, tile) segments of the sorted entries
     DevBuf flag, segid;
-    GM_TRY(flag.alloc((size_t)m * 4));
-    GM_TRY(segid.alloc((size_t)m * 4));
+    GM_TRY(flag.alloc_big((size_t)m * 4));
+    GM_TRY(segid.alloc_big((size_t)m * 4));
     hipLaunchKernelGGL(pb_flags_kernel, dim3(gm_), dim3(256), 0, 0, keys.as<uint64_t>(), m, bin_bits, sb, pl->s_log,
                        flag.as<uint32_t>());
     GM_HIP(hipGetLastError());
@@ -1693,8 +1697,15 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
                        tile_shift, pstart.as<uint32_t>(), pl->delta.as<uint32_t>(), rank_of.as<uint32_t>());
     GM_HIP(hipGetLastError());
 
-    GM_TRY(pl->p2_dst.alloc((size_t)Mv * 2));
-    GM_TRY(pl->p1_src.alloc((size_t)Mp * 2));
+    if (getenv("GM_PB_SPREAD_PLAN")) { // measurement: the two index streams spread the same way
+        unsigned mib = 64, factor = 8, seed = 1;
+        (void)sscanf(getenv("GM_PB_SPREAD_PLAN"), "%u,%u,%u", &mib, &factor, &seed);
+        GM_TRY(pl->p2_dst.alloc_spread((size_t)Mv * 2, (size_t)mib << 20, factor, seed + 101));
+        GM_TRY(pl->p1_src.alloc_spread((size_t)Mp * 2, (size_t)mib << 20, factor, seed + 202));
+    } else { // streamed once per sweep: pieces from all over the arena (arena.hip)
+        GM_TRY(pl->p2_dst.alloc_big((size_t)Mv * 2, 0x9D57));
+        GM_TRY(pl->p1_src.alloc_big((size_t)Mp * 2, 0x9157));
+    }
     GM_TRY(pl->chunk_seg.alloc(((size_t)Mp / PB_WBLK + 1) * 4));
     GM_HIP(hipMemset(pl->p1_src.p, 0x7F, (size_t)Mp * 2)); // padding: an unflagged id (any source of the tile will do)
     GM_HIP(hipMemset(pl->p2_dst.p, 0xFF, (size_t)Mv * 2));
@@ -1733,6 +1744,36 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     GM_HIP(hipMemcpy(pl->wg_first_host.data(), wg_first.p, ((size_t)pl->NT + 1) * 4, hipMemcpyDeviceToHost));
     GM_HIP(hipGetLastError());
     GM_HIP(hipDeviceSynchronize());
+    if (const uint32_t G = (uint32_t)pb_env("GM_PB_WG_GROUP", 0)) {
+        // Tile-major order has the chunks of one tile next to each other: the workgroups running at one time on an XCD
+        // are a few tiles x all their chunks, and what they write to one bin is a few adjacent runs.  Group-major order
+        // (G tiles x ONE chunk at a time) makes it G adjacent runs per bin — longer contiguous stretches of the value
+        // stream filled at one time — at the price of re-reading a tile's out_scores one group pass later.
+        std::vector<uint32_t> tiles(NW), p0s(NW), tg, pg;
+        GM_HIP(hipMemcpy(tiles.data(), pl->wg_tile.p, (size_t)NW * 4, hipMemcpyDeviceToHost));
+        GM_HIP(hipMemcpy(p0s.data(), pl->wg_p0.p, (size_t)NW * 4, hipMemcpyDeviceToHost));
+        tg.reserve(NW), pg.reserve(NW);
+        for (uint32_t t0 = 0; t0 < pl->NT; t0 += G) {
+            const uint32_t t1 = t0 + G < pl->NT ? t0 + G : pl->NT;
+            for (uint32_t c = 0;; ++c) {
+                bool any = false;
+                for (uint32_t t = t0; t < t1; ++t) {
+                    const uint32_t w = pl->wg_first_host[t] + c;
+                    if (w < pl->wg_first_host[t + 1]) {
+                        tg.push_back(tiles[w]), pg.push_back(p0s[w]);
+                        any = true;
+                    }
+                }
+                if (!any)
+                    break;
+            }
+        }
+        GM_CHECK(tg.size() == NW, GM_ERR_INVALID, "pb_build: grouped work list has %zu of %u items", tg.size(), NW);
+        GM_TRY(pl->wg_tile_g.alloc((size_t)NW * 4));
+        GM_TRY(pl->wg_p0_g.alloc((size_t)NW * 4));
+        GM_HIP(hipMemcpy(pl->wg_tile_g.p, tg.data(), (size_t)NW * 4, hipMemcpyHostToDevice));
+        GM_HIP(hipMemcpy(pl->wg_p0_g.p, pg.data(), (size_t)NW * 4, hipMemcpyHostToDevice));
+    }
     return GM_OK;
 }
 
@@ -1804,6 +1845,9 @@ int pb_plan_get(const gm_csr *csr, uint64_t x_len, std::shared_ptr<const PbPlan>
 }
 
 
+static void pb_bin_dispatch(const PbPlan *pl, PbScratch *sc, const float *x_in, uint32_t w_first, uint32_t w_count,
+                            hipStream_t st);
+
 int pb_scratch_create(const PbPlan *pl, PbScratch **out, DevBuf *early)
 {
     PbScratch *sc = new (std::nothrow) PbScratch();
@@ -1822,6 +1866,143 @@ int pb_scratch_create(const PbPlan *pl, PbScratch **out, DevBuf *early)
             sc->vals_raw.bytes = bytes;
         } else {
             (void)hipGetLastError();
+        }
+    }
+    // GM_PB_VALS_VMM=<MiB per physical piece, -1: one piece> (measurement): the stream as a virtual range mapped from
+    // separately allocated physical pieces (HIP virtual-memory API); GM_PB_VALS_VMM_ALIGN=<MiB> aligns the range,
+    // GM_PB_VALS_VMM_SHUFFLE=<seed> maps the pieces in a pseudo-random order
+    // GM_PB_VALS_SHARE=<draw id> (measurement): engines created with the same id use ONE allocation (kept for the life of
+    // the process; one engine at a time may sweep) — variants of the kernels compared on identical pages
+    if (!sc->vals_raw.p && pb_env("GM_PB_VALS_SHARE", 0)) {
+        static std::mutex mu;
+        static std::map<int, std::shared_ptr<DevBuf>> draws;
+        std::lock_guard<std::mutex> lock(mu);
+        std::shared_ptr<DevBuf> &d = draws[pb_env("GM_PB_VALS_SHARE", 0)];
+        const size_t bytes = ((size_t)pl->m + ((size_t)pl->m >> 3) + (64u << 20)) * 4; // room for every variant's padding
+        if (!d) {
+            d = std::make_shared<DevBuf>();
+            if ((rc = pb_env("GM_PB_VALS_VMM", 0) ? d->alloc_vmm(bytes, pb_env("GM_PB_VALS_VMM", 0) < 0 ? 0 : (size_t)pb_env("GM_PB_VALS_VMM", 0) << 20, 0)
+                                                  : d->alloc(bytes))) {
+                d.reset();
+                delete sc;
+                return rc;
+            }
+        }
+        if (d->bytes >= (size_t)(pl->Mv ? pl->Mv : 4) * 4) {
+            sc->vals_shared = d;
+            sc->vals_raw.p = d->p; // borrowed: detached again in the destructor
+            sc->vals_raw.bytes = d->bytes;
+        }
+    }
+    // GM_PB_VALS_POOL="<MiB per piece>,<pieces created>,<first>,<stride>" (measurement): the stream mapped from every
+    // stride-th of a sequence of physical pieces created back to back (DevBuf::alloc_vmm_strided)
+    if (!sc->vals_raw.p && getenv("GM_PB_VALS_POOL")) {
+        unsigned mib = 256, pool = 0, first = 0, stride = 1;
+        (void)sscanf(getenv("GM_PB_VALS_POOL"), "%u,%u,%u,%u", &mib, &pool, &first, &stride);
+        if ((rc = sc->vals_raw.alloc_vmm_strided((size_t)(pl->Mv ? pl->Mv : 4) * 4 + slack, (size_t)mib << 20, pool, first, stride))) {
+            delete sc;
+            return rc;
+        }
+    }
+    // GM_PB_SPREAD="<MiB per piece>,<pool factor>,<seed>": a pseudo-random subset of a pool of pieces (DevBuf::alloc_spread)
+    if (!sc->vals_raw.p && getenv("GM_PB_SPREAD")) {
+        unsigned mib = 64, factor = 8, seed = 1;
+        (void)sscanf(getenv("GM_PB_SPREAD"), "%u,%u,%u", &mib, &factor, &seed);
+        const auto t0 = std::chrono::steady_clock::now();
+        if ((rc = sc->vals_raw.alloc_spread((size_t)(pl->Mv ? pl->Mv : 4) * 4 + slack, (size_t)mib << 20, factor, seed))) {
+            delete sc;
+            return rc;
+        }
+        if (log_enabled())
+            fprintf(stderr, "[graph_mi355x] value stream spread over %zu pieces of %u MiB (pool x%u) took %.2f ms\n",
+                    sc->vals_raw.vmm.size(), mib, factor,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+    if (!sc->vals_raw.p && pb_env("GM_PB_VALS_VMM", 0)) {
+        const size_t bytes = (size_t)(pl->Mv ? pl->Mv : 4) * 4 + slack;
+        const int mib = pb_env("GM_PB_VALS_VMM", 0);
+        const size_t chunk = mib < 0 ? 0 : (size_t)mib << 20;
+        std::vector<uint32_t> order;
+        if (chunk && pb_env("GM_PB_VALS_VMM_SHUFFLE", 0)) {
+            const size_t gran = 2u << 20, c = (chunk + gran - 1) / gran * gran, count = (bytes + c - 1) / c;
+            order.resize(count);
+            for (size_t i = 0; i < count; ++i)
+                order[i] = (uint32_t)i;
+            uint64_t state = (uint64_t)pb_env("GM_PB_VALS_VMM_SHUFFLE", 0) * 0x9E3779B97F4A7C15ull + 1;
+            for (size_t i = count; i > 1; --i) { // Fisher-Yates with a splitmix-style generator
+                state += 0x9E3779B97F4A7C15ull;
+                uint64_t z = state;
+                z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+                z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+                z ^= z >> 31;
+                std::swap(order[i - 1], order[z % i]);
+            }
+        }
+        if ((rc = sc->vals_raw.alloc_vmm(bytes, chunk, (size_t)pb_env("GM_PB_VALS_VMM_ALIGN", 0) << 20,
+                                         order.empty() ? nullptr : order.data()))) {
+            delete sc;
+            return rc;
+        }
+    }
+    // The default: the stream mapped from 64 MiB pieces sampled from all over the arena's free list (arena.hip — right
+    // after a plan build that list holds the build's ~30 GB of temporaries), GM_PB_DRAWS (3) such samples timed with
+    // the bin kernel itself, the fastest kept.  One stretch of physical memory, what hipMalloc returns, costs the bin
+    // kernel 1.66 ms at RMAT scale 26 where a spread stream costs 1.23-1.34 (profiles/r03_placement_*.txt): the DRAM
+    // banks a stretch can use are chosen by high physical address bits.  A draw costs a remap and three launches.
+    if (!sc->vals_raw.p && arena_enabled() && (size_t)pl->Mv * 4 + slack >= ARENA_MIN && pl->NW && pb_env("GM_PB_DRAWS", 3) > 0) {
+        const size_t bytes = (size_t)pl->Mv * 4 + slack;
+        const int draws = pb_env("GM_PB_DRAWS", 3);
+        DevBuf probe_x; // any readable x will do for the timing
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        float best_ms = 0.f;
+        rc = draws > 1 ? probe_x.alloc((size_t)pl->x_len * 4) : GM_OK;
+        hipError_t he = hipSuccess;
+        if (rc == GM_OK && draws > 1) {
+            he = hipMemset(probe_x.p, 0, (size_t)pl->x_len * 4);
+            if (he == hipSuccess)
+                he = hipEventCreate(&e0);
+            if (he == hipSuccess)
+                he = hipEventCreate(&e1);
+        }
+        for (int k = 0; k < draws && rc == GM_OK && he == hipSuccess; ++k) {
+            DevBuf cand;
+            rc = cand.alloc_big(bytes, 0xA11CE5 + 7919ull * (uint64_t)k + pl->NS, 4);
+            if (rc != GM_OK || draws == 1) {
+                if (rc == GM_OK)
+                    sc->vals_raw = std::move(cand);
+                break;
+            }
+            sc->vals = cand.as<float>();
+            pb_bin_dispatch(pl, sc, probe_x.as<float>(), 0, pl->NW, (hipStream_t)0); // clocks up, pages touched
+            he = hipEventRecord(e0, (hipStream_t)0);
+            pb_bin_dispatch(pl, sc, probe_x.as<float>(), 0, pl->NW, (hipStream_t)0);
+            pb_bin_dispatch(pl, sc, probe_x.as<float>(), 0, pl->NW, (hipStream_t)0);
+            if (he == hipSuccess)
+                he = hipEventRecord(e1, (hipStream_t)0);
+            if (he == hipSuccess)
+                he = hipEventSynchronize(e1);
+            float ms = 0.f;
+            if (he == hipSuccess)
+                he = hipEventElapsedTime(&ms, e0, e1);
+            if (log_enabled())
+                fprintf(stderr, "[graph_mi355x] value stream draw %d: bin kernel %.3f ms\n", k, ms / 2);
+            if (he == hipSuccess && (!sc->vals_raw.p || ms < best_ms)) {
+                best_ms = ms;
+                sc->vals_raw = std::move(cand); // the loser goes back to the arena
+            }
+        }
+        sc->vals = nullptr;
+        if (e0)
+            (void)hipEventDestroy(e0);
+        if (e1)
+            (void)hipEventDestroy(e1);
+        if (he != hipSuccess && rc == GM_OK) {
+            set_error("pb_scratch_create: timing the value stream draws: %s", hipGetErrorString(he));
+            rc = GM_ERR_HIP;
+        }
+        if (rc != GM_OK) {
+            delete sc;
+            return rc;
         }
     }
     if ((rc = sc->vals_raw.p ? GM_OK : sc->vals_raw.alloc((size_t)(pl->Mv ? pl->Mv : 4) * 4 + slack)) ||
@@ -1878,8 +2059,10 @@ void pb_plan_info(const PbPlan *pl, const PbScratch *sc, uint64_t *info, uint32_
 template <int ABL, int S_LOG>
 void pb_launch_bin(const PbPlan *pl, PbScratch *sc, const float *x_in, uint32_t w_first, uint32_t w_count, hipStream_t st)
 {
+    const bool grouped = pl->wg_tile_g.p && w_first == 0 && w_count == pl->NW; // whole sweeps only
     hipLaunchKernelGGL((pb_bin_kernel<ABL, S_LOG>), dim3(w_count), dim3(PB_BIN_BLOCK), (4u << S_LOG) + PB_DCACHE * 4, st, x_in,
-                       pl->x_len, pl->tile_p.as<uint32_t>(), pl->wg_tile.as<uint32_t>(), pl->wg_p0.as<uint32_t>(),
+                       pl->x_len, pl->tile_p.as<uint32_t>(), (grouped ? pl->wg_tile_g : pl->wg_tile).as<uint32_t>(),
+                       (grouped ? pl->wg_p0_g : pl->wg_p0).as<uint32_t>(),
                        pl->p1_src.as<uint16_t>(), pl->chunk_seg.as<uint32_t>(), pl->delta.as<uint32_t>(), sc->vals,
                        pl->chunk, w_first, pl->xcd_aware);
 }
@@ -1950,14 +2133,21 @@ static void pb_hot_dispatch(const PbPlan *pl, PbScratch *sc, const float *x_in, 
                            pl->hot_ids.as<uint32_t>(), pl->H, sc->hot_x.as<float>());
 }
 
-int pb_sweep_main(const PbPlan *pl, PbScratch *sc, const float *x_in, float *x_out, float *scores,
-                  const uint32_t *outdeg, float base, float damping, hipStream_t st)
+// GM_PB_VALS_OFFSET=<KiB> (measurements only; needs GM_PB_VALS_SLACK at creation): where inside its allocation the value
+// stream starts, re-read at every launch
+static void pb_apply_vals_offset(const PbPlan *pl, PbScratch *sc)
 {
-    if (const char *off = getenv("GM_PB_VALS_OFFSET")) { // measurements only (needs GM_PB_VALS_SLACK at creation)
+    if (const char *off = getenv("GM_PB_VALS_OFFSET")) {
         const size_t bytes = (size_t)atoll(off) << 10;
         if (bytes + (size_t)pl->Mv * 4 <= sc->vals_raw.bytes)
             sc->vals = reinterpret_cast<float *>(sc->vals_raw.as<char>() + bytes);
     }
+}
+
+int pb_sweep_main(const PbPlan *pl, PbScratch *sc, const float *x_in, float *x_out, float *scores,
+                  const uint32_t *outdeg, float base, float damping, hipStream_t st)
+{
+    pb_apply_vals_offset(pl, sc);
     pb_hot_dispatch(pl, sc, x_in, st);
     pb_bin_dispatch(pl, sc, x_in, 0, pl->NW, st);
     // the hub groups need little LDS: on a second stream their workgroups run beside those of the ordinary bins
@@ -2027,6 +2217,7 @@ int pb_sweep_bin_range(const PbPlan *pl, PbScratch *sc, const float *x_in, uint6
     if (pl->NW == 0 || tile_lo >= tile_hi)
         return GM_OK;
     const uint32_t w0 = pl->wg_first_host[tile_lo], w1 = pl->wg_first_host[tile_hi > pl->NT ? pl->NT : tile_hi];
+    pb_apply_vals_offset(pl, sc);
     pb_bin_dispatch(pl, sc, x_in, w0, w1 - w0, st);
     GM_HIP(hipGetLastError());
     return GM_OK;

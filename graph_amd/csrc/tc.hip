@@ -101,6 +101,61 @@ __global__ __launch_bounds__(TC_BLOCK) void tc_order_kernel(const uint32_t *__re
         atomicOr(flags, f);
 }
 
+// Is the CSR its own transpose?  tc_rows_kernel finds the pairs (u, v), v < u, through v's UPPER neighbours, which is
+// only right when every entry (v, u) has its mirror (u, v) — true for UndirectedCsrGraph builds, not for whatever
+// sorted CSR a caller uploads or wraps.  On strictly increasing lists every ordered pair occurs at most once, so the
+// lists are symmetric iff the multiset of pairs named by upper entries equals the one named by lower entries: two
+// independent 64-bit fingerprints, sum over upper entries of H(u, t) minus sum over lower entries of H(t, u), both 0
+// (mod 2^64).  A mismatch sends the whole count down the search path, which reads only L(u) and L(v).
+__device__ __forceinline__ uint64_t tc_mix(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(TC_BLOCK) void tc_symmetry_kernel(const uint32_t *__restrict__ off,
+                                                               const uint32_t *__restrict__ tgt, uint32_t n,
+                                                               unsigned long long *__restrict__ fp /* [2] */)
+{
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t n_pad = (n + kWave - 1) / kWave * kWave;
+    uint64_t a = 0, b = 0;
+    auto add = [&](uint32_t u, uint32_t t) {
+        if (t == u)
+            return;
+        const uint64_t key = t > u ? ((uint64_t)u << 32 | t) : ((uint64_t)t << 32 | u);
+        const uint64_t h1 = tc_mix(key + 0x9E3779B97F4A7C15ull), h2 = tc_mix(key ^ 0xD6E8FEB86659FD93ull);
+        a += t > u ? h1 : (uint64_t)0 - h1;
+        b += t > u ? h2 : (uint64_t)0 - h2;
+    };
+    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n_pad; u += stride) {
+        uint32_t s = 0, e = 0;
+        if (u < n) {
+            s = off[u];
+            e = off[u + 1];
+        }
+        if (e - s <= 32)
+            for (uint32_t i = s; i < e; ++i)
+                add(u, tgt[i]);
+        uint64_t big = __ballot(e - s > 32);
+        while (big) {
+            const int src = __ffsll((unsigned long long)big) - 1;
+            big &= big - 1;
+            const uint32_t bu = __shfl(u, src, kWave), bs = __shfl(s, src, kWave), be = __shfl(e, src, kWave);
+            for (uint32_t i = bs + lane; i < be; i += kWave)
+                add(bu, tgt[i]);
+        }
+    }
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (lane == 0 && (a | b)) {
+        atomicAdd(&fp[0], (unsigned long long)a);
+        atomicAdd(&fp[1], (unsigned long long)b);
+    }
+}
+
 __global__ void tc_short_pad_kernel(const uint32_t *__restrict__ short_len, uint32_t n, uint32_t *__restrict__ padded)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -478,6 +533,7 @@ struct gm::TcDag {
     uint32_t flags = 0; // 2: some list has equal neighbours or a self-loop (general path only)
     uint32_t dag_m = 0;
     bool rows_ok = false; // dag16 / rec exist: tc_rows_kernel can run
+    bool symmetric = true; // strictly increasing lists only: every entry has its mirror (else: search path only)
 };
 
 namespace {
@@ -535,6 +591,18 @@ int tc_prepare(const gm_csr *g, gm::TcDag &d)
         return GM_OK;
     // the 2-byte fronts and the records are only read by tc_rows_kernel (strictly increasing lists)
     d.rows_ok = (d.flags & 2u) == 0; // they need 2 B x short entries + 128 B x nodes beside the DAG
+    if (d.rows_ok) { // ... and a CSR that is its own transpose (tc_symmetry_kernel)
+        gm::DevBuf fp;
+        GM_TRY(fp.alloc(16));
+        GM_HIP(hipMemset(fp.p, 0, 16));
+        hipLaunchKernelGGL(tc_symmetry_kernel, dim3(grid), dim3(TC_BLOCK), 0, 0, g->offsets, g->targets, n,
+                           fp.as<unsigned long long>());
+        GM_HIP(hipGetLastError());
+        unsigned long long h[2] = {0, 0};
+        GM_HIP(hipMemcpy(h, fp.p, 16, hipMemcpyDeviceToHost));
+        d.symmetric = (h[0] | h[1]) == 0;
+        d.rows_ok = d.symmetric;
+    }
     GM_HIP(hipMemcpy(&short_m, loff16.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost));
     GM_TRY(d.dag_src.alloc((size_t)d.dag_m * 4));
     GM_TRY(d.dag_tgt.alloc((size_t)d.dag_m * 4));

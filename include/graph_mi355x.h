@@ -13,8 +13,19 @@
  *     gm_last_error() gives a thread-local message for the last failure on this thread.
  *   - node ids on the device are u32 (the reference's NI = u32; usize graphs are narrowed at
  *     upload with a range check -> GM_ERR_RANGE).
- *   - host buffers are owned by the caller; a gm_csr is immutable after creation and may be
- *     used from several host threads at once (every call allocates its own scratch).
+ *   - host buffers are owned by the caller; the graph a gm_csr holds is immutable after creation and
+ *     the handle may be used from several host threads at once.
+ *   - WHAT A HANDLE RETAINS.  Besides the graph, a handle keeps what its algorithms derived from it
+ *     or last worked in, so that repeated calls (the reference's app times each algorithm in a loop)
+ *     do not pay for it again: PageRank's propagation-blocking plan (~4.3 B/edge) and the stream,
+ *     vectors and engine of the last gm_page_rank call (~3.4 B/edge + 12 B/node: ~9 GB at RMAT
+ *     scale 26); the working set of the last gm_sssp_delta_stepping (~9 B/node) and gm_wcc_* call
+ *     (~8 B/node); gm_triangle_count's DAG of lower prefixes and list records (~6 B/entry +
+ *     128 B/node: 4.7 GB at scale 24).  A concurrent second call of one algorithm allocates its own
+ *     working set.  gm_csr_trim() releases all of it (the next call rebuilds what it needs);
+ *     gm_csr_free() releases everything.  Large buffers come from a per-device arena of 64 MiB
+ *     physical pieces that the library keeps for reuse (up to GM_ARENA_KEEP_GIB, default 32);
+ *     gm_trim() returns the unused ones to the driver.
  *   - "device pointer" arguments are plain addresses in the HBM of the handle's device
  *     (e.g. hipMalloc or torch.Tensor.data_ptr()); `stream` is a hipStream_t passed as void*.
  */
@@ -68,6 +79,14 @@ int gm_csr_upload_u64(const uint64_t *offsets, const uint64_t *targets, const fl
 int gm_csr_wrap_device(uint64_t d_offsets, uint64_t d_targets, uint64_t d_weights, uint64_t n, uint64_t m,
                        int device, gm_csr **out);
 void gm_csr_free(gm_csr *csr);
+/* Releases what the handle has parked for later calls (see "WHAT A HANDLE RETAINS" above): plans, DAGs,
+ * working sets.  The graph itself stays; calls in flight keep what they are using. */
+int gm_csr_trim(const gm_csr *csr);
+/* Returns the arena's unused physical memory on `device` (-1: the current device) to the driver. */
+int gm_trim(int device);
+/* info_out[4]: bytes of device memory the arena holds, bytes of it not in use, 64 MiB pieces created so far,
+ * pieces handed out so far. */
+int gm_arena_info(int device, uint64_t *info_out);
 uint64_t gm_csr_node_count(const gm_csr *csr);
 uint64_t gm_csr_edge_count(const gm_csr *csr); /* number of target entries (csr.rs:76-78) */
 int gm_csr_device(const gm_csr *csr);
