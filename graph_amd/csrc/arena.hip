@@ -86,29 +86,42 @@ size_t arena_keep_bytes()
     return (size_t)(gib < 0 ? 0 : gib) << 30;
 }
 
-int arena_take(int dev, size_t count, uint64_t spread_seed, size_t spread_factor, std::vector<ArenaPiece> &out)
+int arena_take(int dev, size_t count, uint64_t spread_seed, size_t spread_factor, std::vector<ArenaPiece> &out,
+               uint64_t serial_lo, uint64_t serial_hi)
 {
     Arena &a = arena_of(dev);
     std::lock_guard<std::mutex> lock(a.mu);
     out.clear();
+    const bool ranged = serial_lo != 0 || serial_hi != ~0ull;
     const size_t want_free = spread_seed ? count * (spread_factor ? spread_factor : 1) : count;
-    if (a.free_list.size() < want_free) {
+    if (!ranged && a.free_list.size() < want_free) {
         const int rc = create_pieces(a, dev, want_free - a.free_list.size());
         if (rc != GM_OK && a.free_list.size() < count)
             return rc; // a smaller pool than asked for still serves the request
     }
-    a.reused += count;
     if (!spread_seed) { // any pieces: the most recently returned ones
+        a.reused += count;
         out.assign(a.free_list.end() - (ptrdiff_t)count, a.free_list.end());
         a.free_list.resize(a.free_list.size() - count);
         return GM_OK;
     }
-    // one pseudo-random piece from every stratum of the free list (kept in creation order)
+    // one pseudo-random piece from every stratum of the free list (kept in creation order) — of its part with serials
+    // in [serial_lo, serial_hi) when a range is given
     std::sort(a.free_list.begin(), a.free_list.end(), [](const ArenaPiece &x, const ArenaPiece &y) { return x.serial < y.serial; });
-    const size_t F = a.free_list.size();
+    size_t f0 = 0, f1 = a.free_list.size();
+    while (f0 < f1 && a.free_list[f0].serial < serial_lo)
+        ++f0;
+    while (f1 > f0 && a.free_list[f1 - 1].serial >= serial_hi)
+        --f1;
+    if (f1 - f0 < count) {
+        set_error("arena: %zu free pieces in the serial range, %zu wanted", f1 - f0, count);
+        return GM_ERR_NOMEM;
+    }
+    a.reused += count;
+    const size_t F = a.free_list.size(), W = f1 - f0;
     std::vector<bool> taken(F, false);
     for (size_t i = 0; i < count; ++i) {
-        const size_t lo = i * F / count, hi = (i + 1) * F / count; // hi > lo: F >= count
+        const size_t lo = f0 + i * W / count, hi = f0 + (i + 1) * W / count; // hi > lo: W >= count
         const size_t k = lo + (size_t)(mix64(spread_seed * 0x9E3779B97F4A7C15ull + i) % (hi - lo));
         taken[k] = true;
         out.push_back(a.free_list[k]);
@@ -149,6 +162,16 @@ void arena_trim(int dev, size_t keep_bytes)
     Arena &a = arena_of(dev);
     std::lock_guard<std::mutex> lock(a.mu);
     trim_locked(a, keep_bytes);
+}
+
+// `count` more pieces in the free list (newer serials than any before); *first_serial_out = the first of them
+int arena_grow(int dev, size_t count, uint64_t *first_serial_out)
+{
+    Arena &a = arena_of(dev);
+    std::lock_guard<std::mutex> lock(a.mu);
+    if (first_serial_out)
+        *first_serial_out = a.next_serial;
+    return create_pieces(a, dev, count);
 }
 
 void arena_stats(int dev, uint64_t *out4)

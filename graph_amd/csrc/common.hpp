@@ -80,7 +80,10 @@ struct ArenaPiece {
 };
 bool arena_enabled(); // GM_ARENA=0: every buffer from hipMalloc
 // `count` pieces; spread_seed != 0: a stratified pseudo-random subset of a free list of >= count x spread_factor pieces
-int arena_take(int dev, size_t count, uint64_t spread_seed, size_t spread_factor, std::vector<ArenaPiece> &out);
+// (of the free pieces created as numbers [serial_lo, serial_hi), when that range is given: no growth then)
+int arena_take(int dev, size_t count, uint64_t spread_seed, size_t spread_factor, std::vector<ArenaPiece> &out,
+               uint64_t serial_lo = 0, uint64_t serial_hi = ~0ull);
+int arena_grow(int dev, size_t count, uint64_t *first_serial_out);
 void arena_give(int dev, std::vector<ArenaPiece> &pieces);
 void arena_trim(int dev, size_t keep_bytes);
 void arena_stats(int dev, uint64_t *out4);
@@ -154,7 +157,10 @@ struct DevBuf {
     // A large buffer from the arena's 64 MiB pieces (arena.hip); spread_seed != 0: pieces sampled from all over the
     // arena's free list, which is grown to spread_factor times the request first.  Small requests, and every request
     // under GM_ARENA=0, take the hipMalloc path.  Contents are NOT zero (hipMalloc does not promise that either).
-    int alloc_big(size_t nbytes, uint64_t spread_seed = 0, size_t spread_factor = 4)
+    // serial_lo / serial_hi: only pieces created as numbers [lo, hi) (arena_grow); split_serial != 0: every other piece
+    // of the buffer from below that serial, the others from it on
+    int alloc_big(size_t nbytes, uint64_t spread_seed = 0, size_t spread_factor = 4, uint64_t serial_lo = 0,
+                  uint64_t serial_hi = ~0ull, uint64_t split_serial = 0)
     {
         if (!arena_enabled() || nbytes < ARENA_MIN)
             return alloc(nbytes);
@@ -162,7 +168,22 @@ struct DevBuf {
         int dev = 0;
         GM_HIP(hipGetDevice(&dev));
         const size_t count = (nbytes + ARENA_PIECE - 1) / ARENA_PIECE, span = count * ARENA_PIECE;
-        GM_TRY(arena_take(dev, count, spread_seed, spread_factor, arena));
+        if (split_serial && spread_seed) {
+            std::vector<ArenaPiece> older, newer;
+            GM_TRY(arena_take(dev, count / 2, spread_seed, 1, older, serial_lo, split_serial));
+            int rc2 = arena_take(dev, count - count / 2, spread_seed + 1, 1, newer, split_serial, serial_hi);
+            if (rc2 != GM_OK) {
+                arena_give(dev, older);
+                return rc2;
+            }
+            for (size_t i = 0; i < newer.size(); ++i) {
+                arena.push_back(newer[i]);
+                if (i < older.size())
+                    arena.push_back(older[i]);
+            }
+        } else {
+            GM_TRY(arena_take(dev, count, spread_seed, spread_factor, arena, serial_lo, serial_hi));
+        }
         arena_dev = dev;
         void *base = nullptr;
         hipError_t e = hipMemAddressReserve(&base, span, ARENA_PIECE, nullptr, 0);

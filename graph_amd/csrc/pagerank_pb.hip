@@ -76,6 +76,7 @@ struct HubUnit {
 constexpr uint32_t PB_HUB_MAX = 64;  // rows of a hub group (one lane of a wavefront each)
 constexpr uint16_t PB_HUBROW = 0xFFFEu; // cidx of a hub row: its sum is produced by pb_hub_kernel, not by its bin
 constexpr uint16_t PB_FLAG = 0x8000u;
+constexpr int PB_TIERS_DEFAULT = 16;  // at most this many tiers of hot sources unless GM_PB_TIERS says otherwise
 constexpr float PB_FIX_SCALE = 4611686018427387904.0f;     // 2^62
 constexpr float PB_FIX_INV = 2.168404344971008868e-19f;    // 2^-62
 
@@ -161,10 +162,16 @@ struct PbPlan {
     uint32_t NI = 0;    // accumulate workgroups
     // hot sources: the H most frequent sources of this rank's edges skip the value stream; their
     // out_scores are staged in LDS by the accumulate kernel and gathered there
-    uint32_t H = 0;     // hot sources (0 = feature off)
-    DevBuf hot_ids;     // u32[H]   x index of each hot source
-    DevBuf hot_ent;     // u32[Mh]  hot edges, bin-major: row_in_bin << 16 | hot index; 0xFFFFFFFF = padding
-    DevBuf hbin_v;      // u32[B+1] hot-edge range of each bin (multiples of 4)
+    // ... in TIERS: the LDS beside the accumulators holds the out_scores of H sources at a time, and an accumulate
+    // workgroup walks through T such tables one after the other (tier t = the sources ranked [t H, (t + 1) H) by
+    // frequency), each followed by the bin's hot edges of that tier.  A further tier costs every workgroup one table
+    // load from L2 (4 H bytes) and two barriers, and moves its edges from 12 to 4 streamed bytes.
+    uint32_t H = 0;     // hot sources per tier (0 = feature off)
+    uint32_t T = 1;     // tiers
+    uint32_t Htot = 0;  // hot sources in all (<= T * H; the last tier may be partly filled)
+    DevBuf hot_ids;     // u32[Htot] x index of each hot source, by rank
+    DevBuf hot_ent;     // u32[Mh]  hot edges, (bin, tier)-major: row_in_bin << 16 | index inside the tier; 0xFFFFFFFF = padding
+    DevBuf hbin_v;      // u32[(B + G) T + 1] hot-edge range of each (bin, tier) (multiples of 4)
     uint64_t Mh = 0;
     // host copies for launches over a range of source tiles / a group of bins (partitioned sweeps that
     // overlap the exchange of one part of x with the work on another)
@@ -189,13 +196,13 @@ namespace {
 // from that table was most of this kernel's time).
 __device__ __forceinline__ uint64_t pb_make_key(uint64_t hi_cold, uint32_t src, int sb, int bb,
                                                 const uint32_t *filter, int fshift,
-                                                const uint16_t *__restrict__ hot_rank)
+                                                const uint32_t *__restrict__ hot_rank)
 {
     if (filter) {
         const uint32_t blk = src >> fshift;
         if ((filter[blk >> 5] >> (blk & 31u)) & 1u) {
-            const uint16_t h = hot_rank[src];
-            if (h != PB_NULL)
+            const uint32_t h = hot_rank[src];
+            if (h != 0xFFFFFFFFu)
                 return hi_cold | (1ull << (sb + bb)) | h;
         }
     }
@@ -294,27 +301,49 @@ __global__ __launch_bounds__(256) void pb_count_keys_kernel(const uint32_t *__re
 
 // the first H candidates become hot: rank table + the block filter pb_keys_kernel stages in LDS
 __global__ void pb_hot_select_kernel(const uint64_t *__restrict__ sorted, uint32_t H, uint32_t *__restrict__ hot_ids,
-                                     uint16_t *__restrict__ hot_rank, uint32_t *__restrict__ hot_blk, int fshift)
+                                     uint32_t *__restrict__ hot_rank, uint32_t *__restrict__ hot_blk, int fshift)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= H)
         return;
     const uint32_t id = (uint32_t)sorted[k];
     hot_ids[k] = id;
-    hot_rank[id] = (uint16_t)k;
+    hot_rank[id] = k;
     atomicOr(&hot_blk[(id >> fshift) >> 5], 1u << ((id >> fshift) & 31u));
 }
 
+// (bin, tier) of a hot key as one index: bin * T + rank / H
+__device__ __forceinline__ uint32_t pb_hot_cell(uint64_t k, int sb, int bb, uint32_t H, uint32_t T)
+{
+    const uint32_t bin = (uint32_t)(k >> sb) & (uint32_t)((1ull << bb) - 1ull);
+    const uint32_t r = (uint32_t)(k & ((1ull << sb) - 1ull));
+    return bin * T + r / H;
+}
+
+// hstart[c] = first hot key (they are sorted by (bin, rank)) whose cell is >= c, for c in [0, cells]
+__global__ void pb_hot_bounds_kernel(const uint64_t *__restrict__ hkeys, uint32_t mh, int sb, int bb, uint32_t H, uint32_t T,
+                                     uint32_t cells, uint32_t *__restrict__ hstart)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= mh; i += stride) {
+        const uint32_t lo = i == 0 ? 0u : pb_hot_cell(hkeys[i - 1], sb, bb, H, T) + 1u;
+        const uint32_t hi = i == mh ? cells : pb_hot_cell(hkeys[i], sb, bb, H, T);
+        for (uint32_t c = lo; c <= hi; ++c)
+            hstart[c] = i;
+    }
+}
+
 __global__ void pb_hot_fill_kernel(const uint64_t *__restrict__ hkeys, uint32_t mh, const uint32_t *__restrict__ hstart,
-                                   const uint32_t *__restrict__ hbin_v, int sb, int bb, uint32_t *__restrict__ hot_ent)
+                                   const uint32_t *__restrict__ hbin_v, int sb, int bb, uint32_t H, uint32_t T,
+                                   uint32_t *__restrict__ hot_ent)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < mh; i += stride) {
         const uint64_t k = hkeys[i];
-        const uint32_t bin = (uint32_t)(k >> sb) & (uint32_t)((1ull << bb) - 1ull);
+        const uint32_t cell = pb_hot_cell(k, sb, bb, H, T);
         const uint32_t slot = (uint32_t)(k >> (sb + bb + 1));
-        const uint32_t h = (uint32_t)(k & ((1ull << sb) - 1ull));
-        hot_ent[hbin_v[bin] + (i - hstart[bin])] = (slot << 16) | h;
+        const uint32_t r = (uint32_t)(k & ((1ull << sb) - 1ull));
+        hot_ent[hbin_v[cell] + (i - hstart[cell])] = (slot << 16) | (r % H);
     }
 }
 
@@ -340,7 +369,7 @@ constexpr int PB_FILTER_DEFAULT = 18; // measured at scale 26: 2^20 bits 14.2 ms
 __global__ __launch_bounds__(PB_KEYS_BLOCK) void pb_keys_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt,
                                                                uint32_t n, int rb, int sb, int bb,
                                                                const uint32_t *__restrict__ hot_blk, uint32_t filter_words,
-                                                               int fshift, const uint16_t *__restrict__ hot_rank,
+                                                               int fshift, const uint32_t *__restrict__ hot_rank,
                                                                const uint16_t *__restrict__ cidx,
                                                                const uint32_t *__restrict__ pos_h,
                                                                const uint32_t *__restrict__ hub_first, uint32_t B, uint32_t G,
@@ -753,8 +782,9 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
                                                                 const uint16_t *__restrict__ p2_dst,
                                                                 const PbItem *__restrict__ items,
                                                                 const uint32_t *__restrict__ hot_ent,
-                                                                const float *__restrict__ hot_x, uint32_t H,
-                                                                unsigned long long *partials, uint32_t *tickets,
+                                                                const uint32_t *__restrict__ hbin_v,
+                                                                const float *__restrict__ hot_x, uint32_t H, uint32_t T,
+                                                                uint32_t Htot, unsigned long long *partials, uint32_t *tickets,
                                                                 const uint16_t *__restrict__ cidx,
                                                                 const uint32_t *__restrict__ outdeg, float *__restrict__ scores,
                                                                 float *__restrict__ x_out, double *__restrict__ bin_err,
@@ -766,7 +796,7 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
     __shared__ bool is_last;
     const PbItem item = items[blockIdx.x]; // longest items are dispatched first
     const uint32_t b = item.bin, tid = threadIdx.x;
-    float *hot = reinterpret_cast<float *>(acc + Racc); // H out_scores of the hot sources
+    float *hot = reinterpret_cast<float *>(acc + Racc); // the out_scores of one tier of hot sources (H at most)
     const uint32_t qb = item.q0, qe = (ABL == 4 ? item.q0 : item.q1); // multiples of 4
     constexpr int U = PB_ACC_U;
     constexpr uint32_t STEP = PB_ACC_BLOCK * PB_VEC;
@@ -794,21 +824,64 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
         fetch(q_first, v, d);
     for (uint32_t i = tid; i < Racc; i += PB_ACC_BLOCK)
         acc[i] = 0ull;
-    if (item.h1 > item.h0) { // hot_x and the LDS table are 16-byte aligned and padded to a multiple of 4
-        constexpr int HB = 4;
-        const uint32_t H4 = (H + 3u) / 4u;
-        for (uint32_t i0 = tid; i0 < H4; i0 += PB_ACC_BLOCK * HB) {
-            f32x4 t[HB];
-#pragma unroll
-            for (int k = 0; k < HB; ++k)
-                if (i0 + k * PB_ACC_BLOCK < H4)
-                    t[k] = *reinterpret_cast<const f32x4 *>(hot_x + 4u * (i0 + k * PB_ACC_BLOCK));
-#pragma unroll
-            for (int k = 0; k < HB; ++k)
-                if (i0 + k * PB_ACC_BLOCK < H4)
-                    *reinterpret_cast<f32x4 *>(hot + 4u * (i0 + k * PB_ACC_BLOCK)) = t[k];
+    // hot edges of this item, tier by tier: [ha, hb) inside the (bin, tier) cell; a slice of an over-long bin takes its
+    // share of every cell
+    auto tier_range = [&](uint32_t t, uint32_t &ha, uint32_t &hb) {
+        ha = hbin_v[b * T + t];
+        hb = hbin_v[b * T + t + 1];
+        if (item.nparts > 1) {
+            const uint32_t per = (((hb - ha) + item.nparts - 1u) / item.nparts + 3u) & ~3u;
+            const uint32_t lo = ha + item.part * per;
+            ha = lo < hb ? lo : hb;
+            hb = (hb - ha) < per ? hb : ha + per;
         }
-    }
+    };
+    // Two tables in LDS (T > 1): while the edges of one tier gather from one of them, the next tier's table is on its
+    // way through registers (tier_fetch, three float4 per lane) into the other (tier_store), and ONE barrier per tier
+    // separates the two uses of a buffer.  A tier switch that waited for its table cost every workgroup ~5 us
+    // (measured: +0.04 ms per tier and sweep at scale 26).  hot_x and the tables are 16-byte aligned, a tier is
+    // padded to a multiple of 4.
+    constexpr int HB = 4; // float4 per lane: tables of up to 16384 sources (one table, T == 1: up to 32768 in two rounds)
+    const uint32_t Hpad = (H + 3u) & ~3u;
+    f32x4 tnext[HB];
+    auto tier_fetch = [&](uint32_t t, uint32_t round) {
+        const uint32_t len = (Htot - t * H) < H ? (Htot - t * H) : H;
+        const uint32_t H4 = (len + 3u) / 4u;
+        const float *src = hot_x + (size_t)t * H;
+#pragma unroll
+        for (int k = 0; k < HB; ++k) {
+            const uint32_t i = tid + (round * HB + k) * PB_ACC_BLOCK;
+            if (i < H4)
+                tnext[k] = *reinterpret_cast<const f32x4 *>(src + 4u * i);
+        }
+    };
+    auto tier_store = [&](uint32_t t, uint32_t round, float *table) {
+        const uint32_t len = (Htot - t * H) < H ? (Htot - t * H) : H;
+        const uint32_t H4 = (len + 3u) / 4u;
+#pragma unroll
+        for (int k = 0; k < HB; ++k) {
+            const uint32_t i = tid + (round * HB + k) * PB_ACC_BLOCK;
+            if (i < H4)
+                *reinterpret_cast<f32x4 *>(table + 4u * i) = tnext[k];
+        }
+    };
+    // the first tier with edges for this item at or behind t (T: none); uniform over the workgroup
+    auto next_tier = [&](uint32_t t) {
+        for (; H && t < T && ABL != 4; ++t) {
+            uint32_t ha, hb;
+            tier_range(t, ha, hb);
+            if (hb > ha)
+                break;
+        }
+        return (H && ABL != 4) ? t : T;
+    };
+    uint32_t tier = next_tier(0);
+    float *table = hot; // the table the current tier's edges gather from
+    if (tier < T)
+        for (uint32_t round = 0; round * HB * PB_ACC_BLOCK * 4u < H; ++round) {
+            tier_fetch(tier, round);
+            tier_store(tier, round, table);
+        }
     __syncthreads();
     for (uint32_t q0 = q_first; q0 < qe; q0 += STEP * U) {
         f32x4 vn[U];
@@ -835,29 +908,66 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
             }
         }
     }
-    // hot edges: 4 bytes each (row_in_bin << 16 | hot index), the value comes from the LDS table
-    {
-        constexpr int HU = 4;
-        const uint32_t h_end = ABL == 4 ? item.h0 : item.h1;
-        for (uint32_t h0 = item.h0 + tid * PB_VEC; h0 < h_end; h0 += PB_ACC_BLOCK * PB_VEC * HU) {
-            uint4 e[HU];
+    // hot edges: 4 bytes each (row_in_bin << 16 | index inside the tier), the value comes from the tier's LDS table.
+    // The (tier, batch) pairs form ONE software-pipelined sequence: the entries of the next batch — the first one of
+    // the next tier, when this tier is done — are requested before this batch is processed, and the next tier's
+    // table is requested at this tier's first batch.  A tier with a few thousand edges per bin is a single, partly
+    // filled batch: without the pipeline across the tier switch every tier cost one exposed HBM round trip.
+    if (tier < T) {
+        constexpr int HU = 2;
+        constexpr uint32_t BATCH = PB_ACC_BLOCK * PB_VEC * HU; // entries of one batch
+        uint32_t base, h_end; // this batch starts at `base` (workgroup-uniform) of the tier's range [.., h_end)
+        tier_range(tier, base, h_end);
+        auto fetch_hot = [&](uint32_t b0, uint32_t end, uint4(&ee)[HU]) {
 #pragma unroll
             for (int k = 0; k < HU; ++k) {
-                const uint32_t h = h0 + (uint32_t)k * PB_ACC_BLOCK * PB_VEC;
-                e[k] = h < h_end ? *reinterpret_cast<const uint4 *>(hot_ent + h)
-                                 : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+                const uint32_t h = b0 + tid * PB_VEC + (uint32_t)k * PB_ACC_BLOCK * PB_VEC;
+                ee[k] = h < end ? *reinterpret_cast<const uint4 *>(hot_ent + h)
+                                : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
             }
+        };
+        uint4 e[HU], en[HU];
+        fetch_hot(base, h_end, e);
+        uint32_t after = next_tier(tier + 1); // the tier behind this one (T: none)
+        if (after < T)
+            tier_fetch(after, 0); // T > 1: H <= 16384, one round
+        for (;;) {
+            // where the next batch lies
+            uint32_t nbase = base + BATCH, nend = h_end, ntier = tier;
+            if (nbase >= h_end) {
+                ntier = after;
+                if (ntier < T)
+                    tier_range(ntier, nbase, nend);
+            }
+            if (ntier < T)
+                fetch_hot(nbase, nend, en);
 #pragma unroll
             for (int k = 0; k < HU; ++k) {
                 if (e[k].x != 0xFFFFFFFFu)
-                    atomicAdd(&acc[e[k].x >> 16], pb_to_fix(hot[e[k].x & 0xFFFFu]));
+                    atomicAdd(&acc[e[k].x >> 16], pb_to_fix(table[e[k].x & 0xFFFFu]));
                 if (e[k].y != 0xFFFFFFFFu)
-                    atomicAdd(&acc[e[k].y >> 16], pb_to_fix(hot[e[k].y & 0xFFFFu]));
+                    atomicAdd(&acc[e[k].y >> 16], pb_to_fix(table[e[k].y & 0xFFFFu]));
                 if (e[k].z != 0xFFFFFFFFu)
-                    atomicAdd(&acc[e[k].z >> 16], pb_to_fix(hot[e[k].z & 0xFFFFu]));
+                    atomicAdd(&acc[e[k].z >> 16], pb_to_fix(table[e[k].z & 0xFFFFu]));
                 if (e[k].w != 0xFFFFFFFFu)
-                    atomicAdd(&acc[e[k].w >> 16], pb_to_fix(hot[e[k].w & 0xFFFFu]));
+                    atomicAdd(&acc[e[k].w >> 16], pb_to_fix(table[e[k].w & 0xFFFFu]));
             }
+            if (ntier >= T)
+                break;
+            if (ntier != tier) {
+                // the other buffer: every wavefront left it at the last barrier (it held the tier before this one)
+                float *other = table == hot ? hot + Hpad : hot;
+                tier_store(ntier, 0, other);
+                __syncthreads();
+                table = other;
+                after = next_tier(ntier + 1);
+                if (after < T)
+                    tier_fetch(after, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < HU; ++k)
+                e[k] = en[k];
+            tier = ntier, base = nbase, h_end = nend;
         }
     }
     __syncthreads();
@@ -1288,8 +1398,12 @@ int pb_make_items(PbPlan *pl)
     const uint32_t Bv = pl->B + pl->G; // virtual bins of the streams
     std::vector<uint32_t> bv((size_t)Bv + 1), hv((size_t)Bv + 1, 0u);
     GM_HIP(hipMemcpy(bv.data(), pl->bin_v.p, bv.size() * 4, hipMemcpyDeviceToHost));
-    if (pl->H)
-        GM_HIP(hipMemcpy(hv.data(), pl->hbin_v.p, hv.size() * 4, hipMemcpyDeviceToHost));
+    if (pl->H) { // hv[b] = where bin b's hot edges (all its tiers) begin
+        std::vector<uint32_t> cells((size_t)Bv * pl->T + 1);
+        GM_HIP(hipMemcpy(cells.data(), pl->hbin_v.p, cells.size() * 4, hipMemcpyDeviceToHost));
+        for (uint32_t b = 0; b <= Bv; ++b)
+            hv[b] = cells[(size_t)b * pl->T];
+    }
     const uint64_t total = (uint64_t)bv[pl->B] + hv[pl->B];
     uint64_t limit = 2 * (total / pl->B + 1);
     if (limit < 65536)
@@ -1462,7 +1576,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
 
     // hot table size: what is left of the LDS beside the accumulators (2 workgroups per CU when the
     // accumulators are <= 64 KiB, else 1)
-    uint32_t H = 0;
+    uint32_t H = 0, H_single = 0; // sources per tier with two tables in LDS / with one
     {
         const size_t acc_bytes = (size_t)pl->Racc * 8;
         int wgs = acc_bytes > 65536 ? 1 : 2; // accumulate workgroups per CU the LDS request should allow
@@ -1479,14 +1593,26 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
         const int cap = pb_env("GM_PB_HOT", -1);
         if (cap >= 0 && (uint32_t)cap < H)
             H = (uint32_t)cap & ~63u;
+        H_single = H;
+        if (pb_env("GM_PB_TIERS", 0) != 1) { // two tables in LDS: a tier is half of the room
+            H = (H / 2) & ~63u;
+            if (H > 16384)
+                H = 16384;
+        }
     }
 
+    // tiers of hot sources (GM_PB_TIERS; measured at RMAT scale 26: see DESIGN 4.1)
+    uint32_t T = (uint32_t)(pb_env("GM_PB_TIERS", 0) > 0 ? pb_env("GM_PB_TIERS", 0) : PB_TIERS_DEFAULT); // 0: automatic, up to the default
+    T = T < 1 ? 1 : (T > 64 ? 64 : T);
+    if (H == 0)
+        T = 1;
     GM_TRY(pl->bin_v.alloc(((size_t)Bv + 1) * 4));
-    GM_TRY(pl->hbin_v.alloc(((size_t)Bv + 1) * 4));
+    GM_TRY(pl->hbin_v.alloc(((size_t)Bv * T + 1) * 4));
     GM_TRY(pl->tile_p.alloc(((size_t)pl->NT + 1) * 4));
-    GM_HIP(hipMemset(pl->hbin_v.p, 0, ((size_t)Bv + 1) * 4));
+    GM_HIP(hipMemset(pl->hbin_v.p, 0, ((size_t)Bv * T + 1) * 4));
     GM_TRY(pl->hot_ent.alloc(16));
-    GM_TRY(pl->hot_ids.alloc((size_t)(H ? H : 1) * 4));
+    GM_TRY(pl->hot_ids.alloc((size_t)(H ? (size_t)H * T : 1) * 4));
+    pl->T = T;
     if (m_all == 0) {
         GM_TRY(pl->p2_dst.alloc(16));
         GM_HIP(hipMemset(pl->bin_v.p, 0, ((size_t)Bv + 1) * 4));
@@ -1510,12 +1636,12 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
         GM_TRY(ckeys.alloc_big((size_t)x_len * 8));
         GM_TRY(calt.alloc_big((size_t)x_len * 8));
         GM_TRY(n_keys.alloc(4));
-        GM_TRY(hot_rank.alloc_big((size_t)x_len * 2));
+        GM_TRY(hot_rank.alloc_big((size_t)x_len * 4));
         GM_TRY(hot_blk.alloc((size_t)filter_words * 4));
         GM_HIP(hipMemset(cnt.p, 0, (size_t)x_len * 4));
         GM_HIP(hipMemset(n_keys.p, 0, 4));
         GM_HIP(hipMemset(hot_blk.p, 0, hot_blk.bytes));
-        GM_HIP(hipMemset(hot_rank.p, 0xFF, (size_t)x_len * 2));
+        GM_HIP(hipMemset(hot_rank.p, 0xFF, (size_t)x_len * 4));
         // one edge in 32 beyond 2^28 edges (one in 8 beyond 2^26): a source of the hot set has thousands of edges, and
         // the 134 M random atomics of a 1/8 sample were 6 ms of the plan at scale 26
         const uint32_t sample_step = m_all > (1u << 28) ? 32u : m_all > (1u << 26) ? 8u : 1u;
@@ -1529,9 +1655,36 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
         if (candidates)
             GM_TRY(sort_keys_u64(ckeys, calt, candidates, 0, 64)); // a few million keys of the 67 M sources at scale 26
         H = H < candidates ? H : candidates;
-        if (H)
-            hipLaunchKernelGGL(pb_hot_select_kernel, dim3(div_up(H, 256)), dim3(256), 0, 0, ckeys.as<uint64_t>(), H,
-                               pl->hot_ids.as<uint32_t>(), hot_rank.as<uint16_t>(), hot_blk.as<uint32_t>(), fshift);
+        if (H) {
+            const uint64_t cap = (uint64_t)H * T; // whole tiers of H sources, the last one possibly short
+            pl->Htot = (uint32_t)(cap < candidates ? cap : candidates);
+            T = (pl->Htot + H - 1) / H;
+            if (T > 1 && pb_env("GM_PB_TIERS", 0) <= 0) {
+                // How many tiers pay?  A tier costs every accumulate workgroup a barrier and a mostly idle pass over its
+                // few edges (~2 us), and saves 8 streamed bytes per edge it takes over: measured break-even ~5000 edges
+                // per (bin, tier) cell (scale 22: one tier; scale 24: sixteen; scale 26: eight).  The candidates' keys
+                // hold their sampled edge counts.
+                std::vector<uint64_t> top(pl->Htot);
+                GM_HIP(hipMemcpy(top.data(), ckeys.p, (size_t)pl->Htot * 8, hipMemcpyDeviceToHost));
+                const double need = 6000.0 * pl->B;
+                uint32_t keep = 1;
+                for (uint32_t t = 1; t < T; ++t) {
+                    double edges = 0;
+                    for (uint32_t k = t * H; k < pl->Htot && k < (t + 1) * H; ++k)
+                        edges += (double)(uint32_t)~(uint32_t)(top[k] >> 32) * sample_step;
+                    if (edges < need)
+                        break;
+                    keep = t + 1;
+                }
+                T = keep;
+                if (T == 1) // one table can use the whole room
+                    H = H_single < candidates ? H_single : candidates;
+                pl->Htot = (uint32_t)(((uint64_t)H * T) < candidates ? (uint64_t)H * T : candidates);
+            }
+            pl->T = T;
+            hipLaunchKernelGGL(pb_hot_select_kernel, dim3(div_up(pl->Htot, 256)), dim3(256), 0, 0, ckeys.as<uint64_t>(), pl->Htot,
+                               pl->hot_ids.as<uint32_t>(), hot_rank.as<uint32_t>(), hot_blk.as<uint32_t>(), fshift);
+        }
         GM_HIP(hipGetLastError());
         GM_HIP(hipDeviceSynchronize());
         if (H == 0) {
@@ -1540,6 +1693,8 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
         }
     }
     pl->H = H;
+    if (H == 0)
+        pl->T = T = 1, pl->Htot = 0;
     timer.done("pb plan: hot source selection");
 
     DevBuf keys, kalt;
@@ -1555,7 +1710,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
         kg = kg > 512 ? 512 : (kg ? kg : 1); // persistent workgroups: each stages the filter once
         hipLaunchKernelGGL(pb_keys_kernel, dim3(kg), dim3(PB_KEYS_BLOCK), lds, 0, csr->offsets, csr->targets, n, rb, sb, bin_bits,
                            H ? hot_blk.as<uint32_t>() : (const uint32_t *)nullptr, H ? filter_words : 0u, fshift,
-                           hot_rank.as<uint16_t>(), pl->cidx.as<uint16_t>(), pos_h.as<uint32_t>(), pl->hub_first.as<uint32_t>(),
+                           hot_rank.as<uint32_t>(), pl->cidx.as<uint16_t>(), pos_h.as<uint32_t>(), pl->hub_first.as<uint32_t>(),
                            pl->B, pl->G, keys.as<uint64_t>());
     }
     GM_HIP(hipGetLastError());
@@ -1569,7 +1724,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     pos_h.release();
     timer.done("pb plan: edge keys + sort");
 
-    if (H) { // hot keys (top bit set) sit behind the cold ones, already ordered by (bin, hot index, row)
+    if (H) { // hot keys (top bit set) sit behind the cold ones, already ordered by (bin, rank = tier-major, row)
         DevBuf split;
         GM_TRY(split.alloc(3 * 4));
         hipLaunchKernelGGL(pb_bounds_kernel, dim3(pb_grid(m_all)), dim3(256), 0, 0, keys.as<uint64_t>(), m_all, hot_bit, 2u,
@@ -1580,22 +1735,22 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
         if (mh) {
             const uint64_t *hkeys = keys.as<uint64_t>() + m;
             DevBuf hstart, hpad;
-            GM_TRY(hstart.alloc(((size_t)Bv + 1) * 4));
-            GM_TRY(hpad.alloc(((size_t)Bv + 1) * 4));
-            const uint32_t bin_mask = (uint32_t)((1ull << bin_bits) - 1ull);
-            hipLaunchKernelGGL(pb_bounds_kernel, dim3(pb_grid(mh)), dim3(256), 0, 0, hkeys, mh, sb, Bv,
-                               hstart.as<uint32_t>(), bin_mask);
-            hipLaunchKernelGGL(pb_pad4_sizes_kernel, dim3(pb_grid((uint64_t)Bv + 1)), dim3(256), 0, 0,
-                               hstart.as<uint32_t>(), Bv, hpad.as<uint32_t>());
+            const uint32_t cells = Bv * T; // (bin, tier) cells
+            GM_TRY(hstart.alloc(((size_t)cells + 1) * 4));
+            GM_TRY(hpad.alloc(((size_t)cells + 1) * 4));
+            hipLaunchKernelGGL(pb_hot_bounds_kernel, dim3(pb_grid(mh)), dim3(256), 0, 0, hkeys, mh, sb, bin_bits, H, T, cells,
+                               hstart.as<uint32_t>());
+            hipLaunchKernelGGL(pb_pad4_sizes_kernel, dim3(pb_grid((uint64_t)cells + 1)), dim3(256), 0, 0,
+                               hstart.as<uint32_t>(), cells, hpad.as<uint32_t>());
             GM_HIP(hipGetLastError());
-            GM_TRY(scan_exclusive<uint32_t>(hpad.as<uint32_t>(), pl->hbin_v.as<uint32_t>(), (uint64_t)Bv + 1));
+            GM_TRY(scan_exclusive<uint32_t>(hpad.as<uint32_t>(), pl->hbin_v.as<uint32_t>(), (uint64_t)cells + 1));
             uint32_t Mh = 0;
-            GM_HIP(hipMemcpy(&Mh, pl->hbin_v.as<uint32_t>() + Bv, 4, hipMemcpyDeviceToHost));
+            GM_HIP(hipMemcpy(&Mh, pl->hbin_v.as<uint32_t>() + cells, 4, hipMemcpyDeviceToHost));
             pl->Mh = Mh;
             GM_TRY(pl->hot_ent.alloc_big((size_t)Mh * 4, 0x407E));
             GM_HIP(hipMemset(pl->hot_ent.p, 0xFF, (size_t)Mh * 4));
             hipLaunchKernelGGL(pb_hot_fill_kernel, dim3(pb_grid(mh)), dim3(256), 0, 0, hkeys, mh, hstart.as<uint32_t>(),
-                               pl->hbin_v.as<uint32_t>(), sb, bin_bits, pl->hot_ent.as<uint32_t>());
+                               pl->hbin_v.as<uint32_t>(), sb, bin_bits, H, T, pl->hot_ent.as<uint32_t>());
             GM_HIP(hipGetLastError());
             GM_HIP(hipDeviceSynchronize());
         }
@@ -1904,6 +2059,27 @@ int pb_scratch_create(const PbPlan *pl, PbScratch **out, DevBuf *early)
             return rc;
         }
     }
+    // GM_PB_VALS_PICK="<MiB per piece>,<pieces created>,i0,i1,..." (measurement): the stream mapped from exactly the pieces
+    // i0, i1, ... of a sequence of physical pieces created back to back (which stretches of physical memory go together?)
+    if (!sc->vals_raw.p && getenv("GM_PB_VALS_PICK")) {
+        std::vector<size_t> nums;
+        for (const char *q = getenv("GM_PB_VALS_PICK"); *q;) {
+            nums.push_back((size_t)strtoull(q, const_cast<char **>(&q), 10));
+            while (*q == ',')
+                ++q;
+        }
+        if (nums.size() >= 3) {
+            const size_t chunk = nums[0] << 20, pool = nums[1];
+            std::vector<size_t> pick(nums.begin() + 2, nums.end());
+            const size_t bytes = (size_t)(pl->Mv ? pl->Mv : 4) * 4 + slack;
+            while (pick.size() * chunk < bytes)
+                pick.push_back(pick.back() + 1);
+            if ((rc = sc->vals_raw.alloc_vmm_pool(bytes, chunk, pool, pick))) {
+                delete sc;
+                return rc;
+            }
+        }
+    }
     // GM_PB_SPREAD="<MiB per piece>,<pool factor>,<seed>": a pseudo-random subset of a pool of pieces (DevBuf::alloc_spread)
     if (!sc->vals_raw.p && getenv("GM_PB_SPREAD")) {
         unsigned mib = 64, factor = 8, seed = 1;
@@ -1946,12 +2122,17 @@ int pb_scratch_create(const PbPlan *pl, PbScratch **out, DevBuf *early)
     }
     // The default: the stream mapped from 64 MiB pieces sampled from all over the arena's free list (arena.hip — right
     // after a plan build that list holds the build's ~30 GB of temporaries), GM_PB_DRAWS (3) such samples timed with
-    // the bin kernel itself, the fastest kept.  One stretch of physical memory, what hipMalloc returns, costs the bin
-    // kernel 1.66 ms at RMAT scale 26 where a spread stream costs 1.23-1.34 (profiles/r03_placement_*.txt): the DRAM
-    // banks a stretch can use are chosen by high physical address bits.  A draw costs a remap and three launches.
+    // the bin kernel itself, the fastest kept.  Where the stream's pages lie relative to the index stream read beside
+    // it decides up to a third of the bin kernel's time (1.23-1.34 ms against 1.66-1.78 at RMAT scale 26,
+    // profiles/r03_placement_*.txt); a draw costs a remap and three launches.  When even the best draw runs below
+    // GM_PB_BW_MIN GB/s (3500: below every fast case seen, above every slow one) the arena's pieces all lie in one unlucky stretch: it is grown
+    // by 8 GiB at a time (GM_PB_GROW_GIB in all, default 16) and the stream drawn from the new pieces, from both, from
+    // everything, until a draw is fast.
     if (!sc->vals_raw.p && arena_enabled() && (size_t)pl->Mv * 4 + slack >= ARENA_MIN && pl->NW && pb_env("GM_PB_DRAWS", 3) > 0) {
         const size_t bytes = (size_t)pl->Mv * 4 + slack;
         const int draws = pb_env("GM_PB_DRAWS", 3);
+        const double moved = (double)pl->Mp * 2 + (double)pl->Mv * 4 + (double)pl->x_len * 4; // bytes of one bin launch
+        const double bw_min = (double)pb_env("GM_PB_BW_MIN", 3500) * 1e9;
         DevBuf probe_x; // any readable x will do for the timing
         hipEvent_t e0 = nullptr, e1 = nullptr;
         float best_ms = 0.f;
@@ -1964,14 +2145,9 @@ int pb_scratch_create(const PbPlan *pl, PbScratch **out, DevBuf *early)
             if (he == hipSuccess)
                 he = hipEventCreate(&e1);
         }
-        for (int k = 0; k < draws && rc == GM_OK && he == hipSuccess; ++k) {
-            DevBuf cand;
-            rc = cand.alloc_big(bytes, 0xA11CE5 + 7919ull * (uint64_t)k + pl->NS, 4);
-            if (rc != GM_OK || draws == 1) {
-                if (rc == GM_OK)
-                    sc->vals_raw = std::move(cand);
-                break;
-            }
+        int tried = 0;
+        // times one candidate and keeps it if it is the fastest so far (the loser goes back to the arena)
+        auto consider = [&](DevBuf &cand, const char *what) {
             sc->vals = cand.as<float>();
             pb_bin_dispatch(pl, sc, probe_x.as<float>(), 0, pl->NW, (hipStream_t)0); // clocks up, pages touched
             he = hipEventRecord(e0, (hipStream_t)0);
@@ -1984,12 +2160,47 @@ int pb_scratch_create(const PbPlan *pl, PbScratch **out, DevBuf *early)
             float ms = 0.f;
             if (he == hipSuccess)
                 he = hipEventElapsedTime(&ms, e0, e1);
+            ms *= 0.5f;
             if (log_enabled())
-                fprintf(stderr, "[graph_mi355x] value stream draw %d: bin kernel %.3f ms\n", k, ms / 2);
+                fprintf(stderr, "[graph_mi355x] value stream draw %d (%s): bin kernel %.3f ms = %.0f GB/s\n", tried, what, ms,
+                        moved / (ms * 1e-3) / 1e9);
+            ++tried;
             if (he == hipSuccess && (!sc->vals_raw.p || ms < best_ms)) {
                 best_ms = ms;
-                sc->vals_raw = std::move(cand); // the loser goes back to the arena
+                sc->vals_raw = std::move(cand);
             }
+            sc->vals = nullptr;
+        };
+        for (int k = 0; k < draws && rc == GM_OK && he == hipSuccess; ++k) {
+            DevBuf cand;
+            rc = cand.alloc_big(bytes, 0xA11CE5 + 7919ull * (uint64_t)k + pl->NS, 4);
+            if (rc != GM_OK || draws == 1) {
+                if (rc == GM_OK)
+                    sc->vals_raw = std::move(cand);
+                break;
+            }
+            consider(cand, "all over the arena");
+        }
+        const size_t count = (bytes + ARENA_PIECE - 1) / ARENA_PIECE;
+        const size_t step = ((size_t)8 << 30) / ARENA_PIECE > 2 * count ? ((size_t)8 << 30) / ARENA_PIECE : 2 * count;
+        size_t budget = ((size_t)pb_env("GM_PB_GROW_GIB", 16) << 30) / ARENA_PIECE;
+        while (draws > 1 && rc == GM_OK && he == hipSuccess && bytes >= ((size_t)1 << 30) && budget >= step &&
+               moved / (best_ms * 1e-3) < bw_min) {
+            budget -= step;
+            uint64_t first = 0;
+            rc = arena_grow(pl->device, step, &first);
+            if (rc != GM_OK) { // out of memory for the experiment: keep what we have
+                rc = GM_OK;
+                (void)hipGetLastError();
+                break;
+            }
+            DevBuf a, b, c;
+            if (a.alloc_big(bytes, 0xB0B + first, 1, first) == GM_OK)
+                consider(a, "the newest 8 GiB");
+            if (he == hipSuccess && b.alloc_big(bytes, 0xC0C + first, 1, 0, ~0ull, first) == GM_OK)
+                consider(b, "half older, half newest");
+            if (he == hipSuccess && c.alloc_big(bytes, 0xD0D + first, 1) == GM_OK)
+                consider(c, "all over the grown arena");
         }
         sc->vals = nullptr;
         if (e0)
@@ -2008,7 +2219,7 @@ int pb_scratch_create(const PbPlan *pl, PbScratch **out, DevBuf *early)
     if ((rc = sc->vals_raw.p ? GM_OK : sc->vals_raw.alloc((size_t)(pl->Mv ? pl->Mv : 4) * 4 + slack)) ||
         (rc = sc->partials.alloc((size_t)(pl->slots ? pl->slots : 1) * pl->Racc * 8)) ||
         (rc = sc->tickets.alloc((size_t)pl->B * 4)) || (rc = sc->bin_err.alloc(((size_t)pl->B + pl->G) * 8)) ||
-        (rc = sc->hot_x.alloc(((size_t)pl->H + 4) * 4))) {
+        (rc = sc->hot_x.alloc(((size_t)pl->H * pl->T + 4) * 4))) {
         delete sc;
         return rc;
     }
@@ -2050,8 +2261,8 @@ void pb_plan_info(const PbPlan *pl, const PbScratch *sc, uint64_t *info, uint32_
         plan_bytes += b->bytes;
     const uint64_t scratch_bytes = sc ? sc->vals_raw.bytes + sc->partials.bytes + sc->tickets.bytes + sc->bin_err.bytes +
                                             sc->hot_x.bytes : 0;
-    const uint64_t v[] = {plan_bytes, (uint64_t)(pl->build_ms * 1000.0), pl->n_hub, pl->hub_edges, pl->hub_deg, pl->H,
-                          pl->Mv, pl->Mh, scratch_bytes, pl->B, pl->NT, pl->NS, pl->G};
+    const uint64_t v[] = {plan_bytes, (uint64_t)(pl->build_ms * 1000.0), pl->n_hub, pl->hub_edges, pl->hub_deg, pl->Htot,
+                          pl->Mv, pl->Mh, scratch_bytes, pl->B, pl->NT, pl->NS, pl->G, pl->T};
     for (uint32_t i = 0; i < count; ++i)
         info[i] = i < sizeof(v) / sizeof(v[0]) ? v[i] : 0;
 }
@@ -2072,8 +2283,9 @@ void pb_launch_accum(const PbPlan *pl, PbScratch *sc, const PbItem *items, uint3
                      const uint32_t *outdeg, float base, float damping, hipStream_t st)
 {
     hipLaunchKernelGGL(pb_accum_kernel<ABL>, dim3(count), dim3(PB_ACC_BLOCK),
-                       (size_t)pl->Racc * 8 + (((size_t)pl->H + 3) & ~(size_t)3) * 4, st, sc->vals, pl->p2_dst.as<uint16_t>(),
-                       items, pl->hot_ent.as<uint32_t>(), sc->hot_x.as<float>(), pl->H,
+                       (size_t)pl->Racc * 8 + (((size_t)pl->H + 3) & ~(size_t)3) * 4 * (pl->T > 1 ? 2 : 1), st, sc->vals,
+                       pl->p2_dst.as<uint16_t>(),
+                       items, pl->hot_ent.as<uint32_t>(), pl->hbin_v.as<uint32_t>(), sc->hot_x.as<float>(), pl->H, pl->T, pl->Htot,
                        sc->partials.as<unsigned long long>(), sc->tickets.as<uint32_t>(), pl->cidx.as<uint16_t>(), outdeg,
                        scores, x_out, sc->bin_err.as<double>(), pl->n_local, pl->R, pl->Racc, base, damping);
 }
@@ -2128,9 +2340,9 @@ static void pb_hub_dispatch(const PbPlan *pl, PbScratch *sc, float *x_out, float
 
 static void pb_hot_dispatch(const PbPlan *pl, PbScratch *sc, const float *x_in, hipStream_t st)
 {
-    if (pl->H)
-        hipLaunchKernelGGL(pb_hot_gather_kernel, dim3(div_up(pl->H, 256)), dim3(256), 0, st, x_in,
-                           pl->hot_ids.as<uint32_t>(), pl->H, sc->hot_x.as<float>());
+    if (pl->Htot)
+        hipLaunchKernelGGL(pb_hot_gather_kernel, dim3(div_up(pl->Htot, 256)), dim3(256), 0, st, x_in,
+                           pl->hot_ids.as<uint32_t>(), pl->Htot, sc->hot_x.as<float>());
 }
 
 // GM_PB_VALS_OFFSET=<KiB> (measurements only; needs GM_PB_VALS_SLACK at creation): where inside its allocation the value
