@@ -14,24 +14,31 @@
 //! How the graph reaches the GPU.  The traits only promise iterators (`NeighborsIterator<'a>: Iterator<Item =
 //! &'a NI>`, crates/builder/src/lib.rs:336-412), so the generic path walks them once — O(n + m) on the host —
 //! into u32 (NI up to 32 bits) or u64 (`u64` / `usize`, narrowed with a range check by `gm_csr_upload_u64`)
-//! arrays, splits `Target<NI, f32>` (AoS, crates/builder/src/graph/mod.rs:5-10) into targets + weights, and
-//! uploads them.  The resulting handles are cached in a process-wide map keyed by (address of the graph,
-//! node_count, edge_count, which CSRs), so every later call on the same graph object starts on resident data:
-//! "offsets/targets uploaded once to HBM".  `forget(&graph)` drops the entry when a graph is mutated in place
-//! (`make_degree_ordered`) or freed.
-use std::any::TypeId;
+//! arrays and splits `Target<NI, f32>` (AoS, crates/builder/src/graph/mod.rs:5-10) into targets + weights.  The
+//! CSR graph types store their targets as ONE slice in node order, which their `std::slice::Iter` hands out
+//! (`out_neighbors(0).as_slice().as_ptr()`): for them only the n + 1 offsets are rebuilt from the degrees and the
+//! target array is uploaded from where it lies (`Residency::out_targets` ...).
+//!
+//! Who owns the device copy.  NOT a process-wide cache keyed by the graph's address (a graph dropped and rebuilt at
+//! the same address with the same counts would silently meet its predecessor's data, and nothing would ever be
+//! evicted).  A plain graph keeps no copy: every call uploads, computes and frees — always correct.  `OnDevice<G>`
+//! wraps a graph together with its copies ("offsets/targets uploaded once to HBM"): it hands out `&G` only, the
+//! copies are dropped the moment `get_mut()` is taken (the one door to in-place changes such as
+//! `make_degree_ordered`) and when the wrapper is dropped.  The algorithms take either: `page_rank(&graph, cfg)` or
+//! `page_rank(&on_device, cfg)`.
 use std::collections::HashMap;
 use std::ffi::{c_char, c_int, CStr};
 use std::hash::Hash;
-use std::sync::{Arc, Mutex, OnceLock};
+use std::ops::Deref;
+use std::sync::{Arc, Mutex};
 
 use atomic_float::AtomicF32;
 use graph_builder::prelude::*;
 
 pub mod prelude {
     pub use super::{
-        delta_stepping, forget, global_triangle_count, page_rank, relabel_graph, wcc_afforest, wcc_afforest_dss,
-        wcc_baseline, Components, DeltaSteppingConfig, PageRankConfig, WccConfig,
+        delta_stepping, global_triangle_count, page_rank, relabel_graph, wcc_afforest, wcc_afforest_dss, wcc_baseline,
+        Components, DeltaSteppingConfig, OnDevice, PageRankConfig, Residency, WccConfig,
     };
     pub use graph_builder::prelude::*;
 }
@@ -124,55 +131,221 @@ fn upload<NI: Idx>(node_count: usize, lists: impl Fn(NI, &mut dyn FnMut(NI, Opti
 }
 
 // ------------------------------------------------------------------------------------------------
-// handle cache: "upload once", next to the graph
+// who keeps the device copies: nobody (plain graphs) or the OnDevice wrapper
 // ------------------------------------------------------------------------------------------------
 #[derive(Clone, Copy, PartialEq, Eq, Hash)]
-enum Kind {
+pub enum Kind {
     Directed,         // out + in lists
     DirectedWeighted, // out lists with f32 values
     OutOnly,          // wcc_baseline needs nothing else
     Undirected,
 }
 
-#[derive(Clone, Copy, PartialEq, Eq, Hash)]
-struct Key {
-    graph: usize, // address of the graph object
-    ty: TypeId,   // its node id type
-    nodes: usize,
-    edges: usize,
-    kind: Kind,
-}
-
-struct Resident {
+pub struct Resident {
     out: Option<DeviceCsr>,
     inc: Option<DeviceCsr>,
 }
 
-fn cache() -> &'static Mutex<HashMap<Key, Arc<Resident>>> {
-    static CACHE: OnceLock<Mutex<HashMap<Key, Arc<Resident>>>> = OnceLock::new();
-    CACHE.get_or_init(|| Mutex::new(HashMap::new()))
+/// The device copies one graph keeps (at most one per `Kind`).
+#[derive(Default)]
+pub struct Copies(Mutex<HashMap<Kind, Arc<Resident>>>);
+
+/// What the algorithms ask of a graph besides the reference's traits.  Implemented for the reference's CSR graph
+/// types (no copies kept, contiguous target arrays exposed) and for `OnDevice<G>` (copies kept).
+pub trait Residency<NI: Idx> {
+    /// Where this graph keeps its device copies; `None`: nowhere, every call uploads and frees its own.
+    fn copies(&self) -> Option<&Copies> {
+        None
+    }
+    /// The whole target array of the out / in / undirected lists, when the graph stores it as one slice in node
+    /// order (CSR): uploaded from where it lies instead of walked.
+    fn out_targets(&self) -> Option<&[NI]> {
+        None
+    }
+    fn in_targets(&self) -> Option<&[NI]> {
+        None
+    }
+    fn undirected_targets(&self) -> Option<&[NI]> {
+        None
+    }
 }
 
-fn resident<NI: Idx, G: Graph<NI>>(graph: &G, kind: Kind, build: impl FnOnce() -> Resident) -> Arc<Resident> {
-    let key = Key {
-        graph: graph as *const G as *const u8 as usize,
-        ty: TypeId::of::<NI>(),
-        nodes: graph.node_count().index(),
-        edges: graph.edge_count().index(),
-        kind,
+/// `first` is node 0's list of a CSR whose lists lie back to back in one allocation of `len` entries.
+unsafe fn whole<NI>(first: &[NI], len: usize) -> &[NI] {
+    std::slice::from_raw_parts(first.as_ptr(), len)
+}
+
+impl<NI: Idx, NV> Residency<NI> for DirectedCsrGraph<NI, NV, ()> {
+    fn out_targets(&self) -> Option<&[NI]> {
+        (self.node_count().index() > 0)
+            .then(|| unsafe { whole(self.out_neighbors(NI::zero()).as_slice(), self.edge_count().index()) })
+    }
+    fn in_targets(&self) -> Option<&[NI]> {
+        (self.node_count().index() > 0)
+            .then(|| unsafe { whole(self.in_neighbors(NI::zero()).as_slice(), self.edge_count().index()) })
+    }
+}
+
+impl<NI: Idx, NV> Residency<NI> for DirectedCsrGraph<NI, NV, f32> {} // Target<NI, f32> records: walked and split
+
+impl<NI: Idx, NV> Residency<NI> for UndirectedCsrGraph<NI, NV, ()> {
+    fn undirected_targets(&self) -> Option<&[NI]> {
+        // Graph::edge_count() of an undirected CSR is half its target entries (csr.rs:687-689)
+        (self.node_count().index() > 0)
+            .then(|| unsafe { whole(self.neighbors(NI::zero()).as_slice(), 2 * self.edge_count().index()) })
+    }
+}
+
+/// A graph together with its copies in HBM.  `&OnDevice<G>` goes wherever `&G` goes (Deref + the reference's traits
+/// delegated below); the copies die with the wrapper or when `get_mut()` opens the graph for changes.
+pub struct OnDevice<G> {
+    graph: G,
+    copies: Copies,
+}
+
+impl<G> OnDevice<G> {
+    pub fn new(graph: G) -> Self {
+        Self { graph, copies: Copies::default() }
+    }
+    /// The one way to `&mut G`: whatever is done through it, no device copy of the old content survives it.
+    pub fn get_mut(&mut self) -> &mut G {
+        self.copies.0.lock().unwrap().clear();
+        &mut self.graph
+    }
+    pub fn into_inner(self) -> G {
+        self.graph
+    }
+}
+
+impl<G> Deref for OnDevice<G> {
+    type Target = G;
+    fn deref(&self) -> &G {
+        &self.graph
+    }
+}
+
+impl<NI: Idx, G: Residency<NI>> Residency<NI> for OnDevice<G> {
+    fn copies(&self) -> Option<&Copies> {
+        Some(&self.copies)
+    }
+    fn out_targets(&self) -> Option<&[NI]> {
+        self.graph.out_targets()
+    }
+    fn in_targets(&self) -> Option<&[NI]> {
+        self.graph.in_targets()
+    }
+    fn undirected_targets(&self) -> Option<&[NI]> {
+        self.graph.undirected_targets()
+    }
+}
+
+impl<NI: Idx, G: Graph<NI>> Graph<NI> for OnDevice<G> {
+    fn node_count(&self) -> NI {
+        self.graph.node_count()
+    }
+    fn edge_count(&self) -> NI {
+        self.graph.edge_count()
+    }
+}
+
+impl<NI: Idx, G: DirectedDegrees<NI>> DirectedDegrees<NI> for OnDevice<G> {
+    fn out_degree(&self, node: NI) -> NI {
+        self.graph.out_degree(node)
+    }
+    fn in_degree(&self, node: NI) -> NI {
+        self.graph.in_degree(node)
+    }
+}
+
+impl<NI: Idx, G: UndirectedDegrees<NI>> UndirectedDegrees<NI> for OnDevice<G> {
+    fn degree(&self, node: NI) -> NI {
+        self.graph.degree(node)
+    }
+}
+
+impl<NI: Idx, G: DirectedNeighbors<NI>> DirectedNeighbors<NI> for OnDevice<G> {
+    type NeighborsIterator<'a>
+        = G::NeighborsIterator<'a>
+    where
+        Self: 'a;
+    fn out_neighbors(&self, node: NI) -> Self::NeighborsIterator<'_> {
+        self.graph.out_neighbors(node)
+    }
+    fn in_neighbors(&self, node: NI) -> Self::NeighborsIterator<'_> {
+        self.graph.in_neighbors(node)
+    }
+}
+
+impl<NI: Idx, G: DirectedNeighborsWithValues<NI, f32>> DirectedNeighborsWithValues<NI, f32> for OnDevice<G> {
+    type NeighborsIterator<'a>
+        = G::NeighborsIterator<'a>
+    where
+        Self: 'a;
+    fn out_neighbors_with_values(&self, node: NI) -> Self::NeighborsIterator<'_> {
+        self.graph.out_neighbors_with_values(node)
+    }
+    fn in_neighbors_with_values(&self, node: NI) -> Self::NeighborsIterator<'_> {
+        self.graph.in_neighbors_with_values(node)
+    }
+}
+
+impl<NI: Idx, G: UndirectedNeighbors<NI>> UndirectedNeighbors<NI> for OnDevice<G> {
+    type NeighborsIterator<'a>
+        = G::NeighborsIterator<'a>
+    where
+        Self: 'a;
+    fn neighbors(&self, node: NI) -> Self::NeighborsIterator<'_> {
+        self.graph.neighbors(node)
+    }
+}
+
+fn resident<NI: Idx, G: Residency<NI>>(graph: &G, kind: Kind, build: impl FnOnce() -> Resident) -> Arc<Resident> {
+    let Some(copies) = graph.copies() else {
+        return Arc::new(build()); // a plain graph: this call's own copy, freed when the call returns
     };
-    if let Some(r) = cache().lock().unwrap().get(&key) {
+    if let Some(r) = copies.0.lock().unwrap().get(&kind) {
         return r.clone();
     }
-    let r = Arc::new(build()); // outside the lock: uploads of different graphs may overlap
-    cache().lock().unwrap().entry(key).or_insert(r).clone()
+    let r = Arc::new(build()); // outside the lock: the four kinds of one graph may be uploaded side by side
+    copies.0.lock().unwrap().entry(kind).or_insert(r).clone()
 }
 
-/// Drops every device copy made for `graph` (call before mutating a graph in place or after freeing it:
-/// the cache is keyed by address + counts and cannot see a content change).
-pub fn forget<G>(graph: &G) {
-    let addr = graph as *const G as *const u8 as usize;
-    cache().lock().unwrap().retain(|k, _| k.graph != addr);
+/// One CSR from its degrees and its target array where it lies (4- or 8-byte ids; `None` for other widths).
+fn upload_contiguous<NI: Idx>(node_count: usize, degree: impl Fn(NI) -> usize, targets: &[NI]) -> Option<DeviceCsr> {
+    let mut out = std::ptr::null_mut();
+    match std::mem::size_of::<NI>() {
+        4 => {
+            assert!(targets.len() < u32::MAX as usize, "more than 2^32 - 1 target entries: beyond the device id type");
+            let mut off = Vec::<u32>::with_capacity(node_count + 1);
+            let mut at = 0u32;
+            off.push(0);
+            for u in 0..node_count {
+                at += degree(NI::new(u)) as u32;
+                off.push(at);
+            }
+            assert_eq!(at as usize, targets.len(), "degrees do not add up to the target array");
+            check(unsafe {
+                gm_csr_upload_u32(off.as_ptr(), targets.as_ptr() as *const u32, std::ptr::null(), node_count as u64,
+                                  targets.len() as u64, 0, &mut out)
+            });
+        }
+        8 => {
+            let mut off = Vec::<u64>::with_capacity(node_count + 1);
+            let mut at = 0u64;
+            off.push(0);
+            for u in 0..node_count {
+                at += degree(NI::new(u)) as u64;
+                off.push(at);
+            }
+            assert_eq!(at as usize, targets.len(), "degrees do not add up to the target array");
+            check(unsafe {
+                gm_csr_upload_u64(off.as_ptr(), targets.as_ptr() as *const u64, std::ptr::null(), node_count as u64,
+                                  targets.len() as u64, 0, &mut out)
+            });
+        }
+        _ => return None,
+    }
+    Some(DeviceCsr(out))
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -204,21 +377,31 @@ impl Default for PageRankConfig {
 fn directed<NI, G>(graph: &G) -> Arc<Resident>
 where
     NI: Idx,
-    G: Graph<NI> + DirectedNeighbors<NI> + Sync,
+    G: Graph<NI> + DirectedDegrees<NI> + DirectedNeighbors<NI> + Residency<NI> + Sync,
 {
     let n = graph.node_count().index();
     resident(graph, Kind::Directed, || Resident {
-        out: Some(upload::<NI>(n, |u, push| graph.out_neighbors(u).for_each(|v| push(*v, None)))),
-        inc: Some(upload::<NI>(n, |u, push| graph.in_neighbors(u).for_each(|v| push(*v, None)))),
+        out: Some(
+            graph
+                .out_targets()
+                .and_then(|t| upload_contiguous::<NI>(n, |u| graph.out_degree(u).index(), t))
+                .unwrap_or_else(|| upload::<NI>(n, |u, push| graph.out_neighbors(u).for_each(|v| push(*v, None)))),
+        ),
+        inc: Some(
+            graph
+                .in_targets()
+                .and_then(|t| upload_contiguous::<NI>(n, |u| graph.in_degree(u).index(), t))
+                .unwrap_or_else(|| upload::<NI>(n, |u, push| graph.in_neighbors(u).for_each(|v| push(*v, None)))),
+        ),
     })
 }
 
-/// Same signature as the reference.  `GM_DEVICES=k` (k > 1) runs the call 1-D partitioned over the first k
+/// The reference's signature plus `Residency` (its CSR graph types and `OnDevice<_>` have it).  `GM_DEVICES=k` (k > 1) runs the call 1-D partitioned over the first k
 /// GPUs of the node (`gm_page_rank_multi`: RCCL all-gather of out_scores per sweep); default: one GPU.
 pub fn page_rank<NI, G>(graph: &G, config: PageRankConfig) -> (Vec<f32>, usize, f64)
 where
     NI: Idx,
-    G: Graph<NI> + DirectedDegrees<NI> + DirectedNeighbors<NI> + Sync,
+    G: Graph<NI> + DirectedDegrees<NI> + DirectedNeighbors<NI> + Residency<NI> + Sync,
 {
     let PageRankConfig { max_iterations, tolerance, damping_factor } = config;
     let g = directed(graph);
@@ -288,7 +471,7 @@ impl<NI: Idx> Components<NI> for DeviceComponents {
 pub fn wcc_afforest<NI, G>(graph: &G, config: WccConfig) -> impl Components<NI>
 where
     NI: Idx + Hash,
-    G: Graph<NI> + DirectedDegrees<NI> + DirectedNeighbors<NI> + Sync,
+    G: Graph<NI> + DirectedDegrees<NI> + DirectedNeighbors<NI> + Residency<NI> + Sync,
 {
     let g = directed(graph);
     let mut comp = vec![0u32; graph.node_count().index()];
@@ -303,7 +486,7 @@ where
 pub fn wcc_afforest_dss<NI, G>(graph: &G, config: WccConfig) -> impl Components<NI>
 where
     NI: Idx + Hash,
-    G: Graph<NI> + DirectedDegrees<NI> + DirectedNeighbors<NI> + Sync,
+    G: Graph<NI> + DirectedDegrees<NI> + DirectedNeighbors<NI> + Residency<NI> + Sync,
 {
     wcc_afforest(graph, config)
 }
@@ -311,10 +494,11 @@ where
 pub fn wcc_baseline<NI, G>(graph: &G, _config: WccConfig) -> impl Components<NI>
 where
     NI: Idx,
-    G: Graph<NI> + DirectedNeighbors<NI> + Sync,
+    G: Graph<NI> + DirectedNeighbors<NI> + Residency<NI> + Sync,
 {
     let n = graph.node_count().index();
     let g = resident(graph, Kind::OutOnly, || Resident {
+        // no degrees in this function's bounds: the lists are walked (wcc_afforest's copy has the fast path)
         out: Some(upload::<NI>(n, |u, push| graph.out_neighbors(u).for_each(|v| push(*v, None)))),
         inc: None,
     });
@@ -342,7 +526,7 @@ impl DeltaSteppingConfig {
 pub fn delta_stepping<NI, G>(graph: &G, config: DeltaSteppingConfig) -> Vec<AtomicF32>
 where
     NI: Idx,
-    G: Graph<NI> + DirectedNeighborsWithValues<NI, f32> + Sync,
+    G: Graph<NI> + DirectedNeighborsWithValues<NI, f32> + Residency<NI> + Sync,
 {
     let n = graph.node_count().index();
     let g = resident(graph, Kind::DirectedWeighted, || Resident {
@@ -367,11 +551,16 @@ where
 pub fn global_triangle_count<NI, G>(graph: &G) -> u64
 where
     NI: Idx,
-    G: Graph<NI> + UndirectedNeighbors<NI> + Sync,
+    G: Graph<NI> + UndirectedNeighbors<NI> + Residency<NI> + Sync,
 {
     let n = graph.node_count().index();
     let g = resident(graph, Kind::Undirected, || Resident {
-        out: Some(upload::<NI>(n, |u, push| graph.neighbors(u).for_each(|v| push(*v, None)))),
+        out: Some(
+            graph
+                .undirected_targets()
+                .and_then(|t| upload_contiguous::<NI>(n, |u| graph.neighbors(u).count(), t)) // O(1) on slice iterators
+                .unwrap_or_else(|| upload::<NI>(n, |u, push| graph.neighbors(u).for_each(|v| push(*v, None)))),
+        ),
         inc: None,
     });
     let mut triangles = 0u64;
@@ -379,13 +568,23 @@ where
     triangles
 }
 
-/// `make_degree_ordered` rewrites the host graph in place (graph_ops.rs:511-638), so any device copy of
-/// it is stale afterwards: drop it, the next algorithm call uploads the relabelled lists.
+/// `make_degree_ordered` rewrites the host graph in place (graph_ops.rs:511-638).  A plain graph keeps no device copy,
+/// so there is nothing to invalidate; for a graph that lives on the device too use `OnDevice::relabel`.
 pub fn relabel_graph<NI, G, EV>(graph: &mut G)
 where
     NI: Idx,
     G: RelabelByDegreeOp<NI, EV>,
 {
-    forget(graph);
     graph.make_degree_ordered();
+}
+
+impl<G> OnDevice<G> {
+    /// `relabel_graph` for a graph with device copies: they are dropped first (`get_mut`), the next algorithm call
+    /// uploads the relabelled lists.
+    pub fn relabel<NI: Idx, EV>(&mut self)
+    where
+        G: RelabelByDegreeOp<NI, EV>,
+    {
+        self.get_mut().make_degree_ordered();
+    }
 }

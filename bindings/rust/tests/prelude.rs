@@ -75,10 +75,36 @@ fn tc_three_shapes() {
 }
 
 #[test]
-fn second_call_reuses_the_resident_graph() {
+fn on_device_keeps_one_copy_and_plain_graphs_keep_none() {
     let graph: DirectedCsrGraph<u32> = GraphBuilder::new().csr_layout(CsrLayout::Sorted).edges(vec![(0, 1), (1, 2), (2, 0)]).build();
-    let a = page_rank(&graph, PageRankConfig::default());
-    let b = page_rank(&graph, PageRankConfig::default()); // no second upload: the handle cache is keyed by the graph
+    let a = page_rank(&graph, PageRankConfig::default()); // a plain graph: uploaded for this call, freed after it
+    let resident = OnDevice::new(graph);
+    let b = page_rank(&resident, PageRankConfig::default()); // uploads once ...
+    let c = page_rank(&resident, PageRankConfig::default()); // ... and runs on the same copy
     assert_eq!(a.0, b.0);
-    forget(&graph);
+    assert_eq!(b.0, c.0);
+    assert_eq!(wcc_afforest(&resident, WccConfig::default()).to_vec(), vec![0u32, 0, 0]); // the same Directed copy
+}
+
+#[test]
+fn graphs_rebuilt_at_one_address_with_equal_counts_are_not_confused() {
+    // the failure of an address-keyed cache: same stack slot, same node and edge counts, other edges
+    let mut results = Vec::new();
+    for edges in [vec![(0u32, 1u32), (1, 2), (2, 0), (3, 0)], vec![(0, 1), (1, 0), (2, 3), (3, 2)]] {
+        let graph: DirectedCsrGraph<u32> = GraphBuilder::new().csr_layout(CsrLayout::Sorted).edges(edges).build();
+        results.push(wcc_afforest(&graph, WccConfig::default()).to_vec());
+    }
+    assert_eq!(results[0], vec![0u32, 0, 0, 0]);
+    assert_eq!(results[1], vec![0u32, 0, 2, 2]);
+}
+
+#[test]
+fn relabel_through_on_device_drops_the_stale_copy() {
+    let graph: UndirectedCsrGraph<u32> =
+        GraphBuilder::new().csr_layout(CsrLayout::Deduplicated).edges(vec![(0, 1), (1, 2), (0, 2), (2, 3)]).build();
+    let mut resident = OnDevice::new(graph);
+    assert_eq!(global_triangle_count(&resident), 1);
+    resident.relabel(); // make_degree_ordered through get_mut(): the device copy of the old ids is gone
+    assert_eq!(global_triangle_count(&resident), 1);
+    assert_eq!(resident.degree(0), 3); // the old node 2 is node 0 now
 }

@@ -893,6 +893,312 @@ ORC_EXPORT int orc_delta_stepping(uint32_t n, const uint32_t *off, const uint32_
     return 0;
 }
 
+/* ---- timed CPU baselines of WCC and delta-stepping (tools/bench_algos.py's cpu_baseline legs) ------------------------
+ * The reference runs both on the rayon pool: wcc.rs:186-301 (`into_par_iter().chunks(chunk_size)` over the nodes,
+ * Afforest::union with a CAS, afforest.rs:22-39, a parallel compress, :47-53) and sssp.rs:64-94 (one ThreadLocalBins per
+ * thread, the shared frontier drained in 64-node batches from an atomic cursor, CAS on the distances, :170-204).  These
+ * two functions restate that threading with pthreads for the TIMED leg only; the checkers above stay sequential.  Both
+ * return what the sequential functions return on the inputs they are used on (labels are schedule-free; distances are
+ * schedule-free unless the reference's stale check misfires, see orc_sssp_fixed_point). */
+typedef struct {
+    pthread_barrier_t *bar;
+    uint32_t t, T, n;
+    const uint32_t *out_off, *out_tgt, *in_off, *in_tgt;
+    uint32_t *parent;
+    uint64_t neighbor_rounds, chunk;
+    atomic_uint_fast64_t *cursor; /* [4]: one per parallel phase */
+    const uint32_t *skip;         /* set by thread 0 between the phases */
+} orc_wcc_job;
+
+static inline uint32_t orc_ld(const uint32_t *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+
+static void orc_af_union_mt(uint32_t *parent, uint32_t u, uint32_t v)
+{
+    uint32_t p1 = orc_ld(&parent[u]), p2 = orc_ld(&parent[v]);
+    while (p1 != p2) {
+        uint32_t high = p1 > p2 ? p1 : p2;
+        uint32_t low = p1 + p2 - high;
+        uint32_t p_high = orc_ld(&parent[high]);
+        if (p_high == low)
+            break;
+        if (p_high == high) {
+            uint32_t expect = high;
+            if (__atomic_compare_exchange_n(&parent[high], &expect, low, 0, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE))
+                break;
+        }
+        p1 = orc_ld(&parent[orc_ld(&parent[high])]);
+        p2 = orc_ld(&parent[low]);
+    }
+}
+
+static void orc_wcc_compress_mt(orc_wcc_job *j, atomic_uint_fast64_t *cursor)
+{
+    for (;;) {
+        uint64_t s = atomic_fetch_add(cursor, 65536);
+        if (s >= j->n)
+            break;
+        uint64_t e = s + 65536 < j->n ? s + 65536 : j->n;
+        for (uint64_t i = s; i < e; ++i)
+            while (orc_ld(&j->parent[i]) != orc_ld(&j->parent[orc_ld(&j->parent[i])]))
+                __atomic_store_n(&j->parent[i], orc_ld(&j->parent[orc_ld(&j->parent[i])]), __ATOMIC_SEQ_CST);
+    }
+}
+
+static void *orc_wcc_worker(void *arg)
+{
+    orc_wcc_job *j = (orc_wcc_job *)arg;
+    /* sample_subgraph (wcc.rs:186-204) */
+    for (;;) {
+        uint64_t s = atomic_fetch_add(&j->cursor[0], j->chunk);
+        if (s >= j->n)
+            break;
+        uint64_t e = s + j->chunk < j->n ? s + j->chunk : j->n;
+        for (uint64_t u = s; u < e; ++u) {
+            uint64_t deg = j->out_off[u + 1] - j->out_off[u];
+            uint64_t take = deg < j->neighbor_rounds ? deg : j->neighbor_rounds;
+            for (uint64_t k = 0; k < take; ++k)
+                orc_af_union_mt(j->parent, (uint32_t)u, j->out_tgt[j->out_off[u] + k]);
+        }
+    }
+    pthread_barrier_wait(j->bar);
+    orc_wcc_compress_mt(j, &j->cursor[1]);
+    pthread_barrier_wait(j->bar); /* thread 0 samples the largest component (sequential in the reference too) */
+    pthread_barrier_wait(j->bar);
+    const uint32_t skip = *j->skip;
+    /* link_remaining (wcc.rs:274-301) */
+    for (;;) {
+        uint64_t s = atomic_fetch_add(&j->cursor[2], j->chunk);
+        if (s >= j->n)
+            break;
+        uint64_t e = s + j->chunk < j->n ? s + j->chunk : j->n;
+        for (uint64_t u = s; u < e; ++u) {
+            if (orc_ld(&j->parent[u]) == skip)
+                continue;
+            uint64_t deg = j->out_off[u + 1] - j->out_off[u];
+            if (deg > j->neighbor_rounds)
+                for (uint64_t i = j->out_off[u] + j->neighbor_rounds; i < j->out_off[u + 1]; ++i)
+                    orc_af_union_mt(j->parent, (uint32_t)u, j->out_tgt[i]);
+            for (uint32_t i = j->in_off[u]; i < j->in_off[u + 1]; ++i)
+                orc_af_union_mt(j->parent, (uint32_t)u, j->in_tgt[i]);
+        }
+    }
+    pthread_barrier_wait(j->bar);
+    orc_wcc_compress_mt(j, &j->cursor[3]);
+    return NULL;
+}
+
+/* wcc_afforest on `threads` threads; seconds_out = wall time of the five phases (the union-find's creation excluded, as
+ * the reference logs it separately, wcc.rs:132-141) */
+ORC_EXPORT int orc_wcc_afforest_timed(uint32_t n, const uint32_t *out_off, const uint32_t *out_tgt, const uint32_t *in_off,
+                                      const uint32_t *in_tgt, uint64_t neighbor_rounds, uint64_t sampling_size, uint64_t seed,
+                                      uint64_t chunk_size, uint32_t threads, uint32_t *components_out, double *seconds_out)
+{
+    if (threads == 0)
+        threads = 4;
+    if (n == 0 || sampling_size == 0 || chunk_size == 0)
+        return -2;
+    uint32_t *parent = components_out;
+    orc_uf_new(n, parent);
+    pthread_barrier_t bar;
+    pthread_barrier_init(&bar, NULL, threads + 1);
+    atomic_uint_fast64_t cursor[4];
+    for (int k = 0; k < 4; ++k)
+        atomic_init(&cursor[k], 0);
+    uint32_t skip = 0;
+    pthread_t *tid = (pthread_t *)malloc(threads * sizeof(pthread_t));
+    orc_wcc_job *jobs = (orc_wcc_job *)malloc(threads * sizeof(orc_wcc_job));
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (uint32_t t = 0; t < threads; ++t) {
+        jobs[t] = (orc_wcc_job){&bar, t, threads, n, out_off, out_tgt, in_off, in_tgt, parent, neighbor_rounds, chunk_size, cursor, &skip};
+        pthread_create(&tid[t], NULL, orc_wcc_worker, &jobs[t]);
+    }
+    pthread_barrier_wait(&bar); /* subgraph linked */
+    pthread_barrier_wait(&bar); /* compressed */
+    {
+        uint32_t *samples = (uint32_t *)malloc(sampling_size * sizeof(uint32_t));
+        for (uint64_t k = 0; k < sampling_size; ++k)
+            samples[k] = parent[orc_splitmix64(seed + k) % n];
+        qsort(samples, sampling_size, sizeof(uint32_t), orc_u32_cmp);
+        uint64_t best = 0, runlen = 0;
+        skip = samples[0];
+        for (uint64_t k = 0; k < sampling_size; ++k) {
+            runlen = (k > 0 && samples[k] == samples[k - 1]) ? runlen + 1 : 1;
+            if (runlen > best) {
+                best = runlen;
+                skip = samples[k];
+            }
+        }
+        free(samples);
+    }
+    pthread_barrier_wait(&bar); /* skip component known */
+    pthread_barrier_wait(&bar); /* remaining edges linked */
+    for (uint32_t t = 0; t < threads; ++t)
+        pthread_join(tid[t], NULL);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    *seconds_out = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    pthread_barrier_destroy(&bar);
+    free(tid);
+    free(jobs);
+    return 0;
+}
+
+typedef struct {
+    pthread_barrier_t *bar;
+    uint32_t t, T, n;
+    const uint32_t *off, *tgt;
+    const float *w;
+    uint32_t *dist; /* f32 bit patterns (non-negative: ordered like the floats) */
+    float delta;
+    orc_bins bins;
+    uint32_t *frontier;
+    atomic_uint_fast64_t *cursor;
+    size_t *curr, *flen;       /* shared, written by thread 0 between barriers */
+    size_t *next_of, *len_of;  /* [T]: every thread's minimum non-empty bin / length of its `next` bin */
+} orc_ds_job;
+
+static void orc_relax_edges_mt(orc_ds_job *j, uint32_t node)
+{
+    for (uint32_t i = j->off[node]; i < j->off[node + 1]; ++i) {
+        const uint32_t t = j->tgt[i];
+        uint32_t old_bits = __atomic_load_n(&j->dist[t], __ATOMIC_ACQUIRE);
+        uint32_t node_bits = __atomic_load_n(&j->dist[node], __ATOMIC_ACQUIRE);
+        float node_d, old_d;
+        memcpy(&node_d, &node_bits, 4);
+        const float new_d = node_d + j->w[i];
+        uint32_t new_bits;
+        memcpy(&new_bits, &new_d, 4);
+        memcpy(&old_d, &old_bits, 4);
+        while (new_d < old_d) {
+            if (__atomic_compare_exchange_n(&j->dist[t], &old_bits, new_bits, 1, __ATOMIC_RELEASE, __ATOMIC_RELAXED)) {
+                size_t dest = (size_t)(new_d / j->delta);
+                if (dest >= j->bins.len)
+                    orc_bins_resize(&j->bins, dest + 1);
+                orc_bin_push(&j->bins.bins[dest], t);
+                break;
+            }
+            memcpy(&old_d, &old_bits, 4);
+        }
+    }
+}
+
+static void *orc_ds_worker(void *arg)
+{
+    orc_ds_job *j = (orc_ds_job *)arg;
+    const size_t NO_BIN = (size_t)-1;
+    for (;;) {
+        pthread_barrier_wait(j->bar); /* curr / flen / cursor published */
+        const size_t curr = *j->curr, flen = *j->flen;
+        if (curr == NO_BIN)
+            break;
+        for (;;) { /* process_shared_bin (sssp.rs:104-132) */
+            uint64_t o = atomic_fetch_add(j->cursor, 64);
+            if (o >= flen)
+                break;
+            uint64_t lim = o + 64 < flen ? o + 64 : flen;
+            for (uint64_t k = o; k < lim; ++k) {
+                const uint32_t node = j->frontier[k];
+                uint32_t b = __atomic_load_n(&j->dist[node], __ATOMIC_ACQUIRE);
+                float d;
+                memcpy(&d, &b, 4);
+                if (d >= j->delta * (float)curr)
+                    orc_relax_edges_mt(j, node);
+            }
+        }
+        while (curr < j->bins.len && j->bins.bins[curr].len != 0 && j->bins.bins[curr].len < 1000) { /* :134-157 */
+            size_t cl = j->bins.bins[curr].len;
+            uint32_t *copy = (uint32_t *)malloc(cl * sizeof(uint32_t));
+            memcpy(copy, j->bins.bins[curr].v, cl * sizeof(uint32_t));
+            j->bins.bins[curr].len = 0;
+            for (size_t k = 0; k < cl; ++k)
+                orc_relax_edges_mt(j, copy[k]);
+            free(copy);
+        }
+        size_t next = NO_BIN; /* :159-168 */
+        for (size_t b = curr; b < j->bins.len; ++b)
+            if (j->bins.bins[b].len != 0) {
+                next = b;
+                break;
+            }
+        j->next_of[j->t] = next;
+        pthread_barrier_wait(j->bar); /* every thread's minimum known */
+        size_t gnext = NO_BIN;
+        for (uint32_t t = 0; t < j->T; ++t)
+            gnext = j->next_of[t] < gnext ? j->next_of[t] : gnext;
+        j->len_of[j->t] = (gnext != NO_BIN && gnext < j->bins.len) ? j->bins.bins[gnext].len : 0;
+        pthread_barrier_wait(j->bar); /* every thread's slice length known (frontier_slices, :206-225) */
+        if (gnext != NO_BIN) {
+            size_t at = 0;
+            for (uint32_t t = 0; t < j->t; ++t)
+                at += j->len_of[t];
+            if (j->len_of[j->t]) {
+                memcpy(j->frontier + at, j->bins.bins[gnext].v, j->len_of[j->t] * sizeof(uint32_t));
+                j->bins.bins[gnext].len = 0;
+            }
+        }
+        pthread_barrier_wait(j->bar); /* frontier complete */
+        if (j->t == 0) {
+            size_t total = 0;
+            for (uint32_t t = 0; t < j->T; ++t)
+                total += j->len_of[t];
+            *j->curr = gnext;
+            *j->flen = total;
+            atomic_store(j->cursor, 0);
+        }
+    }
+    for (size_t b = 0; b < j->bins.cap; ++b)
+        free(j->bins.bins[b].v);
+    free(j->bins.bins);
+    return NULL;
+}
+
+/* delta_stepping on `threads` persistent threads (the rayon pool); seconds_out = wall time from the first round on */
+ORC_EXPORT int orc_delta_stepping_timed(uint32_t n, const uint32_t *off, const uint32_t *tgt, const float *w, uint64_t start_node,
+                                        float delta, uint32_t threads, float *dist, double *seconds_out)
+{
+    if (start_node >= n)
+        return -2;
+    if (threads == 0)
+        threads = 4;
+    const float inf = FLT_MAX;
+    uint32_t inf_bits;
+    memcpy(&inf_bits, &inf, 4);
+    uint32_t *bits = (uint32_t *)dist;
+    for (uint32_t i = 0; i < n; ++i)
+        bits[i] = inf_bits;
+    bits[start_node] = 0;
+    uint32_t *frontier = (uint32_t *)malloc(((size_t)off[n] + 1) * sizeof(uint32_t)); /* edge_count entries, sssp.rs:55 */
+    if (!frontier)
+        return -1;
+    frontier[0] = (uint32_t)start_node;
+    size_t curr = 0, flen = 1;
+    atomic_uint_fast64_t cursor;
+    atomic_init(&cursor, 0);
+    pthread_barrier_t bar;
+    pthread_barrier_init(&bar, NULL, threads);
+    pthread_t *tid = (pthread_t *)malloc(threads * sizeof(pthread_t));
+    orc_ds_job *jobs = (orc_ds_job *)calloc(threads, sizeof(orc_ds_job));
+    size_t *next_of = (size_t *)malloc(threads * sizeof(size_t)), *len_of = (size_t *)malloc(threads * sizeof(size_t));
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (uint32_t t = 0; t < threads; ++t) {
+        jobs[t] = (orc_ds_job){&bar, t, threads, n, off, tgt, w, bits, delta, {0}, frontier, &cursor, &curr, &flen, next_of, len_of};
+        orc_bins_resize(&jobs[t].bins, 1);
+        pthread_create(&tid[t], NULL, orc_ds_worker, &jobs[t]);
+    }
+    for (uint32_t t = 0; t < threads; ++t)
+        pthread_join(tid[t], NULL);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    *seconds_out = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    pthread_barrier_destroy(&bar);
+    free(tid);
+    free(jobs);
+    free(next_of);
+    free(len_of);
+    free(frontier);
+    return 0;
+}
+
 /* The least fixed point of d[v] = min(d[u] (+) w(u,v)) under f32 addition (f32 Dijkstra with a binary
  * heap): what delta-stepping computes under ANY schedule as long as no improvement is dropped.  The
  * reference does drop some: a node whose new distance d lands in bin (usize)(d/delta) (sssp.rs:192) is

@@ -102,6 +102,12 @@ def _bind(L):
     L.orc_wcc.restype = C.c_int
     L.orc_delta_stepping.argtypes = [C.c_uint32, _u32p, _u32p, _f32p, C.c_uint64, C.c_float, _f32p]
     L.orc_delta_stepping.restype = C.c_int
+    L.orc_wcc_afforest_timed.argtypes = [C.c_uint32, _u32p, _u32p, _u32p, _u32p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
+                                         C.c_uint32, _u32p, C.POINTER(C.c_double)]
+    L.orc_wcc_afforest_timed.restype = C.c_int
+    L.orc_delta_stepping_timed.argtypes = [C.c_uint32, _u32p, _u32p, _f32p, C.c_uint64, C.c_float, C.c_uint32, _f32p,
+                                           C.POINTER(C.c_double)]
+    L.orc_delta_stepping_timed.restype = C.c_int
     L.orc_triangle_count.argtypes = [C.c_uint32, _u32p, _u32p, C.c_uint32]
     L.orc_triangle_count.restype = C.c_uint64
     L.orc_greedy_degree_partition.argtypes = [C.c_uint32, _u32p, C.c_uint32, _u32p]
@@ -276,6 +282,34 @@ def wcc(out_off, out_tgt, in_off, in_tgt, algo=AFFOREST, neighbor_rounds=2, samp
     if rc != 0:
         raise ValueError(f"orc_wcc rc={rc}")
     return comp[:n]
+
+
+def wcc_afforest_timed(out_off, out_tgt, in_off, in_tgt, threads=0, neighbor_rounds=2, sampling_size=1024, seed=1,
+                       chunk_size=16384, native=True):
+    """(labels, seconds): wcc_afforest on `threads` threads as the reference runs it on rayon (wcc.rs:186-301,
+    afforest.rs:22-53) — the TIMED cpu_baseline leg; the labels equal wcc(...)'s"""
+    n = out_off.size - 1
+    comp = np.empty(max(n, 1), np.uint32)
+    secs = C.c_double(0)
+    rc = (native_lib() if native else lib()).orc_wcc_afforest_timed(n, out_off, _tgt(out_tgt), in_off, _tgt(in_tgt), neighbor_rounds,
+                                                                    sampling_size, seed, chunk_size, threads or effective_cores(), comp,
+                                                                    C.byref(secs))
+    if rc != 0:
+        raise ValueError(f"orc_wcc_afforest_timed rc={rc}")
+    return comp[:n], secs.value
+
+
+def delta_stepping_timed(off, tgt, w, start_node: int, delta: float, threads=0, native=True):
+    """(distances, seconds): delta_stepping on `threads` threads with thread-local bins (sssp.rs:64-204) — the TIMED leg"""
+    n = off.size - 1
+    dist = np.empty(max(n, 1), np.float32)
+    wv = np.ascontiguousarray(w, np.float32)
+    secs = C.c_double(0)
+    rc = (native_lib() if native else lib()).orc_delta_stepping_timed(n, off, _tgt(tgt), wv if wv.size else np.zeros(1, np.float32),
+                                                                      start_node, delta, threads or effective_cores(), dist, C.byref(secs))
+    if rc != 0:
+        raise IndexError(f"orc_delta_stepping_timed rc={rc}")
+    return dist[:n], secs.value
 
 
 def delta_stepping(off, tgt, w, start_node: int, delta: float, native=False):

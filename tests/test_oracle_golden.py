@@ -309,3 +309,25 @@ def test_sssp_reference_stale_check_quirk(oracle):
                 agree += 1
                 assert np.array_equal(ds, fp)
     assert agree > 100
+
+
+def test_threaded_timed_legs_return_what_the_sequential_checkers_return(oracle):
+    """orc_wcc_afforest_timed / orc_delta_stepping_timed (the reference's rayon threading restated for the TIMED
+    cpu_baseline legs, wcc.rs:186-301 / sssp.rs:64-204) against the sequential checkers, several thread counts"""
+    O = oracle
+    for scale in (10, 14):
+        s, d = O.rmat_edges(scale, 42)
+        n = 1 << scale
+        ooff, otgt = O.csr_build(n, s, d, O.OUTGOING, O.SORTED)
+        ioff, itgt = O.csr_build(n, s, d, O.INCOMING, O.SORTED)
+        ref = O.wcc(ooff, otgt, ioff, itgt)
+        w = O.rmat_weights(s.size, 44)
+        off, tgt, wv = O.csr_build(n, s, d, O.OUTGOING, O.SORTED, w)
+        start = int(np.flatnonzero(np.diff(off) > 0)[0])
+        dref = O.delta_stepping(off, tgt, wv, start, 0.1)
+        assert not O.stale_check_misfires(dref, 0.1).any() or np.array_equal(dref, O.sssp_fixed_point(off, tgt, wv, start))
+        for threads in (1, 2, 5):
+            got, secs = O.wcc_afforest_timed(ooff, otgt, ioff, itgt, threads, native=False)
+            assert np.array_equal(got, ref) and secs > 0
+            dist, secs = O.delta_stepping_timed(off, tgt, wv, start, 0.1, threads, native=False)
+            assert np.array_equal(dist.view(np.uint32), dref.view(np.uint32)) and secs > 0
