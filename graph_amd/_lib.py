@@ -63,6 +63,8 @@ SIGNATURES = {
     "gm_pr_part_geometry": (i32, [vp, vp, vp]),
     "gm_pr_set_parts": (i32, [vp, vp, u64]),
     "gm_pr_sweep_bin": (i32, [vp, u64, u64, u64, vp]),
+    "gm_pr_set_bin_regions": (i32, [vp, vp, vp, vp, u64, u32]),
+    "gm_pr_sweep_bin_region": (i32, [vp, u64, u32, vp]),
     "gm_pr_sweep_hot": (i32, [vp, u64, vp]),
     "gm_pr_sweep_accum": (i32, [vp, u64, u64, u64, u64, i32, vp]),
     "gm_wcc_afforest": (i32, [vp, vp, u64, u64, vp]),

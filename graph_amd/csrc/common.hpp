@@ -427,13 +427,10 @@ inline unsigned div_up(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) /
 
 // GM_LOG=1: phase timings on stderr, the counterpart of the reference's `log::info!` lines
 // (page_rank.rs:95-100, wcc.rs:132-182, sssp.rs:99).  Costs a stream synchronisation per phase.
-inline bool log_enabled()
+inline bool log_enabled() // read at every phase boundary (a getenv), so that a host can switch it on for one call
 {
-    static const bool on = [] {
-        const char *v = getenv("GM_LOG");
-        return v && *v && *v != '0';
-    }();
-    return on;
+    const char *v = getenv("GM_LOG");
+    return v && *v && *v != '0';
 }
 
 struct PhaseTimer { // wall clock around stream-ordered work; only active under GM_LOG
@@ -472,6 +469,10 @@ struct PbPlan; // propagation-blocking layout of a CSR (pagerank_pb.hip); immuta
 // each and a graph is usually queried from many start nodes.
 struct TcDag;       // what gm_triangle_count derives from the graph alone (tc.hip); immutable once built
 struct PrCallState; // what one gm_page_rank call allocates (pagerank.hip), parked in the handle between calls
+struct MultiState;  // what gm_page_rank_multi derives from a graph and a device list (multi.hip), parked likewise
+struct MultiStateDeleter {
+    void operator()(MultiState *p) const; // multi.hip (the type is complete there)
+};
 struct WccScratch {
     DevBuf work;   // chunk count + chunk items + sample buffer (wcc.hip:wcc_device)
     DevBuf labels; // u32[n] of gm_wcc_afforest / gm_wcc_baseline
@@ -503,5 +504,6 @@ struct gm_csr {
     mutable std::unique_ptr<gm::WccScratch> wcc_scratch;   // likewise
     mutable std::shared_ptr<gm::PrCallState> pr_call;      // likewise (stream, vectors, engine + its scratch)
     mutable std::shared_ptr<const gm::TcDag> tc_dag;       // the DAG of lower prefixes + list records of gm_triangle_count
+    mutable std::unique_ptr<gm::MultiState, gm::MultiStateDeleter> multi; // gm_page_rank_multi's resident run (in-CSR handle)
     mutable std::atomic<int> long_rows{-1};           // 1: some row has >= GM_PB_HUB_DEG entries (-1: not looked at yet)
 };

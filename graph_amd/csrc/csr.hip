@@ -230,8 +230,10 @@ GM_API int gm_csr_trim(const gm_csr *csr)
     std::unique_ptr<gm::WccScratch> wcc;
     std::shared_ptr<gm::PrCallState> pr;
     std::shared_ptr<const gm::TcDag> dag;
+    std::unique_ptr<gm::MultiState, gm::MultiStateDeleter> multi;
     {
         std::lock_guard<std::mutex> lock(csr->cache_mu);
+        multi = std::move(csr->multi);
         plans.swap(csr->pb_plans);
         sssp = std::move(csr->sssp_scratch);
         wcc = std::move(csr->wcc_scratch);

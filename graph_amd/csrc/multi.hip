@@ -9,12 +9,20 @@
 //   partition   contiguous row ranges balanced by in-degree: the reference's greedy walk, in_degree_partition +
 //               greedy_node_map_partition, crates/builder/src/graph_ops.rs:431-439,479-509
 //   exchange    only nodes WITH out-edges are ever gathered (the out_score of the others is +inf and never read,
-//               page_rank.rs:78,158): they are numbered rank-major with a fixed per-rank stride, every rank's
+//               page_rank.rs:78,158): they are numbered rank-major (ascending node ids: the order in which the reference
+//               adds a row's terms, which the engines' hub rows follow) with a fixed per-rank stride, every rank's
 //               targets are rewritten into that index space once, and the all-gather output is consumed directly
 //               as the next sweep's x vector (an all-gather moves half the bytes of the all-reduce of a
 //               zero-padded vector and gives the same result)
-//   per sweep   local sweep kernels (the same engines as the single-GPU path) -> compaction gather -> ncclAllGather
-//               on the rank's stream -> f64 error partials summed on the host in rank order (deterministic)
+//   per sweep   the exchanged vector is cut into K regions (GM_MULTI_PARTS, default 2; region k = row group k of every
+//               rank, whole source tiles) and every rank's rows into K groups: propagate region 0 as soon as it has
+//               landed, then region 1; accumulate group 0 -> compact it -> START its all-gather on the rank's exchange
+//               stream -> accumulate group 1 -> start its all-gather: region k travels under the work on the other
+//               groups and under the next sweep's propagation of the regions before it.  Events order the two
+//               streams; the host synchronises only to read the error (never, when tolerance == 0).  Slices too
+//               small for propagation-blocking engines run one whole sweep + one all-gather per sweep.
+//   residency   partition, slices, engines, buffers, streams, events and communicators are parked in the in-CSR's
+//               handle (gm::MultiState): a second call on the same graph / device list only re-initialises the scores
 //
 // Rows below the hub threshold get the same bits as the single-GPU run (exactly rounded row sums do not depend on
 // the partition); hub rows agree to ~1e-6 (their step boundaries move with the bin layout).
@@ -44,6 +52,7 @@ struct Rccl {
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -65,10 +74,11 @@ int rccl_get(const Rccl **out)
         t.CommInitAll = reinterpret_cast<decltype(t.CommInitAll)>(dlsym(h, "ncclCommInitAll"));
         t.CommDestroy = reinterpret_cast<decltype(t.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
         t.AllGather = reinterpret_cast<decltype(t.AllGather)>(dlsym(h, "ncclAllGather"));
+        t.Broadcast = reinterpret_cast<decltype(t.Broadcast)>(dlsym(h, "ncclBroadcast"));
         t.GroupStart = reinterpret_cast<decltype(t.GroupStart)>(dlsym(h, "ncclGroupStart"));
         t.GroupEnd = reinterpret_cast<decltype(t.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
         t.GetErrorString = reinterpret_cast<decltype(t.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
-        GM_CHECK(t.CommInitAll && t.CommDestroy && t.AllGather && t.GroupStart && t.GroupEnd && t.GetErrorString,
+        GM_CHECK(t.CommInitAll && t.CommDestroy && t.AllGather && t.Broadcast && t.GroupStart && t.GroupEnd && t.GetErrorString,
                  GM_ERR_UNSUPPORTED, "gm_page_rank_multi: librccl.so lacks an expected symbol");
         r = t;
     }
@@ -93,29 +103,14 @@ __global__ void mg_has_out_kernel(const uint32_t *__restrict__ out_off, uint32_t
         flag[u] = (u < n && out_off[u + 1] > out_off[u]) ? 1u : 0u;
 }
 
-// node v of rank p (bounds[p] <= v < bounds[p+1]) with out-edges -> slot p * stride + (its rank among the
-// rank's nodes with out-edges); nodes without out-edges are never a target of an in-list
-__global__ void mg_node_map_kernel(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ pos,
-                                   const uint32_t *__restrict__ bounds, uint32_t parts, uint32_t stride, uint32_t n,
-                                   uint32_t *__restrict__ node_map)
-{
-    const uint32_t s = gridDim.x * blockDim.x;
-    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += s) {
-        uint32_t p = 0; // parts <= 64: a short scan
-        while (p + 1 < parts && v >= bounds[p + 1])
-            ++p;
-        node_map[v] = flag[v] ? p * stride + (pos[v] - pos[bounds[p]]) : 0xFFFFFFFFu;
-    }
-}
-
 // local rows (of [lo, hi)) that have out-edges, in order: what the rank contributes to the exchange
 __global__ void mg_send_rows_kernel(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ pos, uint32_t lo,
-                                    uint32_t hi, uint32_t *__restrict__ rows)
+                                    uint32_t hi, uint32_t rank_lo, uint32_t *__restrict__ rows)
 {
     const uint32_t s = gridDim.x * blockDim.x;
     for (uint32_t v = lo + blockIdx.x * blockDim.x + threadIdx.x; v < hi; v += s)
         if (flag[v])
-            rows[pos[v] - pos[lo]] = v - lo;
+            rows[pos[v] - pos[lo]] = v - rank_lo;
 }
 
 __global__ void mg_out_degree_kernel(const uint32_t *__restrict__ out_off, uint32_t lo, uint32_t count,
@@ -190,24 +185,43 @@ std::vector<uint32_t> greedy_in_degree_bounds(const std::vector<uint32_t> &off, 
     return bounds;
 }
 
+constexpr uint32_t MG_ROW_ALIGN = 16384;   // row splits of a sweep in pieces: a multiple of any plan's rows per bin
+constexpr uint32_t MG_SOURCE_TILE = 32768; // regions of the exchanged vector: a multiple of any plan's source tile
+constexpr uint32_t MG_MAX_PARTS = 4;
+
 struct Rank {
     int device = 0;
-    uint32_t lo = 0, hi = 0, send_count = 0;
-    hipStream_t st = nullptr;
+    uint32_t lo = 0, hi = 0;
+    uint32_t send_count[MG_MAX_PARTS] = {0, 0, 0, 0};
+    hipStream_t st = nullptr;  // the sweep kernels
+    hipStream_t cst = nullptr; // the exchange: runs under the kernels of the other row groups
+    hipEvent_t ev_ready[MG_MAX_PARTS] = {};   // x_send[k] compacted (recorded on st)
+    hipEvent_t ev_done[2][MG_MAX_PARTS] = {}; // region k of x[buf] complete (recorded on cst)
     gm_csr *rows = nullptr; // row slice with targets in exchange index space (lives on `device`)
     gm_pr *pr = nullptr;
-    DevBuf outdeg, scores, x_loc, x[2], x_send, send_rows, err;
+    DevBuf outdeg, scores, x_loc, x[2], x_send[MG_MAX_PARTS], send_rows[MG_MAX_PARTS], err;
     ~Rank()
     {
         DeviceGuard g(device);
+        if (st)
+            (void)hipStreamSynchronize(st);
+        if (cst)
+            (void)hipStreamSynchronize(cst);
         if (pr)
             gm_pr_destroy(pr);
         if (rows)
             gm_csr_free(rows);
+        for (uint32_t k = 0; k < MG_MAX_PARTS; ++k) {
+            if (ev_ready[k])
+                (void)hipEventDestroy(ev_ready[k]);
+            for (int b = 0; b < 2; ++b)
+                if (ev_done[b][k])
+                    (void)hipEventDestroy(ev_done[b][k]);
+        }
         if (st)
             (void)hipStreamDestroy(st);
-        outdeg.release(), scores.release(), x_loc.release(), x[0].release(), x[1].release(), x_send.release(),
-            send_rows.release(), err.release();
+        if (cst)
+            (void)hipStreamDestroy(cst);
     }
 };
 
@@ -221,6 +235,411 @@ struct Comms {
                 (void)rc->CommDestroy(k);
     }
 };
+
+// node v of rank p, row group k (splits[p * (K + 1) + k] <= v < ... + k + 1], global ids) with out-edges -> slot
+// p * rank_stride + group_off[k] + (its rank among the group's nodes with out-edges); others are never gathered.
+// RANK-MAJOR: the slots ascend with the node ids, so a row's terms reach the engines in the order the reference adds them
+__global__ void mg_node_map_parts_kernel(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ pos,
+                                         const uint32_t *__restrict__ splits, uint32_t P, uint32_t K,
+                                         uint32_t rank_stride, const uint32_t *__restrict__ region_off, uint32_t n,
+                                         uint32_t *__restrict__ node_map)
+{
+    const uint32_t s = gridDim.x * blockDim.x;
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += s) {
+        uint32_t p = 0; // P <= 64, K <= 4: short scans
+        while (p + 1 < P && v >= splits[(p + 1) * (K + 1)])
+            ++p;
+        uint32_t k = 0;
+        while (k + 1 < K && v >= splits[p * (K + 1) + k + 1])
+            ++k;
+        node_map[v] = flag[v] ? p * rank_stride + region_off[k] + (pos[v] - pos[splits[p * (K + 1) + k]]) : 0xFFFFFFFFu;
+    }
+}
+
+} // namespace
+
+// Everything a partitioned run derives from (out CSR, in CSR, device list, damping): the partition, the exchange
+// layout, every rank's row slice / engine / buffers / streams / events, the communicators.  Parked in the in-CSR's
+// handle between calls (the reference's app calls page_rank in a loop): a second call only re-initialises the scores.
+struct gm::MultiState {
+    const gm_csr *out_csr = nullptr;
+    std::vector<int> devs;
+    float damping = 0.f;
+    int engine = 0;
+    uint32_t K = 1;
+    uint32_t P = 0, n = 0;
+    bool distinct = true, pieces = false;
+    std::vector<uint32_t> bounds, strides, region_off; // region_off[k]: where row group k starts inside a rank's stretch of x
+    uint32_t rank_stride = 0;                          // floats per rank in x (sum of the strides)
+    uint64_t x_len = 0;
+    std::vector<std::unique_ptr<Rank>> ranks;
+    Comms comms;
+    PinnedBuf herr;
+    ~MultiState()
+    {
+        ranks.clear(); // streams drained and destroyed before the communicators go
+    }
+};
+
+void gm::MultiStateDeleter::operator()(gm::MultiState *p) const { delete p; }
+
+namespace {
+
+using MultiPtr = std::unique_ptr<gm::MultiState, gm::MultiStateDeleter>;
+
+int multi_build(const gm_csr *out_csr, const gm_csr *in_csr, const std::vector<int> &devs, bool distinct, float damping_factor,
+                int engine_env, uint32_t K_want, MultiPtr *out)
+{
+    MultiPtr ms(new (std::nothrow) gm::MultiState());
+    GM_CHECK(ms, GM_ERR_NOMEM, "gm_page_rank_multi: out of host memory");
+    const uint32_t n = (uint32_t)in_csr->n, P = (uint32_t)devs.size();
+    const int src_dev = in_csr->device;
+    ms->out_csr = out_csr, ms->devs = devs, ms->damping = damping_factor, ms->engine = engine_env, ms->P = P, ms->n = n,
+    ms->distinct = distinct;
+    gm::PhaseTimer timer((hipStream_t)0);
+
+    // ---- partition (on the host, from the offsets) ----------------------------------------------------------
+    std::vector<uint32_t> off_host((size_t)n + 1);
+    {
+        DeviceGuard g(src_dev);
+        GM_HIP(hipMemcpy(off_host.data(), in_csr->offsets, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost));
+    }
+    ms->bounds = greedy_in_degree_bounds(off_host, P);
+    const std::vector<uint32_t> &bounds = ms->bounds;
+    // a sweep in pieces needs propagation-blocking engines on every rank: every slice large enough for AUTO to pick
+    // one (pagerank.hip: 2^24 edges), or forced by GM_MULTI_ENGINE=pb
+    uint64_t min_edges = ~0ull;
+    for (uint32_t p = 0; p < P; ++p)
+        min_edges = std::min<uint64_t>(min_edges, (uint64_t)off_host[bounds[p + 1]] - off_host[bounds[p]]);
+    ms->pieces = K_want > 1 && (engine_env == GM_PR_ENGINE_PB || (engine_env == GM_PR_ENGINE_AUTO && min_edges >= (1ull << 24)));
+    const uint32_t K = ms->pieces ? K_want : 1;
+    ms->K = K;
+    const int engine = ms->pieces ? GM_PR_ENGINE_PB : engine_env;
+    // row groups of every rank (global ids), cut at multiples of MG_ROW_ALIGN local rows
+    std::vector<uint32_t> splits((size_t)P * (K + 1));
+    for (uint32_t p = 0; p < P; ++p) {
+        const uint32_t rows = bounds[p + 1] - bounds[p];
+        for (uint32_t k = 0; k <= K; ++k) {
+            uint64_t cut = k == K ? rows : ((uint64_t)rows * k / K + MG_ROW_ALIGN - 1) / MG_ROW_ALIGN * MG_ROW_ALIGN;
+            splits[(size_t)p * (K + 1) + k] = bounds[p] + (uint32_t)std::min<uint64_t>(cut, rows);
+        }
+    }
+
+    // ---- exchange layout (on the device that holds the graph) -------------------------------------------------
+    DevBuf flag, pos, d_splits, d_strides, d_region, node_map;
+    std::vector<uint32_t> pos_at(splits.size());
+    ms->strides.assign(K, 0), ms->region_off.assign(K, 0);
+    {
+        DeviceGuard g(src_dev);
+        GM_TRY(flag.alloc(((size_t)n + 1) * 4));
+        GM_TRY(pos.alloc(((size_t)n + 1) * 4));
+        GM_TRY(node_map.alloc((size_t)n * 4));
+        hipLaunchKernelGGL(mg_has_out_kernel, dim3(mg_grid((uint64_t)n + 1)), dim3(256), 0, 0, out_csr->offsets, n,
+                           flag.as<uint32_t>());
+        GM_HIP(hipGetLastError());
+        size_t tmp_bytes = 0;
+        GM_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, flag.as<uint32_t>(), pos.as<uint32_t>(), 0u, (size_t)n + 1,
+                                       rocprim::plus<uint32_t>(), (hipStream_t)0));
+        DevBuf tmp;
+        GM_TRY(tmp.alloc(tmp_bytes));
+        GM_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, flag.as<uint32_t>(), pos.as<uint32_t>(), 0u, (size_t)n + 1,
+                                       rocprim::plus<uint32_t>(), (hipStream_t)0));
+        for (size_t i = 0; i < splits.size(); ++i)
+            GM_HIP(hipMemcpy(&pos_at[i], pos.as<uint32_t>() + splits[i], 4, hipMemcpyDeviceToHost));
+        uint64_t off = 0;
+        for (uint32_t k = 0; k < K; ++k) {
+            uint32_t most = 1;
+            for (uint32_t p = 0; p < P; ++p)
+                most = std::max(most, pos_at[(size_t)p * (K + 1) + k + 1] - pos_at[(size_t)p * (K + 1) + k]);
+            // whole source tiles per rank when the vector is consumed region by region; float4-aligned otherwise
+            const uint32_t unit = K > 1 ? MG_SOURCE_TILE : 4u;
+            ms->strides[k] = (most + unit - 1) / unit * unit;
+            ms->region_off[k] = (uint32_t)off;
+            off += ms->strides[k];
+        }
+        GM_CHECK(off * P < (1ull << 32), GM_ERR_RANGE, "gm_page_rank_multi: exchange vector exceeds u32");
+        ms->rank_stride = (uint32_t)off;
+        ms->x_len = off * P;
+        GM_TRY(d_splits.alloc(splits.size() * 4));
+        GM_TRY(d_strides.alloc((size_t)K * 4));
+        GM_TRY(d_region.alloc((size_t)K * 4));
+        GM_HIP(hipMemcpy(d_splits.p, splits.data(), splits.size() * 4, hipMemcpyHostToDevice));
+        GM_HIP(hipMemcpy(d_strides.p, ms->strides.data(), (size_t)K * 4, hipMemcpyHostToDevice));
+        GM_HIP(hipMemcpy(d_region.p, ms->region_off.data(), (size_t)K * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(mg_node_map_parts_kernel, dim3(mg_grid(n)), dim3(256), 0, 0, flag.as<uint32_t>(), pos.as<uint32_t>(),
+                           d_splits.as<uint32_t>(), P, K, ms->rank_stride, d_region.as<uint32_t>(), n,
+                           node_map.as<uint32_t>());
+        GM_HIP(hipGetLastError());
+        GM_HIP(hipDeviceSynchronize());
+    }
+    const uint64_t x_len = ms->x_len;
+    timer.done("multi: partition + exchange layout (%u ranks, %u regions)", P, K);
+
+    // ---- one rank per device: row slice, exchange buffers, engine ------------------------------------------
+    for (uint32_t p = 0; p < P; ++p) {
+        ms->ranks.emplace_back(new Rank());
+        Rank &r = *ms->ranks.back();
+        r.device = devs[p];
+        r.lo = bounds[p], r.hi = bounds[p + 1];
+        const uint32_t rows = r.hi - r.lo;
+        const uint64_t e0 = off_host[r.lo], e1 = off_host[r.hi], cnt = e1 - e0;
+        DeviceGuard g(r.device);
+        GM_HIP(hipStreamCreateWithFlags(&r.st, hipStreamNonBlocking));
+        GM_HIP(hipStreamCreateWithFlags(&r.cst, hipStreamNonBlocking));
+        for (uint32_t k = 0; k < K; ++k) {
+            GM_HIP(hipEventCreateWithFlags(&r.ev_ready[k], hipEventDisableTiming));
+            GM_HIP(hipEventCreateWithFlags(&r.ev_done[0][k], hipEventDisableTiming));
+            GM_HIP(hipEventCreateWithFlags(&r.ev_done[1][k], hipEventDisableTiming));
+        }
+        DevBuf d_off, d_tgt, d_map;
+        GM_TRY(d_off.alloc(((size_t)rows + 1) * 4));
+        GM_TRY(d_tgt.alloc((size_t)cnt * 4));
+        GM_TRY(r.outdeg.alloc((size_t)rows * 4));
+        // the slice's raw arrays, then offsets rebased / targets rewritten on the rank's own device
+        GM_HIP(mg_copy(d_off.p, r.device, in_csr->offsets + r.lo, src_dev, ((size_t)rows + 1) * 4));
+        GM_HIP(mg_copy(d_tgt.p, r.device, in_csr->targets + e0, src_dev, (size_t)cnt * 4));
+        const uint32_t *map_here = node_map.as<uint32_t>();
+        if (r.device != src_dev) {
+            GM_TRY(d_map.alloc((size_t)n * 4));
+            GM_HIP(mg_copy(d_map.p, r.device, node_map.p, src_dev, (size_t)n * 4));
+            map_here = d_map.as<uint32_t>();
+        }
+        {   // out-degrees and the send lists are cut on the source device, then moved
+            DeviceGuard gs(src_dev);
+            DevBuf od;
+            GM_TRY(od.alloc((size_t)rows * 4));
+            if (rows)
+                hipLaunchKernelGGL(mg_out_degree_kernel, dim3(mg_grid(rows)), dim3(256), 0, 0, out_csr->offsets, r.lo, rows,
+                                   od.as<uint32_t>());
+            GM_HIP(hipGetLastError());
+            GM_HIP(hipDeviceSynchronize());
+            GM_HIP(mg_copy(r.outdeg.p, r.device, od.p, src_dev, (size_t)rows * 4));
+            for (uint32_t k = 0; k < K; ++k) {
+                const uint32_t g_lo = splits[(size_t)p * (K + 1) + k], g_hi = splits[(size_t)p * (K + 1) + k + 1];
+                r.send_count[k] = pos_at[(size_t)p * (K + 1) + k + 1] - pos_at[(size_t)p * (K + 1) + k];
+                DevBuf sr;
+                GM_TRY(sr.alloc((size_t)r.send_count[k] * 4));
+                if (g_hi > g_lo) // rows[rank among the group's senders] = v - (rank's first row)
+                    hipLaunchKernelGGL(mg_send_rows_kernel, dim3(mg_grid(g_hi - g_lo)), dim3(256), 0, 0, flag.as<uint32_t>(),
+                                       pos.as<uint32_t>(), g_lo, g_hi, r.lo, sr.as<uint32_t>());
+                GM_HIP(hipGetLastError());
+                GM_HIP(hipDeviceSynchronize());
+                DeviceGuard gr(r.device);
+                GM_TRY(r.send_rows[k].alloc((size_t)r.send_count[k] * 4));
+                GM_HIP(mg_copy(r.send_rows[k].p, r.device, sr.p, src_dev, (size_t)r.send_count[k] * 4));
+            }
+        }
+        hipLaunchKernelGGL(mg_rebase_kernel, dim3(mg_grid((uint64_t)rows + 1)), dim3(256), 0, 0, d_off.as<uint32_t>(), rows + 1,
+                           (uint32_t)e0);
+        if (cnt)
+            hipLaunchKernelGGL(mg_map_targets_kernel, dim3(mg_grid(cnt)), dim3(256), 0, 0, d_tgt.as<uint32_t>(), cnt, map_here);
+        GM_HIP(hipGetLastError());
+        GM_HIP(hipDeviceSynchronize());
+        // hand the arrays to an owning handle: wrap, then let the Rank keep the buffers alive through the handle
+        gm_csr *c = new (std::nothrow) gm_csr();
+        GM_CHECK(c, GM_ERR_NOMEM, "gm_page_rank_multi: out of host memory");
+        c->n = rows, c->m = cnt, c->device = r.device, c->owns = true;
+        c->own_offsets = std::move(d_off);
+        c->own_targets = std::move(d_tgt);
+        c->offsets = c->own_offsets.as<uint32_t>();
+        c->targets = c->own_targets.as<uint32_t>();
+        r.rows = c;
+        GM_TRY(r.scores.alloc((size_t)rows * 4));
+        GM_TRY(r.x_loc.alloc((size_t)rows * 4));
+        GM_TRY(r.x[0].alloc((size_t)x_len * 4));
+        GM_TRY(r.x[1].alloc((size_t)x_len * 4));
+        GM_TRY(r.err.alloc(8));
+        GM_HIP(hipMemset(r.x[0].p, 0, (size_t)x_len * 4));
+        GM_HIP(hipMemset(r.x[1].p, 0, (size_t)x_len * 4));
+        for (uint32_t k = 0; k < K; ++k) {
+            GM_TRY(r.x_send[k].alloc((size_t)ms->strides[k] * 4));
+            GM_HIP(hipMemset(r.x_send[k].p, 0, (size_t)ms->strides[k] * 4));
+        }
+        GM_HIP(hipMemset(r.err.p, 0, 8));
+        GM_HIP(hipDeviceSynchronize());
+        GM_TRY(gm_pr_create_with(r.rows, n, r.lo, x_len, (uint64_t)r.outdeg.p, damping_factor, engine, &r.pr));
+        if (ms->pieces) {
+            GM_CHECK(gm_pr_engine(r.pr) == GM_PR_ENGINE_PB, GM_ERR_INVALID, "gm_page_rank_multi: rank %u did not get a propagation-blocking engine", p);
+            uint64_t sp[MG_MAX_PARTS + 1];
+            for (uint32_t k = 0; k <= K; ++k)
+                sp[k] = splits[(size_t)p * (K + 1) + k] - r.lo;
+            GM_TRY(gm_pr_set_parts(r.pr, sp, K));
+            // region k of the vector = row group k of every rank: P ranges, propagated in one launch
+            std::vector<uint64_t> x_lo, x_hi;
+            std::vector<uint32_t> reg;
+            for (uint32_t q = 0; q < P; ++q)
+                for (uint32_t k = 0; k < K; ++k) {
+                    x_lo.push_back((uint64_t)q * ms->rank_stride + ms->region_off[k]);
+                    x_hi.push_back(x_lo.back() + ms->strides[k]);
+                    reg.push_back(k);
+                }
+            GM_TRY(gm_pr_set_bin_regions(r.pr, x_lo.data(), x_hi.data(), reg.data(), x_lo.size(), K));
+        }
+    }
+    timer.done("multi: row slices + engines");
+    if (distinct) {
+        GM_TRY(rccl_get(&ms->comms.rc));
+        ms->comms.c.assign(P, nullptr);
+        GM_NCCL(ms->comms.rc, ms->comms.rc->CommInitAll(ms->comms.c.data(), (int)P, devs.data()));
+        timer.done("multi: ncclCommInitAll");
+    }
+    GM_TRY(ms->herr.alloc((size_t)P * 8));
+    *out = std::move(ms);
+    return GM_OK;
+}
+
+// compacts the out_scores of row group k on every rank (its sweep stream) and starts their all-gather into region k
+// of x[buf] on the exchange streams; nothing waits on the host
+int multi_start_exchange(gm::MultiState &ms, int buf, uint32_t k)
+{
+    const uint32_t P = ms.P;
+    for (auto &rp : ms.ranks) {
+        Rank &r = *rp;
+        DeviceGuard g(r.device);
+        if (!ms.distinct) // copies stand in for the collective: x_send[k] is still being read until EVERY receiver of its last use is done
+            for (auto &other : ms.ranks)
+                GM_HIP(hipStreamWaitEvent(r.st, other->ev_done[1 - buf][k], 0));
+        if (r.send_count[k])
+            hipLaunchKernelGGL(mg_compact_kernel, dim3(mg_grid(r.send_count[k])), dim3(256), 0, r.st, r.x_loc.as<float>(),
+                               r.send_rows[k].as<uint32_t>(), r.send_count[k], r.x_send[k].as<float>());
+        GM_HIP(hipGetLastError());
+        GM_HIP(hipEventRecord(r.ev_ready[k], r.st));
+    }
+    const size_t stride = ms.strides[k];
+    if (ms.distinct) {
+        const Rccl *rc = ms.comms.rc;
+        for (auto &rp : ms.ranks) {
+            DeviceGuard g(rp->device);
+            GM_HIP(hipStreamWaitEvent(rp->cst, rp->ev_ready[k], 0));
+        }
+        GM_NCCL(rc, rc->GroupStart());
+        ncclResult_t bad = ncclSuccess;
+        for (uint32_t q = 0; q < P && bad == ncclSuccess; ++q) {
+            Rank &r = *ms.ranks[q];
+            if (ms.K == 1) { // one region: the ranks' stretches are exactly what an all-gather lays out
+                bad = rc->AllGather(r.x_send[k].p, r.x[buf].p, stride, ncclFloat32, ms.comms.c[q], r.cst);
+                continue;
+            }
+            // row group k of rank p goes to p * rank_stride + region_off[k] on every rank: P broadcasts in one group
+            for (uint32_t p = 0; p < P && bad == ncclSuccess; ++p)
+                bad = rc->Broadcast(r.x_send[k].p, r.x[buf].as<float>() + (size_t)p * ms.rank_stride + ms.region_off[k], stride,
+                                    ncclFloat32, (int)p, ms.comms.c[q], r.cst);
+        }
+        const ncclResult_t end = rc->GroupEnd(); // always closed, also after a failed call inside the group
+        if (bad != ncclSuccess || end != ncclSuccess) {
+            gm::set_error("gm_page_rank_multi: ncclAllGather failed: %s", rc->GetErrorString(bad != ncclSuccess ? bad : end));
+            return GM_ERR_HIP;
+        }
+    } else { // virtual ranks on shared devices: the same data movement with copies, on the receivers' exchange streams
+        for (uint32_t q = 0; q < P; ++q) {
+            Rank &dst = *ms.ranks[q];
+            DeviceGuard g(dst.device);
+            // like a collective, nothing moves before every rank has arrived — the receiver included: its own sweep has
+            // then left the buffer that is overwritten here
+            for (uint32_t p = 0; p < P; ++p)
+                GM_HIP(hipStreamWaitEvent(dst.cst, ms.ranks[p]->ev_ready[k], 0));
+            for (uint32_t p = 0; p < P; ++p) {
+                Rank &src = *ms.ranks[p];
+                float *to = dst.x[buf].as<float>() + (size_t)p * ms.rank_stride + ms.region_off[k];
+                if (dst.device == src.device)
+                    GM_HIP(hipMemcpyAsync(to, src.x_send[k].p, stride * 4, hipMemcpyDeviceToDevice, dst.cst));
+                else
+                    GM_HIP(hipMemcpyPeerAsync(to, dst.device, src.x_send[k].p, src.device, stride * 4, dst.cst));
+            }
+        }
+    }
+    for (auto &rp : ms.ranks) {
+        DeviceGuard g(rp->device);
+        GM_HIP(hipEventRecord(rp->ev_done[buf][k], rp->cst));
+    }
+    return GM_OK;
+}
+
+int multi_run(gm::MultiState &ms, uint64_t max_iterations, double tolerance, float *scores_out, uint64_t *iterations_out,
+              double *error_out)
+{
+    const uint32_t P = ms.P, K = ms.K;
+    uint64_t host_syncs = 0;
+    for (auto &rp : ms.ranks) {
+        DeviceGuard g(rp->device);
+        GM_TRY(gm_pr_init(rp->pr, (uint64_t)rp->scores.p, (uint64_t)rp->x_loc.p, rp->st));
+    }
+    int cur = 0;
+    for (uint32_t k = 0; k < K; ++k)
+        GM_TRY(multi_start_exchange(ms, cur, k));
+    uint64_t iter = 0;
+    double err = 0.0;
+    const bool can_stop_early = tolerance > 0.0;
+    for (;;) {
+        // a region of x[cur] is propagated as soon as it has landed; then the row groups, each followed by the start
+        // of its region's exchange into x[1 - cur] — which travels under the work on the other groups
+        if (ms.pieces) {
+            for (uint32_t k = 0; k < K; ++k)
+                for (auto &rp : ms.ranks) {
+                    DeviceGuard g(rp->device);
+                    GM_HIP(hipStreamWaitEvent(rp->st, rp->ev_done[cur][k], 0));
+                    GM_TRY(gm_pr_sweep_bin_region(rp->pr, (uint64_t)rp->x[cur].p, k, rp->st));
+                }
+            for (uint32_t k = 0; k < K; ++k) {
+                for (auto &rp : ms.ranks) {
+                    DeviceGuard g(rp->device);
+                    GM_TRY(gm_pr_sweep_accum(rp->pr, (uint64_t)rp->x[cur].p, (uint64_t)rp->x_loc.p, (uint64_t)rp->scores.p, k,
+                                             k == 0 ? 1 : 0, rp->st));
+                }
+                if (iter + 1 != max_iterations || can_stop_early) // the last sweep's out_scores are not needed by anyone
+                    GM_TRY(multi_start_exchange(ms, 1 - cur, k));
+            }
+            for (auto &rp : ms.ranks) {
+                DeviceGuard g(rp->device);
+                GM_TRY(gm_pr_sweep_fixup(rp->pr, (uint64_t)rp->x_loc.p, (uint64_t)rp->scores.p, (uint64_t)rp->err.p, rp->st));
+            }
+        } else {
+            for (auto &rp : ms.ranks) {
+                DeviceGuard g(rp->device);
+                GM_HIP(hipStreamWaitEvent(rp->st, rp->ev_done[cur][0], 0));
+                GM_TRY(gm_pr_sweep(rp->pr, (uint64_t)rp->x[cur].p, (uint64_t)rp->x_loc.p, (uint64_t)rp->scores.p,
+                                   (uint64_t)rp->err.p, rp->st));
+            }
+            if (iter + 1 != max_iterations || can_stop_early)
+                GM_TRY(multi_start_exchange(ms, 1 - cur, 0));
+        }
+        iter += 1;
+        const bool last = iter == max_iterations;
+        if (can_stop_early || last) {
+            for (uint32_t p = 0; p < P; ++p) {
+                DeviceGuard g(ms.ranks[p]->device);
+                GM_HIP(hipMemcpyAsync(ms.herr.as<double>() + p, ms.ranks[p]->err.p, 8, hipMemcpyDeviceToHost, ms.ranks[p]->st));
+            }
+            for (auto &rp : ms.ranks) {
+                DeviceGuard g(rp->device);
+                GM_HIP(hipStreamSynchronize(rp->st));
+            }
+            ++host_syncs;
+            err = 0.0;
+            for (uint32_t p = 0; p < P; ++p) // rank order: the same bits on every run
+                err += ms.herr.as<double>()[p];
+            if (err < tolerance || last)
+                break;
+        }
+        cur = 1 - cur;
+    }
+    for (auto &rp : ms.ranks) {
+        DeviceGuard g(rp->device);
+        if (rp->hi > rp->lo)
+            GM_HIP(hipMemcpyAsync(scores_out + rp->lo, rp->scores.p, (size_t)(rp->hi - rp->lo) * 4, hipMemcpyDeviceToHost, rp->st));
+    }
+    for (auto &rp : ms.ranks) { // exchanges still in flight (started for a sweep that the stop rule cancelled) included
+        DeviceGuard g(rp->device);
+        GM_HIP(hipStreamSynchronize(rp->st));
+        GM_HIP(hipStreamSynchronize(rp->cst));
+    }
+    if (gm::log_enabled())
+        fprintf(stderr, "[graph_mi355x] multi: %llu sweeps on %u ranks, %u region(s)%s, %llu host synchronisation(s) before the result copy\n",
+                (unsigned long long)iter, P, K, ms.pieces ? " overlapped with the work" : "", (unsigned long long)host_syncs);
+    *iterations_out = iter;
+    *error_out = err;
+    return GM_OK;
+}
 
 } // namespace
 
@@ -252,214 +671,33 @@ GM_API int gm_page_rank_multi(const gm_csr *out_csr, const gm_csr *in_csr, const
         for (uint32_t q = 0; q < p; ++q)
             distinct = distinct && devs[q] != devs[p];
     }
-    const int src_dev = in_csr->device;
-
-    // ---- partition + exchange layout (on the device that holds the graph) --------------------------------
-    std::vector<uint32_t> off_host((size_t)n + 1);
-    std::vector<uint32_t> bounds, pos_at(P + 1);
-    DevBuf flag, pos, d_bounds, node_map;
-    uint32_t stride = 1;
-    {
-        DeviceGuard g(src_dev);
-        GM_HIP(hipMemcpy(off_host.data(), in_csr->offsets, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost));
-        bounds = greedy_in_degree_bounds(off_host, P);
-        GM_TRY(flag.alloc(((size_t)n + 1) * 4));
-        GM_TRY(pos.alloc(((size_t)n + 1) * 4));
-        GM_TRY(d_bounds.alloc(((size_t)P + 1) * 4));
-        GM_TRY(node_map.alloc((size_t)n * 4));
-        hipLaunchKernelGGL(mg_has_out_kernel, dim3(mg_grid((uint64_t)n + 1)), dim3(256), 0, 0, out_csr->offsets, n,
-                           flag.as<uint32_t>());
-        GM_HIP(hipGetLastError());
-        size_t tmp_bytes = 0;
-        GM_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, flag.as<uint32_t>(), pos.as<uint32_t>(), 0u, (size_t)n + 1,
-                                       rocprim::plus<uint32_t>(), (hipStream_t)0));
-        DevBuf tmp;
-        GM_TRY(tmp.alloc(tmp_bytes));
-        GM_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, flag.as<uint32_t>(), pos.as<uint32_t>(), 0u, (size_t)n + 1,
-                                       rocprim::plus<uint32_t>(), (hipStream_t)0));
-        for (uint32_t p = 0; p <= P; ++p)
-            GM_HIP(hipMemcpy(&pos_at[p], pos.as<uint32_t>() + bounds[p], 4, hipMemcpyDeviceToHost));
-        for (uint32_t p = 0; p < P; ++p)
-            stride = std::max(stride, pos_at[p + 1] - pos_at[p]);
-        stride = (stride + 3u) & ~3u; // float4-aligned slots
-        GM_CHECK((uint64_t)P * stride < (1ull << 32), GM_ERR_RANGE, "gm_page_rank_multi: exchange vector exceeds u32");
-        GM_HIP(hipMemcpy(d_bounds.p, bounds.data(), ((size_t)P + 1) * 4, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(mg_node_map_kernel, dim3(mg_grid(n)), dim3(256), 0, 0, flag.as<uint32_t>(), pos.as<uint32_t>(),
-                           d_bounds.as<uint32_t>(), P, stride, n, node_map.as<uint32_t>());
-        GM_HIP(hipGetLastError());
-        GM_HIP(hipDeviceSynchronize());
-    }
-    const uint64_t x_len = (uint64_t)P * stride;
+    // knobs, read once per call (never inside the sweep loop)
     const int engine = [] {
         const char *v = getenv("GM_MULTI_ENGINE"); // tests: "pb" / "pull"; default: by the size of each slice
         return v && v[0] == 'p' && v[1] == 'b' ? GM_PR_ENGINE_PB : v && v[0] == 'p' ? GM_PR_ENGINE_PULL : GM_PR_ENGINE_AUTO;
     }();
+    uint32_t K = 2; // regions of the exchange that overlap with the work (GM_MULTI_PARTS; 1 = one all-gather per sweep)
+    if (const char *v = getenv("GM_MULTI_PARTS"))
+        K = (uint32_t)atoi(v);
+    K = K < 1 ? 1 : (K > MG_MAX_PARTS ? MG_MAX_PARTS : K);
 
-    // ---- one rank per device: row slice, exchange buffers, engine ------------------------------------------
-    std::vector<std::unique_ptr<Rank>> ranks;
-    for (uint32_t p = 0; p < P; ++p) {
-        ranks.emplace_back(new Rank());
-        Rank &r = *ranks.back();
-        r.device = devs[p];
-        r.lo = bounds[p], r.hi = bounds[p + 1];
-        r.send_count = pos_at[p + 1] - pos_at[p];
-        const uint32_t rows = r.hi - r.lo;
-        const uint64_t e0 = off_host[r.lo], e1 = off_host[r.hi], cnt = e1 - e0;
-        DeviceGuard g(r.device);
-        GM_HIP(hipStreamCreateWithFlags(&r.st, hipStreamNonBlocking));
-        DevBuf d_off, d_tgt, d_map;
-        GM_TRY(d_off.alloc(((size_t)rows + 1) * 4));
-        GM_TRY(d_tgt.alloc((size_t)cnt * 4));
-        GM_TRY(r.outdeg.alloc((size_t)rows * 4));
-        GM_TRY(r.send_rows.alloc((size_t)r.send_count * 4));
-        // the slice's raw arrays, then offsets rebased / targets rewritten on the rank's own device
-        GM_HIP(mg_copy(d_off.p, r.device, in_csr->offsets + r.lo, src_dev, ((size_t)rows + 1) * 4));
-        GM_HIP(mg_copy(d_tgt.p, r.device, in_csr->targets + e0, src_dev, (size_t)cnt * 4));
-        const uint32_t *map_here = node_map.as<uint32_t>();
-        if (r.device != src_dev) {
-            GM_TRY(d_map.alloc((size_t)n * 4));
-            GM_HIP(mg_copy(d_map.p, r.device, node_map.p, src_dev, (size_t)n * 4));
-            map_here = d_map.as<uint32_t>();
-        }
-        {   // out-degrees and the send list are cut on the source device, then moved
-            DeviceGuard gs(src_dev);
-            DevBuf od, sr;
-            GM_TRY(od.alloc((size_t)rows * 4));
-            GM_TRY(sr.alloc((size_t)r.send_count * 4));
-            if (rows)
-                hipLaunchKernelGGL(mg_out_degree_kernel, dim3(mg_grid(rows)), dim3(256), 0, 0, out_csr->offsets, r.lo, rows,
-                                   od.as<uint32_t>());
-            if (rows)
-                hipLaunchKernelGGL(mg_send_rows_kernel, dim3(mg_grid(rows)), dim3(256), 0, 0, flag.as<uint32_t>(),
-                                   pos.as<uint32_t>(), r.lo, r.hi, sr.as<uint32_t>());
-            GM_HIP(hipGetLastError());
-            GM_HIP(hipDeviceSynchronize());
-            GM_HIP(mg_copy(r.outdeg.p, r.device, od.p, src_dev, (size_t)rows * 4));
-            GM_HIP(mg_copy(r.send_rows.p, r.device, sr.p, src_dev, (size_t)r.send_count * 4));
-        }
-        hipLaunchKernelGGL(mg_rebase_kernel, dim3(mg_grid((uint64_t)rows + 1)), dim3(256), 0, 0, d_off.as<uint32_t>(), rows + 1,
-                           (uint32_t)e0);
-        if (cnt)
-            hipLaunchKernelGGL(mg_map_targets_kernel, dim3(mg_grid(cnt)), dim3(256), 0, 0, d_tgt.as<uint32_t>(), cnt, map_here);
-        GM_HIP(hipGetLastError());
-        GM_HIP(hipDeviceSynchronize());
-        // hand the arrays to an owning handle: wrap, then let the Rank keep the buffers alive through the handle
-        gm_csr *c = new (std::nothrow) gm_csr();
-        GM_CHECK(c, GM_ERR_NOMEM, "gm_page_rank_multi: out of host memory");
-        c->n = rows, c->m = cnt, c->device = r.device, c->owns = true;
-        c->own_offsets = std::move(d_off);
-        c->own_targets = std::move(d_tgt);
-        c->offsets = c->own_offsets.as<uint32_t>();
-        c->targets = c->own_targets.as<uint32_t>();
-        r.rows = c;
-        GM_TRY(r.scores.alloc((size_t)rows * 4));
-        GM_TRY(r.x_loc.alloc((size_t)rows * 4));
-        GM_TRY(r.x[0].alloc((size_t)x_len * 4));
-        GM_TRY(r.x[1].alloc((size_t)x_len * 4));
-        GM_TRY(r.x_send.alloc((size_t)stride * 4));
-        GM_TRY(r.err.alloc(8));
-        GM_HIP(hipMemset(r.x[0].p, 0, (size_t)x_len * 4));
-        GM_HIP(hipMemset(r.x[1].p, 0, (size_t)x_len * 4));
-        GM_HIP(hipMemset(r.x_send.p, 0, (size_t)stride * 4));
-        GM_HIP(hipMemset(r.err.p, 0, 8));
-        GM_HIP(hipDeviceSynchronize());
-        GM_TRY(gm_pr_create_with(r.rows, n, r.lo, x_len, (uint64_t)r.outdeg.p, damping_factor, engine, &r.pr));
+    // the resident state of the previous call on this graph, if it was made for the same run
+    MultiPtr ms;
+    {
+        std::lock_guard<std::mutex> lock(in_csr->cache_mu);
+        if (in_csr->multi && in_csr->multi->out_csr == out_csr && in_csr->multi->devs == devs &&
+            in_csr->multi->damping == damping_factor && in_csr->multi->engine == engine &&
+            (in_csr->multi->K == K || (!in_csr->multi->pieces && in_csr->multi->K == 1)) && !getenv("GM_MULTI_NOCACHE") &&
+            !(getenv("GM_PB_NOCACHE") && atoi(getenv("GM_PB_NOCACHE")))) // measurement runs that switch plan knobs build afresh
+            ms = std::move(in_csr->multi);
     }
-
-    Comms comms;
-    if (distinct) {
-        GM_TRY(rccl_get(&comms.rc));
-        comms.c.assign(P, nullptr);
-        GM_NCCL(comms.rc, comms.rc->CommInitAll(comms.c.data(), (int)P, devs.data()));
+    if (!ms)
+        GM_TRY(multi_build(out_csr, in_csr, devs, distinct, damping_factor, engine, K, &ms));
+    const int rc = multi_run(*ms, max_iterations, tolerance, scores_out, iterations_out, error_out);
+    if (rc == GM_OK && !(getenv("GM_PB_NOCACHE") && atoi(getenv("GM_PB_NOCACHE")))) { // parked for the next call (a failed run is torn down)
+        std::lock_guard<std::mutex> lock(in_csr->cache_mu);
+        if (!in_csr->multi)
+            in_csr->multi = std::move(ms);
     }
-
-    // the out_scores every rank contributes, gathered into x[buf] of every rank
-    auto exchange = [&](int buf) -> int {
-        for (auto &rp : ranks) {
-            Rank &r = *rp;
-            DeviceGuard g(r.device);
-            if (r.send_count)
-                hipLaunchKernelGGL(mg_compact_kernel, dim3(mg_grid(r.send_count)), dim3(256), 0, r.st, r.x_loc.as<float>(),
-                                   r.send_rows.as<uint32_t>(), r.send_count, r.x_send.as<float>());
-            GM_HIP(hipGetLastError());
-        }
-        if (distinct) {
-            GM_NCCL(comms.rc, comms.rc->GroupStart());
-            for (uint32_t p = 0; p < P; ++p) {
-                Rank &r = *ranks[p];
-                GM_NCCL(comms.rc, comms.rc->AllGather(r.x_send.p, r.x[buf].p, stride, ncclFloat32, comms.c[p], r.st));
-            }
-            GM_NCCL(comms.rc, comms.rc->GroupEnd());
-        } else { // virtual ranks on shared devices: the same data movement with copies
-            for (auto &rp : ranks) {
-                DeviceGuard g(rp->device);
-                GM_HIP(hipStreamSynchronize(rp->st));
-            }
-            for (uint32_t p = 0; p < P; ++p)
-                for (uint32_t q = 0; q < P; ++q) {
-                    DeviceGuard g(ranks[q]->device);
-                    float *dst = ranks[q]->x[buf].as<float>() + (size_t)p * stride;
-                    if (ranks[q]->device == ranks[p]->device)
-                        GM_HIP(hipMemcpyAsync(dst, ranks[p]->x_send.p, (size_t)stride * 4, hipMemcpyDeviceToDevice, ranks[q]->st));
-                    else
-                        GM_HIP(hipMemcpyPeerAsync(dst, ranks[q]->device, ranks[p]->x_send.p, ranks[p]->device,
-                                                  (size_t)stride * 4, ranks[q]->st));
-                }
-            for (auto &rp : ranks) {
-                DeviceGuard g(rp->device);
-                GM_HIP(hipStreamSynchronize(rp->st));
-            }
-        }
-        return GM_OK;
-    };
-
-    PinnedBuf herr;
-    GM_TRY(herr.alloc((size_t)P * 8));
-    for (auto &rp : ranks) {
-        DeviceGuard g(rp->device);
-        GM_TRY(gm_pr_init(rp->pr, (uint64_t)rp->scores.p, (uint64_t)rp->x_loc.p, rp->st));
-    }
-    GM_TRY(exchange(0));
-    uint64_t iter = 0;
-    double err = 0.0;
-    int cur = 0;
-    const bool can_stop_early = tolerance > 0.0;
-    for (;;) {
-        for (auto &rp : ranks) {
-            DeviceGuard g(rp->device);
-            GM_TRY(gm_pr_sweep(rp->pr, (uint64_t)rp->x[cur].p, (uint64_t)rp->x_loc.p, (uint64_t)rp->scores.p,
-                               (uint64_t)rp->err.p, rp->st));
-        }
-        iter += 1;
-        const bool last = iter == max_iterations;
-        if (can_stop_early || last) {
-            for (uint32_t p = 0; p < P; ++p) {
-                DeviceGuard g(ranks[p]->device);
-                GM_HIP(hipMemcpyAsync(herr.as<double>() + p, ranks[p]->err.p, 8, hipMemcpyDeviceToHost, ranks[p]->st));
-            }
-            for (auto &rp : ranks) {
-                DeviceGuard g(rp->device);
-                GM_HIP(hipStreamSynchronize(rp->st));
-            }
-            err = 0.0;
-            for (uint32_t p = 0; p < P; ++p) // rank order: the same bits on every run
-                err += herr.as<double>()[p];
-            if (err < tolerance || last)
-                break;
-        }
-        GM_TRY(exchange(1 - cur));
-        cur = 1 - cur;
-    }
-    for (auto &rp : ranks) {
-        DeviceGuard g(rp->device);
-        if (rp->hi > rp->lo)
-            GM_HIP(hipMemcpyAsync(scores_out + rp->lo, rp->scores.p, (size_t)(rp->hi - rp->lo) * 4, hipMemcpyDeviceToHost, rp->st));
-    }
-    for (auto &rp : ranks) {
-        DeviceGuard g(rp->device);
-        GM_HIP(hipStreamSynchronize(rp->st));
-    }
-    *iterations_out = iter;
-    *error_out = err;
-    return GM_OK;
+    return rc;
 }

@@ -606,6 +606,25 @@ GM_API int gm_pr_sweep_bin(gm_pr *pr, uint64_t d_x_in_global, uint64_t x_lo, uin
                                   (hipStream_t)stream);
 }
 
+GM_API int gm_pr_set_bin_regions(gm_pr *pr, const uint64_t *x_lo, const uint64_t *x_hi, const uint32_t *region, uint64_t count,
+                                 uint32_t n_regions)
+{
+    GM_CHECK(pr && (count == 0 || (x_lo && x_hi && region)), GM_ERR_INVALID, "gm_pr_set_bin_regions: null argument");
+    GM_CHECK(pr->engine == GM_PR_ENGINE_PB, GM_ERR_UNSUPPORTED, "gm_pr_set_bin_regions: not a propagation-blocking engine");
+    GM_CHECK(n_regions >= 1 && n_regions <= 64 && count <= 65536, GM_ERR_INVALID, "gm_pr_set_bin_regions: %u regions, %llu ranges",
+             n_regions, (unsigned long long)count);
+    gm::DeviceGuard guard(pr->csr->device);
+    return gm::pb_set_regions(pr->pb, pr->pb_scratch, x_lo, x_hi, region, (uint32_t)count, n_regions);
+}
+
+GM_API int gm_pr_sweep_bin_region(gm_pr *pr, uint64_t d_x_in_global, uint32_t region, void *stream)
+{
+    GM_CHECK(pr && d_x_in_global, GM_ERR_INVALID, "gm_pr_sweep_bin_region: null argument");
+    GM_CHECK(pr->engine == GM_PR_ENGINE_PB, GM_ERR_UNSUPPORTED, "gm_pr_sweep_bin_region: not a propagation-blocking engine");
+    gm::DeviceGuard guard(pr->csr->device);
+    return gm::pb_sweep_bin_region(pr->pb, pr->pb_scratch, reinterpret_cast<const float *>(d_x_in_global), region, (hipStream_t)stream);
+}
+
 GM_API int gm_pr_plan_info(const gm_pr *pr, uint64_t *info, uint32_t count)
 {
     GM_CHECK(pr && info, GM_ERR_INVALID, "gm_pr_plan_info: null argument");

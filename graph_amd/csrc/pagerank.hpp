@@ -39,6 +39,9 @@ uint32_t pb_source_tile(const PbPlan *plan);
 int pb_set_parts(const PbPlan *plan, PbScratch *scratch, const uint64_t *row_splits, uint32_t n_parts);
 int pb_sweep_bin_range(const PbPlan *plan, PbScratch *scratch, const float *x_in, uint64_t x_lo, uint64_t x_hi,
                        hipStream_t st);
+int pb_set_regions(const PbPlan *plan, PbScratch *scratch, const uint64_t *x_lo, const uint64_t *x_hi, const uint32_t *reg,
+                   uint32_t count, uint32_t n_regions);
+int pb_sweep_bin_region(const PbPlan *plan, PbScratch *scratch, const float *x_in, uint32_t region, hipStream_t st);
 int pb_sweep_hot(const PbPlan *plan, PbScratch *scratch, const float *x_in, hipStream_t st);
 int pb_sweep_accum_part(const PbPlan *plan, PbScratch *scratch, const float *x_in, float *x_out, float *scores,
                         const uint32_t *outdeg, float base, float damping, uint32_t part, int stage_hot, hipStream_t st);

@@ -88,6 +88,10 @@ struct PbScratch {
     // part_items[part_off[k] .. part_off[k+1]), each part longest-first
     DevBuf part_items;
     std::vector<uint32_t> part_off;
+    // regions of the x vector given as lists of tile ranges (gm_pr_set_bin_regions): the phase-1 work items of region r
+    // are region_items[region_off[r] .. region_off[r + 1])
+    DevBuf region_items;
+    std::vector<uint32_t> region_off;
     DevBuf vals_raw; // backing allocation of the value stream
     std::shared_ptr<DevBuf> vals_shared; // GM_PB_VALS_SHARE (measurement): one allocation behind the streams of several engines
     float *vals = nullptr; // f32[Mv] per-edge values, bin-major, segments padded to 4
@@ -667,13 +671,15 @@ __global__ __launch_bounds__(PB_BIN_BLOCK) void pb_bin_kernel(const float *__res
                                                               const uint16_t *__restrict__ p1_src,
                                                               const uint32_t *__restrict__ chunk_seg,
                                                               const uint32_t *__restrict__ delta, float *__restrict__ vals,
-                                                              uint32_t PB_BIN_CHUNK, uint32_t w_first, int xcd_aware)
+                                                              uint32_t PB_BIN_CHUNK, uint32_t w_first, int xcd_aware,
+                                                              const uint32_t *__restrict__ item_list)
 {
     constexpr uint32_t PB_S = 1u << S_LOG;                          // sources per tile
     extern __shared__ float xs[];                                   // PB_S floats ...
     uint32_t *dl = reinterpret_cast<uint32_t *>(xs + PB_S);         // ... + PB_DCACHE segment deltas
     const uint32_t tid = threadIdx.x;
-    const uint32_t item = w_first + (xcd_aware ? pb_xcd_item(blockIdx.x, gridDim.x) : blockIdx.x);
+    const uint32_t slot = xcd_aware ? pb_xcd_item(blockIdx.x, gridDim.x) : blockIdx.x;
+    const uint32_t item = item_list ? item_list[slot] : w_first + slot; // a list: the items of a region of several tile ranges
     const uint32_t t = wg_tile[item];
     const uint32_t p_begin = wg_p0[item];
     const uint32_t tile_end = tile_p[t + 1];
@@ -1101,7 +1107,8 @@ __global__ __launch_bounds__(PB_ACC_BLOCK, 8) void pb_hub_kernel(const float *__
                                                               const uint32_t *__restrict__ hub_rows,
                                                               const uint32_t *__restrict__ outdeg, float *__restrict__ scores,
                                                               float *__restrict__ x_out, double *__restrict__ group_err,
-                                                              float base, float damping, uint32_t long2, uint32_t long4)
+                                                              float base, float damping, uint32_t long2, uint32_t long4,
+                                                              uint32_t graded)
 {
     // per step and row: the sum of the step's terms rounded at ulp(S) [0] and at 2 ulp(S) [1], in R replicas
     // (lane mod R) so that the LDS atomics of a wavefront spread over ~64 addresses; three steps in rotation
@@ -1173,8 +1180,18 @@ __global__ __launch_bounds__(PB_ACC_BLOCK, 8) void pb_hub_kernel(const float *__
         return x;
     };
     // the terms of one 4096-entry block of the stream, rounded and added to the step sums hub_q[buf]
-    auto add_block = [&](auto few_tag, const f32x4 &cv, const U16x4 &cd) {
+    // only the entries [e_lo, e_hi) of the block take part (the others count as padding): a block can be added in several
+    // passes, each followed by end_step
+    auto add_block = [&](auto few_tag, const f32x4 &cv, const U16x4 &cd_in, uint32_t e_lo = 0, uint32_t e_hi = STEP) {
         constexpr bool FEW = decltype(few_tag)::value;
+        U16x4 cd = cd_in;
+        if (e_lo != 0 || e_hi != STEP) { // a pass over part of the block (workgroup-uniform, off the hot path)
+            const uint32_t i0 = tid * PB_VEC;
+            cd.a = (i0 >= e_lo && i0 < e_hi) ? cd.a : PB_NULL;
+            cd.b = (i0 + 1u >= e_lo && i0 + 1u < e_hi) ? cd.b : PB_NULL;
+            cd.c = (i0 + 2u >= e_lo && i0 + 2u < e_hi) ? cd.c : PB_NULL;
+            cd.d = (i0 + 3u >= e_lo && i0 + 3u < e_hi) ? cd.d : PB_NULL;
+        }
         const uint32_t sl[4] = {cd.a < nh ? cd.a : nh, cd.b < nh ? cd.b : nh, cd.c < nh ? cd.c : nh, cd.d < nh ? cd.d : nh};
         const float vl[4] = {cv.x, cv.y, cv.z, cv.w};
         uint32_t slow = 0;
@@ -1281,10 +1298,28 @@ __global__ __launch_bounds__(PB_ACC_BLOCK, 8) void pb_hub_kernel(const float *__
     // other seven).  Measured with 65536 / 262144: that rank 1.02 -> 0.95 ms, scale 22 on one GPU 0.210 -> 0.204 ms, but
     // the 400,000-term row of scale 24 moves from 3.0e-6 to 6.5e-6 of the reference (limit 1e-5): not worth the margin.
     const uint32_t per_step = !few ? 1u : (he - hb) >= long4 ? 4u : (he - hb) >= long2 ? 2u : 1u; // FEW: blocks per step
+    // The FIRST block of a group goes in passes of 64, 64, 128, 256 ... entries: a row's sum starts from nothing and would
+    // otherwise cross a dozen binades inside one step, summed exactly — without the rounding the reference applies from
+    // its second term on.  A large early term then cost up to 1.5e-4 (tests/test_gpu_hub_adversarial.py, "one giant
+    // first"); with 64-entry passes the unrounded stretch is at most 64 terms: 64 x 2^-25 = 2e-6.  (A term far above the
+    // running sum in the MIDDLE of a long row still mis-rounds what follows it inside its step: at most 4095 terms at
+    // half an ulp each.  Walking such steps again in small passes was tried and cost the kernel its registers — the
+    // climbs are common in groups of many rows, where they are harmless: a row has a few hundred terms per step.)
     auto walk = [&](auto few_tag) {
         constexpr bool FEW = decltype(few_tag)::value;
+        {
+            const f32x4 cv = hv[0];
+            const U16x4 cd = hd[0];
+            for (uint32_t lo = 0, hi = graded ? 64u : STEP; lo < STEP; lo = hi, hi = hi * 2u < STEP ? hi * 2u : STEP) {
+                add_block(few_tag, cv, cd, lo, hi);
+                end_step();
+            }
+        }
+        const uint32_t q1 = h_first + STEP; // the steps proper start at the second block
+        load_step(q1, hv[0], hd[0]);
+        load_step(q1 + STEP, hv[1], hd[1]);
         uint32_t since = 0; // FEW: blocks added since the last end_step
-        for (uint32_t qs = hb, q0 = h_first; qs < he; qs += HS * STEP, q0 += HS * STEP) {
+        for (uint32_t qs = hb + STEP, q0 = q1; qs < he; qs += HS * STEP, q0 += HS * STEP) {
 #pragma unroll
             for (int k = 0; k < HS; k += FEW ? 1 : 2) {
                 if (qs + (uint32_t)k * STEP >= he) // uniform over the workgroup
@@ -2001,7 +2036,7 @@ int pb_plan_get(const gm_csr *csr, uint64_t x_len, std::shared_ptr<const PbPlan>
 
 
 static void pb_bin_dispatch(const PbPlan *pl, PbScratch *sc, const float *x_in, uint32_t w_first, uint32_t w_count,
-                            hipStream_t st);
+                            hipStream_t st, const uint32_t *item_list = nullptr);
 
 int pb_scratch_create(const PbPlan *pl, PbScratch **out, DevBuf *early)
 {
@@ -2268,14 +2303,15 @@ void pb_plan_info(const PbPlan *pl, const PbScratch *sc, uint64_t *info, uint32_
 }
 
 template <int ABL, int S_LOG>
-void pb_launch_bin(const PbPlan *pl, PbScratch *sc, const float *x_in, uint32_t w_first, uint32_t w_count, hipStream_t st)
+void pb_launch_bin(const PbPlan *pl, PbScratch *sc, const float *x_in, uint32_t w_first, uint32_t w_count, hipStream_t st,
+                   const uint32_t *item_list = nullptr)
 {
-    const bool grouped = pl->wg_tile_g.p && w_first == 0 && w_count == pl->NW; // whole sweeps only
+    const bool grouped = pl->wg_tile_g.p && w_first == 0 && w_count == pl->NW && !item_list; // whole sweeps only
     hipLaunchKernelGGL((pb_bin_kernel<ABL, S_LOG>), dim3(w_count), dim3(PB_BIN_BLOCK), (4u << S_LOG) + PB_DCACHE * 4, st, x_in,
                        pl->x_len, pl->tile_p.as<uint32_t>(), (grouped ? pl->wg_tile_g : pl->wg_tile).as<uint32_t>(),
                        (grouped ? pl->wg_p0_g : pl->wg_p0).as<uint32_t>(),
                        pl->p1_src.as<uint16_t>(), pl->chunk_seg.as<uint32_t>(), pl->delta.as<uint32_t>(), sc->vals,
-                       pl->chunk, w_first, pl->xcd_aware);
+                       pl->chunk, w_first, pl->xcd_aware, item_list);
 }
 
 template <int ABL>
@@ -2293,16 +2329,16 @@ void pb_launch_accum(const PbPlan *pl, PbScratch *sc, const PbItem *items, uint3
 // GM_PB_ABLATE = 10*accumulate variant + bin variant; 0 = the product kernels (re-read per call so that
 // tools/ablate.py can switch variants on one resident graph)
 static void pb_bin_dispatch(const PbPlan *pl, PbScratch *sc, const float *x_in, uint32_t w_first, uint32_t w_count,
-                            hipStream_t st)
+                            hipStream_t st, const uint32_t *item_list)
 {
     if (w_count == 0)
         return;
-    const int abl = pb_env("GM_PB_ABLATE", 0) % 10;
+    const int abl = item_list ? 0 : pb_env("GM_PB_ABLATE", 0) % 10;
     if (pl->s_log == 15) {
         switch (abl) {
         case 3: pb_launch_bin<3, 15>(pl, sc, x_in, w_first, w_count, st); break;
         case 5: pb_launch_bin<5, 15>(pl, sc, x_in, w_first, w_count, st); break;
-        default: pb_launch_bin<0, 15>(pl, sc, x_in, w_first, w_count, st); break;
+        default: pb_launch_bin<0, 15>(pl, sc, x_in, w_first, w_count, st, item_list); break;
         }
         return;
     }
@@ -2311,7 +2347,7 @@ static void pb_bin_dispatch(const PbPlan *pl, PbScratch *sc, const float *x_in, 
     case 3: pb_launch_bin<3, 14>(pl, sc, x_in, w_first, w_count, st); break;
     case 4: pb_launch_bin<4, 14>(pl, sc, x_in, w_first, w_count, st); break;
     case 5: pb_launch_bin<5, 14>(pl, sc, x_in, w_first, w_count, st); break;
-    default: pb_launch_bin<0, 14>(pl, sc, x_in, w_first, w_count, st); break;
+    default: pb_launch_bin<0, 14>(pl, sc, x_in, w_first, w_count, st, item_list); break;
     }
 }
 
@@ -2335,7 +2371,7 @@ static void pb_hub_dispatch(const PbPlan *pl, PbScratch *sc, float *x_out, float
         hipLaunchKernelGGL(pb_hub_kernel, dim3(pl->G), dim3(PB_ACC_BLOCK), 0, st, sc->vals, pl->p2_dst.as<uint16_t>(),
                            pl->hub_items.as<PbHubItem>(), pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out,
                            sc->bin_err.as<double>() + pl->B, base, damping, (uint32_t)pb_env("GM_PB_HUB_LONG2", 0x7FFFFFFF),
-                           (uint32_t)pb_env("GM_PB_HUB_LONG4", 0x7FFFFFFF));
+                           (uint32_t)pb_env("GM_PB_HUB_LONG4", 0x7FFFFFFF), (uint32_t)pb_env("GM_PB_HUB_GRADED", 1));
 }
 
 static void pb_hot_dispatch(const PbPlan *pl, PbScratch *sc, const float *x_in, hipStream_t st)
@@ -2431,6 +2467,51 @@ int pb_sweep_bin_range(const PbPlan *pl, PbScratch *sc, const float *x_in, uint6
     const uint32_t w0 = pl->wg_first_host[tile_lo], w1 = pl->wg_first_host[tile_hi > pl->NT ? pl->NT : tile_hi];
     pb_apply_vals_offset(pl, sc);
     pb_bin_dispatch(pl, sc, x_in, w0, w1 - w0, st);
+    GM_HIP(hipGetLastError());
+    return GM_OK;
+}
+
+// Regions of the x vector as LISTS of tile ranges: range i = [x_lo[i], x_hi[i]) (whole source tiles; x_hi may be the end
+// of the vector) belongs to region reg[i].  A partitioned run keeps x rank-major — ascending node ids, which the hub
+// rows' summation order follows — and exchanges row group k of every rank as region k: P ranges, one launch.
+int pb_set_regions(const PbPlan *pl, PbScratch *sc, const uint64_t *x_lo, const uint64_t *x_hi, const uint32_t *reg,
+                   uint32_t count, uint32_t n_regions)
+{
+    const uint64_t S = 1ull << pl->s_log;
+    std::vector<std::vector<uint32_t>> items(n_regions);
+    for (uint32_t i = 0; i < count; ++i) {
+        uint64_t lo = x_lo[i], hi = x_hi[i] > pl->x_len ? pl->x_len : x_hi[i];
+        GM_CHECK(reg[i] < n_regions, GM_ERR_INVALID, "gm_pr_set_bin_regions: range %u names region %u of %u", i, reg[i], n_regions);
+        GM_CHECK(lo % S == 0 && (hi % S == 0 || hi == pl->x_len) && lo <= hi, GM_ERR_INVALID,
+                 "gm_pr_set_bin_regions: [%llu, %llu) is not a range of whole source tiles (%llu)", (unsigned long long)lo,
+                 (unsigned long long)hi, (unsigned long long)S);
+        if (pl->NW == 0 || lo >= hi)
+            continue;
+        const uint64_t t_lo = lo >> pl->s_log, t_hi = (hi + S - 1) >> pl->s_log;
+        for (uint32_t w = pl->wg_first_host[t_lo]; w < pl->wg_first_host[t_hi > pl->NT ? pl->NT : t_hi]; ++w)
+            items[reg[i]].push_back(w);
+    }
+    std::vector<uint32_t> flat;
+    sc->region_off.assign(n_regions + 1, 0);
+    for (uint32_t r = 0; r < n_regions; ++r) {
+        sc->region_off[r] = (uint32_t)flat.size();
+        flat.insert(flat.end(), items[r].begin(), items[r].end());
+    }
+    sc->region_off[n_regions] = (uint32_t)flat.size();
+    GM_TRY(sc->region_items.alloc((flat.size() ? flat.size() : 1) * 4));
+    if (!flat.empty())
+        GM_HIP(hipMemcpy(sc->region_items.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice));
+    return GM_OK;
+}
+
+// propagates the tiles of region `region` (pb_set_regions) into the value stream: one launch
+int pb_sweep_bin_region(const PbPlan *pl, PbScratch *sc, const float *x_in, uint32_t region, hipStream_t st)
+{
+    GM_CHECK(region + 1 < sc->region_off.size(), GM_ERR_INVALID, "gm_pr_sweep_bin_region: region %u of %zu (call gm_pr_set_bin_regions first)",
+             region, sc->region_off.empty() ? (size_t)0 : sc->region_off.size() - 1);
+    const uint32_t i0 = sc->region_off[region], i1 = sc->region_off[region + 1];
+    pb_apply_vals_offset(pl, sc);
+    pb_bin_dispatch(pl, sc, x_in, 0, i1 - i0, st, sc->region_items.as<uint32_t>() + i0);
     GM_HIP(hipGetLastError());
     return GM_OK;
 }

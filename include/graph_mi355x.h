@@ -231,6 +231,13 @@ int gm_pr_sweep_fixup(gm_pr *pr, uint64_t d_x_out_local, uint64_t d_scores_local
 int gm_pr_part_geometry(const gm_pr *pr, uint64_t *rows_per_bin_out, uint64_t *source_tile_out);
 int gm_pr_set_parts(gm_pr *pr, const uint64_t *row_splits /* n_parts + 1 values: 0 .. n_local */, uint64_t n_parts);
 int gm_pr_sweep_bin(gm_pr *pr, uint64_t d_x_in_global, uint64_t x_lo, uint64_t x_hi /* elements of x_in */, void *stream);
+/* Regions given as lists of ranges: range i = [x_lo[i], x_hi[i]) (whole source tiles) belongs to region region[i];
+ * gm_pr_sweep_bin_region propagates all ranges of one region in ONE launch.  A partitioned run keeps the exchanged
+ * vector rank-major (ascending node ids — the order the hub rows' sums follow, page_rank.rs:143-146) and exchanges row
+ * group k of every rank as region k: n_ranks ranges. */
+int gm_pr_set_bin_regions(gm_pr *pr, const uint64_t *x_lo, const uint64_t *x_hi, const uint32_t *region, uint64_t count,
+                          uint32_t n_regions);
+int gm_pr_sweep_bin_region(gm_pr *pr, uint64_t d_x_in_global, uint32_t region, void *stream);
 int gm_pr_sweep_hot(gm_pr *pr, uint64_t d_x_in_global, void *stream); /* stage the hot sources (whole vector needed) */
 int gm_pr_sweep_accum(gm_pr *pr, uint64_t d_x_in_global, uint64_t d_x_out_local, uint64_t d_scores_local,
                       uint64_t part, int stage_hot /* 1: gm_pr_sweep_hot first, on this stream */, void *stream);
@@ -243,7 +250,7 @@ uint64_t gm_pr_tile_count(const gm_pr *pr); /* workgroups per sweep (diagnostics
  * (page_rank.rs:143-146), [3] their in-edges, [4] the in-degree threshold for that (GM_PB_HUB_DEG, default
  * 4096, 0 = off), [5] hot sources, [6] entries of the value stream, [7] hot edges, [8] bytes of this engine's
  * scratch (value stream etc.), [9] bins, [10] source tiles, [11] (tile, bin) segments, [12] hub groups (the hub
- * rows are walked in groups of <= 64 rows, one workgroup each).  Further entries are 0. */
+ * rows are walked in groups of <= 64 rows, one workgroup each), [13] tiers of hot sources.  Further entries are 0. */
 int gm_pr_plan_info(const gm_pr *pr, uint64_t *info, uint32_t count);
 
 /* ---------------------------------------------------------------------------------------------

@@ -69,3 +69,41 @@ def test_partitioned_page_rank_more_ranks_than_rows_with_edges(P):
     got = P.page_rank_multi(g, P.PageRankConfig(5, 0.0, 0.85), devices=[0, 0, 0])
     np.testing.assert_allclose(got[0], ref[0], rtol=2e-7, atol=0)
     assert got[1] == 5
+
+
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]])
+def test_overlapped_regions_give_the_bits_of_the_blocking_exchange_and_reuse_the_resident_state(P, oracle, devices, monkeypatch, capfd):
+    """The exchange in K = 2 regions that travel under the work (the default), the one-region path (GM_MULTI_PARTS=1)
+    and the single-GPU engine: with exactly rounded rows the same bits.  The run's partition / slices / engines /
+    streams are parked in the in-CSR handle: a second call on the same device list builds nothing."""
+    import time
+
+    monkeypatch.setenv("GM_MULTI_ENGINE", "pb")
+    monkeypatch.setenv("GM_PB_HUB_DEG", "0")
+    monkeypatch.setenv("GM_LOG", "1")
+    g, _ = _graph(P, oracle, 18, seed=3)
+    cfg = P.PageRankConfig(9, 0.0, 0.85)
+    one, _, err1 = P.page_rank(g, cfg, P.PageRankMode.JacobiPB)
+    capfd.readouterr()
+    t0 = time.perf_counter()
+    two, it, err = P.page_rank_multi(g, cfg, devices=devices)       # builds the resident state, two regions
+    t_first = time.perf_counter() - t0
+    log_first = capfd.readouterr().err
+    t0 = time.perf_counter()
+    again, _, err_again = P.page_rank_multi(g, cfg, devices=devices)  # ... and runs on it again
+    t_again = time.perf_counter() - t0
+    log_again = capfd.readouterr().err
+    assert it == 9 and np.array_equal(two, one) and np.array_equal(again, one) and err == err_again
+    assert "2 region(s) overlapped with the work" in log_first and "0 host synchronisation(s)" not in log_first  # the last sweep's error is read
+    assert "1 host synchronisation(s)" in log_first               # tolerance 0: only the final error read-back
+    assert "multi: row slices + engines" in log_first and "multi: row slices + engines" not in log_again
+    print(f"{len(devices)} virtual ranks: first call {t_first * 1e3:.1f} ms, second call on the resident state {t_again * 1e3:.1f} ms")
+    monkeypatch.setenv("GM_MULTI_PARTS", "1")
+    blocking, _, err_b = P.page_rank_multi(g, cfg, devices=devices)   # another layout: rebuilt, one region
+    log_b = capfd.readouterr().err
+    assert np.array_equal(blocking, one) and "1 region(s)" in log_b and "multi: row slices + engines" in log_b
+    # a tolerance that stops the run early: the stop rule reads the error every sweep, results unchanged
+    monkeypatch.delenv("GM_MULTI_PARTS")
+    ref, it_ref, _ = P.page_rank(g, P.PageRankConfig(50, 1e-7, 0.85), P.PageRankMode.JacobiPB)
+    got, it_got, _ = P.page_rank_multi(g, P.PageRankConfig(50, 1e-7, 0.85), devices=devices)
+    assert it_got == it_ref and np.array_equal(got, ref)
