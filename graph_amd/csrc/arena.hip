@@ -21,8 +21,20 @@ namespace gm {
 
 namespace {
 
+// Virtual addresses are the arena's own too: ONE large reservation per device (more when it runs out), carved up here and
+// never handed back.  Measured on ROCm 7.0: after hipMemAddressFree of a range that had held mappings, later hipMalloc
+// allocations of the process turned up with garbage in them (PageRank returned NaN at RMAT scale 21-24; with the freed
+// ranges leaked instead, every result was right) — the runtime reuses the addresses while something still remembers
+// the old mappings.  Address space is not scarce (the default reservation is 1 TiB of a 2^47-byte space).
+struct VaRange {
+    char *base = nullptr;
+    size_t size = 0, bump = 0;
+};
+
 struct Arena {
     std::mutex mu;
+    std::vector<VaRange> va;                   // reservations, the last one is the one being carved up
+    std::multimap<size_t, char *> va_free;     // returned stretches by size (buffers of a few recurring sizes come and go)
     std::vector<ArenaPiece> free_list; // ascending serial = creation order
     uint64_t next_serial = 0;
     uint64_t alive = 0; // pieces created and not released to the driver
@@ -69,6 +81,50 @@ int create_pieces(Arena &a, int dev, size_t count)
 }
 
 } // namespace
+
+int arena_va_alloc(int dev, size_t span, void **out)
+{
+    Arena &a = arena_of(dev);
+    std::lock_guard<std::mutex> lock(a.mu);
+    auto it = a.va_free.find(span);
+    if (it != a.va_free.end()) {
+        *out = it->second;
+        a.va_free.erase(it);
+        return GM_OK;
+    }
+    if (a.va.empty() || a.va.back().size - a.va.back().bump < span) {
+        const char *v = getenv("GM_ARENA_VA_GIB");
+        size_t want = (size_t)(v && atol(v) > 0 ? atol(v) : 1024) << 30;
+        while (want < 2 * span)
+            want *= 2;
+        void *base = nullptr;
+        hipError_t e = hipErrorOutOfMemory;
+        for (; want >= span; want /= 2) { // a smaller reservation if the large one is refused
+            e = hipMemAddressReserve(&base, want, ARENA_PIECE, nullptr, 0);
+            if (e == hipSuccess)
+                break;
+            (void)hipGetLastError();
+        }
+        if (e != hipSuccess) {
+            set_error("arena: hipMemAddressReserve(%zu bytes) failed: %s", span, hipGetErrorString(e));
+            return GM_ERR_NOMEM;
+        }
+        if (!a.va.empty() && a.va.back().size > a.va.back().bump) // what is left of the old reservation stays usable
+            a.va_free.emplace(a.va.back().size - a.va.back().bump, a.va.back().base + a.va.back().bump);
+        a.va.push_back(VaRange{static_cast<char *>(base), want, 0});
+    }
+    VaRange &r = a.va.back();
+    *out = r.base + r.bump;
+    r.bump += span;
+    return GM_OK;
+}
+
+void arena_va_free(int dev, void *ptr, size_t span)
+{
+    Arena &a = arena_of(dev);
+    std::lock_guard<std::mutex> lock(a.mu);
+    a.va_free.emplace(span, static_cast<char *>(ptr));
+}
 
 bool arena_enabled()
 {

@@ -79,11 +79,25 @@ struct ArenaPiece {
     uint64_t serial; // creation order
 };
 bool arena_enabled(); // GM_ARENA=0: every buffer from hipMalloc
+inline int &arena_site() // which part of the library is allocating (1 CSR build, 2 plan temporaries, 4 plan streams, 8 value stream)
+{
+    static thread_local int site = 0;
+    return site;
+}
+inline bool arena_site_enabled(int site) // GM_ARENA_SITES=<mask> (debugging): which of them may use the arena
+{
+    const char *v = getenv("GM_ARENA_SITES");
+    const int s = site ? site : arena_site();
+    return !(v && *v) || s == 0 || (atoi(v) & s);
+}
 // `count` pieces; spread_seed != 0: a stratified pseudo-random subset of a free list of >= count x spread_factor pieces
 // (of the free pieces created as numbers [serial_lo, serial_hi), when that range is given: no growth then)
 int arena_take(int dev, size_t count, uint64_t spread_seed, size_t spread_factor, std::vector<ArenaPiece> &out,
                uint64_t serial_lo = 0, uint64_t serial_hi = ~0ull);
 int arena_grow(int dev, size_t count, uint64_t *first_serial_out);
+// virtual addresses out of the arena's own reservation (never returned to the runtime: see arena.hip)
+int arena_va_alloc(int dev, size_t span, void **out);
+void arena_va_free(int dev, void *ptr, size_t span);
 void arena_give(int dev, std::vector<ArenaPiece> &pieces);
 void arena_trim(int dev, size_t keep_bytes);
 void arena_stats(int dev, uint64_t *out4);
@@ -124,16 +138,19 @@ struct DevBuf {
             // hipFree waits for the device; so does this (a kernel may still be reading the buffer)
             DeviceSwitch sw(arena_dev);
             (void)hipDeviceSynchronize();
-            if (p) {
-                (void)hipMemUnmap(p, vmm_span);
-                (void)hipMemAddressFree(p, vmm_span);
+            if (p) { // piece by piece, as they were mapped (one hipMemUnmap over the whole range left the later pieces mapped:
+                     // the freed addresses then reached hipMalloc with the arena's memory still behind them)
+                for (size_t i = 0; i < arena.size(); ++i)
+                    (void)hipMemUnmap(static_cast<char *>(p) + i * ARENA_PIECE, ARENA_PIECE);
+                arena_va_free(arena_dev, p, vmm_span); // back to the arena's own address space, not to the runtime
             }
             arena_give(arena_dev, arena);
             vmm_chunk = vmm_span = 0;
         } else if (vmm_span) {
             if (p) {
-                (void)hipMemUnmap(p, vmm_span);
-                (void)hipMemAddressFree(p, vmm_span);
+                for (size_t i = 0; i < vmm.size(); ++i)
+                    (void)hipMemUnmap(static_cast<char *>(p) + i * vmm_chunk, vmm_chunk);
+                // the range itself is left reserved (measurement paths only): freed ranges corrupt later allocations (arena.hip)
             }
             for (hipMemGenericAllocationHandle_t h : vmm)
                 (void)hipMemRelease(h);
@@ -152,6 +169,16 @@ struct DevBuf {
             nbytes = 16; // keep pointers non-null for empty graphs
         GM_HIP(hipMalloc(&p, nbytes));
         bytes = nbytes;
+        // GM_POISON="<min bytes>,<max bytes>" (debugging): allocations in that size range start out as 0xFF bytes (f32 NaN)
+        // instead of whatever the driver hands out (usually zeros) — finds code that reads what it never wrote
+        if (const char *v = getenv("GM_POISON")) {
+            unsigned long long lo = 0, hi = ~0ull;
+            (void)sscanf(v, "%llu,%llu", &lo, &hi);
+            if (nbytes >= lo && nbytes <= hi) {
+                GM_HIP(hipMemset(p, 0xFF, nbytes));
+                GM_HIP(hipDeviceSynchronize());
+            }
+        }
         return GM_OK;
     }
     // A large buffer from the arena's 64 MiB pieces (arena.hip); spread_seed != 0: pieces sampled from all over the
@@ -160,9 +187,9 @@ struct DevBuf {
     // serial_lo / serial_hi: only pieces created as numbers [lo, hi) (arena_grow); split_serial != 0: every other piece
     // of the buffer from below that serial, the others from it on
     int alloc_big(size_t nbytes, uint64_t spread_seed = 0, size_t spread_factor = 4, uint64_t serial_lo = 0,
-                  uint64_t serial_hi = ~0ull, uint64_t split_serial = 0)
+                  uint64_t serial_hi = ~0ull, uint64_t split_serial = 0, int site = 0)
     {
-        if (!arena_enabled() || nbytes < ARENA_MIN)
+        if (!arena_enabled() || nbytes < ARENA_MIN || !arena_site_enabled(site))
             return alloc(nbytes);
         release();
         int dev = 0;
@@ -186,11 +213,19 @@ struct DevBuf {
         }
         arena_dev = dev;
         void *base = nullptr;
-        hipError_t e = hipMemAddressReserve(&base, span, ARENA_PIECE, nullptr, 0);
+        {
+            const int rc_va = arena_va_alloc(dev, span, &base);
+            if (rc_va != GM_OK) {
+                arena_give(dev, arena);
+                return rc_va;
+            }
+        }
+        hipError_t e = hipSuccess;
         for (size_t i = 0; i < count && e == hipSuccess; ++i) {
             e = hipMemMap(static_cast<char *>(base) + i * ARENA_PIECE, ARENA_PIECE, 0, arena[i].handle, 0);
-            if (e != hipSuccess && i)
-                (void)hipMemUnmap(base, i * ARENA_PIECE);
+            if (e != hipSuccess)
+                for (size_t j = 0; j < i; ++j)
+                    (void)hipMemUnmap(static_cast<char *>(base) + j * ARENA_PIECE, ARENA_PIECE);
         }
         if (e == hipSuccess) {
             hipMemAccessDesc desc{};
@@ -199,12 +234,12 @@ struct DevBuf {
             desc.flags = hipMemAccessFlagsProtReadWrite;
             e = hipMemSetAccess(base, span, &desc, 1);
             if (e != hipSuccess)
-                (void)hipMemUnmap(base, span);
+                for (size_t j = 0; j < count; ++j)
+                    (void)hipMemUnmap(static_cast<char *>(base) + j * ARENA_PIECE, ARENA_PIECE);
         }
         if (e != hipSuccess) {
             gm::set_error("alloc_big(%zu bytes): %s", nbytes, hipGetErrorString(e));
-            if (base)
-                (void)hipMemAddressFree(base, span);
+            arena_va_free(dev, base, span);
             arena_give(dev, arena);
             return e == hipErrorOutOfMemory ? GM_ERR_NOMEM : GM_ERR_HIP;
         }

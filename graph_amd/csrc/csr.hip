@@ -697,7 +697,7 @@ int exclusive_scan_u32(const uint32_t *in, uint32_t *out, uint64_t count)
 
 } // namespace
 
-GM_API int gm_csr_build_device(uint64_t n, uint64_t m, uint64_t d_src, uint64_t d_dst, uint64_t d_weights,
+static int gm_csr_build_device_impl(uint64_t n, uint64_t m, uint64_t d_src, uint64_t d_dst, uint64_t d_weights,
                                int direction, int layout, int device, gm_csr **out)
 {
     GM_CHECK(out && ((d_src && d_dst) || m == 0), GM_ERR_INVALID, "gm_csr_build_device: null argument");
@@ -824,6 +824,17 @@ GM_API int gm_csr_build_device(uint64_t n, uint64_t m, uint64_t d_src, uint64_t 
     }
     *out = hold.release();
     return GM_OK;
+}
+
+GM_API int gm_csr_build_device(uint64_t n, uint64_t m, uint64_t d_src, uint64_t d_dst, uint64_t d_weights, int direction,
+                               int layout, int device, gm_csr **out)
+{
+    struct Site {
+        int prev;
+        Site() : prev(gm::arena_site()) { gm::arena_site() = 1; }
+        ~Site() { gm::arena_site() = prev; }
+    } site;
+    return gm_csr_build_device_impl(n, m, d_src, d_dst, d_weights, direction, layout, device, out);
 }
 
 GM_API int gm_csr_build_host(uint64_t n, uint64_t m, const uint32_t *src, const uint32_t *dst, const float *weights,

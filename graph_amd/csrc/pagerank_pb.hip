@@ -1305,12 +1305,16 @@ __global__ __launch_bounds__(PB_ACC_BLOCK, 8) void pb_hub_kernel(const float *__
     // running sum in the MIDDLE of a long row still mis-rounds what follows it inside its step: at most 4095 terms at
     // half an ulp each.  Walking such steps again in small passes was tried and cost the kernel its registers — the
     // climbs are common in groups of many rows, where they are harmless: a row has a few hundred terms per step.)
+    // groups of 3 ... 16 rows: their rows are long (a row of an 8-row group has ~512 terms per block), so the step is one
+    // block there; groups of more rows take two blocks per step (half the barriers, rows of at most ~500 terms per step).
+    // Measured at scale 26 on one box: one-block steps up to 32 rows 2.86 ms per sweep, none 2.75-2.81.
+    const bool fine_steps = nh <= 16u && (graded & 2u); // GM_PB_HUB_GRADED bit 1 (measurements: 1 = graded first block only)
     auto walk = [&](auto few_tag) {
         constexpr bool FEW = decltype(few_tag)::value;
         {
             const f32x4 cv = hv[0];
             const U16x4 cd = hd[0];
-            for (uint32_t lo = 0, hi = graded ? 64u : STEP; lo < STEP; lo = hi, hi = hi * 2u < STEP ? hi * 2u : STEP) {
+            for (uint32_t lo = 0, hi = (graded & 1u) ? 64u : STEP; lo < STEP; lo = hi, hi = hi * 2u < STEP ? hi * 2u : STEP) {
                 add_block(few_tag, cv, cd, lo, hi);
                 end_step();
             }
@@ -1329,6 +1333,8 @@ __global__ __launch_bounds__(PB_ACC_BLOCK, 8) void pb_hub_kernel(const float *__
                 load_step(q0 + (uint32_t)(k + HS) * STEP, hv[k], hd[k]); // requested before the LDS work of this step
                 add_block(few_tag, cv0, cd0);
                 if constexpr (!FEW) {
+                    if (fine_steps) // few rows in the group: a row has hundreds of terms per block, one block per step
+                        end_step();
                     const f32x4 cv1 = hv[k + 1];
                     const U16x4 cd1 = hd[k + 1];
                     load_step(q0 + (uint32_t)(k + 1 + HS) * STEP, hv[k + 1], hd[k + 1]);
@@ -1493,6 +1499,11 @@ int pb_make_items(PbPlan *pl)
 
 int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
 {
+    struct Site {
+        int prev;
+        Site() : prev(arena_site()) { arena_site() = 2; }
+        ~Site() { arena_site() = prev; }
+    } site_guard;
     const uint32_t n = (uint32_t)csr->n, m_all = (uint32_t)csr->m;
     uint32_t m = m_all; // becomes the number of cold (value-stream) edges once the hot ones are split off
     pl->n_local = n;
@@ -1782,7 +1793,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
             uint32_t Mh = 0;
             GM_HIP(hipMemcpy(&Mh, pl->hbin_v.as<uint32_t>() + cells, 4, hipMemcpyDeviceToHost));
             pl->Mh = Mh;
-            GM_TRY(pl->hot_ent.alloc_big((size_t)Mh * 4, 0x407E));
+            GM_TRY(pl->hot_ent.alloc_big((size_t)Mh * 4, 0x407E, 4, 0, ~0ull, 0, 4));
             GM_HIP(hipMemset(pl->hot_ent.p, 0xFF, (size_t)Mh * 4));
             hipLaunchKernelGGL(pb_hot_fill_kernel, dim3(pb_grid(mh)), dim3(256), 0, 0, hkeys, mh, hstart.as<uint32_t>(),
                                pl->hbin_v.as<uint32_t>(), sb, bin_bits, H, T, pl->hot_ent.as<uint32_t>());
@@ -1893,8 +1904,8 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
         GM_TRY(pl->p2_dst.alloc_spread((size_t)Mv * 2, (size_t)mib << 20, factor, seed + 101));
         GM_TRY(pl->p1_src.alloc_spread((size_t)Mp * 2, (size_t)mib << 20, factor, seed + 202));
     } else { // streamed once per sweep: pieces from all over the arena (arena.hip)
-        GM_TRY(pl->p2_dst.alloc_big((size_t)Mv * 2, 0x9D57));
-        GM_TRY(pl->p1_src.alloc_big((size_t)Mp * 2, 0x9157));
+        GM_TRY(pl->p2_dst.alloc_big((size_t)Mv * 2, 0x9D57, 4, 0, ~0ull, 0, 4));
+        GM_TRY(pl->p1_src.alloc_big((size_t)Mp * 2, 0x9157, 4, 0, ~0ull, 0, 4));
     }
     GM_TRY(pl->chunk_seg.alloc(((size_t)Mp / PB_WBLK + 1) * 4));
     GM_HIP(hipMemset(pl->p1_src.p, 0x7F, (size_t)Mp * 2)); // padding: an unflagged id (any source of the tile will do)
@@ -2208,7 +2219,7 @@ int pb_scratch_create(const PbPlan *pl, PbScratch **out, DevBuf *early)
         };
         for (int k = 0; k < draws && rc == GM_OK && he == hipSuccess; ++k) {
             DevBuf cand;
-            rc = cand.alloc_big(bytes, 0xA11CE5 + 7919ull * (uint64_t)k + pl->NS, 4);
+            rc = cand.alloc_big(bytes, 0xA11CE5 + 7919ull * (uint64_t)k + pl->NS, 4, 0, ~0ull, 0, 8);
             if (rc != GM_OK || draws == 1) {
                 if (rc == GM_OK)
                     sc->vals_raw = std::move(cand);
@@ -2371,7 +2382,7 @@ static void pb_hub_dispatch(const PbPlan *pl, PbScratch *sc, float *x_out, float
         hipLaunchKernelGGL(pb_hub_kernel, dim3(pl->G), dim3(PB_ACC_BLOCK), 0, st, sc->vals, pl->p2_dst.as<uint16_t>(),
                            pl->hub_items.as<PbHubItem>(), pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out,
                            sc->bin_err.as<double>() + pl->B, base, damping, (uint32_t)pb_env("GM_PB_HUB_LONG2", 0x7FFFFFFF),
-                           (uint32_t)pb_env("GM_PB_HUB_LONG4", 0x7FFFFFFF), (uint32_t)pb_env("GM_PB_HUB_GRADED", 1));
+                           (uint32_t)pb_env("GM_PB_HUB_LONG4", 0x7FFFFFFF), (uint32_t)pb_env("GM_PB_HUB_GRADED", 3));
 }
 
 static void pb_hot_dispatch(const PbPlan *pl, PbScratch *sc, const float *x_in, hipStream_t st)

@@ -1,0 +1,7 @@
+#!/bin/bash
+export TMPDIR=/tmp
+for env in "GM_ARENA_LEAK_VA=1" "X=1"; do
+env $env timeout 300 python tools/parity_pagerank.py --scale 21 --mode pb --iterations 5 --tolerance 0 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$env: max rel', d['max_rel_vs_reference'], 'rows over', d['rows_over_1e-5'])"
+done
