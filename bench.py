@@ -238,6 +238,9 @@ def main():
                 dst_region[rank * st:(rank + 1) * st] = src
         ex = PiecewiseExchange(engine, layout, rank, n_local, dev, gather=gather, split_bin=bool(args.bin_pieces),
                                streams=bool(args.piece_streams))
+        if emu:  # the slots of the ranks that do not exist: a typical out_score instead of zeros (rows that sum to 0 are not
+            for buf in ex.x:  # what a sweep of the partitioned job walks)
+                buf.fill_(1.0 / (16.0 * n))
         ex.start(scores)
     elif sparse and not emu:
         sx = SparseExchange(layout, n_local, dev)
@@ -386,7 +389,8 @@ def main():
             "csr_build_s": round(t_build, 3), "final_sweep_error": final_err, "workgroups_per_sweep": engine.tiles, "engine": engine.engine,
             "plan_build_ms": round(plan["plan_build_us"] / 1e3, 2) if plan else None, "plan_rebuild_ms": plan_rebuild_ms,
             "plan_bytes": plan.get("plan_bytes") if plan else None, "scratch_bytes": plan.get("scratch_bytes") if plan else None,
-            "hub_rows_in_reference_order": {k: plan[k] for k in ("hub_in_degree", "hub_rows", "hub_edges", "hub_groups")} if plan else None,
+            "hub_rows_in_reference_order": {k: plan[k] for k in ("hub_in_degree", "hub_rows", "hub_edges", "hub_groups", "long_chain_groups",
+                                                               "long_chain_blocks", "long_chains_fell_back")} if plan else None,
             "hot_sources": plan.get("hot_sources") if plan else None, "hot_tiers": plan.get("hot_tiers") if plan else None,
             "hot_edges": plan.get("hot_edges") if plan else None, "value_entries": plan.get("value_entries") if plan else None,
             "parity": parity,

@@ -92,6 +92,10 @@ struct PbScratch {
     // are region_items[region_off[r] .. region_off[r + 1])
     DevBuf region_items;
     std::vector<uint32_t> region_off;
+    // long chains walked block-parallel (pb_hubchain_*): per block and row the exact sum, the predicted binade, the sums
+    // rounded on four grids; per group and row the running sum after the first block; per group an arrival counter
+    // (self-resetting) and a "prediction failed" flag
+    DevBuf par_exact, par_binade, par_round, par_state, par_ticket, par_fail;
     DevBuf vals_raw; // backing allocation of the value stream
     std::shared_ptr<DevBuf> vals_shared; // GM_PB_VALS_SHARE (measurement): one allocation behind the streams of several engines
     float *vals = nullptr; // f32[Mv] per-edge values, bin-major, segments padded to 4
@@ -100,8 +104,16 @@ struct PbScratch {
     DevBuf bin_err;  // f64[B + G]
     hipStream_t side = nullptr;           // the hub groups run beside the ordinary bins
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t chain = nullptr;          // ... and the long chains' block-parallel walk beside the other hub groups
+    hipEvent_t ev_chain_fork = nullptr, ev_chain_join = nullptr;
     ~PbScratch()
     {
+        if (chain)
+            (void)hipStreamDestroy(chain);
+        if (ev_chain_fork)
+            (void)hipEventDestroy(ev_chain_fork);
+        if (ev_chain_join)
+            (void)hipEventDestroy(ev_chain_join);
         if (vals_shared)
             vals_raw.p = nullptr, vals_raw.bytes = 0;
         if (side)
@@ -141,7 +153,12 @@ struct PbPlan {
     uint64_t hub_edges = 0;
     DevBuf hub_rows;       // u32[n_hub] row id of every hub row, ascending
     DevBuf hub_first;      // u32[G+1]   first hub row (index into hub_rows) of every group
-    DevBuf hub_items;      // PbHubItem[G] longest first
+    DevBuf hub_items;      // PbHubItem[G]: the G_few groups of one or two rows (the long chains) first, each part longest first
+    uint32_t G_few = 0;
+    // the long chains' 4096-entry blocks as one index space (pb_hubchain_*): block b of group g = few_blk_first[g] + b
+    uint32_t few_blocks = 0;
+    DevBuf few_blk_first;  // u32[G_few + 1]
+    DevBuf few_blk_group;  // u32[few_blocks] group (index into hub_items) of every block
     std::vector<uint32_t> hub_first_host;
     double build_ms = 0.0; // wall time of pb_build (device work included)
     uint32_t NT = 0;       // source tiles
@@ -1108,8 +1125,14 @@ __global__ __launch_bounds__(PB_ACC_BLOCK, 8) void pb_hub_kernel(const float *__
                                                               const uint32_t *__restrict__ outdeg, float *__restrict__ scores,
                                                               float *__restrict__ x_out, double *__restrict__ group_err,
                                                               float base, float damping, uint32_t long2, uint32_t long4,
-                                                              uint32_t graded)
+                                                              uint32_t graded, unsigned long long *__restrict__ state_out,
+                                                              const uint32_t *__restrict__ only_failed)
 {
+    // state_out != null: only the group's first block is walked (graded passes), and the rows' running sums are left in
+    // state_out[2 * group-in-launch + row] for the block-parallel walk of the long chains (pb_hubchain_kernel).  only_failed != null: the
+    // groups whose flag is 0 are skipped (the fallback launch behind pb_hubchain_kernel).
+    if (only_failed && only_failed[blockIdx.x] == 0u)
+        return;
     // per step and row: the sum of the step's terms rounded at ulp(S) [0] and at 2 ulp(S) [1], in R replicas
     // (lane mod R) so that the LDS atomics of a wavefront spread over ~64 addresses; three steps in rotation
     // (filled / read / cleared).  Row nh is the dummy row of the padding entries.
@@ -1319,6 +1342,11 @@ __global__ __launch_bounds__(PB_ACC_BLOCK, 8) void pb_hub_kernel(const float *__
                 end_step();
             }
         }
+        if (state_out) { // every wavefront's lane g holds the same S: wavefront 0 writes it
+            if (tid < nh)
+                state_out[2u * blockIdx.x + tid] = S;
+            return;
+        }
         const uint32_t q1 = h_first + STEP; // the steps proper start at the second block
         load_step(q1, hv[0], hd[0]);
         load_step(q1 + STEP, hv[1], hd[1]);
@@ -1353,6 +1381,8 @@ __global__ __launch_bounds__(PB_ACC_BLOCK, 8) void pb_hub_kernel(const float *__
         walk(std::true_type{});
     else
         walk(std::false_type{});
+    if (state_out)
+        return;
     // epilogue of the reference for the group's rows (page_rank.rs:149-159); S is on the f32 grid: the
     // conversion is exact
     double err = 0.0;
@@ -1361,6 +1391,226 @@ __global__ __launch_bounds__(PB_ACC_BLOCK, 8) void pb_hub_kernel(const float *__
     const double total = block_sum<double, PB_ACC_BLOCK / kWave>(err, red);
     if (tid == 0)
         group_err[item.group] = total;
+}
+
+// ---- the long chains in parallel ------------------------------------------------------------------------------------
+// A group of one or two rows (a row of 854,315 terms at RMAT scale 26) is a chain of up to 209 steps that pb_hub_kernel
+// walks one after the other: 2.9 us a step — the arithmetic of one 4096-entry block on one CU — 0.6 ms in all, the whole
+// sweep of the rank that owns the row in an 8-way partition.  What a step needs from its predecessors is only the BINADE
+// of the running sum, and the exact prefix sum of the raw terms predicts it: the reference's drift is < 0.1 % of the sum.
+// So, with one workgroup per BLOCK:
+//   pb_hubchain_exact_kernel  per block and row the exact sum of the terms (64-bit fixed point);
+//   pb_hub_kernel(state_out)  the group's first block in graded passes, as before: the running sum after it;
+//   pb_hubchain_kernel        block b: running sum after block 0 + exact sums of blocks 1..b-1 = predicted sum, hence
+//                             binade; the block's terms rounded on the grids of that binade - 1, the binade, + 1, + 2 —
+//                             exactly what add_block computes for the grid of the running sum.  The group's last block to
+//                             arrive (a ticket) then runs end_step's arithmetic over the blocks with the sums of the grid
+//                             that MATCHES the running sum it tracks: bit for bit what the sequential walk computes.
+// The chain is read twice instead of once, by a few hundred CUs instead of one.  (Tried and measured: one kernel per phase,
+// five launches, each waiting ~70 us for its turn behind the accumulate kernel's workgroups; one workgroup per GROUP doing
+// all phases, 1.7x slower than the sequential walk — a block's arithmetic on four grids is what a CU needs 2.9 us for.)
+// If the running sum ever leaves the predicted binades the group's flag is raised and pb_hub_kernel walks that group the
+// old way (only_failed).
+constexpr uint32_t PB_CHAIN_WG = 256;    // threads of the per-block workgroups
+constexpr uint32_t PB_CHAIN_STAGE = 128; // blocks staged in LDS at a time by the walk
+
+struct PbChainBlock {
+    uint32_t group, b, nb, nh, q0, q1; // group (index into items), block within the group, the group's blocks and rows, entries
+};
+
+__device__ __forceinline__ PbChainBlock pb_chain_block(const PbHubItem *__restrict__ items, const uint32_t *__restrict__ blk_first,
+                                                       const uint32_t *__restrict__ blk_group)
+{
+    constexpr uint32_t STEP = PB_ACC_BLOCK * PB_VEC;
+    PbChainBlock r;
+    r.group = blk_group[blockIdx.x];
+    r.b = blockIdx.x - blk_first[r.group];
+    const PbHubItem item = items[r.group];
+    r.nh = item.nh;
+    r.nb = (item.q1 - item.q0 + STEP - 1) / STEP;
+    r.q0 = item.q0 + r.b * STEP;
+    r.q1 = (item.q1 - r.q0) < STEP ? item.q1 : r.q0 + STEP;
+    return r;
+}
+
+// sum over the workgroup (PB_CHAIN_WG threads); red: one slot per wavefront
+__device__ __forceinline__ unsigned long long pb_chain_sum(unsigned long long v, unsigned long long *red)
+{
+    v = wave_sum((uint64_t)v);
+    __syncthreads();
+    if ((threadIdx.x & (kWave - 1)) == 0)
+        red[threadIdx.x / kWave] = v;
+    __syncthreads();
+    unsigned long long t = 0ull;
+#pragma unroll
+    for (uint32_t w = 0; w < PB_CHAIN_WG / kWave; ++w)
+        t += red[w];
+    return t;
+}
+
+__global__ __launch_bounds__(PB_CHAIN_WG) void pb_hubchain_exact_kernel(const float *__restrict__ vals, const uint16_t *__restrict__ p2_dst,
+                                                                        const PbHubItem *__restrict__ items,
+                                                                        const uint32_t *__restrict__ blk_first,
+                                                                        const uint32_t *__restrict__ blk_group,
+                                                                        unsigned long long *__restrict__ exact)
+{
+    __shared__ unsigned long long red[PB_CHAIN_WG / kWave];
+    const PbChainBlock r = pb_chain_block(items, blk_first, blk_group);
+    if (r.b == 0)
+        return; // walked by pb_hub_kernel
+    unsigned long long s0 = 0ull, s1 = 0ull;
+    for (uint32_t q = r.q0 + threadIdx.x * PB_VEC; q < r.q1; q += PB_CHAIN_WG * PB_VEC) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(vals + q);
+        const u32x2 raw = *reinterpret_cast<const u32x2 *>(p2_dst + q);
+        const unsigned long long f0 = pb_to_fix(v.x), f1 = pb_to_fix(v.y), f2 = pb_to_fix(v.z), f3 = pb_to_fix(v.w);
+        const uint32_t l0 = raw.x & 0xFFFFu, l1 = raw.x >> 16, l2 = raw.y & 0xFFFFu, l3 = raw.y >> 16;
+        s0 += (l0 == 0u ? f0 : 0ull) + (l1 == 0u ? f1 : 0ull) + (l2 == 0u ? f2 : 0ull) + (l3 == 0u ? f3 : 0ull);
+        s1 += (l0 == 1u ? f0 : 0ull) + (l1 == 1u ? f1 : 0ull) + (l2 == 1u ? f2 : 0ull) + (l3 == 1u ? f3 : 0ull);
+    }
+    s0 = pb_chain_sum(s0, red);
+    s1 = pb_chain_sum(s1, red);
+    if (threadIdx.x == 0)
+        exact[2u * blockIdx.x] = s0, exact[2u * blockIdx.x + 1] = s1;
+}
+
+__global__ __launch_bounds__(PB_CHAIN_WG) void pb_hubchain_kernel(const float *__restrict__ vals, const uint16_t *__restrict__ p2_dst,
+                                                                  const PbHubItem *__restrict__ items, const uint32_t *__restrict__ blk_first,
+                                                                  const uint32_t *__restrict__ blk_group,
+                                                                  const uint32_t *__restrict__ hub_rows,
+                                                                  const unsigned long long *__restrict__ exact,
+                                                                  const unsigned long long *__restrict__ state, int *__restrict__ binade,
+                                                                  unsigned long long *__restrict__ rounded, uint32_t *__restrict__ tickets,
+                                                                  uint32_t *__restrict__ fail, const uint32_t *__restrict__ outdeg,
+                                                                  float *__restrict__ scores, float *__restrict__ x_out,
+                                                                  double *__restrict__ group_err, float base, float damping)
+{
+    __shared__ unsigned long long red[PB_CHAIN_WG / kWave];
+    __shared__ unsigned long long st_rq[PB_CHAIN_STAGE][2][4];
+    __shared__ int st_bn[PB_CHAIN_STAGE][2];
+    __shared__ bool is_last;
+    const uint32_t tid = threadIdx.x;
+    const PbChainBlock r = pb_chain_block(items, blk_first, blk_group);
+    const uint32_t first = blockIdx.x - r.b; // the group's block 0 in the launch's index space
+    if (r.b) {
+        // predicted running sum before this block
+        unsigned long long p0 = 0ull, p1 = 0ull;
+        for (uint32_t i = 1 + tid; i < r.b; i += PB_CHAIN_WG)
+            p0 += exact[2u * (first + i)], p1 += exact[2u * (first + i) + 1];
+        p0 = pb_chain_sum(p0, red) + state[2u * r.group];
+        p1 = pb_chain_sum(p1, red) + state[2u * r.group + 1];
+        const int e0 = p0 >= (1ull << 24) ? 63 - __clzll((long long)p0) : -1;
+        const int e1 = r.nh > 1 && p1 >= (1ull << 24) ? 63 - __clzll((long long)p1) : -1;
+        // the block's terms of each row on the four grids around the prediction
+        unsigned long long a[2][4] = {{0ull, 0ull, 0ull, 0ull}, {0ull, 0ull, 0ull, 0ull}};
+        auto term = [&](float v, uint32_t slot) {
+#pragma unroll
+            for (int row = 0; row < 2; ++row) {
+                const int ee = row ? e1 : e0;
+                const float val = (slot == (uint32_t)row && ee >= 0) ? v : 0.0f;
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const int sh = ee - 1 + h - 23;
+                    const float t = val * __uint_as_float((uint32_t)(127 + 62 - sh) << 23);
+                    a[row][h] += t < 2147483648.0f
+                                     ? (unsigned long long)(uint32_t)__builtin_rintf(t) << sh
+                                     // more than 2^31 units of the grid: the general code of pb_hub_kernel (slow_term)
+                                     : pb_to_fix(__builtin_rintf(t) * __uint_as_float((uint32_t)(127 + sh - 62) << 23));
+                }
+            }
+        };
+        for (uint32_t q = r.q0 + tid * PB_VEC; q < r.q1; q += PB_CHAIN_WG * PB_VEC) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(vals + q);
+            const u32x2 raw = *reinterpret_cast<const u32x2 *>(p2_dst + q);
+            term(v.x, raw.x & 0xFFFFu), term(v.y, raw.x >> 16), term(v.z, raw.y & 0xFFFFu), term(v.w, raw.y >> 16);
+        }
+#pragma unroll
+        for (int row = 0; row < 2; ++row)
+#pragma unroll
+            for (int h = 0; h < 4; ++h)
+                a[row][h] = pb_chain_sum(a[row][h], red);
+        if (tid == 0) {
+#pragma unroll
+            for (int row = 0; row < 2; ++row)
+#pragma unroll
+                for (int h = 0; h < 4; ++h)
+                    rounded[8u * blockIdx.x + 4 * row + h] = a[row][h];
+        }
+        if (tid < 2)
+            binade[2u * blockIdx.x + tid] = tid ? e1 : e0;
+    }
+    // the group's last block to arrive walks the chain (hand-off as in pb_accum_kernel: agent-scope release / acquire)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t prev = atomicAdd(&tickets[r.group], 1u);
+        is_last = prev == r.nb - 1u;
+        if (is_last) {
+            st_agent(&tickets[r.group], 0u); // ready for the next sweep
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+    }
+    __syncthreads();
+    if (!is_last)
+        return;
+    const bool mine = tid < r.nh;
+    unsigned long long S = mine ? state[2u * r.group + tid] : 0ull;
+    int e = S ? 63 - __clzll((long long)S) : -1;
+    bool bad = false;
+    for (uint32_t c0 = 1; c0 < r.nb; c0 += PB_CHAIN_STAGE) {
+        const uint32_t cn = (r.nb - c0) < PB_CHAIN_STAGE ? (r.nb - c0) : PB_CHAIN_STAGE;
+        __syncthreads();
+        for (uint32_t i = tid; i < cn * 8u; i += PB_CHAIN_WG)
+            (&st_rq[0][0][0])[i] = rounded[8u * (first + c0) + i];
+        for (uint32_t i = tid; i < cn * 2u; i += PB_CHAIN_WG)
+            (&st_bn[0][0])[i] = binade[2u * (first + c0) + i];
+        __syncthreads();
+        if (mine && !bad)
+            for (uint32_t i = 0; i < cn; ++i) { // end_step of pb_hub_kernel, word for word, on the sums of the matching grid
+                const int eb = st_bn[i][tid], d = e - eb;
+                if (e < 24 || eb < 0 || d < -1 || d > 1) { // the sum left the predicted binades
+                    bad = true;
+                    break;
+                }
+                const unsigned long long c1 = st_rq[i][tid][1], c2 = st_rq[i][tid][2];
+                const unsigned long long A = d < 0 ? st_rq[i][tid][0] : d == 0 ? c1 : c2;
+                const unsigned long long B = d < 0 ? c1 : d == 0 ? c2 : st_rq[i][tid][3];
+                const unsigned long long top = 1ull << (e + 1);
+                if (S + A < top) {
+                    S += A;
+                } else {
+                    const unsigned long long rem = S + A - top;
+                    S = top + __double2ull_rn((double)B * ((double)rem / (double)A));
+                }
+                e = -1;
+                if (S) {
+                    int ee = 63 - __clzll((long long)S);
+                    if (ee >= 24) {
+                        const int sh = ee - 23;
+                        const unsigned long long half = 1ull << (sh - 1), rr = S & ((1ull << sh) - 1ull);
+                        unsigned long long qv = S >> sh;
+                        qv += (rr > half || (rr == half && (qv & 1ull))) ? 1ull : 0ull;
+                        S = qv << sh;
+                        ee = 63 - __clzll((long long)S);
+                    }
+                    e = ee;
+                }
+            }
+    }
+    const unsigned long long any_bad = pb_chain_sum(bad ? 1ull : 0ull, red);
+    if (tid == 0)
+        fail[r.group] = any_bad ? 1u : 0u;
+    if (any_bad)
+        return; // pb_hub_kernel (only_failed) walks the group the sequential way
+    double err = 0.0;
+    if (mine)
+        err = pr_finalize(hub_rows[items[r.group].row0 + tid], (float)S * PB_FIX_INV, base, damping, outdeg, scores, x_out);
+    if (tid < kWave) {
+        const double total = wave_sum(err);
+        if (tid == 0)
+            group_err[items[r.group].group] = total;
+    }
 }
 
 __global__ __launch_bounds__(1024) void pb_err_kernel(const double *__restrict__ bin_err, uint32_t B, double *__restrict__ err_out)
@@ -1491,9 +1741,27 @@ int pb_make_items(PbPlan *pl)
         hubs.push_back(PbHubItem{bv[pl->B + g], bv[pl->B + g + 1], pl->hub_first_host[g + 1] - pl->hub_first_host[g],
                                  pl->hub_first_host[g], g});
     std::stable_sort(hubs.begin(), hubs.end(), [](const PbHubItem &a, const PbHubItem &c) { return a.q1 - a.q0 > c.q1 - c.q0; });
+    std::stable_partition(hubs.begin(), hubs.end(), [](const PbHubItem &a) { return a.nh <= 2u; }); // each part longest first
+    pl->G_few = 0;
+    for (const PbHubItem &h : hubs)
+        pl->G_few += h.nh <= 2u ? 1u : 0u;
     GM_TRY(pl->hub_items.alloc((hubs.size() ? hubs.size() : 1) * sizeof(PbHubItem)));
     if (!hubs.empty())
         GM_HIP(hipMemcpy(pl->hub_items.p, hubs.data(), hubs.size() * sizeof(PbHubItem), hipMemcpyHostToDevice));
+    {
+        std::vector<uint32_t> first(pl->G_few + 1, 0u), group;
+        for (uint32_t g = 0; g < pl->G_few; ++g) {
+            const uint32_t nb = (hubs[g].q1 - hubs[g].q0 + PB_ACC_BLOCK * PB_VEC - 1) / (PB_ACC_BLOCK * PB_VEC);
+            first[g + 1] = first[g] + nb;
+            group.insert(group.end(), nb, g);
+        }
+        pl->few_blocks = first[pl->G_few];
+        GM_TRY(pl->few_blk_first.alloc(first.size() * 4));
+        GM_HIP(hipMemcpy(pl->few_blk_first.p, first.data(), first.size() * 4, hipMemcpyHostToDevice));
+        GM_TRY(pl->few_blk_group.alloc((group.size() ? group.size() : 1) * 4));
+        if (!group.empty())
+            GM_HIP(hipMemcpy(pl->few_blk_group.p, group.data(), group.size() * 4, hipMemcpyHostToDevice));
+    }
     return GM_OK;
 }
 
@@ -2265,14 +2533,28 @@ int pb_scratch_create(const PbPlan *pl, PbScratch **out, DevBuf *early)
     if ((rc = sc->vals_raw.p ? GM_OK : sc->vals_raw.alloc((size_t)(pl->Mv ? pl->Mv : 4) * 4 + slack)) ||
         (rc = sc->partials.alloc((size_t)(pl->slots ? pl->slots : 1) * pl->Racc * 8)) ||
         (rc = sc->tickets.alloc((size_t)pl->B * 4)) || (rc = sc->bin_err.alloc(((size_t)pl->B + pl->G) * 8)) ||
-        (rc = sc->hot_x.alloc(((size_t)pl->H * pl->T + 4) * 4))) {
+        (rc = sc->hot_x.alloc(((size_t)pl->H * pl->T + 4) * 4)) ||
+        (pl->few_blocks && ((rc = sc->par_exact.alloc((size_t)pl->few_blocks * 2 * 8)) ||
+                            (rc = sc->par_binade.alloc((size_t)pl->few_blocks * 2 * 4)) ||
+                            (rc = sc->par_round.alloc((size_t)pl->few_blocks * 2 * 4 * 8)) ||
+                            (rc = sc->par_state.alloc((size_t)pl->G_few * 2 * 8)) || (rc = sc->par_ticket.alloc((size_t)pl->G_few * 4)) ||
+                            (rc = sc->par_fail.alloc((size_t)pl->G_few * 4))))) {
         delete sc;
         return rc;
     }
     sc->vals = sc->vals_raw.as<float>();
     hipError_t e = hipMemset(sc->tickets.p, 0, (size_t)pl->B * 4);
+    if (e == hipSuccess && sc->par_ticket.p)
+        e = hipMemset(sc->par_ticket.p, 0, sc->par_ticket.bytes);
     if (e == hipSuccess)
         e = hipMemset(sc->vals_raw.p, 0, sc->vals_raw.bytes);
+    if (e == hipSuccess && pl->few_blocks > pl->G_few) { // the long chains' own stream
+        e = hipStreamCreateWithFlags(&sc->chain, hipStreamNonBlocking);
+        if (e == hipSuccess)
+            e = hipEventCreateWithFlags(&sc->ev_chain_fork, hipEventDisableTiming);
+        if (e == hipSuccess)
+            e = hipEventCreateWithFlags(&sc->ev_chain_join, hipEventDisableTiming);
+    }
     if (e == hipSuccess && pl->G) { // the hub groups' own stream
         e = hipStreamCreateWithFlags(&sc->side, hipStreamNonBlocking);
         if (e == hipSuccess)
@@ -2307,8 +2589,16 @@ void pb_plan_info(const PbPlan *pl, const PbScratch *sc, uint64_t *info, uint32_
         plan_bytes += b->bytes;
     const uint64_t scratch_bytes = sc ? sc->vals_raw.bytes + sc->partials.bytes + sc->tickets.bytes + sc->bin_err.bytes +
                                             sc->hot_x.bytes : 0;
+    // long chains whose parallel walk fell back to the sequential one in the last sweep (a blocking read-back: diagnostics)
+    uint64_t fell_back = 0;
+    if (sc && sc->par_fail.p && pl->G_few) {
+        std::vector<uint32_t> f(pl->G_few);
+        if (hipMemcpy(f.data(), sc->par_fail.p, (size_t)pl->G_few * 4, hipMemcpyDeviceToHost) == hipSuccess)
+            for (uint32_t x : f)
+                fell_back += x ? 1u : 0u;
+    }
     const uint64_t v[] = {plan_bytes, (uint64_t)(pl->build_ms * 1000.0), pl->n_hub, pl->hub_edges, pl->hub_deg, pl->Htot,
-                          pl->Mv, pl->Mh, scratch_bytes, pl->B, pl->NT, pl->NS, pl->G, pl->T};
+                          pl->Mv, pl->Mh, scratch_bytes, pl->B, pl->NT, pl->NS, pl->G, pl->T, pl->G_few, pl->few_blocks, fell_back};
     for (uint32_t i = 0; i < count; ++i)
         info[i] = i < sizeof(v) / sizeof(v[0]) ? v[i] : 0;
 }
@@ -2378,11 +2668,41 @@ static void pb_accum_dispatch(const PbPlan *pl, PbScratch *sc, const PbItem *ite
 static void pb_hub_dispatch(const PbPlan *pl, PbScratch *sc, float *x_out, float *scores, const uint32_t *outdeg, float base,
                             float damping, hipStream_t st)
 {
-    if (pl->G)
-        hipLaunchKernelGGL(pb_hub_kernel, dim3(pl->G), dim3(PB_ACC_BLOCK), 0, st, sc->vals, pl->p2_dst.as<uint16_t>(),
-                           pl->hub_items.as<PbHubItem>(), pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out,
-                           sc->bin_err.as<double>() + pl->B, base, damping, (uint32_t)pb_env("GM_PB_HUB_LONG2", 0x7FFFFFFF),
-                           (uint32_t)pb_env("GM_PB_HUB_LONG4", 0x7FFFFFFF), (uint32_t)pb_env("GM_PB_HUB_GRADED", 3));
+    const uint32_t long2 = (uint32_t)pb_env("GM_PB_HUB_LONG2", 0x7FFFFFFF), long4 = (uint32_t)pb_env("GM_PB_HUB_LONG4", 0x7FFFFFFF);
+    const uint32_t graded = (uint32_t)pb_env("GM_PB_HUB_GRADED", 3);
+    double *gerr = sc->bin_err.as<double>() + pl->B;
+    // the long chains (groups of one or two rows) block-parallel on a stream of their own, beside the other groups: see
+    // pb_hubchain_kernel (GM_PB_HUB_PAR=0: the sequential walk, all groups in one launch)
+    const bool par = pl->G_few && pl->few_blocks > pl->G_few && sc->chain && pb_env("GM_PB_HUB_PAR", 1) && long2 == 0x7FFFFFFFu &&
+                     long4 == 0x7FFFFFFFu;
+    const uint32_t first = par ? pl->G_few : 0u;
+    if (par) {
+        hipStream_t cs = sc->chain;
+        const PbHubItem *items = pl->hub_items.as<PbHubItem>();
+        (void)hipEventRecord(sc->ev_chain_fork, st);
+        (void)hipStreamWaitEvent(cs, sc->ev_chain_fork, 0);
+        hipLaunchKernelGGL(pb_hubchain_exact_kernel, dim3(pl->few_blocks), dim3(PB_CHAIN_WG), 0, cs, sc->vals, pl->p2_dst.as<uint16_t>(),
+                           items, pl->few_blk_first.as<uint32_t>(), pl->few_blk_group.as<uint32_t>(),
+                           sc->par_exact.as<unsigned long long>());
+        hipLaunchKernelGGL(pb_hub_kernel, dim3(pl->G_few), dim3(PB_ACC_BLOCK), 0, cs, sc->vals, pl->p2_dst.as<uint16_t>(), items,
+                           pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr, base, damping, long2, long4, graded,
+                           sc->par_state.as<unsigned long long>(), (const uint32_t *)nullptr);
+        hipLaunchKernelGGL(pb_hubchain_kernel, dim3(pl->few_blocks), dim3(PB_CHAIN_WG), 0, cs, sc->vals, pl->p2_dst.as<uint16_t>(), items,
+                           pl->few_blk_first.as<uint32_t>(), pl->few_blk_group.as<uint32_t>(), pl->hub_rows.as<uint32_t>(),
+                           sc->par_exact.as<unsigned long long>(), sc->par_state.as<unsigned long long>(), sc->par_binade.as<int>(),
+                           sc->par_round.as<unsigned long long>(), sc->par_ticket.as<uint32_t>(), sc->par_fail.as<uint32_t>(), outdeg,
+                           scores, x_out, gerr, base, damping);
+        hipLaunchKernelGGL(pb_hub_kernel, dim3(pl->G_few), dim3(PB_ACC_BLOCK), 0, cs, sc->vals, pl->p2_dst.as<uint16_t>(), items,
+                           pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr, base, damping, long2, long4, graded,
+                           (unsigned long long *)nullptr, sc->par_fail.as<uint32_t>());
+        (void)hipEventRecord(sc->ev_chain_join, cs);
+    }
+    if (pl->G > first)
+        hipLaunchKernelGGL(pb_hub_kernel, dim3(pl->G - first), dim3(PB_ACC_BLOCK), 0, st, sc->vals, pl->p2_dst.as<uint16_t>(),
+                           pl->hub_items.as<PbHubItem>() + first, pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr, base,
+                           damping, long2, long4, graded, (unsigned long long *)nullptr, (const uint32_t *)nullptr);
+    if (par)
+        (void)hipStreamWaitEvent(st, sc->ev_chain_join, 0);
 }
 
 static void pb_hot_dispatch(const PbPlan *pl, PbScratch *sc, const float *x_in, hipStream_t st)

@@ -170,3 +170,38 @@ def test_random_small_graphs_through_the_hub_path(P, monkeypatch):
         assert worst_of[4] <= 3e-5, (case, n, m, worst_of)
     print(f"40 random graphs through the hub path (threshold 64): worst row after one sweep {worst:.2e} from the sequential sums, "
           f"after four sweeps {worst4:.2e}")
+
+
+@pytest.mark.parametrize("hubs,sources,kind", [(1, 1 << 20, "lognormal"), (1, (1 << 20) + 1, "ascending"), (2, 300_000, "descending"),
+                                               (2, 300_000, "one giant last"), (1, 1 << 20, "one giant first"), (2, 5000, "lognormal")])
+def test_long_chains_walked_in_parallel_give_the_bits_of_the_sequential_walk(P, monkeypatch, hubs, sources, kind):
+    """Groups of one or two rows are walked block-parallel (pb_hubchain_kernel: exact prefix sums predict the binade of the
+    running sum, every block is rounded on the grids around the prediction at once, one short sequential pass picks the
+    grid that matches): the same bits as pb_hub_kernel's walk, one step after the other (GM_PB_HUB_PAR=0)."""
+    monkeypatch.setenv("GM_PB_NOCACHE", "1")
+    rng = np.random.default_rng(hubs * 7919 + sources)
+    n, s, d = _star(hubs, sources)
+    x0 = np.full(n, np.inf, np.float32)
+    x0[hubs:] = TERMS[kind](sources, rng).astype(np.float32)
+    scores0 = np.full(n, np.float32(1.0) / np.float32(n), np.float32)
+    monkeypatch.setenv("GM_PB_HUB_PAR", "0")
+    seq_walk, seq, info, _ = _sweep(P, n, s, d, x0, scores0)
+    monkeypatch.setenv("GM_PB_HUB_PAR", "1")
+    par_walk, _, _, _ = _sweep(P, n, s, d, x0, scores0)
+    assert info["hub_rows"] == hubs
+    assert np.array_equal(par_walk, seq_walk)
+    rel = np.abs(par_walk[:hubs].astype(np.float64) - seq[:hubs]) / seq[:hubs]
+    assert rel.max() <= 1e-5
+
+
+def test_rmat_fixed_point_is_the_same_with_the_parallel_and_the_sequential_walk(P, oracle, monkeypatch):
+    scale, n = 20, 1 << 20
+    s, d = oracle.rmat_edges(scale, seed=42)
+    g = P.DirectedCsrGraph(P.DeviceCsr.from_edges(n, s, d, None, P.Direction.Outgoing, P.CsrLayout.Sorted),
+                           P.DeviceCsr.from_edges(n, s, d, None, P.Direction.Incoming, P.CsrLayout.Sorted), P.CsrLayout.Sorted)
+    cfg = P.PageRankConfig(60, 0.0, 0.85)
+    monkeypatch.setenv("GM_PB_HUB_PAR", "0")
+    a, _, ea = P.page_rank(g, cfg, P.PageRankMode.JacobiPB)
+    monkeypatch.setenv("GM_PB_HUB_PAR", "1")
+    b, _, eb = P.page_rank(g, cfg, P.PageRankMode.JacobiPB)
+    assert np.array_equal(a, b) and ea == eb
