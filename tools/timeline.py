@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Start / end of every kernel dispatch of the LAST sweeps of a rocprofv3 --kernel-trace run (rocpd sqlite):
+"""Start / end of every kernel dispatch of a few sweeps from the MIDDLE of a rocprofv3 --kernel-trace run (rocpd sqlite):
 usage: timeline.py <dir-or-db> [sweeps=2]  ->  per dispatch: start relative to the sweep's first kernel, duration, kernel"""
 import glob, os, sqlite3, sys
 
@@ -15,8 +15,8 @@ rows = list(c.execute(f"select name, start, end{''.join(', ' + k for k in extra)
 starts = [i for i, r in enumerate(rows) if "pb_bin_kernel" in r[0]]
 if len(starts) < sweeps + 1:
     sys.exit("not enough sweeps in the trace")
-lo = starts[-sweeps - 1]
-hi = starts[-1]
+mid = len(starts) // 2
+lo, hi = starts[mid], starts[mid + sweeps] if mid + sweeps < len(starts) else len(rows)
 t0 = rows[lo][1]
 for r in rows[lo:hi]:
     if "pb_bin_kernel" in r[0]:
