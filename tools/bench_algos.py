@@ -112,9 +112,9 @@ def main():
             ooff, otgt, _ = g_out.host()
             ioff, itgt, _ = g_in.host()
             ref = O.wcc(ooff, otgt, ioff, itgt, O.AFFOREST, native=True)  # the checker: sequential
-            timed, cpu_s = O.wcc_afforest_timed(ooff, otgt, ioff, itgt, cores)  # the baseline: the reference's threading
+            thr_out, cpu_s = O.wcc_afforest_timed(ooff, otgt, ioff, itgt, cores)  # the baseline: the reference's threading
             rec["parity"] = {"bit_exact_vs_oracle": bool(np.array_equal(ref, comp)), "oracle": "orc_wcc AFFOREST (wcc.rs:158-301)",
-                             "threaded_baseline_eq_oracle": bool(np.array_equal(timed, ref))}
+                             "threaded_baseline_eq_oracle": bool(np.array_equal(thr_out, ref))}
             rec["cpu_baseline"] = {"value": m / cpu_s, "unit": "edges/s", "seconds": cpu_s, "cores": cores, "kind": "port",
                                    "sample": "one full run of orc_wcc_afforest_timed on the same graph: 16384-node chunks from an "
                                              "atomic cursor, CAS union, parallel compress (wcc.rs:186-301, afforest.rs:22-53)"}
@@ -144,13 +144,13 @@ def main():
         if O is not None:
             off, tgt, wv = g_out.host()
             ref = O.delta_stepping(off, tgt, wv, start, 0.1, native=True)  # the checker: sequential
-            timed, cpu_s = O.delta_stepping_timed(off, tgt, wv, start, 0.1, cores)  # the baseline: thread-local bins
+            thr_out, cpu_s = O.delta_stepping_timed(off, tgt, wv, start, 0.1, cores)  # the baseline: thread-local bins
             mis = O.stale_check_misfires(ref, 0.1)
             neq = int((ref.view(np.uint32) != dist.view(np.uint32)).sum())
             rec["parity"] = {"bit_exact_vs_oracle": neq == 0, "nodes_differing": neq,
                              "stale_check_misfire_candidates": int(mis.sum()),
                              "oracle": "orc_delta_stepping (sssp.rs:38-204)"}
-            rec["parity"]["threaded_baseline_differs_on"] = int((timed.view(np.uint32) != ref.view(np.uint32)).sum())
+            rec["parity"]["threaded_baseline_differs_on"] = int((thr_out.view(np.uint32) != ref.view(np.uint32)).sum())
             rec["cpu_baseline"] = {"value": relaxed / cpu_s, "unit": "relaxed edges/s", "seconds": cpu_s, "cores": cores,
                                    "kind": "port", "sample": "one full run of orc_delta_stepping_timed on the same graph: one set of "
                                                              "bins per thread, 64-node batches of the shared frontier, CAS on the "
