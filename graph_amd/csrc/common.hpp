@@ -513,7 +513,7 @@ struct WccScratch {
     DevBuf labels; // u32[n] of gm_wcc_afforest / gm_wcc_baseline
 };
 struct SsspScratch {
-    DevBuf dist, flags, wmin, hflags, settled, ctrl, chunks, queues;
+    DevBuf dist, flags, wmin, hflags, settled, done, ctrl, chunks, queues;
     PinnedBuf hctrl;
     size_t items = 0; // capacity of `chunks` in work items; 0: not (completely) allocated
 };

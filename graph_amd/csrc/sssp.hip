@@ -70,7 +70,7 @@ enum : int { R_ALL = 0, R_LIGHT = 1, R_HEAVY = 2 };
 constexpr int SSSP_MLP = 4;
 __device__ __forceinline__ void relax_range(const uint32_t *__restrict__ tgt, const float *__restrict__ w, uint32_t *dist,
                                             uint32_t *flags, uint32_t *wmin, float du, uint32_t first, uint32_t end,
-                                            uint32_t step, uint32_t thr, int which, const uint32_t *__restrict__ settled,
+                                            uint32_t step, uint32_t thr, int which, const uint32_t *__restrict__ final_bits,
                                             RelaxOut &ro)
 {
     for (uint32_t i = first; i < end; i += step * SSSP_MLP) {
@@ -84,14 +84,17 @@ __device__ __forceinline__ void relax_range(const uint32_t *__restrict__ tgt, co
             if (which == R_LIGHT ? nb[k] > thr : which == R_HEAVY ? nb[k] <= thr : false)
                 nb[k] = 0xFFFFFFFFu;
         }
-        if (which == R_HEAVY && settled) {
-            // a heavy candidate is beyond the threshold, and a target that was ever taken up had a distance at or below
-            // it: nothing to improve.  One bit per node (2 MB at scale 24: it stays in L2) instead of a probe of the
-            // 64 MB distance vector — after the phase that takes up most of the graph nearly every target is settled.
+        if (final_bits) {
+            // One bit per node (2 MB at scale 24: it stays in L2) instead of a probe of the 64 MB distance vector, for
+            // targets whose distance is known to be final:
+            // * heavy round (`settled`): a heavy candidate is beyond the threshold, and a target that was ever taken up had
+            //   a distance at or below it — after the phase that takes up most of the graph nearly every target is settled;
+            // * light round (`done` = the nodes taken up in EARLIER phases, see sssp_round_kernel): their distances are
+            //   final and at or below the previous threshold, every source of the running phase lies beyond it.
             uint32_t bits[SSSP_MLP];
 #pragma unroll
             for (int k = 0; k < SSSP_MLP; ++k)
-                bits[k] = nb[k] != 0xFFFFFFFFu ? settled[t[k] >> 5] : 0u;
+                bits[k] = nb[k] != 0xFFFFFFFFu ? final_bits[t[k] >> 5] : 0u;
 #pragma unroll
             for (int k = 0; k < SSSP_MLP; ++k)
                 if ((bits[k] >> (t[k] & 31u)) & 1u)
@@ -110,7 +113,10 @@ __device__ __forceinline__ void relax_range(const uint32_t *__restrict__ tgt, co
 enum : uint32_t { C_AGAIN = 0, C_FAR = 1, C_BAD = 2, C_THR = 3, C_DONE = 4, C_ROUND = 5, C_ADVANCES = 6,
                   C_WORK = 7 /* edges streamed so far / 64: drives the schedule */, C_HEAVY = 8 /* 1: this round is a phase's heavy round */,
                   C_WIDTH = 9 /* f32 bits: current threshold step */,
-                  C_MARK = 10 /* C_WORK at the last advance */, C_TICKET = 11 /* workgroups of sssp_finish_kernel done */ };
+                  C_MARK = 10 /* C_WORK at the last advance */, C_TICKET = 11 /* workgroups of sssp_finish_kernel done */,
+                  C_SNAP = 12 /* 1: the threshold has just moved: the next round copies `settled` into `done` */,
+                  C_NDONE = 13 /* bits set in `done` (as of the last completed snapshot: a lower bound) */,
+                  C_NCOUNT = 14 /* ... of the snapshot being taken */ };
 
 // The work-item queue of a round is SSSP_QUEUES sub-queues, node group g appending to sub-queue g % SSSP_QUEUES:
 // each has its own 64-bit counter (low half: items queued this round, high half: out-edges of the nodes taken up — the
@@ -147,9 +153,10 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_round_kernel(const uint32_t *
                                                                 const uint32_t *__restrict__ tgt,
                                                                 const float *__restrict__ w, uint32_t *dist,
                                                                 uint32_t *flags, uint32_t *wmin, uint32_t *hflags,
-                                                                uint32_t *settled, uint32_t nwords,
-                                                                uint2 *__restrict__ chunks, QueueState *__restrict__ qs,
-                                                                uint32_t *ctrl, uint32_t chunk_edges, uint32_t coop)
+                                                                uint32_t *settled, uint32_t *done, uint32_t done_min,
+                                                                uint32_t nwords, uint2 *__restrict__ chunks,
+                                                                QueueState *__restrict__ qs, uint32_t *ctrl,
+                                                                uint32_t chunk_edges, uint32_t coop)
 {
     __shared__ uint16_t list[SSSP_BLOCK / kWave][SSSP_GROUP];          // node - first node of the group
     __shared__ uint8_t owner[SSSP_BLOCK / kWave][kWave * SSSP_COOP];    // short-list edge slot -> lane holding its node
@@ -163,10 +170,24 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_round_kernel(const uint32_t *
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t ngroups = (nwords * 2u + kWave - 1) / kWave;
     const uint32_t sh = (lane & 1u) * 16u; // this lane's half of its flag word
+    // `done`: the nodes taken up in earlier phases — final, at or below the previous threshold, so nothing a source of the
+    // running phase offers can improve them.  Snapshot of `settled`, taken by the first round after the threshold has
+    // moved: every wavefront copies the words of its own groups before it takes up their nodes (a word's bits are only
+    // ever set by its owner).  Readers may see the old or the new snapshot of a word: both hold final nodes only.  The
+    // bit test replaces the probe of the distance once enough nodes are final to pay for the extra L2 access
+    // (done_min; 0xFFFFFFFF = never).
+    const bool snap = done != nullptr && ld_agent(&ctrl[C_SNAP]) != 0u;
+    const uint32_t *skip_done = done != nullptr && ld_agent(&ctrl[C_NDONE]) >= done_min ? done : nullptr;
+    uint32_t copied = 0;
     RelaxOut ro{0u};
     for (uint32_t grp = wave; grp < ngroups; grp += nwaves) {
         const uint32_t my_word = (grp * kWave + lane) >> 1;
         const bool valid = my_word < nwords;
+        if (snap && valid && sh == 0u) {
+            const uint32_t bits = ld_agent(&settled[my_word]);
+            done[my_word] = bits;
+            copied += (uint32_t)__popc(bits);
+        }
         uint32_t near = 0u; // 16 bits
         if (heavy) {
             near = valid ? (ld_agent(&hflags[my_word]) >> sh) & 0xFFFFu : 0u;
@@ -280,6 +301,16 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_round_kernel(const uint32_t *
                         t[k] = in ? tgt[j] : 0u;
                         nb[k] = in ? __float_as_uint(__fadd_rn(od, w[j])) : 0xFFFFFFFFu;
                     }
+                    if (skip_done) {
+                        uint32_t bits[SSSP_MLP];
+#pragma unroll
+                        for (int k = 0; k < SSSP_MLP; ++k)
+                            bits[k] = nb[k] != 0xFFFFFFFFu ? skip_done[t[k] >> 5] : 0u;
+#pragma unroll
+                        for (int k = 0; k < SSSP_MLP; ++k)
+                            if ((bits[k] >> (t[k] & 31u)) & 1u)
+                                nb[k] = 0xFFFFFFFFu;
+                    }
 #pragma unroll
                     for (int k = 0; k < SSSP_MLP; ++k)
                         pre[k] = nb[k] != 0xFFFFFFFFu ? ld_agent(&dist[t[k]]) : 0u;
@@ -319,6 +350,13 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_round_kernel(const uint32_t *
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // the list is rewritten by the next step
     }
+    if (snap && (wave & 63u) == 0u) {
+        // an estimate from every 64th wavefront (their groups are spread evenly over the ids): 16 000 wavefronts adding to
+        // one word serialise at ~15 ns apiece — 0.25 ms per snapshot, 6 ms of a 9 ms call at scale 24 when all of them did
+        copied = (uint32_t)wave_sum((uint64_t)copied);
+        if (lane == 0 && copied)
+            atomicAdd(&ctrl[C_NCOUNT], copied * 64u);
+    }
     if (__ballot(ro.again != 0) && lane == 0 && !ld_agent(&ctrl[C_AGAIN]))
         atomicOr(&ctrl[C_AGAIN], 1u);
 }
@@ -331,6 +369,7 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_chunk_kernel(const uint32_t *
                                                                 const float *__restrict__ w, uint32_t *dist,
                                                                 uint32_t *flags, uint32_t *wmin,
                                                                 const uint32_t *__restrict__ settled,
+                                                                const uint32_t *__restrict__ done, uint32_t done_min,
                                                                 const uint2 *__restrict__ chunks,
                                                                 const QueueState *__restrict__ qs, uint32_t *ctrl,
                                                                 uint32_t chunk_edges)
@@ -354,6 +393,8 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_chunk_kernel(const uint32_t *
     const uint32_t q_base = qs->start[lane] - (q_incl - q_items); // slot of item f of sub-queue q = q_base + f
     const uint32_t thr = ld_agent(&ctrl[C_THR]);
     const bool heavy = ld_agent(&ctrl[C_HEAVY]) != 0u;
+    // heavy round: targets ever taken up; light round: targets taken up in earlier phases (once there are enough of them)
+    const uint32_t *final_bits = heavy ? settled : (done && ld_agent(&ctrl[C_NDONE]) >= done_min ? done : nullptr);
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     RelaxOut ro{0u};
@@ -363,7 +404,7 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_chunk_kernel(const uint32_t *
         const float du = __uint_as_float(ld_agent(&dist[ch.x]));
         const uint32_t end_u = off[ch.x + 1];
         const uint32_t end = ch.y + chunk_edges < end_u ? ch.y + chunk_edges : end_u;
-        relax_range(tgt, w, dist, flags, wmin, du, ch.y + lane, end, kWave, thr, heavy ? R_HEAVY : R_LIGHT, settled, ro);
+        relax_range(tgt, w, dist, flags, wmin, du, ch.y + lane, end, kWave, thr, heavy ? R_HEAVY : R_LIGHT, final_bits, ro);
     }
     if (__ballot(ro.again != 0) && lane == 0 && !ld_agent(&ctrl[C_AGAIN]))
         atomicOr(&ctrl[C_AGAIN], 1u);
@@ -413,6 +454,11 @@ __device__ void sssp_advance(uint32_t *ctrl, QueueState *qs, uint32_t adapt_lo, 
     if (threadIdx.x != 0)
         return;
     ctrl[C_WORK] += (uint32_t)((round_work + 63u) >> 6);
+    if (ctrl[C_SNAP]) { // the round that just ran took the snapshot: publish its count
+        ctrl[C_NDONE] = ld_agent(&ctrl[C_NCOUNT]);
+        ctrl[C_NCOUNT] = 0u;
+    }
+    ctrl[C_SNAP] = 0u;
     const uint32_t far = ld_agent(&ctrl[C_FAR]); // folded in by other workgroups of this launch: not through L1
     if (!ctrl[C_HEAVY]) {
         if (!ctrl[C_AGAIN])
@@ -439,6 +485,7 @@ __device__ void sssp_advance(uint32_t *ctrl, QueueState *qs, uint32_t adapt_lo, 
             nb = nb > far && next < 3.0e38f ? nb : far; // always covers the pending minimum
             ctrl[C_THR] = nb > ctrl[C_THR] ? nb : ctrl[C_THR];         // (a stale-low word bound never moves it back)
             ctrl[C_ADVANCES] += 1u;
+            ctrl[C_SNAP] = 1u; // the next round snapshots `settled` into `done` and counts it
         }
     }
     ctrl[C_AGAIN] = 0u;
@@ -607,6 +654,7 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
         GM_TRY(sc->wmin.alloc(((size_t)nwords + kWave) * 4));
         GM_TRY(sc->hflags.alloc(((size_t)nwords + kWave) * 4));
         GM_TRY(sc->settled.alloc(((size_t)nwords + kWave) * 4));
+        GM_TRY(sc->done.alloc(((size_t)nwords + kWave) * 4));
         GM_TRY(sc->ctrl.alloc(64));
         GM_TRY(sc->queues.alloc(sizeof(QueueState)));
         GM_TRY(sc->hctrl.alloc(64));
@@ -664,6 +712,7 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
     GM_HIP(hipMemsetAsync(flags.p, 0, flags.bytes, st));
     GM_HIP(hipMemsetAsync(hflags.p, 0, hflags.bytes, st));
     GM_HIP(hipMemsetAsync(settled.p, 0, settled.bytes, st));
+    GM_HIP(hipMemsetAsync(sc->done.p, 0, sc->done.bytes, st));
     GM_HIP(hipMemsetAsync(qs, 0, sizeof(QueueState), st));
     hipLaunchKernelGGL(sssp_caps_kernel, dim3(round_grid), dim3(SSSP_BLOCK), 0, st, g->offsets, n, ngroups, qs, chunk_edges,
                        coop);
@@ -683,6 +732,14 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
     unsigned far_grid = gm::div_up(nwords, SSSP_BLOCK * 8);
     far_grid = far_grid > 256 ? 256 : far_grid;
     const bool use_settled = getenv("GM_SSSP_SETTLED") == nullptr || atoi(getenv("GM_SSSP_SETTLED")) != 0;
+    // GM_SSSP_DONE: 0 (default) = light rounds probe every target's distance, 1 = targets taken up in earlier phases are
+    // skipped by their bit once n / GM_SSSP_DONE_DIV (default 8) nodes are final, 2 = from the first phase on.  Measured at
+    // scale 24 (tools/runs/r03_call39.sh, one box, bit-identical results): 9.26 ms off, 9.60 ms mode 1, 9.71 ms mode 2 — the
+    // light rounds' probes of already-final targets are too few to pay for a second dependent access; off.
+    const int done_mode = getenv("GM_SSSP_DONE") ? atoi(getenv("GM_SSSP_DONE")) : 0;
+    const int done_div = getenv("GM_SSSP_DONE_DIV") && atoi(getenv("GM_SSSP_DONE_DIV")) > 0 ? atoi(getenv("GM_SSSP_DONE_DIV")) : 8;
+    uint32_t *done_bits = done_mode ? sc->done.as<uint32_t>() : nullptr;
+    const uint32_t done_min = done_mode >= 2 ? 0u : n / (uint32_t)done_div + 1u;
     const bool stats = getenv("GM_SSSP_STATS") != nullptr;
     const int batch = stats ? 1 : 8; // rounds enqueued per host synchronisation
     auto t_prev = std::chrono::steady_clock::now();
@@ -690,11 +747,11 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
         for (int k = 0; k < batch; ++k) {
             hipLaunchKernelGGL(sssp_round_kernel, dim3(round_grid), dim3(SSSP_BLOCK), 0, st, g->offsets, g->targets, g->weights,
                                dist.as<uint32_t>(), flags.as<uint32_t>(), wmin.as<uint32_t>(), hflags.as<uint32_t>(),
-                               settled.as<uint32_t>(), nwords,
+                               settled.as<uint32_t>(), done_bits, done_min, nwords,
                                chunks.as<uint2>(), qs,
                                ctrl.as<uint32_t>(), chunk_edges, coop);
             hipLaunchKernelGGL(sssp_chunk_kernel, dim3(grid), dim3(SSSP_BLOCK), 0, st, g->offsets, g->targets, g->weights,
-                               dist.as<uint32_t>(), flags.as<uint32_t>(), wmin.as<uint32_t>(), use_settled ? settled.as<uint32_t>() : (const uint32_t *)nullptr,
+                               dist.as<uint32_t>(), flags.as<uint32_t>(), wmin.as<uint32_t>(), use_settled ? settled.as<uint32_t>() : (const uint32_t *)nullptr, done_bits, done_min,
                                chunks.as<uint2>(), qs, ctrl.as<uint32_t>(), chunk_edges);
             hipLaunchKernelGGL(sssp_finish_kernel, dim3(far_grid), dim3(SSSP_BLOCK), 0, st, wmin.as<uint32_t>(), nwords,
                                ctrl.as<uint32_t>(), qs, adapt_lo, adapt_hi, delta / 1024.0f, 1.0e30f);

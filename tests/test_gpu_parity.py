@@ -463,6 +463,31 @@ def test_sssp_result_does_not_depend_on_the_work_split(P, oracle, monkeypatch, c
     assert np.array_equal(P.delta_stepping(g, P.DeltaSteppingConfig(start, 0.1)), ref)
 
 
+@pytest.mark.parametrize("mode,width,adapt", [("0", "0.03125", "0.75,3"), ("1", "0.03125", "0.75,3"), ("2", "0.03125", "0.75,3"),
+                                              ("2", "0.001", "0.001,0.01"), ("2", "1", "0,0"), ("2", "1000", "0,0")])
+def test_sssp_final_targets_are_skipped_without_changing_the_result(P, oracle, monkeypatch, mode, width, adapt):
+    """Light rounds skip targets taken up in EARLIER phases by a bit test instead of probing their distance (their distances
+    are final and at or below the previous threshold; every source of the running phase lies beyond it, sssp.rs:170-204
+    would find nothing to improve): off, on once an eighth of the nodes is final, on from the first phase — under the
+    default schedule, many tiny phases, and one single phase — must all give the oracle's bits.  Zero-weight edges and
+    duplicates included (a candidate equal to the source's distance)."""
+    scale = 16
+    s, d = oracle.rmat_edges(scale, seed=27)
+    w = oracle.rmat_weights(s.size, seed=28)
+    w[::7] = 0.0
+    n = 1 << scale
+    g = _directed(P, n, s, d, P.CsrLayout.Sorted, w)
+    off, tgt, wv = oracle.csr_build(n, s, d, oracle.OUTGOING, oracle.SORTED, w)
+    start = int(np.flatnonzero(np.diff(off) > 0)[0])
+    ref = oracle.sssp_fixed_point(off, tgt, wv, start)
+    monkeypatch.setenv("GM_SSSP_DONE", mode)
+    monkeypatch.setenv("GM_SSSP_WIDTH", width)
+    monkeypatch.setenv("GM_SSSP_ADAPT", adapt)
+    for delta in (0.1, 0.02):
+        got = P.delta_stepping(g, P.DeltaSteppingConfig(start, delta))
+        assert np.array_equal(got, ref)
+
+
 def test_sssp_many_start_nodes_on_one_handle(P, oracle):
     """The working buffers are parked in the CSR handle between calls and the weight check runs once per handle:
     later calls (other start nodes, other deltas, an isolated start node) must not see anything of the earlier ones."""

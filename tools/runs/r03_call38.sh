@@ -1,0 +1,27 @@
+#!/bin/bash
+# round 3, GPU call 38: SSSP light rounds skip targets that were final before the phase: parity tests, then scale-24 times per mode
+OUT=gpurun_out/r03ze; mkdir -p $OUT; export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_parity.py -q -k sssp > $OUT/pytest_sssp.log 2>&1; grep -E "passed|failed|^E  " $OUT/pytest_sssp.log | tail -8
+cat > /tmp/sssp_modes.py <<'PY'
+import os, sys, time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
+import numpy as np, torch
+from graph_amd import synth
+import graph_amd.prelude as P
+sc = 24
+n = 1 << sc
+src, dst = synth.rmat_edges(sc, 42); m = int(src.numel()); w = synth.rmat_weights(m, 44)
+g_out = synth.build_csr(n, src, dst, P.Direction.Outgoing, P.CsrLayout.Sorted, w); del src, dst, w
+g = P.DirectedCsrGraph(g_out, g_out, P.CsrLayout.Sorted)
+start = int(np.flatnonzero(g_out.degrees() > 0)[0])
+base = None
+for mode, div in (("0", "8"), ("1", "8"), ("1", "4"), ("1", "16"), ("1", "64"), ("2", "8"), ("0", "8"), ("1", "8")):
+    os.environ["GM_SSSP_DONE"] = mode; os.environ["GM_SSSP_DONE_DIV"] = div
+    P.delta_stepping(g, P.DeltaSteppingConfig(start, 0.1))
+    ts = []
+    for _ in range(5):
+        t = time.perf_counter(); d = P.delta_stepping(g, P.DeltaSteppingConfig(start, 0.1)); ts.append(time.perf_counter() - t)
+    if base is None: base = d
+    print(f"mode {mode} div {div}: min {min(ts)*1e3:.3f} ms median {sorted(ts)[2]*1e3:.3f} ms  same bits {bool(np.array_equal(d.view(np.uint32), base.view(np.uint32)))}", flush=True)
+PY
+timeout 600 python /tmp/sssp_modes.py 2>&1 | tail -9
