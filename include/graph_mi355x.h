@@ -21,7 +21,8 @@
  *     vectors and engine of the last gm_page_rank call (~3.4 B/edge + 12 B/node: ~9 GB at RMAT
  *     scale 26); the working set of the last gm_sssp_delta_stepping (~9 B/node) and gm_wcc_* call
  *     (~8 B/node); gm_triangle_count's DAG of lower prefixes and list records (~6 B/entry +
- *     128 B/node: 4.7 GB at scale 24).  A concurrent second call of one algorithm allocates its own
+ *     128 B/node: 4.7 GB at scale 24); the partition of the last gm_page_rank_multi call (slices,
+ *     engines, exchange buffers on every device it named).  A concurrent second call of one algorithm allocates its own
  *     working set.  gm_csr_trim() releases all of it (the next call rebuilds what it needs);
  *     gm_csr_free() releases everything.  Large buffers come from a per-device arena of 64 MiB
  *     physical pieces that the library keeps for reuse (up to GM_ARENA_KEEP_GIB, default 32);
@@ -175,6 +176,10 @@ int gm_page_rank_directed(const gm_csr *out_csr, const gm_csr *in_csr, uint64_t 
  * the in-CSR, a sweep engine and a replica of out_scores; per sweep: local sweep kernels -> ncclAllGather of the
  * out_scores of the nodes that have out-edges -> the f64 error partials summed in rank order.  Same stop rule and
  * results as gm_page_rank_directed (rows below the hub threshold bit-identical, hub rows to ~1e-6).
+ * The exchange travels in K regions (GM_MULTI_PARTS, default 2) on streams of its own, under the work of the other
+ * regions; the host synchronises only when the stop rule needs the error (tolerance > 0: every sweep; 0: once).  The
+ * partition, slices, engines, streams and communicator of a call are parked in in_csr's handle: a second call with the
+ * same device list builds nothing (gm_csr_trim releases them).
  * devices: n_devices device ordinals, or NULL for 0 .. n_devices-1.  A device named more than once gives
  * "virtual ranks" (the exchange then uses device-to-device copies instead of RCCL) — for exercising the
  * partitioned path on a single GPU.  librccl.so is loaded on first use; GM_ERR_UNSUPPORTED if it is missing. */
@@ -250,7 +255,9 @@ uint64_t gm_pr_tile_count(const gm_pr *pr); /* workgroups per sweep (diagnostics
  * (page_rank.rs:143-146), [3] their in-edges, [4] the in-degree threshold for that (GM_PB_HUB_DEG, default
  * 4096, 0 = off), [5] hot sources, [6] entries of the value stream, [7] hot edges, [8] bytes of this engine's
  * scratch (value stream etc.), [9] bins, [10] source tiles, [11] (tile, bin) segments, [12] hub groups (the hub
- * rows are walked in groups of <= 64 rows, one workgroup each), [13] tiers of hot sources.  Further entries are 0. */
+ * rows are walked in groups of <= 64 rows, one workgroup each), [13] tiers of hot sources, [14] hub groups of one or
+ * two rows (the long chains, walked block-parallel), [15] their 4096-entry blocks, [16] how many of them fell back to
+ * the sequential walk in the last sweep (scratch != NULL).  Further entries are 0. */
 int gm_pr_plan_info(const gm_pr *pr, uint64_t *info, uint32_t count);
 
 /* ---------------------------------------------------------------------------------------------
