@@ -540,5 +540,6 @@ struct gm_csr {
     mutable std::shared_ptr<gm::PrCallState> pr_call;      // likewise (stream, vectors, engine + its scratch)
     mutable std::shared_ptr<const gm::TcDag> tc_dag;       // the DAG of lower prefixes + list records of gm_triangle_count
     mutable std::unique_ptr<gm::MultiState, gm::MultiStateDeleter> multi; // gm_page_rank_multi's resident run (in-CSR handle)
-    mutable std::atomic<int> long_rows{-1};           // 1: some row has >= GM_PB_HUB_DEG entries (-1: not looked at yet)
+    // (threshold << 1 | answer) of the last look: does some row have >= GM_PB_HUB_DEG entries?  -1: not looked at yet
+    mutable std::atomic<long long> long_rows{-1};
 };

@@ -695,9 +695,12 @@ GM_API int gm_page_rank_multi(const gm_csr *out_csr, const gm_csr *in_csr, const
         GM_TRY(multi_build(out_csr, in_csr, devs, distinct, damping_factor, engine, K, &ms));
     const int rc = multi_run(*ms, max_iterations, tolerance, scores_out, iterations_out, error_out);
     if (rc == GM_OK && !(getenv("GM_PB_NOCACHE") && atoi(getenv("GM_PB_NOCACHE")))) { // parked for the next call (a failed run is torn down)
-        std::lock_guard<std::mutex> lock(in_csr->cache_mu);
-        if (!in_csr->multi)
+        MultiPtr old; // the state of another run (other devices, another K) makes room: destroyed outside the lock
+        {
+            std::lock_guard<std::mutex> lock(in_csr->cache_mu);
+            old = std::move(in_csr->multi);
             in_csr->multi = std::move(ms);
+        }
     }
     return rc;
 }

@@ -378,13 +378,14 @@ __global__ __launch_bounds__(kWave) void pr_seq_kernel(const uint32_t *__restric
 // Does some row have at least GM_PB_HUB_DEG (default 4096) in-edges?  Such rows need the propagation-blocking
 // engine, which sums them in the reference's left-to-right f32 order (pagerank_pb.hip): the pull tiles reduce a
 // long row as a tree, and on long rows the two differ by more than the 1e-5 the results must agree to
-// (measured 1.2e-5 at RMAT scale 18).  Looked at once per handle.
+// (measured 1.2e-5 at RMAT scale 18).  Looked at once per handle and threshold.
 static int pr_has_long_rows(const gm_csr *csr, bool *out)
 {
-    int state = csr->long_rows.load();
+    const char *v = getenv("GM_PB_HUB_DEG");
+    const long thr = v && *v && atol(v) > 0 ? atol(v) : (v && *v ? 0 : 4096);
+    const long long cached = csr->long_rows.load();
+    int state = cached >= 0 && (cached >> 1) == (long long)thr ? (int)(cached & 1) : -1; // an answer for another threshold does not count
     if (state < 0) {
-        const char *v = getenv("GM_PB_HUB_DEG");
-        const long thr = v && *v ? atol(v) : 4096;
         state = 0;
         if (thr > 0 && csr->n && csr->m >= (uint64_t)thr) {
             gm::DevBuf flag;
@@ -398,7 +399,7 @@ static int pr_has_long_rows(const gm_csr *csr, bool *out)
             GM_HIP(hipMemcpy(&h, flag.p, 4, hipMemcpyDeviceToHost));
             state = h ? 1 : 0;
         }
-        csr->long_rows.store(state);
+        csr->long_rows.store(((long long)thr << 1) | (long long)state);
     }
     *out = state == 1;
     return GM_OK;
