@@ -61,6 +61,18 @@ def _ptr(a):
     return a.ctypes.data_as(vp) if a is not None else None
 
 
+def trim_device(device: int = -1):
+    """gm_trim: hand the unused 64 MiB pieces of the library's device arena back to the driver (-1: current device)"""
+    check(lib().gm_trim(int(device)))
+
+
+def arena_info(device: int = -1):
+    """gm_arena_info: what the device arena holds — bytes held, bytes of it idle, pieces created, pieces handed out so far"""
+    out = (C.c_uint64 * 4)()
+    check(lib().gm_arena_info(int(device), out))
+    return {"held_bytes": int(out[0]), "idle_bytes": int(out[1]), "pieces_created": int(out[2]), "pieces_handed_out": int(out[3])}
+
+
 class DeviceCsr:
     """One device-resident CSR (offsets/targets[/weights] in HBM); lazily mirrored to the host for
     the per-node accessors of the reference's graph traits."""
@@ -132,6 +144,11 @@ class DeviceCsr:
         d = np.empty(self.n, np.uint32)
         check(lib().gm_csr_degrees(self._h, _ptr(d) if self.n else None))
         return d
+
+    def trim(self):
+        """gm_csr_trim: release what the handle parked for later calls (PageRank plan and call state, SSSP / WCC working
+        sets, the triangle count's DAG, the multi-GPU state); the graph stays, the next call rebuilds what it needs."""
+        check(lib().gm_csr_trim(self._h))
 
 
 class _GraphBase:
@@ -455,7 +472,7 @@ def relabel_graph(graph: UndirectedCsrGraph):
 
 __all__ = [
     "CsrLayout", "Direction", "DeviceCsr", "DirectedCsrGraph", "UndirectedCsrGraph", "EdgeListInput",
-    "Graph500Input", "GraphBuilder", "PageRankConfig", "PageRankMode", "page_rank", "page_rank_multi", "WccConfig", "Components",
+    "Graph500Input", "GraphBuilder", "PageRankConfig", "PageRankMode", "page_rank", "page_rank_multi", "trim_device", "arena_info", "WccConfig", "Components",
     "wcc_afforest", "wcc_afforest_dss", "wcc_baseline", "DeltaSteppingConfig", "delta_stepping",
     "global_triangle_count", "relabel_graph",
 ]
