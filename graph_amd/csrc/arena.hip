@@ -43,8 +43,10 @@ struct Arena {
 
 Arena &arena_of(int dev)
 {
-    static std::mutex mu;
-    static std::map<int, std::unique_ptr<Arena>> arenas;
+    // never destroyed: a handle released during static destruction (a global graph object of the host program) still
+    // finds its arena
+    static std::mutex &mu = *new std::mutex;
+    static std::map<int, std::unique_ptr<Arena>> &arenas = *new std::map<int, std::unique_ptr<Arena>>;
     std::lock_guard<std::mutex> lock(mu);
     std::unique_ptr<Arena> &a = arenas[dev];
     if (!a)
@@ -154,6 +156,10 @@ int arena_take(int dev, size_t count, uint64_t spread_seed, size_t spread_factor
         const int rc = create_pieces(a, dev, want_free - a.free_list.size());
         if (rc != GM_OK && a.free_list.size() < count)
             return rc; // a smaller pool than asked for still serves the request
+    }
+    if (a.free_list.size() < count) {
+        set_error("arena: %zu free pieces, %zu wanted", a.free_list.size(), count);
+        return GM_ERR_NOMEM;
     }
     if (!spread_seed) { // any pieces: the most recently returned ones
         a.reused += count;

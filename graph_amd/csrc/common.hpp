@@ -191,6 +191,18 @@ struct DevBuf {
     {
         if (!arena_enabled() || nbytes < ARENA_MIN || !arena_site_enabled(site))
             return alloc(nbytes);
+        // the arena is a matter of speed, not of function: if the virtual-memory path fails (no pieces left, a runtime
+        // that refuses the mapping), the buffer comes from hipMalloc like every small one
+        if (alloc_from_arena(nbytes, spread_seed, spread_factor, serial_lo, serial_hi, split_serial) == GM_OK)
+            return GM_OK;
+        if (const char *v = getenv("GM_LOG"))
+            if (*v && *v != '0')
+                fprintf(stderr, "[graph_mi355x] arena: %s; falling back to hipMalloc for %zu bytes\n", gm_last_error(), nbytes);
+        return alloc(nbytes);
+    }
+    int alloc_from_arena(size_t nbytes, uint64_t spread_seed, size_t spread_factor, uint64_t serial_lo, uint64_t serial_hi,
+                         uint64_t split_serial)
+    {
         release();
         int dev = 0;
         GM_HIP(hipGetDevice(&dev));

@@ -2546,6 +2546,8 @@ int pb_scratch_create(const PbPlan *pl, PbScratch **out, DevBuf *early)
     hipError_t e = hipMemset(sc->tickets.p, 0, (size_t)pl->B * 4);
     if (e == hipSuccess && sc->par_ticket.p)
         e = hipMemset(sc->par_ticket.p, 0, sc->par_ticket.bytes);
+    if (e == hipSuccess && sc->par_fail.p)
+        e = hipMemset(sc->par_fail.p, 0, sc->par_fail.bytes);
     if (e == hipSuccess)
         e = hipMemset(sc->vals_raw.p, 0, sc->vals_raw.bytes);
     if (e == hipSuccess && pl->few_blocks > pl->G_few) { // the long chains' own stream
