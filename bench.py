@@ -393,6 +393,8 @@ def main():
                                                                "long_chain_blocks", "long_chains_fell_back")} if plan else None,
             "hot_sources": plan.get("hot_sources") if plan else None, "hot_tiers": plan.get("hot_tiers") if plan else None,
             "hot_edges": plan.get("hot_edges") if plan else None, "value_entries": plan.get("value_entries") if plan else None,
+            "value_stream_placement": {k: plan.get(k) for k in ("value_stream_from_arena", "draws_timed", "draw_best_us", "draw_worst_us",
+                                                                 "arena_grown_pieces")} if plan else None,
             "parity": parity,
         },
         "roofline": {

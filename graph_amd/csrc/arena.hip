@@ -246,6 +246,19 @@ void arena_stats(int dev, uint64_t *out4)
     out4[3] = a.reused;
 }
 
+void arena_free_range(int dev, uint64_t *lo, uint64_t *hi, size_t *count)
+{
+    Arena &a = arena_of(dev);
+    std::lock_guard<std::mutex> lock(a.mu);
+    *lo = ~0ull, *hi = 0, *count = a.free_list.size();
+    for (const ArenaPiece &p : a.free_list) {
+        *lo = p.serial < *lo ? p.serial : *lo;
+        *hi = p.serial + 1 > *hi ? p.serial + 1 : *hi;
+    }
+    if (a.free_list.empty())
+        *lo = 0;
+}
+
 } // namespace gm
 
 // Releases what the library holds in reserve on `device` (-1: the current device): the arena's free pieces.  Buffers in

@@ -101,6 +101,8 @@ void arena_va_free(int dev, void *ptr, size_t span);
 void arena_give(int dev, std::vector<ArenaPiece> &pieces);
 void arena_trim(int dev, size_t keep_bytes);
 void arena_stats(int dev, uint64_t *out4);
+// serials of the oldest and (one past) the newest piece of the free list, and how many are free
+void arena_free_range(int dev, uint64_t *lo, uint64_t *hi, size_t *count);
 
 // RAII device allocation; movable, not copyable.  Two backings: hipMalloc / hipFree, or (alloc_vmm) a reserved
 // virtual range mapped chunk by chunk from physical allocations of the HIP virtual-memory API — the caller decides
@@ -186,14 +188,16 @@ struct DevBuf {
     // under GM_ARENA=0, take the hipMalloc path.  Contents are NOT zero (hipMalloc does not promise that either).
     // serial_lo / serial_hi: only pieces created as numbers [lo, hi) (arena_grow); split_serial != 0: every other piece
     // of the buffer from below that serial, the others from it on
+    // split_serial != 0: half of the pieces from serials [serial_lo, older_hi ? older_hi : split_serial), half from
+    // [split_serial, serial_hi), interleaved
     int alloc_big(size_t nbytes, uint64_t spread_seed = 0, size_t spread_factor = 4, uint64_t serial_lo = 0,
-                  uint64_t serial_hi = ~0ull, uint64_t split_serial = 0, int site = 0)
+                  uint64_t serial_hi = ~0ull, uint64_t split_serial = 0, int site = 0, uint64_t older_hi = 0)
     {
         if (!arena_enabled() || nbytes < ARENA_MIN || !arena_site_enabled(site))
             return alloc(nbytes);
         // the arena is a matter of speed, not of function: if the virtual-memory path fails (no pieces left, a runtime
         // that refuses the mapping), the buffer comes from hipMalloc like every small one
-        if (alloc_from_arena(nbytes, spread_seed, spread_factor, serial_lo, serial_hi, split_serial) == GM_OK)
+        if (alloc_from_arena(nbytes, spread_seed, spread_factor, serial_lo, serial_hi, split_serial, older_hi) == GM_OK)
             return GM_OK;
         if (const char *v = getenv("GM_LOG"))
             if (*v && *v != '0')
@@ -201,7 +205,7 @@ struct DevBuf {
         return alloc(nbytes);
     }
     int alloc_from_arena(size_t nbytes, uint64_t spread_seed, size_t spread_factor, uint64_t serial_lo, uint64_t serial_hi,
-                         uint64_t split_serial)
+                         uint64_t split_serial, uint64_t older_hi = 0)
     {
         release();
         int dev = 0;
@@ -209,7 +213,7 @@ struct DevBuf {
         const size_t count = (nbytes + ARENA_PIECE - 1) / ARENA_PIECE, span = count * ARENA_PIECE;
         if (split_serial && spread_seed) {
             std::vector<ArenaPiece> older, newer;
-            GM_TRY(arena_take(dev, count / 2, spread_seed, 1, older, serial_lo, split_serial));
+            GM_TRY(arena_take(dev, count / 2, spread_seed, 1, older, serial_lo, older_hi ? older_hi : split_serial));
             int rc2 = arena_take(dev, count - count / 2, spread_seed + 1, 1, newer, split_serial, serial_hi);
             if (rc2 != GM_OK) {
                 arena_give(dev, older);

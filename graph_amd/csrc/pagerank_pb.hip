@@ -96,6 +96,9 @@ struct PbScratch {
     // rounded on four grids; per group and row the running sum after the first block; per group an arrival counter
     // (self-resetting) and a "prediction failed" flag
     DevBuf par_exact, par_binade, par_round, par_state, par_ticket, par_fail;
+    // how the value stream got its memory (diagnostics, gm_pr_plan_info): bin-kernel time of the fastest / slowest timed
+    // draw in us, draws timed, 64 MiB pieces the arena was grown by for it
+    uint32_t draw_best_us = 0, draw_worst_us = 0, draws_timed = 0, grown_pieces = 0;
     DevBuf vals_raw; // backing allocation of the value stream
     std::shared_ptr<DevBuf> vals_shared; // GM_PB_VALS_SHARE (measurement): one allocation behind the streams of several engines
     float *vals = nullptr; // f32[Mv] per-edge values, bin-major, segments padded to 4
@@ -2268,6 +2271,9 @@ static hipError_t pb_set_kernel_attributes()
     return e;
 }
 
+static void pb_bin_dispatch(const PbPlan *pl, PbScratch *sc, const float *x_in, uint32_t w_first, uint32_t w_count,
+                            hipStream_t st, const uint32_t *item_list = nullptr);
+
 int pb_plan_create(const gm_csr *csr, uint64_t x_len, PbPlan **out)
 {
     PbPlan *pl = new (std::nothrow) PbPlan();
@@ -2313,9 +2319,6 @@ int pb_plan_get(const gm_csr *csr, uint64_t x_len, std::shared_ptr<const PbPlan>
     return GM_OK;
 }
 
-
-static void pb_bin_dispatch(const PbPlan *pl, PbScratch *sc, const float *x_in, uint32_t w_first, uint32_t w_count,
-                            hipStream_t st, const uint32_t *item_list = nullptr);
 
 int pb_scratch_create(const PbPlan *pl, PbScratch **out, DevBuf *early)
 {
@@ -2434,19 +2437,23 @@ int pb_scratch_create(const PbPlan *pl, PbScratch **out, DevBuf *early)
             return rc;
         }
     }
-    // The default: the stream mapped from 64 MiB pieces sampled from all over the arena's free list (arena.hip — right
-    // after a plan build that list holds the build's ~30 GB of temporaries), GM_PB_DRAWS (3) such samples timed with
-    // the bin kernel itself, the fastest kept.  Where the stream's pages lie relative to the index stream read beside
-    // it decides up to a third of the bin kernel's time (1.23-1.34 ms against 1.66-1.78 at RMAT scale 26,
-    // profiles/r03_placement_*.txt); a draw costs a remap and three launches.  When even the best draw runs below
-    // GM_PB_BW_MIN GB/s (3500: below every fast case seen, above every slow one) the arena's pieces all lie in one unlucky stretch: it is grown
-    // by 8 GiB at a time (GM_PB_GROW_GIB in all, default 16) and the stream drawn from the new pieces, from both, from
-    // everything, until a draw is fast.
-    if (!sc->vals_raw.p && arena_enabled() && (size_t)pl->Mv * 4 + slack >= ARENA_MIN && pl->NW && pb_env("GM_PB_DRAWS", 3) > 0) {
+    // The default: the stream mapped from 64 MiB pieces of the arena (arena.hip — right after a plan build its free list
+    // holds the build's ~20-30 GB of temporaries), several candidate sets timed with the bin kernel itself, the fastest
+    // kept.  Which physical memory the stream lies in — relative to the index stream read beside it — decides up to a third
+    // of the bin kernel's time (1.11-1.22 ms against 1.41-1.59 at RMAT scale 26, profiles/r03_placement_*.txt); a candidate
+    // costs a remap and three launches (~5 ms).  GM_PB_DRAWS (4) candidates of different kinds are tried until one reaches
+    // GM_PB_BW_OK (4000 GB/s); if the best stays below GM_PB_BW_MIN (3700 GB/s: between the medium and the slow level) the
+    // arena is grown by 8 GiB at a time (GM_PB_GROW_GIB in all, default 16) and every fresh stretch tried alone and mixed
+    // with the pool.  What this search cannot reach (tools/runs/r03_call45.sh, profiles/r03_placement_search_log.txt): in about
+    // one process in four the bin kernel runs at 1.36-1.52 ms whatever the value stream is mapped from — ten candidates of
+    // all kinds within 1 % of each other — and re-placing the plan's index stream (copied into the pool's oldest / newest
+    // pieces, spread sets, fresh memory) does not move it either; a second plan of the same graph in the same process may
+    // run at another level.  That state belongs to the process (or the plan's small arrays), not to these two streams.
+    if (!sc->vals_raw.p && arena_enabled() && (size_t)pl->Mv * 4 + slack >= ARENA_MIN && pl->NW && pb_env("GM_PB_DRAWS", 4) > 0) {
         const size_t bytes = (size_t)pl->Mv * 4 + slack;
-        const int draws = pb_env("GM_PB_DRAWS", 3);
+        const int draws = pb_env("GM_PB_DRAWS", 4);
         const double moved = (double)pl->Mp * 2 + (double)pl->Mv * 4 + (double)pl->x_len * 4; // bytes of one bin launch
-        const double bw_min = (double)pb_env("GM_PB_BW_MIN", 3500) * 1e9;
+        const double bw_min = (double)pb_env("GM_PB_BW_MIN", 3700) * 1e9;
         DevBuf probe_x; // any readable x will do for the timing
         hipEvent_t e0 = nullptr, e1 = nullptr;
         float best_ms = 0.f;
@@ -2479,26 +2486,58 @@ int pb_scratch_create(const PbPlan *pl, PbScratch **out, DevBuf *early)
                 fprintf(stderr, "[graph_mi355x] value stream draw %d (%s): bin kernel %.3f ms = %.0f GB/s\n", tried, what, ms,
                         moved / (ms * 1e-3) / 1e9);
             ++tried;
+            if (he == hipSuccess) {
+                const uint32_t us = (uint32_t)(ms * 1000.0f);
+                sc->draw_best_us = sc->draws_timed == 0 || us < sc->draw_best_us ? us : sc->draw_best_us;
+                sc->draw_worst_us = us > sc->draw_worst_us ? us : sc->draw_worst_us;
+                ++sc->draws_timed;
+            }
             if (he == hipSuccess && (!sc->vals_raw.p || ms < best_ms)) {
                 best_ms = ms;
                 sc->vals_raw = std::move(cand);
             }
             sc->vals = nullptr;
         };
-        for (int k = 0; k < draws && rc == GM_OK && he == hipSuccess; ++k) {
+        const size_t count = (bytes + ARENA_PIECE - 1) / ARENA_PIECE;
+        const size_t step = ((size_t)8 << 30) / ARENA_PIECE > 2 * count ? ((size_t)8 << 30) / ARENA_PIECE : 2 * count;
+        // fast enough to stop looking (GM_PB_BW_OK GB/s by the `moved` model: the fast level is 4060-4500, the slow one <= 3510)
+        const double bw_ok = (double)pb_env("GM_PB_BW_OK", 4000) * 1e9;
+        auto fast_enough = [&] { return sc->vals_raw.p && best_ms > 0.f && moved / (best_ms * 1e-3) >= bw_ok; };
+        // Candidates that differ in KIND, not only in seed (three spread draws of one pool measure the same to 1 %): spread
+        // over the whole pool; the pool's oldest pieces only; its newest only; spread again.  What makes a set of pieces fast
+        // is not understood beyond the maps in profiles/r03_placement_*.txt — pieces that are fast alone can be slow mixed
+        // and the other way round — so the stream is chosen by measurement.
+        uint64_t pool_lo = 0, pool_hi = 0;
+        size_t pool_free = 0;
+        for (int k = 0; k < draws && rc == GM_OK && he == hipSuccess && !fast_enough(); ++k) {
             DevBuf cand;
-            rc = cand.alloc_big(bytes, 0xA11CE5 + 7919ull * (uint64_t)k + pl->NS, 4, 0, ~0ull, 0, 8);
+            const char *what = "all over the arena";
+            if (k == 0 || k >= 3 || draws == 1) {
+                rc = cand.alloc_big(bytes, 0xA11CE5 + 7919ull * (uint64_t)k + pl->NS, 4, 0, ~0ull, 0, 8);
+                arena_free_range(pl->device, &pool_lo, &pool_hi, &pool_free); // the pool as the first draw left it
+            } else {
+                const uint64_t window = 2 * count; // serials; pieces of the range that are in use elsewhere are simply missing
+                const bool oldest = k == 1;
+                what = oldest ? "the pool's oldest pieces" : "the pool's newest pieces";
+                if (pool_hi - pool_lo < 3 * window || pool_free < 3 * window)
+                    continue; // a pool this small has no distinct ends
+                // (straight from the arena: a window without enough free pieces is not a candidate, no hipMalloc stand-in)
+                const int rcw = oldest ? cand.alloc_from_arena(bytes, 0x01DE57 + pl->NS, 1, pool_lo, pool_lo + window, 0)
+                                       : cand.alloc_from_arena(bytes, 0x0E3E57 + pl->NS, 1, pool_hi - window, pool_hi, 0);
+                if (rcw != GM_OK)
+                    continue;
+            }
             if (rc != GM_OK || draws == 1) {
                 if (rc == GM_OK)
                     sc->vals_raw = std::move(cand);
                 break;
             }
-            consider(cand, "all over the arena");
+            consider(cand, what);
         }
-        const size_t count = (bytes + ARENA_PIECE - 1) / ARENA_PIECE;
-        const size_t step = ((size_t)8 << 30) / ARENA_PIECE > 2 * count ? ((size_t)8 << 30) / ARENA_PIECE : 2 * count;
+        // ... and if none of them is above the slow level, stretches of fresh memory behind the pool: alone, and half-and-half
+        // with the pool; one candidate at a time (the loser's pieces and address range go back before the next is drawn)
         size_t budget = ((size_t)pb_env("GM_PB_GROW_GIB", 16) << 30) / ARENA_PIECE;
-        while (draws > 1 && rc == GM_OK && he == hipSuccess && bytes >= ((size_t)1 << 30) && budget >= step &&
+        while (draws > 1 && rc == GM_OK && he == hipSuccess && bytes >= ((size_t)1 << 30) && budget >= step && sc->vals_raw.p &&
                moved / (best_ms * 1e-3) < bw_min) {
             budget -= step;
             uint64_t first = 0;
@@ -2508,13 +2547,47 @@ int pb_scratch_create(const PbPlan *pl, PbScratch **out, DevBuf *early)
                 (void)hipGetLastError();
                 break;
             }
-            DevBuf a, b, c;
-            if (a.alloc_big(bytes, 0xB0B + first, 1, first) == GM_OK)
-                consider(a, "the newest 8 GiB");
-            if (he == hipSuccess && b.alloc_big(bytes, 0xC0C + first, 1, 0, ~0ull, first) == GM_OK)
-                consider(b, "half older, half newest");
-            if (he == hipSuccess && c.alloc_big(bytes, 0xD0D + first, 1) == GM_OK)
-                consider(c, "all over the grown arena");
+            sc->grown_pieces += (uint32_t)step;
+            for (int variant = 0; variant < 2 && he == hipSuccess && moved / (best_ms * 1e-3) < bw_min; ++variant) {
+                DevBuf cand;
+                const int rcc = variant == 0 ? cand.alloc_from_arena(bytes, 0xB0B + first, 1, first, first + step, 0)
+                                             : cand.alloc_from_arena(bytes, 0xC0C + first, 1, pool_lo, first + step, first, pool_hi);
+                if (rcc == GM_OK)
+                    consider(cand, variant == 0 ? "a fresh 8 GiB behind the pool" : "half pool, half fresh");
+            }
+        }
+        if (const char *gm = getenv("GM_PB_GROW_MAP")) { // measurement (profiles/r03_placement_grow_map.txt): which later stretches
+            // of memory are fast alone, which pair well with the pool?  k-th stretch of 8 GiB created behind the pool, timed
+            // alone and half-and-half with the pool as it was; one candidate at a time
+            uint64_t pool_end = 0;
+            (void)arena_grow(pl->device, 0, &pool_end);
+            for (int k = 0; k < atoi(gm) && rc == GM_OK && he == hipSuccess && draws > 1; ++k) {
+                uint64_t first = 0;
+                if (arena_grow(pl->device, step, &first) != GM_OK)
+                    break;
+                float t[2] = {0.f, 0.f};
+                for (int variant = 0; variant < 2; ++variant) {
+                    DevBuf cand;
+                    const int rcc = variant == 0 ? cand.alloc_from_arena(bytes, 0xE0E + first, 1, first, first + step, 0)
+                                                 : cand.alloc_from_arena(bytes, 0xF0F + first, 1, 0, first + step, first, pool_end);
+                    if (rcc != GM_OK)
+                        continue;
+                    sc->vals = cand.as<float>();
+                    pb_bin_dispatch(pl, sc, probe_x.as<float>(), 0, pl->NW, (hipStream_t)0);
+                    he = hipEventRecord(e0, (hipStream_t)0);
+                    pb_bin_dispatch(pl, sc, probe_x.as<float>(), 0, pl->NW, (hipStream_t)0);
+                    pb_bin_dispatch(pl, sc, probe_x.as<float>(), 0, pl->NW, (hipStream_t)0);
+                    if (he == hipSuccess)
+                        he = hipEventRecord(e1, (hipStream_t)0);
+                    if (he == hipSuccess)
+                        he = hipEventSynchronize(e1);
+                    if (he == hipSuccess)
+                        he = hipEventElapsedTime(&t[variant], e0, e1);
+                    sc->vals = nullptr;
+                }
+                fprintf(stderr, "[graph_mi355x] grow map: stretch %2d (pieces %llu..%llu, pool ended at %llu): alone %.3f ms, half pool + half stretch %.3f ms\n",
+                        k, (unsigned long long)first, (unsigned long long)(first + step), (unsigned long long)pool_end, t[0] * 0.5f, t[1] * 0.5f);
+            }
         }
         sc->vals = nullptr;
         if (e0)
@@ -2600,7 +2673,9 @@ void pb_plan_info(const PbPlan *pl, const PbScratch *sc, uint64_t *info, uint32_
                 fell_back += x ? 1u : 0u;
     }
     const uint64_t v[] = {plan_bytes, (uint64_t)(pl->build_ms * 1000.0), pl->n_hub, pl->hub_edges, pl->hub_deg, pl->Htot,
-                          pl->Mv, pl->Mh, scratch_bytes, pl->B, pl->NT, pl->NS, pl->G, pl->T, pl->G_few, pl->few_blocks, fell_back};
+                          pl->Mv, pl->Mh, scratch_bytes, pl->B, pl->NT, pl->NS, pl->G, pl->T, pl->G_few, pl->few_blocks, fell_back,
+                          sc ? sc->draw_best_us : 0u, sc ? sc->draw_worst_us : 0u, sc ? sc->draws_timed : 0u,
+                          sc ? sc->grown_pieces : 0u, sc && !sc->vals_raw.arena.empty() ? 1u : 0u};
     for (uint32_t i = 0; i < count; ++i)
         info[i] = i < sizeof(v) / sizeof(v[0]) ? v[i] : 0;
 }

@@ -257,7 +257,9 @@ uint64_t gm_pr_tile_count(const gm_pr *pr); /* workgroups per sweep (diagnostics
  * scratch (value stream etc.), [9] bins, [10] source tiles, [11] (tile, bin) segments, [12] hub groups (the hub
  * rows are walked in groups of <= 64 rows, one workgroup each), [13] tiers of hot sources, [14] hub groups of one or
  * two rows (the long chains, walked block-parallel), [15] their 4096-entry blocks, [16] how many of them fell back to
- * the sequential walk in the last sweep (scratch != NULL).  Further entries are 0. */
+ * the sequential walk in the last sweep (scratch != NULL), [17] / [18] bin-kernel time (us) of the fastest / slowest timed
+ * placement draw of the engine's value stream, [19] draws timed, [20] 64 MiB pieces the device arena was grown by for it,
+ * [21] 1: the value stream is mapped from arena pieces (0: hipMalloc).  Further entries are 0. */
 int gm_pr_plan_info(const gm_pr *pr, uint64_t *info, uint32_t count);
 
 /* ---------------------------------------------------------------------------------------------
