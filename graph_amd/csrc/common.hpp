@@ -188,6 +188,15 @@ struct DevBuf {
     // under GM_ARENA=0, take the hipMalloc path.  Contents are NOT zero (hipMalloc does not promise that either).
     // serial_lo / serial_hi: only pieces created as numbers [lo, hi) (arena_grow); split_serial != 0: every other piece
     // of the buffer from below that serial, the others from it on
+    // a temporary of a build step: from the arena's idle pieces (any of them) from 32 MiB up — a hipMalloc / hipFree pair
+    // per temporary is what stalls the NEXT hipMalloc for hundreds of milliseconds (the driver clears freed VRAM first)
+    int alloc_scratch(size_t nbytes)
+    {
+        if (arena_enabled() && nbytes >= ((size_t)32 << 20) && arena_site_enabled(2) &&
+            alloc_from_arena(nbytes, 0, 1, 0, ~0ull, 0) == GM_OK)
+            return GM_OK;
+        return alloc(nbytes);
+    }
     // split_serial != 0: half of the pieces from serials [serial_lo, older_hi ? older_hi : split_serial), half from
     // [split_serial, serial_hi), interleaved
     int alloc_big(size_t nbytes, uint64_t spread_seed = 0, size_t spread_factor = 4, uint64_t serial_lo = 0,

@@ -1818,12 +1818,12 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     GM_TRY(pl->cidx.alloc((size_t)(n ? n : 1) * 2));
     pl->Racc = 1;
     DevBuf pos_h; // hub rows before each row (kept until the keys are built)
-    GM_TRY(pos_h.alloc(((size_t)n + 1) * 4));
+    GM_TRY(pos_h.alloc_scratch(((size_t)n + 1) * 4));
     pl->hub_first_host.assign(1, 0u);
     if (n) {
         DevBuf flag, pos, bin_rows;
-        GM_TRY(flag.alloc(((size_t)n + 1) * 4));
-        GM_TRY(pos.alloc(((size_t)n + 1) * 4));
+        GM_TRY(flag.alloc_scratch(((size_t)n + 1) * 4));
+        GM_TRY(pos.alloc_scratch(((size_t)n + 1) * 4));
         GM_TRY(bin_rows.alloc((size_t)pl->B * 4));
         hipLaunchKernelGGL(pb_hubflag_kernel, dim3(pb_grid((uint64_t)n + 1)), dim3(256), 0, 0, csr->offsets, n, pl->hub_deg,
                            flag.as<uint32_t>());
@@ -2102,11 +2102,11 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     const int tile_shift = bin_bits + jb;
     GM_CHECK(tile_bits + tile_shift <= 64, GM_ERR_RANGE, "pb_build: %u tiles x %u bins x %u segments do not fit a 64-bit key",
              pl->NT, Bv, NS);
-    GM_TRY(vstart.alloc((size_t)NS * 4));
-    GM_TRY(segkey.alloc((size_t)NS * 8));
-    GM_TRY(segkalt.alloc((size_t)NS * 8));
-    GM_TRY(segval.alloc((size_t)NS * 4));
-    GM_TRY(segbin.alloc((size_t)NS * 8));
+    GM_TRY(vstart.alloc_scratch((size_t)NS * 4));
+    GM_TRY(segkey.alloc_scratch((size_t)NS * 8));
+    GM_TRY(segkalt.alloc_scratch((size_t)NS * 8));
+    GM_TRY(segval.alloc_scratch((size_t)NS * 4));
+    GM_TRY(segbin.alloc_scratch((size_t)NS * 8));
     hipLaunchKernelGGL(pb_segments_kernel, dim3(gm_), dim3(256), 0, 0, keys.as<uint64_t>(), flag.as<uint32_t>(),
                        segid.as<uint32_t>(), m, bin_bits, sb, pl->s_log, jb, vstart.as<uint32_t>(), segkey.as<uint64_t>(),
                        segbin.as<uint64_t>());
@@ -2130,14 +2130,14 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     GM_HIP(hipGetLastError());
 
     DevBuf cnt, cs, cntv, vstart4, tile_seg, tile_pad, pstart, rank_of;
-    GM_TRY(cnt.alloc(((size_t)NS + 1) * 4));
-    GM_TRY(cs.alloc(((size_t)NS + 1) * 4));
-    GM_TRY(cntv.alloc(((size_t)NS + 1) * 4));
-    GM_TRY(vstart4.alloc(((size_t)NS + 1) * 4));
+    GM_TRY(cnt.alloc_scratch(((size_t)NS + 1) * 4));
+    GM_TRY(cs.alloc_scratch(((size_t)NS + 1) * 4));
+    GM_TRY(cntv.alloc_scratch(((size_t)NS + 1) * 4));
+    GM_TRY(vstart4.alloc_scratch(((size_t)NS + 1) * 4));
     GM_TRY(tile_seg.alloc(((size_t)pl->NT + 1) * 4));
     GM_TRY(tile_pad.alloc(((size_t)pl->NT + 1) * 4));
-    GM_TRY(pstart.alloc((size_t)NS * 4));
-    GM_TRY(rank_of.alloc((size_t)NS * 4));
+    GM_TRY(pstart.alloc_scratch((size_t)NS * 4));
+    GM_TRY(rank_of.alloc_scratch((size_t)NS * 4));
     GM_TRY(pl->delta.alloc((size_t)NS * 4));
     hipLaunchKernelGGL(pb_seg_counts_kernel, dim3(gs), dim3(256), 0, 0, segval.as<uint32_t>(), vstart.as<uint32_t>(), NS,
                        m, cnt.as<uint32_t>(), cntv.as<uint32_t>());
