@@ -128,6 +128,18 @@ void arena_va_free(int dev, void *ptr, size_t span)
     a.va_free.emplace(span, static_cast<char *>(ptr));
 }
 
+size_t arena_piece_bytes()
+{
+    static const size_t bytes = [] {
+        const char *v = getenv("GM_ARENA_PIECE_MIB");
+        long mib = v && *v ? atol(v) : 64;
+        if (mib < 2 || mib > 4096 || (mib & (mib - 1)))
+            mib = 64;
+        return (size_t)mib << 20;
+    }();
+    return bytes;
+}
+
 bool arena_enabled()
 {
     static const bool on = [] {

@@ -72,7 +72,9 @@ struct DeviceSwitch { // sets the current device for a scope (DeviceGuard below 
 };
 
 // arena.hip: the library's own supply of 64 MiB physical pieces for its large buffers
-constexpr size_t ARENA_PIECE = (size_t)64 << 20;
+// Size of the arena's physical pieces (GM_ARENA_PIECE_MIB, read once; a power of two from 2 to 4096).
+size_t arena_piece_bytes();
+#define ARENA_PIECE (gm::arena_piece_bytes())
 constexpr size_t ARENA_MIN = (size_t)128 << 20; // smaller buffers stay with hipMalloc
 struct ArenaPiece {
     hipMemGenericAllocationHandle_t handle;
