@@ -151,6 +151,7 @@ struct DevBuf {
             arena_give(arena_dev, arena);
             vmm_chunk = vmm_span = 0;
         } else if (vmm_span) {
+            (void)hipDeviceSynchronize(); // as hipFree would: a kernel may still be using the buffer
             if (p) {
                 for (size_t i = 0; i < vmm.size(); ++i)
                     (void)hipMemUnmap(static_cast<char *>(p) + i * vmm_chunk, vmm_chunk);

@@ -2556,6 +2556,27 @@ int pb_scratch_create(const PbPlan *pl, PbScratch **out, DevBuf *early)
                     consider(cand, variant == 0 ? "a fresh 8 GiB behind the pool" : "half pool, half fresh");
             }
         }
+        // Last resort.  In a process where every set of arena pieces is slow (about one in four: 1.45-1.59 ms), memory obtained
+        // in OTHER ways was measured faster — fresh VMM pieces of 256 MiB 1.33 ms, plain hipMalloc 1.37 ms against 1.575 ms for
+        // eight arena candidates (profiles/r03_placement_piece_size.txt, third box) — although both are slower than the
+        // arena wherever the arena is fast.  So they are tried only here, and only kept if they win.
+        if (draws > 1 && rc == GM_OK && he == hipSuccess && sc->vals_raw.p && moved / (best_ms * 1e-3) < bw_min &&
+            pb_env("GM_PB_LAST_RESORT", 1)) {
+            {
+                DevBuf cand;
+                if (cand.alloc_vmm(bytes, (size_t)256 << 20, 0) == GM_OK)
+                    consider(cand, "fresh VMM pieces of 256 MiB");
+                else
+                    (void)hipGetLastError();
+            }
+            if (he == hipSuccess && moved / (best_ms * 1e-3) < bw_min) {
+                DevBuf cand;
+                if (cand.alloc(bytes) == GM_OK)
+                    consider(cand, "plain hipMalloc");
+                else
+                    (void)hipGetLastError();
+            }
+        }
         if (const char *gm = getenv("GM_PB_GROW_MAP")) { // measurement (profiles/r03_placement_grow_map.txt): which later stretches
             // of memory are fast alone, which pair well with the pool?  k-th stretch of 8 GiB created behind the pool, timed
             // alone and half-and-half with the pool as it was; one candidate at a time
