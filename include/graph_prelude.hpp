@@ -89,6 +89,13 @@ public:
     const gm_csr *csr_out() const { return out_.get(); }
     const gm_csr *csr_inc() const { return inc_.get(); }
     CsrLayout layout() const { return layout_; }
+    // not in the reference: releases what the device handles parked for later calls (PageRank plan and call state, SSSP / WCC
+    // working sets, the multi-GPU state); the graph stays resident, the next call rebuilds what it needs
+    void release_device_caches() const
+    {
+        detail::check(gm_csr_trim(out_.get()));
+        detail::check(gm_csr_trim(inc_.get()));
+    }
     // ToUndirectedOp::to_undirected (crates/builder/src/graph_ops.rs:176-230); defined after UndirectedCsrGraph
     template <class U = NI> auto to_undirected(CsrLayout layout) const;
 
@@ -118,6 +125,7 @@ public:
         host_ = detail::HostCsr{};
     }
     const gm_csr *csr() const { return csr_.get(); }
+    void release_device_caches() const { detail::check(gm_csr_trim(csr_.get())); } // the triangle count's DAG, WCC working set
 
 private:
     const detail::HostCsr &host() const { detail::load(csr_.get(), host_); return host_; }

@@ -69,6 +69,12 @@ int main(int argc, char **argv)
                     EXPECT(std::fabs(many[i] - one[i]) <= 2e-7f * one[i]);
                 (void)e;
             }
+            // what the handles parked (plan, call state, the multi-GPU state) released: the next calls rebuild and agree
+            g.release_device_caches();
+            EXPECT(gm_trim(-1) == GM_OK);
+            auto [again, it2, e2] = page_rank(g, PageRankConfig{12, 0.0, 0.85f}, GM_PR_JACOBI);
+            EXPECT(it2 == it1 && again == one);
+            (void)e2;
             (void)e1;
         }
         { // crates/algos/src/wcc.rs:307-329
