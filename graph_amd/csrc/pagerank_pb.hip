@@ -675,7 +675,7 @@ struct alignas(8) U16x4 {
 };
 
 constexpr int PB_BIN_U = 4;         // 256-entry blocks a wavefront of pb_bin_kernel handles per pipeline stage
-constexpr int PB_ACC_U = 2;         // float4 groups per lane and pipeline stage of pb_accum_kernel's value stream
+constexpr int PB_ACC_DEPTH = 4;     // register groups (float4 + 4 slots per lane) of pb_accum_kernel's value stream in flight
 constexpr int PB_EPI = 2;           // groups of 4 rows a lane of the accumulate epilogue keeps in flight
 constexpr uint32_t PB_DCACHE = 4096; // segment deltas cached in LDS per workgroup (16 KiB)
 
@@ -803,7 +803,7 @@ __device__ __forceinline__ unsigned long long pb_to_fix(float x)
     return (unsigned long long)(x * PB_FIX_SCALE); // exact scaling by 2^62, truncation below 2^-62
 }
 
-template <int ABL>
+template <int ABL, int D = PB_ACC_DEPTH>
 __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__restrict__ vals,
                                                                 const uint16_t *__restrict__ p2_dst,
                                                                 const PbItem *__restrict__ items,
@@ -824,30 +824,30 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
     const uint32_t b = item.bin, tid = threadIdx.x;
     float *hot = reinterpret_cast<float *>(acc + Racc); // the out_scores of one tier of hot sources (H at most)
     const uint32_t qb = item.q0, qe = (ABL == 4 ? item.q0 : item.q1); // multiples of 4
-    constexpr int U = PB_ACC_U;
     constexpr uint32_t STEP = PB_ACC_BLOCK * PB_VEC;
     // Every phase keeps several independent loads per lane in flight and the first group of the value
     // stream is requested before the prologue: with one or two workgroups per CU nothing else hides a
     // phase that waits for one load at a time (measured at scale 26: hot table 27 + hot edges 18 +
     // epilogue 32 dependent round trips per workgroup were a third of the kernel).
-    f32x4 v[U];
-    U16x4 d[U];
-    auto fetch = [&](uint32_t q0, f32x4(&vv)[U], U16x4(&dd)[U]) {
-#pragma unroll
-        for (int k = 0; k < U; ++k) {
-            const uint32_t q = q0 + k * STEP;
-            if (q < qe) {
-                vv[k] = *reinterpret_cast<const f32x4 *>(vals + q);
-                const u32x2 raw = *reinterpret_cast<const u32x2 *>(p2_dst + q);
-                dd[k] = U16x4{(uint16_t)raw.x, (uint16_t)(raw.x >> 16), (uint16_t)raw.y, (uint16_t)(raw.y >> 16)};
-            } else {
-                dd[k] = U16x4{PB_NULL, PB_NULL, PB_NULL, PB_NULL};
-            }
+    // The value stream runs through a RING of D register groups: a group is consumed and at once refilled with the entries
+    // D steps ahead, so D groups (D x 24 bytes per lane, 96 KiB per workgroup) are in flight all the time — the earlier
+    // "fetch the next pair, consume this pair, copy" kept two in flight with the same number of registers, and with one
+    // workgroup per CU the bytes in flight are what the CU's share of the HBM bandwidth is made of.
+    f32x4 v[D];
+    U16x4 d[D];
+    auto fetch1 = [&](uint32_t q, f32x4 &vv, U16x4 &dd) {
+        if (q < qe) {
+            vv = *reinterpret_cast<const f32x4 *>(vals + q);
+            const u32x2 raw = *reinterpret_cast<const u32x2 *>(p2_dst + q);
+            dd = U16x4{(uint16_t)raw.x, (uint16_t)(raw.x >> 16), (uint16_t)raw.y, (uint16_t)(raw.y >> 16)};
+        } else {
+            dd = U16x4{PB_NULL, PB_NULL, PB_NULL, PB_NULL};
         }
     };
     const uint32_t q_first = qb + tid * PB_VEC;
-    if (q_first < qe)
-        fetch(q_first, v, d);
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+        fetch1(q_first + (uint32_t)k * STEP, v[k], d[k]);
     for (uint32_t i = tid; i < Racc; i += PB_ACC_BLOCK)
         acc[i] = 0ull;
     // hot edges of this item, tier by tier: [ha, hb) inside the (bin, tier) cell; a slice of an over-long bin takes its
@@ -909,14 +909,9 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
             tier_store(tier, round, table);
         }
     __syncthreads();
-    for (uint32_t q0 = q_first; q0 < qe; q0 += STEP * U) {
-        f32x4 vn[U];
-        U16x4 dn[U];
-        const uint32_t qn = q0 + STEP * U;
-        if (qn < qe)
-            fetch(qn, vn, dn);
+    for (uint32_t q0 = q_first; q0 < qe; q0 += STEP * D) {
 #pragma unroll
-        for (int k = 0; k < U; ++k) {
+        for (int k = 0; k < D; ++k) {
             if (d[k].a != PB_NULL)
                 atomicAdd(&acc[d[k].a], pb_to_fix(v[k].x));
             if (d[k].b != PB_NULL)
@@ -925,13 +920,7 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
                 atomicAdd(&acc[d[k].c], pb_to_fix(v[k].z));
             if (d[k].d != PB_NULL)
                 atomicAdd(&acc[d[k].d], pb_to_fix(v[k].w));
-        }
-        if (qn < qe) {
-#pragma unroll
-            for (int k = 0; k < U; ++k) {
-                v[k] = vn[k];
-                d[k] = dn[k];
-            }
+            fetch1(q0 + (uint32_t)(k + D) * STEP, v[k], d[k]);
         }
     }
     // hot edges: 4 bytes each (row_in_bin << 16 | index inside the tier), the value comes from the tier's LDS table.
@@ -2259,6 +2248,8 @@ static hipError_t pb_set_kernel_attributes()
         reinterpret_cast<const void *>(&pb_bin_kernel<5, 14>), reinterpret_cast<const void *>(&pb_bin_kernel<0, 15>),
         reinterpret_cast<const void *>(&pb_bin_kernel<3, 15>), reinterpret_cast<const void *>(&pb_bin_kernel<5, 15>)};
     const void *acc_fns[] = {reinterpret_cast<const void *>(&pb_accum_kernel<0>),
+                             reinterpret_cast<const void *>(&pb_accum_kernel<0, 2>),
+                             reinterpret_cast<const void *>(&pb_accum_kernel<0, 6>),
                              reinterpret_cast<const void *>(&pb_accum_kernel<3>),
                              reinterpret_cast<const void *>(&pb_accum_kernel<4>)};
     hipError_t e = hipSuccess;
@@ -2713,11 +2704,11 @@ void pb_launch_bin(const PbPlan *pl, PbScratch *sc, const float *x_in, uint32_t 
                        pl->chunk, w_first, pl->xcd_aware, item_list);
 }
 
-template <int ABL>
+template <int ABL, int D = PB_ACC_DEPTH>
 void pb_launch_accum(const PbPlan *pl, PbScratch *sc, const PbItem *items, uint32_t count, float *x_out, float *scores,
                      const uint32_t *outdeg, float base, float damping, hipStream_t st)
 {
-    hipLaunchKernelGGL(pb_accum_kernel<ABL>, dim3(count), dim3(PB_ACC_BLOCK),
+    hipLaunchKernelGGL((pb_accum_kernel<ABL, D>), dim3(count), dim3(PB_ACC_BLOCK),
                        (size_t)pl->Racc * 8 + (((size_t)pl->H + 3) & ~(size_t)3) * 4 * (pl->T > 1 ? 2 : 1), st, sc->vals,
                        pl->p2_dst.as<uint16_t>(),
                        items, pl->hot_ent.as<uint32_t>(), pl->hbin_v.as<uint32_t>(), sc->hot_x.as<float>(), pl->H, pl->T, pl->Htot,
@@ -2758,7 +2749,13 @@ static void pb_accum_dispatch(const PbPlan *pl, PbScratch *sc, const PbItem *ite
     switch (pb_env("GM_PB_ABLATE", 0) / 10) {
     case 3: pb_launch_accum<3>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
     case 4: pb_launch_accum<4>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
-    default: pb_launch_accum<0>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
+    default:
+        switch (pb_env("GM_PB_ACC_DEPTH", PB_ACC_DEPTH)) { // measurement: register groups of the value stream in flight
+        case 2: pb_launch_accum<0, 2>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
+        case 6: pb_launch_accum<0, 6>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
+        default: pb_launch_accum<0>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
+        }
+        break;
     }
 }
 
