@@ -88,6 +88,9 @@ int arena_va_alloc(int dev, size_t span, void **out)
 {
     Arena &a = arena_of(dev);
     std::lock_guard<std::mutex> lock(a.mu);
+    // exact size only: a stretch is reused for a buffer of the size it held before.  (Best fit with split remainders was
+    // tried — tools/runs/r03_call60.sh — and a process then hung: mapping into a PART of a range that had carried a larger
+    // mapping is one more thing this runtime does not take well.  Buffers come in a few recurring sizes.)
     auto it = a.va_free.find(span);
     if (it != a.va_free.end()) {
         *out = it->second;
