@@ -44,6 +44,24 @@ def test_partitioned_page_rank_matches_the_single_gpu_engine(P, oracle, devices,
     assert np.array_equal(got0, one0)
 
 
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0, 0, 0]])
+def test_partitioned_page_rank_matches_the_reference_directly(P, oracle, devices):
+    """The partitioned engine against the ORACLE (the reference's threaded path, page_rank.rs:113-168), both at their
+    fixed points, on every row — not through the single-GPU engine.  Scale 18: hub rows (>= 4096 in-edges) exist and
+    are cut by the rank boundaries (in-degree ranges, graph_ops.rs:431-439,479-509)."""
+    g, indeg = _graph(P, oracle, 18)
+    assert int((indeg >= 4096).sum()) > 0
+    cfg = P.PageRankConfig(200, 1e-10, 0.85)
+    got, it, _ = P.page_rank_multi(g, cfg, devices=devices)
+    ioff, itgt, _ = g.csr_inc.host()
+    ref, it_ref, _ = oracle.page_rank_chunked(ioff, itgt, g.csr_out.degrees().astype(np.uint32), 200, 1e-10, 0.85)
+    rel = np.abs(got.astype(np.float64) - ref) / ref
+    print(f"{len(devices)} virtual ranks, scale 18: {it} sweeps (reference {it_ref}); max rel {rel.max():.2e} on every row, "
+          f"{rel[indeg >= 4096].max():.2e} on hub rows")
+    assert rel.max() <= 1e-5, rel.max()
+    assert rel.max() <= 8e-6
+
+
 def test_partitioned_page_rank_stop_rule_and_default_engines(P, oracle):
     g, _ = _graph(P, oracle, 15, seed=7)
     ref, it_ref, err_ref = P.page_rank(g, P.PageRankConfig(), P.PageRankMode.Jacobi)
