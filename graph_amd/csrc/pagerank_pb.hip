@@ -76,6 +76,10 @@ struct HubUnit {
 constexpr uint32_t PB_HUB_MAX = 64;  // rows of a hub group (one lane of a wavefront each)
 constexpr uint16_t PB_HUBROW = 0xFFFEu; // cidx of a hub row: its sum is produced by pb_hub_kernel, not by its bin
 constexpr uint16_t PB_FLAG = 0x8000u;
+constexpr uint32_t PB_SEQ_WG = 256;  // threads of a pb_hubseq_kernel workgroup (wavefront 0 walks, all four stage)
+constexpr uint32_t PB_SEQ_PAD = 16;  // a row's stretch of the staged block is padded to 16 floats (4 x ds_read_b128 per step)
+constexpr uint32_t PB_SEQ_BUF = PB_ACC_BLOCK * PB_VEC + PB_HUB_MAX * (PB_SEQ_PAD - 1); // floats: 4096 terms + the rows' padding
+constexpr size_t PB_SEQ_LDS = 20480; // static LDS of pb_hubseq_kernel, rounded up
 constexpr int PB_TIERS_DEFAULT = 16;  // at most this many tiers of hot sources unless GM_PB_TIERS says otherwise
 constexpr float PB_FIX_SCALE = 4611686018427387904.0f;     // 2^62
 constexpr float PB_FIX_INV = 2.168404344971008868e-19f;    // 2^-62
@@ -163,6 +167,13 @@ struct PbPlan {
     DevBuf few_blk_first;  // u32[G_few + 1]
     DevBuf few_blk_group;  // u32[few_blocks] group (index into hub_items) of every block
     std::vector<uint32_t> hub_first_host;
+    // hub groups of three or more rows, hub_items[G_few .. G): walked by pb_hubseq_kernel with one lane per row, every row sum
+    // the reference's own left-to-right f32 sum (page_rank.rs:143-146) bit for bit.  Their part of p2_dst holds, instead of
+    // the row slot, the entry's place in the row-major LDS arrangement of its 4096-entry block (pb_hubseq_layout_kernel).
+    uint32_t hub_seq = 1;  // GM_PB_HUB_SEQ=0 (measurement): the step-wise emulation of pb_hub_kernel for every group
+    uint32_t seq_blocks = 0;
+    DevBuf seq_blk_first;  // u32[G - G_few + 1] first block of each such group, in hub_items order
+    DevBuf seq_rows;       // u32[seq_blocks x 64] per block and row: first LDS slot << 16 | terms of the row in this block
     double build_ms = 0.0; // wall time of pb_build (device work included)
     uint32_t NT = 0;       // source tiles
     uint32_t NS = 0;       // non-empty (tile, bin) segments
@@ -1605,6 +1616,242 @@ __global__ __launch_bounds__(PB_CHAIN_WG) void pb_hubchain_kernel(const float *_
     }
 }
 
+// ---- hub groups of three or more rows: the reference's own sums ------------------------------------------------------
+// The reference adds a row's terms left to right in f32 (page_rank.rs:143-146).  pb_hub_kernel imitates that with integer
+// counts of ulps per 4096-entry step (~300 wavefront instructions per step on sixteen wavefronts: it kept a quarter of the
+// chip's issue slots busy beside the accumulate kernel).  Here the sum is simply COMPUTED that way: a group's stream is
+// sorted by source with its rows interleaved, so at plan time every 4096-entry block gets a stable permutation that makes
+// it row-major (pb_hubseq_layout_kernel: p2_dst holds the entry's place in the block's LDS arrangement, `rows` the first
+// place and the number of terms of every row), and per block the workgroup's four wavefronts scatter the values into LDS
+// while lane g of wavefront 0 adds row g's terms in order: S = S + v, one v_add_f32 per term.  The sum is the reference's
+// bit for bit for the same out_scores, whatever the partition; a block costs ~16 terms-per-row steps of one wavefront
+// instead of ~4800 wavefront instructions.  What stays serial is the chain of a row's adds (~5 cycles per term): groups of
+// one or two rows — rows of 10^5 ... 10^6 terms — keep the block-parallel emulation below (pb_hubchain_*).
+__global__ __launch_bounds__(PB_ACC_BLOCK) void pb_hubseq_layout_kernel(const PbHubItem *__restrict__ items,
+                                                                         const uint32_t *__restrict__ blk_first, uint32_t n_groups,
+                                                                         uint16_t *__restrict__ p2_dst, uint32_t *__restrict__ rows)
+{
+    constexpr uint32_t STEP = PB_ACC_BLOCK * PB_VEC, NWV = PB_ACC_BLOCK / kWave, NONE = PB_HUB_MAX;
+    __shared__ uint32_t hist[NWV][PB_HUB_MAX + 1]; // terms of every row per wavefront, then their exclusive prefix
+    __shared__ uint32_t rbase[PB_HUB_MAX + 1];
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    // the group of this block: the last g with blk_first[g] <= blockIdx.x
+    const uint32_t g = (uint32_t)lower_bound_fn(0, n_groups + 1, (uint64_t)blockIdx.x + 1, [&](uint64_t k) { return (uint64_t)blk_first[k]; }) - 1u;
+    const PbHubItem item = items[g];
+    const uint32_t q0 = item.q0 + (blockIdx.x - blk_first[g]) * STEP;
+    const uint32_t q1 = (item.q1 - q0) < STEP ? item.q1 : q0 + STEP;
+    for (uint32_t i = tid; i < NWV * (PB_HUB_MAX + 1); i += PB_ACC_BLOCK)
+        (&hist[0][0])[i] = 0u;
+    __syncthreads();
+    const uint32_t q = q0 + tid * PB_VEC;
+    uint32_t s[4] = {NONE, NONE, NONE, NONE};
+    if (q < q1) {
+        const u32x2 raw = *reinterpret_cast<const u32x2 *>(p2_dst + q);
+        const uint32_t v[4] = {raw.x & 0xFFFFu, raw.x >> 16, raw.y & 0xFFFFu, raw.y >> 16};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            s[k] = v[k] < item.nh ? v[k] : NONE; // padding entries (PB_NULL) keep no place
+    }
+    // stable rank of an entry among the entries of its row: entries before it in this wavefront (stream order = lane-major)
+    // by matching the 7 bits of the row number against ballots, wavefronts before it through the histogram
+    uint64_t bm[4][7];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int bit = 0; bit < 7; ++bit)
+            bm[k][bit] = __ballot((s[k] >> bit) & 1u);
+    const uint64_t lt = (1ull << lane) - 1ull;
+    uint32_t rank[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) {
+            uint64_t m = ~0ull;
+#pragma unroll
+            for (int bit = 0; bit < 7; ++bit)
+                m &= ((s[k] >> bit) & 1u) ? bm[k2][bit] : ~bm[k2][bit];
+            c += (uint32_t)__popcll(m & lt) + ((k2 < k && s[k2] == s[k]) ? 1u : 0u);
+        }
+        rank[k] = c;
+        if (s[k] != NONE)
+            atomicAdd(&hist[wave][s[k]], 1u);
+    }
+    __syncthreads();
+    if (tid < PB_HUB_MAX) {
+        uint32_t c = 0;
+        for (uint32_t w = 0; w < NWV; ++w) {
+            const uint32_t t = hist[w][tid];
+            hist[w][tid] = c;
+            c += t;
+        }
+        rbase[tid] = c;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t at = 0;
+        for (uint32_t r = 0; r < PB_HUB_MAX; ++r) {
+            const uint32_t c = rbase[r];
+            rbase[r] = at;
+            rows[(size_t)blockIdx.x * PB_HUB_MAX + r] = (at << 16) | c;
+            at += (c + PB_SEQ_PAD - 1u) & ~(PB_SEQ_PAD - 1u);
+        }
+    }
+    __syncthreads();
+    if (q < q1) {
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            o[k] = s[k] != NONE ? rbase[s[k]] + hist[wave][s[k]] + rank[k] : (uint32_t)PB_NULL;
+        u32x2 raw;
+        raw.x = o[0] | (o[1] << 16), raw.y = o[2] | (o[3] << 16);
+        *reinterpret_cast<u32x2 *>(p2_dst + q) = raw;
+    }
+}
+
+__global__ __launch_bounds__(PB_SEQ_WG) void pb_hubseq_kernel(const float *__restrict__ vals, const uint16_t *__restrict__ p2_dst,
+                                                              const PbHubItem *__restrict__ items,
+                                                              const uint32_t *__restrict__ blk_first,
+                                                              const uint32_t *__restrict__ rows,
+                                                              const uint32_t *__restrict__ hub_rows,
+                                                              const uint32_t *__restrict__ outdeg, float *__restrict__ scores,
+                                                              float *__restrict__ x_out, double *__restrict__ group_err, float base,
+                                                              float damping)
+{
+    constexpr uint32_t STEP = PB_ACC_BLOCK * PB_VEC;            // entries of a block
+    constexpr int PER = (int)(STEP / (PB_SEQ_WG * PB_VEC));     // float4 + 4 places per thread and block
+    __shared__ __attribute__((aligned(16))) float buf[PB_SEQ_BUF + 4]; // + where the padding entries of the stream land
+    __shared__ double red[PB_SEQ_WG / kWave];
+    const PbHubItem item = items[blockIdx.x]; // longest groups first
+    const uint32_t tid = threadIdx.x, nh = item.nh;
+    const bool walker = tid < nh; // nh <= 64: lane g of wavefront 0 owns row g
+    const uint32_t nb = (item.q1 - item.q0 + STEP - 1u) / STEP;
+    const uint32_t *ri = rows + (size_t)blk_first[blockIdx.x] * PB_HUB_MAX;
+    // a block's values and places on their way from memory: two sets, so that block b + 2 is requested before block b is
+    // walked (with one block of lookahead a group of many short rows spent its time waiting for the next block: the
+    // latency of a global load under the accumulate kernel's traffic is longer than the walk of ~64 terms per row)
+    struct Staged {
+        f32x4 v[PER];
+        u32x2 d[PER];
+    } sa, sb;
+    auto load = [&](uint32_t b, Staged &st) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const uint32_t q = item.q0 + b * STEP + ((uint32_t)j * PB_SEQ_WG + tid) * PB_VEC;
+            st.d[j].x = st.d[j].y = 0xFFFFFFFFu;
+            if (q < item.q1) {
+                st.v[j] = *reinterpret_cast<const f32x4 *>(vals + q);
+                st.d[j] = *reinterpret_cast<const u32x2 *>(p2_dst + q);
+            }
+        }
+    };
+    auto scatter = [&](const Staged &st) { // no branch per term: a padding entry (PB_NULL) goes to the slot behind the buffer
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const uint32_t p0 = st.d[j].x & 0xFFFFu, p1 = st.d[j].x >> 16, p2 = st.d[j].y & 0xFFFFu, p3 = st.d[j].y >> 16;
+            buf[p0 < PB_SEQ_BUF ? p0 : PB_SEQ_BUF] = st.v[j].x;
+            buf[p1 < PB_SEQ_BUF ? p1 : PB_SEQ_BUF] = st.v[j].y;
+            buf[p2 < PB_SEQ_BUF ? p2 : PB_SEQ_BUF] = st.v[j].z;
+            buf[p3 < PB_SEQ_BUF ? p3 : PB_SEQ_BUF] = st.v[j].w;
+        }
+    };
+    // zeros behind a row's terms up to its 16-float boundary: the walk adds whole steps (x + 0 = x)
+    auto pads = [&](uint32_t info) {
+        const uint32_t at = (info >> 16) + (info & 0xFFFFu), end = (info >> 16) + (((info & 0xFFFFu) + PB_SEQ_PAD - 1u) & ~(PB_SEQ_PAD - 1u));
+#pragma unroll
+        for (uint32_t j = 0; j < PB_SEQ_PAD - 1u; ++j)
+            if (at + j < end)
+                buf[at + j] = 0.0f;
+    };
+    uint32_t info = 0, info_a = 0, info_b = 0; // row info of the block in the buffer / staged in sa / in sb
+    if (tid < kWave)
+        __builtin_amdgcn_s_setprio(3); // the walk is the group's critical path: first in line at its SIMD's issue
+    load(0, sa);
+    if (walker) {
+        info = ri[tid];
+        pads(info);
+    }
+    scatter(sa);
+    if (nb > 1u) {
+        load(1u, sa);
+        if (walker)
+            info_a = ri[(size_t)PB_HUB_MAX + tid];
+    }
+    __syncthreads();
+    float S = 0.0f; // page_rank.rs:143: the row's sum starts at zero ...
+    const f32x4 *b4 = reinterpret_cast<const f32x4 *>(buf);
+    // one block: `cur` holds block b + 1 (requested one round ago), block b + 2 is requested into `nxt`, block b is walked
+    auto round = [&](uint32_t b, Staged &cur, uint32_t &info_cur, Staged &nxt, uint32_t &info_nxt) {
+        const bool more = b + 1u < nb;
+        if (b + 2u < nb) {
+            load(b + 2u, nxt);
+            if (walker)
+                info_nxt = ri[(size_t)(b + 2u) * PB_HUB_MAX + tid];
+        }
+        if (walker) {
+            uint32_t k = (info >> 16) / 4u;
+            const uint32_t end = k + (((info & 0xFFFFu) + PB_SEQ_PAD - 1u) / PB_SEQ_PAD) * (PB_SEQ_PAD / 4u);
+            if (k < end) {
+                // Three register sets in turn, no copies: a step's 16 terms are requested two steps before they are added
+                // (16 dependent v_add_f32 = 64 cycles; an LDS round trip is longer than that — with one step of lookahead the
+                // walk measured ~12 cycles per term).  Every term is added to the sum in CSR order, each add rounded to f32
+                // (page_rank.rs:144-146).
+                constexpr uint32_t Q = PB_SEQ_PAD / 4u;
+                f32x4 a0, a1, a2, a3, n0, n1, n2, n3, c0, c1, c2, c3;
+#define GM_SEQ_GET(x0, x1, x2, x3, at) x0 = b4[at], x1 = b4[(at) + 1], x2 = b4[(at) + 2], x3 = b4[(at) + 3]
+#define GM_SEQ_ADD(x0, x1, x2, x3)                                                                                          \
+    S = __fadd_rn(S, x0.x), S = __fadd_rn(S, x0.y), S = __fadd_rn(S, x0.z), S = __fadd_rn(S, x0.w);                         \
+    S = __fadd_rn(S, x1.x), S = __fadd_rn(S, x1.y), S = __fadd_rn(S, x1.z), S = __fadd_rn(S, x1.w);                         \
+    S = __fadd_rn(S, x2.x), S = __fadd_rn(S, x2.y), S = __fadd_rn(S, x2.z), S = __fadd_rn(S, x2.w);                         \
+    S = __fadd_rn(S, x3.x), S = __fadd_rn(S, x3.y), S = __fadd_rn(S, x3.z), S = __fadd_rn(S, x3.w)
+                GM_SEQ_GET(a0, a1, a2, a3, k);
+                if (k + Q < end)
+                    GM_SEQ_GET(n0, n1, n2, n3, k + Q);
+                for (;;) { // a = step k, n = step k + Q (if any): request k + 2Q, add k
+                    if (k + 2u * Q < end)
+                        GM_SEQ_GET(c0, c1, c2, c3, k + 2u * Q);
+                    GM_SEQ_ADD(a0, a1, a2, a3);
+                    k += Q;
+                    if (k >= end)
+                        break;
+                    if (k + 2u * Q < end)
+                        GM_SEQ_GET(a0, a1, a2, a3, k + 2u * Q);
+                    GM_SEQ_ADD(n0, n1, n2, n3);
+                    k += Q;
+                    if (k >= end)
+                        break;
+                    if (k + 2u * Q < end)
+                        GM_SEQ_GET(n0, n1, n2, n3, k + 2u * Q);
+                    GM_SEQ_ADD(c0, c1, c2, c3);
+                    k += Q;
+                    if (k >= end)
+                        break;
+                }
+#undef GM_SEQ_ADD
+#undef GM_SEQ_GET
+            }
+            if (more)
+                pads(info_cur); // the next block's arrangement: these slots are not among the places its terms are scattered to
+        }
+        __syncthreads(); // the walk is over: the buffer may be overwritten
+        if (more)
+            scatter(cur);
+        info = info_cur;
+        __syncthreads();
+    };
+    for (uint32_t b = 0; b < nb; b += 2u) {
+        round(b, sa, info_a, sb, info_b);
+        if (b + 1u < nb)
+            round(b + 1u, sb, info_b, sa, info_a);
+    }
+    double err = 0.0;
+    if (walker)
+        err = pr_finalize(hub_rows[item.row0 + tid], S, base, damping, outdeg, scores, x_out);
+    const double total = block_sum<double, PB_SEQ_WG / kWave>(err, red);
+    if (tid == 0)
+        group_err[item.group] = total;
+}
+
 __global__ __launch_bounds__(1024) void pb_err_kernel(const double *__restrict__ bin_err, uint32_t B, double *__restrict__ err_out)
 {
     __shared__ double red[1024 / kWave];
@@ -1748,6 +1995,13 @@ int pb_make_items(PbPlan *pl)
             group.insert(group.end(), nb, g);
         }
         pl->few_blocks = first[pl->G_few];
+        // the groups of three or more rows: blocks of pb_hubseq_kernel
+        std::vector<uint32_t> sfirst(pl->G - pl->G_few + 1, 0u);
+        for (uint32_t g = pl->G_few; g < pl->G; ++g)
+            sfirst[g - pl->G_few + 1] = sfirst[g - pl->G_few] + (hubs[g].q1 - hubs[g].q0 + PB_ACC_BLOCK * PB_VEC - 1) / (PB_ACC_BLOCK * PB_VEC);
+        pl->seq_blocks = pl->hub_seq ? sfirst.back() : 0u;
+        GM_TRY(pl->seq_blk_first.alloc(sfirst.size() * 4));
+        GM_HIP(hipMemcpy(pl->seq_blk_first.p, sfirst.data(), sfirst.size() * 4, hipMemcpyHostToDevice));
         GM_TRY(pl->few_blk_first.alloc(first.size() * 4));
         GM_HIP(hipMemcpy(pl->few_blk_first.p, first.data(), first.size() * 4, hipMemcpyHostToDevice));
         GM_TRY(pl->few_blk_group.alloc((group.size() ? group.size() : 1) * 4));
@@ -1804,6 +2058,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     // accumulator slots only for rows that have in-edges (RMAT: about half of the rows have none); hub rows
     // (summed in the reference's order, see the header) leave the ordinary bins and form hub groups
     pl->hub_deg = (uint32_t)pb_env("GM_PB_HUB_DEG", 4096);
+    pl->hub_seq = pb_env("GM_PB_HUB_SEQ", 1) ? 1u : 0u;
     GM_TRY(pl->cidx.alloc((size_t)(n ? n : 1) * 2));
     pl->Racc = 1;
     DevBuf pos_h; // hub rows before each row (kept until the keys are built)
@@ -1890,7 +2145,9 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
             wgs = 1;
         // static LDS of the accumulate kernel: PB_ACC_STATIC; with hub groups, room for one pb_hub_kernel workgroup
         // (13.5 KiB) beside the accumulate workgroup(s) of a CU
-        const size_t hub_room = (pl->G && pb_env("GM_PB_HUB_FORK", 1)) ? 14336 : 0;
+        size_t hub_room = (pl->G && pb_env("GM_PB_HUB_FORK", 1)) ? (pl->hub_seq ? PB_SEQ_LDS : 14336) : 0;
+        if (pb_env("GM_PB_HUB_ROOM", -1) >= 0) // measurement: LDS left free beside an accumulate workgroup
+            hub_room = (size_t)pb_env("GM_PB_HUB_ROOM", -1);
         const size_t budget = wgs == 1 ? (163840 - hub_room - PB_ACC_STATIC - acc_bytes)
                                        : ((163840 - hub_room) / 2 - PB_ACC_STATIC - acc_bytes);
         H = (uint32_t)(budget / 4) & ~63u;
@@ -2178,6 +2435,14 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     GM_HIP(hipGetLastError());
     timer.done("pb plan: segment layout + stream fill");
     GM_TRY(pb_make_items(pl));
+    if (pl->seq_blocks) { // row-major places of the hub groups walked by pb_hubseq_kernel
+        GM_TRY(pl->seq_rows.alloc((size_t)pl->seq_blocks * PB_HUB_MAX * 4));
+        hipLaunchKernelGGL(pb_hubseq_layout_kernel, dim3(pl->seq_blocks), dim3(PB_ACC_BLOCK), 0, 0,
+                           pl->hub_items.as<PbHubItem>() + pl->G_few, pl->seq_blk_first.as<uint32_t>(), pl->G - pl->G_few,
+                           pl->p2_dst.as<uint16_t>(), pl->seq_rows.as<uint32_t>());
+        GM_HIP(hipGetLastError());
+        timer.done("pb plan: hub groups row-major (%u blocks)", pl->seq_blocks);
+    }
     // phase-1 workgroup list: a tile's stream is cut into chunks of 32768 entries (measured best on
     // MI355X at scales 22-26: enough workgroups to hide latency, x-tile reloads stay in L2)
     {
@@ -2635,15 +2900,21 @@ int pb_scratch_create(const PbPlan *pl, PbScratch **out, DevBuf *early)
         e = hipMemset(sc->par_fail.p, 0, sc->par_fail.bytes);
     if (e == hipSuccess)
         e = hipMemset(sc->vals_raw.p, 0, sc->vals_raw.bytes);
+    // The hub kernels' streams get the LOWEST priority the device offers (GM_PB_SIDE_PRIO=0: the default one): their small
+    // workgroups are meant to fill the room the accumulate workgroups leave on a CU, not to take CUs from them — several of
+    // them on one CU leave no room for an accumulate workgroup (143 KiB of LDS) until they have finished.
+    int prio_least = 0, prio_greatest = 0;
+    if (e == hipSuccess && pb_env("GM_PB_SIDE_PRIO", 1))
+        e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     if (e == hipSuccess && pl->few_blocks > pl->G_few) { // the long chains' own stream
-        e = hipStreamCreateWithFlags(&sc->chain, hipStreamNonBlocking);
+        e = hipStreamCreateWithPriority(&sc->chain, hipStreamNonBlocking, prio_least);
         if (e == hipSuccess)
             e = hipEventCreateWithFlags(&sc->ev_chain_fork, hipEventDisableTiming);
         if (e == hipSuccess)
             e = hipEventCreateWithFlags(&sc->ev_chain_join, hipEventDisableTiming);
     }
     if (e == hipSuccess && pl->G) { // the hub groups' own stream
-        e = hipStreamCreateWithFlags(&sc->side, hipStreamNonBlocking);
+        e = hipStreamCreateWithPriority(&sc->side, hipStreamNonBlocking, prio_least);
         if (e == hipSuccess)
             e = hipEventCreateWithFlags(&sc->ev_fork, hipEventDisableTiming);
         if (e == hipSuccess)
@@ -2769,7 +3040,7 @@ static void pb_hub_dispatch(const PbPlan *pl, PbScratch *sc, float *x_out, float
     // the long chains (groups of one or two rows) block-parallel on a stream of their own, beside the other groups: see
     // pb_hubchain_kernel (GM_PB_HUB_PAR=0: the sequential walk, all groups in one launch)
     const bool par = pl->G_few && pl->few_blocks > pl->G_few && sc->chain && pb_env("GM_PB_HUB_PAR", 1) && long2 == 0x7FFFFFFFu &&
-                     long4 == 0x7FFFFFFFu;
+                     long4 == 0x7FFFFFFFu && !(pb_env("GM_PB_HUB_SKIP", 0) & 2);
     const uint32_t first = par ? pl->G_few : 0u;
     if (par) {
         hipStream_t cs = sc->chain;
@@ -2792,8 +3063,14 @@ static void pb_hub_dispatch(const PbPlan *pl, PbScratch *sc, float *x_out, float
                            (unsigned long long *)nullptr, sc->par_fail.as<uint32_t>());
         (void)hipEventRecord(sc->ev_chain_join, cs);
     }
-    if (pl->G > first)
-        hipLaunchKernelGGL(pb_hub_kernel, dim3(pl->G - first), dim3(PB_ACC_BLOCK), 0, st, sc->vals, pl->p2_dst.as<uint16_t>(),
+    const uint32_t seq_first = pl->seq_blocks ? pl->G_few : pl->G; // groups [seq_first, G): the reference's own sums, one lane per row
+    const int skip = pb_env("GM_PB_HUB_SKIP", 0); // measurement (wrong results by design): 1 = no pb_hubseq_kernel, 2 = no long chains
+    if (pl->G > seq_first && !(skip & 1))
+        hipLaunchKernelGGL(pb_hubseq_kernel, dim3(pl->G - seq_first), dim3(PB_SEQ_WG), 0, st, sc->vals, pl->p2_dst.as<uint16_t>(),
+                           pl->hub_items.as<PbHubItem>() + seq_first, pl->seq_blk_first.as<uint32_t>(), pl->seq_rows.as<uint32_t>(),
+                           pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr, base, damping);
+    if (seq_first > first && !(skip & 2))
+        hipLaunchKernelGGL(pb_hub_kernel, dim3(seq_first - first), dim3(PB_ACC_BLOCK), 0, st, sc->vals, pl->p2_dst.as<uint16_t>(),
                            pl->hub_items.as<PbHubItem>() + first, pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr, base,
                            damping, long2, long4, graded, (unsigned long long *)nullptr, (const uint32_t *)nullptr);
     if (par)
