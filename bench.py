@@ -389,8 +389,8 @@ def main():
             "csr_build_s": round(t_build, 3), "final_sweep_error": final_err, "workgroups_per_sweep": engine.tiles, "engine": engine.engine,
             "plan_build_ms": round(plan["plan_build_us"] / 1e3, 2) if plan else None, "plan_rebuild_ms": plan_rebuild_ms,
             "plan_bytes": plan.get("plan_bytes") if plan else None, "scratch_bytes": plan.get("scratch_bytes") if plan else None,
-            "hub_rows_in_reference_order": {k: plan[k] for k in ("hub_in_degree", "hub_rows", "hub_edges", "hub_groups", "long_chain_groups",
-                                                               "long_chain_blocks", "long_chains_fell_back")} if plan else None,
+            "hub_rows_in_reference_order": {k: plan[k] for k in ("hub_in_degree", "hub_rows", "hub_edges", "hub_groups", "long_rows",
+                                                               "long_row_terms", "hub_seq_blocks")} if plan else None,
             "hot_sources": plan.get("hot_sources") if plan else None, "hot_tiers": plan.get("hot_tiers") if plan else None,
             "hot_edges": plan.get("hot_edges") if plan else None, "value_entries": plan.get("value_entries") if plan else None,
             "value_stream_placement": {k: plan.get(k) for k in ("value_stream_from_arena", "draws_timed", "draw_best_us", "draw_worst_us",
@@ -398,7 +398,7 @@ def main():
             "parity": parity,
         },
         "roofline": {
-            "kernel": "pr_tile_kernel" if engine.engine == "pull" else "pb_bin_kernel+pb_accum_kernel+pb_hub_kernel",
+            "kernel": "pr_tile_kernel" if engine.engine == "pull" else "pb_bin_kernel+pb_accum_kernel+pb_hubseq_kernel+pb_hublong_kernel",
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(tile_ms_avg, 5),

@@ -36,13 +36,17 @@
 // ordinary bins: consecutive hub rows form HUB GROUPS (<= 64 rows, about one ordinary bin's worth of terms),
 // every group is one more "bin" of the value stream (so (tile, group) segments are as long as (tile, bin)
 // ones), and no hub row uses the hot path — all its terms arrive in the stream in ascending source order, the
-// CSR order of the Sorted / Deduplicated layouts.  pb_hub_kernel walks a group one 4096-entry step at a time:
-// a term v is first rounded to the f32 grid of the row's running sum S — rint(v / ulp(S)) * ulp(S), what
-// fl(S + v) - S is while S stays in one binade, whatever the order inside the step — and the step's rounded
-// terms are added as exact integers.  Between steps (one __syncthreads) S, its binade and ulp are updated; a
-// step in which S crosses into the next binade is resolved by interpolation between the step's sums rounded
-// at ulp and at 2 ulp.  Deterministic (integer sums, fixed step boundaries).  The kernel needs 13 KiB of LDS,
-// so its workgroups run beside the accumulate workgroups of the ordinary bins (second stream).
+// CSR order of the Sorted / Deduplicated layouts.  Their sums are then COMPUTED the reference's way, bit for bit
+// for the same out_scores (rounds 2 and 3 imitated the order with integer counts of ulps per 4096-entry step,
+// within ~3e-6 and at the price of as many vector instructions as the accumulate kernel itself):
+//   pb_hubseq_kernel   rows below `hub_long` terms (32768): a group's 4096-entry blocks are made row-major in LDS by a
+//                      permutation fixed at plan time, and lane g of one wavefront adds row g's terms in order,
+//                      one v_add_f32 per term;
+//   pb_hublong_kernel  longer rows, one workgroup each: inside one binade of the running sum S = J ulp, adding a term
+//                      v moves J by rint(v / ulp) — up or down on a tie as the parity of J says — so a run of terms is
+//                      a function (count from even J, count from odd J) and runs compose associatively: 512 threads
+//                      take 16 terms each, one scan gives every thread its J, and the thread in whose run S leaves
+//                      the binade adds its 16 terms the slow way before the rest is redone on the coarser grid.
 //
 // HBM traffic per edge and sweep: cold 2 B (source id) + 4 B (value write) + 4 B (value read) + 2 B (slot)
 // = 12 B, hot 4 B, all streaming, against 8 B "algorithmic" of which 4 B are a random gather.
@@ -67,19 +71,16 @@ constexpr int PB_ACC_BLOCK = 1024;
 constexpr uint32_t PB_VEC = 4;                  // segments are padded to multiples of 4 entries in both streams
 constexpr uint32_t PB_WBLK = kWave * PB_VEC;    // entries one wavefront covers per step (256)
 constexpr uint16_t PB_NULL = 0xFFFFu;
-constexpr uint32_t PB_HUB_Q = 256;      // replicated step sums of the hub rows of a bin (hub slots x replicas)
 constexpr size_t PB_ACC_STATIC = 512;  // static LDS of pb_accum_kernel, rounded up
-struct HubUnit {
-    float iu; // 1 / ulp(S) of a hub row's running sum S
-    int sh;   // ulp(S) = 2^sh units of the 2^-62 fixed point; < 0: S has no binade yet
-};
 constexpr uint32_t PB_HUB_MAX = 64;  // rows of a hub group (one lane of a wavefront each)
-constexpr uint16_t PB_HUBROW = 0xFFFEu; // cidx of a hub row: its sum is produced by pb_hub_kernel, not by its bin
+constexpr uint16_t PB_HUBROW = 0xFFFEu; // cidx of a hub row: its sum is produced by pb_hubseq_kernel / pb_hublong_kernel, not by its bin
 constexpr uint16_t PB_FLAG = 0x8000u;
 constexpr uint32_t PB_SEQ_WG = 256;  // threads of a pb_hubseq_kernel workgroup (wavefront 0 walks, all four stage)
 constexpr uint32_t PB_SEQ_PAD = 16;  // a row's stretch of the staged block is padded to 16 floats (4 x ds_read_b128 per step)
 constexpr uint32_t PB_SEQ_BUF = PB_ACC_BLOCK * PB_VEC + PB_HUB_MAX * (PB_SEQ_PAD - 1); // floats: 4096 terms + the rows' padding
 constexpr size_t PB_SEQ_LDS = 20480; // static LDS of pb_hubseq_kernel, rounded up
+constexpr uint32_t PB_LONG_WG = 512;  // threads of a pb_hublong_kernel workgroup
+constexpr uint32_t PB_LONG_PER = 16;  // consecutive terms per thread and pass
 constexpr int PB_TIERS_DEFAULT = 16;  // at most this many tiers of hot sources unless GM_PB_TIERS says otherwise
 constexpr float PB_FIX_SCALE = 4611686018427387904.0f;     // 2^62
 constexpr float PB_FIX_INV = 2.168404344971008868e-19f;    // 2^-62
@@ -96,10 +97,6 @@ struct PbScratch {
     // are region_items[region_off[r] .. region_off[r + 1])
     DevBuf region_items;
     std::vector<uint32_t> region_off;
-    // long chains walked block-parallel (pb_hubchain_*): per block and row the exact sum, the predicted binade, the sums
-    // rounded on four grids; per group and row the running sum after the first block; per group an arrival counter
-    // (self-resetting) and a "prediction failed" flag
-    DevBuf par_exact, par_binade, par_round, par_state, par_ticket, par_fail;
     // how the value stream got its memory (diagnostics, gm_pr_plan_info): bin-kernel time of the fastest / slowest timed
     // draw in us, draws timed, 64 MiB pieces the arena was grown by for it
     uint32_t draw_best_us = 0, draw_worst_us = 0, draws_timed = 0, grown_pieces = 0;
@@ -111,7 +108,7 @@ struct PbScratch {
     DevBuf bin_err;  // f64[B + G]
     hipStream_t side = nullptr;           // the hub groups run beside the ordinary bins
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipStream_t chain = nullptr;          // ... and the long chains' block-parallel walk beside the other hub groups
+    hipStream_t chain = nullptr;          // ... and the long rows (pb_hublong_kernel) beside the other hub groups
     hipEvent_t ev_chain_fork = nullptr, ev_chain_join = nullptr;
     ~PbScratch()
     {
@@ -160,19 +157,17 @@ struct PbPlan {
     uint64_t hub_edges = 0;
     DevBuf hub_rows;       // u32[n_hub] row id of every hub row, ascending
     DevBuf hub_first;      // u32[G+1]   first hub row (index into hub_rows) of every group
-    DevBuf hub_items;      // PbHubItem[G]: the G_few groups of one or two rows (the long chains) first, each part longest first
-    uint32_t G_few = 0;
-    // the long chains' 4096-entry blocks as one index space (pb_hubchain_*): block b of group g = few_blk_first[g] + b
-    uint32_t few_blocks = 0;
-    DevBuf few_blk_first;  // u32[G_few + 1]
-    DevBuf few_blk_group;  // u32[few_blocks] group (index into hub_items) of every block
+    DevBuf hub_items;      // PbHubItem[G]: the G_long groups that are one long row first, each part longest first
+    uint32_t hub_long = 32768; // rows with at least this many in-edges are a group of their own (pb_hublong_kernel); GM_PB_HUB_LONG
+    uint32_t G_long = 0;
+    uint64_t long_terms = 0;   // in-edges of the long rows
     std::vector<uint32_t> hub_first_host;
-    // hub groups of three or more rows, hub_items[G_few .. G): walked by pb_hubseq_kernel with one lane per row, every row sum
-    // the reference's own left-to-right f32 sum (page_rank.rs:143-146) bit for bit.  Their part of p2_dst holds, instead of
-    // the row slot, the entry's place in the row-major LDS arrangement of its 4096-entry block (pb_hubseq_layout_kernel).
-    uint32_t hub_seq = 1;  // GM_PB_HUB_SEQ=0 (measurement): the step-wise emulation of pb_hub_kernel for every group
+    std::vector<uint8_t> hub_long_host; // per group: 1 = one long row
+    // the other hub groups, hub_items[G_long .. G): walked by pb_hubseq_kernel with one lane per row.  Their part of p2_dst
+    // holds, instead of the row slot, the entry's place in the row-major LDS arrangement of its 4096-entry block
+    // (pb_hubseq_layout_kernel).
     uint32_t seq_blocks = 0;
-    DevBuf seq_blk_first;  // u32[G - G_few + 1] first block of each such group, in hub_items order
+    DevBuf seq_blk_first;  // u32[G - G_long + 1] first block of each such group, in hub_items order
     DevBuf seq_rows;       // u32[seq_blocks x 64] per block and row: first LDS slot << 16 | terms of the row in this block
     double build_ms = 0.0; // wall time of pb_build (device work included)
     uint32_t NT = 0;       // source tiles
@@ -1046,7 +1041,7 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
                 if (full[k]) {
                     const u32x2 raw = *reinterpret_cast<const u32x2 *>(cidx + r);
                     c4[k] = U16x4{(uint16_t)raw.x, (uint16_t)(raw.x >> 16), (uint16_t)raw.y, (uint16_t)(raw.y >> 16)};
-                    // a hub row among the four is finished by pb_hub_kernel, possibly right now: no vector store
+                    // a hub row among the four is finished by the hub kernels, possibly right now: no vector store
                     full[k] = c4[k].a != PB_HUBROW && c4[k].b != PB_HUBROW && c4[k].c != PB_HUBROW && c4[k].d != PB_HUBROW;
                 }
                 if (full[k]) {
@@ -1093,7 +1088,7 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
             if (r < n_local) {
                 const uint32_t c = cidx[r]; // rows without in-edges own no accumulator: incoming = 0
                 if (c == PB_HUBROW)
-                    continue; // finished by pb_hub_kernel
+                    continue; // finished by the hub kernels
                 unsigned long long sum = 0ull;
                 if (c != PB_NULL) {
                     if (item.nparts > 1) { // slices of one bin own consecutive partial slots [slot0, slot0 + nparts)
@@ -1113,520 +1108,17 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
         bin_err[b] = total;
 }
 
-// The rows of one hub group, summed in the reference's left-to-right f32 order (header): one workgroup walks the
-// group's part of the value stream one 4096-entry step at a time.  Per step: every lane rounds its four terms to
-// the grid of their rows' running sums and adds them — as integer counts of ulps — to the step sums in LDS; barrier;
-// wavefront 0 (lane g = row g) moves the rows' running sums S (scale 2^62), binades and ulps on; barrier.
-// The kernel is bound by instruction issue, not by memory (measured: 16 wavefronts x ~300 instructions per step =
-// 2.7 us against 1.2 us for the step's 24 KiB at the sweep's memory rate), hence: no branches per term (padding
-// goes to a dummy row whose scale is 0), the rare general cases out of line, and the step's bookkeeping on one
-// wavefront instead of redundantly on all sixteen.
-__global__ __launch_bounds__(PB_ACC_BLOCK, 8) void pb_hub_kernel(const float *__restrict__ vals,
-                                                              const uint16_t *__restrict__ p2_dst,
-                                                              const PbHubItem *__restrict__ items,
-                                                              const uint32_t *__restrict__ hub_rows,
-                                                              const uint32_t *__restrict__ outdeg, float *__restrict__ scores,
-                                                              float *__restrict__ x_out, double *__restrict__ group_err,
-                                                              float base, float damping, uint32_t long2, uint32_t long4,
-                                                              uint32_t graded, unsigned long long *__restrict__ state_out,
-                                                              const uint32_t *__restrict__ only_failed)
-{
-    // state_out != null: only the group's first block is walked (graded passes), and the rows' running sums are left in
-    // state_out[2 * group-in-launch + row] for the block-parallel walk of the long chains (pb_hubchain_kernel).  only_failed != null: the
-    // groups whose flag is 0 are skipped (the fallback launch behind pb_hubchain_kernel).
-    if (only_failed && only_failed[blockIdx.x] == 0u)
-        return;
-    // per step and row: the sum of the step's terms rounded at ulp(S) [0] and at 2 ulp(S) [1], in R replicas
-    // (lane mod R) so that the LDS atomics of a wavefront spread over ~64 addresses; three steps in rotation
-    // (filled / read / cleared).  Row nh is the dummy row of the padding entries.
-    __shared__ unsigned long long hub_q[3][2][PB_HUB_Q];
-    __shared__ HubUnit hub_unit[PB_HUB_MAX + 1];
-    __shared__ double red[PB_ACC_BLOCK / kWave];
-    const PbHubItem item = items[blockIdx.x]; // longest groups are dispatched first
-    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), nh = item.nh;
-    constexpr uint32_t STEP = PB_ACC_BLOCK * PB_VEC;
-    const uint32_t hb = item.q0, he = item.q1;
-    auto load_step = [&](uint32_t q, f32x4 &vv, U16x4 &dd) {
-        dd = U16x4{PB_NULL, PB_NULL, PB_NULL, PB_NULL};
-        vv = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (q < he) {
-            vv = *reinterpret_cast<const f32x4 *>(vals + q);
-            const u32x2 raw = *reinterpret_cast<const u32x2 *>(p2_dst + q);
-            dd = U16x4{(uint16_t)raw.x, (uint16_t)(raw.x >> 16), (uint16_t)raw.y, (uint16_t)(raw.y >> 16)};
-        }
-    };
-    constexpr int HS = 2; // blocks in flight (64 VGPRs: the workgroup fits beside an accumulate workgroup on its CU)
-    f32x4 hv[HS];
-    U16x4 hd[HS];
-    const uint32_t h_first = hb + tid * PB_VEC;
-#pragma unroll
-    for (int k = 0; k < HS; ++k)
-        load_step(h_first + (uint32_t)k * STEP, hv[k], hd[k]);
-    for (uint32_t i = tid; i < 3 * 2 * PB_HUB_Q; i += PB_ACC_BLOCK)
-        (&hub_q[0][0][0])[i] = 0ull;
-    if (tid <= PB_HUB_MAX)
-        hub_unit[tid] = tid < nh ? HubUnit{PB_FIX_SCALE, -1}  // "no rounding" until the sum has a binade
-                                 : HubUnit{0.0f, 0};          // the dummy row: every term counts 0 ulps
-    __syncthreads();
-    // Groups of one or two rows are the long chains (a 854,315-term row is a group of its own) and every lane's
-    // terms go to the same one or two sums: they are added up in registers first (`few`).  Otherwise
-    // R = 16 replicas for 3-4 rows ... 1 for more than 32.
-    const bool few = nh <= 2; // uniform over the group
-    const uint32_t rlog = few ? 0u : nh <= 4 ? 4u : nh <= 8 ? 3u : nh <= 16 ? 2u : nh <= 32 ? 1u : 0u;
-    const uint32_t rep = lane & ((1u << rlog) - 1u);
-    unsigned long long S = 0ull; // wavefront 0, lane g: the running sum of row g and its binade
-    int e = -1;
-    uint32_t buf = 0;
-    // The rare terms — the sum has no binade yet (sh < 0: nothing to round against), or a term far above the sum
-    // so far (more than 2^31 ulps) — go through ONE copy of the general code per step.
-    auto slow_term = [&](uint32_t slot, float val) {
-        const HubUnit un = hub_unit[slot];
-        unsigned long long fa, fb;
-        if (un.sh >= 0) {
-            const float t = val * un.iu, u = __uint_as_float((uint32_t)(127 + un.sh - 62) << 23);
-            fa = pb_to_fix(__builtin_rintf(t) * u);
-            fb = pb_to_fix(__builtin_rintf(t * 0.5f) * (u * 2.0f));
-        } else {
-            fa = fb = pb_to_fix(val);
-        }
-        atomicAdd(&hub_q[buf][0][(slot << rlog) | rep], fa);
-        atomicAdd(&hub_q[buf][1][(slot << rlog) | rep], fb);
-    };
-    auto slow_terms = [&](uint32_t slow, const f32x4 &cv, const uint32_t (&sl)[4]) {
-#pragma nounroll
-        for (uint32_t j = 0; j < 4 && slow; ++j, slow >>= 1)
-            if (slow & 1u)
-                slow_term(j == 0 ? sl[0] : j == 1 ? sl[1] : j == 2 ? sl[2] : sl[3],
-                          j == 0 ? cv.x : j == 1 ? cv.y : j == 2 ? cv.z : cv.w);
-    };
-    auto wave_sum32 = [&](uint32_t x) {
-#pragma unroll
-        for (int o = 32; o; o >>= 1)
-            x += (uint32_t)__shfl_xor((int)x, o, kWave);
-        return x;
-    };
-    // the terms of one 4096-entry block of the stream, rounded and added to the step sums hub_q[buf]
-    // only the entries [e_lo, e_hi) of the block take part (the others count as padding): a block can be added in several
-    // passes, each followed by end_step
-    auto add_block = [&](auto few_tag, const f32x4 &cv, const U16x4 &cd_in, uint32_t e_lo = 0, uint32_t e_hi = STEP) {
-        constexpr bool FEW = decltype(few_tag)::value;
-        U16x4 cd = cd_in;
-        if (e_lo != 0 || e_hi != STEP) { // a pass over part of the block (workgroup-uniform, off the hot path)
-            const uint32_t i0 = tid * PB_VEC;
-            cd.a = (i0 >= e_lo && i0 < e_hi) ? cd.a : PB_NULL;
-            cd.b = (i0 + 1u >= e_lo && i0 + 1u < e_hi) ? cd.b : PB_NULL;
-            cd.c = (i0 + 2u >= e_lo && i0 + 2u < e_hi) ? cd.c : PB_NULL;
-            cd.d = (i0 + 3u >= e_lo && i0 + 3u < e_hi) ? cd.d : PB_NULL;
-        }
-        const uint32_t sl[4] = {cd.a < nh ? cd.a : nh, cd.b < nh ? cd.b : nh, cd.c < nh ? cd.c : nh, cd.d < nh ? cd.d : nh};
-        const float vl[4] = {cv.x, cv.y, cv.z, cv.w};
-        uint32_t slow = 0;
-        if constexpr (FEW) {
-            // counts summed over the lane's terms and over the wavefront as two 32-bit halves (low 16 bits / the
-            // rest: neither sum can overflow); one lane per wavefront adds the wavefront's total to the step sum —
-            // 8192 LDS atomics on one address per step ran at the LDS's conflict rate (measured: 5 us per step)
-#pragma nounroll
-            for (uint32_t k = 0; k < nh; ++k) { // nh <= 2
-                const HubUnit un = hub_unit[k];
-                uint32_t a_lo = 0, a_hi = 0, b_lo = 0, b_hi = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float t = sl[j] == k ? vl[j] * un.iu : 0.0f;
-                    const bool ok = un.sh >= 0 && t < 2147483648.0f;
-                    const uint32_t ca = ok ? (uint32_t)__builtin_rintf(t) : 0u, cb = ok ? (uint32_t)__builtin_rintf(t * 0.5f) : 0u;
-                    a_lo += ca & 0xFFFFu, a_hi += ca >> 16;
-                    b_lo += cb & 0xFFFFu, b_hi += cb >> 16;
-                    slow |= (sl[j] == k && !ok) ? 1u << j : 0u;
-                }
-                a_lo = wave_sum32(a_lo), a_hi = wave_sum32(a_hi), b_lo = wave_sum32(b_lo), b_hi = wave_sum32(b_hi);
-                if (lane == 0 && un.sh >= 0) {
-                    atomicAdd(&hub_q[buf][0][k], (((unsigned long long)a_hi << 16) + a_lo) << un.sh);
-                    atomicAdd(&hub_q[buf][1][k], (((unsigned long long)b_hi << 16) + b_lo) << (un.sh + 1));
-                }
-            }
-        } else {
-            HubUnit un[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                un[j] = hub_unit[sl[j]]; // 1 / ulp(S) and log2 of ulp(S) in fixed-point units; four reads in flight
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float t = vl[j] * un[j].iu; // a power-of-two scaling: exact (0 for padding)
-                const bool ok = un[j].sh >= 0 && t < 2147483648.0f;
-                const uint32_t ca = ok ? (uint32_t)__builtin_rintf(t) : 0u, cb = ok ? (uint32_t)__builtin_rintf(t * 0.5f) : 0u;
-                const uint32_t qi = (sl[j] << rlog) | rep;
-                const int sh = un[j].sh & 63;
-                atomicAdd(&hub_q[buf][0][qi], (unsigned long long)ca << sh);
-                atomicAdd(&hub_q[buf][1][qi], (unsigned long long)cb << ((sh + 1) & 63));
-                slow |= ok ? 0u : 1u << j;
-            }
-        }
-        if (__ballot(slow != 0)) // almost never
-            slow_terms(slow, cv, sl);
-    };
-    // between two steps: lane g < nh of EVERY wavefront moves the running sum of row g on — identical copies,
-    // computed from the same LDS sums, so one barrier per step is enough
-    auto end_step = [&]() {
-        // every term of this step is in hub_q[buf] (LDS traffic only: the prefetched global loads stay in flight)
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (lane < nh) {
-            unsigned long long A = 0ull, B = 0ull;
-            const uint32_t q0i = lane << rlog;
-            for (uint32_t r = 0; r < (1u << rlog); ++r) {
-                A += hub_q[buf][0][q0i + r];
-                B += hub_q[buf][1][q0i + r];
-            }
-            if (e < 24) {
-                S += A; // no binade yet (the row's first terms): A was added without rounding
-            } else {
-                const unsigned long long top = 1ull << (e + 1);
-                if (S + A < top) {
-                    S += A; // S stayed in its binade: exactly what the left-to-right f32 sum does
-                } else {
-                    // S crossed into the next binade inside this step: the terms behind the crossing are
-                    // rounded at 2 ulp.  Terms arrive in source order, a homogeneous sequence, so the share
-                    // of the step behind the crossing is the share of A beyond `top`.
-                    const unsigned long long rem = S + A - top;
-                    S = top + __double2ull_rn((double)B * ((double)rem / (double)A));
-                }
-            }
-            HubUnit un{PB_FIX_SCALE, -1};
-            e = -1;
-            if (S) {
-                int ee = 63 - __clzll((long long)S);
-                if (ee >= 24) { // keep S on the f32 grid of its binade (round to nearest even, as fl() does)
-                    const int sh = ee - 23;
-                    const unsigned long long half = 1ull << (sh - 1), r = S & ((1ull << sh) - 1ull);
-                    unsigned long long qv = S >> sh;
-                    qv += (r > half || (r == half && (qv & 1ull))) ? 1ull : 0ull;
-                    S = qv << sh;
-                    ee = 63 - __clzll((long long)S);
-                    un = HubUnit{__uint_as_float((uint32_t)(127 + 85 - ee) << 23), ee - 23};
-                }
-                e = ee;
-            }
-            hub_unit[lane] = un; // every wavefront writes the same value
-        }
-        if (tid < ((nh + 1u) << rlog)) { // cleared two steps before it is filled again
-            hub_q[(buf + 2u) % 3u][0][tid] = 0ull;
-            hub_q[(buf + 2u) % 3u][1][tid] = 0ull;
-        }
-        buf = (buf + 1u) % 3u;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wavefront's unit writes before its next reads
-    };
-    // A step is one block (4096 entries) for groups of one or two rows — their rows see thousands of terms per
-    // block — and two blocks for the others (a row of a 30-row group sees ~270 terms in 8192 entries): the
-    // barrier and the bookkeeping are paid half as often.  The kernel is bound by instruction issue (measured:
-    // ~570 wavefront instructions per block), not by memory.  Chains of at least long2 / long4 terms can take two / four
-    // blocks per step (GM_PB_HUB_LONG2 / GM_PB_HUB_LONG4; off by default).  The walk of the longest row is a sequence
-    // nothing else can shorten — 0.62 ms for the 854,315-term row of scale 26, hidden under the accumulate kernel on
-    // one GPU but the critical path of the rank that owns the row in an 8-way split (1.02 ms against 0.55-0.70 for the
-    // other seven).  Measured with 65536 / 262144: that rank 1.02 -> 0.95 ms, scale 22 on one GPU 0.210 -> 0.204 ms, but
-    // the 400,000-term row of scale 24 moves from 3.0e-6 to 6.5e-6 of the reference (limit 1e-5): not worth the margin.
-    const uint32_t per_step = !few ? 1u : (he - hb) >= long4 ? 4u : (he - hb) >= long2 ? 2u : 1u; // FEW: blocks per step
-    // The FIRST block of a group goes in passes of 64, 64, 128, 256 ... entries: a row's sum starts from nothing and would
-    // otherwise cross a dozen binades inside one step, summed exactly — without the rounding the reference applies from
-    // its second term on.  A large early term then cost up to 1.5e-4 (tests/test_gpu_hub_adversarial.py, "one giant
-    // first"); with 64-entry passes the unrounded stretch is at most 64 terms: 64 x 2^-25 = 2e-6.  (A term far above the
-    // running sum in the MIDDLE of a long row still mis-rounds what follows it inside its step: at most 4095 terms at
-    // half an ulp each.  Walking such steps again in small passes was tried and cost the kernel its registers — the
-    // climbs are common in groups of many rows, where they are harmless: a row has a few hundred terms per step.)
-    // groups of 3 ... 16 rows: their rows are long (a row of an 8-row group has ~512 terms per block), so the step is one
-    // block there; groups of more rows take two blocks per step (half the barriers, rows of at most ~500 terms per step).
-    // Measured at scale 26 on one box: one-block steps up to 32 rows 2.86 ms per sweep, none 2.75-2.81.
-    const bool fine_steps = nh <= 16u && (graded & 2u); // GM_PB_HUB_GRADED bit 1 (measurements: 1 = graded first block only)
-    auto walk = [&](auto few_tag) {
-        constexpr bool FEW = decltype(few_tag)::value;
-        {
-            const f32x4 cv = hv[0];
-            const U16x4 cd = hd[0];
-            for (uint32_t lo = 0, hi = (graded & 1u) ? 64u : STEP; lo < STEP; lo = hi, hi = hi * 2u < STEP ? hi * 2u : STEP) {
-                add_block(few_tag, cv, cd, lo, hi);
-                end_step();
-            }
-        }
-        if (state_out) { // every wavefront's lane g holds the same S: wavefront 0 writes it
-            if (tid < nh)
-                state_out[2u * blockIdx.x + tid] = S;
-            return;
-        }
-        const uint32_t q1 = h_first + STEP; // the steps proper start at the second block
-        load_step(q1, hv[0], hd[0]);
-        load_step(q1 + STEP, hv[1], hd[1]);
-        uint32_t since = 0; // FEW: blocks added since the last end_step
-        for (uint32_t qs = hb + STEP, q0 = q1; qs < he; qs += HS * STEP, q0 += HS * STEP) {
-#pragma unroll
-            for (int k = 0; k < HS; k += FEW ? 1 : 2) {
-                if (qs + (uint32_t)k * STEP >= he) // uniform over the workgroup
-                    break;
-                const f32x4 cv0 = hv[k];
-                const U16x4 cd0 = hd[k];
-                load_step(q0 + (uint32_t)(k + HS) * STEP, hv[k], hd[k]); // requested before the LDS work of this step
-                add_block(few_tag, cv0, cd0);
-                if constexpr (!FEW) {
-                    if (fine_steps) // few rows in the group: a row has hundreds of terms per block, one block per step
-                        end_step();
-                    const f32x4 cv1 = hv[k + 1];
-                    const U16x4 cd1 = hd[k + 1];
-                    load_step(q0 + (uint32_t)(k + 1 + HS) * STEP, hv[k + 1], hd[k + 1]);
-                    add_block(few_tag, cv1, cd1);
-                    end_step();
-                } else if (++since == per_step) {
-                    end_step();
-                    since = 0;
-                }
-            }
-        }
-        if (since) // the last, shorter step of a long chain
-            end_step();
-    };
-    if (few)
-        walk(std::true_type{});
-    else
-        walk(std::false_type{});
-    if (state_out)
-        return;
-    // epilogue of the reference for the group's rows (page_rank.rs:149-159); S is on the f32 grid: the
-    // conversion is exact
-    double err = 0.0;
-    if (tid < nh)
-        err = pr_finalize(hub_rows[item.row0 + tid], (float)S * PB_FIX_INV, base, damping, outdeg, scores, x_out);
-    const double total = block_sum<double, PB_ACC_BLOCK / kWave>(err, red);
-    if (tid == 0)
-        group_err[item.group] = total;
-}
-
-// ---- the long chains in parallel ------------------------------------------------------------------------------------
-// A group of one or two rows (a row of 854,315 terms at RMAT scale 26) is a chain of up to 209 steps that pb_hub_kernel
-// walks one after the other: 2.9 us a step — the arithmetic of one 4096-entry block on one CU — 0.6 ms in all, the whole
-// sweep of the rank that owns the row in an 8-way partition.  What a step needs from its predecessors is only the BINADE
-// of the running sum, and the exact prefix sum of the raw terms predicts it: the reference's drift is < 0.1 % of the sum.
-// So, with one workgroup per BLOCK:
-//   pb_hubchain_exact_kernel  per block and row the exact sum of the terms (64-bit fixed point);
-//   pb_hub_kernel(state_out)  the group's first block in graded passes, as before: the running sum after it;
-//   pb_hubchain_kernel        block b: running sum after block 0 + exact sums of blocks 1..b-1 = predicted sum, hence
-//                             binade; the block's terms rounded on the grids of that binade - 1, the binade, + 1, + 2 —
-//                             exactly what add_block computes for the grid of the running sum.  The group's last block to
-//                             arrive (a ticket) then runs end_step's arithmetic over the blocks with the sums of the grid
-//                             that MATCHES the running sum it tracks: bit for bit what the sequential walk computes.
-// The chain is read twice instead of once, by a few hundred CUs instead of one.  (Tried and measured: one kernel per phase,
-// five launches, each waiting ~70 us for its turn behind the accumulate kernel's workgroups; one workgroup per GROUP doing
-// all phases, 1.7x slower than the sequential walk — a block's arithmetic on four grids is what a CU needs 2.9 us for.)
-// If the running sum ever leaves the predicted binades the group's flag is raised and pb_hub_kernel walks that group the
-// old way (only_failed).
-constexpr uint32_t PB_CHAIN_WG = 256;    // threads of the per-block workgroups
-constexpr uint32_t PB_CHAIN_STAGE = 128; // blocks staged in LDS at a time by the walk
-
-struct PbChainBlock {
-    uint32_t group, b, nb, nh, q0, q1; // group (index into items), block within the group, the group's blocks and rows, entries
-};
-
-__device__ __forceinline__ PbChainBlock pb_chain_block(const PbHubItem *__restrict__ items, const uint32_t *__restrict__ blk_first,
-                                                       const uint32_t *__restrict__ blk_group)
-{
-    constexpr uint32_t STEP = PB_ACC_BLOCK * PB_VEC;
-    PbChainBlock r;
-    r.group = blk_group[blockIdx.x];
-    r.b = blockIdx.x - blk_first[r.group];
-    const PbHubItem item = items[r.group];
-    r.nh = item.nh;
-    r.nb = (item.q1 - item.q0 + STEP - 1) / STEP;
-    r.q0 = item.q0 + r.b * STEP;
-    r.q1 = (item.q1 - r.q0) < STEP ? item.q1 : r.q0 + STEP;
-    return r;
-}
-
-// sum over the workgroup (PB_CHAIN_WG threads); red: one slot per wavefront
-__device__ __forceinline__ unsigned long long pb_chain_sum(unsigned long long v, unsigned long long *red)
-{
-    v = wave_sum((uint64_t)v);
-    __syncthreads();
-    if ((threadIdx.x & (kWave - 1)) == 0)
-        red[threadIdx.x / kWave] = v;
-    __syncthreads();
-    unsigned long long t = 0ull;
-#pragma unroll
-    for (uint32_t w = 0; w < PB_CHAIN_WG / kWave; ++w)
-        t += red[w];
-    return t;
-}
-
-__global__ __launch_bounds__(PB_CHAIN_WG) void pb_hubchain_exact_kernel(const float *__restrict__ vals, const uint16_t *__restrict__ p2_dst,
-                                                                        const PbHubItem *__restrict__ items,
-                                                                        const uint32_t *__restrict__ blk_first,
-                                                                        const uint32_t *__restrict__ blk_group,
-                                                                        unsigned long long *__restrict__ exact)
-{
-    __shared__ unsigned long long red[PB_CHAIN_WG / kWave];
-    const PbChainBlock r = pb_chain_block(items, blk_first, blk_group);
-    if (r.b == 0)
-        return; // walked by pb_hub_kernel
-    unsigned long long s0 = 0ull, s1 = 0ull;
-    for (uint32_t q = r.q0 + threadIdx.x * PB_VEC; q < r.q1; q += PB_CHAIN_WG * PB_VEC) {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(vals + q);
-        const u32x2 raw = *reinterpret_cast<const u32x2 *>(p2_dst + q);
-        const unsigned long long f0 = pb_to_fix(v.x), f1 = pb_to_fix(v.y), f2 = pb_to_fix(v.z), f3 = pb_to_fix(v.w);
-        const uint32_t l0 = raw.x & 0xFFFFu, l1 = raw.x >> 16, l2 = raw.y & 0xFFFFu, l3 = raw.y >> 16;
-        s0 += (l0 == 0u ? f0 : 0ull) + (l1 == 0u ? f1 : 0ull) + (l2 == 0u ? f2 : 0ull) + (l3 == 0u ? f3 : 0ull);
-        s1 += (l0 == 1u ? f0 : 0ull) + (l1 == 1u ? f1 : 0ull) + (l2 == 1u ? f2 : 0ull) + (l3 == 1u ? f3 : 0ull);
-    }
-    s0 = pb_chain_sum(s0, red);
-    s1 = pb_chain_sum(s1, red);
-    if (threadIdx.x == 0)
-        exact[2u * blockIdx.x] = s0, exact[2u * blockIdx.x + 1] = s1;
-}
-
-__global__ __launch_bounds__(PB_CHAIN_WG) void pb_hubchain_kernel(const float *__restrict__ vals, const uint16_t *__restrict__ p2_dst,
-                                                                  const PbHubItem *__restrict__ items, const uint32_t *__restrict__ blk_first,
-                                                                  const uint32_t *__restrict__ blk_group,
-                                                                  const uint32_t *__restrict__ hub_rows,
-                                                                  const unsigned long long *__restrict__ exact,
-                                                                  const unsigned long long *__restrict__ state, int *__restrict__ binade,
-                                                                  unsigned long long *__restrict__ rounded, uint32_t *__restrict__ tickets,
-                                                                  uint32_t *__restrict__ fail, const uint32_t *__restrict__ outdeg,
-                                                                  float *__restrict__ scores, float *__restrict__ x_out,
-                                                                  double *__restrict__ group_err, float base, float damping)
-{
-    __shared__ unsigned long long red[PB_CHAIN_WG / kWave];
-    __shared__ unsigned long long st_rq[PB_CHAIN_STAGE][2][4];
-    __shared__ int st_bn[PB_CHAIN_STAGE][2];
-    __shared__ bool is_last;
-    const uint32_t tid = threadIdx.x;
-    const PbChainBlock r = pb_chain_block(items, blk_first, blk_group);
-    const uint32_t first = blockIdx.x - r.b; // the group's block 0 in the launch's index space
-    if (r.b) {
-        // predicted running sum before this block
-        unsigned long long p0 = 0ull, p1 = 0ull;
-        for (uint32_t i = 1 + tid; i < r.b; i += PB_CHAIN_WG)
-            p0 += exact[2u * (first + i)], p1 += exact[2u * (first + i) + 1];
-        p0 = pb_chain_sum(p0, red) + state[2u * r.group];
-        p1 = pb_chain_sum(p1, red) + state[2u * r.group + 1];
-        const int e0 = p0 >= (1ull << 24) ? 63 - __clzll((long long)p0) : -1;
-        const int e1 = r.nh > 1 && p1 >= (1ull << 24) ? 63 - __clzll((long long)p1) : -1;
-        // the block's terms of each row on the four grids around the prediction
-        unsigned long long a[2][4] = {{0ull, 0ull, 0ull, 0ull}, {0ull, 0ull, 0ull, 0ull}};
-        auto term = [&](float v, uint32_t slot) {
-#pragma unroll
-            for (int row = 0; row < 2; ++row) {
-                const int ee = row ? e1 : e0;
-                const float val = (slot == (uint32_t)row && ee >= 0) ? v : 0.0f;
-#pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    const int sh = ee - 1 + h - 23;
-                    const float t = val * __uint_as_float((uint32_t)(127 + 62 - sh) << 23);
-                    a[row][h] += t < 2147483648.0f
-                                     ? (unsigned long long)(uint32_t)__builtin_rintf(t) << sh
-                                     // more than 2^31 units of the grid: the general code of pb_hub_kernel (slow_term)
-                                     : pb_to_fix(__builtin_rintf(t) * __uint_as_float((uint32_t)(127 + sh - 62) << 23));
-                }
-            }
-        };
-        for (uint32_t q = r.q0 + tid * PB_VEC; q < r.q1; q += PB_CHAIN_WG * PB_VEC) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(vals + q);
-            const u32x2 raw = *reinterpret_cast<const u32x2 *>(p2_dst + q);
-            term(v.x, raw.x & 0xFFFFu), term(v.y, raw.x >> 16), term(v.z, raw.y & 0xFFFFu), term(v.w, raw.y >> 16);
-        }
-#pragma unroll
-        for (int row = 0; row < 2; ++row)
-#pragma unroll
-            for (int h = 0; h < 4; ++h)
-                a[row][h] = pb_chain_sum(a[row][h], red);
-        if (tid == 0) {
-#pragma unroll
-            for (int row = 0; row < 2; ++row)
-#pragma unroll
-                for (int h = 0; h < 4; ++h)
-                    rounded[8u * blockIdx.x + 4 * row + h] = a[row][h];
-        }
-        if (tid < 2)
-            binade[2u * blockIdx.x + tid] = tid ? e1 : e0;
-    }
-    // the group's last block to arrive walks the chain (hand-off as in pb_accum_kernel: agent-scope release / acquire)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t prev = atomicAdd(&tickets[r.group], 1u);
-        is_last = prev == r.nb - 1u;
-        if (is_last) {
-            st_agent(&tickets[r.group], 0u); // ready for the next sweep
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-    }
-    __syncthreads();
-    if (!is_last)
-        return;
-    const bool mine = tid < r.nh;
-    unsigned long long S = mine ? state[2u * r.group + tid] : 0ull;
-    int e = S ? 63 - __clzll((long long)S) : -1;
-    bool bad = false;
-    for (uint32_t c0 = 1; c0 < r.nb; c0 += PB_CHAIN_STAGE) {
-        const uint32_t cn = (r.nb - c0) < PB_CHAIN_STAGE ? (r.nb - c0) : PB_CHAIN_STAGE;
-        __syncthreads();
-        for (uint32_t i = tid; i < cn * 8u; i += PB_CHAIN_WG)
-            (&st_rq[0][0][0])[i] = rounded[8u * (first + c0) + i];
-        for (uint32_t i = tid; i < cn * 2u; i += PB_CHAIN_WG)
-            (&st_bn[0][0])[i] = binade[2u * (first + c0) + i];
-        __syncthreads();
-        if (mine && !bad)
-            for (uint32_t i = 0; i < cn; ++i) { // end_step of pb_hub_kernel, word for word, on the sums of the matching grid
-                const int eb = st_bn[i][tid], d = e - eb;
-                if (e < 24 || eb < 0 || d < -1 || d > 1) { // the sum left the predicted binades
-                    bad = true;
-                    break;
-                }
-                const unsigned long long c1 = st_rq[i][tid][1], c2 = st_rq[i][tid][2];
-                const unsigned long long A = d < 0 ? st_rq[i][tid][0] : d == 0 ? c1 : c2;
-                const unsigned long long B = d < 0 ? c1 : d == 0 ? c2 : st_rq[i][tid][3];
-                const unsigned long long top = 1ull << (e + 1);
-                if (S + A < top) {
-                    S += A;
-                } else {
-                    const unsigned long long rem = S + A - top;
-                    S = top + __double2ull_rn((double)B * ((double)rem / (double)A));
-                }
-                e = -1;
-                if (S) {
-                    int ee = 63 - __clzll((long long)S);
-                    if (ee >= 24) {
-                        const int sh = ee - 23;
-                        const unsigned long long half = 1ull << (sh - 1), rr = S & ((1ull << sh) - 1ull);
-                        unsigned long long qv = S >> sh;
-                        qv += (rr > half || (rr == half && (qv & 1ull))) ? 1ull : 0ull;
-                        S = qv << sh;
-                        ee = 63 - __clzll((long long)S);
-                    }
-                    e = ee;
-                }
-            }
-    }
-    const unsigned long long any_bad = pb_chain_sum(bad ? 1ull : 0ull, red);
-    if (tid == 0)
-        fail[r.group] = any_bad ? 1u : 0u;
-    if (any_bad)
-        return; // pb_hub_kernel (only_failed) walks the group the sequential way
-    double err = 0.0;
-    if (mine)
-        err = pr_finalize(hub_rows[items[r.group].row0 + tid], (float)S * PB_FIX_INV, base, damping, outdeg, scores, x_out);
-    if (tid < kWave) {
-        const double total = wave_sum(err);
-        if (tid == 0)
-            group_err[items[r.group].group] = total;
-    }
-}
-
-// ---- hub groups of three or more rows: the reference's own sums ------------------------------------------------------
-// The reference adds a row's terms left to right in f32 (page_rank.rs:143-146).  pb_hub_kernel imitates that with integer
-// counts of ulps per 4096-entry step (~300 wavefront instructions per step on sixteen wavefronts: it kept a quarter of the
-// chip's issue slots busy beside the accumulate kernel).  Here the sum is simply COMPUTED that way: a group's stream is
-// sorted by source with its rows interleaved, so at plan time every 4096-entry block gets a stable permutation that makes
-// it row-major (pb_hubseq_layout_kernel: p2_dst holds the entry's place in the block's LDS arrangement, `rows` the first
-// place and the number of terms of every row), and per block the workgroup's four wavefronts scatter the values into LDS
-// while lane g of wavefront 0 adds row g's terms in order: S = S + v, one v_add_f32 per term.  The sum is the reference's
-// bit for bit for the same out_scores, whatever the partition; a block costs ~16 terms-per-row steps of one wavefront
-// instead of ~4800 wavefront instructions.  What stays serial is the chain of a row's adds (~5 cycles per term): groups of
-// one or two rows — rows of 10^5 ... 10^6 terms — keep the block-parallel emulation below (pb_hubchain_*).
+// ---- hub rows: the reference's own sums ---------------------------------------------------------------------------------
+// The reference adds a row's terms left to right in f32 (page_rank.rs:143-146).  Rounds 2 and 3 imitated that with integer
+// counts of ulps per 4096-entry step (pb_hub_kernel: ~300 wavefront instructions per step on sixteen wavefronts — measured
+// in round 4, profiles/r04_accum_corun_ab.txt: as many vector instructions as the accumulate kernel itself for 22 % of the
+// edges).  Here the sum is simply COMPUTED that way.  Rows below hub_long terms: a group's stream is sorted by source with
+// its rows interleaved, so at plan time every 4096-entry block gets a stable permutation that makes it row-major
+// (pb_hubseq_layout_kernel: p2_dst holds the entry's place in the block's LDS arrangement, `rows` the first place and the
+// number of terms of every row), and per block the workgroup's four wavefronts scatter the values into LDS while lane g
+// of wavefront 0 adds row g's terms in order: S = S + v, one v_add_f32 per term.  The sum is the reference's bit for bit
+// for the same out_scores, whatever the partition.  What stays serial is the chain of a row's adds (~5 cycles per term):
+// longer rows go to pb_hublong_kernel below.
 __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_hubseq_layout_kernel(const PbHubItem *__restrict__ items,
                                                                          const uint32_t *__restrict__ blk_first, uint32_t n_groups,
                                                                          uint16_t *__restrict__ p2_dst, uint32_t *__restrict__ rows)
@@ -1852,6 +1344,150 @@ __global__ __launch_bounds__(PB_SEQ_WG) void pb_hubseq_kernel(const float *__res
         group_err[item.group] = total;
 }
 
+// ---- long rows: the same sums, in parallel ----------------------------------------------------------------------------
+// S_{k+1} = fl(S_k + v_k) looks like a chain, but while S stays inside one binade [2^e, 2^(e+1)) it is integer arithmetic:
+// with ulp = 2^(e-23), S = J ulp (2^23 <= J < 2^24) and v = t ulp, fl(S + v) = RNE(J + t) ulp, and RNE(J + t) = J + rint(t)
+// unless t ends in exactly .5, where the result is the EVEN one of J + floor(t) and J + floor(t) + 1: it depends on J only
+// through its parity.  So a run of terms acts on J as (count added when the run starts on an even J, count added when it
+// starts on an odd J), and two runs compose into such a pair again — an associative operation, hence a scan:
+//   every thread takes 16 consecutive terms and forms its pair (one pass over the terms when none of them is a tie);
+//   an exclusive scan over the workgroup gives every thread the J its run starts from;
+//   the first thread whose run ends at or beyond 2^24 — S leaves the binade there — starts from an exactly known S and
+//   adds its 16 terms with v_add_f32, one after the other; everything behind it is redone on the new grid.
+// S leaves a binade a few dozen times per row (and at every doubling of the first few thousand terms), so a super-block of
+// 8192 terms costs one pass, sometimes two.  Bit for bit the reference's sum: tests/test_gpu_hub_adversarial.py compares
+// rows of up to 2^20 + 1 terms with orc_page_rank_jacobi_sweep's sequential sums for equality.
+__global__ __launch_bounds__(PB_LONG_WG) void pb_hublong_kernel(const float *__restrict__ vals, const uint16_t *__restrict__ p2_dst,
+                                                                const PbHubItem *__restrict__ items,
+                                                                const uint32_t *__restrict__ hub_rows,
+                                                                const uint32_t *__restrict__ outdeg, float *__restrict__ scores,
+                                                                float *__restrict__ x_out, double *__restrict__ group_err, float base,
+                                                                float damping)
+{
+    constexpr uint32_t NWV = PB_LONG_WG / kWave, PER = PB_LONG_PER, SUPER = PB_LONG_WG * PER, SAT = 1u << 30, NONE = 0xFFFFFFFFu;
+    __shared__ uint32_t w_a0[NWV], w_a1[NWV], w_first[NWV];
+    __shared__ float s_bcast;
+    const PbHubItem item = items[blockIdx.x]; // one row: slot 0 (padding entries: PB_NULL)
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    // (counts from an even / odd start) of run F followed by run G; saturated: beyond the first run that leaves the binade
+    // nothing is used
+    auto compose = [&](uint32_t f0, uint32_t f1, uint32_t g0, uint32_t g1, uint32_t &h0, uint32_t &h1) {
+        const uint32_t n0 = f0 + ((f0 & 1u) ? g1 : g0), n1 = f1 + ((f1 & 1u) ? g0 : g1);
+        h0 = n0 < SAT ? n0 : SAT, h1 = n1 < SAT ? n1 : SAT;
+    };
+    float S = 0.0f; // page_rank.rs:143
+    for (uint32_t sb = item.q0; sb < item.q1; sb += SUPER) {
+        float v[PER];
+#pragma unroll
+        for (uint32_t j = 0; j < PER; j += 4) {
+            const uint32_t q = sb + tid * PER + j;
+            v[j] = v[j + 1] = v[j + 2] = v[j + 3] = 0.0f;
+            if (q < item.q1) {
+                const f32x4 x = *reinterpret_cast<const f32x4 *>(vals + q);
+                const u32x2 d = *reinterpret_cast<const u32x2 *>(p2_dst + q);
+                v[j] = (d.x & 0xFFFFu) == 0u ? x.x : 0.0f;
+                v[j + 1] = (d.x >> 16) == 0u ? x.y : 0.0f;
+                v[j + 2] = (d.y & 0xFFFFu) == 0u ? x.z : 0.0f;
+                v[j + 3] = (d.y >> 16) == 0u ? x.w : 0.0f;
+            }
+        }
+        uint32_t done = 0; // threads below `done` have had their terms added
+        for (;;) {
+            const uint32_t sbits = __float_as_uint(S), e = sbits >> 23; // S >= 0
+            const bool binade = e >= 24u && e < 255u;                   // S is a normal number with a usable grid
+            const uint32_t J0 = (sbits & 0x7FFFFFu) | 0x800000u;
+            const float iu = __uint_as_float((277u - (binade ? e : 150u)) << 23); // 1 / ulp(S)
+            const float ulp = __uint_as_float(((binade ? e : 150u) - 23u) << 23);
+            uint32_t a0 = 0, a1 = 0;
+            bool big = false;
+            if (tid >= done) {
+                if (!binade) {
+                    big = true; // S is still zero (or tiny): the first thread adds its terms the slow way
+                } else {
+                    bool tie = false;
+                    uint32_t sum = 0;
+#pragma unroll
+                    for (uint32_t j = 0; j < PER; ++j) {
+                        const float t = v[j] * iu; // exact: a power-of-two scaling
+                        const bool ok = t < 16777216.0f;
+                        big |= !ok; // a term of at least 2^24 ulps: S leaves the binade here for certain
+                        sum += ok ? (uint32_t)__builtin_rintf(t) : 0u;
+                        tie |= (t - __builtin_floorf(t)) == 0.5f;
+                    }
+                    a0 = a1 = sum < SAT ? sum : SAT;
+                    if (tie && !big) { // the two-state walk: a tie goes to the even J
+                        uint32_t x0 = 0, x1 = 0, p0 = 0, p1 = 1;
+#pragma unroll
+                        for (uint32_t j = 0; j < PER; ++j) {
+                            const float t = v[j] * iu, fl = __builtin_floorf(t);
+                            const uint32_t c = (uint32_t)__builtin_rintf(t), f = (uint32_t)fl;
+                            const bool half = (t - fl) == 0.5f;
+                            const uint32_t c0 = half ? f + ((p0 + f) & 1u) : c, c1 = half ? f + ((p1 + f) & 1u) : c;
+                            x0 += c0, x1 += c1;
+                            p0 = (p0 + c0) & 1u, p1 = (p1 + c1) & 1u;
+                        }
+                        a0 = x0 < SAT ? x0 : SAT, a1 = x1 < SAT ? x1 : SAT;
+                    }
+                }
+            }
+            // inclusive scan over the wavefront, then the wavefronts before this one
+            uint32_t i0 = a0, i1 = a1;
+#pragma unroll
+            for (uint32_t o = 1; o < (uint32_t)kWave; o <<= 1) {
+                const uint32_t f0 = (uint32_t)__shfl_up((int)i0, o, kWave), f1 = (uint32_t)__shfl_up((int)i1, o, kWave);
+                if (lane >= o)
+                    compose(f0, f1, i0, i1, i0, i1);
+            }
+            uint32_t e0 = (uint32_t)__shfl_up((int)i0, 1, kWave), e1 = (uint32_t)__shfl_up((int)i1, 1, kWave);
+            if (lane == 0)
+                e0 = e1 = 0u;
+            if (lane == kWave - 1)
+                w_a0[wave] = i0, w_a1[wave] = i1;
+            __syncthreads();
+            uint32_t b0 = 0, b1 = 0, t0 = 0, t1 = 0; // the wavefronts before this one; all of them
+#pragma unroll
+            for (uint32_t w = 0; w < NWV; ++w) {
+                if (w == wave)
+                    b0 = t0, b1 = t1;
+                compose(t0, t1, w_a0[w], w_a1[w], t0, t1);
+            }
+            const uint32_t P0 = J0 & 1u;
+            const uint32_t bw = P0 ? b1 : b0;             // added by the wavefronts before this one
+            const uint32_t pw = (P0 + bw) & 1u;
+            const uint32_t bl = pw ? e1 : e0;             // ... and by the lanes before this one
+            const uint32_t before = (bw + bl) < SAT ? bw + bl : SAT;
+            const uint32_t mine = ((pw + bl) & 1u) ? a1 : a0;
+            const bool cross = tid >= done && (big || J0 + before + mine >= (1u << 24));
+            const uint64_t cm = __ballot(cross);
+            if (lane == 0)
+                w_first[wave] = cm ? wave * kWave + (uint32_t)__ffsll((unsigned long long)cm) - 1u : NONE;
+            __syncthreads();
+            uint32_t first = NONE;
+#pragma unroll
+            for (uint32_t w = 0; w < NWV; ++w)
+                first = w_first[w] < first ? w_first[w] : first;
+            if (first == NONE) { // every remaining run stayed inside the binade: S = (J0 + count) ulp, exactly
+                S = (float)(J0 + (P0 ? t1 : t0)) * ulp;
+                break;
+            }
+            if (tid == first) {
+                float s = binade ? (float)(J0 + before) * ulp : S; // exact: J0 + before < 2^24
+#pragma unroll
+                for (uint32_t j = 0; j < PER; ++j)
+                    s = __fadd_rn(s, v[j]); // page_rank.rs:144-146
+                s_bcast = s;
+            }
+            __syncthreads();
+            S = s_bcast;
+            done = first + 1u;
+            if (done >= PB_LONG_WG)
+                break;
+        }
+    }
+    if (tid == 0)
+        group_err[item.group] = pr_finalize(hub_rows[item.row0], S, base, damping, outdeg, scores, x_out);
+}
+
 __global__ __launch_bounds__(1024) void pb_err_kernel(const double *__restrict__ bin_err, uint32_t B, double *__restrict__ err_out)
 {
     __shared__ double red[1024 / kWave];
@@ -1974,40 +1610,34 @@ int pb_make_items(PbPlan *pl)
     GM_HIP(hipMemcpy(pl->items.p, items.data(), items.size() * sizeof(PbItem), hipMemcpyHostToDevice));
     pl->items_host = items;
     pl->slots = slots;
-    // hub groups: one workgroup walks a group in order (the running sums of its rows are a sequence); longest first
-    std::vector<PbHubItem> hubs;
+    // hub groups, longest first: the long rows (one row per group, pb_hublong_kernel), then the groups pb_hubseq_kernel walks
+    struct Tagged {
+        PbHubItem item;
+        bool is_long;
+    };
+    std::vector<Tagged> tagged;
     for (uint32_t g = 0; g < pl->G; ++g)
-        hubs.push_back(PbHubItem{bv[pl->B + g], bv[pl->B + g + 1], pl->hub_first_host[g + 1] - pl->hub_first_host[g],
-                                 pl->hub_first_host[g], g});
-    std::stable_sort(hubs.begin(), hubs.end(), [](const PbHubItem &a, const PbHubItem &c) { return a.q1 - a.q0 > c.q1 - c.q0; });
-    std::stable_partition(hubs.begin(), hubs.end(), [](const PbHubItem &a) { return a.nh <= 2u; }); // each part longest first
-    pl->G_few = 0;
-    for (const PbHubItem &h : hubs)
-        pl->G_few += h.nh <= 2u ? 1u : 0u;
+        tagged.push_back(Tagged{PbHubItem{bv[pl->B + g], bv[pl->B + g + 1], pl->hub_first_host[g + 1] - pl->hub_first_host[g],
+                                          pl->hub_first_host[g], g},
+                                g < pl->hub_long_host.size() && pl->hub_long_host[g] != 0});
+    std::stable_sort(tagged.begin(), tagged.end(), [](const Tagged &a, const Tagged &c) { return a.item.q1 - a.item.q0 > c.item.q1 - c.item.q0; });
+    std::stable_partition(tagged.begin(), tagged.end(), [](const Tagged &a) { return a.is_long; }); // each part longest first
+    std::vector<PbHubItem> hubs;
+    pl->G_long = 0;
+    for (const Tagged &t : tagged) {
+        hubs.push_back(t.item);
+        pl->G_long += t.is_long ? 1u : 0u;
+    }
     GM_TRY(pl->hub_items.alloc((hubs.size() ? hubs.size() : 1) * sizeof(PbHubItem)));
     if (!hubs.empty())
         GM_HIP(hipMemcpy(pl->hub_items.p, hubs.data(), hubs.size() * sizeof(PbHubItem), hipMemcpyHostToDevice));
-    {
-        std::vector<uint32_t> first(pl->G_few + 1, 0u), group;
-        for (uint32_t g = 0; g < pl->G_few; ++g) {
-            const uint32_t nb = (hubs[g].q1 - hubs[g].q0 + PB_ACC_BLOCK * PB_VEC - 1) / (PB_ACC_BLOCK * PB_VEC);
-            first[g + 1] = first[g] + nb;
-            group.insert(group.end(), nb, g);
-        }
-        pl->few_blocks = first[pl->G_few];
-        // the groups of three or more rows: blocks of pb_hubseq_kernel
-        std::vector<uint32_t> sfirst(pl->G - pl->G_few + 1, 0u);
-        for (uint32_t g = pl->G_few; g < pl->G; ++g)
-            sfirst[g - pl->G_few + 1] = sfirst[g - pl->G_few] + (hubs[g].q1 - hubs[g].q0 + PB_ACC_BLOCK * PB_VEC - 1) / (PB_ACC_BLOCK * PB_VEC);
-        pl->seq_blocks = pl->hub_seq ? sfirst.back() : 0u;
-        GM_TRY(pl->seq_blk_first.alloc(sfirst.size() * 4));
-        GM_HIP(hipMemcpy(pl->seq_blk_first.p, sfirst.data(), sfirst.size() * 4, hipMemcpyHostToDevice));
-        GM_TRY(pl->few_blk_first.alloc(first.size() * 4));
-        GM_HIP(hipMemcpy(pl->few_blk_first.p, first.data(), first.size() * 4, hipMemcpyHostToDevice));
-        GM_TRY(pl->few_blk_group.alloc((group.size() ? group.size() : 1) * 4));
-        if (!group.empty())
-            GM_HIP(hipMemcpy(pl->few_blk_group.p, group.data(), group.size() * 4, hipMemcpyHostToDevice));
-    }
+    // blocks of the groups pb_hubseq_kernel walks
+    std::vector<uint32_t> sfirst(pl->G - pl->G_long + 1, 0u);
+    for (uint32_t g = pl->G_long; g < pl->G; ++g)
+        sfirst[g - pl->G_long + 1] = sfirst[g - pl->G_long] + (hubs[g].q1 - hubs[g].q0 + PB_ACC_BLOCK * PB_VEC - 1) / (PB_ACC_BLOCK * PB_VEC);
+    pl->seq_blocks = sfirst.back();
+    GM_TRY(pl->seq_blk_first.alloc(sfirst.size() * 4));
+    GM_HIP(hipMemcpy(pl->seq_blk_first.p, sfirst.data(), sfirst.size() * 4, hipMemcpyHostToDevice));
     return GM_OK;
 }
 
@@ -2058,7 +1688,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     // accumulator slots only for rows that have in-edges (RMAT: about half of the rows have none); hub rows
     // (summed in the reference's order, see the header) leave the ordinary bins and form hub groups
     pl->hub_deg = (uint32_t)pb_env("GM_PB_HUB_DEG", 4096);
-    pl->hub_seq = pb_env("GM_PB_HUB_SEQ", 1) ? 1u : 0u;
+    pl->hub_long = (uint32_t)pb_env("GM_PB_HUB_LONG", 32768);
     GM_TRY(pl->cidx.alloc((size_t)(n ? n : 1) * 2));
     pl->Racc = 1;
     DevBuf pos_h; // hub rows before each row (kept until the keys are built)
@@ -2093,15 +1723,21 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
                 target = (uint64_t)pb_env("GM_PB_HUB_GROUP", 0);
             uint64_t acc_edges = 0;
             uint32_t count = 0;
+            bool prev_long = false;
             for (uint32_t i = 0; i < pl->n_hub; ++i) {
                 pl->hub_edges += degs[i];
-                if (count && (count == PB_HUB_MAX || acc_edges + degs[i] > target)) {
+                const bool is_long = degs[i] >= pl->hub_long; // a group of its own: pb_hublong_kernel
+                pl->long_terms += is_long ? degs[i] : 0u;
+                if (count && (count == PB_HUB_MAX || acc_edges + degs[i] > target || is_long || prev_long)) {
                     pl->hub_first_host.push_back(i);
+                    pl->hub_long_host.push_back(prev_long ? 1 : 0);
                     acc_edges = 0, count = 0;
                 }
                 acc_edges += degs[i];
                 ++count;
+                prev_long = is_long;
             }
+            pl->hub_long_host.push_back(prev_long ? 1 : 0);
             pl->hub_first_host.push_back(pl->n_hub);
             pl->G = (uint32_t)pl->hub_first_host.size() - 1;
         }
@@ -2143,9 +1779,9 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
         int wgs = acc_bytes > 65536 ? 1 : 2; // accumulate workgroups per CU the LDS request should allow
         if (pb_env("GM_PB_WGS", 0) == 1 || (pb_env("GM_PB_WGS", 0) == 0 && acc_bytes > 32768))
             wgs = 1;
-        // static LDS of the accumulate kernel: PB_ACC_STATIC; with hub groups, room for one pb_hub_kernel workgroup
-        // (13.5 KiB) beside the accumulate workgroup(s) of a CU
-        size_t hub_room = (pl->G && pb_env("GM_PB_HUB_FORK", 1)) ? (pl->hub_seq ? PB_SEQ_LDS : 14336) : 0;
+        // static LDS of the accumulate kernel: PB_ACC_STATIC; with hub groups, room for one pb_hubseq_kernel workgroup
+        // (20 KiB) beside the accumulate workgroup(s) of a CU
+        size_t hub_room = (pl->G && pb_env("GM_PB_HUB_FORK", 1)) ? PB_SEQ_LDS : 0;
         if (pb_env("GM_PB_HUB_ROOM", -1) >= 0) // measurement: LDS left free beside an accumulate workgroup
             hub_room = (size_t)pb_env("GM_PB_HUB_ROOM", -1);
         const size_t budget = wgs == 1 ? (163840 - hub_room - PB_ACC_STATIC - acc_bytes)
@@ -2438,7 +2074,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     if (pl->seq_blocks) { // row-major places of the hub groups walked by pb_hubseq_kernel
         GM_TRY(pl->seq_rows.alloc((size_t)pl->seq_blocks * PB_HUB_MAX * 4));
         hipLaunchKernelGGL(pb_hubseq_layout_kernel, dim3(pl->seq_blocks), dim3(PB_ACC_BLOCK), 0, 0,
-                           pl->hub_items.as<PbHubItem>() + pl->G_few, pl->seq_blk_first.as<uint32_t>(), pl->G - pl->G_few,
+                           pl->hub_items.as<PbHubItem>() + pl->G_long, pl->seq_blk_first.as<uint32_t>(), pl->G - pl->G_long,
                            pl->p2_dst.as<uint16_t>(), pl->seq_rows.as<uint32_t>());
         GM_HIP(hipGetLastError());
         timer.done("pb plan: hub groups row-major (%u blocks)", pl->seq_blocks);
@@ -2883,21 +2519,12 @@ int pb_scratch_create(const PbPlan *pl, PbScratch **out, DevBuf *early)
     if ((rc = sc->vals_raw.p ? GM_OK : sc->vals_raw.alloc((size_t)(pl->Mv ? pl->Mv : 4) * 4 + slack)) ||
         (rc = sc->partials.alloc((size_t)(pl->slots ? pl->slots : 1) * pl->Racc * 8)) ||
         (rc = sc->tickets.alloc((size_t)pl->B * 4)) || (rc = sc->bin_err.alloc(((size_t)pl->B + pl->G) * 8)) ||
-        (rc = sc->hot_x.alloc(((size_t)pl->H * pl->T + 4) * 4)) ||
-        (pl->few_blocks && ((rc = sc->par_exact.alloc((size_t)pl->few_blocks * 2 * 8)) ||
-                            (rc = sc->par_binade.alloc((size_t)pl->few_blocks * 2 * 4)) ||
-                            (rc = sc->par_round.alloc((size_t)pl->few_blocks * 2 * 4 * 8)) ||
-                            (rc = sc->par_state.alloc((size_t)pl->G_few * 2 * 8)) || (rc = sc->par_ticket.alloc((size_t)pl->G_few * 4)) ||
-                            (rc = sc->par_fail.alloc((size_t)pl->G_few * 4))))) {
+        (rc = sc->hot_x.alloc(((size_t)pl->H * pl->T + 4) * 4))) {
         delete sc;
         return rc;
     }
     sc->vals = sc->vals_raw.as<float>();
     hipError_t e = hipMemset(sc->tickets.p, 0, (size_t)pl->B * 4);
-    if (e == hipSuccess && sc->par_ticket.p)
-        e = hipMemset(sc->par_ticket.p, 0, sc->par_ticket.bytes);
-    if (e == hipSuccess && sc->par_fail.p)
-        e = hipMemset(sc->par_fail.p, 0, sc->par_fail.bytes);
     if (e == hipSuccess)
         e = hipMemset(sc->vals_raw.p, 0, sc->vals_raw.bytes);
     // The hub kernels' streams get the LOWEST priority the device offers (GM_PB_SIDE_PRIO=0: the default one): their small
@@ -2906,7 +2533,7 @@ int pb_scratch_create(const PbPlan *pl, PbScratch **out, DevBuf *early)
     int prio_least = 0, prio_greatest = 0;
     if (e == hipSuccess && pb_env("GM_PB_SIDE_PRIO", 1))
         e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    if (e == hipSuccess && pl->few_blocks > pl->G_few) { // the long chains' own stream
+    if (e == hipSuccess && pl->G_long && pl->G > pl->G_long) { // the long rows' own stream
         e = hipStreamCreateWithPriority(&sc->chain, hipStreamNonBlocking, prio_least);
         if (e == hipSuccess)
             e = hipEventCreateWithFlags(&sc->ev_chain_fork, hipEventDisableTiming);
@@ -2947,16 +2574,8 @@ void pb_plan_info(const PbPlan *pl, const PbScratch *sc, uint64_t *info, uint32_
         plan_bytes += b->bytes;
     const uint64_t scratch_bytes = sc ? sc->vals_raw.bytes + sc->partials.bytes + sc->tickets.bytes + sc->bin_err.bytes +
                                             sc->hot_x.bytes : 0;
-    // long chains whose parallel walk fell back to the sequential one in the last sweep (a blocking read-back: diagnostics)
-    uint64_t fell_back = 0;
-    if (sc && sc->par_fail.p && pl->G_few) {
-        std::vector<uint32_t> f(pl->G_few);
-        if (hipMemcpy(f.data(), sc->par_fail.p, (size_t)pl->G_few * 4, hipMemcpyDeviceToHost) == hipSuccess)
-            for (uint32_t x : f)
-                fell_back += x ? 1u : 0u;
-    }
     const uint64_t v[] = {plan_bytes, (uint64_t)(pl->build_ms * 1000.0), pl->n_hub, pl->hub_edges, pl->hub_deg, pl->Htot,
-                          pl->Mv, pl->Mh, scratch_bytes, pl->B, pl->NT, pl->NS, pl->G, pl->T, pl->G_few, pl->few_blocks, fell_back,
+                          pl->Mv, pl->Mh, scratch_bytes, pl->B, pl->NT, pl->NS, pl->G, pl->T, pl->G_long, pl->long_terms, pl->seq_blocks,
                           sc ? sc->draw_best_us : 0u, sc ? sc->draw_worst_us : 0u, sc ? sc->draws_timed : 0u,
                           sc ? sc->grown_pieces : 0u, sc && !sc->vals_raw.arena.empty() ? 1u : 0u};
     for (uint32_t i = 0; i < count; ++i)
@@ -3034,46 +2653,27 @@ static void pb_accum_dispatch(const PbPlan *pl, PbScratch *sc, const PbItem *ite
 static void pb_hub_dispatch(const PbPlan *pl, PbScratch *sc, float *x_out, float *scores, const uint32_t *outdeg, float base,
                             float damping, hipStream_t st)
 {
-    const uint32_t long2 = (uint32_t)pb_env("GM_PB_HUB_LONG2", 0x7FFFFFFF), long4 = (uint32_t)pb_env("GM_PB_HUB_LONG4", 0x7FFFFFFF);
-    const uint32_t graded = (uint32_t)pb_env("GM_PB_HUB_GRADED", 3);
     double *gerr = sc->bin_err.as<double>() + pl->B;
-    // the long chains (groups of one or two rows) block-parallel on a stream of their own, beside the other groups: see
-    // pb_hubchain_kernel (GM_PB_HUB_PAR=0: the sequential walk, all groups in one launch)
-    const bool par = pl->G_few && pl->few_blocks > pl->G_few && sc->chain && pb_env("GM_PB_HUB_PAR", 1) && long2 == 0x7FFFFFFFu &&
-                     long4 == 0x7FFFFFFFu && !(pb_env("GM_PB_HUB_SKIP", 0) & 2);
-    const uint32_t first = par ? pl->G_few : 0u;
-    if (par) {
-        hipStream_t cs = sc->chain;
-        const PbHubItem *items = pl->hub_items.as<PbHubItem>();
-        (void)hipEventRecord(sc->ev_chain_fork, st);
-        (void)hipStreamWaitEvent(cs, sc->ev_chain_fork, 0);
-        hipLaunchKernelGGL(pb_hubchain_exact_kernel, dim3(pl->few_blocks), dim3(PB_CHAIN_WG), 0, cs, sc->vals, pl->p2_dst.as<uint16_t>(),
-                           items, pl->few_blk_first.as<uint32_t>(), pl->few_blk_group.as<uint32_t>(),
-                           sc->par_exact.as<unsigned long long>());
-        hipLaunchKernelGGL(pb_hub_kernel, dim3(pl->G_few), dim3(PB_ACC_BLOCK), 0, cs, sc->vals, pl->p2_dst.as<uint16_t>(), items,
-                           pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr, base, damping, long2, long4, graded,
-                           sc->par_state.as<unsigned long long>(), (const uint32_t *)nullptr);
-        hipLaunchKernelGGL(pb_hubchain_kernel, dim3(pl->few_blocks), dim3(PB_CHAIN_WG), 0, cs, sc->vals, pl->p2_dst.as<uint16_t>(), items,
-                           pl->few_blk_first.as<uint32_t>(), pl->few_blk_group.as<uint32_t>(), pl->hub_rows.as<uint32_t>(),
-                           sc->par_exact.as<unsigned long long>(), sc->par_state.as<unsigned long long>(), sc->par_binade.as<int>(),
-                           sc->par_round.as<unsigned long long>(), sc->par_ticket.as<uint32_t>(), sc->par_fail.as<uint32_t>(), outdeg,
-                           scores, x_out, gerr, base, damping);
-        hipLaunchKernelGGL(pb_hub_kernel, dim3(pl->G_few), dim3(PB_ACC_BLOCK), 0, cs, sc->vals, pl->p2_dst.as<uint16_t>(), items,
-                           pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr, base, damping, long2, long4, graded,
-                           (unsigned long long *)nullptr, sc->par_fail.as<uint32_t>());
-        (void)hipEventRecord(sc->ev_chain_join, cs);
-    }
-    const uint32_t seq_first = pl->seq_blocks ? pl->G_few : pl->G; // groups [seq_first, G): the reference's own sums, one lane per row
-    const int skip = pb_env("GM_PB_HUB_SKIP", 0); // measurement (wrong results by design): 1 = no pb_hubseq_kernel, 2 = no long chains
-    if (pl->G > seq_first && !(skip & 1))
-        hipLaunchKernelGGL(pb_hubseq_kernel, dim3(pl->G - seq_first), dim3(PB_SEQ_WG), 0, st, sc->vals, pl->p2_dst.as<uint16_t>(),
-                           pl->hub_items.as<PbHubItem>() + seq_first, pl->seq_blk_first.as<uint32_t>(), pl->seq_rows.as<uint32_t>(),
+    const PbHubItem *items = pl->hub_items.as<PbHubItem>();
+    const int skip = pb_env("GM_PB_HUB_SKIP", 0); // measurement (wrong results by design): 1 = no pb_hubseq_kernel, 2 = no long rows
+    // the long rows on a stream of their own beside the other groups (when there are both)
+    const bool own = pl->G_long && sc->chain;
+    hipStream_t ls = own ? sc->chain : st;
+    if (pl->G_long && !(skip & 2)) {
+        if (own) {
+            (void)hipEventRecord(sc->ev_chain_fork, st);
+            (void)hipStreamWaitEvent(ls, sc->ev_chain_fork, 0);
+        }
+        hipLaunchKernelGGL(pb_hublong_kernel, dim3(pl->G_long), dim3(PB_LONG_WG), 0, ls, sc->vals, pl->p2_dst.as<uint16_t>(), items,
                            pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr, base, damping);
-    if (seq_first > first && !(skip & 2))
-        hipLaunchKernelGGL(pb_hub_kernel, dim3(seq_first - first), dim3(PB_ACC_BLOCK), 0, st, sc->vals, pl->p2_dst.as<uint16_t>(),
-                           pl->hub_items.as<PbHubItem>() + first, pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr, base,
-                           damping, long2, long4, graded, (unsigned long long *)nullptr, (const uint32_t *)nullptr);
-    if (par)
+        if (own)
+            (void)hipEventRecord(sc->ev_chain_join, ls);
+    }
+    if (pl->G > pl->G_long && !(skip & 1))
+        hipLaunchKernelGGL(pb_hubseq_kernel, dim3(pl->G - pl->G_long), dim3(PB_SEQ_WG), 0, st, sc->vals, pl->p2_dst.as<uint16_t>(),
+                           items + pl->G_long, pl->seq_blk_first.as<uint32_t>(), pl->seq_rows.as<uint32_t>(),
+                           pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr, base, damping);
+    if (pl->G_long && !(skip & 2) && own)
         (void)hipStreamWaitEvent(st, sc->ev_chain_join, 0);
 }
 

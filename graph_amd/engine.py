@@ -57,8 +57,8 @@ class PageRankEngine:
         v = (C.c_uint64 * 22)()
         check(lib().gm_pr_plan_info(self._h, v, 22))
         keys = ("plan_bytes", "plan_build_us", "hub_rows", "hub_edges", "hub_in_degree", "hot_sources", "value_entries",
-                "hot_edges", "scratch_bytes", "bins", "source_tiles", "segments", "hub_groups", "hot_tiers", "long_chain_groups",
-                "long_chain_blocks", "long_chains_fell_back", "draw_best_us", "draw_worst_us", "draws_timed", "arena_grown_pieces",
+                "hot_edges", "scratch_bytes", "bins", "source_tiles", "segments", "hub_groups", "hot_tiers", "long_rows",
+                "long_row_terms", "hub_seq_blocks", "draw_best_us", "draw_worst_us", "draws_timed", "arena_grown_pieces",
                 "value_stream_from_arena")
         return dict(zip(keys, (int(x) for x in v)))
 

@@ -1,8 +1,9 @@
 """Hub rows of the propagation-blocking PageRank engine follow the reference's left-to-right f32 row sums
 (crates/algos/src/page_rank.rs:143-146): on long rows that order has a systematic drift (thousands of equal
 terms, each rounded the same way against the running sum), so matching the reference within 1e-5 means
-reproducing its rounding.  Checked two ways: one sweep from the same out_scores against the sequential sum
-(orc_page_rank_jacobi_sweep), and the fixed point against the reference's threaded path on EVERY row."""
+reproducing its rounding.  Since round 4 the hub rows' sums ARE those sums (pb_hubseq_kernel / pb_hublong_kernel).
+Checked two ways: one sweep from the same out_scores against the sequential sum (orc_page_rank_jacobi_sweep) — hub
+rows bit for bit — and the fixed point against the reference's threaded path on EVERY row."""
 import numpy as np
 import pytest
 
@@ -63,8 +64,9 @@ def test_one_sweep_hub_rows_match_the_sequential_sum(P, oracle, scale, monkeypat
     print(f"scale {scale}: one sweep vs sequential sums, hub rows: emulated order {rel[hub].max():.2e} (rms "
           f"{np.sqrt((rel[hub] ** 2).mean()):.2e}), exactly rounded {rel0[hub].max():.2e}; other rows {rel[~hub].max():.2e}")
     assert np.array_equal(got[~hub], exact[~hub])       # rows below the threshold are untouched
-    assert rel[hub].max() <= 3e-6                        # vs 9e-6 for the exactly rounded sum at this scale
-    assert rel[hub].max() < 0.5 * rel0[hub].max()
+    assert np.array_equal(got[hub], seq[hub])           # hub rows: the reference's own left-to-right f32 sums, bit for bit
+    assert info["long_rows"] == int((deg >= 32768).sum()) and info["long_row_terms"] == int(deg[deg >= 32768].sum())
+    assert rel0[hub].max() > 3e-6                        # what the exactly rounded sum misses at this scale (9e-6)
     assert rel.max() <= 5e-6
 
 
@@ -82,21 +84,16 @@ def test_fixed_point_within_1e5_of_the_reference_on_every_row(P, oracle, scale):
     assert rel.max() <= 1e-5
 
 
-@pytest.mark.parametrize("long2,long4", [("4096", "1000000000"), ("4096", "16384"), ("1", "1")])
-def test_long_chains_with_two_and_four_blocks_per_step(P, oracle, monkeypatch, long2, long4):
-    """Long chains can be walked two or four 4096-term blocks per step (GM_PB_HUB_LONG2 / GM_PB_HUB_LONG4, off by
-    default: at scale 24 the four-block walk of the 400,000-term row costs parity margin).  With the thresholds lowered
-    every hub row of a scale-20 graph takes those paths: the fixed point must stay within the guard of the reference on
-    every row, and the two walks — each within ~2.6e-6 of the reference — within 5e-6 of each other."""
+@pytest.mark.parametrize("hub_long", ["4096", "20000", "1000000000"])
+def test_hub_rows_give_the_same_bits_whichever_kernel_sums_them(P, oracle, monkeypatch, hub_long):
+    """Rows of at least GM_PB_HUB_LONG (32768) in-edges are summed by pb_hublong_kernel (runs of 16 terms composed by a scan),
+    shorter hub rows by pb_hubseq_kernel (one lane per row): both compute the reference's left-to-right f32 sum, so the
+    threshold between them must not change a bit — every hub row through the scan, the usual split, every one through the
+    lane walk."""
     n, g, ioff, itgt, od = _graph(P, oracle, 20)
-    ref, _, _ = oracle.page_rank_chunked(ioff, itgt, od, 200, 1e-10, 0.85)
-    base, _, _ = P.page_rank(g, P.PageRankConfig(200, 1e-10, 0.85), P.PageRankMode.JacobiPB)
-    monkeypatch.setenv("GM_PB_HUB_LONG2", long2)
-    monkeypatch.setenv("GM_PB_HUB_LONG4", long4)
-    got, _, _ = P.page_rank(g, P.PageRankConfig(200, 1e-10, 0.85), P.PageRankMode.JacobiPB)
-    rel = np.abs(got.astype(np.float64) - ref) / ref
-    deg = np.diff(ioff.astype(np.int64))
-    print(f"long2 {long2} long4 {long4}: max rel vs the reference {rel.max():.2e} (hub rows {rel[deg >= 4096].max():.2e}), "
-          f"vs the one-block walk {np.abs(got.astype(np.float64) - base).max() / base.max():.2e}")
-    assert rel.max() <= 6e-6
-    assert (np.abs(got.astype(np.float64) - base) / base).max() <= 5e-6
+    cfg = P.PageRankConfig(30, 0.0, 0.85)
+    base, _, eb = P.page_rank(g, cfg, P.PageRankMode.JacobiPB)
+    monkeypatch.setenv("GM_PB_HUB_LONG", hub_long)
+    monkeypatch.setenv("GM_PB_NOCACHE", "1")
+    got, _, eg = P.page_rank(g, cfg, P.PageRankMode.JacobiPB)
+    assert np.array_equal(got, base) and eg == eb

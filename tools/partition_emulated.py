@@ -28,8 +28,7 @@ for n_parts in [int(p) for p in args.parts.split(",")]:
         m = re.search(r"all-gather of (\d+) B/rank/sweep", d["config"]["partition"])
         ranks.append({"rank": r, "sweep_ms": d["ms_per_step"], "edges": d["roofline"]["edges_per_launch"],
                       "rows": d["roofline"]["rows_per_launch"], "exchange_bytes_sent": int(m.group(1)) if m else 0,
-                      "long_chain_groups": h.get("long_chain_groups"), "long_chain_blocks": h.get("long_chain_blocks"),
-                      "long_chains_fell_back": h.get("long_chains_fell_back")})
+                      "long_rows": h.get("long_rows"), "long_row_terms": h.get("long_row_terms")})
         edges_total, device = d["config"]["edges"], d["config"]["device"]
         print(f"parts {n_parts} rank {r}: {d['ms_per_step']} ms", file=sys.stderr, flush=True)
     slow = max(x["sweep_ms"] for x in ranks)

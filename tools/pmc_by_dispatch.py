@@ -3,7 +3,7 @@
 usage: pmc_by_dispatch.py <dir-or-db> [kernel-substring ...]  ->  one line per dispatch: kernel, duration, counters"""
 import glob, os, sqlite3, sys
 
-src, pats = sys.argv[1], sys.argv[2:] or ["pb_bin_kernel", "pb_accum_kernel", "pb_hub_kernel"]
+src, pats = sys.argv[1], sys.argv[2:] or ["pb_bin_kernel", "pb_accum_kernel", "pb_hubseq_kernel", "pb_hublong_kernel"]
 dbs = [src] if src.endswith(".db") else sorted(glob.glob(os.path.join(src, "**", "*.db"), recursive=True))
 for db in dbs:
     c = sqlite3.connect(db)

@@ -21,12 +21,12 @@ rec["_method"] = (
     "(calibrated on pr_init_kernel: two 268,435,456-byte arrays written -> WRITE_SIZE 524288 KiB).")
 entry = {}
 total = 0
-# one sweep = one pb_accum_kernel (or pr_tile_kernel) dispatch; kernels launched several times per sweep (pb_hub_kernel: the
+# one sweep = one pb_accum_kernel (or pr_tile_kernel) dispatch; kernels launched several times per sweep (round 3's pb_hub_kernel: the
 # long chains' first blocks, their fall-back, the other groups) count with all their dispatches.  pb_bin_kernel also runs
 # outside sweeps (the timed placement draws of pb_scratch_create): its per-dispatch average is what one sweep moves.
 sweeps = max([c.get("FETCH_SIZE_dispatches", 0) for name, c in d.items() if "pb_accum_kernel" in name or "pr_tile_kernel" in name] or [0])
 for name, c in d.items():
-    if any(k in name for k in ("pb_bin_kernel", "pb_accum_kernel", "pb_hub_kernel", "pb_hubchain", "pr_tile_kernel", "pb_hot_gather")):
+    if any(k in name for k in ("pb_bin_kernel", "pb_accum_kernel", "pb_hub_kernel", "pb_hubchain", "pb_hubseq_kernel", "pb_hublong_kernel", "pr_tile_kernel", "pb_hot_gather")):
         short = name.split("::")[-1].split("(")[0].split("<")[0]
         if sweeps and "FETCH_SIZE_total" in c and "pb_bin_kernel" not in name:
             f, w = c.get("FETCH_SIZE_total", 0) / sweeps, c.get("WRITE_SIZE_total", 0) / sweeps
