@@ -39,7 +39,7 @@
 // CSR order of the Sorted / Deduplicated layouts.  Their sums are then COMPUTED the reference's way, bit for bit
 // for the same out_scores (rounds 2 and 3 imitated the order with integer counts of ulps per 4096-entry step,
 // within ~3e-6 and at the price of as many vector instructions as the accumulate kernel itself):
-//   pb_hubseq_kernel   rows below `hub_long` terms (32768): a group's 4096-entry blocks are made row-major in LDS by a
+//   pb_hubseq_kernel   rows below `hub_long` terms (8192 or more, see pb_build): a group's 4096-entry blocks are made row-major in LDS by a
 //                      permutation fixed at plan time, and lane g of one wavefront adds row g's terms in order,
 //                      one v_add_f32 per term;
 //   pb_hublong_kernel  longer rows, one workgroup each: inside one binade of the running sum S = J ulp, adding a term
@@ -80,7 +80,7 @@ constexpr uint32_t PB_SEQ_PAD = 16;  // a row's stretch of the staged block is p
 constexpr uint32_t PB_SEQ_BUF = PB_ACC_BLOCK * PB_VEC + PB_HUB_MAX * (PB_SEQ_PAD - 1); // floats: 4096 terms + the rows' padding
 constexpr size_t PB_SEQ_LDS = 20480; // static LDS of pb_hubseq_kernel, rounded up
 constexpr uint32_t PB_LONG_WG = 512;  // threads of a pb_hublong_kernel workgroup
-constexpr uint32_t PB_LONG_PER = 16;  // consecutive terms per thread and pass
+constexpr uint32_t PB_LONG_PER = 32;  // consecutive terms per thread and pass
 constexpr int PB_TIERS_DEFAULT = 16;  // at most this many tiers of hot sources unless GM_PB_TIERS says otherwise
 constexpr float PB_FIX_SCALE = 4611686018427387904.0f;     // 2^62
 constexpr float PB_FIX_INV = 2.168404344971008868e-19f;    // 2^-62
@@ -158,7 +158,7 @@ struct PbPlan {
     DevBuf hub_rows;       // u32[n_hub] row id of every hub row, ascending
     DevBuf hub_first;      // u32[G+1]   first hub row (index into hub_rows) of every group
     DevBuf hub_items;      // PbHubItem[G]: the G_long groups that are one long row first, each part longest first
-    uint32_t hub_long = 32768; // rows with at least this many in-edges are a group of their own (pb_hublong_kernel); GM_PB_HUB_LONG
+    uint32_t hub_long = 8192;  // rows with at least this many in-edges are a group of their own (pb_hublong_kernel): see pb_build
     uint32_t G_long = 0;
     uint64_t long_terms = 0;   // in-edges of the long rows
     std::vector<uint32_t> hub_first_host;
@@ -679,6 +679,11 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 struct alignas(8) U16x4 {
     uint16_t a, b, c, d;
 };
+
+// A workgroup barrier for data exchanged through LDS only.  __syncthreads() also waits for every outstanding global load
+// (s_waitcnt vmcnt(0)): a kernel that keeps the next block's loads in flight across its barriers would wait for them at
+// the first one — measured on pb_hubseq_kernel / pb_hublong_kernel: the whole memory latency exposed once per block.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 constexpr int PB_BIN_U = 4;         // 256-entry blocks a wavefront of pb_bin_kernel handles per pipeline stage
 constexpr int PB_ACC_DEPTH = 4;     // register groups (float4 + 4 slots per lane) of pb_accum_kernel's value stream in flight
@@ -1269,7 +1274,7 @@ __global__ __launch_bounds__(PB_SEQ_WG) void pb_hubseq_kernel(const float *__res
         if (walker)
             info_a = ri[(size_t)PB_HUB_MAX + tid];
     }
-    __syncthreads();
+    lds_barrier();
     float S = 0.0f; // page_rank.rs:143: the row's sum starts at zero ...
     const f32x4 *b4 = reinterpret_cast<const f32x4 *>(buf);
     // one block: `cur` holds block b + 1 (requested one round ago), block b + 2 is requested into `nxt`, block b is walked
@@ -1325,11 +1330,11 @@ __global__ __launch_bounds__(PB_SEQ_WG) void pb_hubseq_kernel(const float *__res
             if (more)
                 pads(info_cur); // the next block's arrangement: these slots are not among the places its terms are scattered to
         }
-        __syncthreads(); // the walk is over: the buffer may be overwritten
+        lds_barrier(); // the walk is over: the buffer may be overwritten
         if (more)
             scatter(cur);
         info = info_cur;
-        __syncthreads();
+        lds_barrier();
     };
     for (uint32_t b = 0; b < nb; b += 2u) {
         round(b, sa, info_a, sb, info_b);
@@ -1350,12 +1355,12 @@ __global__ __launch_bounds__(PB_SEQ_WG) void pb_hubseq_kernel(const float *__res
 // unless t ends in exactly .5, where the result is the EVEN one of J + floor(t) and J + floor(t) + 1: it depends on J only
 // through its parity.  So a run of terms acts on J as (count added when the run starts on an even J, count added when it
 // starts on an odd J), and two runs compose into such a pair again — an associative operation, hence a scan:
-//   every thread takes 16 consecutive terms and forms its pair (one pass over the terms when none of them is a tie);
+//   every thread takes 32 consecutive terms and forms its pair (one pass over the terms when none of them is a tie);
 //   an exclusive scan over the workgroup gives every thread the J its run starts from;
 //   the first thread whose run ends at or beyond 2^24 — S leaves the binade there — starts from an exactly known S and
-//   adds its 16 terms with v_add_f32, one after the other; everything behind it is redone on the new grid.
+//   adds its 32 terms with v_add_f32, one after the other; everything behind it is redone on the new grid.
 // S leaves a binade a few dozen times per row (and at every doubling of the first few thousand terms), so a super-block of
-// 8192 terms costs one pass, sometimes two.  Bit for bit the reference's sum: tests/test_gpu_hub_adversarial.py compares
+// 16384 terms costs one pass (one barrier), sometimes two.  Bit for bit the reference's sum: tests/test_gpu_hub_adversarial.py compares
 // rows of up to 2^20 + 1 terms with orc_page_rank_jacobi_sweep's sequential sums for equality.
 __global__ __launch_bounds__(PB_LONG_WG) void pb_hublong_kernel(const float *__restrict__ vals, const uint16_t *__restrict__ p2_dst,
                                                                 const PbHubItem *__restrict__ items,
@@ -1365,8 +1370,14 @@ __global__ __launch_bounds__(PB_LONG_WG) void pb_hublong_kernel(const float *__r
                                                                 float damping)
 {
     constexpr uint32_t NWV = PB_LONG_WG / kWave, PER = PB_LONG_PER, SUPER = PB_LONG_WG * PER, SAT = 1u << 30, NONE = 0xFFFFFFFFu;
-    __shared__ uint32_t w_a0[NWV], w_a1[NWV], w_first[NWV];
+    constexpr uint32_t WARM = 32; // threads whose terms (the row's first 1024) are added one after the other, see below
+    // per wavefront: its runs composed, the first thread whose run leaves the binade; two copies used in turn: a wavefront
+    // that leaves a pass through its single barrier may write the next pass's totals while another still reads these
+    __shared__ uint32_t w_a0s[2][NWV], w_a1s[2][NWV], w_firsts[2][NWV];
     __shared__ float s_bcast;
+    constexpr uint32_t TROW = PER + 4; // floats between two threads' rows in the turning buffer
+    __shared__ __attribute__((aligned(16))) float tbuf[(PB_LONG_WG / 4) * TROW];
+    static_assert(PB_LONG_WG == 512 && PB_LONG_PER == 32, "the turning buffer is laid out for 512 threads x 32 terms");
     const PbHubItem item = items[blockIdx.x]; // one row: slot 0 (padding entries: PB_NULL)
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     // (counts from an even / odd start) of run F followed by run G; saturated: beyond the first run that leaves the binade
@@ -1375,75 +1386,146 @@ __global__ __launch_bounds__(PB_LONG_WG) void pb_hublong_kernel(const float *__r
         const uint32_t n0 = f0 + ((f0 & 1u) ? g1 : g0), n1 = f1 + ((f1 & 1u) ? g0 : g1);
         h0 = n0 < SAT ? n0 : SAT, h1 = n1 < SAT ? n1 : SAT;
     };
-    float S = 0.0f; // page_rank.rs:143
-    for (uint32_t sb = item.q0; sb < item.q1; sb += SUPER) {
-        float v[PER];
+    // The super-block at sb as the memory system likes it: lane-interleaved float4s (a thread reading its own 32 consecutive
+    // terms touches a cache line of its own with every load — 64 lines per wavefront instruction, measured ~4 us per
+    // super-block and CU).  Padding entries and what lies behind the row: 0.  w[(2 r + c) 4 ..] = round r, float4 c.
+    auto fetch = [&](uint32_t sb, float(&w)[PER]) {
 #pragma unroll
-        for (uint32_t j = 0; j < PER; j += 4) {
-            const uint32_t q = sb + tid * PER + j;
-            v[j] = v[j + 1] = v[j + 2] = v[j + 3] = 0.0f;
+        for (uint32_t k = 0; k < PER / 4; ++k) {
+            const uint32_t q = sb + (k * PB_LONG_WG + tid) * 4u;
+            w[4 * k] = w[4 * k + 1] = w[4 * k + 2] = w[4 * k + 3] = 0.0f;
             if (q < item.q1) {
                 const f32x4 x = *reinterpret_cast<const f32x4 *>(vals + q);
                 const u32x2 d = *reinterpret_cast<const u32x2 *>(p2_dst + q);
-                v[j] = (d.x & 0xFFFFu) == 0u ? x.x : 0.0f;
-                v[j + 1] = (d.x >> 16) == 0u ? x.y : 0.0f;
-                v[j + 2] = (d.y & 0xFFFFu) == 0u ? x.z : 0.0f;
-                v[j + 3] = (d.y >> 16) == 0u ? x.w : 0.0f;
+                w[4 * k] = (d.x & 0xFFFFu) == 0u ? x.x : 0.0f;
+                w[4 * k + 1] = (d.x >> 16) == 0u ? x.y : 0.0f;
+                w[4 * k + 2] = (d.y & 0xFFFFu) == 0u ? x.z : 0.0f;
+                w[4 * k + 3] = (d.y >> 16) == 0u ? x.w : 0.0f;
             }
         }
+    };
+    // ... and turned, a quarter (4096 terms) at a time through 18 KiB of LDS, into 32 CONSECUTIVE terms per thread: the 128
+    // threads that own the quarter read their rows (36 floats apart: conflict-free 16-byte reads)
+    auto turn = [&](const float(&w)[PER], float(&out)[PER]) {
+#pragma unroll
+        for (uint32_t r = 0; r < 4; ++r) {
+#pragma unroll
+            for (uint32_t c = 0; c < 2; ++c) {
+                const uint32_t i = (c * PB_LONG_WG + tid) * 4u, k = 2 * r + c; // place inside the quarter
+                f32x4 x;
+                x.x = w[4 * k], x.y = w[4 * k + 1], x.z = w[4 * k + 2], x.w = w[4 * k + 3];
+                *reinterpret_cast<f32x4 *>(tbuf + (i >> 5) * TROW + (i & 31u)) = x;
+            }
+            lds_barrier();
+            if ((tid >> 7) == r) {
+#pragma unroll
+                for (uint32_t k = 0; k < PER / 4; ++k) {
+                    const f32x4 x = *reinterpret_cast<const f32x4 *>(tbuf + (tid & 127u) * TROW + 4 * k);
+                    out[4 * k] = x.x, out[4 * k + 1] = x.y, out[4 * k + 2] = x.z, out[4 * k + 3] = x.w;
+                }
+            }
+            lds_barrier();
+        }
+    };
+    float S = 0.0f; // page_rank.rs:143
+    uint32_t flip = 0;
+    float v[PER], vn[PER];
+    fetch(item.q0, vn);
+    for (uint32_t sb = item.q0; sb < item.q1; sb += SUPER) {
+        turn(vn, v);
+        if (item.q1 - sb > SUPER) // the next super-block's terms travel while this one's are added (every barrier below waits
+            fetch(sb + SUPER, vn); // for LDS traffic only: __syncthreads() would wait for these loads as well)
         uint32_t done = 0; // threads below `done` have had their terms added
+        if (sb == item.q0) {
+            // The row's first terms: a sum that starts at zero doubles after 2, 4, 8, ... terms, and every doubling would
+            // be a pass of its own.  The first 32 threads' terms (1024) are simply added in order by wavefront 0, the sum
+            // handed from lane to lane: ~170 cycles per thread instead of a pass of the whole workgroup per doubling.
+            if (wave == 0) {
+                float s = 0.0f;
+                for (uint32_t k = 0; k < WARM; ++k) {
+                    float mine = s;
+#pragma unroll
+                    for (uint32_t j = 0; j < PER; ++j)
+                        mine = __fadd_rn(mine, v[j]); // page_rank.rs:144-146
+                    s = __shfl(mine, (int)k, kWave);
+                }
+                if (lane == 0)
+                    s_bcast = s;
+            }
+            lds_barrier();
+            S = s_bcast;
+            done = WARM;
+        }
         for (;;) {
+            uint32_t *w_a0 = w_a0s[flip], *w_a1 = w_a1s[flip], *w_first = w_firsts[flip];
+            flip ^= 1u;
             const uint32_t sbits = __float_as_uint(S), e = sbits >> 23; // S >= 0
             const bool binade = e >= 24u && e < 255u;                   // S is a normal number with a usable grid
             const uint32_t J0 = (sbits & 0x7FFFFFu) | 0x800000u;
             const float iu = __uint_as_float((277u - (binade ? e : 150u)) << 23); // 1 / ulp(S)
             const float ulp = __uint_as_float(((binade ? e : 150u) - 23u) << 23);
+            // my run as (count from an even J, count from an odd J); a term of 2^24 ulps or more makes the count reach 2^24 by
+            // itself, which is what marks the run as the one where S leaves the binade
             uint32_t a0 = 0, a1 = 0;
-            bool big = false;
+            bool tie = false;
             if (tid >= done) {
                 if (!binade) {
-                    big = true; // S is still zero (or tiny): the first thread adds its terms the slow way
+                    a0 = a1 = SAT; // S is still zero (or tiny): the first thread adds its terms the slow way
                 } else {
-                    bool tie = false;
                     uint32_t sum = 0;
 #pragma unroll
                     for (uint32_t j = 0; j < PER; ++j) {
-                        const float t = v[j] * iu; // exact: a power-of-two scaling
-                        const bool ok = t < 16777216.0f;
-                        big |= !ok; // a term of at least 2^24 ulps: S leaves the binade here for certain
-                        sum += ok ? (uint32_t)__builtin_rintf(t) : 0u;
-                        tie |= (t - __builtin_floorf(t)) == 0.5f;
+                        const float t = __builtin_fminf(v[j] * iu, 16777216.0f); // exact: a power-of-two scaling
+                        const float r = __builtin_rintf(t);
+                        sum += (uint32_t)r;
+                        tie |= __builtin_fabsf(t - r) == 0.5f; // t - r is exact
                     }
-                    a0 = a1 = sum < SAT ? sum : SAT;
-                    if (tie && !big) { // the two-state walk: a tie goes to the even J
+                    a0 = a1 = sum; // <= 32 x 2^24 < SAT
+                    if (tie) { // the two-state walk: a tie goes to the even J
                         uint32_t x0 = 0, x1 = 0, p0 = 0, p1 = 1;
-#pragma unroll
+#pragma unroll 4
                         for (uint32_t j = 0; j < PER; ++j) {
-                            const float t = v[j] * iu, fl = __builtin_floorf(t);
+                            const float t = __builtin_fminf(v[j] * iu, 16777216.0f), fl = __builtin_floorf(t);
                             const uint32_t c = (uint32_t)__builtin_rintf(t), f = (uint32_t)fl;
                             const bool half = (t - fl) == 0.5f;
                             const uint32_t c0 = half ? f + ((p0 + f) & 1u) : c, c1 = half ? f + ((p1 + f) & 1u) : c;
                             x0 += c0, x1 += c1;
                             p0 = (p0 + c0) & 1u, p1 = (p1 + c1) & 1u;
                         }
-                        a0 = x0 < SAT ? x0 : SAT, a1 = x1 < SAT ? x1 : SAT;
+                        a0 = x0, a1 = x1;
                     }
                 }
             }
-            // inclusive scan over the wavefront, then the wavefronts before this one
-            uint32_t i0 = a0, i1 = a1;
+            // the wavefront's runs composed.  Without a tie in the wavefront a run adds the same count from either parity and
+            // composing is adding: a butterfly sum of one value; otherwise the inclusive scan of the pairs.
+            const bool wave_tie = __ballot(tie) != 0ull;
+            uint32_t i0 = a0, i1 = a1; // the scan, when it is made
+            bool scanned = false;
+            auto scan = [&]() {
 #pragma unroll
-            for (uint32_t o = 1; o < (uint32_t)kWave; o <<= 1) {
-                const uint32_t f0 = (uint32_t)__shfl_up((int)i0, o, kWave), f1 = (uint32_t)__shfl_up((int)i1, o, kWave);
-                if (lane >= o)
-                    compose(f0, f1, i0, i1, i0, i1);
+                for (uint32_t o = 1; o < (uint32_t)kWave; o <<= 1) {
+                    const uint32_t f0 = (uint32_t)__shfl_up((int)i0, o, kWave), f1 = (uint32_t)__shfl_up((int)i1, o, kWave);
+                    if (lane >= o)
+                        compose(f0, f1, i0, i1, i0, i1);
+                }
+                scanned = true;
+            };
+            uint32_t wt0, wt1;
+            if (wave_tie) {
+                scan();
+                wt0 = (uint32_t)__shfl((int)i0, kWave - 1, kWave), wt1 = (uint32_t)__shfl((int)i1, kWave - 1, kWave);
+            } else {
+                uint32_t x = a0;
+#pragma unroll
+                for (int o = kWave / 2; o > 0; o >>= 1) {
+                    x += (uint32_t)__shfl_xor((int)x, o, kWave);
+                    x = x < SAT ? x : SAT;
+                }
+                wt0 = wt1 = x;
             }
-            uint32_t e0 = (uint32_t)__shfl_up((int)i0, 1, kWave), e1 = (uint32_t)__shfl_up((int)i1, 1, kWave);
             if (lane == 0)
-                e0 = e1 = 0u;
-            if (lane == kWave - 1)
-                w_a0[wave] = i0, w_a1[wave] = i1;
-            __syncthreads();
+                w_a0[wave] = wt0, w_a1[wave] = wt1;
+            lds_barrier();
             uint32_t b0 = 0, b1 = 0, t0 = 0, t1 = 0; // the wavefronts before this one; all of them
 #pragma unroll
             for (uint32_t w = 0; w < NWV; ++w) {
@@ -1452,24 +1534,30 @@ __global__ __launch_bounds__(PB_LONG_WG) void pb_hublong_kernel(const float *__r
                 compose(t0, t1, w_a0[w], w_a1[w], t0, t1);
             }
             const uint32_t P0 = J0 & 1u;
+            if (binade && J0 + (P0 ? t1 : t0) < (1u << 24)) { // every remaining run stayed inside the binade:
+                S = (float)(J0 + (P0 ? t1 : t0)) * ulp;        // S = (J0 + count) ulp, exactly — the common pass, one barrier
+                break;
+            }
+            // S leaves the binade somewhere: the first thread in whose run it does
+            if (!scanned)
+                scan();
+            uint32_t e0 = (uint32_t)__shfl_up((int)i0, 1, kWave), e1 = (uint32_t)__shfl_up((int)i1, 1, kWave);
+            if (lane == 0)
+                e0 = e1 = 0u;
             const uint32_t bw = P0 ? b1 : b0;             // added by the wavefronts before this one
             const uint32_t pw = (P0 + bw) & 1u;
             const uint32_t bl = pw ? e1 : e0;             // ... and by the lanes before this one
             const uint32_t before = (bw + bl) < SAT ? bw + bl : SAT;
             const uint32_t mine = ((pw + bl) & 1u) ? a1 : a0;
-            const bool cross = tid >= done && (big || J0 + before + mine >= (1u << 24));
+            const bool cross = tid >= done && (!binade || J0 + before + mine >= (1u << 24));
             const uint64_t cm = __ballot(cross);
             if (lane == 0)
                 w_first[wave] = cm ? wave * kWave + (uint32_t)__ffsll((unsigned long long)cm) - 1u : NONE;
-            __syncthreads();
+            lds_barrier();
             uint32_t first = NONE;
 #pragma unroll
             for (uint32_t w = 0; w < NWV; ++w)
                 first = w_first[w] < first ? w_first[w] : first;
-            if (first == NONE) { // every remaining run stayed inside the binade: S = (J0 + count) ulp, exactly
-                S = (float)(J0 + (P0 ? t1 : t0)) * ulp;
-                break;
-            }
             if (tid == first) {
                 float s = binade ? (float)(J0 + before) * ulp : S; // exact: J0 + before < 2^24
 #pragma unroll
@@ -1477,7 +1565,7 @@ __global__ __launch_bounds__(PB_LONG_WG) void pb_hublong_kernel(const float *__r
                     s = __fadd_rn(s, v[j]); // page_rank.rs:144-146
                 s_bcast = s;
             }
-            __syncthreads();
+            lds_barrier();
             S = s_bcast;
             done = first + 1u;
             if (done >= PB_LONG_WG)
@@ -1688,7 +1776,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     // accumulator slots only for rows that have in-edges (RMAT: about half of the rows have none); hub rows
     // (summed in the reference's order, see the header) leave the ordinary bins and form hub groups
     pl->hub_deg = (uint32_t)pb_env("GM_PB_HUB_DEG", 4096);
-    pl->hub_long = (uint32_t)pb_env("GM_PB_HUB_LONG", 32768);
+    pl->hub_long = pb_env("GM_PB_HUB_LONG", 0) > 0 ? (uint32_t)pb_env("GM_PB_HUB_LONG", 0) : 8192u;
     GM_TRY(pl->cidx.alloc((size_t)(n ? n : 1) * 2));
     pl->Racc = 1;
     DevBuf pos_h; // hub rows before each row (kept until the keys are built)
@@ -1721,6 +1809,17 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
                 target = 65536;
             if (pb_env("GM_PB_HUB_GROUP", 0) > 0)
                 target = (uint64_t)pb_env("GM_PB_HUB_GROUP", 0);
+            // Which rows are "long"?  A row walked by one lane of pb_hubseq_kernel costs ~6 ns per term, all of it latency (a
+            // chain of dependent adds); pb_hublong_kernel sums a row of 10^4 terms in ~15 us and one of 10^6 in ~100, but
+            // keeps a 512-thread workgroup busy with vector work.  So: rows of at least 8192 in-edges, but not more than
+            // about two per CU — the threshold moves up until at most 512 rows are long.  GM_PB_HUB_LONG fixes it.
+            if (pb_env("GM_PB_HUB_LONG", 0) <= 0) {
+                std::vector<uint32_t> sorted(degs);
+                std::sort(sorted.begin(), sorted.end(), [](uint32_t a, uint32_t c) { return a > c; });
+                pl->hub_long = 8192;
+                if (sorted.size() > 512 && sorted[512] + 1u > pl->hub_long)
+                    pl->hub_long = sorted[512] + 1u;
+            }
             uint64_t acc_edges = 0;
             uint32_t count = 0;
             bool prev_long = false;
