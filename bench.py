@@ -16,10 +16,16 @@ N = 1: the whole graph on one GPU.  N > 1: 1-D vertex-range partition (reference
 partitioner), replicated out_scores, one RCCL all-gather per sweep — strong scaling (fixed graph).
 
 Extra objects in the JSON line:
-  roofline      dominant kernel (pr_tile_kernel): algorithmic bytes per launch (8m + 20n + 4 over the
-                rank's rows) / its average duration measured here with HIP events on the launch stream
+  roofline      the sweep's kernels (propagation blocking: pb_bin_kernel, then pb_accum_kernel with pb_hubseq_kernel /
+                pb_hublong_kernel beside it; below 2^24 edges pr_tile_kernel): algorithmic bytes per launch (8m + 20n + 4
+                over the rank's rows) / their average duration measured here with HIP events on the launch stream;
+                `traffic` = HBM bytes per sweep from profiles/pmc_traffic.json IF that record was measured on the very
+                library this process loaded (sha256 stamp), else null
   cpu_baseline  the oracle's restatement of the reference's threaded path (oracle/graph_oracle.c:
                 orc_page_rank_chunked; kind "port") timed on this box's host cores on the same graph
+  extra         N = 1: the reference app's other three algorithms in the same run (crates/app/src/app.rs:124-153 times all four):
+                wcc_afforest RMAT scale-22, delta_stepping and global_triangle_count scale-24 — device time, byte-model
+                roofline, threaded CPU leg, bit-exactness (tools/bench_algos.py; --algos 0 skips it)
 """
 from __future__ import annotations
 
@@ -48,6 +54,8 @@ def parse_args():
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores (available_parallelism)")
     ap.add_argument("--parity", type=int, default=1, help="N = 1, inside the cpu_baseline leg: run the timed engine and the CPU "
                     "path to their fixed points and compare every row (about 20 s of host time at scale 26; 0 = skip)")
+    ap.add_argument("--algos", type=int, default=1, help="N = 1, default scale only: WCC scale 22 / SSSP scale 24 / triangle count scale 24 "
+                    "after the PageRank leg -> `extra` (about 15 s; 0 = skip)")
     ap.add_argument("--relabel", type=int, default=0, help="(experimental) internal degree-ordered layout")
     ap.add_argument("--engine", choices=["auto", "pull", "pb"], default="auto")
     ap.add_argument("--prewarm-ms", type=float, default=400.0, help="untimed sweeps before the W warm-up steps so "
@@ -107,6 +115,22 @@ def _device_note(torch, dev):
         return note
     except Exception as exc:  # informational only
         return f"unknown ({exc})"
+
+
+def _placement(plan, engine, scale):
+    """How the value stream's memory was chosen (arena.hip / pb_scratch_create) and which LEVEL this process landed on: the
+    bin kernel's rate by its byte model during the timed draws — at RMAT scale 26 the fast level is 4060-4500 GB/s, the slow
+    one (about one process in four, box-dependent, profiles/r03_box_survey.txt) <= 3700."""
+    out = {k: plan.get(k) for k in ("value_stream_from_arena", "draws_timed", "draw_best_us", "draw_worst_us", "arena_grown_pieces")}
+    us = plan.get("draw_best_us") or 0
+    if us and plan.get("draws_timed", 0) > 0:
+        moved = plan.get("value_entries", 0) * 6 + (1 << scale) * 4  # 2 B id + 4 B value per entry + the out_scores once
+        gbs = moved / (us * 1e-6) / 1e9
+        out["bin_kernel_GBps_by_byte_model"] = round(gbs, 0)
+        out["level"] = "fast" if gbs >= 4000 else ("medium" if gbs >= 3700 else "slow")
+        if out["level"] == "slow":
+            out["note"] = "every candidate placement of the value stream stayed at the slow level in this process"
+    return out
 
 
 def main():
@@ -332,16 +356,27 @@ def main():
     alg_bytes = engine.algorithmic_bytes  # 8*m_local + 20*n_local + 4
     achieved = alg_bytes / (tile_ms_avg * 1e-3) / 1e9 if tile_ms_avg > 0 else 0.0
 
-    # PMC-derived HBM traffic per launch, if a matching rocprofv3 --pmc summary was committed
-    traffic = None
+    # PMC-derived HBM traffic per launch: only if the committed rocprofv3 --pmc summary was measured on the library this
+    # process loaded (tools/pmc_traffic.py stamps the record with the sha256 of libgraph_mi355x.so)
+    traffic, traffic_note = None, None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path):
         try:
-            rec = json.load(open(pmc_path))
-            key = f"scale{scale}_gpus{world}"
-            traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+            import hashlib
+
+            rec = json.load(open(pmc_path)).get(f"scale{scale}_gpus{world}", {})
+            with open(graph_amd.LIB_PATH, "rb") as fh:
+                loaded = hashlib.sha256(fh.read()).hexdigest()
+            if rec.get("hbm_bytes_per_launch") is None:
+                traffic_note = "no PMC record for this configuration"
+            elif rec.get("library_sha256") == loaded:
+                traffic = rec["hbm_bytes_per_launch"]
+                traffic_note = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this library ({loaded[:16]}), {rec.get('measured', 'undated')}"
+            else:
+                traffic_note = (f"profiles/pmc_traffic.json was measured on library {str(rec.get('library_sha256'))[:16]}, this process "
+                                f"loaded {loaded[:16]}: not quoted")
+        except Exception as exc:
+            traffic, traffic_note = None, f"unreadable PMC record: {exc}"
 
     plan = engine.plan_info()  # propagation-blocking engines: what the resident plan cost and holds
     # The plan above was built first thing in this process (its time includes ~29 ms of one-time work of the HIP
@@ -393,14 +428,13 @@ def main():
                                                                "long_row_terms", "hub_seq_blocks")} if plan else None,
             "hot_sources": plan.get("hot_sources") if plan else None, "hot_tiers": plan.get("hot_tiers") if plan else None,
             "hot_edges": plan.get("hot_edges") if plan else None, "value_entries": plan.get("value_entries") if plan else None,
-            "value_stream_placement": {k: plan.get(k) for k in ("value_stream_from_arena", "draws_timed", "draw_best_us", "draw_worst_us",
-                                                                 "arena_grown_pieces")} if plan else None,
+            "value_stream_placement": _placement(plan, engine, scale) if plan else None,
             "parity": parity,
         },
         "roofline": {
             "kernel": "pr_tile_kernel" if engine.engine == "pull" else "pb_bin_kernel+pb_accum_kernel+pb_hubseq_kernel+pb_hublong_kernel",
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_note,
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(tile_ms_avg, 5),
             "edges_per_launch": m_local, "rows_per_launch": n_local,
         },
@@ -453,6 +487,33 @@ def main():
                 "source": "measured in this run: the timed engine run on to its fixed point against oracle "
                           "orc_page_rank_chunked (page_rank.rs:113-168) on the host cores, PageRankConfig::new(200, 1e-10, 0.85)",
             }
+    # ---- the reference app's other three algorithms, same run (N = 1, BASELINE's own scale only) -----------------------
+    if world == 1 and not emu and args.algos and args.scale == 26 and args.cpu_sweeps > 0:
+        engine = None
+        ex = None
+        del local_csr, scores, x
+        in_csr = None
+        import gc
+
+        gc.collect()
+        torch.cuda.empty_cache()
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_algos
+
+        try:
+            rec = bench_algos.measure(bench_algos.parse(["--oracle", "2", "--skip", "prapi", "--reps", "3"]))
+            result["extra"] = {
+                k: {"config": rec[k]["config"], "ms": round(rec[k]["ms"], 3), "roofline": rec[k]["roofline"],
+                    "bit_exact": rec[k]["parity"]["bit_exact_vs_oracle"] if rec[k]["parity"]["bit_exact_vs_oracle"] is not None
+                    else rec[k]["parity"].get("equals_the_count_pinned_by_that_test"), "parity": rec[k]["parity"],
+                    "cpu_baseline": rec[k].get("cpu_baseline"),
+                    **({"triangles": rec[k]["triangles"]} if k == "tc" else {}),
+                    **({"relaxed_edges": rec[k]["relaxed_edges"]} if k == "sssp" else {})}
+                for k in ("wcc", "sssp", "tc") if k in rec}
+            result["extra"]["protocol"] = ("tools/bench_algos.py in this process after the PageRank leg: best of 3 calls through the "
+                                           "prelude API (results downloaded), crates/app/src/app.rs:124-153")
+        except Exception as exc:  # the headline line must not depend on the extras
+            result["extra"] = {"error": repr(exc)}
     if emu:
         result["config"]["emulated"] = f"rank {rank} of {world} on one device, exchange replaced by a local copy"
     if rank == 0 or emu:
@@ -463,7 +524,7 @@ def main():
     # release every device object explicitly before interpreter shutdown (a HIP call from a
     # destructor during Python finalisation was seen to block forever under rocprofv3)
     ex = None
-    del engine, local_csr
+    engine = local_csr = None
     in_csr = None
     import gc
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turns the per-kernel FETCH_SIZE / WRITE_SIZE averages of two `rocprofv3 --pmc` passes into
-profiles/pmc_traffic.json (the `traffic` field of bench.py).  usage: pmc_traffic.py <pmc_summary.json> <key>"""
+profiles/pmc_traffic.json (the `traffic` field of bench.py).  usage: pmc_traffic.py <pmc_summary.json> <key> [algorithmic bytes] [note]"""
 import json
 import sys
 
@@ -41,6 +41,11 @@ for name, c in d.items():
         e["dispatches_per_sweep"] += per
         total += b
 entry["hbm_bytes_per_launch"] = total
+# the record belongs to ONE library: bench.py quotes it only when the library it loaded has this hash
+import hashlib, os, time
+lib_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "graph_amd", "libgraph_mi355x.so")
+entry["library_sha256"] = hashlib.sha256(open(lib_path, "rb").read()).hexdigest()
+entry["measured"] = time.strftime("%Y-%m-%d") + (f", {sys.argv[4]}" if len(sys.argv) > 4 else "")
 if alg:
     entry["algorithmic_bytes_per_launch"] = alg
     entry["traffic_over_algorithmic"] = round(total / alg, 3)
