@@ -11,21 +11,29 @@
 //!   delta_stepping<NI, G>(&G, DeltaSteppingConfig) -> Vec<AtomicF32>       crates/algos/src/sssp.rs:38-42
 //!   global_triangle_count<NI, G>(&G) -> u64                                crates/algos/src/triangle_count.rs:22-26
 //!
+//! The free functions have EXACTLY the reference's bounds: any graph type that compiles against `graph::prelude` — the
+//! CSR graphs, the adjacency-list graphs (crates/builder/src/graph/adj_list.rs), a caller's own type — compiles here.
+//!
 //! How the graph reaches the GPU.  The traits only promise iterators (`NeighborsIterator<'a>: Iterator<Item =
-//! &'a NI>`, crates/builder/src/lib.rs:336-412), so the generic path walks them once — O(n + m) on the host —
-//! into u32 (NI up to 32 bits) or u64 (`u64` / `usize`, narrowed with a range check by `gm_csr_upload_u64`)
-//! arrays and splits `Target<NI, f32>` (AoS, crates/builder/src/graph/mod.rs:5-10) into targets + weights.  The
-//! CSR graph types store their targets as ONE slice in node order, which their `std::slice::Iter` hands out
-//! (`out_neighbors(0).as_slice().as_ptr()`): for them only the n + 1 offsets are rebuilt from the degrees and the
-//! target array is uploaded from where it lies (`Residency::out_targets` ...).
+//! &'a NI>`, crates/builder/src/lib.rs:336-412), so every list is flattened through them, node by node, into one
+//! array: `Vec::extend(iter_of_refs)`.  For the CSR graph types that iterator is `std::slice::Iter`, for which the
+//! standard library's `extend` is a `memcpy` of the node's slice (monomorphisation picks it, no trait of ours is
+//! involved) — no per-element work, and no pointer is ever used outside the borrow it came from.  (Rounds 2-3 uploaded
+//! the CSR's target array "from where it lies" by stretching node 0's slice over the whole array: that relies on the
+//! crate-private layout of `Csr` and is undefined behaviour under strict provenance.  A one-line public accessor
+//! upstream — INTEGRATION.md — would make the zero-copy path sound; this crate does not pretend to have it.)
+//! `Target<NI, f32>` records (AoS, crates/builder/src/graph/mod.rs:5-10) are split into targets + weights.
+//! Ids of 4 bytes go through `gm_csr_upload_u32`, wider ones through `gm_csr_upload_u64` (narrowed with a range check).
 //!
 //! Who owns the device copy.  NOT a process-wide cache keyed by the graph's address (a graph dropped and rebuilt at
 //! the same address with the same counts would silently meet its predecessor's data, and nothing would ever be
-//! evicted).  A plain graph keeps no copy: every call uploads, computes and frees — always correct.  `OnDevice<G>`
-//! wraps a graph together with its copies ("offsets/targets uploaded once to HBM"): it hands out `&G` only, the
-//! copies are dropped the moment `get_mut()` is taken (the one door to in-place changes such as
-//! `make_degree_ordered`) and when the wrapper is dropped.  The algorithms take either: `page_rank(&graph, cfg)` or
-//! `page_rank(&on_device, cfg)`.
+//! evicted).  The free functions keep no copy: every call flattens, uploads, computes and frees — always correct,
+//! and O(n + m) of host work + PCIe per call (a loop over `page_rank(&graph, ..)` the way the reference's app runs it
+//! re-pays that and the plan build every time).  `OnDevice<G>` is the "offsets/targets uploaded once to HBM" of the
+//! design: it owns a graph together with its device copies and offers the same algorithms as methods
+//! (`on_device.page_rank(cfg)`, ...), with the same bounds on `G`; it hands out `&G` (Deref), the copies are dropped
+//! the moment `get_mut()` is taken (the one door to in-place changes such as `make_degree_ordered`) and when the
+//! wrapper is dropped.
 use std::collections::HashMap;
 use std::ffi::{c_char, c_int, CStr};
 use std::hash::Hash;
@@ -38,7 +46,7 @@ use graph_builder::prelude::*;
 pub mod prelude {
     pub use super::{
         delta_stepping, global_triangle_count, page_rank, relabel_graph, wcc_afforest, wcc_afforest_dss, wcc_baseline,
-        Components, DeltaSteppingConfig, OnDevice, PageRankConfig, Residency, WccConfig,
+        Components, DeltaSteppingConfig, OnDevice, PageRankConfig, WccConfig,
     };
     pub use graph_builder::prelude::*;
 }
@@ -89,43 +97,53 @@ impl Drop for DeviceCsr {
     }
 }
 
-/// One neighbour list walked into flat arrays; `wide` = ids do not fit u32 by type (u64 / usize / i64 ...).
-fn upload<NI: Idx>(node_count: usize, lists: impl Fn(NI, &mut dyn FnMut(NI, Option<f32>))) -> DeviceCsr {
-    let wide = std::mem::size_of::<NI>() > 4;
-    let mut weights: Vec<f32> = Vec::new();
-    let mut weighted = false;
+/// The lists of nodes 0 .. node_count flattened into (offsets, targets) and uploaded.  `extend_list(u, &mut targets)`
+/// appends node u's list: `targets.extend(graph.out_neighbors(u))` — a memcpy per node for slice iterators.
+fn upload_lists<NI: Idx>(node_count: usize, edge_hint: usize, mut extend_list: impl FnMut(NI, &mut Vec<NI>)) -> DeviceCsr {
+    let mut tgt: Vec<NI> = Vec::with_capacity(edge_hint);
+    let mut off: Vec<u64> = Vec::with_capacity(node_count + 1);
+    off.push(0);
+    for u in 0..node_count {
+        extend_list(NI::new(u), &mut tgt);
+        off.push(tgt.len() as u64);
+    }
+    upload_flat::<NI>(node_count, &off, &tgt, None)
+}
+
+/// ... with `Target<NI, f32>` records split into targets and weights
+fn upload_weighted_lists<NI: Idx>(node_count: usize, mut each: impl FnMut(NI, &mut dyn FnMut(NI, f32))) -> DeviceCsr {
+    let (mut tgt, mut weights): (Vec<NI>, Vec<f32>) = (Vec::new(), Vec::new());
+    let mut off: Vec<u64> = Vec::with_capacity(node_count + 1);
+    off.push(0);
+    for u in 0..node_count {
+        each(NI::new(u), &mut |v, w| {
+            tgt.push(v);
+            weights.push(w);
+        });
+        off.push(tgt.len() as u64);
+    }
+    upload_flat::<NI>(node_count, &off, &tgt, Some(&weights))
+}
+
+fn upload_flat<NI: Idx>(node_count: usize, off: &[u64], tgt: &[NI], weights: Option<&[f32]>) -> DeviceCsr {
     let mut out = std::ptr::null_mut();
-    if wide {
-        let (mut off, mut tgt) = (Vec::<u64>::with_capacity(node_count + 1), Vec::<u64>::new());
-        off.push(0);
-        for u in 0..node_count {
-            lists(NI::new(u), &mut |v, w| {
-                tgt.push(v.index() as u64);
-                if let Some(w) = w {
-                    weighted = true;
-                    weights.push(w);
-                }
-            });
-            off.push(tgt.len() as u64); // u64: no overflow; gm_csr_upload_u64 rejects n or m >= 2^32 (GM_ERR_RANGE)
-        }
-        let wp = if weighted { weights.as_ptr() } else { std::ptr::null() };
-        check(unsafe { gm_csr_upload_u64(off.as_ptr(), tgt.as_ptr(), wp, node_count as u64, tgt.len() as u64, 0, &mut out) });
-    } else {
-        let (mut off, mut tgt) = (Vec::<u32>::with_capacity(node_count + 1), Vec::<u32>::new());
-        off.push(0);
-        for u in 0..node_count {
-            lists(NI::new(u), &mut |v, w| {
-                tgt.push(v.index() as u32);
-                if let Some(w) = w {
-                    weighted = true;
-                    weights.push(w);
-                }
-            });
+    let wp = weights.map_or(std::ptr::null(), |w| w.as_ptr());
+    let (n, m) = (node_count as u64, tgt.len() as u64);
+    match std::mem::size_of::<NI>() {
+        // Idx is implemented for the primitive integers: a 4-byte NI has u32's layout, an 8-byte one u64's
+        4 => {
             assert!(tgt.len() < u32::MAX as usize, "more than 2^32 - 1 target entries: beyond the device id type");
-            off.push(tgt.len() as u32);
+            let off32: Vec<u32> = off.iter().map(|&o| o as u32).collect();
+            check(unsafe { gm_csr_upload_u32(off32.as_ptr(), tgt.as_ptr() as *const u32, wp, n, m, 0, &mut out) });
         }
-        let wp = if weighted { weights.as_ptr() } else { std::ptr::null() };
-        check(unsafe { gm_csr_upload_u32(off.as_ptr(), tgt.as_ptr(), wp, node_count as u64, tgt.len() as u64, 0, &mut out) });
+        8 => {
+            // gm_csr_upload_u64 rejects n or m >= 2^32 and ids beyond u32 (GM_ERR_RANGE)
+            check(unsafe { gm_csr_upload_u64(off.as_ptr(), tgt.as_ptr() as *const u64, wp, n, m, 0, &mut out) });
+        }
+        _ => {
+            let wide: Vec<u64> = tgt.iter().map(|v| v.index() as u64).collect();
+            check(unsafe { gm_csr_upload_u64(off.as_ptr(), wide.as_ptr(), wp, n, m, 0, &mut out) });
+        }
     }
     DeviceCsr(out)
 }
@@ -134,70 +152,24 @@ fn upload<NI: Idx>(node_count: usize, lists: impl Fn(NI, &mut dyn FnMut(NI, Opti
 // who keeps the device copies: nobody (plain graphs) or the OnDevice wrapper
 // ------------------------------------------------------------------------------------------------
 #[derive(Clone, Copy, PartialEq, Eq, Hash)]
-pub enum Kind {
+enum Kind {
     Directed,         // out + in lists
     DirectedWeighted, // out lists with f32 values
     OutOnly,          // wcc_baseline needs nothing else
     Undirected,
 }
 
-pub struct Resident {
+struct Resident {
     out: Option<DeviceCsr>,
     inc: Option<DeviceCsr>,
 }
 
 /// The device copies one graph keeps (at most one per `Kind`).
 #[derive(Default)]
-pub struct Copies(Mutex<HashMap<Kind, Arc<Resident>>>);
+struct Copies(Mutex<HashMap<Kind, Arc<Resident>>>);
 
-/// What the algorithms ask of a graph besides the reference's traits.  Implemented for the reference's CSR graph
-/// types (no copies kept, contiguous target arrays exposed) and for `OnDevice<G>` (copies kept).
-pub trait Residency<NI: Idx> {
-    /// Where this graph keeps its device copies; `None`: nowhere, every call uploads and frees its own.
-    fn copies(&self) -> Option<&Copies> {
-        None
-    }
-    /// The whole target array of the out / in / undirected lists, when the graph stores it as one slice in node
-    /// order (CSR): uploaded from where it lies instead of walked.
-    fn out_targets(&self) -> Option<&[NI]> {
-        None
-    }
-    fn in_targets(&self) -> Option<&[NI]> {
-        None
-    }
-    fn undirected_targets(&self) -> Option<&[NI]> {
-        None
-    }
-}
-
-/// `first` is node 0's list of a CSR whose lists lie back to back in one allocation of `len` entries.
-unsafe fn whole<NI>(first: &[NI], len: usize) -> &[NI] {
-    std::slice::from_raw_parts(first.as_ptr(), len)
-}
-
-impl<NI: Idx, NV> Residency<NI> for DirectedCsrGraph<NI, NV, ()> {
-    fn out_targets(&self) -> Option<&[NI]> {
-        (self.node_count().index() > 0)
-            .then(|| unsafe { whole(self.out_neighbors(NI::zero()).as_slice(), self.edge_count().index()) })
-    }
-    fn in_targets(&self) -> Option<&[NI]> {
-        (self.node_count().index() > 0)
-            .then(|| unsafe { whole(self.in_neighbors(NI::zero()).as_slice(), self.edge_count().index()) })
-    }
-}
-
-impl<NI: Idx, NV> Residency<NI> for DirectedCsrGraph<NI, NV, f32> {} // Target<NI, f32> records: walked and split
-
-impl<NI: Idx, NV> Residency<NI> for UndirectedCsrGraph<NI, NV, ()> {
-    fn undirected_targets(&self) -> Option<&[NI]> {
-        // Graph::edge_count() of an undirected CSR is half its target entries (csr.rs:687-689)
-        (self.node_count().index() > 0)
-            .then(|| unsafe { whole(self.neighbors(NI::zero()).as_slice(), 2 * self.edge_count().index()) })
-    }
-}
-
-/// A graph together with its copies in HBM.  `&OnDevice<G>` goes wherever `&G` goes (Deref + the reference's traits
-/// delegated below); the copies die with the wrapper or when `get_mut()` opens the graph for changes.
+/// A graph together with its copies in HBM: the algorithms as methods (below, next to their free functions), `&G` through
+/// Deref; the copies die with the wrapper or when `get_mut()` opens the graph for changes.
 pub struct OnDevice<G> {
     graph: G,
     copies: Copies,
@@ -224,128 +196,16 @@ impl<G> Deref for OnDevice<G> {
     }
 }
 
-impl<NI: Idx, G: Residency<NI>> Residency<NI> for OnDevice<G> {
-    fn copies(&self) -> Option<&Copies> {
-        Some(&self.copies)
-    }
-    fn out_targets(&self) -> Option<&[NI]> {
-        self.graph.out_targets()
-    }
-    fn in_targets(&self) -> Option<&[NI]> {
-        self.graph.in_targets()
-    }
-    fn undirected_targets(&self) -> Option<&[NI]> {
-        self.graph.undirected_targets()
-    }
-}
-
-impl<NI: Idx, G: Graph<NI>> Graph<NI> for OnDevice<G> {
-    fn node_count(&self) -> NI {
-        self.graph.node_count()
-    }
-    fn edge_count(&self) -> NI {
-        self.graph.edge_count()
-    }
-}
-
-impl<NI: Idx, G: DirectedDegrees<NI>> DirectedDegrees<NI> for OnDevice<G> {
-    fn out_degree(&self, node: NI) -> NI {
-        self.graph.out_degree(node)
-    }
-    fn in_degree(&self, node: NI) -> NI {
-        self.graph.in_degree(node)
-    }
-}
-
-impl<NI: Idx, G: UndirectedDegrees<NI>> UndirectedDegrees<NI> for OnDevice<G> {
-    fn degree(&self, node: NI) -> NI {
-        self.graph.degree(node)
-    }
-}
-
-impl<NI: Idx, G: DirectedNeighbors<NI>> DirectedNeighbors<NI> for OnDevice<G> {
-    type NeighborsIterator<'a>
-        = G::NeighborsIterator<'a>
-    where
-        Self: 'a;
-    fn out_neighbors(&self, node: NI) -> Self::NeighborsIterator<'_> {
-        self.graph.out_neighbors(node)
-    }
-    fn in_neighbors(&self, node: NI) -> Self::NeighborsIterator<'_> {
-        self.graph.in_neighbors(node)
-    }
-}
-
-impl<NI: Idx, G: DirectedNeighborsWithValues<NI, f32>> DirectedNeighborsWithValues<NI, f32> for OnDevice<G> {
-    type NeighborsIterator<'a>
-        = G::NeighborsIterator<'a>
-    where
-        Self: 'a;
-    fn out_neighbors_with_values(&self, node: NI) -> Self::NeighborsIterator<'_> {
-        self.graph.out_neighbors_with_values(node)
-    }
-    fn in_neighbors_with_values(&self, node: NI) -> Self::NeighborsIterator<'_> {
-        self.graph.in_neighbors_with_values(node)
-    }
-}
-
-impl<NI: Idx, G: UndirectedNeighbors<NI>> UndirectedNeighbors<NI> for OnDevice<G> {
-    type NeighborsIterator<'a>
-        = G::NeighborsIterator<'a>
-    where
-        Self: 'a;
-    fn neighbors(&self, node: NI) -> Self::NeighborsIterator<'_> {
-        self.graph.neighbors(node)
-    }
-}
-
-fn resident<NI: Idx, G: Residency<NI>>(graph: &G, kind: Kind, build: impl FnOnce() -> Resident) -> Arc<Resident> {
-    let Some(copies) = graph.copies() else {
-        return Arc::new(build()); // a plain graph: this call's own copy, freed when the call returns
+/// The copy of `kind`: from `copies` (an `OnDevice` graph: built once, kept), or this call's own, freed when it returns.
+fn resident(copies: Option<&Copies>, kind: Kind, build: impl FnOnce() -> Resident) -> Arc<Resident> {
+    let Some(copies) = copies else {
+        return Arc::new(build());
     };
     if let Some(r) = copies.0.lock().unwrap().get(&kind) {
         return r.clone();
     }
     let r = Arc::new(build()); // outside the lock: the four kinds of one graph may be uploaded side by side
     copies.0.lock().unwrap().entry(kind).or_insert(r).clone()
-}
-
-/// One CSR from its degrees and its target array where it lies (4- or 8-byte ids; `None` for other widths).
-fn upload_contiguous<NI: Idx>(node_count: usize, degree: impl Fn(NI) -> usize, targets: &[NI]) -> Option<DeviceCsr> {
-    let mut out = std::ptr::null_mut();
-    match std::mem::size_of::<NI>() {
-        4 => {
-            assert!(targets.len() < u32::MAX as usize, "more than 2^32 - 1 target entries: beyond the device id type");
-            let mut off = Vec::<u32>::with_capacity(node_count + 1);
-            let mut at = 0u32;
-            off.push(0);
-            for u in 0..node_count {
-                at += degree(NI::new(u)) as u32;
-                off.push(at);
-            }
-            assert_eq!(at as usize, targets.len(), "degrees do not add up to the target array");
-            check(unsafe {
-                gm_csr_upload_u32(off.as_ptr(), targets.as_ptr() as *const u32, std::ptr::null(), node_count as u64,
-                                  targets.len() as u64, 0, &mut out)
-            });
-        }
-        8 => {
-            let mut off = Vec::<u64>::with_capacity(node_count + 1);
-            let mut at = 0u64;
-            off.push(0);
-            for u in 0..node_count {
-                at += degree(NI::new(u)) as u64;
-                off.push(at);
-            }
-            assert_eq!(at as usize, targets.len(), "degrees do not add up to the target array");
-            check(unsafe {
-                gm_csr_upload_u64(off.as_ptr(), targets.as_ptr() as *const u64, std::ptr::null(), node_count as u64,
-                                  targets.len() as u64, 0, &mut out)
-            });
-        }
-        _ => return None,
-    }
-    Some(DeviceCsr(out))
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -374,37 +234,35 @@ impl Default for PageRankConfig {
     }
 }
 
-fn directed<NI, G>(graph: &G) -> Arc<Resident>
+fn directed<NI, G>(graph: &G, copies: Option<&Copies>) -> Arc<Resident>
 where
     NI: Idx,
-    G: Graph<NI> + DirectedDegrees<NI> + DirectedNeighbors<NI> + Residency<NI> + Sync,
+    G: Graph<NI> + DirectedDegrees<NI> + DirectedNeighbors<NI> + Sync,
 {
-    let n = graph.node_count().index();
-    resident(graph, Kind::Directed, || Resident {
-        out: Some(
-            graph
-                .out_targets()
-                .and_then(|t| upload_contiguous::<NI>(n, |u| graph.out_degree(u).index(), t))
-                .unwrap_or_else(|| upload::<NI>(n, |u, push| graph.out_neighbors(u).for_each(|v| push(*v, None)))),
-        ),
-        inc: Some(
-            graph
-                .in_targets()
-                .and_then(|t| upload_contiguous::<NI>(n, |u| graph.in_degree(u).index(), t))
-                .unwrap_or_else(|| upload::<NI>(n, |u, push| graph.in_neighbors(u).for_each(|v| push(*v, None)))),
-        ),
+    let (n, m) = (graph.node_count().index(), graph.edge_count().index());
+    resident(copies, Kind::Directed, || Resident {
+        out: Some(upload_lists::<NI>(n, m, |u, tgt| tgt.extend(graph.out_neighbors(u)))),
+        inc: Some(upload_lists::<NI>(n, m, |u, tgt| tgt.extend(graph.in_neighbors(u)))),
     })
 }
 
-/// The reference's signature plus `Residency` (its CSR graph types and `OnDevice<_>` have it).  `GM_DEVICES=k` (k > 1) runs the call 1-D partitioned over the first k
-/// GPUs of the node (`gm_page_rank_multi`: RCCL all-gather of out_scores per sweep); default: one GPU.
+/// crates/algos/src/page_rank.rs:58-62, the same bounds.  `GM_DEVICES=k` (k > 1) runs the call 1-D partitioned over the
+/// first k GPUs of the node (`gm_page_rank_multi`: RCCL all-gather of out_scores per sweep); default: one GPU.
 pub fn page_rank<NI, G>(graph: &G, config: PageRankConfig) -> (Vec<f32>, usize, f64)
 where
     NI: Idx,
-    G: Graph<NI> + DirectedDegrees<NI> + DirectedNeighbors<NI> + Residency<NI> + Sync,
+    G: Graph<NI> + DirectedDegrees<NI> + DirectedNeighbors<NI> + Sync,
+{
+    page_rank_on(graph, None, config)
+}
+
+fn page_rank_on<NI, G>(graph: &G, copies: Option<&Copies>, config: PageRankConfig) -> (Vec<f32>, usize, f64)
+where
+    NI: Idx,
+    G: Graph<NI> + DirectedDegrees<NI> + DirectedNeighbors<NI> + Sync,
 {
     let PageRankConfig { max_iterations, tolerance, damping_factor } = config;
-    let g = directed(graph);
+    let g = directed(graph, copies);
     let mut scores = vec![0f32; graph.node_count().index()];
     let (mut iterations, mut error) = (0u64, 0f64);
     let (out, inc) = (g.out.as_ref().unwrap().0, g.inc.as_ref().unwrap().0);
@@ -471,9 +329,17 @@ impl<NI: Idx> Components<NI> for DeviceComponents {
 pub fn wcc_afforest<NI, G>(graph: &G, config: WccConfig) -> impl Components<NI>
 where
     NI: Idx + Hash,
-    G: Graph<NI> + DirectedDegrees<NI> + DirectedNeighbors<NI> + Residency<NI> + Sync,
+    G: Graph<NI> + DirectedDegrees<NI> + DirectedNeighbors<NI> + Sync,
 {
-    let g = directed(graph);
+    wcc_afforest_on(graph, None, config)
+}
+
+fn wcc_afforest_on<NI, G>(graph: &G, copies: Option<&Copies>, config: WccConfig) -> DeviceComponents
+where
+    NI: Idx,
+    G: Graph<NI> + DirectedDegrees<NI> + DirectedNeighbors<NI> + Sync,
+{
+    let g = directed(graph, copies);
     let mut comp = vec![0u32; graph.node_count().index()];
     check(unsafe {
         gm_wcc_afforest(g.out.as_ref().unwrap().0, g.inc.as_ref().unwrap().0, config.neighbor_rounds as u64,
@@ -486,20 +352,27 @@ where
 pub fn wcc_afforest_dss<NI, G>(graph: &G, config: WccConfig) -> impl Components<NI>
 where
     NI: Idx + Hash,
-    G: Graph<NI> + DirectedDegrees<NI> + DirectedNeighbors<NI> + Residency<NI> + Sync,
+    G: Graph<NI> + DirectedDegrees<NI> + DirectedNeighbors<NI> + Sync,
 {
-    wcc_afforest(graph, config)
+    wcc_afforest_on(graph, None, config)
 }
 
-pub fn wcc_baseline<NI, G>(graph: &G, _config: WccConfig) -> impl Components<NI>
+pub fn wcc_baseline<NI, G>(graph: &G, config: WccConfig) -> impl Components<NI>
 where
     NI: Idx,
-    G: Graph<NI> + DirectedNeighbors<NI> + Residency<NI> + Sync,
+    G: Graph<NI> + DirectedNeighbors<NI> + Sync,
 {
-    let n = graph.node_count().index();
-    let g = resident(graph, Kind::OutOnly, || Resident {
-        // no degrees in this function's bounds: the lists are walked (wcc_afforest's copy has the fast path)
-        out: Some(upload::<NI>(n, |u, push| graph.out_neighbors(u).for_each(|v| push(*v, None)))),
+    wcc_baseline_on(graph, None, config)
+}
+
+fn wcc_baseline_on<NI, G>(graph: &G, copies: Option<&Copies>, _config: WccConfig) -> DeviceComponents
+where
+    NI: Idx,
+    G: Graph<NI> + DirectedNeighbors<NI> + Sync,
+{
+    let (n, m) = (graph.node_count().index(), graph.edge_count().index());
+    let g = resident(copies, Kind::OutOnly, || Resident {
+        out: Some(upload_lists::<NI>(n, m, |u, tgt| tgt.extend(graph.out_neighbors(u)))),
         inc: None,
     });
     let mut comp = vec![0u32; n];
@@ -526,13 +399,21 @@ impl DeltaSteppingConfig {
 pub fn delta_stepping<NI, G>(graph: &G, config: DeltaSteppingConfig) -> Vec<AtomicF32>
 where
     NI: Idx,
-    G: Graph<NI> + DirectedNeighborsWithValues<NI, f32> + Residency<NI> + Sync,
+    G: Graph<NI> + DirectedNeighborsWithValues<NI, f32> + Sync,
+{
+    delta_stepping_on(graph, None, config)
+}
+
+fn delta_stepping_on<NI, G>(graph: &G, copies: Option<&Copies>, config: DeltaSteppingConfig) -> Vec<AtomicF32>
+where
+    NI: Idx,
+    G: Graph<NI> + DirectedNeighborsWithValues<NI, f32> + Sync,
 {
     let n = graph.node_count().index();
-    let g = resident(graph, Kind::DirectedWeighted, || Resident {
+    let g = resident(copies, Kind::DirectedWeighted, || Resident {
         // Target<NI, f32> is an 8-byte AoS record on the host; the device streams targets and weights apart
-        out: Some(upload::<NI>(n, |u, push| {
-            graph.out_neighbors_with_values(u).for_each(|t| push(t.target, Some(t.value)))
+        out: Some(upload_weighted_lists::<NI>(n, |u, push| {
+            graph.out_neighbors_with_values(u).for_each(|t| push(t.target, t.value))
         })),
         inc: None,
     });
@@ -551,16 +432,20 @@ where
 pub fn global_triangle_count<NI, G>(graph: &G) -> u64
 where
     NI: Idx,
-    G: Graph<NI> + UndirectedNeighbors<NI> + Residency<NI> + Sync,
+    G: Graph<NI> + UndirectedNeighbors<NI> + Sync,
 {
-    let n = graph.node_count().index();
-    let g = resident(graph, Kind::Undirected, || Resident {
-        out: Some(
-            graph
-                .undirected_targets()
-                .and_then(|t| upload_contiguous::<NI>(n, |u| graph.neighbors(u).count(), t)) // O(1) on slice iterators
-                .unwrap_or_else(|| upload::<NI>(n, |u, push| graph.neighbors(u).for_each(|v| push(*v, None)))),
-        ),
+    global_triangle_count_on(graph, None)
+}
+
+fn global_triangle_count_on<NI, G>(graph: &G, copies: Option<&Copies>) -> u64
+where
+    NI: Idx,
+    G: Graph<NI> + UndirectedNeighbors<NI> + Sync,
+{
+    // Graph::edge_count() of an undirected CSR is half its target entries (csr.rs:687-689)
+    let (n, m) = (graph.node_count().index(), 2 * graph.edge_count().index());
+    let g = resident(copies, Kind::Undirected, || Resident {
+        out: Some(upload_lists::<NI>(n, m, |u, tgt| tgt.extend(graph.neighbors(u)))),
         inc: None,
     });
     let mut triangles = 0u64;
@@ -578,7 +463,58 @@ where
     graph.make_degree_ordered();
 }
 
+// ------------------------------------------------------------------------------------------------
+// the same algorithms on a graph that keeps its device copies: same bounds on G, same results
+// ------------------------------------------------------------------------------------------------
 impl<G> OnDevice<G> {
+    pub fn page_rank<NI>(&self, config: PageRankConfig) -> (Vec<f32>, usize, f64)
+    where
+        NI: Idx,
+        G: Graph<NI> + DirectedDegrees<NI> + DirectedNeighbors<NI> + Sync,
+    {
+        page_rank_on(&self.graph, Some(&self.copies), config)
+    }
+
+    pub fn wcc_afforest<NI>(&self, config: WccConfig) -> impl Components<NI>
+    where
+        NI: Idx + Hash,
+        G: Graph<NI> + DirectedDegrees<NI> + DirectedNeighbors<NI> + Sync,
+    {
+        wcc_afforest_on(&self.graph, Some(&self.copies), config)
+    }
+
+    pub fn wcc_afforest_dss<NI>(&self, config: WccConfig) -> impl Components<NI>
+    where
+        NI: Idx + Hash,
+        G: Graph<NI> + DirectedDegrees<NI> + DirectedNeighbors<NI> + Sync,
+    {
+        wcc_afforest_on(&self.graph, Some(&self.copies), config)
+    }
+
+    pub fn wcc_baseline<NI>(&self, config: WccConfig) -> impl Components<NI>
+    where
+        NI: Idx,
+        G: Graph<NI> + DirectedNeighbors<NI> + Sync,
+    {
+        wcc_baseline_on(&self.graph, Some(&self.copies), config)
+    }
+
+    pub fn delta_stepping<NI>(&self, config: DeltaSteppingConfig) -> Vec<AtomicF32>
+    where
+        NI: Idx,
+        G: Graph<NI> + DirectedNeighborsWithValues<NI, f32> + Sync,
+    {
+        delta_stepping_on(&self.graph, Some(&self.copies), config)
+    }
+
+    pub fn global_triangle_count<NI>(&self) -> u64
+    where
+        NI: Idx,
+        G: Graph<NI> + UndirectedNeighbors<NI> + Sync,
+    {
+        global_triangle_count_on(&self.graph, Some(&self.copies))
+    }
+
     /// `relabel_graph` for a graph with device copies: they are dropped first (`get_mut`), the next algorithm call
     /// uploads the relabelled lists.
     pub fn relabel<NI: Idx, EV>(&mut self)

@@ -79,11 +79,60 @@ fn on_device_keeps_one_copy_and_plain_graphs_keep_none() {
     let graph: DirectedCsrGraph<u32> = GraphBuilder::new().csr_layout(CsrLayout::Sorted).edges(vec![(0, 1), (1, 2), (2, 0)]).build();
     let a = page_rank(&graph, PageRankConfig::default()); // a plain graph: uploaded for this call, freed after it
     let resident = OnDevice::new(graph);
-    let b = page_rank(&resident, PageRankConfig::default()); // uploads once ...
-    let c = page_rank(&resident, PageRankConfig::default()); // ... and runs on the same copy
+    let b = resident.page_rank(PageRankConfig::default()); // uploads once ...
+    let c = resident.page_rank(PageRankConfig::default()); // ... and runs on the same copy
     assert_eq!(a.0, b.0);
     assert_eq!(b.0, c.0);
-    assert_eq!(wcc_afforest(&resident, WccConfig::default()).to_vec(), vec![0u32, 0, 0]); // the same Directed copy
+    assert_eq!(resident.wcc_afforest(WccConfig::default()).to_vec(), vec![0u32, 0, 0]); // the same Directed copy
+    // &OnDevice<G> derefs to &G: the free functions take it like any graph (and upload for the call)
+    assert_eq!(page_rank(&*resident, PageRankConfig::default()).0, a.0);
+}
+
+/// A graph type of the caller's own that implements only the reference's traits (here: adjacency lists in plain Vecs):
+/// the free functions have the reference's bounds, so it compiles and runs without any trait of this crate.
+struct VecGraph {
+    out: Vec<Vec<u32>>,
+    inc: Vec<Vec<u32>>,
+}
+
+impl Graph<u32> for VecGraph {
+    fn node_count(&self) -> u32 {
+        self.out.len() as u32
+    }
+    fn edge_count(&self) -> u32 {
+        self.out.iter().map(|l| l.len() as u32).sum()
+    }
+}
+
+impl DirectedDegrees<u32> for VecGraph {
+    fn out_degree(&self, node: u32) -> u32 {
+        self.out[node as usize].len() as u32
+    }
+    fn in_degree(&self, node: u32) -> u32 {
+        self.inc[node as usize].len() as u32
+    }
+}
+
+impl DirectedNeighbors<u32> for VecGraph {
+    type NeighborsIterator<'a> = std::slice::Iter<'a, u32>;
+    fn out_neighbors(&self, node: u32) -> Self::NeighborsIterator<'_> {
+        self.out[node as usize].iter()
+    }
+    fn in_neighbors(&self, node: u32) -> Self::NeighborsIterator<'_> {
+        self.inc[node as usize].iter()
+    }
+}
+
+#[test]
+fn a_graph_type_that_only_knows_the_reference_traits_is_accepted() {
+    let g = VecGraph { out: vec![vec![1], vec![2], vec![0], vec![]], inc: vec![vec![2], vec![0], vec![1], vec![]] };
+    let csr: DirectedCsrGraph<u32> = GraphBuilder::new().csr_layout(CsrLayout::Sorted).edges(vec![(0, 1), (1, 2), (2, 0), (3, 3)]).build();
+    let _ = csr; // (3, 3) only makes node 3 exist in the CSR build; VecGraph's node 3 is isolated
+    let (scores, iterations, _) = page_rank(&g, PageRankConfig::default());
+    assert_eq!(scores.len(), 4);
+    assert!(iterations >= 1);
+    assert_eq!(wcc_afforest(&g, WccConfig::default()).to_vec(), vec![0u32, 0, 0, 3]);
+    assert_eq!(wcc_baseline(&g, WccConfig::default()).to_vec(), vec![0u32, 0, 0, 3]);
 }
 
 #[test]
@@ -103,8 +152,8 @@ fn relabel_through_on_device_drops_the_stale_copy() {
     let graph: UndirectedCsrGraph<u32> =
         GraphBuilder::new().csr_layout(CsrLayout::Deduplicated).edges(vec![(0, 1), (1, 2), (0, 2), (2, 3)]).build();
     let mut resident = OnDevice::new(graph);
-    assert_eq!(global_triangle_count(&resident), 1);
+    assert_eq!(resident.global_triangle_count(), 1);
     resident.relabel(); // make_degree_ordered through get_mut(): the device copy of the old ids is gone
-    assert_eq!(global_triangle_count(&resident), 1);
+    assert_eq!(resident.global_triangle_count(), 1);
     assert_eq!(resident.degree(0), 3); // the old node 2 is node 0 now
 }

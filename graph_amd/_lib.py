@@ -32,6 +32,7 @@ SIGNATURES = {
     "gm_csr_trim": (i32, [vp]),
     "gm_trim": (i32, [i32]),
     "gm_arena_info": (i32, [i32, vp]),
+    "gm_arena_va_info": (i32, [i32, vp]),
     "gm_csr_node_count": (u64, [vp]),
     "gm_csr_edge_count": (u64, [vp]),
     "gm_csr_device": (i32, [vp]),

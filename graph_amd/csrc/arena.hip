@@ -9,7 +9,10 @@
 //  * hipMalloc after large hipFree calls stalls for seconds (the driver hands freed VRAM back only after clearing it):
 //    memory that never goes back to the driver is never waited for.
 // So large buffers are mapped (HIP virtual-memory API) from 64 MiB physical pieces that the arena creates on demand
-// and keeps when a buffer is released (up to GM_ARENA_KEEP_GIB, default 32; gm_trim() releases them).  A buffer asks
+// and keeps when a buffer is released (up to GM_ARENA_KEEP_GIB, default 32, and never more than a quarter of what the
+// device has free or idle; gm_trim() releases them).  Sizes come in CLASSES (arena_class_pieces: three mantissa bits, at
+// most 12.5 % above the request), so that the address ranges and piece sets of released buffers fit the next request of
+// about the same size: a long-lived process with graphs of many sizes reuses a bounded set of ranges.  A buffer asks
 // either for any pieces or for a SPREAD subset: one pseudo-random piece out of every stratum of the free list in
 // creation order — consecutive creations are mostly neighbours in physical memory, so the subset samples the whole
 // stretch the arena has seen.
@@ -33,6 +36,7 @@ struct VaRange {
 
 struct Arena {
     std::mutex mu;
+    uint64_t va_reserved = 0;                  // bytes of address space reserved so far (never returned: see above)
     std::vector<VaRange> va;                   // reservations, the last one is the one being carved up
     std::multimap<size_t, char *> va_free;     // returned stretches by size (buffers of a few recurring sizes come and go)
     std::vector<ArenaPiece> free_list; // ascending serial = creation order
@@ -117,6 +121,7 @@ int arena_va_alloc(int dev, size_t span, void **out)
         if (!a.va.empty() && a.va.back().size > a.va.back().bump) // what is left of the old reservation stays usable
             a.va_free.emplace(a.va.back().size - a.va.back().bump, a.va.back().base + a.va.back().bump);
         a.va.push_back(VaRange{static_cast<char *>(base), want, 0});
+        a.va_reserved += want;
     }
     VaRange &r = a.va.back();
     *out = r.base + r.bump;
@@ -152,11 +157,35 @@ bool arena_enabled()
     return on;
 }
 
-size_t arena_keep_bytes()
+// idle pieces the arena may hold on to: GM_ARENA_KEEP_GIB (default 32), but at most a quarter of the memory that is free or
+// idle in the arena right now — on a device other tenants have filled (torch's caching allocator, other graphs) the reserve
+// shrinks with what is left.  `idle_bytes`: the arena's own idle pieces (they do not show up as free memory).
+size_t arena_keep_bytes(size_t idle_bytes)
 {
     const char *v = getenv("GM_ARENA_KEEP_GIB");
     const long gib = v && *v ? atol(v) : 32;
-    return (size_t)(gib < 0 ? 0 : gib) << 30;
+    size_t keep = (size_t)(gib < 0 ? 0 : gib) << 30;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const size_t quarter = (free_b + idle_bytes) / 4;
+        keep = keep < quarter ? keep : quarter;
+    } else {
+        (void)hipGetLastError();
+    }
+    return keep;
+}
+
+// pieces of the size class of a request of `count` pieces: up to 16 exact, beyond that three mantissa bits (the next multiple
+// of 2^(floor(log2 count) - 3): at most 12.5 % more)
+size_t arena_class_pieces(size_t count)
+{
+    if (count <= 16)
+        return count;
+    int top = 0;
+    while ((count >> (top + 1)) != 0)
+        ++top;
+    const size_t step = (size_t)1 << (top - 3);
+    return (count + step - 1) / step * step;
 }
 
 int arena_take(int dev, size_t count, uint64_t spread_seed, size_t spread_factor, std::vector<ArenaPiece> &out,
@@ -166,11 +195,33 @@ int arena_take(int dev, size_t count, uint64_t spread_seed, size_t spread_factor
     std::lock_guard<std::mutex> lock(a.mu);
     out.clear();
     const bool ranged = serial_lo != 0 || serial_hi != ~0ull;
-    const size_t want_free = spread_seed ? count * (spread_factor ? spread_factor : 1) : count;
+    size_t want_free = spread_seed ? count * (spread_factor ? spread_factor : 1) : count;
     if (!ranged && a.free_list.size() < want_free) {
-        const int rc = create_pieces(a, dev, want_free - a.free_list.size());
-        if (rc != GM_OK && a.free_list.size() < count)
-            return rc; // a smaller pool than asked for still serves the request
+        // The pool beyond the request itself (a spread draw wants `spread_factor` times the pieces to choose from) is a
+        // matter of speed: it never takes more than half of what the device has free, and if the device runs out on the
+        // way the surplus goes back at once — the arena must not be what makes a later hipMalloc fail.
+        size_t free_b = 0, total_b = 0;
+        if (want_free > count && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t have = a.free_list.size(), need = count > have ? count - have : 0;
+            const size_t extra_cap = free_b / 2 / ARENA_PIECE > need ? free_b / 2 / ARENA_PIECE - need : 0;
+            const size_t capped = (have > count ? have : count) + extra_cap;
+            want_free = want_free < capped ? want_free : capped;
+        }
+        const int rc = a.free_list.size() < want_free ? create_pieces(a, dev, want_free - a.free_list.size()) : GM_OK;
+        if (rc != GM_OK) {
+            (void)hipGetLastError();
+            if (a.free_list.size() < count)
+                return rc;
+            // a smaller pool than asked for still serves the request; what was created beyond it is handed back so that
+            // at least 1/16 of the device stays free
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+                while (a.free_list.size() > count && free_b < total_b / 16) {
+                    (void)hipMemRelease(a.free_list.back().handle);
+                    a.free_list.pop_back();
+                    --a.alive;
+                    free_b += ARENA_PIECE;
+                }
+        }
     }
     if (a.free_list.size() < count) {
         set_error("arena: %zu free pieces, %zu wanted", a.free_list.size(), count);
@@ -230,8 +281,9 @@ void arena_give(int dev, std::vector<ArenaPiece> &pieces)
     std::lock_guard<std::mutex> lock(a.mu);
     a.free_list.insert(a.free_list.end(), pieces.begin(), pieces.end());
     pieces.clear();
-    if (a.free_list.size() * ARENA_PIECE > arena_keep_bytes() + (arena_keep_bytes() >> 2)) // hysteresis: trim in batches
-        trim_locked(a, arena_keep_bytes());
+    const size_t idle = a.free_list.size() * ARENA_PIECE, keep = arena_keep_bytes(idle);
+    if (idle > keep + (keep >> 2)) // hysteresis: trim in batches
+        trim_locked(a, keep);
 }
 
 void arena_trim(int dev, size_t keep_bytes)
@@ -259,6 +311,21 @@ void arena_stats(int dev, uint64_t *out4)
     out4[1] = a.free_list.size() * ARENA_PIECE;
     out4[2] = a.created;
     out4[3] = a.reused;
+}
+
+void arena_va_stats(int dev, uint64_t *out3)
+{
+    Arena &a = arena_of(dev);
+    std::lock_guard<std::mutex> lock(a.mu);
+    uint64_t idle = 0;
+    for (const auto &kv : a.va_free)
+        idle += kv.first;
+    uint64_t unused = 0; // never handed out: the rest of the reservation being carved up
+    if (!a.va.empty())
+        unused = a.va.back().size - a.va.back().bump;
+    out3[0] = a.va_reserved;
+    out3[1] = idle;
+    out3[2] = unused;
 }
 
 void arena_free_range(int dev, uint64_t *lo, uint64_t *hi, size_t *count)
@@ -297,5 +364,17 @@ GM_API int gm_arena_info(int device, uint64_t *bytes_out)
     if (dev < 0)
         GM_HIP(hipGetDevice(&dev));
     gm::arena_stats(dev, bytes_out);
+    return GM_OK;
+}
+
+// bytes_out[3]: bytes of virtual address space the arena has reserved (never returned to the runtime), bytes of it in
+// released ranges waiting for a request of their size class, bytes never handed out yet
+GM_API int gm_arena_va_info(int device, uint64_t *bytes_out)
+{
+    GM_CHECK(bytes_out, GM_ERR_INVALID, "gm_arena_va_info: null argument");
+    int dev = device;
+    if (dev < 0)
+        GM_HIP(hipGetDevice(&dev));
+    gm::arena_va_stats(dev, bytes_out);
     return GM_OK;
 }

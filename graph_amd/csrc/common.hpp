@@ -103,6 +103,8 @@ void arena_va_free(int dev, void *ptr, size_t span);
 void arena_give(int dev, std::vector<ArenaPiece> &pieces);
 void arena_trim(int dev, size_t keep_bytes);
 void arena_stats(int dev, uint64_t *out4);
+void arena_va_stats(int dev, uint64_t *out3);
+size_t arena_class_pieces(size_t count); // size classes of the arena's buffers: see arena.hip
 // serials of the oldest and (one past) the newest piece of the free list, and how many are free
 void arena_free_range(int dev, uint64_t *lo, uint64_t *hi, size_t *count);
 
@@ -172,7 +174,19 @@ struct DevBuf {
         release();
         if (nbytes == 0)
             nbytes = 16; // keep pointers non-null for empty graphs
-        GM_HIP(hipMalloc(&p, nbytes));
+        hipError_t me = hipMalloc(&p, nbytes);
+        if (me == hipErrorOutOfMemory && arena_enabled()) {
+            // the arena's idle pieces are the library's own reserve: hand them back and try once more before reporting
+            // a device that "has no memory"
+            (void)hipGetLastError();
+            int dev_now = 0;
+            if (hipGetDevice(&dev_now) == hipSuccess) {
+                (void)hipDeviceSynchronize();
+                arena_trim(dev_now, 0);
+                me = hipMalloc(&p, nbytes);
+            }
+        }
+        GM_HIP(me);
         bytes = nbytes;
         // GM_POISON="<min bytes>,<max bytes>" (debugging): allocations in that size range start out as 0xFF bytes (f32 NaN)
         // instead of whatever the driver hands out (usually zeros) — finds code that reads what it never wrote
@@ -222,7 +236,8 @@ struct DevBuf {
         release();
         int dev = 0;
         GM_HIP(hipGetDevice(&dev));
-        const size_t count = (nbytes + ARENA_PIECE - 1) / ARENA_PIECE, span = count * ARENA_PIECE;
+        // whole size classes: the released range and piece set fit the next buffer of about this size (arena.hip)
+        const size_t count = arena_class_pieces((nbytes + ARENA_PIECE - 1) / ARENA_PIECE), span = count * ARENA_PIECE;
         if (split_serial && spread_seed) {
             std::vector<ArenaPiece> older, newer;
             GM_TRY(arena_take(dev, count / 2, spread_seed, 1, older, serial_lo, older_hi ? older_hi : split_serial));

@@ -73,6 +73,13 @@ def arena_info(device: int = -1):
     return {"held_bytes": int(out[0]), "idle_bytes": int(out[1]), "pieces_created": int(out[2]), "pieces_handed_out": int(out[3])}
 
 
+def arena_va_info(device: int = -1):
+    """gm_arena_va_info: the arena's virtual address space — bytes reserved, bytes in released ranges, bytes never handed out"""
+    out = (C.c_uint64 * 3)()
+    check(lib().gm_arena_va_info(int(device), out))
+    return {"reserved_bytes": int(out[0]), "released_bytes": int(out[1]), "unused_bytes": int(out[2])}
+
+
 class DeviceCsr:
     """One device-resident CSR (offsets/targets[/weights] in HBM); lazily mirrored to the host for
     the per-node accessors of the reference's graph traits."""

@@ -88,6 +88,11 @@ int gm_trim(int device);
 /* info_out[4]: bytes of device memory the arena holds, bytes of it not in use, 64 MiB pieces created so far,
  * pieces handed out so far. */
 int gm_arena_info(int device, uint64_t *info_out);
+/* info_out[3]: bytes of virtual address space the arena has reserved on `device` (never returned to the runtime: ROCm 7.0
+ * corrupts later allocations after hipMemAddressFree of a range that carried mappings), bytes of it in released ranges
+ * waiting for a request of their size class, bytes never handed out.  Buffer sizes come in classes (at most 12.5 % above
+ * the request), so a process that builds graphs of many sizes reuses a bounded set of ranges. */
+int gm_arena_va_info(int device, uint64_t *info_out);
 uint64_t gm_csr_node_count(const gm_csr *csr);
 uint64_t gm_csr_edge_count(const gm_csr *csr); /* number of target entries (csr.rs:76-78) */
 int gm_csr_device(const gm_csr *csr);

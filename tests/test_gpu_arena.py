@@ -88,3 +88,49 @@ def test_other_algorithms_work_across_a_trim(P):
     P.trim_device()
     assert np.array_equal(P.delta_stepping(g, P.DeltaSteppingConfig(start, 0.1)), d1)
     assert np.array_equal(P.wcc_afforest(g, P.WccConfig()).to_vec(), c1)
+
+
+def test_a_hundred_graphs_of_varied_sizes_keep_the_arena_bounded(P):
+    """A long-lived process that builds, uses and drops graphs of many different sizes: buffer sizes come in classes (at most
+    12.5 % above the request), so the address ranges and pieces released by one graph serve the next — the device memory the
+    arena holds and the address space it has handed out must stop growing after the first few graphs instead of following
+    the number of graphs (address space is never returned to the runtime: arena.hip)."""
+    from graph_amd import synth
+
+    rng = np.random.default_rng(7)
+    P.trim_device(0)
+    base_va = P.arena_va_info()
+    used_va, held, ref = [], [], {}
+    for k in range(100):
+        scale = 20 if k % 10 else 22  # every tenth graph is four times larger
+        n = 1 << scale
+        m = int(rng.integers(10, 17) * n + rng.integers(0, n))  # a different edge count every time: 10-17 edges per node
+        src, dst = synth.rmat_edges(scale, 100 + k)
+        src, dst = src[:m].contiguous(), dst[:m].contiguous()
+        g = P.DirectedCsrGraph(synth.build_csr(n, src, dst, P.Direction.Outgoing, P.CsrLayout.Sorted),
+                               synth.build_csr(n, src, dst, P.Direction.Incoming, P.CsrLayout.Sorted), P.CsrLayout.Sorted)
+        del src, dst
+        got, it, _ = P.page_rank(g, P.PageRankConfig(3, 0.0, 0.85), P.PageRankMode.JacobiPB)
+        assert it == 3 and np.isfinite(got).all()
+        if k in (0, 50):  # the same graph again much later: the same bits from recycled ranges and pieces
+            ref[k] = (got.copy(), m)
+        del g
+        va = P.arena_va_info()
+        used_va.append(va["reserved_bytes"] - va["unused_bytes"] - (base_va["reserved_bytes"] - base_va["unused_bytes"]))
+        held.append(P.arena_info()["held_bytes"])
+    # after the first twenty graphs (every size class seen) the next eighty add little: not 4x more
+    print(f"address space handed out after 20 / 100 graphs: {used_va[19] / 2**30:.1f} / {used_va[99] / 2**30:.1f} GiB; "
+          f"device memory held: {held[19] / 2**30:.1f} / {held[99] / 2**30:.1f} GiB")
+    assert used_va[99] <= 1.5 * used_va[19] + (8 << 30)
+    assert max(held[20:]) <= 1.5 * max(held[:20]) + (4 << 30)
+    for k, (want, m) in ref.items():
+        scale, n = (22 if k % 10 == 0 else 20), None
+        n = 1 << scale
+        src, dst = synth.rmat_edges(scale, 100 + k)
+        src, dst = src[:m].contiguous(), dst[:m].contiguous()
+        g = P.DirectedCsrGraph(synth.build_csr(n, src, dst, P.Direction.Outgoing, P.CsrLayout.Sorted),
+                               synth.build_csr(n, src, dst, P.Direction.Incoming, P.CsrLayout.Sorted), P.CsrLayout.Sorted)
+        again, _, _ = P.page_rank(g, P.PageRankConfig(3, 0.0, 0.85), P.PageRankMode.JacobiPB)
+        assert np.array_equal(again, want)
+        del g
+    P.trim_device(0)
