@@ -59,6 +59,7 @@ SIGNATURES = {
     "gm_pr_sweep_fixup": (i32, [vp, u64, u64, u64, vp]),
     "gm_pr_algorithmic_bytes": (u64, [vp]),
     "gm_page_rank_multi": (i32, [vp, vp, vp, u32, u64, f64, f32, vp, C.POINTER(u64), C.POINTER(f64)]),
+    "gm_page_rank_multi_slices": (i32, [vp, vp, vp, u64, vp, u32, u64, f64, f32, vp, C.POINTER(u64), C.POINTER(f64)]),
     "gm_pr_tile_count": (u64, [vp]),
     "gm_pr_plan_info": (i32, [vp, vp, u32]),
     "gm_pr_part_geometry": (i32, [vp, vp, vp]),

@@ -42,6 +42,8 @@
 #include <memory>
 #include <vector>
 
+extern char **environ; // unistd.h's, declared here at global scope
+
 namespace {
 
 using namespace gm;
@@ -96,11 +98,11 @@ int rccl_get(const Rccl **out)
     } while (0)
 
 // ---- kernels ----------------------------------------------------------------------------------------------
-__global__ void mg_has_out_kernel(const uint32_t *__restrict__ out_off, uint32_t n, uint32_t *__restrict__ flag)
+__global__ void mg_has_out_degree_kernel(const uint32_t *__restrict__ outdeg, uint32_t n, uint32_t *__restrict__ flag)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u <= n; u += stride)
-        flag[u] = (u < n && out_off[u + 1] > out_off[u]) ? 1u : 0u;
+        flag[u] = (u < n && outdeg[u] != 0u) ? 1u : 0u;
 }
 
 // local rows (of [lo, hi)) that have out-edges, in order: what the rank contributes to the exchange
@@ -211,6 +213,11 @@ struct Rank {
             gm_pr_destroy(pr);
         if (rows)
             gm_csr_free(rows);
+        // the buffers go while the rank's device is current (members are destroyed after this body, when the guard has
+        // already restored the caller's device)
+        outdeg.release(), scores.release(), x_loc.release(), x[0].release(), x[1].release(), err.release();
+        for (uint32_t k = 0; k < MG_MAX_PARTS; ++k)
+            x_send[k].release(), send_rows[k].release();
         for (uint32_t k = 0; k < MG_MAX_PARTS; ++k) {
             if (ev_ready[k])
                 (void)hipEventDestroy(ev_ready[k]);
@@ -266,6 +273,7 @@ struct gm::MultiState {
     std::vector<int> devs;
     float damping = 0.f;
     int engine = 0;
+    uint64_t env_hash = 0; // the GM_PB_* / GM_MULTI_* / GM_ARENA* knobs the engines were built under
     uint32_t K = 1;
     uint32_t P = 0, n = 0;
     bool distinct = true, pieces = false;
@@ -287,30 +295,49 @@ namespace {
 
 using MultiPtr = std::unique_ptr<gm::MultiState, gm::MultiStateDeleter>;
 
-int multi_build(const gm_csr *out_csr, const gm_csr *in_csr, const std::vector<int> &devs, bool distinct, float damping_factor,
-                int engine_env, uint32_t K_want, MultiPtr *out)
+// What a rank is built from, all of it on the rank's own device: its rows of the in-CSR (offsets rebased to 0, targets as
+// GLOBAL node ids) and the out-degree of EVERY node (which nodes are ever gathered, and its own rows' divisors).  Consumed.
+struct RankInput {
+    int device = 0;
+    DevBuf off, tgt, outdeg_full;
+    uint64_t edges = 0;
+};
+
+// the plan / engine knobs of the environment as one number: a parked state built under other knobs is not reused
+uint64_t multi_env_hash()
+{
+    uint64_t h = 0;
+    for (char **e = ::environ; e && *e; ++e) {
+        const char *v = *e;
+        if (strncmp(v, "GM_PB_", 6) != 0 && strncmp(v, "GM_MULTI_", 9) != 0 && strncmp(v, "GM_PR_", 6) != 0)
+            continue;
+        uint64_t x = 1469598103934665603ull;
+        for (const char *c = v; *c; ++c)
+            x = (x ^ (uint64_t)(unsigned char)*c) * 1099511628211ull;
+        h += x; // order of the entries does not matter
+    }
+    return h;
+}
+
+// The partitioned run's state from per-rank inputs: nothing here touches a device that holds "the whole graph" — every
+// rank derives the exchange layout from the out-degree vector on its own device (a scan of n flags: the same numbers on
+// every rank) and rewrites its own targets.
+int multi_build_from(std::vector<RankInput> &in, const std::vector<uint32_t> &bounds_in, uint32_t n, const std::vector<int> &devs,
+                     bool distinct, float damping_factor, int engine_env, uint32_t K_want, MultiPtr *out)
 {
     MultiPtr ms(new (std::nothrow) gm::MultiState());
     GM_CHECK(ms, GM_ERR_NOMEM, "gm_page_rank_multi: out of host memory");
-    const uint32_t n = (uint32_t)in_csr->n, P = (uint32_t)devs.size();
-    const int src_dev = in_csr->device;
-    ms->out_csr = out_csr, ms->devs = devs, ms->damping = damping_factor, ms->engine = engine_env, ms->P = P, ms->n = n,
-    ms->distinct = distinct;
+    const uint32_t P = (uint32_t)devs.size();
+    ms->devs = devs, ms->damping = damping_factor, ms->engine = engine_env, ms->P = P, ms->n = n, ms->distinct = distinct;
+    ms->env_hash = multi_env_hash();
+    ms->bounds = bounds_in;
     gm::PhaseTimer timer((hipStream_t)0);
-
-    // ---- partition (on the host, from the offsets) ----------------------------------------------------------
-    std::vector<uint32_t> off_host((size_t)n + 1);
-    {
-        DeviceGuard g(src_dev);
-        GM_HIP(hipMemcpy(off_host.data(), in_csr->offsets, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost));
-    }
-    ms->bounds = greedy_in_degree_bounds(off_host, P);
     const std::vector<uint32_t> &bounds = ms->bounds;
     // a sweep in pieces needs propagation-blocking engines on every rank: every slice large enough for AUTO to pick
     // one (pagerank.hip: 2^24 edges), or forced by GM_MULTI_ENGINE=pb
     uint64_t min_edges = ~0ull;
     for (uint32_t p = 0; p < P; ++p)
-        min_edges = std::min<uint64_t>(min_edges, (uint64_t)off_host[bounds[p + 1]] - off_host[bounds[p]]);
+        min_edges = std::min<uint64_t>(min_edges, in[p].edges);
     ms->pieces = K_want > 1 && (engine_env == GM_PR_ENGINE_PB || (engine_env == GM_PR_ENGINE_AUTO && min_edges >= (1ull << 24)));
     const uint32_t K = ms->pieces ? K_want : 1;
     ms->K = K;
@@ -325,50 +352,55 @@ int multi_build(const gm_csr *out_csr, const gm_csr *in_csr, const std::vector<i
         }
     }
 
-    // ---- exchange layout (on the device that holds the graph) -------------------------------------------------
-    DevBuf flag, pos, d_splits, d_strides, d_region, node_map;
+    // ---- per rank, on its own device: who is gathered (flag / pos), the exchange layout, the node map -------------------
+    struct Local {
+        DevBuf flag, pos, node_map;
+    };
+    std::vector<Local> loc(P);
     std::vector<uint32_t> pos_at(splits.size());
     ms->strides.assign(K, 0), ms->region_off.assign(K, 0);
-    {
-        DeviceGuard g(src_dev);
-        GM_TRY(flag.alloc(((size_t)n + 1) * 4));
-        GM_TRY(pos.alloc(((size_t)n + 1) * 4));
-        GM_TRY(node_map.alloc((size_t)n * 4));
-        hipLaunchKernelGGL(mg_has_out_kernel, dim3(mg_grid((uint64_t)n + 1)), dim3(256), 0, 0, out_csr->offsets, n,
-                           flag.as<uint32_t>());
+    for (uint32_t p = 0; p < P; ++p) {
+        DeviceGuard g(devs[p]);
+        GM_TRY(loc[p].flag.alloc(((size_t)n + 1) * 4));
+        GM_TRY(loc[p].pos.alloc(((size_t)n + 1) * 4));
+        hipLaunchKernelGGL(mg_has_out_degree_kernel, dim3(mg_grid((uint64_t)n + 1)), dim3(256), 0, 0, in[p].outdeg_full.as<uint32_t>(),
+                           n, loc[p].flag.as<uint32_t>());
         GM_HIP(hipGetLastError());
         size_t tmp_bytes = 0;
-        GM_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, flag.as<uint32_t>(), pos.as<uint32_t>(), 0u, (size_t)n + 1,
+        GM_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, loc[p].flag.as<uint32_t>(), loc[p].pos.as<uint32_t>(), 0u, (size_t)n + 1,
                                        rocprim::plus<uint32_t>(), (hipStream_t)0));
         DevBuf tmp;
         GM_TRY(tmp.alloc(tmp_bytes));
-        GM_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, flag.as<uint32_t>(), pos.as<uint32_t>(), 0u, (size_t)n + 1,
+        GM_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, loc[p].flag.as<uint32_t>(), loc[p].pos.as<uint32_t>(), 0u, (size_t)n + 1,
                                        rocprim::plus<uint32_t>(), (hipStream_t)0));
-        for (size_t i = 0; i < splits.size(); ++i)
-            GM_HIP(hipMemcpy(&pos_at[i], pos.as<uint32_t>() + splits[i], 4, hipMemcpyDeviceToHost));
-        uint64_t off = 0;
-        for (uint32_t k = 0; k < K; ++k) {
-            uint32_t most = 1;
-            for (uint32_t p = 0; p < P; ++p)
-                most = std::max(most, pos_at[(size_t)p * (K + 1) + k + 1] - pos_at[(size_t)p * (K + 1) + k]);
-            // whole source tiles per rank when the vector is consumed region by region; float4-aligned otherwise
-            const uint32_t unit = K > 1 ? MG_SOURCE_TILE : 4u;
-            ms->strides[k] = (most + unit - 1) / unit * unit;
-            ms->region_off[k] = (uint32_t)off;
-            off += ms->strides[k];
+        GM_HIP(hipDeviceSynchronize());
+        if (p == 0) { // the layout's numbers: the same on every rank, read once
+            for (size_t i = 0; i < splits.size(); ++i)
+                GM_HIP(hipMemcpy(&pos_at[i], loc[0].pos.as<uint32_t>() + splits[i], 4, hipMemcpyDeviceToHost));
+            uint64_t off = 0;
+            for (uint32_t k = 0; k < K; ++k) {
+                uint32_t most = 1;
+                for (uint32_t q = 0; q < P; ++q)
+                    most = std::max(most, pos_at[(size_t)q * (K + 1) + k + 1] - pos_at[(size_t)q * (K + 1) + k]);
+                // whole source tiles per rank when the vector is consumed region by region; float4-aligned otherwise
+                const uint32_t unit = K > 1 ? MG_SOURCE_TILE : 4u;
+                ms->strides[k] = (most + unit - 1) / unit * unit;
+                ms->region_off[k] = (uint32_t)off;
+                off += ms->strides[k];
+            }
+            GM_CHECK(off * P < (1ull << 32), GM_ERR_RANGE, "gm_page_rank_multi: exchange vector exceeds u32");
+            ms->rank_stride = (uint32_t)off;
+            ms->x_len = off * P;
         }
-        GM_CHECK(off * P < (1ull << 32), GM_ERR_RANGE, "gm_page_rank_multi: exchange vector exceeds u32");
-        ms->rank_stride = (uint32_t)off;
-        ms->x_len = off * P;
+        DevBuf d_splits, d_region;
+        GM_TRY(loc[p].node_map.alloc((size_t)n * 4));
         GM_TRY(d_splits.alloc(splits.size() * 4));
-        GM_TRY(d_strides.alloc((size_t)K * 4));
         GM_TRY(d_region.alloc((size_t)K * 4));
         GM_HIP(hipMemcpy(d_splits.p, splits.data(), splits.size() * 4, hipMemcpyHostToDevice));
-        GM_HIP(hipMemcpy(d_strides.p, ms->strides.data(), (size_t)K * 4, hipMemcpyHostToDevice));
         GM_HIP(hipMemcpy(d_region.p, ms->region_off.data(), (size_t)K * 4, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(mg_node_map_parts_kernel, dim3(mg_grid(n)), dim3(256), 0, 0, flag.as<uint32_t>(), pos.as<uint32_t>(),
-                           d_splits.as<uint32_t>(), P, K, ms->rank_stride, d_region.as<uint32_t>(), n,
-                           node_map.as<uint32_t>());
+        hipLaunchKernelGGL(mg_node_map_parts_kernel, dim3(mg_grid(n)), dim3(256), 0, 0, loc[p].flag.as<uint32_t>(),
+                           loc[p].pos.as<uint32_t>(), d_splits.as<uint32_t>(), P, K, ms->rank_stride, d_region.as<uint32_t>(), n,
+                           loc[p].node_map.as<uint32_t>());
         GM_HIP(hipGetLastError());
         GM_HIP(hipDeviceSynchronize());
     }
@@ -382,7 +414,7 @@ int multi_build(const gm_csr *out_csr, const gm_csr *in_csr, const std::vector<i
         r.device = devs[p];
         r.lo = bounds[p], r.hi = bounds[p + 1];
         const uint32_t rows = r.hi - r.lo;
-        const uint64_t e0 = off_host[r.lo], e1 = off_host[r.hi], cnt = e1 - e0;
+        const uint64_t cnt = in[p].edges;
         DeviceGuard g(r.device);
         GM_HIP(hipStreamCreateWithFlags(&r.st, hipStreamNonBlocking));
         GM_HIP(hipStreamCreateWithFlags(&r.cst, hipStreamNonBlocking));
@@ -391,61 +423,36 @@ int multi_build(const gm_csr *out_csr, const gm_csr *in_csr, const std::vector<i
             GM_HIP(hipEventCreateWithFlags(&r.ev_done[0][k], hipEventDisableTiming));
             GM_HIP(hipEventCreateWithFlags(&r.ev_done[1][k], hipEventDisableTiming));
         }
-        DevBuf d_off, d_tgt, d_map;
-        GM_TRY(d_off.alloc(((size_t)rows + 1) * 4));
-        GM_TRY(d_tgt.alloc((size_t)cnt * 4));
-        GM_TRY(r.outdeg.alloc((size_t)rows * 4));
-        // the slice's raw arrays, then offsets rebased / targets rewritten on the rank's own device
-        GM_HIP(mg_copy(d_off.p, r.device, in_csr->offsets + r.lo, src_dev, ((size_t)rows + 1) * 4));
-        GM_HIP(mg_copy(d_tgt.p, r.device, in_csr->targets + e0, src_dev, (size_t)cnt * 4));
-        const uint32_t *map_here = node_map.as<uint32_t>();
-        if (r.device != src_dev) {
-            GM_TRY(d_map.alloc((size_t)n * 4));
-            GM_HIP(mg_copy(d_map.p, r.device, node_map.p, src_dev, (size_t)n * 4));
-            map_here = d_map.as<uint32_t>();
-        }
-        {   // out-degrees and the send lists are cut on the source device, then moved
-            DeviceGuard gs(src_dev);
-            DevBuf od;
-            GM_TRY(od.alloc((size_t)rows * 4));
-            if (rows)
-                hipLaunchKernelGGL(mg_out_degree_kernel, dim3(mg_grid(rows)), dim3(256), 0, 0, out_csr->offsets, r.lo, rows,
-                                   od.as<uint32_t>());
+        GM_TRY(r.outdeg.alloc((size_t)(rows ? rows : 1) * 4));
+        if (rows)
+            GM_HIP(hipMemcpy(r.outdeg.p, in[p].outdeg_full.as<uint32_t>() + r.lo, (size_t)rows * 4, hipMemcpyDeviceToDevice));
+        for (uint32_t k = 0; k < K; ++k) { // rows[rank among the group's senders] = v - (rank's first row)
+            const uint32_t g_lo = splits[(size_t)p * (K + 1) + k], g_hi = splits[(size_t)p * (K + 1) + k + 1];
+            r.send_count[k] = pos_at[(size_t)p * (K + 1) + k + 1] - pos_at[(size_t)p * (K + 1) + k];
+            GM_TRY(r.send_rows[k].alloc((size_t)r.send_count[k] * 4));
+            if (g_hi > g_lo)
+                hipLaunchKernelGGL(mg_send_rows_kernel, dim3(mg_grid(g_hi - g_lo)), dim3(256), 0, 0, loc[p].flag.as<uint32_t>(),
+                                   loc[p].pos.as<uint32_t>(), g_lo, g_hi, r.lo, r.send_rows[k].as<uint32_t>());
             GM_HIP(hipGetLastError());
-            GM_HIP(hipDeviceSynchronize());
-            GM_HIP(mg_copy(r.outdeg.p, r.device, od.p, src_dev, (size_t)rows * 4));
-            for (uint32_t k = 0; k < K; ++k) {
-                const uint32_t g_lo = splits[(size_t)p * (K + 1) + k], g_hi = splits[(size_t)p * (K + 1) + k + 1];
-                r.send_count[k] = pos_at[(size_t)p * (K + 1) + k + 1] - pos_at[(size_t)p * (K + 1) + k];
-                DevBuf sr;
-                GM_TRY(sr.alloc((size_t)r.send_count[k] * 4));
-                if (g_hi > g_lo) // rows[rank among the group's senders] = v - (rank's first row)
-                    hipLaunchKernelGGL(mg_send_rows_kernel, dim3(mg_grid(g_hi - g_lo)), dim3(256), 0, 0, flag.as<uint32_t>(),
-                                       pos.as<uint32_t>(), g_lo, g_hi, r.lo, sr.as<uint32_t>());
-                GM_HIP(hipGetLastError());
-                GM_HIP(hipDeviceSynchronize());
-                DeviceGuard gr(r.device);
-                GM_TRY(r.send_rows[k].alloc((size_t)r.send_count[k] * 4));
-                GM_HIP(mg_copy(r.send_rows[k].p, r.device, sr.p, src_dev, (size_t)r.send_count[k] * 4));
-            }
         }
-        hipLaunchKernelGGL(mg_rebase_kernel, dim3(mg_grid((uint64_t)rows + 1)), dim3(256), 0, 0, d_off.as<uint32_t>(), rows + 1,
-                           (uint32_t)e0);
-        if (cnt)
-            hipLaunchKernelGGL(mg_map_targets_kernel, dim3(mg_grid(cnt)), dim3(256), 0, 0, d_tgt.as<uint32_t>(), cnt, map_here);
+        if (cnt) // targets into the exchange index space
+            hipLaunchKernelGGL(mg_map_targets_kernel, dim3(mg_grid(cnt)), dim3(256), 0, 0, in[p].tgt.as<uint32_t>(), cnt,
+                               loc[p].node_map.as<uint32_t>());
         GM_HIP(hipGetLastError());
         GM_HIP(hipDeviceSynchronize());
-        // hand the arrays to an owning handle: wrap, then let the Rank keep the buffers alive through the handle
+        loc[p].flag.release(), loc[p].pos.release(), loc[p].node_map.release();
+        in[p].outdeg_full.release();
+        // hand the arrays to an owning handle: the Rank keeps the buffers alive through it
         gm_csr *c = new (std::nothrow) gm_csr();
         GM_CHECK(c, GM_ERR_NOMEM, "gm_page_rank_multi: out of host memory");
         c->n = rows, c->m = cnt, c->device = r.device, c->owns = true;
-        c->own_offsets = std::move(d_off);
-        c->own_targets = std::move(d_tgt);
+        c->own_offsets = std::move(in[p].off);
+        c->own_targets = std::move(in[p].tgt);
         c->offsets = c->own_offsets.as<uint32_t>();
         c->targets = c->own_targets.as<uint32_t>();
         r.rows = c;
-        GM_TRY(r.scores.alloc((size_t)rows * 4));
-        GM_TRY(r.x_loc.alloc((size_t)rows * 4));
+        GM_TRY(r.scores.alloc((size_t)(rows ? rows : 1) * 4));
+        GM_TRY(r.x_loc.alloc((size_t)(rows ? rows : 1) * 4));
         GM_TRY(r.x[0].alloc((size_t)x_len * 4));
         GM_TRY(r.x[1].alloc((size_t)x_len * 4));
         GM_TRY(r.err.alloc(8));
@@ -485,6 +492,48 @@ int multi_build(const gm_csr *out_csr, const gm_csr *in_csr, const std::vector<i
     }
     GM_TRY(ms->herr.alloc((size_t)P * 8));
     *out = std::move(ms);
+    return GM_OK;
+}
+
+// gm_page_rank_multi: both CSRs whole on one device: the reference's partitioner on the host (from the in-offsets), then
+// every rank's input is cut there and moved to the rank's device
+int multi_build(const gm_csr *out_csr, const gm_csr *in_csr, const std::vector<int> &devs, bool distinct, float damping_factor,
+                int engine_env, uint32_t K_want, MultiPtr *out)
+{
+    const uint32_t n = (uint32_t)in_csr->n, P = (uint32_t)devs.size();
+    const int src_dev = in_csr->device;
+    std::vector<uint32_t> off_host((size_t)n + 1);
+    DevBuf od_full;
+    {
+        DeviceGuard g(src_dev);
+        GM_HIP(hipMemcpy(off_host.data(), in_csr->offsets, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost));
+        GM_TRY(od_full.alloc((size_t)n * 4));
+        hipLaunchKernelGGL(mg_out_degree_kernel, dim3(mg_grid(n)), dim3(256), 0, 0, out_csr->offsets, 0u, n, od_full.as<uint32_t>());
+        GM_HIP(hipGetLastError());
+        GM_HIP(hipDeviceSynchronize());
+    }
+    const std::vector<uint32_t> bounds = greedy_in_degree_bounds(off_host, P);
+    std::vector<RankInput> in(P);
+    for (uint32_t p = 0; p < P; ++p) {
+        RankInput &ri = in[p];
+        ri.device = devs[p];
+        const uint32_t lo = bounds[p], rows = bounds[p + 1] - bounds[p];
+        const uint64_t e0 = off_host[lo], cnt = (uint64_t)off_host[lo + rows] - e0;
+        ri.edges = cnt;
+        DeviceGuard g(ri.device);
+        GM_TRY(ri.off.alloc(((size_t)rows + 1) * 4));
+        GM_TRY(ri.tgt.alloc((size_t)cnt * 4));
+        GM_TRY(ri.outdeg_full.alloc((size_t)n * 4));
+        GM_HIP(mg_copy(ri.off.p, ri.device, in_csr->offsets + lo, src_dev, ((size_t)rows + 1) * 4));
+        GM_HIP(mg_copy(ri.tgt.p, ri.device, in_csr->targets + e0, src_dev, (size_t)cnt * 4));
+        GM_HIP(mg_copy(ri.outdeg_full.p, ri.device, od_full.p, src_dev, (size_t)n * 4));
+        hipLaunchKernelGGL(mg_rebase_kernel, dim3(mg_grid((uint64_t)rows + 1)), dim3(256), 0, 0, ri.off.as<uint32_t>(), rows + 1,
+                           (uint32_t)e0);
+        GM_HIP(hipGetLastError());
+        GM_HIP(hipDeviceSynchronize());
+    }
+    GM_TRY(multi_build_from(in, bounds, n, devs, distinct, damping_factor, engine_env, K_want, out));
+    (*out)->out_csr = out_csr;
     return GM_OK;
 }
 
@@ -686,7 +735,7 @@ GM_API int gm_page_rank_multi(const gm_csr *out_csr, const gm_csr *in_csr, const
     {
         std::lock_guard<std::mutex> lock(in_csr->cache_mu);
         if (in_csr->multi && in_csr->multi->out_csr == out_csr && in_csr->multi->devs == devs &&
-            in_csr->multi->damping == damping_factor && in_csr->multi->engine == engine &&
+            in_csr->multi->damping == damping_factor && in_csr->multi->engine == engine && in_csr->multi->env_hash == multi_env_hash() &&
             (in_csr->multi->K == K || (!in_csr->multi->pieces && in_csr->multi->K == 1)) && !getenv("GM_MULTI_NOCACHE") &&
             !(getenv("GM_PB_NOCACHE") && atoi(getenv("GM_PB_NOCACHE")))) // measurement runs that switch plan knobs build afresh
             ms = std::move(in_csr->multi);
@@ -703,4 +752,74 @@ GM_API int gm_page_rank_multi(const gm_csr *out_csr, const gm_csr *in_csr, const
         }
     }
     return rc;
+}
+
+// The same run from per-device pieces: no device ever holds the whole graph.  in_slices[p]: the rows [bounds[p],
+// bounds[p + 1]) of the in-CSR on devices[p] (n_local rows, offsets from 0, targets as GLOBAL node ids, Sorted / Deduplicated
+// layout for the reference's summation order); d_out_degree_full[p]: u32[n] on devices[p], the out-degree of every node
+// (a host that builds the pieces separately gets it by an all-reduce of per-piece histograms).  The inputs are copied, not
+// consumed.  The partition is the caller's: in_degree_partition's greedy ranges (graph_ops.rs:431-439,479-509) give the
+// same bits as gm_page_rank_multi on the whole graph.
+GM_API int gm_page_rank_multi_slices(const gm_csr *const *in_slices, const uint64_t *bounds, const uint64_t *d_out_degree_full,
+                                     uint64_t n, const int *devices, uint32_t n_devices, uint64_t max_iterations, double tolerance,
+                                     float damping_factor, float *scores_out, uint64_t *iterations_out, double *error_out)
+{
+    GM_CHECK(in_slices && bounds && d_out_degree_full && iterations_out && error_out, GM_ERR_INVALID,
+             "gm_page_rank_multi_slices: null argument");
+    GM_CHECK(n_devices >= 1 && n_devices <= 64, GM_ERR_INVALID, "gm_page_rank_multi_slices: n_devices %u not in [1, 64]", n_devices);
+    GM_CHECK(n < (1ull << 32), GM_ERR_RANGE, "gm_page_rank_multi_slices: %llu nodes", (unsigned long long)n);
+    GM_CHECK(max_iterations != 0 || tolerance > 0.0, GM_ERR_INVALID,
+             "gm_page_rank_multi_slices: max_iterations == 0 with tolerance <= 0 never terminates (reference: infinite loop)");
+    if (n == 0) {
+        *iterations_out = 1;
+        *error_out = 0.0;
+        return GM_OK;
+    }
+    GM_CHECK(scores_out, GM_ERR_INVALID, "gm_page_rank_multi_slices: scores_out is null");
+    const uint32_t P = n_devices;
+    int visible = 0;
+    GM_HIP(hipGetDeviceCount(&visible));
+    std::vector<int> devs(P);
+    std::vector<uint32_t> b32(P + 1);
+    bool distinct = true;
+    GM_CHECK(bounds[0] == 0 && bounds[P] == n, GM_ERR_INVALID, "gm_page_rank_multi_slices: bounds must run from 0 to n");
+    for (uint32_t p = 0; p <= P; ++p)
+        b32[p] = (uint32_t)bounds[p];
+    for (uint32_t p = 0; p < P; ++p) {
+        devs[p] = devices ? devices[p] : (int)p;
+        GM_CHECK(devs[p] >= 0 && devs[p] < visible, GM_ERR_INVALID, "gm_page_rank_multi_slices: device %d of %d visible", devs[p],
+                 visible);
+        for (uint32_t q = 0; q < p; ++q)
+            distinct = distinct && devs[q] != devs[p];
+        GM_CHECK(bounds[p] <= bounds[p + 1], GM_ERR_INVALID, "gm_page_rank_multi_slices: bounds must ascend");
+        GM_CHECK(in_slices[p] && in_slices[p]->n == bounds[p + 1] - bounds[p] && in_slices[p]->device == devs[p] && d_out_degree_full[p],
+                 GM_ERR_INVALID, "gm_page_rank_multi_slices: piece %u is not the rows [%llu, %llu) on device %d", p,
+                 (unsigned long long)bounds[p], (unsigned long long)bounds[p + 1], devs[p]);
+    }
+    const int engine = [] {
+        const char *v = getenv("GM_MULTI_ENGINE");
+        return v && v[0] == 'p' && v[1] == 'b' ? GM_PR_ENGINE_PB : v && v[0] == 'p' ? GM_PR_ENGINE_PULL : GM_PR_ENGINE_AUTO;
+    }();
+    uint32_t K = 2;
+    if (const char *v = getenv("GM_MULTI_PARTS"))
+        K = (uint32_t)atoi(v);
+    K = K < 1 ? 1 : (K > MG_MAX_PARTS ? MG_MAX_PARTS : K);
+    std::vector<RankInput> in(P);
+    for (uint32_t p = 0; p < P; ++p) {
+        RankInput &ri = in[p];
+        const gm_csr *sl = in_slices[p];
+        ri.device = devs[p];
+        ri.edges = sl->m;
+        DeviceGuard g(ri.device);
+        GM_TRY(ri.off.alloc(((size_t)sl->n + 1) * 4));
+        GM_TRY(ri.tgt.alloc((size_t)sl->m * 4));
+        GM_TRY(ri.outdeg_full.alloc((size_t)n * 4));
+        GM_HIP(hipMemcpy(ri.off.p, sl->offsets, ((size_t)sl->n + 1) * 4, hipMemcpyDeviceToDevice));
+        if (sl->m)
+            GM_HIP(hipMemcpy(ri.tgt.p, sl->targets, (size_t)sl->m * 4, hipMemcpyDeviceToDevice));
+        GM_HIP(hipMemcpy(ri.outdeg_full.p, reinterpret_cast<const void *>(d_out_degree_full[p]), (size_t)n * 4, hipMemcpyDeviceToDevice));
+    }
+    MultiPtr ms;
+    GM_TRY(multi_build_from(in, b32, (uint32_t)n, devs, distinct, damping_factor, engine, K, &ms));
+    return multi_run(*ms, max_iterations, tolerance, scores_out, iterations_out, error_out);
 }

@@ -703,8 +703,18 @@ __global__ __launch_bounds__(PB_BIN_BLOCK) void pb_bin_kernel(const float *__res
                                                               const uint32_t *__restrict__ chunk_seg,
                                                               const uint32_t *__restrict__ delta, float *__restrict__ vals,
                                                               uint32_t PB_BIN_CHUNK, uint32_t w_first, int xcd_aware,
-                                                              const uint32_t *__restrict__ item_list)
+                                                              const uint32_t *__restrict__ item_list,
+                                                              const uint32_t *__restrict__ hot_ids, uint32_t Htot,
+                                                              float *__restrict__ hot_x)
 {
+    // whole sweeps: the out_scores of the hot sources (read by the accumulate kernel from hot_x) are gathered here, a share
+    // per workgroup, instead of by a launch of their own in front of this one (pb_hot_gather_kernel: 4 us + a kernel boundary)
+    if (hot_ids) {
+        const uint32_t per = (Htot + gridDim.x - 1u) / gridDim.x;
+        const uint32_t k = blockIdx.x * per + threadIdx.x;
+        if (threadIdx.x < per && k < Htot)
+            hot_x[k] = x_in[hot_ids[k]];
+    }
     constexpr uint32_t PB_S = 1u << S_LOG;                          // sources per tile
     extern __shared__ float xs[];                                   // PB_S floats ...
     uint32_t *dl = reinterpret_cast<uint32_t *>(xs + PB_S);         // ... + PB_DCACHE segment deltas
@@ -2262,8 +2272,8 @@ static hipError_t pb_set_kernel_attributes()
     return e;
 }
 
-static void pb_bin_dispatch(const PbPlan *pl, PbScratch *sc, const float *x_in, uint32_t w_first, uint32_t w_count,
-                            hipStream_t st, const uint32_t *item_list = nullptr);
+static bool pb_bin_dispatch(const PbPlan *pl, PbScratch *sc, const float *x_in, uint32_t w_first, uint32_t w_count,
+                            hipStream_t st, const uint32_t *item_list = nullptr, bool fold_hot = false);
 
 int pb_plan_create(const gm_csr *csr, uint64_t x_len, PbPlan **out)
 {
@@ -2683,14 +2693,18 @@ void pb_plan_info(const PbPlan *pl, const PbScratch *sc, uint64_t *info, uint32_
 
 template <int ABL, int S_LOG>
 void pb_launch_bin(const PbPlan *pl, PbScratch *sc, const float *x_in, uint32_t w_first, uint32_t w_count, hipStream_t st,
-                   const uint32_t *item_list = nullptr)
+                   const uint32_t *item_list = nullptr, bool fold_hot = false)
 {
+    // the hot sources' share per workgroup must fit its threads: Htot <= w_count x 1024 on every whole sweep that has a
+    // value stream worth the name; otherwise (and for partial launches) pb_hot_gather_kernel does it
+    fold_hot = fold_hot && pl->Htot && (uint64_t)w_count * PB_BIN_BLOCK >= pl->Htot;
     const bool grouped = pl->wg_tile_g.p && w_first == 0 && w_count == pl->NW && !item_list; // whole sweeps only
     hipLaunchKernelGGL((pb_bin_kernel<ABL, S_LOG>), dim3(w_count), dim3(PB_BIN_BLOCK), (4u << S_LOG) + PB_DCACHE * 4, st, x_in,
                        pl->x_len, pl->tile_p.as<uint32_t>(), (grouped ? pl->wg_tile_g : pl->wg_tile).as<uint32_t>(),
                        (grouped ? pl->wg_p0_g : pl->wg_p0).as<uint32_t>(),
                        pl->p1_src.as<uint16_t>(), pl->chunk_seg.as<uint32_t>(), pl->delta.as<uint32_t>(), sc->vals,
-                       pl->chunk, w_first, pl->xcd_aware, item_list);
+                       pl->chunk, w_first, pl->xcd_aware, item_list, fold_hot ? pl->hot_ids.as<uint32_t>() : (const uint32_t *)nullptr,
+                       pl->Htot, sc->hot_x.as<float>());
 }
 
 template <int ABL, int D = PB_ACC_DEPTH>
@@ -2707,27 +2721,30 @@ void pb_launch_accum(const PbPlan *pl, PbScratch *sc, const PbItem *items, uint3
 
 // GM_PB_ABLATE = 10*accumulate variant + bin variant; 0 = the product kernels (re-read per call so that
 // tools/ablate.py can switch variants on one resident graph)
-static void pb_bin_dispatch(const PbPlan *pl, PbScratch *sc, const float *x_in, uint32_t w_first, uint32_t w_count,
-                            hipStream_t st, const uint32_t *item_list)
+// returns whether the launch gathered the hot sources' out_scores as well (whole sweeps of the product kernel)
+static bool pb_bin_dispatch(const PbPlan *pl, PbScratch *sc, const float *x_in, uint32_t w_first, uint32_t w_count,
+                            hipStream_t st, const uint32_t *item_list, bool fold_hot)
 {
     if (w_count == 0)
-        return;
+        return false;
     const int abl = item_list ? 0 : pb_env("GM_PB_ABLATE", 0) % 10;
+    fold_hot = fold_hot && abl == 0 && pl->Htot && (uint64_t)w_count * PB_BIN_BLOCK >= pl->Htot;
     if (pl->s_log == 15) {
         switch (abl) {
         case 3: pb_launch_bin<3, 15>(pl, sc, x_in, w_first, w_count, st); break;
         case 5: pb_launch_bin<5, 15>(pl, sc, x_in, w_first, w_count, st); break;
-        default: pb_launch_bin<0, 15>(pl, sc, x_in, w_first, w_count, st, item_list); break;
+        default: pb_launch_bin<0, 15>(pl, sc, x_in, w_first, w_count, st, item_list, fold_hot); break;
         }
-        return;
+        return fold_hot;
     }
     switch (abl) {
     case 1: pb_launch_bin<1, 14>(pl, sc, x_in, w_first, w_count, st); break;
     case 3: pb_launch_bin<3, 14>(pl, sc, x_in, w_first, w_count, st); break;
     case 4: pb_launch_bin<4, 14>(pl, sc, x_in, w_first, w_count, st); break;
     case 5: pb_launch_bin<5, 14>(pl, sc, x_in, w_first, w_count, st); break;
-    default: pb_launch_bin<0, 14>(pl, sc, x_in, w_first, w_count, st, item_list); break;
+    default: pb_launch_bin<0, 14>(pl, sc, x_in, w_first, w_count, st, item_list, fold_hot); break;
     }
+    return fold_hot;
 }
 
 static void pb_accum_dispatch(const PbPlan *pl, PbScratch *sc, const PbItem *items, uint32_t count, float *x_out,
@@ -2798,8 +2815,8 @@ int pb_sweep_main(const PbPlan *pl, PbScratch *sc, const float *x_in, float *x_o
                   const uint32_t *outdeg, float base, float damping, hipStream_t st)
 {
     pb_apply_vals_offset(pl, sc);
-    pb_hot_dispatch(pl, sc, x_in, st);
-    pb_bin_dispatch(pl, sc, x_in, 0, pl->NW, st);
+    if (!pb_bin_dispatch(pl, sc, x_in, 0, pl->NW, st, nullptr, pb_env("GM_PB_FOLD_HOT", 1) != 0))
+        pb_hot_dispatch(pl, sc, x_in, st); // (in front of the accumulate kernel, which reads hot_x; the bin kernel does not)
     // the hub groups need little LDS: on a second stream their workgroups run beside those of the ordinary bins
     // (measured at scale 26 / 22 on one box: 3.12 / 3.24 ms forked vs 3.33 / 3.44 ms in line, 0.216 vs 0.252 ms;
     // with the 85-VGPR version of the kernel the two could not share a CU and forking gained nothing)

@@ -471,3 +471,66 @@ def sssp_partitioned(relax_rows, dist_bits: torch.Tensor, group=None, max_rounds
         if int(flag.item()) == 0:
             return rounds
     raise RuntimeError("sssp_partitioned did not converge")
+
+
+# ------------------------------------------------------------------------------------------------
+# Partition-local construction: no device ever holds the whole graph (gm_page_rank_multi_slices)
+# ------------------------------------------------------------------------------------------------
+def rmat_degrees(scale: int, seed: int = 42, edge_factor: int = 16, device: int = 0, chunk: int = 1 << 26):
+    """(in_degree, out_degree) of every node of the R-MAT graph, int64 on `device`, from the counter-based generator in
+    chunks of `chunk` edges: n-sized vectors only, the edge list never exists as a whole.  (A job whose ranks each scan
+    m / P edge indices sums these histograms with an all-reduce; here every caller scans all of them.)"""
+    from . import synth
+
+    n, m = 1 << scale, edge_factor << scale
+    dev = torch.device("cuda", device)
+    ind = torch.zeros(n, dtype=torch.int64, device=dev)
+    outd = torch.zeros(n, dtype=torch.int64, device=dev)
+    for first in range(0, m, chunk):
+        src, dst = synth.rmat_edge_range(scale, seed, first, min(chunk, m - first), device)
+        ind += torch.bincount(dst, minlength=n)
+        outd += torch.bincount(src, minlength=n)
+        del src, dst
+    return ind, outd
+
+
+def partition_local_slices(scale: int, seed: int, ranks: int, devices=None, edge_factor: int = 16, chunk: int = 1 << 26):
+    """The pieces gm_page_rank_multi_slices takes, built WITHOUT the whole graph on any device: the reference's greedy
+    in-degree ranges (graph_ops.rs:431-439,479-509) from the degree histograms, then per rank: the edges whose destination lies
+    in its range (kept from a chunked scan of the generator), a Sorted in-CSR over them and its row slice.
+    Returns (slices, bounds, out_degree_full_u32 per rank, devices)."""
+    import ctypes as C
+
+    from . import synth
+    from ._lib import check, lib, vp
+    from .prelude import CsrLayout, DeviceCsr, Direction
+
+    devices = list(devices) if devices is not None else [0] * ranks
+    n, m = 1 << scale, edge_factor << scale
+    ind, outd = rmat_degrees(scale, seed, edge_factor, devices[0], chunk)
+    off = np.zeros(n + 1, np.int64)
+    np.cumsum(ind.cpu().numpy(), out=off[1:])
+    bounds, _ = pad_bounds(greedy_degree_partition(off, ranks), ranks, n)
+    slices, out_full = [], []
+    for p in range(ranks):
+        dev = devices[p]
+        lo, hi = int(bounds[p]), int(bounds[p + 1])
+        keep_s, keep_d = [], []
+        for first in range(0, m, chunk):
+            src, dst = synth.rmat_edge_range(scale, seed, first, min(chunk, m - first), dev)
+            mine = (dst >= lo) & (dst < hi)
+            keep_s.append(src[mine])
+            keep_d.append(dst[mine])
+            del src, dst, mine
+        s = torch.cat(keep_s) if keep_s else torch.empty(0, dtype=torch.int32, device=dev)
+        d = torch.cat(keep_d) if keep_d else torch.empty(0, dtype=torch.int32, device=dev)
+        del keep_s, keep_d
+        # a CSR over the rank's own edges (n rows, nearly all of them empty: n + 1 offsets), then its rows [lo, hi)
+        local = synth.build_csr(n, s, d, Direction.Incoming, CsrLayout.Sorted, None, dev)
+        del s, d
+        h = vp()
+        check(lib().gm_csr_slice_rows(local.handle, lo, hi, None, 0, 0, C.byref(h)))
+        slices.append(DeviceCsr(h))
+        del local
+        out_full.append(outd.to(torch.device("cuda", dev)).to(torch.int32).contiguous())
+    return slices, [int(b) for b in bounds], out_full, devices

@@ -405,6 +405,26 @@ def page_rank_multi(graph: DirectedCsrGraph, config: PageRankConfig | None = Non
     return scores, int(it.value), float(err.value)
 
 
+def page_rank_multi_slices(slices, bounds, out_degree_full, config: PageRankConfig | None = None, devices=None):
+    """gm_page_rank_multi_slices: the partitioned page_rank from PIECES — slices[p]: DeviceCsr with the rows [bounds[p],
+    bounds[p + 1]) of the in-CSR on devices[p] (targets: global node ids); out_degree_full[p]: device address of u32[n] on
+    devices[p] (or an object with data_ptr()).  No device holds the whole graph (graph_amd/distributed.py:
+    partition_local_slices builds such pieces)."""
+    config = config or PageRankConfig()
+    count = len(slices)
+    n = int(bounds[-1])
+    devices = list(devices) if devices is not None else list(range(count))
+    scores = _result_buffer(n, np.float32)
+    it, err = u64(0), f64(0.0)
+    hs = (vp * count)(*[s.handle for s in slices])
+    bd = (C.c_uint64 * (count + 1))(*[int(b) for b in bounds])
+    od = (C.c_uint64 * count)(*[int(o.data_ptr() if hasattr(o, "data_ptr") else o) for o in out_degree_full])
+    dv = (C.c_int * count)(*[int(d) for d in devices])
+    check(lib().gm_page_rank_multi_slices(hs, bd, od, n, dv, count, int(config.max_iterations), float(config.tolerance),
+                                          float(config.damping_factor), _ptr(scores) if n else None, C.byref(it), C.byref(err)))
+    return scores, int(it.value), float(err.value)
+
+
 @dataclass
 class WccConfig:
     """crates/algos/src/wcc.rs:43-79 (chunk_size is a CPU scheduling knob; ignored on the device)"""

@@ -26,6 +26,18 @@ def rmat_edges(scale: int, seed: int = 42, edge_factor: int = 16, device: int = 
     return src, dst
 
 
+def rmat_edge_range(scale: int, seed: int, first: int, count: int, device: int = 0):
+    """edges [first, first + count) of the same R-MAT edge list (the generator is counter-based: any range, on any device)"""
+    dev = torch.device("cuda", device)
+    src = torch.empty(count, dtype=torch.int32, device=dev)
+    dst = torch.empty(count, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib().gm_rmat_edges_device(scale, seed, first, count, src.data_ptr(), dst.data_ptr(), device,
+                                         vp(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.current_stream().synchronize()
+    return src, dst
+
+
 def rmat_weights(m: int, seed: int = 44, device: int = 0):
     dev = torch.device("cuda", device)
     w = torch.empty(m, dtype=torch.float32, device=dev)

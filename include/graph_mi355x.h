@@ -180,7 +180,8 @@ int gm_page_rank_directed(const gm_csr *out_csr, const gm_csr *in_csr, uint64_t 
  * reference's greedy partitioner, crates/builder/src/graph_ops.rs:431-439,479-509); every device gets its rows of
  * the in-CSR, a sweep engine and a replica of out_scores; per sweep: local sweep kernels -> ncclAllGather of the
  * out_scores of the nodes that have out-edges -> the f64 error partials summed in rank order.  Same stop rule and
- * results as gm_page_rank_directed (rows below the hub threshold bit-identical, hub rows to ~1e-6).
+ * results as gm_page_rank_directed — bit-identical: ordinary rows are exactly rounded sums, hub rows the reference's own
+ * left-to-right sums (page_rank.rs:143-146); neither depends on the partition.
  * The exchange travels in K regions (GM_MULTI_PARTS, default 2) on streams of its own, under the work of the other
  * regions; the host synchronises only when the stop rule needs the error (tolerance > 0: every sweep; 0: once).  The
  * partition, slices, engines, streams and communicator of a call are parked in in_csr's handle: a second call with the
@@ -191,6 +192,18 @@ int gm_page_rank_directed(const gm_csr *out_csr, const gm_csr *in_csr, uint64_t 
 int gm_page_rank_multi(const gm_csr *out_csr, const gm_csr *in_csr, const int *devices, uint32_t n_devices,
                        uint64_t max_iterations, double tolerance, float damping_factor, float *scores_out /* n, host */,
                        uint64_t *iterations_out, double *error_out);
+/* The same run from PIECES, for graphs that never sit whole on one device (north_star: "graphs larger than one GPU are 1-D
+ * vertex-range partitioned"): in_slices[p] = the rows [bounds[p], bounds[p + 1]) of the in-CSR, resident on devices[p], with
+ * n_local rows, offsets from 0 and targets as GLOBAL node ids (e.g. gm_csr_build_device over the edges whose destination lies
+ * in the range, then gm_csr_slice_rows); d_out_degree_full[p] = device address, on devices[p], of u32[n]: the out-degree of
+ * EVERY node (pieces built apart get it by summing their histograms: an all-reduce).  bounds: n_devices + 1 ascending row
+ * bounds from 0 to n — the reference's in_degree_partition ranges (graph_ops.rs:431-439,479-509) reproduce gm_page_rank_multi
+ * bit for bit.  Every rank derives the exchange layout on its own device; the inputs are copied, not consumed; nothing is
+ * parked.  (graph_amd/distributed.py: partition_local_slices builds such pieces from the counter-based R-MAT generator.) */
+int gm_page_rank_multi_slices(const gm_csr *const *in_slices, const uint64_t *bounds, const uint64_t *d_out_degree_full,
+                              uint64_t n, const int *devices, uint32_t n_devices, uint64_t max_iterations, double tolerance,
+                              float damping_factor, float *scores_out /* n, host */, uint64_t *iterations_out,
+                              double *error_out);
 
 /* Resident PageRank engine: the per-sweep hot loop (page_rank_iteration, page_rank.rs:113-168)
  * over rows [row_begin, row_begin + n_local) of a graph with n_global nodes.  One engine per
