@@ -39,7 +39,7 @@
 // CSR order of the Sorted / Deduplicated layouts.  Their sums are then COMPUTED the reference's way, bit for bit
 // for the same out_scores (rounds 2 and 3 imitated the order with integer counts of ulps per 4096-entry step,
 // within ~3e-6 and at the price of as many vector instructions as the accumulate kernel itself):
-//   pb_hubseq_kernel   rows below `hub_long` terms (8192 or more, see pb_build): a group's 4096-entry blocks are made row-major in LDS by a
+//   pb_hubseq_kernel   rows below `hub_long` terms (8192 or more, see pb_build): a group's 2048-entry blocks are made row-major in LDS by a
 //                      permutation fixed at plan time, and lane g of one wavefront adds row g's terms in order,
 //                      one v_add_f32 per term;
 //   pb_hublong_kernel  longer rows, one workgroup each: inside one binade of the running sum S = J ulp, adding a term
@@ -77,10 +77,14 @@ constexpr uint16_t PB_HUBROW = 0xFFFEu; // cidx of a hub row: its sum is produce
 constexpr uint16_t PB_FLAG = 0x8000u;
 constexpr uint32_t PB_SEQ_WG = 256;  // threads of a pb_hubseq_kernel workgroup (wavefront 0 walks, all four stage)
 constexpr uint32_t PB_SEQ_PAD = 16;  // a row's stretch of the staged block is padded to 16 floats (4 x ds_read_b128 per step)
-constexpr uint32_t PB_SEQ_BUF = PB_ACC_BLOCK * PB_VEC + PB_HUB_MAX * (PB_SEQ_PAD - 1); // floats: 4096 terms + the rows' padding
-constexpr size_t PB_SEQ_LDS = 20480; // static LDS of pb_hubseq_kernel, rounded up
+constexpr uint32_t PB_SEQ_STEP = 2048; // entries of a block of pb_hubseq_kernel
+constexpr uint32_t PB_SEQ_BUF = PB_SEQ_STEP + PB_HUB_MAX * (PB_SEQ_PAD - 1); // floats: 2048 terms + the rows' padding (12 KiB)
+// LDS left free beside an accumulate workgroup: ONE pb_hubseq_kernel workgroup (12.1 KiB) AND one pb_hublong_kernel workgroup
+// (9.3 KiB).  With room for only one of the two (20 KiB blocks / an 18 KiB turning buffer, the first version) the long rows
+// waited for the lane walks to leave the CUs: at scale 22 the hub phase was 67 + 55 us instead of max(67, 55).
+constexpr size_t PB_HUB_ROOM = 22016;
 constexpr uint32_t PB_LONG_WG = 512;  // threads of a pb_hublong_kernel workgroup
-constexpr uint32_t PB_LONG_PER = 32;  // consecutive terms per thread and pass
+constexpr uint32_t PB_LONG_PER = 16;  // consecutive terms per thread and pass (32: 174 VGPRs — no room beside the accumulate wavefronts)
 constexpr int PB_TIERS_DEFAULT = 16;  // at most this many tiers of hot sources unless GM_PB_TIERS says otherwise
 constexpr float PB_FIX_SCALE = 4611686018427387904.0f;     // 2^62
 constexpr float PB_FIX_INV = 2.168404344971008868e-19f;    // 2^-62
@@ -164,7 +168,7 @@ struct PbPlan {
     std::vector<uint32_t> hub_first_host;
     std::vector<uint8_t> hub_long_host; // per group: 1 = one long row
     // the other hub groups, hub_items[G_long .. G): walked by pb_hubseq_kernel with one lane per row.  Their part of p2_dst
-    // holds, instead of the row slot, the entry's place in the row-major LDS arrangement of its 4096-entry block
+    // holds, instead of the row slot, the entry's place in the row-major LDS arrangement of its 2048-entry block
     // (pb_hubseq_layout_kernel).
     uint32_t seq_blocks = 0;
     DevBuf seq_blk_first;  // u32[G - G_long + 1] first block of each such group, in hub_items order
@@ -1128,17 +1132,17 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
 // counts of ulps per 4096-entry step (pb_hub_kernel: ~300 wavefront instructions per step on sixteen wavefronts — measured
 // in round 4, profiles/r04_accum_corun_ab.txt: as many vector instructions as the accumulate kernel itself for 22 % of the
 // edges).  Here the sum is simply COMPUTED that way.  Rows below hub_long terms: a group's stream is sorted by source with
-// its rows interleaved, so at plan time every 4096-entry block gets a stable permutation that makes it row-major
+// its rows interleaved, so at plan time every 2048-entry block gets a stable permutation that makes it row-major
 // (pb_hubseq_layout_kernel: p2_dst holds the entry's place in the block's LDS arrangement, `rows` the first place and the
 // number of terms of every row), and per block the workgroup's four wavefronts scatter the values into LDS while lane g
 // of wavefront 0 adds row g's terms in order: S = S + v, one v_add_f32 per term.  The sum is the reference's bit for bit
 // for the same out_scores, whatever the partition.  What stays serial is the chain of a row's adds (~5 cycles per term):
 // longer rows go to pb_hublong_kernel below.
-__global__ __launch_bounds__(PB_ACC_BLOCK) void pb_hubseq_layout_kernel(const PbHubItem *__restrict__ items,
+__global__ __launch_bounds__(PB_SEQ_STEP / PB_VEC) void pb_hubseq_layout_kernel(const PbHubItem *__restrict__ items,
                                                                          const uint32_t *__restrict__ blk_first, uint32_t n_groups,
                                                                          uint16_t *__restrict__ p2_dst, uint32_t *__restrict__ rows)
 {
-    constexpr uint32_t STEP = PB_ACC_BLOCK * PB_VEC, NWV = PB_ACC_BLOCK / kWave, NONE = PB_HUB_MAX;
+    constexpr uint32_t STEP = PB_SEQ_STEP, THREADS = STEP / PB_VEC, NWV = THREADS / kWave, NONE = PB_HUB_MAX;
     __shared__ uint32_t hist[NWV][PB_HUB_MAX + 1]; // terms of every row per wavefront, then their exclusive prefix
     __shared__ uint32_t rbase[PB_HUB_MAX + 1];
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
@@ -1147,7 +1151,7 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_hubseq_layout_kernel(const Pb
     const PbHubItem item = items[g];
     const uint32_t q0 = item.q0 + (blockIdx.x - blk_first[g]) * STEP;
     const uint32_t q1 = (item.q1 - q0) < STEP ? item.q1 : q0 + STEP;
-    for (uint32_t i = tid; i < NWV * (PB_HUB_MAX + 1); i += PB_ACC_BLOCK)
+    for (uint32_t i = tid; i < NWV * (PB_HUB_MAX + 1); i += THREADS)
         (&hist[0][0])[i] = 0u;
     __syncthreads();
     const uint32_t q = q0 + tid * PB_VEC;
@@ -1225,7 +1229,7 @@ __global__ __launch_bounds__(PB_SEQ_WG) void pb_hubseq_kernel(const float *__res
                                                               float *__restrict__ x_out, double *__restrict__ group_err, float base,
                                                               float damping)
 {
-    constexpr uint32_t STEP = PB_ACC_BLOCK * PB_VEC;            // entries of a block
+    constexpr uint32_t STEP = PB_SEQ_STEP;                      // entries of a block
     constexpr int PER = (int)(STEP / (PB_SEQ_WG * PB_VEC));     // float4 + 4 places per thread and block
     __shared__ __attribute__((aligned(16))) float buf[PB_SEQ_BUF + 4]; // + where the padding entries of the stream land
     __shared__ double red[PB_SEQ_WG / kWave];
@@ -1365,14 +1369,15 @@ __global__ __launch_bounds__(PB_SEQ_WG) void pb_hubseq_kernel(const float *__res
 // unless t ends in exactly .5, where the result is the EVEN one of J + floor(t) and J + floor(t) + 1: it depends on J only
 // through its parity.  So a run of terms acts on J as (count added when the run starts on an even J, count added when it
 // starts on an odd J), and two runs compose into such a pair again — an associative operation, hence a scan:
-//   every thread takes 32 consecutive terms and forms its pair (one pass over the terms when none of them is a tie);
+//   every thread takes 16 consecutive terms and forms its pair (one pass over the terms when none of them is a tie);
 //   an exclusive scan over the workgroup gives every thread the J its run starts from;
 //   the first thread whose run ends at or beyond 2^24 — S leaves the binade there — starts from an exactly known S and
-//   adds its 32 terms with v_add_f32, one after the other; everything behind it is redone on the new grid.
+//   adds its 16 terms with v_add_f32, one after the other; everything behind it is redone on the new grid.
 // S leaves a binade a few dozen times per row (and at every doubling of the first few thousand terms), so a super-block of
-// 16384 terms costs one pass (one barrier), sometimes two.  Bit for bit the reference's sum: tests/test_gpu_hub_adversarial.py compares
+// 8192 terms costs one pass (one barrier), sometimes two.  Bit for bit the reference's sum: tests/test_gpu_hub_adversarial.py compares
 // rows of up to 2^20 + 1 terms with orc_page_rank_jacobi_sweep's sequential sums for equality.
-__global__ __launch_bounds__(PB_LONG_WG) void pb_hublong_kernel(const float *__restrict__ vals, const uint16_t *__restrict__ p2_dst,
+// (at most 96 VGPRs: two of its wavefronts, one of pb_hubseq_kernel's and four of the accumulate kernel's share a SIMD's 512)
+__global__ __launch_bounds__(PB_LONG_WG) __attribute__((amdgpu_waves_per_eu(5, 8))) void pb_hublong_kernel(const float *__restrict__ vals, const uint16_t *__restrict__ p2_dst,
                                                                 const PbHubItem *__restrict__ items,
                                                                 const uint32_t *__restrict__ hub_rows,
                                                                 const uint32_t *__restrict__ outdeg, float *__restrict__ scores,
@@ -1380,14 +1385,15 @@ __global__ __launch_bounds__(PB_LONG_WG) void pb_hublong_kernel(const float *__r
                                                                 float damping)
 {
     constexpr uint32_t NWV = PB_LONG_WG / kWave, PER = PB_LONG_PER, SUPER = PB_LONG_WG * PER, SAT = 1u << 30, NONE = 0xFFFFFFFFu;
-    constexpr uint32_t WARM = 32; // threads whose terms (the row's first 1024) are added one after the other, see below
+    constexpr uint32_t WARM = 1024 / PER; // threads whose terms (the row's first 1024) are added one after the other, see below
     // per wavefront: its runs composed, the first thread whose run leaves the binade; two copies used in turn: a wavefront
     // that leaves a pass through its single barrier may write the next pass's totals while another still reads these
     __shared__ uint32_t w_a0s[2][NWV], w_a1s[2][NWV], w_firsts[2][NWV];
     __shared__ float s_bcast;
-    constexpr uint32_t TROW = PER + 4; // floats between two threads' rows in the turning buffer
-    __shared__ __attribute__((aligned(16))) float tbuf[(PB_LONG_WG / 4) * TROW];
-    static_assert(PB_LONG_WG == 512 && PB_LONG_PER == 32, "the turning buffer is laid out for 512 threads x 32 terms");
+    constexpr uint32_t TROW = PER + 4;          // floats between two threads' rows in the turning buffer (conflict-free 16-byte reads)
+    constexpr uint32_t TOWN = PB_LONG_WG * 4 / PER; // threads that own the 2048 terms of one round
+    __shared__ __attribute__((aligned(16))) float tbuf[TOWN * TROW]; // 2048 terms of the super-block at a time: 10 KiB
+    static_assert(PB_LONG_WG == 512 && (PB_LONG_PER == 16 || PB_LONG_PER == 32) && WARM <= (uint32_t)kWave, "turning buffer / warm-up layout");
     const PbHubItem item = items[blockIdx.x]; // one row: slot 0 (padding entries: PB_NULL)
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     // (counts from an even / odd start) of run F followed by run G; saturated: beyond the first run that leaves the binade
@@ -1398,40 +1404,44 @@ __global__ __launch_bounds__(PB_LONG_WG) void pb_hublong_kernel(const float *__r
     };
     // The super-block at sb as the memory system likes it: lane-interleaved float4s (a thread reading its own 32 consecutive
     // terms touches a cache line of its own with every load — 64 lines per wavefront instruction, measured ~4 us per
-    // super-block and CU).  Padding entries and what lies behind the row: 0.  w[(2 r + c) 4 ..] = round r, float4 c.
-    auto fetch = [&](uint32_t sb, float(&w)[PER]) {
+    // super-block and CU).  The loaded registers are NOT touched here — the values and their slots stay raw until `turn`
+    // needs them, one pass later: masking the padding entries at once made the loads synchronous (measured with cycle
+    // stamps: 49 % of a row's time was spent "issuing" the next super-block's loads).
+    struct Raw {
+        f32x4 x[PER / 4];
+        u32x2 d[PER / 4];
+    } raw;
+    auto fetch = [&](uint32_t sb) {
 #pragma unroll
         for (uint32_t k = 0; k < PER / 4; ++k) {
             const uint32_t q = sb + (k * PB_LONG_WG + tid) * 4u;
-            w[4 * k] = w[4 * k + 1] = w[4 * k + 2] = w[4 * k + 3] = 0.0f;
+            raw.d[k].x = raw.d[k].y = 0xFFFFFFFFu; // behind the row: padding
+            raw.x[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             if (q < item.q1) {
-                const f32x4 x = *reinterpret_cast<const f32x4 *>(vals + q);
-                const u32x2 d = *reinterpret_cast<const u32x2 *>(p2_dst + q);
-                w[4 * k] = (d.x & 0xFFFFu) == 0u ? x.x : 0.0f;
-                w[4 * k + 1] = (d.x >> 16) == 0u ? x.y : 0.0f;
-                w[4 * k + 2] = (d.y & 0xFFFFu) == 0u ? x.z : 0.0f;
-                w[4 * k + 3] = (d.y >> 16) == 0u ? x.w : 0.0f;
+                raw.x[k] = *reinterpret_cast<const f32x4 *>(vals + q);
+                raw.d[k] = *reinterpret_cast<const u32x2 *>(p2_dst + q);
             }
         }
     };
-    // ... and turned, a quarter (4096 terms) at a time through 18 KiB of LDS, into 32 CONSECUTIVE terms per thread: the 128
-    // threads that own the quarter read their rows (36 floats apart: conflict-free 16-byte reads)
-    auto turn = [&](const float(&w)[PER], float(&out)[PER]) {
+    // ... and turned, 2048 terms at a time through 10 KiB of LDS, into PER CONSECUTIVE terms per thread (padding entries —
+    // slot PB_NULL instead of 0 — become 0): the threads that own the round's terms read their rows.  raw.x[r] = round r.
+    auto turn = [&](float(&out)[PER]) {
 #pragma unroll
-        for (uint32_t r = 0; r < 4; ++r) {
-#pragma unroll
-            for (uint32_t c = 0; c < 2; ++c) {
-                const uint32_t i = (c * PB_LONG_WG + tid) * 4u, k = 2 * r + c; // place inside the quarter
-                f32x4 x;
-                x.x = w[4 * k], x.y = w[4 * k + 1], x.z = w[4 * k + 2], x.w = w[4 * k + 3];
-                *reinterpret_cast<f32x4 *>(tbuf + (i >> 5) * TROW + (i & 31u)) = x;
-            }
+        for (uint32_t r = 0; r < PER / 4; ++r) {
+            const uint32_t i = tid * 4u; // place inside the round's 2048 terms
+            f32x4 x = raw.x[r];
+            const u32x2 d = raw.d[r];
+            x.x = (d.x & 0xFFFFu) == 0u ? x.x : 0.0f;
+            x.y = (d.x >> 16) == 0u ? x.y : 0.0f;
+            x.z = (d.y & 0xFFFFu) == 0u ? x.z : 0.0f;
+            x.w = (d.y >> 16) == 0u ? x.w : 0.0f;
+            *reinterpret_cast<f32x4 *>(tbuf + (i / PER) * TROW + (i % PER)) = x;
             lds_barrier();
-            if ((tid >> 7) == r) {
+            if (tid / TOWN == r) {
 #pragma unroll
                 for (uint32_t k = 0; k < PER / 4; ++k) {
-                    const f32x4 x = *reinterpret_cast<const f32x4 *>(tbuf + (tid & 127u) * TROW + 4 * k);
-                    out[4 * k] = x.x, out[4 * k + 1] = x.y, out[4 * k + 2] = x.z, out[4 * k + 3] = x.w;
+                    const f32x4 y = *reinterpret_cast<const f32x4 *>(tbuf + (tid % TOWN) * TROW + 4 * k);
+                    out[4 * k] = y.x, out[4 * k + 1] = y.y, out[4 * k + 2] = y.z, out[4 * k + 3] = y.w;
                 }
             }
             lds_barrier();
@@ -1439,17 +1449,17 @@ __global__ __launch_bounds__(PB_LONG_WG) void pb_hublong_kernel(const float *__r
     };
     float S = 0.0f; // page_rank.rs:143
     uint32_t flip = 0;
-    float v[PER], vn[PER];
-    fetch(item.q0, vn);
+    float v[PER];
+    fetch(item.q0);
     for (uint32_t sb = item.q0; sb < item.q1; sb += SUPER) {
-        turn(vn, v);
+        turn(v);
         if (item.q1 - sb > SUPER) // the next super-block's terms travel while this one's are added (every barrier below waits
-            fetch(sb + SUPER, vn); // for LDS traffic only: __syncthreads() would wait for these loads as well)
+            fetch(sb + SUPER);     // for LDS traffic only: __syncthreads() would wait for these loads as well)
         uint32_t done = 0; // threads below `done` have had their terms added
         if (sb == item.q0) {
             // The row's first terms: a sum that starts at zero doubles after 2, 4, 8, ... terms, and every doubling would
-            // be a pass of its own.  The first 32 threads' terms (1024) are simply added in order by wavefront 0, the sum
-            // handed from lane to lane: ~170 cycles per thread instead of a pass of the whole workgroup per doubling.
+            // be a pass of its own.  The first 64 threads' terms (1024) are simply added in order by wavefront 0, the sum
+            // handed from lane to lane: ~100 cycles per thread instead of a pass of the whole workgroup per doubling.
             if (wave == 0) {
                 float s = 0.0f;
                 for (uint32_t k = 0; k < WARM; ++k) {
@@ -1490,7 +1500,7 @@ __global__ __launch_bounds__(PB_LONG_WG) void pb_hublong_kernel(const float *__r
                         sum += (uint32_t)r;
                         tie |= __builtin_fabsf(t - r) == 0.5f; // t - r is exact
                     }
-                    a0 = a1 = sum; // <= 32 x 2^24 < SAT
+                    a0 = a1 = sum; // <= PER x 2^24 < SAT
                     if (tie) { // the two-state walk: a tie goes to the even J
                         uint32_t x0 = 0, x1 = 0, p0 = 0, p1 = 1;
 #pragma unroll 4
@@ -1732,7 +1742,7 @@ int pb_make_items(PbPlan *pl)
     // blocks of the groups pb_hubseq_kernel walks
     std::vector<uint32_t> sfirst(pl->G - pl->G_long + 1, 0u);
     for (uint32_t g = pl->G_long; g < pl->G; ++g)
-        sfirst[g - pl->G_long + 1] = sfirst[g - pl->G_long] + (hubs[g].q1 - hubs[g].q0 + PB_ACC_BLOCK * PB_VEC - 1) / (PB_ACC_BLOCK * PB_VEC);
+        sfirst[g - pl->G_long + 1] = sfirst[g - pl->G_long] + (hubs[g].q1 - hubs[g].q0 + PB_SEQ_STEP - 1) / PB_SEQ_STEP;
     pl->seq_blocks = sfirst.back();
     GM_TRY(pl->seq_blk_first.alloc(sfirst.size() * 4));
     GM_HIP(hipMemcpy(pl->seq_blk_first.p, sfirst.data(), sfirst.size() * 4, hipMemcpyHostToDevice));
@@ -1889,8 +1899,8 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
         if (pb_env("GM_PB_WGS", 0) == 1 || (pb_env("GM_PB_WGS", 0) == 0 && acc_bytes > 32768))
             wgs = 1;
         // static LDS of the accumulate kernel: PB_ACC_STATIC; with hub groups, room for one pb_hubseq_kernel workgroup
-        // (20 KiB) beside the accumulate workgroup(s) of a CU
-        size_t hub_room = (pl->G && pb_env("GM_PB_HUB_FORK", 1)) ? PB_SEQ_LDS : 0;
+        // and one pb_hublong_kernel workgroup (21.5 KiB together) beside the accumulate workgroup(s) of a CU
+        size_t hub_room = (pl->G && pb_env("GM_PB_HUB_FORK", 1)) ? PB_HUB_ROOM : 0;
         if (pb_env("GM_PB_HUB_ROOM", -1) >= 0) // measurement: LDS left free beside an accumulate workgroup
             hub_room = (size_t)pb_env("GM_PB_HUB_ROOM", -1);
         const size_t budget = wgs == 1 ? (163840 - hub_room - PB_ACC_STATIC - acc_bytes)
@@ -2182,7 +2192,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     GM_TRY(pb_make_items(pl));
     if (pl->seq_blocks) { // row-major places of the hub groups walked by pb_hubseq_kernel
         GM_TRY(pl->seq_rows.alloc((size_t)pl->seq_blocks * PB_HUB_MAX * 4));
-        hipLaunchKernelGGL(pb_hubseq_layout_kernel, dim3(pl->seq_blocks), dim3(PB_ACC_BLOCK), 0, 0,
+        hipLaunchKernelGGL(pb_hubseq_layout_kernel, dim3(pl->seq_blocks), dim3(PB_SEQ_STEP / PB_VEC), 0, 0,
                            pl->hub_items.as<PbHubItem>() + pl->G_long, pl->seq_blk_first.as<uint32_t>(), pl->G - pl->G_long,
                            pl->p2_dst.as<uint16_t>(), pl->seq_rows.as<uint32_t>());
         GM_HIP(hipGetLastError());
