@@ -425,7 +425,7 @@ def main():
             "plan_build_ms": round(plan["plan_build_us"] / 1e3, 2) if plan else None, "plan_rebuild_ms": plan_rebuild_ms,
             "plan_bytes": plan.get("plan_bytes") if plan else None, "scratch_bytes": plan.get("scratch_bytes") if plan else None,
             "hub_rows_in_reference_order": {k: plan[k] for k in ("hub_in_degree", "hub_rows", "hub_edges", "hub_groups", "long_rows",
-                                                               "long_row_terms", "hub_seq_blocks")} if plan else None,
+                                                               "long_row_terms", "hub_seq_blocks", "hub_hot_edges")} if plan else None,
             "hot_sources": plan.get("hot_sources") if plan else None, "hot_tiers": plan.get("hot_tiers") if plan else None,
             "hot_edges": plan.get("hot_edges") if plan else None, "value_entries": plan.get("value_entries") if plan else None,
             "value_stream_placement": _placement(plan, engine, scale) if plan else None,

@@ -7,7 +7,7 @@
 // random 4-byte accesses fast enough, so the sweep is restructured so that every random access
 // lands in LDS and everything that touches HBM is a sequential stream:
 //
-//   pb_bin_kernel    one workgroup per chunk (32768 entries) of a SOURCE TILE (2^s_log = 16384 or 32768
+//   pb_bin_kernel    one workgroup per chunk (24576 entries) of a SOURCE TILE (2^s_log = 16384 or 32768
 //                    consecutive ids of x): the tile's out_scores are loaded into LDS (64 / 128 KiB,
 //                    coalesced); the tile's edges — stored once, at plan creation, as 2-byte local source
 //                    ids grouped by destination bin — are streamed and each edge's value xs[src] is
@@ -77,7 +77,9 @@ constexpr uint16_t PB_HUBROW = 0xFFFEu; // cidx of a hub row: its sum is produce
 constexpr uint16_t PB_FLAG = 0x8000u;
 constexpr uint32_t PB_SEQ_WG = 256;  // threads of a pb_hubseq_kernel workgroup (wavefront 0 walks, all four stage)
 constexpr uint32_t PB_SEQ_PAD = 16;  // a row's stretch of the staged block is padded to 16 floats (4 x ds_read_b128 per step)
-constexpr uint32_t PB_SEQ_STEP = 2048; // entries of a block of pb_hubseq_kernel
+constexpr uint32_t PB_SEQ_STEP = 2048; // entries of a block of pb_hubseq_kernel: what one round of loads covers
+constexpr uint32_t PB_SEQ_CAP = 2040;  // terms of a block (its stretch of the value stream may start 3 entries into a float4)
+constexpr uint32_t PB_SEQ_HOT = 4;     // hot records per thread and block that travel through the prefetch registers
 constexpr uint32_t PB_SEQ_BUF = PB_SEQ_STEP + PB_HUB_MAX * (PB_SEQ_PAD - 1); // floats: 2048 terms + the rows' padding (12 KiB)
 // LDS left free beside an accumulate workgroup: ONE pb_hubseq_kernel workgroup (12.1 KiB) AND one pb_hublong_kernel workgroup
 // (9.3 KiB).  With room for only one of the two (20 KiB blocks / an 18 KiB turning buffer, the first version) the long rows
@@ -167,12 +169,19 @@ struct PbPlan {
     uint64_t long_terms = 0;   // in-edges of the long rows
     std::vector<uint32_t> hub_first_host;
     std::vector<uint8_t> hub_long_host; // per group: 1 = one long row
+    std::vector<PbHubItem> hub_items_host;
     // the other hub groups, hub_items[G_long .. G): walked by pb_hubseq_kernel with one lane per row.  Their part of p2_dst
     // holds, instead of the row slot, the entry's place in the row-major LDS arrangement of its 2048-entry block
     // (pb_hubseq_layout_kernel).
     uint32_t seq_blocks = 0;
     DevBuf seq_blk_first;  // u32[G - G_long + 1] first block of each such group, in hub_items order
     DevBuf seq_rows;       // u32[seq_blocks x 64] per block and row: first LDS slot << 16 | terms of the row in this block
+    // ... and their terms from HOT sources do not pass the value stream at all (12 B per edge): a block is PB_SEQ_CAP consecutive
+    // entries of the group's terms in source order, cold ones (a stretch of the value stream, padding included) and hot ones
+    // (4-byte records: place << 18 | hot rank, the value gathered from hot_x) merged
+    DevBuf seq_blk;        // uint4[seq_blocks]: {first, end of the block's stretch of the value stream, first, end of its hot records}
+    DevBuf hh_ent;         // u32[Mhh] hot records of the hub groups, block-major
+    uint64_t Mhh = 0;
     double build_ms = 0.0; // wall time of pb_build (device work included)
     uint32_t NT = 0;       // source tiles
     uint32_t NS = 0;       // non-empty (tile, bin) segments
@@ -228,16 +237,19 @@ namespace {
 // 2^fshift consecutive sources, set when one of them is hot.  It answers "not hot" for most edges without leaving the
 // CU; only the rest look their source up in the rank table (134 MB at scale 26 — a random 2-byte gather per edge
 // from that table was most of this kernel's time).
+// hh_bit != 0 (a hub row walked by pb_hubseq_kernel): an edge from a hot source keeps its place among the row's edges — the
+// key stays (virtual bin, source) — and only carries the flag (above the slot, in the unsorted bits): it is taken out of the
+// value stream after the sort and becomes a hot record of its block (pb_hubseq_layout_kernel)
 __device__ __forceinline__ uint64_t pb_make_key(uint64_t hi_cold, uint32_t src, int sb, int bb,
                                                 const uint32_t *filter, int fshift,
-                                                const uint32_t *__restrict__ hot_rank)
+                                                const uint32_t *__restrict__ hot_rank, uint64_t hh_bit = 0)
 {
     if (filter) {
         const uint32_t blk = src >> fshift;
         if ((filter[blk >> 5] >> (blk & 31u)) & 1u) {
             const uint32_t h = hot_rank[src];
             if (h != 0xFFFFFFFFu)
-                return hi_cold | (1ull << (sb + bb)) | h;
+                return hh_bit ? (hi_cold | hh_bit | src) : (hi_cold | (1ull << (sb + bb)) | h);
         }
     }
     return hi_cold | src;
@@ -407,6 +419,7 @@ __global__ __launch_bounds__(PB_KEYS_BLOCK) void pb_keys_kernel(const uint32_t *
                                                                const uint16_t *__restrict__ cidx,
                                                                const uint32_t *__restrict__ pos_h,
                                                                const uint32_t *__restrict__ hub_first, uint32_t B, uint32_t G,
+                                                               const uint32_t *__restrict__ group_long, uint64_t hh_bit,
                                                                uint64_t *__restrict__ keys)
 {
     extern __shared__ uint32_t pb_filter[];
@@ -428,11 +441,13 @@ __global__ __launch_bounds__(PB_KEYS_BLOCK) void pb_keys_kernel(const uint32_t *
         uint32_t vbin = r >> rb;
         const uint32_t len = e - s;
         const bool hub = r < n && len && slot == PB_HUBROW;
+        int hot_hub = 0; // a hub row whose hot terms leave the value stream (not a long row, and the plan wants it: hh_bit)
         if (hub) { // virtual bin B + group, slot = position inside the group
             const uint32_t i = pos_h[r];
             const uint32_t g = (uint32_t)lower_bound_fn(0, G + 1, (uint64_t)i + 1, [&](uint64_t k) { return (uint64_t)hub_first[k]; }) - 1u;
             vbin = B + g;
             slot = i - hub_first[g];
+            hot_hub = hh_bit && !group_long[g] ? 1 : 0;
         }
         const uint64_t hi = ((uint64_t)(slot & rmask) << (sb + bb + 1)) | ((uint64_t)vbin << sb);
         if (len <= 32)
@@ -445,6 +460,7 @@ __global__ __launch_bounds__(PB_KEYS_BLOCK) void pb_keys_kernel(const uint32_t *
             const uint32_t bs = __shfl(s, src, kWave), be = __shfl(e, src, kWave);
             const uint64_t bhi = __shfl(hi, src, kWave);
             const bool bhub = __shfl((int)hub, src, kWave) != 0;
+            const uint64_t bhh = __shfl(hot_hub, src, kWave) ? hh_bit : 0ull;
             // four loads in flight per lane: one at a time left the long rows (most of the edges) waiting on each
             for (uint32_t i = bs + lane; i < be; i += kWave * 4u) {
                 uint32_t t4[4];
@@ -454,7 +470,7 @@ __global__ __launch_bounds__(PB_KEYS_BLOCK) void pb_keys_kernel(const uint32_t *
 #pragma unroll
                 for (uint32_t q = 0; q < 4u; ++q)
                     if (i + q * kWave < be)
-                        keys[i + q * kWave] = pb_make_key(bhi, t4[q], sb, bb, bhub ? nullptr : filter, fshift, hot_rank);
+                        keys[i + q * kWave] = pb_make_key(bhi, t4[q], sb, bb, (bhub && !bhh) ? nullptr : filter, fshift, hot_rank, bhh);
             }
         }
     }
@@ -575,7 +591,8 @@ __global__ void pb_seg_layout_kernel(const uint64_t *__restrict__ segkey_sorted,
 __global__ void pb_fill_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ segid_incl,
                                const uint32_t *__restrict__ vstart, const uint32_t *__restrict__ vstart4,
                                const uint32_t *__restrict__ rank_of, const uint32_t *__restrict__ pstart, uint32_t m,
-                               int bb, int sb, int s_log, uint16_t *__restrict__ p1_src, uint16_t *__restrict__ p2_dst)
+                               int bb, int sb, int s_log, uint16_t *__restrict__ p1_src, uint16_t *__restrict__ p2_dst,
+                               uint32_t *__restrict__ hubsrc, uint32_t hub_q0)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < m; q += stride) {
@@ -586,7 +603,25 @@ __global__ void pb_fill_kernel(const uint64_t *__restrict__ keys, const uint32_t
         const uint32_t src = (uint32_t)(k & ((1ull << sb) - 1ull));
         p1_src[p] = (uint16_t)((src & ((1u << s_log) - 1u)) | (q == vs ? PB_FLAG : 0));
         p2_dst[vstart4[j] + (q - vs)] = (uint16_t)(k >> (sb + bb + 1));
+        if (hubsrc && vstart4[j] >= hub_q0) // a hub group's entry (the hub groups are the stream's last bins): its source
+            hubsrc[vstart4[j] + (q - vs) - hub_q0] = src;
     }
+}
+
+// padding entries of the hub groups' part of the stream (0xFFFFFFFF after the fill) take the source of the entry before them:
+// the part reads as a non-decreasing sequence per group, which is what the merge with the hot records goes by
+__global__ void pb_hubsrc_pad_kernel(uint32_t *__restrict__ hubsrc, uint32_t count)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride)
+        if (hubsrc[i] == 0xFFFFFFFFu) {
+            uint32_t j = i;
+            while (j > 0 && hubsrc[j - 1] == 0xFFFFFFFFu)
+                --j;
+            // (a padding run is at most 3 + 255 entries; other threads may be filling it from the same source meanwhile: same value)
+            const uint32_t v = j > 0 ? hubsrc[j - 1] : 0u;
+            hubsrc[i] = v == 0xFFFFFFFFu ? 0u : v;
+        }
 }
 
 // GM_PB_BIN_GAP (measurement): a pseudo-random run of unused entries (multiple of 4, below `max_gap`) behind every bin's
@@ -1138,39 +1173,117 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
 // of wavefront 0 adds row g's terms in order: S = S + v, one v_add_f32 per term.  The sum is the reference's bit for bit
 // for the same out_scores, whatever the partition.  What stays serial is the chain of a row's adds (~5 cycles per term):
 // longer rows go to pb_hublong_kernel below.
-__global__ __launch_bounds__(PB_SEQ_STEP / PB_VEC) void pb_hubseq_layout_kernel(const PbHubItem *__restrict__ items,
-                                                                         const uint32_t *__restrict__ blk_first, uint32_t n_groups,
-                                                                         uint16_t *__restrict__ p2_dst, uint32_t *__restrict__ rows)
+// per group of pb_hubseq_kernel (hub_items order): where its stretch of hubsrc / of the sorted hot-hub keys / of hh_ent begins
+struct PbSeqGroup {
+    uint32_t q0, q1;     // its part of the value stream
+    uint32_t hk0, hk1;   // its hot-hub keys (sorted by source)
+    uint32_t ent0;       // its first hot record
+    uint32_t blk0, nblk; // its blocks
+    uint32_t nh;         // rows
+};
+
+// Block b of a group = the entries [b CAP, (b + 1) CAP) of the group's terms in source order, cold ones (positions of the value
+// stream, padding entries counted: they read as the source before them) and hot ones merged — a merge-path split per block
+// boundary: how many of the first R entries are cold.  A source is hot or cold for all its edges, so no two entries of the two
+// lists compare equal.
+__device__ __forceinline__ uint32_t pb_seq_split(const uint32_t *__restrict__ csrc, uint32_t nc, const uint64_t *__restrict__ hk,
+                                                 uint32_t nhot, uint64_t smask, uint32_t R)
+{
+    uint32_t lo = R > nhot ? R - nhot : 0u, hi = R < nc ? R : nc;
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1); // candidates: mid cold entries, R - mid hot ones
+        // cold[mid] belongs to the first R entries iff it lies before hot[R - mid - 1]
+        if (csrc[mid] < (uint32_t)(hk[R - mid - 1u] & smask))
+            lo = mid + 1u;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+__global__ void pb_hubseq_blocks_kernel(const PbSeqGroup *__restrict__ groups, uint32_t n_groups, uint32_t n_blocks,
+                                        const uint32_t *__restrict__ hubsrc, uint32_t hub_q0, const uint64_t *__restrict__ hk,
+                                        uint64_t smask, uint4 *__restrict__ blk)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blocks)
+        return;
+    const uint32_t g = (uint32_t)lower_bound_fn(0, n_groups, (uint64_t)b + 1, [&](uint64_t k) { return (uint64_t)groups[k].blk0 + groups[k].nblk; });
+    const PbSeqGroup gr = groups[g];
+    const uint32_t nc = gr.q1 - gr.q0, nhot = gr.hk1 - gr.hk0, total = nc + nhot;
+    const uint32_t *cs = hubsrc + (gr.q0 - hub_q0);
+    const uint64_t *hs = hk + gr.hk0;
+    const uint32_t k = b - gr.blk0;
+    const uint32_t R0 = k * PB_SEQ_CAP < total ? k * PB_SEQ_CAP : total, R1 = (k + 1u) * PB_SEQ_CAP < total ? (k + 1u) * PB_SEQ_CAP : total;
+    const uint32_t i0 = pb_seq_split(cs, nc, hs, nhot, smask, R0), i1 = pb_seq_split(cs, nc, hs, nhot, smask, R1);
+    blk[b] = make_uint4(gr.q0 + i0, gr.q0 + i1, gr.ent0 + (R0 - i0), gr.ent0 + (R1 - i1));
+}
+
+// One workgroup per block: the places of the block's terms in its row-major LDS arrangement.  Merged index of a cold entry =
+// its index among the cold ones + the hot sources before it (a search in LDS), of a hot one likewise; then the stable rank of
+// every entry among its row's entries in merged order (7-bit ballots per wavefront, wavefronts through a histogram), rows
+// padded to 16 floats.  p2_dst: the place of every cold entry (PB_NULL: padding); hh_ent: place << 18 | hot rank.
+__global__ __launch_bounds__(PB_SEQ_STEP / PB_VEC) void pb_hubseq_layout_kernel(const PbSeqGroup *__restrict__ groups, uint32_t n_groups,
+                                                                               const uint4 *__restrict__ blk,
+                                                                               const uint32_t *__restrict__ hubsrc, uint32_t hub_q0,
+                                                                               const uint64_t *__restrict__ hk, uint64_t smask, int slot_shift,
+                                                                               uint32_t slot_mask, const uint32_t *__restrict__ hot_rank,
+                                                                               uint16_t *__restrict__ p2_dst, uint32_t *__restrict__ hh_ent,
+                                                                               uint32_t *__restrict__ rows)
 {
     constexpr uint32_t STEP = PB_SEQ_STEP, THREADS = STEP / PB_VEC, NWV = THREADS / kWave, NONE = PB_HUB_MAX;
+    __shared__ uint32_t csrc[STEP], hsrc[STEP];
+    __shared__ uint8_t rowof[STEP];
+    __shared__ uint16_t placeof[STEP];
     __shared__ uint32_t hist[NWV][PB_HUB_MAX + 1]; // terms of every row per wavefront, then their exclusive prefix
     __shared__ uint32_t rbase[PB_HUB_MAX + 1];
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-    // the group of this block: the last g with blk_first[g] <= blockIdx.x
-    const uint32_t g = (uint32_t)lower_bound_fn(0, n_groups + 1, (uint64_t)blockIdx.x + 1, [&](uint64_t k) { return (uint64_t)blk_first[k]; }) - 1u;
-    const PbHubItem item = items[g];
-    const uint32_t q0 = item.q0 + (blockIdx.x - blk_first[g]) * STEP;
-    const uint32_t q1 = (item.q1 - q0) < STEP ? item.q1 : q0 + STEP;
+    const uint32_t g = (uint32_t)lower_bound_fn(0, n_groups, (uint64_t)blockIdx.x + 1, [&](uint64_t k) { return (uint64_t)groups[k].blk0 + groups[k].nblk; });
+    const PbSeqGroup gr = groups[g];
+    const uint4 bk = blk[blockIdx.x];
+    const uint32_t nc = bk.y - bk.x, nhot = bk.w - bk.z; // nc + nhot <= PB_SEQ_CAP
+    const uint64_t *hs = hk + gr.hk0 + (bk.z - gr.ent0);
     for (uint32_t i = tid; i < NWV * (PB_HUB_MAX + 1); i += THREADS)
         (&hist[0][0])[i] = 0u;
-    __syncthreads();
-    const uint32_t q = q0 + tid * PB_VEC;
-    uint32_t s[4] = {NONE, NONE, NONE, NONE};
-    if (q < q1) {
-        const u32x2 raw = *reinterpret_cast<const u32x2 *>(p2_dst + q);
-        const uint32_t v[4] = {raw.x & 0xFFFFu, raw.x >> 16, raw.y & 0xFFFFu, raw.y >> 16};
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            s[k] = v[k] < item.nh ? v[k] : NONE; // padding entries (PB_NULL) keep no place
+    for (uint32_t i = tid; i < STEP; i += THREADS) {
+        csrc[i] = i < nc ? hubsrc[bk.x - hub_q0 + i] : 0xFFFFFFFFu;
+        hsrc[i] = i < nhot ? (uint32_t)(hs[i] & smask) : 0xFFFFFFFFu;
+        rowof[i] = (uint8_t)NONE;
     }
-    // stable rank of an entry among the entries of its row: entries before it in this wavefront (stream order = lane-major)
-    // by matching the 7 bits of the row number against ballots, wavefronts before it through the histogram
+    __syncthreads();
+    // merged index and row of my entries: cold 4 t .. 4 t + 3, hot 4 t .. 4 t + 3
+    uint32_t cmi[4], hmi[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        const uint32_t pc = tid * 4u + k;
+        cmi[k] = 0xFFFFFFFFu, hmi[k] = 0xFFFFFFFFu;
+        if (pc < nc) {
+            const uint32_t slot = p2_dst[bk.x + pc];
+            if (slot < gr.nh) { // a real entry (padding: PB_NULL)
+                const uint32_t before = (uint32_t)lower_bound_fn(0, nhot, (uint64_t)csrc[pc], [&](uint64_t j) { return (uint64_t)hsrc[j]; });
+                cmi[k] = pc + before;
+                rowof[cmi[k]] = (uint8_t)slot;
+            }
+        }
+        if (pc < nhot) {
+            // cold positions (padding included: it reads as the source before it) in front of this hot source
+            const uint32_t before = (uint32_t)lower_bound_fn(0, nc, (uint64_t)hsrc[pc], [&](uint64_t j) { return (uint64_t)csrc[j]; });
+            hmi[k] = pc + before;
+            rowof[hmi[k]] = (uint8_t)((uint32_t)(hs[pc] >> slot_shift) & slot_mask);
+        }
+    }
+    __syncthreads();
+    // stable rank among the entries of the same row, in merged order
+    uint32_t s4[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k)
+        s4[k] = rowof[tid * 4u + k];
     uint64_t bm[4][7];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
         for (int bit = 0; bit < 7; ++bit)
-            bm[k][bit] = __ballot((s[k] >> bit) & 1u);
+            bm[k][bit] = __ballot((s4[k] >> bit) & 1u);
     const uint64_t lt = (1ull << lane) - 1ull;
     uint32_t rank[4];
 #pragma unroll
@@ -1181,12 +1294,12 @@ __global__ __launch_bounds__(PB_SEQ_STEP / PB_VEC) void pb_hubseq_layout_kernel(
             uint64_t m = ~0ull;
 #pragma unroll
             for (int bit = 0; bit < 7; ++bit)
-                m &= ((s[k] >> bit) & 1u) ? bm[k2][bit] : ~bm[k2][bit];
-            c += (uint32_t)__popcll(m & lt) + ((k2 < k && s[k2] == s[k]) ? 1u : 0u);
+                m &= ((s4[k] >> bit) & 1u) ? bm[k2][bit] : ~bm[k2][bit];
+            c += (uint32_t)__popcll(m & lt) + ((k2 < k && s4[k2] == s4[k]) ? 1u : 0u);
         }
         rank[k] = c;
-        if (s[k] != NONE)
-            atomicAdd(&hist[wave][s[k]], 1u);
+        if (s4[k] != NONE)
+            atomicAdd(&hist[wave][s4[k]], 1u);
     }
     __syncthreads();
     if (tid < PB_HUB_MAX) {
@@ -1209,61 +1322,94 @@ __global__ __launch_bounds__(PB_SEQ_STEP / PB_VEC) void pb_hubseq_layout_kernel(
         }
     }
     __syncthreads();
-    if (q < q1) {
-        uint32_t o[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            o[k] = s[k] != NONE ? rbase[s[k]] + hist[wave][s[k]] + rank[k] : (uint32_t)PB_NULL;
-        u32x2 raw;
-        raw.x = o[0] | (o[1] << 16), raw.y = o[2] | (o[3] << 16);
-        *reinterpret_cast<u32x2 *>(p2_dst + q) = raw;
+    for (uint32_t k = 0; k < 4; ++k)
+        if (s4[k] != NONE)
+            placeof[tid * 4u + k] = (uint16_t)(rbase[s4[k]] + hist[wave][s4[k]] + rank[k]);
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        const uint32_t pc = tid * 4u + k;
+        if (cmi[k] != 0xFFFFFFFFu)
+            p2_dst[bk.x + pc] = placeof[cmi[k]];
+        if (hmi[k] != 0xFFFFFFFFu)
+            hh_ent[bk.z + pc] = ((uint32_t)placeof[hmi[k]] << 18) | hot_rank[hsrc[pc]];
     }
 }
 
 __global__ __launch_bounds__(PB_SEQ_WG) void pb_hubseq_kernel(const float *__restrict__ vals, const uint16_t *__restrict__ p2_dst,
                                                               const PbHubItem *__restrict__ items,
                                                               const uint32_t *__restrict__ blk_first,
-                                                              const uint32_t *__restrict__ rows,
+                                                              const uint4 *__restrict__ blk, const uint32_t *__restrict__ rows,
+                                                              const uint32_t *__restrict__ hh_ent, const float *__restrict__ hot_x,
                                                               const uint32_t *__restrict__ hub_rows,
                                                               const uint32_t *__restrict__ outdeg, float *__restrict__ scores,
                                                               float *__restrict__ x_out, double *__restrict__ group_err, float base,
                                                               float damping)
 {
-    constexpr uint32_t STEP = PB_SEQ_STEP;                      // entries of a block
+    constexpr uint32_t STEP = PB_SEQ_STEP;                      // stream entries one round of loads covers
     constexpr int PER = (int)(STEP / (PB_SEQ_WG * PB_VEC));     // float4 + 4 places per thread and block
+    constexpr int HP = (int)PB_SEQ_HOT;                         // hot records per thread and block in the prefetch registers
     __shared__ __attribute__((aligned(16))) float buf[PB_SEQ_BUF + 4]; // + where the padding entries of the stream land
     __shared__ double red[PB_SEQ_WG / kWave];
     const PbHubItem item = items[blockIdx.x]; // longest groups first
     const uint32_t tid = threadIdx.x, nh = item.nh;
     const bool walker = tid < nh; // nh <= 64: lane g of wavefront 0 owns row g
-    const uint32_t nb = (item.q1 - item.q0 + STEP - 1u) / STEP;
-    const uint32_t *ri = rows + (size_t)blk_first[blockIdx.x] * PB_HUB_MAX;
+    const uint32_t b0 = blk_first[blockIdx.x], nb = blk_first[blockIdx.x + 1] - b0;
+    const uint32_t *ri = rows + (size_t)b0 * PB_HUB_MAX;
+    const uint4 *bt = blk + b0;
     // a block's values and places on their way from memory: two sets, so that block b + 2 is requested before block b is
     // walked (with one block of lookahead a group of many short rows spent its time waiting for the next block: the
-    // latency of a global load under the accumulate kernel's traffic is longer than the walk of ~64 terms per row)
+    // latency of a global load under the accumulate kernel's traffic is longer than the walk of ~32 terms per row).  The
+    // block's stretch of the stream starts anywhere: the loads start at the float4 below it, entries outside [x, y) are dropped.
     struct Staged {
         f32x4 v[PER];
         u32x2 d[PER];
+        uint32_t rec[HP]; // the block's first 1024 hot records: place << 18 | hot rank (0xFFFFFFFF: none)
+        uint4 range;
     } sa, sb;
     auto load = [&](uint32_t b, Staged &st) {
+        st.range = bt[b];
+        const uint32_t qa = st.range.x & ~3u;
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
-            const uint32_t q = item.q0 + b * STEP + ((uint32_t)j * PB_SEQ_WG + tid) * PB_VEC;
+            const uint32_t q = qa + ((uint32_t)j * PB_SEQ_WG + tid) * PB_VEC;
             st.d[j].x = st.d[j].y = 0xFFFFFFFFu;
-            if (q < item.q1) {
+            if (q < st.range.y) {
                 st.v[j] = *reinterpret_cast<const f32x4 *>(vals + q);
                 st.d[j] = *reinterpret_cast<const u32x2 *>(p2_dst + q);
             }
         }
+#pragma unroll
+        for (int k = 0; k < HP; ++k) {
+            const uint32_t h = st.range.z + (uint32_t)k * PB_SEQ_WG + tid;
+            st.rec[k] = h < st.range.w ? hh_ent[h] : 0xFFFFFFFFu;
+        }
     };
-    auto scatter = [&](const Staged &st) { // no branch per term: a padding entry (PB_NULL) goes to the slot behind the buffer
+    // the hot terms' values: gathered from hot_x (300 KB, L2-resident) one round after their records were requested
+    auto gather = [&](const Staged &st, float(&hv)[HP]) {
+#pragma unroll
+        for (int k = 0; k < HP; ++k)
+            hv[k] = st.rec[k] != 0xFFFFFFFFu ? hot_x[st.rec[k] & 0x3FFFFu] : 0.0f;
+    };
+    auto scatter = [&](const Staged &st, const float(&hv)[HP]) { // no branch per term: what is not a term goes to the slot behind the buffer
+        const uint32_t qa = st.range.x & ~3u;
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
+            const uint32_t q = qa + ((uint32_t)j * PB_SEQ_WG + tid) * PB_VEC;
             const uint32_t p0 = st.d[j].x & 0xFFFFu, p1 = st.d[j].x >> 16, p2 = st.d[j].y & 0xFFFFu, p3 = st.d[j].y >> 16;
-            buf[p0 < PB_SEQ_BUF ? p0 : PB_SEQ_BUF] = st.v[j].x;
-            buf[p1 < PB_SEQ_BUF ? p1 : PB_SEQ_BUF] = st.v[j].y;
-            buf[p2 < PB_SEQ_BUF ? p2 : PB_SEQ_BUF] = st.v[j].z;
-            buf[p3 < PB_SEQ_BUF ? p3 : PB_SEQ_BUF] = st.v[j].w;
+            buf[(p0 < PB_SEQ_BUF && q >= st.range.x && q < st.range.y) ? p0 : PB_SEQ_BUF] = st.v[j].x;
+            buf[(p1 < PB_SEQ_BUF && q + 1u >= st.range.x && q + 1u < st.range.y) ? p1 : PB_SEQ_BUF] = st.v[j].y;
+            buf[(p2 < PB_SEQ_BUF && q + 2u >= st.range.x && q + 2u < st.range.y) ? p2 : PB_SEQ_BUF] = st.v[j].z;
+            buf[(p3 < PB_SEQ_BUF && q + 3u >= st.range.x && q + 3u < st.range.y) ? p3 : PB_SEQ_BUF] = st.v[j].w;
+        }
+#pragma unroll
+        for (int k = 0; k < HP; ++k)
+            buf[st.rec[k] != 0xFFFFFFFFu ? (st.rec[k] >> 18) : PB_SEQ_BUF] = hv[k];
+        // a block with more than 1024 hot terms (rare: more than half of its terms): the rest without the pipeline
+        for (uint32_t h = st.range.z + (uint32_t)HP * PB_SEQ_WG + tid; h < st.range.w; h += PB_SEQ_WG) {
+            const uint32_t rec = hh_ent[h];
+            buf[rec >> 18] = hot_x[rec & 0x3FFFFu];
         }
     };
     // zeros behind a row's terms up to its 16-float boundary: the walk adds whole steps (x + 0 = x)
@@ -1275,6 +1421,7 @@ __global__ __launch_bounds__(PB_SEQ_WG) void pb_hubseq_kernel(const float *__res
                 buf[at + j] = 0.0f;
     };
     uint32_t info = 0, info_a = 0, info_b = 0; // row info of the block in the buffer / staged in sa / in sb
+    float hv[HP];
     if (tid < kWave)
         __builtin_amdgcn_s_setprio(3); // the walk is the group's critical path: first in line at its SIMD's issue
     load(0, sa);
@@ -1282,7 +1429,8 @@ __global__ __launch_bounds__(PB_SEQ_WG) void pb_hubseq_kernel(const float *__res
         info = ri[tid];
         pads(info);
     }
-    scatter(sa);
+    gather(sa, hv);
+    scatter(sa, hv);
     if (nb > 1u) {
         load(1u, sa);
         if (walker)
@@ -1299,6 +1447,8 @@ __global__ __launch_bounds__(PB_SEQ_WG) void pb_hubseq_kernel(const float *__res
             if (walker)
                 info_nxt = ri[(size_t)(b + 2u) * PB_HUB_MAX + tid];
         }
+        if (more)
+            gather(cur, hv); // its records arrived during the last round; the values arrive during this walk
         if (walker) {
             uint32_t k = (info >> 16) / 4u;
             const uint32_t end = k + (((info & 0xFFFFu) + PB_SEQ_PAD - 1u) / PB_SEQ_PAD) * (PB_SEQ_PAD / 4u);
@@ -1346,7 +1496,7 @@ __global__ __launch_bounds__(PB_SEQ_WG) void pb_hubseq_kernel(const float *__res
         }
         lds_barrier(); // the walk is over: the buffer may be overwritten
         if (more)
-            scatter(cur);
+            scatter(cur, hv);
         info = info_cur;
         lds_barrier();
     };
@@ -1663,6 +1813,38 @@ int sort_keys_u64(DevBuf &keys, DevBuf &alt, uint64_t count, int begin_bit, int 
     return GM_OK;
 }
 
+struct PbHasBit {
+    uint64_t bit;
+    bool want;
+    __host__ __device__ bool operator()(const uint64_t &k) const { return ((k & bit) != 0) == want; }
+};
+
+// out = the keys of in[0, count) whose `bit` is set (want) / clear, in order; *count_out (device) = how many
+int select_keys_u64(const uint64_t *in, uint64_t *out, uint32_t count, uint64_t bit, bool want, uint32_t *count_out)
+{
+    size_t tmp_bytes = 0;
+    GM_HIP(rocprim::select(nullptr, tmp_bytes, in, out, count_out, (size_t)count, PbHasBit{bit, want}, (hipStream_t)0));
+    DevBuf tmp;
+    GM_TRY(tmp.alloc(tmp_bytes));
+    GM_HIP(rocprim::select(tmp.p, tmp_bytes, in, out, count_out, (size_t)count, PbHasBit{bit, want}, (hipStream_t)0));
+    GM_HIP(hipDeviceSynchronize());
+    return GM_OK;
+}
+
+// *out = the first index whose bin field is >= bin (one thread: a binary search)
+__global__ void pb_first_of_bin_kernel(const uint64_t *__restrict__ keys, uint32_t count, int shift, uint32_t mask, uint32_t bin,
+                                       uint32_t *__restrict__ out)
+{
+    *out = (uint32_t)lower_bound_fn(0, count, (uint64_t)bin, [&](uint64_t i) { return (uint64_t)((uint32_t)(keys[i] >> shift) & mask); });
+}
+
+__global__ void pb_clear_bit_kernel(uint64_t *__restrict__ keys, uint32_t count, uint64_t bit)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride)
+        keys[i] &= ~bit;
+}
+
 // Accumulate work items: one per bin, except that a bin more than twice the average size (a range of
 // rows that attracts a large share of the edges, e.g. degree-sorted ids) is cut into slices so that no
 // workgroup streams more than ~2x the average; longest first.  Built on the host from the B+1 bin
@@ -1739,13 +1921,7 @@ int pb_make_items(PbPlan *pl)
     GM_TRY(pl->hub_items.alloc((hubs.size() ? hubs.size() : 1) * sizeof(PbHubItem)));
     if (!hubs.empty())
         GM_HIP(hipMemcpy(pl->hub_items.p, hubs.data(), hubs.size() * sizeof(PbHubItem), hipMemcpyHostToDevice));
-    // blocks of the groups pb_hubseq_kernel walks
-    std::vector<uint32_t> sfirst(pl->G - pl->G_long + 1, 0u);
-    for (uint32_t g = pl->G_long; g < pl->G; ++g)
-        sfirst[g - pl->G_long + 1] = sfirst[g - pl->G_long] + (hubs[g].q1 - hubs[g].q0 + PB_SEQ_STEP - 1) / PB_SEQ_STEP;
-    pl->seq_blocks = sfirst.back();
-    GM_TRY(pl->seq_blk_first.alloc(sfirst.size() * 4));
-    GM_HIP(hipMemcpy(pl->seq_blk_first.p, sfirst.data(), sfirst.size() * 4, hipMemcpyHostToDevice));
+    pl->hub_items_host = hubs;
     return GM_OK;
 }
 
@@ -2020,6 +2196,18 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     GM_TRY(kalt.alloc_big((size_t)m_all * 8)); // process may need them again (no hipMalloc stall after large frees)
     timer.done("pb plan: - key buffers (2 x %.1f GB)", (double)m_all * 8 / 1e9);
     const int hot_bit = bin_bits + sb; // the flag bit of a hot edge: the highest sorted bit
+    // hub groups walked by pb_hubseq_kernel take their terms from hot sources off the value stream (GM_PB_HUB_HOT=0: not): the
+    // flag of such an edge sits above the slot
+    const bool hub_hot = H && pl->G > 0 && pb_env("GM_PB_HUB_HOT", 1) != 0 && bin_bits + sb + rb + 2 <= 64 && pl->Htot < (1u << 18);
+    const uint64_t hh_bit = hub_hot ? 1ull << (sb + bin_bits + 1 + rb) : 0ull;
+    DevBuf group_long;
+    {
+        std::vector<uint32_t> gl(pl->G ? pl->G : 1, 0u);
+        for (uint32_t g = 0; g < pl->G && g < pl->hub_long_host.size(); ++g)
+            gl[g] = pl->hub_long_host[g] ? 1u : 0u;
+        GM_TRY(group_long.alloc(gl.size() * 4));
+        GM_HIP(hipMemcpy(group_long.p, gl.data(), gl.size() * 4, hipMemcpyHostToDevice));
+    }
     {
         const size_t lds = H ? (size_t)filter_words * 4 : 0;
         GM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pb_keys_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2029,15 +2217,17 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
         hipLaunchKernelGGL(pb_keys_kernel, dim3(kg), dim3(PB_KEYS_BLOCK), lds, 0, csr->offsets, csr->targets, n, rb, sb, bin_bits,
                            H ? hot_blk.as<uint32_t>() : (const uint32_t *)nullptr, H ? filter_words : 0u, fshift,
                            hot_rank.as<uint32_t>(), pl->cidx.as<uint16_t>(), pos_h.as<uint32_t>(), pl->hub_first.as<uint32_t>(),
-                           pl->B, pl->G, keys.as<uint64_t>());
+                           pl->B, pl->G, group_long.as<uint32_t>(), hh_bit, keys.as<uint64_t>());
     }
     GM_HIP(hipGetLastError());
     timer.done("pb plan: - edge keys");
     // the slot sits above the sorted bits (rocPRIM's radix sort was measured 14x slower with a non-zero BEGIN bit at
     // this size, so the unsorted field is at the top, not at the bottom)
     GM_TRY(sort_keys_u64(keys, kalt, m_all, 0, H ? hot_bit + 1 : hot_bit));
-    kalt.release();
-    hot_rank.release();
+    if (!hub_hot) {
+        kalt.release();
+        hot_rank.release(); // (with hub_hot: kept for the hot records of the hub groups, pb_hubseq_layout_kernel)
+    }
     hot_blk.release();
     pos_h.release();
     timer.done("pb plan: edge keys + sort");
@@ -2073,6 +2263,40 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
             GM_HIP(hipDeviceSynchronize());
         }
     }
+    // ---- the hub groups' terms from hot sources leave the value stream: their keys (flag hh_bit, in (group, source) order
+    // among the cold ones) are taken out into `hk`, the others close ranks
+    DevBuf hk;
+    uint32_t mhh = 0;
+    if (hub_hot && m) {
+        DevBuf cnt_dev;
+        GM_TRY(cnt_dev.alloc(2 * 4));
+        // the hub groups are the last (virtual) bins: only the tail of the cold keys, from the first key of bin B on, can
+        // carry the flag — a quarter of the keys at RMAT scale 26
+        hipLaunchKernelGGL(pb_first_of_bin_kernel, dim3(1), dim3(1), 0, 0, keys.as<uint64_t>(), m, sb, (uint32_t)((1ull << bin_bits) - 1ull),
+                           pl->B, cnt_dev.as<uint32_t>() + 1);
+        GM_HIP(hipGetLastError());
+        uint32_t k0 = 0;
+        GM_HIP(hipMemcpy(&k0, cnt_dev.as<uint32_t>() + 1, 4, hipMemcpyDeviceToHost));
+        const uint32_t tail = m - k0;
+        const uint64_t cap = pl->hub_edges - pl->long_terms;
+        GM_TRY(hk.alloc_scratch((size_t)(cap ? cap : 1) * 8));
+        if (tail)
+            GM_TRY(select_keys_u64(keys.as<uint64_t>() + k0, hk.as<uint64_t>(), tail, hh_bit, true, cnt_dev.as<uint32_t>()));
+        if (tail)
+            GM_HIP(hipMemcpy(&mhh, cnt_dev.p, 4, hipMemcpyDeviceToHost));
+        if (mhh == m) { // nothing would be left of the stream (a tiny graph whose every source is hot): they stay in it after all
+            hipLaunchKernelGGL(pb_clear_bit_kernel, dim3(pb_grid(m)), dim3(256), 0, 0, keys.as<uint64_t>(), m, hh_bit);
+            GM_HIP(hipGetLastError());
+            mhh = 0;
+        } else if (mhh) { // the tail's other keys close ranks in place (through kalt: select is not an in-place operation)
+            GM_TRY(select_keys_u64(keys.as<uint64_t>() + k0, kalt.as<uint64_t>(), tail, hh_bit, false, cnt_dev.as<uint32_t>()));
+            GM_HIP(hipMemcpy(keys.as<uint64_t>() + k0, kalt.p, (size_t)(tail - mhh) * 8, hipMemcpyDeviceToDevice));
+            m -= mhh;
+        }
+        kalt.release();
+        timer.done("pb plan: hub groups' hot terms taken out (%u)", mhh);
+    }
+    pl->Mhh = mhh;
     if (m == 0) { // every edge is hot
         GM_TRY(pl->p2_dst.alloc(16));
         GM_HIP(hipMemset(pl->bin_v.p, 0, ((size_t)Bv + 1) * 4));
@@ -2182,26 +2406,85 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     GM_TRY(pl->chunk_seg.alloc(((size_t)Mp / PB_WBLK + 1) * 4));
     GM_HIP(hipMemset(pl->p1_src.p, 0x7F, (size_t)Mp * 2)); // padding: an unflagged id (any source of the tile will do)
     GM_HIP(hipMemset(pl->p2_dst.p, 0xFF, (size_t)Mv * 2));
+    // the sources of the hub groups' stream entries (the stream's last bins): what their blocks are merged by
+    DevBuf hubsrc;
+    uint32_t hub_q0 = Mv;
+    if (pl->G) {
+        GM_HIP(hipMemcpy(&hub_q0, pl->bin_v.as<uint32_t>() + pl->B, 4, hipMemcpyDeviceToHost));
+        GM_TRY(hubsrc.alloc_scratch((size_t)(Mv - hub_q0 + 1) * 4));
+        GM_HIP(hipMemset(hubsrc.p, 0xFF, (size_t)(Mv - hub_q0 + 1) * 4));
+    }
     hipLaunchKernelGGL(pb_fill_kernel, dim3(gm_), dim3(256), 0, 0, keys.as<uint64_t>(), segid.as<uint32_t>(),
                        vstart.as<uint32_t>(), vstart4.as<uint32_t>(), rank_of.as<uint32_t>(), pstart.as<uint32_t>(), m,
-                       bin_bits, sb, pl->s_log, pl->p1_src.as<uint16_t>(), pl->p2_dst.as<uint16_t>());
+                       bin_bits, sb, pl->s_log, pl->p1_src.as<uint16_t>(), pl->p2_dst.as<uint16_t>(),
+                       pl->G ? hubsrc.as<uint32_t>() : (uint32_t *)nullptr, hub_q0);
+    if (pl->G && Mv > hub_q0)
+        hipLaunchKernelGGL(pb_hubsrc_pad_kernel, dim3(pb_grid(Mv - hub_q0)), dim3(256), 0, 0, hubsrc.as<uint32_t>(), Mv - hub_q0);
     hipLaunchKernelGGL(pb_chunk_seg_kernel, dim3(pb_grid(Mp / PB_WBLK + 1)), dim3(256), 0, 0, pstart.as<uint32_t>(), NS,
                        Mp / PB_WBLK + 1, pl->chunk_seg.as<uint32_t>());
     GM_HIP(hipGetLastError());
     timer.done("pb plan: segment layout + stream fill");
     GM_TRY(pb_make_items(pl));
-    if (pl->seq_blocks) { // row-major places of the hub groups walked by pb_hubseq_kernel
-        GM_TRY(pl->seq_rows.alloc((size_t)pl->seq_blocks * PB_HUB_MAX * 4));
-        hipLaunchKernelGGL(pb_hubseq_layout_kernel, dim3(pl->seq_blocks), dim3(PB_SEQ_STEP / PB_VEC), 0, 0,
-                           pl->hub_items.as<PbHubItem>() + pl->G_long, pl->seq_blk_first.as<uint32_t>(), pl->G - pl->G_long,
-                           pl->p2_dst.as<uint16_t>(), pl->seq_rows.as<uint32_t>());
-        GM_HIP(hipGetLastError());
-        timer.done("pb plan: hub groups row-major (%u blocks)", pl->seq_blocks);
+    if (pl->G > pl->G_long) { // the hub groups walked by pb_hubseq_kernel: blocks, places, hot records
+        const uint32_t GS = pl->G - pl->G_long;
+        // where each group's hot-hub keys lie (sorted by (virtual bin, source))
+        std::vector<uint32_t> hk_start((size_t)Bv + 1, 0u);
+        if (mhh) {
+            DevBuf d_start;
+            GM_TRY(d_start.alloc(((size_t)Bv + 1) * 4));
+            hipLaunchKernelGGL(pb_bounds_kernel, dim3(pb_grid(mhh)), dim3(256), 0, 0, hk.as<uint64_t>(), mhh, sb, Bv,
+                               d_start.as<uint32_t>(), (uint32_t)((1ull << bin_bits) - 1ull));
+            GM_HIP(hipGetLastError());
+            GM_HIP(hipMemcpy(hk_start.data(), d_start.p, ((size_t)Bv + 1) * 4, hipMemcpyDeviceToHost));
+        }
+        std::vector<PbSeqGroup> groups(GS);
+        std::vector<uint32_t> sfirst(GS + 1, 0u);
+        uint32_t ent = 0;
+        for (uint32_t i = 0; i < GS; ++i) {
+            const PbHubItem &it = pl->hub_items_host[pl->G_long + i];
+            PbSeqGroup &gr = groups[i];
+            gr.q0 = it.q0, gr.q1 = it.q1, gr.nh = it.nh;
+            gr.hk0 = hk_start[pl->B + it.group], gr.hk1 = hk_start[pl->B + it.group + 1];
+            gr.ent0 = ent;
+            ent += gr.hk1 - gr.hk0;
+            const uint64_t total = (uint64_t)(gr.q1 - gr.q0) + (gr.hk1 - gr.hk0);
+            gr.blk0 = sfirst[i];
+            gr.nblk = (uint32_t)((total + PB_SEQ_CAP - 1) / PB_SEQ_CAP);
+            sfirst[i + 1] = sfirst[i] + gr.nblk;
+        }
+        GM_CHECK(ent == mhh, GM_ERR_INVALID, "pb_build: %u hot terms of hub groups, %u keys taken out", ent, mhh);
+        pl->seq_blocks = sfirst.back();
+        GM_TRY(pl->seq_blk_first.alloc(sfirst.size() * 4));
+        GM_HIP(hipMemcpy(pl->seq_blk_first.p, sfirst.data(), sfirst.size() * 4, hipMemcpyHostToDevice));
+        DevBuf d_groups;
+        GM_TRY(d_groups.alloc(groups.size() * sizeof(PbSeqGroup)));
+        GM_HIP(hipMemcpy(d_groups.p, groups.data(), groups.size() * sizeof(PbSeqGroup), hipMemcpyHostToDevice));
+        GM_TRY(pl->seq_blk.alloc((size_t)(pl->seq_blocks ? pl->seq_blocks : 1) * sizeof(uint4)));
+        GM_TRY(pl->seq_rows.alloc((size_t)(pl->seq_blocks ? pl->seq_blocks : 1) * PB_HUB_MAX * 4));
+        GM_TRY(pl->hh_ent.alloc((size_t)(mhh ? mhh : 1) * 4));
+        if (pl->seq_blocks) {
+            const uint64_t smask = (1ull << sb) - 1ull;
+            hipLaunchKernelGGL(pb_hubseq_blocks_kernel, dim3(div_up(pl->seq_blocks, 256)), dim3(256), 0, 0, d_groups.as<PbSeqGroup>(), GS,
+                               pl->seq_blocks, hubsrc.as<uint32_t>(), hub_q0, hk.as<uint64_t>(), smask, pl->seq_blk.as<uint4>());
+            hipLaunchKernelGGL(pb_hubseq_layout_kernel, dim3(pl->seq_blocks), dim3(PB_SEQ_STEP / PB_VEC), 0, 0, d_groups.as<PbSeqGroup>(), GS,
+                               pl->seq_blk.as<uint4>(), hubsrc.as<uint32_t>(), hub_q0, hk.as<uint64_t>(), smask, sb + bin_bits + 1,
+                               (uint32_t)((1u << rb) - 1u), hot_rank.as<uint32_t>(), pl->p2_dst.as<uint16_t>(),
+                               pl->hh_ent.as<uint32_t>(), pl->seq_rows.as<uint32_t>());
+            GM_HIP(hipGetLastError());
+            GM_HIP(hipDeviceSynchronize());
+        }
+        timer.done("pb plan: hub groups row-major (%u blocks, %u hot records)", pl->seq_blocks, mhh);
     }
-    // phase-1 workgroup list: a tile's stream is cut into chunks of 32768 entries (measured best on
-    // MI355X at scales 22-26: enough workgroups to hide latency, x-tile reloads stay in L2)
+    hubsrc.release();
+    hk.release();
+    hot_rank.release();
+    // phase-1 workgroup list: a tile's stream is cut into chunks of 24576 entries (enough workgroups to hide latency, x-tile
+    // reloads stay in L2).  Round 4, with the value stream on well-spread pages (tools/runs/r04_call21.sh / 22: fresh
+    // processes on one box, ms per sweep at scale 26): 8192 2.99-3.01, 16384 2.68, 20480 2.61-2.62, 22528 2.61-2.63, 24576
+    // 2.62-2.66, 28672 2.66-2.70, 32768 (the default until then) 2.63-2.71, 49152 2.73-2.76; scale 24 0.663 against 0.673,
+    // scale 22 unchanged
     {
-        uint64_t chunk = 32768;
+        uint64_t chunk = 24576;
         if (pb_env("GM_PB_CHUNK", 0) > 0)
             chunk = ((uint64_t)pb_env("GM_PB_CHUNK", 0) + PB_WBLK - 1) & ~(uint64_t)(PB_WBLK - 1);
         pl->chunk = (uint32_t)chunk;
@@ -2687,7 +2970,8 @@ uint64_t pb_work_items(const PbPlan *plan) { return plan ? (uint64_t)plan->NW + 
 void pb_plan_info(const PbPlan *pl, const PbScratch *sc, uint64_t *info, uint32_t count)
 {
     const DevBuf *bufs[] = {&pl->cidx, &pl->hub_rows, &pl->p1_src, &pl->chunk_seg, &pl->delta, &pl->tile_p, &pl->wg_tile,
-                            &pl->wg_p0,  &pl->p2_dst, &pl->bin_v,  &pl->items,     &pl->hot_ids, &pl->hot_ent, &pl->hbin_v};
+                            &pl->wg_p0,  &pl->p2_dst, &pl->bin_v,  &pl->items,     &pl->hot_ids, &pl->hot_ent, &pl->hbin_v,
+                            &pl->seq_rows, &pl->seq_blk, &pl->hh_ent};
     uint64_t plan_bytes = 0;
     for (const DevBuf *b : bufs)
         plan_bytes += b->bytes;
@@ -2696,7 +2980,7 @@ void pb_plan_info(const PbPlan *pl, const PbScratch *sc, uint64_t *info, uint32_
     const uint64_t v[] = {plan_bytes, (uint64_t)(pl->build_ms * 1000.0), pl->n_hub, pl->hub_edges, pl->hub_deg, pl->Htot,
                           pl->Mv, pl->Mh, scratch_bytes, pl->B, pl->NT, pl->NS, pl->G, pl->T, pl->G_long, pl->long_terms, pl->seq_blocks,
                           sc ? sc->draw_best_us : 0u, sc ? sc->draw_worst_us : 0u, sc ? sc->draws_timed : 0u,
-                          sc ? sc->grown_pieces : 0u, sc && !sc->vals_raw.arena.empty() ? 1u : 0u};
+                          sc ? sc->grown_pieces : 0u, sc && !sc->vals_raw.arena.empty() ? 1u : 0u, pl->Mhh};
     for (uint32_t i = 0; i < count; ++i)
         info[i] = i < sizeof(v) / sizeof(v[0]) ? v[i] : 0;
 }
@@ -2797,8 +3081,9 @@ static void pb_hub_dispatch(const PbPlan *pl, PbScratch *sc, float *x_out, float
     }
     if (pl->G > pl->G_long && !(skip & 1))
         hipLaunchKernelGGL(pb_hubseq_kernel, dim3(pl->G - pl->G_long), dim3(PB_SEQ_WG), 0, st, sc->vals, pl->p2_dst.as<uint16_t>(),
-                           items + pl->G_long, pl->seq_blk_first.as<uint32_t>(), pl->seq_rows.as<uint32_t>(),
-                           pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr, base, damping);
+                           items + pl->G_long, pl->seq_blk_first.as<uint32_t>(), pl->seq_blk.as<uint4>(), pl->seq_rows.as<uint32_t>(),
+                           pl->hh_ent.as<uint32_t>(), sc->hot_x.as<float>(), pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr,
+                           base, damping);
     if (pl->G_long && !(skip & 2) && own)
         (void)hipStreamWaitEvent(st, sc->ev_chain_join, 0);
 }

@@ -54,12 +54,12 @@ class PageRankEngine:
         """what the propagation-blocking plan costs and contains (gm_pr_plan_info); {} for the other engines"""
         if self.engine != "pb":
             return {}
-        v = (C.c_uint64 * 22)()
-        check(lib().gm_pr_plan_info(self._h, v, 22))
+        v = (C.c_uint64 * 23)()
+        check(lib().gm_pr_plan_info(self._h, v, 23))
         keys = ("plan_bytes", "plan_build_us", "hub_rows", "hub_edges", "hub_in_degree", "hot_sources", "value_entries",
                 "hot_edges", "scratch_bytes", "bins", "source_tiles", "segments", "hub_groups", "hot_tiers", "long_rows",
                 "long_row_terms", "hub_seq_blocks", "draw_best_us", "draw_worst_us", "draws_timed", "arena_grown_pieces",
-                "value_stream_from_arena")
+                "value_stream_from_arena", "hub_hot_edges")
         return dict(zip(keys, (int(x) for x in v)))
 
     def init(self, scores_local: torch.Tensor, x_local: torch.Tensor):

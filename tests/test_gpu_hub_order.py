@@ -98,3 +98,28 @@ def test_hub_rows_give_the_same_bits_whichever_kernel_sums_them(P, oracle, monke
     monkeypatch.setenv("GM_PB_NOCACHE", "1")
     got, _, eg = P.page_rank(g, cfg, P.PageRankMode.JacobiPB)
     assert np.array_equal(got, base) and eg == eb
+
+
+def test_hub_rows_take_their_hot_terms_off_the_value_stream_without_changing_a_bit(P, oracle, monkeypatch):
+    """Terms of hub rows that come from hot sources do not pass the value stream (12 B per edge) but are gathered from the hot
+    sources' table by pb_hubseq_kernel at their place in the row's order (4-byte records; GM_PB_HUB_HOT=0: all through the
+    stream).  Same sums, bit for bit; and the plan says how many edges took the short way."""
+    from graph_amd.engine import PageRankEngine
+    import torch
+
+    n, g, ioff, itgt, od = _graph(P, oracle, 20)
+    cfg = P.PageRankConfig(25, 0.0, 0.85)
+    monkeypatch.setenv("GM_PB_NOCACHE", "1")
+    with_hot, _, e1 = P.page_rank(g, cfg, P.PageRankMode.JacobiPB)
+    eng = PageRankEngine(g.csr_inc.handle, n, 0, torch.from_numpy(od.astype(np.int32)).cuda(), 0.85, engine=PageRankEngine.PB)
+    info = eng.plan_info()
+    del eng
+    monkeypatch.setenv("GM_PB_HUB_HOT", "0")
+    without, _, e0 = P.page_rank(g, cfg, P.PageRankMode.JacobiPB)
+    eng = PageRankEngine(g.csr_inc.handle, n, 0, torch.from_numpy(od.astype(np.int32)).cuda(), 0.85, engine=PageRankEngine.PB)
+    info0 = eng.plan_info()
+    del eng
+    print(f"scale 20: {info['hub_hot_edges']} of {info['hub_edges']} hub edges off the stream; value entries {info0['value_entries']} -> {info['value_entries']}")
+    assert info["hub_hot_edges"] > 0 and info0["hub_hot_edges"] == 0
+    assert info0["value_entries"] - info["value_entries"] >= info["hub_hot_edges"]  # (+ the padding that went with them)
+    assert np.array_equal(with_hot, without) and e1 == e0
