@@ -863,7 +863,11 @@ __device__ __forceinline__ unsigned long long pb_to_fix(float x)
     return (unsigned long long)(x * PB_FIX_SCALE); // exact scaling by 2^62, truncation below 2^-62
 }
 
-template <int ABL, int D = PB_ACC_DEPTH>
+// BF (measurement, GM_PB_ACC_BRANCHFREE=1): padding entries go to one more accumulator behind the rows' instead of being
+// branched around (a compare, a scalar mask save / restore and a branch for each of the 1.1 G entries of a sweep at scale 26).
+// Measured in alternating fresh processes on one box (tools/runs/r04_call25.sh): SLOWER, 1831 against 1620 us — the 2 % of
+// padding entries then meet on ONE LDS address and same-address atomics serialise.
+template <int ABL, int D = PB_ACC_DEPTH, bool BF = false>
 __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__restrict__ vals,
                                                                 const uint16_t *__restrict__ p2_dst,
                                                                 const PbItem *__restrict__ items,
@@ -882,7 +886,7 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
     __shared__ bool is_last;
     const PbItem item = items[blockIdx.x]; // longest items are dispatched first
     const uint32_t b = item.bin, tid = threadIdx.x;
-    float *hot = reinterpret_cast<float *>(acc + Racc); // the out_scores of one tier of hot sources (H at most)
+    float *hot = reinterpret_cast<float *>(acc + Racc + 2); // the out_scores of one tier of hot sources (H at most); acc[Racc]: padding
     const uint32_t qb = item.q0, qe = (ABL == 4 ? item.q0 : item.q1); // multiples of 4
     constexpr uint32_t STEP = PB_ACC_BLOCK * PB_VEC;
     // Every phase keeps several independent loads per lane in flight and the first group of the value
@@ -972,14 +976,21 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
     for (uint32_t q0 = q_first; q0 < qe; q0 += STEP * D) {
 #pragma unroll
         for (int k = 0; k < D; ++k) {
-            if (d[k].a != PB_NULL)
-                atomicAdd(&acc[d[k].a], pb_to_fix(v[k].x));
-            if (d[k].b != PB_NULL)
-                atomicAdd(&acc[d[k].b], pb_to_fix(v[k].y));
-            if (d[k].c != PB_NULL)
-                atomicAdd(&acc[d[k].c], pb_to_fix(v[k].z));
-            if (d[k].d != PB_NULL)
-                atomicAdd(&acc[d[k].d], pb_to_fix(v[k].w));
+            if (BF) {
+                atomicAdd(&acc[d[k].a < Racc ? d[k].a : Racc], pb_to_fix(v[k].x));
+                atomicAdd(&acc[d[k].b < Racc ? d[k].b : Racc], pb_to_fix(v[k].y));
+                atomicAdd(&acc[d[k].c < Racc ? d[k].c : Racc], pb_to_fix(v[k].z));
+                atomicAdd(&acc[d[k].d < Racc ? d[k].d : Racc], pb_to_fix(v[k].w));
+            } else {
+                if (d[k].a != PB_NULL)
+                    atomicAdd(&acc[d[k].a], pb_to_fix(v[k].x));
+                if (d[k].b != PB_NULL)
+                    atomicAdd(&acc[d[k].b], pb_to_fix(v[k].y));
+                if (d[k].c != PB_NULL)
+                    atomicAdd(&acc[d[k].c], pb_to_fix(v[k].z));
+                if (d[k].d != PB_NULL)
+                    atomicAdd(&acc[d[k].d], pb_to_fix(v[k].w));
+            }
             fetch1(q0 + (uint32_t)(k + D) * STEP, v[k], d[k]);
         }
     }
@@ -1018,14 +1029,22 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
                 fetch_hot(nbase, nend, en);
 #pragma unroll
             for (int k = 0; k < HU; ++k) {
-                if (e[k].x != 0xFFFFFFFFu)
-                    atomicAdd(&acc[e[k].x >> 16], pb_to_fix(table[e[k].x & 0xFFFFu]));
-                if (e[k].y != 0xFFFFFFFFu)
-                    atomicAdd(&acc[e[k].y >> 16], pb_to_fix(table[e[k].y & 0xFFFFu]));
-                if (e[k].z != 0xFFFFFFFFu)
-                    atomicAdd(&acc[e[k].z >> 16], pb_to_fix(table[e[k].z & 0xFFFFu]));
-                if (e[k].w != 0xFFFFFFFFu)
-                    atomicAdd(&acc[e[k].w >> 16], pb_to_fix(table[e[k].w & 0xFFFFu]));
+                if (BF) { // a padding record (0xFFFFFFFF): the padding accumulator, any entry of the table
+                    const uint32_t hl = Hpad - 1u;
+                    atomicAdd(&acc[(e[k].x >> 16) < Racc ? (e[k].x >> 16) : Racc], pb_to_fix(table[(e[k].x & 0xFFFFu) < hl ? (e[k].x & 0xFFFFu) : hl]));
+                    atomicAdd(&acc[(e[k].y >> 16) < Racc ? (e[k].y >> 16) : Racc], pb_to_fix(table[(e[k].y & 0xFFFFu) < hl ? (e[k].y & 0xFFFFu) : hl]));
+                    atomicAdd(&acc[(e[k].z >> 16) < Racc ? (e[k].z >> 16) : Racc], pb_to_fix(table[(e[k].z & 0xFFFFu) < hl ? (e[k].z & 0xFFFFu) : hl]));
+                    atomicAdd(&acc[(e[k].w >> 16) < Racc ? (e[k].w >> 16) : Racc], pb_to_fix(table[(e[k].w & 0xFFFFu) < hl ? (e[k].w & 0xFFFFu) : hl]));
+                } else {
+                    if (e[k].x != 0xFFFFFFFFu)
+                        atomicAdd(&acc[e[k].x >> 16], pb_to_fix(table[e[k].x & 0xFFFFu]));
+                    if (e[k].y != 0xFFFFFFFFu)
+                        atomicAdd(&acc[e[k].y >> 16], pb_to_fix(table[e[k].y & 0xFFFFu]));
+                    if (e[k].z != 0xFFFFFFFFu)
+                        atomicAdd(&acc[e[k].z >> 16], pb_to_fix(table[e[k].z & 0xFFFFu]));
+                    if (e[k].w != 0xFFFFFFFFu)
+                        atomicAdd(&acc[e[k].w >> 16], pb_to_fix(table[e[k].w & 0xFFFFu]));
+                }
             }
             if (ntier >= T)
                 break;
@@ -2070,7 +2089,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     // accumulators are <= 64 KiB, else 1)
     uint32_t H = 0, H_single = 0; // sources per tier with two tables in LDS / with one
     {
-        const size_t acc_bytes = (size_t)pl->Racc * 8;
+        const size_t acc_bytes = (size_t)pl->Racc * 8 + 16; // + the accumulator the padding entries go to
         int wgs = acc_bytes > 65536 ? 1 : 2; // accumulate workgroups per CU the LDS request should allow
         if (pb_env("GM_PB_WGS", 0) == 1 || (pb_env("GM_PB_WGS", 0) == 0 && acc_bytes > 32768))
             wgs = 1;
@@ -2553,6 +2572,7 @@ static hipError_t pb_set_kernel_attributes()
     const void *acc_fns[] = {reinterpret_cast<const void *>(&pb_accum_kernel<0>),
                              reinterpret_cast<const void *>(&pb_accum_kernel<0, 2>),
                              reinterpret_cast<const void *>(&pb_accum_kernel<0, 6>),
+                             reinterpret_cast<const void *>(&pb_accum_kernel<0, PB_ACC_DEPTH, true>),
                              reinterpret_cast<const void *>(&pb_accum_kernel<3>),
                              reinterpret_cast<const void *>(&pb_accum_kernel<4>)};
     hipError_t e = hipSuccess;
@@ -3001,12 +3021,12 @@ void pb_launch_bin(const PbPlan *pl, PbScratch *sc, const float *x_in, uint32_t 
                        pl->Htot, sc->hot_x.as<float>());
 }
 
-template <int ABL, int D = PB_ACC_DEPTH>
+template <int ABL, int D = PB_ACC_DEPTH, bool BF = false>
 void pb_launch_accum(const PbPlan *pl, PbScratch *sc, const PbItem *items, uint32_t count, float *x_out, float *scores,
                      const uint32_t *outdeg, float base, float damping, hipStream_t st)
 {
-    hipLaunchKernelGGL((pb_accum_kernel<ABL, D>), dim3(count), dim3(PB_ACC_BLOCK),
-                       (size_t)pl->Racc * 8 + (((size_t)pl->H + 3) & ~(size_t)3) * 4 * (pl->T > 1 ? 2 : 1), st, sc->vals,
+    hipLaunchKernelGGL((pb_accum_kernel<ABL, D, BF>), dim3(count), dim3(PB_ACC_BLOCK),
+                       (size_t)pl->Racc * 8 + 16 + (((size_t)pl->H + 3) & ~(size_t)3) * 4 * (pl->T > 1 ? 2 : 1), st, sc->vals,
                        pl->p2_dst.as<uint16_t>(),
                        items, pl->hot_ent.as<uint32_t>(), pl->hbin_v.as<uint32_t>(), sc->hot_x.as<float>(), pl->H, pl->T, pl->Htot,
                        sc->partials.as<unsigned long long>(), sc->tickets.as<uint32_t>(), pl->cidx.as<uint16_t>(), outdeg,
@@ -3053,7 +3073,12 @@ static void pb_accum_dispatch(const PbPlan *pl, PbScratch *sc, const PbItem *ite
         switch (pb_env("GM_PB_ACC_DEPTH", PB_ACC_DEPTH)) { // measurement: register groups of the value stream in flight
         case 2: pb_launch_accum<0, 2>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
         case 6: pb_launch_accum<0, 6>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
-        default: pb_launch_accum<0>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
+        default:
+            if (pb_env("GM_PB_ACC_BRANCHFREE", 0))
+                pb_launch_accum<0, PB_ACC_DEPTH, true>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st);
+            else
+                pb_launch_accum<0>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st);
+            break;
         }
         break;
     }
