@@ -237,9 +237,10 @@ namespace {
 // 2^fshift consecutive sources, set when one of them is hot.  It answers "not hot" for most edges without leaving the
 // CU; only the rest look their source up in the rank table (134 MB at scale 26 — a random 2-byte gather per edge
 // from that table was most of this kernel's time).
-// hh_bit != 0 (a hub row walked by pb_hubseq_kernel): an edge from a hot source keeps its place among the row's edges — the
-// key stays (virtual bin, source) — and only carries the flag (above the slot, in the unsorted bits): it is taken out of the
-// value stream after the sort and becomes a hot record of its block (pb_hubseq_layout_kernel)
+// hh_bit != 0 (a hub row walked by pb_hubseq_kernel): an edge from a hot source becomes a HOT key too, but keeps (virtual bin,
+// SOURCE) as its sorted fields.  Ordinary hot keys carry ordinary bins (< B: no hub row uses the hot tables), so these sort
+// behind all of them, in (group, source) order: no longer in the value stream, and where pb_hubseq_layout_kernel merges them
+// with the group's cold entries into its blocks.
 __device__ __forceinline__ uint64_t pb_make_key(uint64_t hi_cold, uint32_t src, int sb, int bb,
                                                 const uint32_t *filter, int fshift,
                                                 const uint32_t *__restrict__ hot_rank, uint64_t hh_bit = 0)
@@ -249,7 +250,7 @@ __device__ __forceinline__ uint64_t pb_make_key(uint64_t hi_cold, uint32_t src, 
         if ((filter[blk >> 5] >> (blk & 31u)) & 1u) {
             const uint32_t h = hot_rank[src];
             if (h != 0xFFFFFFFFu)
-                return hh_bit ? (hi_cold | hh_bit | src) : (hi_cold | (1ull << (sb + bb)) | h);
+                return hh_bit ? (hi_cold | (1ull << (sb + bb)) | src) : (hi_cold | (1ull << (sb + bb)) | h);
         }
     }
     return hi_cold | src;
@@ -1000,7 +1001,7 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
     // table is requested at this tier's first batch.  A tier with a few thousand edges per bin is a single, partly
     // filled batch: without the pipeline across the tier switch every tier cost one exposed HBM round trip.
     if (tier < T) {
-        constexpr int HU = 2;
+        constexpr int HU = 2; // uint4 of hot records per lane and batch (1 / 2 / 3 measured alike: 2.70-2.72 ms per sweep, tools/runs/r04_call28.sh)
         constexpr uint32_t BATCH = PB_ACC_BLOCK * PB_VEC * HU; // entries of one batch
         uint32_t base, h_end; // this batch starts at `base` (workgroup-uniform) of the tier's range [.., h_end)
         tier_range(tier, base, h_end);
@@ -1832,24 +1833,6 @@ int sort_keys_u64(DevBuf &keys, DevBuf &alt, uint64_t count, int begin_bit, int 
     return GM_OK;
 }
 
-struct PbHasBit {
-    uint64_t bit;
-    bool want;
-    __host__ __device__ bool operator()(const uint64_t &k) const { return ((k & bit) != 0) == want; }
-};
-
-// out = the keys of in[0, count) whose `bit` is set (want) / clear, in order; *count_out (device) = how many
-int select_keys_u64(const uint64_t *in, uint64_t *out, uint32_t count, uint64_t bit, bool want, uint32_t *count_out)
-{
-    size_t tmp_bytes = 0;
-    GM_HIP(rocprim::select(nullptr, tmp_bytes, in, out, count_out, (size_t)count, PbHasBit{bit, want}, (hipStream_t)0));
-    DevBuf tmp;
-    GM_TRY(tmp.alloc(tmp_bytes));
-    GM_HIP(rocprim::select(tmp.p, tmp_bytes, in, out, count_out, (size_t)count, PbHasBit{bit, want}, (hipStream_t)0));
-    GM_HIP(hipDeviceSynchronize());
-    return GM_OK;
-}
-
 // *out = the first index whose bin field is >= bin (one thread: a binary search)
 __global__ void pb_first_of_bin_kernel(const uint64_t *__restrict__ keys, uint32_t count, int shift, uint32_t mask, uint32_t bin,
                                        uint32_t *__restrict__ out)
@@ -2217,8 +2200,8 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     const int hot_bit = bin_bits + sb; // the flag bit of a hot edge: the highest sorted bit
     // hub groups walked by pb_hubseq_kernel take their terms from hot sources off the value stream (GM_PB_HUB_HOT=0: not): the
     // flag of such an edge sits above the slot
-    const bool hub_hot = H && pl->G > 0 && pb_env("GM_PB_HUB_HOT", 1) != 0 && bin_bits + sb + rb + 2 <= 64 && pl->Htot < (1u << 18);
-    const uint64_t hh_bit = hub_hot ? 1ull << (sb + bin_bits + 1 + rb) : 0ull;
+    const bool hub_hot = H && pl->G > 0 && pb_env("GM_PB_HUB_HOT", 1) != 0 && pl->Htot < (1u << 18);
+    const uint64_t hh_bit = hub_hot ? 1ull : 0ull; // (a switch for pb_keys_kernel: the key itself carries no extra bit)
     DevBuf group_long;
     {
         std::vector<uint32_t> gl(pl->G ? pl->G : 1, 0u);
@@ -2243,24 +2226,47 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     // the slot sits above the sorted bits (rocPRIM's radix sort was measured 14x slower with a non-zero BEGIN bit at
     // this size, so the unsorted field is at the top, not at the bottom)
     GM_TRY(sort_keys_u64(keys, kalt, m_all, 0, H ? hot_bit + 1 : hot_bit));
-    if (!hub_hot) {
-        kalt.release();
+    kalt.release();
+    if (!hub_hot)
         hot_rank.release(); // (with hub_hot: kept for the hot records of the hub groups, pb_hubseq_layout_kernel)
-    }
     hot_blk.release();
     pos_h.release();
     timer.done("pb plan: edge keys + sort");
 
-    if (H) { // hot keys (top bit set) sit behind the cold ones, already ordered by (bin, rank = tier-major, row)
+    // hot keys (top bit set) sit behind the cold ones: the ordinary ones (bins < B) ordered by (bin, rank = tier-major, row),
+    // then the hub groups' (bins >= B) ordered by (group, source)
+    const uint64_t *ckeys = keys.as<uint64_t>(); // the cold keys: the value stream's entries
+    const uint64_t *hk = nullptr;                // the hub groups' hot keys
+    uint32_t mhh = 0;
+    if (H) {
         DevBuf split;
-        GM_TRY(split.alloc(3 * 4));
+        GM_TRY(split.alloc(4 * 4));
         hipLaunchKernelGGL(pb_bounds_kernel, dim3(pb_grid(m_all)), dim3(256), 0, 0, keys.as<uint64_t>(), m_all, hot_bit, 2u,
                            split.as<uint32_t>(), 1u);
         GM_HIP(hipGetLastError());
         GM_HIP(hipMemcpy(&m, split.as<uint32_t>() + 1, 4, hipMemcpyDeviceToHost));
-        const uint32_t mh = m_all - m;
+        uint32_t mh = m_all - m;
+        if (mh && hub_hot) { // where the hub groups' hot keys begin
+            uint32_t first_hub = mh;
+            hipLaunchKernelGGL(pb_first_of_bin_kernel, dim3(1), dim3(1), 0, 0, keys.as<uint64_t>() + m, mh, sb,
+                               (uint32_t)((1ull << bin_bits) - 1ull), pl->B, split.as<uint32_t>() + 3);
+            GM_HIP(hipGetLastError());
+            GM_HIP(hipMemcpy(&first_hub, split.as<uint32_t>() + 3, 4, hipMemcpyDeviceToHost));
+            mhh = mh - first_hub;
+            mh = first_hub;
+            hk = keys.as<uint64_t>() + m + mh;
+            if (mhh && m == 0) {
+                // nothing is left of the value stream (a small graph whose every source is hot): the hub groups' hot keys
+                // go back to being cold ones — as a block they are sorted by (virtual bin, source) like cold keys
+                hipLaunchKernelGGL(pb_clear_bit_kernel, dim3(pb_grid(mhh)), dim3(256), 0, 0, keys.as<uint64_t>() + mh, mhh,
+                                   1ull << hot_bit);
+                GM_HIP(hipGetLastError());
+                ckeys = keys.as<uint64_t>() + mh;
+                m = mhh, mhh = 0, hk = nullptr;
+            }
+        }
         if (mh) {
-            const uint64_t *hkeys = keys.as<uint64_t>() + m;
+            const uint64_t *hkeys = keys.as<uint64_t>() + (ckeys == keys.as<uint64_t>() ? m : 0u);
             DevBuf hstart, hpad;
             const uint32_t cells = Bv * T; // (bin, tier) cells
             GM_TRY(hstart.alloc(((size_t)cells + 1) * 4));
@@ -2282,39 +2288,6 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
             GM_HIP(hipDeviceSynchronize());
         }
     }
-    // ---- the hub groups' terms from hot sources leave the value stream: their keys (flag hh_bit, in (group, source) order
-    // among the cold ones) are taken out into `hk`, the others close ranks
-    DevBuf hk;
-    uint32_t mhh = 0;
-    if (hub_hot && m) {
-        DevBuf cnt_dev;
-        GM_TRY(cnt_dev.alloc(2 * 4));
-        // the hub groups are the last (virtual) bins: only the tail of the cold keys, from the first key of bin B on, can
-        // carry the flag — a quarter of the keys at RMAT scale 26
-        hipLaunchKernelGGL(pb_first_of_bin_kernel, dim3(1), dim3(1), 0, 0, keys.as<uint64_t>(), m, sb, (uint32_t)((1ull << bin_bits) - 1ull),
-                           pl->B, cnt_dev.as<uint32_t>() + 1);
-        GM_HIP(hipGetLastError());
-        uint32_t k0 = 0;
-        GM_HIP(hipMemcpy(&k0, cnt_dev.as<uint32_t>() + 1, 4, hipMemcpyDeviceToHost));
-        const uint32_t tail = m - k0;
-        const uint64_t cap = pl->hub_edges - pl->long_terms;
-        GM_TRY(hk.alloc_scratch((size_t)(cap ? cap : 1) * 8));
-        if (tail)
-            GM_TRY(select_keys_u64(keys.as<uint64_t>() + k0, hk.as<uint64_t>(), tail, hh_bit, true, cnt_dev.as<uint32_t>()));
-        if (tail)
-            GM_HIP(hipMemcpy(&mhh, cnt_dev.p, 4, hipMemcpyDeviceToHost));
-        if (mhh == m) { // nothing would be left of the stream (a tiny graph whose every source is hot): they stay in it after all
-            hipLaunchKernelGGL(pb_clear_bit_kernel, dim3(pb_grid(m)), dim3(256), 0, 0, keys.as<uint64_t>(), m, hh_bit);
-            GM_HIP(hipGetLastError());
-            mhh = 0;
-        } else if (mhh) { // the tail's other keys close ranks in place (through kalt: select is not an in-place operation)
-            GM_TRY(select_keys_u64(keys.as<uint64_t>() + k0, kalt.as<uint64_t>(), tail, hh_bit, false, cnt_dev.as<uint32_t>()));
-            GM_HIP(hipMemcpy(keys.as<uint64_t>() + k0, kalt.p, (size_t)(tail - mhh) * 8, hipMemcpyDeviceToDevice));
-            m -= mhh;
-        }
-        kalt.release();
-        timer.done("pb plan: hub groups' hot terms taken out (%u)", mhh);
-    }
     pl->Mhh = mhh;
     if (m == 0) { // every edge is hot
         GM_TRY(pl->p2_dst.alloc(16));
@@ -2331,7 +2304,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     DevBuf flag, segid;
     GM_TRY(flag.alloc_big((size_t)m * 4));
     GM_TRY(segid.alloc_big((size_t)m * 4));
-    hipLaunchKernelGGL(pb_flags_kernel, dim3(gm_), dim3(256), 0, 0, keys.as<uint64_t>(), m, bin_bits, sb, pl->s_log,
+    hipLaunchKernelGGL(pb_flags_kernel, dim3(gm_), dim3(256), 0, 0, ckeys, m, bin_bits, sb, pl->s_log,
                        flag.as<uint32_t>());
     GM_HIP(hipGetLastError());
     GM_TRY(scan_inclusive_u32(flag.as<uint32_t>(), segid.as<uint32_t>(), m));
@@ -2351,7 +2324,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     GM_TRY(segkalt.alloc_scratch((size_t)NS * 8));
     GM_TRY(segval.alloc_scratch((size_t)NS * 4));
     GM_TRY(segbin.alloc_scratch((size_t)NS * 8));
-    hipLaunchKernelGGL(pb_segments_kernel, dim3(gm_), dim3(256), 0, 0, keys.as<uint64_t>(), flag.as<uint32_t>(),
+    hipLaunchKernelGGL(pb_segments_kernel, dim3(gm_), dim3(256), 0, 0, ckeys, flag.as<uint32_t>(),
                        segid.as<uint32_t>(), m, bin_bits, sb, pl->s_log, jb, vstart.as<uint32_t>(), segkey.as<uint64_t>(),
                        segbin.as<uint64_t>());
     GM_HIP(hipGetLastError());
@@ -2433,7 +2406,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
         GM_TRY(hubsrc.alloc_scratch((size_t)(Mv - hub_q0 + 1) * 4));
         GM_HIP(hipMemset(hubsrc.p, 0xFF, (size_t)(Mv - hub_q0 + 1) * 4));
     }
-    hipLaunchKernelGGL(pb_fill_kernel, dim3(gm_), dim3(256), 0, 0, keys.as<uint64_t>(), segid.as<uint32_t>(),
+    hipLaunchKernelGGL(pb_fill_kernel, dim3(gm_), dim3(256), 0, 0, ckeys, segid.as<uint32_t>(),
                        vstart.as<uint32_t>(), vstart4.as<uint32_t>(), rank_of.as<uint32_t>(), pstart.as<uint32_t>(), m,
                        bin_bits, sb, pl->s_log, pl->p1_src.as<uint16_t>(), pl->p2_dst.as<uint16_t>(),
                        pl->G ? hubsrc.as<uint32_t>() : (uint32_t *)nullptr, hub_q0);
@@ -2451,7 +2424,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
         if (mhh) {
             DevBuf d_start;
             GM_TRY(d_start.alloc(((size_t)Bv + 1) * 4));
-            hipLaunchKernelGGL(pb_bounds_kernel, dim3(pb_grid(mhh)), dim3(256), 0, 0, hk.as<uint64_t>(), mhh, sb, Bv,
+            hipLaunchKernelGGL(pb_bounds_kernel, dim3(pb_grid(mhh)), dim3(256), 0, 0, hk, mhh, sb, Bv,
                                d_start.as<uint32_t>(), (uint32_t)((1ull << bin_bits) - 1ull));
             GM_HIP(hipGetLastError());
             GM_HIP(hipMemcpy(hk_start.data(), d_start.p, ((size_t)Bv + 1) * 4, hipMemcpyDeviceToHost));
@@ -2484,9 +2457,9 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
         if (pl->seq_blocks) {
             const uint64_t smask = (1ull << sb) - 1ull;
             hipLaunchKernelGGL(pb_hubseq_blocks_kernel, dim3(div_up(pl->seq_blocks, 256)), dim3(256), 0, 0, d_groups.as<PbSeqGroup>(), GS,
-                               pl->seq_blocks, hubsrc.as<uint32_t>(), hub_q0, hk.as<uint64_t>(), smask, pl->seq_blk.as<uint4>());
+                               pl->seq_blocks, hubsrc.as<uint32_t>(), hub_q0, hk, smask, pl->seq_blk.as<uint4>());
             hipLaunchKernelGGL(pb_hubseq_layout_kernel, dim3(pl->seq_blocks), dim3(PB_SEQ_STEP / PB_VEC), 0, 0, d_groups.as<PbSeqGroup>(), GS,
-                               pl->seq_blk.as<uint4>(), hubsrc.as<uint32_t>(), hub_q0, hk.as<uint64_t>(), smask, sb + bin_bits + 1,
+                               pl->seq_blk.as<uint4>(), hubsrc.as<uint32_t>(), hub_q0, hk, smask, sb + bin_bits + 1,
                                (uint32_t)((1u << rb) - 1u), hot_rank.as<uint32_t>(), pl->p2_dst.as<uint16_t>(),
                                pl->hh_ent.as<uint32_t>(), pl->seq_rows.as<uint32_t>());
             GM_HIP(hipGetLastError());
@@ -2495,7 +2468,6 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
         timer.done("pb plan: hub groups row-major (%u blocks, %u hot records)", pl->seq_blocks, mhh);
     }
     hubsrc.release();
-    hk.release();
     hot_rank.release();
     // phase-1 workgroup list: a tile's stream is cut into chunks of 24576 entries (enough workgroups to hide latency, x-tile
     // reloads stay in L2).  Round 4, with the value stream on well-spread pages (tools/runs/r04_call21.sh / 22: fresh
