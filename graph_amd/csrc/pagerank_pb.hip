@@ -1357,6 +1357,8 @@ __global__ __launch_bounds__(PB_SEQ_STEP / PB_VEC) void pb_hubseq_layout_kernel(
     }
 }
 
+// (106 VGPRs -> 112: with pb_hublong_kernel held at 88, one wavefront of this kernel, two of that and four of the accumulate
+// kernel's share a SIMD's 512 registers)
 __global__ __launch_bounds__(PB_SEQ_WG) void pb_hubseq_kernel(const float *__restrict__ vals, const uint16_t *__restrict__ p2_dst,
                                                               const PbHubItem *__restrict__ items,
                                                               const uint32_t *__restrict__ blk_first,
@@ -1389,7 +1391,9 @@ __global__ __launch_bounds__(PB_SEQ_WG) void pb_hubseq_kernel(const float *__res
         uint4 range;
     } sa, sb;
     auto load = [&](uint32_t b, Staged &st) {
-        st.range = bt[b];
+        const uint4 rg = bt[b]; // the same for every lane: kept in scalar registers
+        st.range = make_uint4((uint32_t)__builtin_amdgcn_readfirstlane((int)rg.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)rg.y),
+                              (uint32_t)__builtin_amdgcn_readfirstlane((int)rg.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)rg.w));
         const uint32_t qa = st.range.x & ~3u;
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
@@ -1473,12 +1477,12 @@ __global__ __launch_bounds__(PB_SEQ_WG) void pb_hubseq_kernel(const float *__res
             uint32_t k = (info >> 16) / 4u;
             const uint32_t end = k + (((info & 0xFFFFu) + PB_SEQ_PAD - 1u) / PB_SEQ_PAD) * (PB_SEQ_PAD / 4u);
             if (k < end) {
-                // Three register sets in turn, no copies: a step's 16 terms are requested two steps before they are added
-                // (16 dependent v_add_f32 = 64 cycles; an LDS round trip is longer than that — with one step of lookahead the
-                // walk measured ~12 cycles per term).  Every term is added to the sum in CSR order, each add rounded to f32
-                // (page_rank.rs:144-146).
+                // Two register sets in turn, no copies: the next step's 16 terms are requested before this step's are added
+                // (16 dependent v_add_f32).  Every term is added to the sum in CSR order, each add rounded to f32
+                // (page_rank.rs:144-146).  (Three sets, two steps of lookahead, measured the same per term and cost the
+                // registers that let this kernel's wavefront sit beside the other two kernels' on a SIMD.)
                 constexpr uint32_t Q = PB_SEQ_PAD / 4u;
-                f32x4 a0, a1, a2, a3, n0, n1, n2, n3, c0, c1, c2, c3;
+                f32x4 a0, a1, a2, a3, n0, n1, n2, n3;
 #define GM_SEQ_GET(x0, x1, x2, x3, at) x0 = b4[at], x1 = b4[(at) + 1], x2 = b4[(at) + 2], x3 = b4[(at) + 3]
 #define GM_SEQ_ADD(x0, x1, x2, x3)                                                                                          \
     S = __fadd_rn(S, x0.x), S = __fadd_rn(S, x0.y), S = __fadd_rn(S, x0.z), S = __fadd_rn(S, x0.w);                         \
@@ -1486,24 +1490,16 @@ __global__ __launch_bounds__(PB_SEQ_WG) void pb_hubseq_kernel(const float *__res
     S = __fadd_rn(S, x2.x), S = __fadd_rn(S, x2.y), S = __fadd_rn(S, x2.z), S = __fadd_rn(S, x2.w);                         \
     S = __fadd_rn(S, x3.x), S = __fadd_rn(S, x3.y), S = __fadd_rn(S, x3.z), S = __fadd_rn(S, x3.w)
                 GM_SEQ_GET(a0, a1, a2, a3, k);
-                if (k + Q < end)
-                    GM_SEQ_GET(n0, n1, n2, n3, k + Q);
-                for (;;) { // a = step k, n = step k + Q (if any): request k + 2Q, add k
-                    if (k + 2u * Q < end)
-                        GM_SEQ_GET(c0, c1, c2, c3, k + 2u * Q);
+                for (;;) {
+                    if (k + Q < end)
+                        GM_SEQ_GET(n0, n1, n2, n3, k + Q);
                     GM_SEQ_ADD(a0, a1, a2, a3);
                     k += Q;
                     if (k >= end)
                         break;
-                    if (k + 2u * Q < end)
-                        GM_SEQ_GET(a0, a1, a2, a3, k + 2u * Q);
+                    if (k + Q < end)
+                        GM_SEQ_GET(a0, a1, a2, a3, k + Q);
                     GM_SEQ_ADD(n0, n1, n2, n3);
-                    k += Q;
-                    if (k >= end)
-                        break;
-                    if (k + 2u * Q < end)
-                        GM_SEQ_GET(n0, n1, n2, n3, k + 2u * Q);
-                    GM_SEQ_ADD(c0, c1, c2, c3);
                     k += Q;
                     if (k >= end)
                         break;
@@ -1546,7 +1542,7 @@ __global__ __launch_bounds__(PB_SEQ_WG) void pb_hubseq_kernel(const float *__res
 // S leaves a binade a few dozen times per row (and at every doubling of the first few thousand terms), so a super-block of
 // 8192 terms costs one pass (one barrier), sometimes two.  Bit for bit the reference's sum: tests/test_gpu_hub_adversarial.py compares
 // rows of up to 2^20 + 1 terms with orc_page_rank_jacobi_sweep's sequential sums for equality.
-// (at most 96 VGPRs: two of its wavefronts, one of pb_hubseq_kernel's and four of the accumulate kernel's share a SIMD's 512)
+// (at most 96 VGPRs: two of its wavefronts, one of pb_hubseq_kernel's (112) and four of the accumulate kernel's (56) share a SIMD's 512)
 __global__ __launch_bounds__(PB_LONG_WG) __attribute__((amdgpu_waves_per_eu(5, 8))) void pb_hublong_kernel(const float *__restrict__ vals, const uint16_t *__restrict__ p2_dst,
                                                                 const PbHubItem *__restrict__ items,
                                                                 const uint32_t *__restrict__ hub_rows,

@@ -1,8 +1,8 @@
 #!/bin/bash
 # round 4, GPU call 11: one hub row of N terms alone on the GPU: duration of pb_hublong_kernel / pb_hubseq_kernel per dispatch
 OUT=gpurun_out/r04k; mkdir -p $OUT; export TMPDIR=/tmp
-for kind in long; do
-  timeout -s KILL 300 rocprofv3 --kernel-trace -d $OUT/$kind -o t -- python tools/hub_probe.py $kind 9000 16384 131072 1048576 > $OUT/$kind.log 2>&1
+for kind in seq long; do
+  timeout -s KILL 300 rocprofv3 --kernel-trace -d $OUT/$kind -o t -- python tools/hub_probe.py $kind 9000 16384 131072 > $OUT/$kind.log 2>&1
   grep -a "N=" $OUT/$kind.log | head -3
   python - <<PY
 import sqlite3, glob
