@@ -57,6 +57,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <memory>
+#include <tuple>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -1357,9 +1358,23 @@ __global__ __launch_bounds__(PB_SEQ_STEP / PB_VEC) void pb_hubseq_layout_kernel(
     }
 }
 
-// (106 VGPRs -> 112: with pb_hublong_kernel held at 88, one wavefront of this kernel, two of that and four of the accumulate
-// kernel's share a SIMD's 512 registers)
-__global__ __launch_bounds__(PB_SEQ_WG) void pb_hubseq_kernel(const float *__restrict__ vals, const uint16_t *__restrict__ p2_dst,
+// One hub group per workgroup; lane g of wavefront 0 owns row g and adds its terms in CSR order, the other wavefronts only
+// move data.  A round = one block of 2040 terms: the walk of block b, then block b + 1 is scattered into the buffer.
+//
+// The memory pipeline is written so that NO wait in the loop is a wait for everything.  The vector-memory counter completes
+// in order: waiting for a load waits for every older one, and the compiler can leave younger ones in flight only if it can
+// COUNT them — so every load of a round is unconditional (indices clamped instead of branches; what lies outside a block's
+// ranges is dropped when it is used) and the rounds issue in a fixed order:
+//     G(b+2)  values of block b + 2's hot terms from hot_x (L2)        needs R(b+2), the oldest load of the round before
+//     R(b+3)  hot records of block b + 3
+//     V(b+2)  values + places of block b + 2's stretch of the stream
+//     I(b+2)  its row table
+//     walk b, barrier, scatter b + 1 (needs G, V, I of b + 1: issued one round ago, 13 younger loads stay in flight), barrier
+// Until round 4's last day the loads sat behind `if (q < end)`: the compiler then has to assume that nothing younger was
+// issued and waits with vmcnt(0) — for the block requested a moment ago as well.  Every round paid a full memory latency
+// under the accumulate kernel's traffic (~8 us per block; the walk of a block's 32..120 terms per row is 0.2..0.8 us).
+// (at most 96 VGPRs: one wavefront of this kernel, two of pb_hublong_kernel's and four of the accumulate kernel's share a SIMD)
+__global__ __launch_bounds__(PB_SEQ_WG) __attribute__((amdgpu_waves_per_eu(5, 8))) void pb_hubseq_kernel(const float *__restrict__ vals, const uint16_t *__restrict__ p2_dst,
                                                               const PbHubItem *__restrict__ items,
                                                               const uint32_t *__restrict__ blk_first,
                                                               const uint4 *__restrict__ blk, const uint32_t *__restrict__ rows,
@@ -1367,71 +1382,86 @@ __global__ __launch_bounds__(PB_SEQ_WG) void pb_hubseq_kernel(const float *__res
                                                               const uint32_t *__restrict__ hub_rows,
                                                               const uint32_t *__restrict__ outdeg, float *__restrict__ scores,
                                                               float *__restrict__ x_out, double *__restrict__ group_err, float base,
-                                                              float damping)
+                                                              float damping, uint32_t v_safe, uint32_t h_safe, uint32_t n_groups, uint32_t walk_prio)
 {
     constexpr uint32_t STEP = PB_SEQ_STEP;                      // stream entries one round of loads covers
     constexpr int PER = (int)(STEP / (PB_SEQ_WG * PB_VEC));     // float4 + 4 places per thread and block
-    constexpr int HP = (int)PB_SEQ_HOT;                         // hot records per thread and block in the prefetch registers
-    __shared__ __attribute__((aligned(16))) float buf[PB_SEQ_BUF + 4]; // + where the padding entries of the stream land
+    constexpr int HP = (int)PB_SEQ_HOT;                         // hot records per thread and block in the pipeline
+    constexpr uint32_t DUMP = PB_SEQ_BUF;                       // where everything that is not a term lands
+    __shared__ __attribute__((aligned(16))) float buf[PB_SEQ_BUF + 4];
     __shared__ double red[PB_SEQ_WG / kWave];
-    const PbHubItem item = items[blockIdx.x]; // longest groups first
-    const uint32_t tid = threadIdx.x, nh = item.nh;
+    const uint32_t tid = threadIdx.x;
+    if (walk_prio && tid < kWave)
+        __builtin_amdgcn_s_setprio(3); // the walk is the group's critical path: first in line at its SIMD's issue
+    // the grid may be smaller than the number of groups (pb_hub_dispatch): workgroup w then takes groups w, w + grid, ...
+    for (uint32_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    const PbHubItem item = items[grp]; // longest groups first
+    const uint32_t nh = item.nh;
     const bool walker = tid < nh; // nh <= 64: lane g of wavefront 0 owns row g
-    const uint32_t b0 = blk_first[blockIdx.x], nb = blk_first[blockIdx.x + 1] - b0;
-    const uint32_t *ri = rows + (size_t)b0 * PB_HUB_MAX;
+    const uint32_t b0 = blk_first[grp], nb = blk_first[grp + 1] - b0;
+    const uint32_t *ri = rows + (size_t)b0 * PB_HUB_MAX + (tid & (PB_HUB_MAX - 1u));
     const uint4 *bt = blk + b0;
-    // a block's values and places on their way from memory: two sets, so that block b + 2 is requested before block b is
-    // walked (with one block of lookahead a group of many short rows spent its time waiting for the next block: the
-    // latency of a global load under the accumulate kernel's traffic is longer than the walk of ~32 terms per row).  The
-    // block's stretch of the stream starts anywhere: the loads start at the float4 below it, entries outside [x, y) are dropped.
-    struct Staged {
+    // block k's ranges {stream first, stream end, hot records first, hot records end}: the same for every lane (scalar loads);
+    // beyond the group's last block: the last block again (loaded, never used)
+    const uint32_t last = nb ? nb - 1u : 0u;
+    auto range_of = [&](uint32_t k) { return bt[k < last ? k : last]; };
+    struct Stream { // V(k), raw
         f32x4 v[PER];
         u32x2 d[PER];
-        uint32_t rec[HP]; // the block's first 1024 hot records: place << 18 | hot rank (0xFFFFFFFF: none)
-        uint4 range;
     } sa, sb;
-    auto load = [&](uint32_t b, Staged &st) {
-        const uint4 rg = bt[b]; // the same for every lane: kept in scalar registers
-        st.range = make_uint4((uint32_t)__builtin_amdgcn_readfirstlane((int)rg.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)rg.y),
-                              (uint32_t)__builtin_amdgcn_readfirstlane((int)rg.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)rg.w));
-        const uint32_t qa = st.range.x & ~3u;
+    struct Hot { // G(k), raw, and where the values go: two 12-bit places per register (DUMP for what is no record)
+        float x[HP];
+        uint32_t at[HP / 2];
+    } ha, hb;
+    uint32_t rx[HP]; // R(k), raw: place << 18 | hot rank
+    auto issue_r = [&](uint32_t k) {
+        const uint4 rg = range_of(k);
+#pragma unroll
+        for (int j = 0; j < HP; ++j) {
+            const uint32_t h = rg.z + (uint32_t)j * PB_SEQ_WG + tid;
+            rx[j] = hh_ent[h < h_safe ? h : h_safe];
+        }
+    };
+    auto issue_g = [&](uint32_t k, Hot &ht) { // needs R(k) in rx
+        const uint4 rg = range_of(k);
+#pragma unroll
+        for (int j = 0; j < HP; ++j) {
+            const bool is = rg.z + (uint32_t)j * PB_SEQ_WG + tid < rg.w;
+            ht.x[j] = hot_x[is ? rx[j] & 0x3FFFFu : 0u];
+            const uint32_t at = is ? rx[j] >> 18 : DUMP;
+            if (j & 1)
+                ht.at[j / 2] |= at << 16;
+            else
+                ht.at[j / 2] = at;
+        }
+    };
+    auto issue_v = [&](uint32_t k, Stream &st) {
+        const uint32_t qa = range_of(k).x & ~3u;
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
-            const uint32_t q = qa + ((uint32_t)j * PB_SEQ_WG + tid) * PB_VEC;
-            st.d[j].x = st.d[j].y = 0xFFFFFFFFu;
-            if (q < st.range.y) {
-                st.v[j] = *reinterpret_cast<const f32x4 *>(vals + q);
-                st.d[j] = *reinterpret_cast<const u32x2 *>(p2_dst + q);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < HP; ++k) {
-            const uint32_t h = st.range.z + (uint32_t)k * PB_SEQ_WG + tid;
-            st.rec[k] = h < st.range.w ? hh_ent[h] : 0xFFFFFFFFu;
+            const uint32_t q = qa + ((uint32_t)j * PB_SEQ_WG + tid) * PB_VEC, qc = q < v_safe ? q : v_safe;
+            st.v[j] = *reinterpret_cast<const f32x4 *>(vals + qc);
+            st.d[j] = *reinterpret_cast<const u32x2 *>(p2_dst + qc);
         }
     };
-    // the hot terms' values: gathered from hot_x (300 KB, L2-resident) one round after their records were requested
-    auto gather = [&](const Staged &st, float(&hv)[HP]) {
-#pragma unroll
-        for (int k = 0; k < HP; ++k)
-            hv[k] = st.rec[k] != 0xFFFFFFFFu ? hot_x[st.rec[k] & 0x3FFFFu] : 0.0f;
-    };
-    auto scatter = [&](const Staged &st, const float(&hv)[HP]) { // no branch per term: what is not a term goes to the slot behind the buffer
-        const uint32_t qa = st.range.x & ~3u;
+    auto issue_i = [&](uint32_t k) { return ri[(size_t)(k < last ? k : last) * PB_HUB_MAX]; };
+    auto scatter = [&](uint32_t k, const Stream &st, const Hot &ht) { // no branch per term: what is not a term goes to DUMP
+        const uint4 rg = range_of(k);
+        const uint32_t qa = rg.x & ~3u;
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
             const uint32_t q = qa + ((uint32_t)j * PB_SEQ_WG + tid) * PB_VEC;
             const uint32_t p0 = st.d[j].x & 0xFFFFu, p1 = st.d[j].x >> 16, p2 = st.d[j].y & 0xFFFFu, p3 = st.d[j].y >> 16;
-            buf[(p0 < PB_SEQ_BUF && q >= st.range.x && q < st.range.y) ? p0 : PB_SEQ_BUF] = st.v[j].x;
-            buf[(p1 < PB_SEQ_BUF && q + 1u >= st.range.x && q + 1u < st.range.y) ? p1 : PB_SEQ_BUF] = st.v[j].y;
-            buf[(p2 < PB_SEQ_BUF && q + 2u >= st.range.x && q + 2u < st.range.y) ? p2 : PB_SEQ_BUF] = st.v[j].z;
-            buf[(p3 < PB_SEQ_BUF && q + 3u >= st.range.x && q + 3u < st.range.y) ? p3 : PB_SEQ_BUF] = st.v[j].w;
+            buf[(p0 < DUMP && q >= rg.x && q < rg.y) ? p0 : DUMP] = st.v[j].x;
+            buf[(p1 < DUMP && q + 1u >= rg.x && q + 1u < rg.y) ? p1 : DUMP] = st.v[j].y;
+            buf[(p2 < DUMP && q + 2u >= rg.x && q + 2u < rg.y) ? p2 : DUMP] = st.v[j].z;
+            buf[(p3 < DUMP && q + 3u >= rg.x && q + 3u < rg.y) ? p3 : DUMP] = st.v[j].w;
         }
 #pragma unroll
-        for (int k = 0; k < HP; ++k)
-            buf[st.rec[k] != 0xFFFFFFFFu ? (st.rec[k] >> 18) : PB_SEQ_BUF] = hv[k];
+        for (int j = 0; j < HP; ++j)
+            buf[(ht.at[j / 2] >> ((j & 1) * 16)) & 0xFFFFu] = ht.x[j];
         // a block with more than 1024 hot terms (rare: more than half of its terms): the rest without the pipeline
-        for (uint32_t h = st.range.z + (uint32_t)HP * PB_SEQ_WG + tid; h < st.range.w; h += PB_SEQ_WG) {
+        for (uint32_t h = rg.z + (uint32_t)HP * PB_SEQ_WG + tid; h < rg.w; h += PB_SEQ_WG) {
             const uint32_t rec = hh_ent[h];
             buf[rec >> 18] = hot_x[rec & 0x3FFFFu];
         }
@@ -1444,43 +1474,37 @@ __global__ __launch_bounds__(PB_SEQ_WG) void pb_hubseq_kernel(const float *__res
             if (at + j < end)
                 buf[at + j] = 0.0f;
     };
-    uint32_t info = 0, info_a = 0, info_b = 0; // row info of the block in the buffer / staged in sa / in sb
-    float hv[HP];
-    if (tid < kWave)
-        __builtin_amdgcn_s_setprio(3); // the walk is the group's critical path: first in line at its SIMD's issue
-    load(0, sa);
-    if (walker) {
-        info = ri[tid];
+    // block 0 without the pipeline, then the pipeline's state at round 0: R(2) in flight, G(1), V(1), I(1) behind it
+    uint32_t info, info_a = 0, info_b = 0; // row table of the block in the buffer / of the block in sa / sb
+    issue_r(0);
+    issue_v(0, sa);
+    info = issue_i(0);
+    issue_g(0, ha);
+    if (walker)
         pads(info);
-    }
-    gather(sa, hv);
-    scatter(sa, hv);
-    if (nb > 1u) {
-        load(1u, sa);
-        if (walker)
-            info_a = ri[(size_t)PB_HUB_MAX + tid];
-    }
+    scatter(0, sa, ha);
+    issue_r(1u);
+    issue_g(1u, ha);
+    issue_r(2u);
+    issue_v(1u, sa);
+    info_a = issue_i(1u);
     lds_barrier();
     float S = 0.0f; // page_rank.rs:143: the row's sum starts at zero ...
     const f32x4 *b4 = reinterpret_cast<const f32x4 *>(buf);
-    // one block: `cur` holds block b + 1 (requested one round ago), block b + 2 is requested into `nxt`, block b is walked
-    auto round = [&](uint32_t b, Staged &cur, uint32_t &info_cur, Staged &nxt, uint32_t &info_nxt) {
+    // round b: `cur` / `hcur` / `info_cur` hold block b + 1 (requested one round ago), block b + 2 goes into `nxt` / `hnxt`
+    auto round = [&](uint32_t b, Stream &cur, Hot &hcur, uint32_t &info_cur, Stream &nxt, Hot &hnxt, uint32_t &info_nxt) {
+        issue_g(b + 2u, hnxt);
+        issue_r(b + 3u);
+        issue_v(b + 2u, nxt);
+        info_nxt = issue_i(b + 2u);
         const bool more = b + 1u < nb;
-        if (b + 2u < nb) {
-            load(b + 2u, nxt);
-            if (walker)
-                info_nxt = ri[(size_t)(b + 2u) * PB_HUB_MAX + tid];
-        }
-        if (more)
-            gather(cur, hv); // its records arrived during the last round; the values arrive during this walk
         if (walker) {
             uint32_t k = (info >> 16) / 4u;
             const uint32_t end = k + (((info & 0xFFFFu) + PB_SEQ_PAD - 1u) / PB_SEQ_PAD) * (PB_SEQ_PAD / 4u);
             if (k < end) {
                 // Two register sets in turn, no copies: the next step's 16 terms are requested before this step's are added
                 // (16 dependent v_add_f32).  Every term is added to the sum in CSR order, each add rounded to f32
-                // (page_rank.rs:144-146).  (Three sets, two steps of lookahead, measured the same per term and cost the
-                // registers that let this kernel's wavefront sit beside the other two kernels' on a SIMD.)
+                // (page_rank.rs:144-146).
                 constexpr uint32_t Q = PB_SEQ_PAD / 4u;
                 f32x4 a0, a1, a2, a3, n0, n1, n2, n3;
 #define GM_SEQ_GET(x0, x1, x2, x3, at) x0 = b4[at], x1 = b4[(at) + 1], x2 = b4[(at) + 2], x3 = b4[(at) + 3]
@@ -1512,14 +1536,14 @@ __global__ __launch_bounds__(PB_SEQ_WG) void pb_hubseq_kernel(const float *__res
         }
         lds_barrier(); // the walk is over: the buffer may be overwritten
         if (more)
-            scatter(cur, hv);
+            scatter(b + 1u, cur, hcur);
         info = info_cur;
         lds_barrier();
     };
     for (uint32_t b = 0; b < nb; b += 2u) {
-        round(b, sa, info_a, sb, info_b);
+        round(b, sa, ha, info_a, sb, hb, info_b);
         if (b + 1u < nb)
-            round(b + 1u, sb, info_b, sa, info_a);
+            round(b + 1u, sb, hb, info_b, sa, ha, info_a);
     }
     double err = 0.0;
     if (walker)
@@ -1527,6 +1551,8 @@ __global__ __launch_bounds__(PB_SEQ_WG) void pb_hubseq_kernel(const float *__res
     const double total = block_sum<double, PB_SEQ_WG / kWave>(err, red);
     if (tid == 0)
         group_err[item.group] = total;
+    lds_barrier();
+    } // groups of this workgroup
 }
 
 // ---- long rows: the same sums, in parallel ----------------------------------------------------------------------------
@@ -1548,7 +1574,7 @@ __global__ __launch_bounds__(PB_LONG_WG) __attribute__((amdgpu_waves_per_eu(5, 8
                                                                 const uint32_t *__restrict__ hub_rows,
                                                                 const uint32_t *__restrict__ outdeg, float *__restrict__ scores,
                                                                 float *__restrict__ x_out, double *__restrict__ group_err, float base,
-                                                                float damping)
+                                                                float damping, uint32_t n_rows)
 {
     constexpr uint32_t NWV = PB_LONG_WG / kWave, PER = PB_LONG_PER, SUPER = PB_LONG_WG * PER, SAT = 1u << 30, NONE = 0xFFFFFFFFu;
     constexpr uint32_t WARM = 1024 / PER; // threads whose terms (the row's first 1024) are added one after the other, see below
@@ -1560,8 +1586,10 @@ __global__ __launch_bounds__(PB_LONG_WG) __attribute__((amdgpu_waves_per_eu(5, 8
     constexpr uint32_t TOWN = PB_LONG_WG * 4 / PER; // threads that own the 2048 terms of one round
     __shared__ __attribute__((aligned(16))) float tbuf[TOWN * TROW]; // 2048 terms of the super-block at a time: 10 KiB
     static_assert(PB_LONG_WG == 512 && (PB_LONG_PER == 16 || PB_LONG_PER == 32) && WARM <= (uint32_t)kWave, "turning buffer / warm-up layout");
-    const PbHubItem item = items[blockIdx.x]; // one row: slot 0 (padding entries: PB_NULL)
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    uint32_t flip = 0;
+    for (uint32_t row = blockIdx.x; row < n_rows; row += gridDim.x) { // (a grid smaller than the rows: pb_hub_dispatch)
+    const PbHubItem item = items[row]; // one row: slot 0 (padding entries: PB_NULL)
     // (counts from an even / odd start) of run F followed by run G; saturated: beyond the first run that leaves the binade
     // nothing is used
     auto compose = [&](uint32_t f0, uint32_t f1, uint32_t g0, uint32_t g1, uint32_t &h0, uint32_t &h1) {
@@ -1614,7 +1642,6 @@ __global__ __launch_bounds__(PB_LONG_WG) __attribute__((amdgpu_waves_per_eu(5, 8
         }
     };
     float S = 0.0f; // page_rank.rs:143
-    uint32_t flip = 0;
     float v[PER];
     fetch(item.q0);
     for (uint32_t sb = item.q0; sb < item.q1; sb += SUPER) {
@@ -1760,6 +1787,8 @@ __global__ __launch_bounds__(PB_LONG_WG) __attribute__((amdgpu_waves_per_eu(5, 8
     }
     if (tid == 0)
         group_err[item.group] = pr_finalize(hub_rows[item.row0], S, base, damping, outdeg, scores, x_out);
+    lds_barrier();
+    } // rows of this workgroup
 }
 
 __global__ __launch_bounds__(1024) void pb_err_kernel(const double *__restrict__ bin_err, uint32_t B, double *__restrict__ err_out)
@@ -2973,6 +3002,24 @@ void pb_plan_info(const PbPlan *pl, const PbScratch *sc, uint64_t *info, uint32_
         info[i] = i < sizeof(v) / sizeof(v[0]) ? v[i] : 0;
 }
 
+// A launch whose packet does not carry the barrier bit (hipExtAnyOrderLaunch): it may start while the launches in front of
+// it ON THE SAME STREAM are still running; the next ordinary launch of the stream waits for all of them.  That is the fork
+// and the join of the accumulate phase (accumulate kernel beside the two hub kernels) without a second stream: the events
+// that carried them cost 10-20 us each way (profiles/r04_*timeline*), a tenth of a sweep at scale 22.
+template <typename... P, typename... A>
+static hipError_t pb_launch_flags(void (*kernel)(P...), dim3 grid, dim3 block, size_t lds, hipStream_t st, bool any_order, A... a)
+{
+    static_assert(sizeof...(P) == sizeof...(A), "argument count");
+    std::tuple<P...> vals(static_cast<P>(a)...);
+    return std::apply(
+        [&](auto &...v) {
+            void *ptrs[] = {(void *)&v...};
+            return hipExtLaunchKernel(reinterpret_cast<const void *>(kernel), grid, block, ptrs, lds, st, nullptr, nullptr,
+                                      any_order ? hipExtAnyOrderLaunch : 0);
+        },
+        vals);
+}
+
 template <int ABL, int S_LOG>
 void pb_launch_bin(const PbPlan *pl, PbScratch *sc, const float *x_in, uint32_t w_first, uint32_t w_count, hipStream_t st,
                    const uint32_t *item_list = nullptr, bool fold_hot = false)
@@ -2991,14 +3038,14 @@ void pb_launch_bin(const PbPlan *pl, PbScratch *sc, const float *x_in, uint32_t 
 
 template <int ABL, int D = PB_ACC_DEPTH, bool BF = false>
 void pb_launch_accum(const PbPlan *pl, PbScratch *sc, const PbItem *items, uint32_t count, float *x_out, float *scores,
-                     const uint32_t *outdeg, float base, float damping, hipStream_t st)
+                     const uint32_t *outdeg, float base, float damping, hipStream_t st, bool any_order = false)
 {
-    hipLaunchKernelGGL((pb_accum_kernel<ABL, D, BF>), dim3(count), dim3(PB_ACC_BLOCK),
-                       (size_t)pl->Racc * 8 + 16 + (((size_t)pl->H + 3) & ~(size_t)3) * 4 * (pl->T > 1 ? 2 : 1), st, sc->vals,
-                       pl->p2_dst.as<uint16_t>(),
-                       items, pl->hot_ent.as<uint32_t>(), pl->hbin_v.as<uint32_t>(), sc->hot_x.as<float>(), pl->H, pl->T, pl->Htot,
-                       sc->partials.as<unsigned long long>(), sc->tickets.as<uint32_t>(), pl->cidx.as<uint16_t>(), outdeg,
-                       scores, x_out, sc->bin_err.as<double>(), pl->n_local, pl->R, pl->Racc, base, damping);
+    (void)pb_launch_flags(pb_accum_kernel<ABL, D, BF>, dim3(count), dim3(PB_ACC_BLOCK),
+                          (size_t)pl->Racc * 8 + 16 + (((size_t)pl->H + 3) & ~(size_t)3) * 4 * (pl->T > 1 ? 2 : 1), st, any_order,
+                          sc->vals, pl->p2_dst.as<uint16_t>(), items, pl->hot_ent.as<uint32_t>(), pl->hbin_v.as<uint32_t>(),
+                          sc->hot_x.as<float>(), pl->H, pl->T, pl->Htot, sc->partials.as<unsigned long long>(),
+                          sc->tickets.as<uint32_t>(), pl->cidx.as<uint16_t>(), outdeg, scores, x_out, sc->bin_err.as<double>(),
+                          pl->n_local, pl->R, pl->Racc, base, damping);
 }
 
 // GM_PB_ABLATE = 10*accumulate variant + bin variant; 0 = the product kernels (re-read per call so that
@@ -3030,7 +3077,8 @@ static bool pb_bin_dispatch(const PbPlan *pl, PbScratch *sc, const float *x_in, 
 }
 
 static void pb_accum_dispatch(const PbPlan *pl, PbScratch *sc, const PbItem *items, uint32_t count, float *x_out,
-                              float *scores, const uint32_t *outdeg, float base, float damping, hipStream_t st)
+                              float *scores, const uint32_t *outdeg, float base, float damping, hipStream_t st,
+                              bool any_order = false)
 {
     if (count == 0)
         return;
@@ -3045,7 +3093,7 @@ static void pb_accum_dispatch(const PbPlan *pl, PbScratch *sc, const PbItem *ite
             if (pb_env("GM_PB_ACC_BRANCHFREE", 0))
                 pb_launch_accum<0, PB_ACC_DEPTH, true>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st);
             else
-                pb_launch_accum<0>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st);
+                pb_launch_accum<0>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st, any_order);
             break;
         }
         break;
@@ -3053,12 +3101,38 @@ static void pb_accum_dispatch(const PbPlan *pl, PbScratch *sc, const PbItem *ite
 }
 
 // every hub group of the plan (its value-stream part must have been written: after the bin kernel)
-static void pb_hub_dispatch(const PbPlan *pl, PbScratch *sc, float *x_out, float *scores, const uint32_t *outdeg, float base,
-                            float damping, hipStream_t st)
+// `inline_any`: both kernels on `st`, the second one (and, by the caller, the accumulate kernel behind them) launched in any
+// order; returns whether anything was launched (the first launch behind the bin kernel must be an ordered one)
+static bool pb_hub_dispatch(const PbPlan *pl, PbScratch *sc, float *x_out, float *scores, const uint32_t *outdeg, float base,
+                            float damping, hipStream_t st, bool inline_any = false)
 {
     double *gerr = sc->bin_err.as<double>() + pl->B;
     const PbHubItem *items = pl->hub_items.as<PbHubItem>();
     const int skip = pb_env("GM_PB_HUB_SKIP", 0); // measurement (wrong results by design): 1 = no pb_hubseq_kernel, 2 = no long rows
+    // GM_PB_LONG_WGS / GM_PB_SEQ_WGS: workgroups of the two kernels (0 = one per row / group)
+    const uint32_t n_seq = pl->G - pl->G_long;
+    uint32_t long_wgs = (uint32_t)pb_env("GM_PB_LONG_WGS", 0), seq_wgs = (uint32_t)pb_env("GM_PB_SEQ_WGS", 0);
+    long_wgs = long_wgs && long_wgs < pl->G_long ? long_wgs : pl->G_long;
+    seq_wgs = seq_wgs && seq_wgs < n_seq ? seq_wgs : n_seq;
+    const uint32_t v_safe = (uint32_t)(pl->Mv >= 4 ? (pl->Mv - 4) & ~3ull : 0), h_safe = (uint32_t)(pl->Mhh ? pl->Mhh - 1u : 0u);
+    if (inline_any) {
+        bool launched = false;
+        if (pl->G_long && !(skip & 2)) {
+            (void)pb_launch_flags(pb_hublong_kernel, dim3(long_wgs), dim3(PB_LONG_WG), 0, st, launched, sc->vals,
+                                  pl->p2_dst.as<uint16_t>(), items, pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr, base,
+                                  damping, pl->G_long);
+            launched = true;
+        }
+        if (pl->G > pl->G_long && !(skip & 1)) {
+            (void)pb_launch_flags(pb_hubseq_kernel, dim3(seq_wgs), dim3(PB_SEQ_WG), 0, st, launched, sc->vals,
+                                  pl->p2_dst.as<uint16_t>(), items + pl->G_long, pl->seq_blk_first.as<uint32_t>(),
+                                  pl->seq_blk.as<uint4>(), pl->seq_rows.as<uint32_t>(), pl->hh_ent.as<uint32_t>(),
+                                  sc->hot_x.as<float>(), pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr, base, damping,
+                                  v_safe, h_safe, n_seq, (uint32_t)pb_env("GM_PB_SEQ_PRIO", 1));
+            launched = true;
+        }
+        return launched;
+    }
     // the long rows on a stream of their own beside the other groups (when there are both)
     const bool own = pl->G_long && sc->chain;
     hipStream_t ls = own ? sc->chain : st;
@@ -3067,18 +3141,19 @@ static void pb_hub_dispatch(const PbPlan *pl, PbScratch *sc, float *x_out, float
             (void)hipEventRecord(sc->ev_chain_fork, st);
             (void)hipStreamWaitEvent(ls, sc->ev_chain_fork, 0);
         }
-        hipLaunchKernelGGL(pb_hublong_kernel, dim3(pl->G_long), dim3(PB_LONG_WG), 0, ls, sc->vals, pl->p2_dst.as<uint16_t>(), items,
-                           pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr, base, damping);
+        hipLaunchKernelGGL(pb_hublong_kernel, dim3(long_wgs), dim3(PB_LONG_WG), 0, ls, sc->vals, pl->p2_dst.as<uint16_t>(), items,
+                           pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr, base, damping, pl->G_long);
         if (own)
             (void)hipEventRecord(sc->ev_chain_join, ls);
     }
     if (pl->G > pl->G_long && !(skip & 1))
-        hipLaunchKernelGGL(pb_hubseq_kernel, dim3(pl->G - pl->G_long), dim3(PB_SEQ_WG), 0, st, sc->vals, pl->p2_dst.as<uint16_t>(),
+        hipLaunchKernelGGL(pb_hubseq_kernel, dim3(seq_wgs), dim3(PB_SEQ_WG), 0, st, sc->vals, pl->p2_dst.as<uint16_t>(),
                            items + pl->G_long, pl->seq_blk_first.as<uint32_t>(), pl->seq_blk.as<uint4>(), pl->seq_rows.as<uint32_t>(),
                            pl->hh_ent.as<uint32_t>(), sc->hot_x.as<float>(), pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr,
-                           base, damping);
+                           base, damping, v_safe, h_safe, n_seq, (uint32_t)pb_env("GM_PB_SEQ_PRIO", 1));
     if (pl->G_long && !(skip & 2) && own)
         (void)hipStreamWaitEvent(st, sc->ev_chain_join, 0);
+    return true;
 }
 
 static void pb_hot_dispatch(const PbPlan *pl, PbScratch *sc, const float *x_in, hipStream_t st)
@@ -3109,6 +3184,12 @@ int pb_sweep_main(const PbPlan *pl, PbScratch *sc, const float *x_in, float *x_o
     // (measured at scale 26 / 22 on one box: 3.12 / 3.24 ms forked vs 3.33 / 3.44 ms in line, 0.216 vs 0.252 ms;
     // with the 85-VGPR version of the kernel the two could not share a CU and forking gained nothing)
     const bool fork = pl->G && sc->side && pl->hub_edges >= (1u << 20) && pb_env("GM_PB_HUB_FORK", 1);
+    if (pl->G && pb_env("GM_PB_ANYORDER", 0)) {
+        const bool any = pb_hub_dispatch(pl, sc, x_out, scores, outdeg, base, damping, st, true);
+        pb_accum_dispatch(pl, sc, pl->items.as<PbItem>(), pl->NI, x_out, scores, outdeg, base, damping, st, any);
+        GM_HIP(hipGetLastError());
+        return GM_OK;
+    }
     if (fork) {
         GM_HIP(hipEventRecord(sc->ev_fork, st));
         GM_HIP(hipStreamWaitEvent(sc->side, sc->ev_fork, 0));
@@ -3241,10 +3322,12 @@ int pb_sweep_accum_part(const PbPlan *pl, PbScratch *sc, const float *x_in, floa
              sc->part_off.empty() ? (size_t)0 : sc->part_off.size() - 1);
     if (stage_hot)
         pb_hot_dispatch(pl, sc, x_in, st);
+    bool any = false;
     if (part == 0) // every hub row is finished with the first part: before any region of x_out is exchanged
-        pb_hub_dispatch(pl, sc, x_out, scores, outdeg, base, damping, st);
+        any = pb_hub_dispatch(pl, sc, x_out, scores, outdeg, base, damping, st, pl->G && pb_env("GM_PB_ANYORDER", 0)) &&
+              pl->G && pb_env("GM_PB_ANYORDER", 0);
     const uint32_t i0 = sc->part_off[part], i1 = sc->part_off[part + 1];
-    pb_accum_dispatch(pl, sc, sc->part_items.as<PbItem>() + i0, i1 - i0, x_out, scores, outdeg, base, damping, st);
+    pb_accum_dispatch(pl, sc, sc->part_items.as<PbItem>() + i0, i1 - i0, x_out, scores, outdeg, base, damping, st, any);
     GM_HIP(hipGetLastError());
     return GM_OK;
 }

@@ -12,7 +12,9 @@ from graph_amd.engine import PageRankEngine
 kind = sys.argv[1]
 os.environ["GM_PB_NOCACHE"] = "1"
 os.environ["GM_PB_HUB_LONG"] = "4096" if kind == "long" else "1000000000"
-hubs = 1 if kind == "long" else 3
+hubs = int(os.environ.get("HUBS", "0")) or (1 if kind == "long" else 3)  # HUBS=<rows>: that many rows of N terms each
+if "HUBS" in os.environ:
+    os.environ.setdefault("GM_PB_HUB_GROUP", str(1 << 30))  # ... in one group (up to 64 rows)
 for N in [int(a) for a in sys.argv[2:]]:
     n = hubs + N
     s = np.repeat(np.arange(hubs, n, dtype=np.uint32), hubs)
