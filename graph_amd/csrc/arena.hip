@@ -300,6 +300,15 @@ int arena_grow(int dev, size_t count, uint64_t *first_serial_out)
     std::lock_guard<std::mutex> lock(a.mu);
     if (first_serial_out)
         *first_serial_out = a.next_serial;
+    // an experiment's memory (pb_scratch_create tries fresh stretches when every candidate of the pool is slow): never more
+    // than half of what the device has free right now — the plain allocations that follow must still fit
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+        (void)hipGetLastError();
+        return GM_ERR_NOMEM;
+    }
+    if (count * ARENA_PIECE > free_b / 2)
+        return GM_ERR_NOMEM;
     return create_pieces(a, dev, count);
 }
 

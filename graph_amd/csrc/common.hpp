@@ -555,8 +555,16 @@ struct WccScratch {
     DevBuf work;   // chunk count + chunk items + sample buffer (wcc.hip:wcc_device)
     DevBuf labels; // u32[n] of gm_wcc_afforest / gm_wcc_baseline
 };
+// every adjacency list of a weighted CSR once more, ordered by weight (sssp.hip: the edges a node relaxes while its phase is
+// busy are then a PREFIX of its list, the others a suffix); immutable once built, kept in the handle like the PageRank plan
+struct SsspOrder {
+    DevBuf targets, weights;
+    // ... and transposed (in_off u32[n + 1], the sources and weights of every node's in-edges, in no particular order):
+    // the far round pulls (sssp.hip)
+    DevBuf in_off, in_src, in_w;
+};
 struct SsspScratch {
-    DevBuf dist, flags, wmin, hflags, settled, done, ctrl, chunks, queues;
+    DevBuf dist, flags, wmin, hflags, fflags, settled, done, ctrl, chunks, queues;
     PinnedBuf hctrl;
     size_t items = 0; // capacity of `chunks` in work items; 0: not (completely) allocated
 };
@@ -579,6 +587,7 @@ struct gm_csr {
     mutable std::atomic<uint64_t> page_rank_calls{0}; // gm_page_rank calls seen by this handle (engine choice); calls may run concurrently
     mutable std::atomic<int> weights_ok{0};                // 1: gm_sssp_delta_stepping has seen that no weight is negative or NaN
     mutable std::unique_ptr<gm::SsspScratch> sssp_scratch; // parked between calls (under cache_mu)
+    mutable std::shared_ptr<const gm::SsspOrder> sssp_order; // likewise; built by the first gm_sssp_delta_stepping call
     mutable std::unique_ptr<gm::WccScratch> wcc_scratch;   // likewise
     mutable std::shared_ptr<gm::PrCallState> pr_call;      // likewise (stream, vectors, engine + its scratch)
     mutable std::shared_ptr<const gm::TcDag> tc_dag;       // the DAG of lower prefixes + list records of gm_triangle_count

@@ -227,6 +227,7 @@ GM_API int gm_csr_trim(const gm_csr *csr)
     // taken out under the lock, destroyed outside it (a destructor may synchronise the device)
     std::map<uint64_t, std::shared_ptr<const gm::PbPlan>> plans;
     std::unique_ptr<gm::SsspScratch> sssp;
+    std::shared_ptr<const gm::SsspOrder> sssp_order;
     std::unique_ptr<gm::WccScratch> wcc;
     std::shared_ptr<gm::PrCallState> pr;
     std::shared_ptr<const gm::TcDag> dag;
@@ -236,6 +237,7 @@ GM_API int gm_csr_trim(const gm_csr *csr)
         multi = std::move(csr->multi);
         plans.swap(csr->pb_plans);
         sssp = std::move(csr->sssp_scratch);
+        sssp_order = std::move(csr->sssp_order);
         wcc = std::move(csr->wcc_scratch);
         pr = std::move(csr->pr_call);
         dag = std::move(csr->tc_dag);

@@ -525,7 +525,8 @@ __global__ void pb_segval_kernel(const uint64_t *__restrict__ segkey_sorted, uin
 // segments in phase-1 order (rank r): cnt[r]; tile_seg[t] = first rank of tile t
 // padded (multiple of 4) segment sizes: cnt_p1[r] in phase-1 order, cnt_v[j] in bin-major order
 __global__ void pb_seg_counts_kernel(const uint32_t *__restrict__ segval_sorted, const uint32_t *__restrict__ vstart,
-                                     uint32_t NS, uint32_t m, uint32_t *__restrict__ cnt_p1, uint32_t *__restrict__ cnt_v)
+                                     uint32_t NS, uint32_t m, uint32_t *__restrict__ cnt_p1, uint32_t *__restrict__ cnt_v,
+                                     uint32_t pad)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r <= NS; r += stride) {
@@ -536,9 +537,9 @@ __global__ void pb_seg_counts_kernel(const uint32_t *__restrict__ segval_sorted,
         }
         const uint32_t j = segval_sorted[r];
         const uint32_t end = j + 1 < NS ? vstart[j + 1] : m;
-        cnt_p1[r] = (end - vstart[j] + PB_VEC - 1u) & ~(PB_VEC - 1u);
+        cnt_p1[r] = (end - vstart[j] + pad - 1u) & ~(pad - 1u);
         const uint32_t end2 = r + 1 < NS ? vstart[r + 1] : m; // r doubles as a bin-major index here
-        cnt_v[r] = (end2 - vstart[r] + PB_VEC - 1u) & ~(PB_VEC - 1u);
+        cnt_v[r] = (end2 - vstart[r] + pad - 1u) & ~(pad - 1u);
     }
 }
 
@@ -2382,7 +2383,9 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     GM_TRY(rank_of.alloc_scratch((size_t)NS * 4));
     GM_TRY(pl->delta.alloc((size_t)NS * 4));
     hipLaunchKernelGGL(pb_seg_counts_kernel, dim3(gs), dim3(256), 0, 0, segval.as<uint32_t>(), vstart.as<uint32_t>(), NS,
-                       m, cnt.as<uint32_t>(), cntv.as<uint32_t>());
+                       m, cnt.as<uint32_t>(), cntv.as<uint32_t>(),
+                       // GM_PB_SEGPAD=8 (measurement): every segment starts on a 32-byte sector of the value stream
+                       pb_env("GM_PB_SEGPAD", (int)PB_VEC) == 8 ? 8u : PB_VEC);
     GM_HIP(hipGetLastError());
     GM_TRY(scan_exclusive<uint32_t>(cnt.as<uint32_t>(), cs.as<uint32_t>(), (uint64_t)NS + 1));
     hipLaunchKernelGGL(pb_bounds_kernel, dim3(gs), dim3(256), 0, 0, segkey.as<uint64_t>(), NS, tile_shift, pl->NT,

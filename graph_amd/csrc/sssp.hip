@@ -28,6 +28,8 @@
 #include "common.hpp"
 #include "device_utils.hpp"
 
+#include <rocprim/rocprim.hpp>
+
 #include <cstdlib>
 
 namespace {
@@ -66,12 +68,14 @@ __device__ __forceinline__ void relax_checked(uint32_t *dist, uint32_t *flags, u
 // of the running phase move again), R_HEAVY = only the others (relaxed once per phase, when it has run dry, with the
 // source's final distance), R_ALL = every edge.  The targets and weights of the skipped edges are streamed, their
 // distances not probed.
-enum : int { R_ALL = 0, R_LIGHT = 1, R_HEAVY = 2 };
+// R_NEAR (lists ordered by weight, a cut above the threshold): the heavy edges up to the cut, thr < candidate <= cut;
+// with R_HEAVY and cut != NO_BUCKET... the far round: only the candidates beyond `cut`.
+enum : int { R_ALL = 0, R_LIGHT = 1, R_HEAVY = 2, R_NEAR = 3, R_FAR = 4 };
 constexpr int SSSP_MLP = 4;
 __device__ __forceinline__ void relax_range(const uint32_t *__restrict__ tgt, const float *__restrict__ w, uint32_t *dist,
                                             uint32_t *flags, uint32_t *wmin, float du, uint32_t first, uint32_t end,
                                             uint32_t step, uint32_t thr, int which, const uint32_t *__restrict__ final_bits,
-                                            RelaxOut &ro)
+                                            RelaxOut &ro, uint32_t cut = NO_BUCKET)
 {
     for (uint32_t i = first; i < end; i += step * SSSP_MLP) {
         uint32_t t[SSSP_MLP], nb[SSSP_MLP], pre[SSSP_MLP];
@@ -81,7 +85,11 @@ __device__ __forceinline__ void relax_range(const uint32_t *__restrict__ tgt, co
             const bool in = j < end;
             t[k] = in ? tgt[j] : 0u;
             nb[k] = in ? __float_as_uint(__fadd_rn(du, w[j])) : 0xFFFFFFFFu;
-            if (which == R_LIGHT ? nb[k] > thr : which == R_HEAVY ? nb[k] <= thr : false)
+            if (which == R_LIGHT ? nb[k] > thr
+                : which == R_HEAVY ? nb[k] <= thr
+                : which == R_NEAR  ? (nb[k] <= thr || nb[k] > cut)
+                : which == R_FAR   ? nb[k] <= cut
+                                   : false)
                 nb[k] = 0xFFFFFFFFu;
         }
         if (final_bits) {
@@ -116,7 +124,12 @@ enum : uint32_t { C_AGAIN = 0, C_FAR = 1, C_BAD = 2, C_THR = 3, C_DONE = 4, C_RO
                   C_MARK = 10 /* C_WORK at the last advance */, C_TICKET = 11 /* workgroups of sssp_finish_kernel done */,
                   C_SNAP = 12 /* 1: the threshold has just moved: the next round copies `settled` into `done` */,
                   C_NDONE = 13 /* bits set in `done` (as of the last completed snapshot: a lower bound) */,
-                  C_NCOUNT = 14 /* ... of the snapshot being taken */ };
+                  C_NCOUNT = 14 /* ... of the snapshot being taken */,
+                  C_CUT = 15 /* f32 bits: heavy rounds relax candidates up to here, the rest waits for the far round; NO_BUCKET: no cut */,
+                  C_FAROWED = 16 /* some node has edges waiting for the far round (fflags) */,
+                  C_CUTUSED = 17 /* the far round has run: no second cut */,
+                  C_WORDS = 32 };
+// C_HEAVY: 0 = light round, 1 = a phase's heavy round, 2 = the far round
 
 // The work-item queue of a round is SSSP_QUEUES sub-queues, node group g appending to sub-queue g % SSSP_QUEUES:
 // each has its own 64-bit counter (low half: items queued this round, high half: out-edges of the nodes taken up — the
@@ -149,23 +162,158 @@ constexpr uint32_t SSSP_CHUNK = 256; // edges per work item (GM_SSSP_CHUNK overr
 
 __device__ __forceinline__ void sssp_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// ---- the far round as a PULL ------------------------------------------------------------------------------------------
+// When the far round runs, nearly every node that will ever be reached has been taken up; the edges that wait (candidates
+// beyond the cut, out of nodes taken up since the cut was set) are a large share of all edges, and pushing them means a
+// bit test per edge (235 M of them at RMAT scale 24: 2.3 ms at the L2's random-access rate).  Seen from the other side the
+// work is small: only a node that has NOT been taken up can still improve, and such a node takes the minimum of
+// dist[s] (+) w over its in-edges — every relaxation that could reach it, waiting or not (extra relaxations are harmless:
+// the distances are the least fixed point).  The in-edges come from the transposed copy of the lists in the handle
+// (SsspOrder::in_*).  One lane per node (16 nodes per lane, a wavefront per 1024 as everywhere); in-lists longer than
+// 256 are read by the whole wavefront.
+__device__ __forceinline__ uint32_t sssp_pull_list(const uint32_t *__restrict__ in_src, const float *__restrict__ in_w,
+                                                   const uint32_t *dist, uint32_t first, uint32_t end, uint32_t step)
+{
+    uint32_t best = NO_BUCKET;
+    for (uint32_t j = first; j < end; j += step * SSSP_MLP) {
+        uint32_t s[SSSP_MLP], ds[SSSP_MLP];
+        float wj[SSSP_MLP];
+#pragma unroll
+        for (int k = 0; k < SSSP_MLP; ++k) {
+            const uint32_t i = j + (uint32_t)k * step;
+            s[k] = i < end ? in_src[i] : 0xFFFFFFFFu;
+            wj[k] = i < end ? in_w[i] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < SSSP_MLP; ++k)
+            ds[k] = s[k] != 0xFFFFFFFFu ? ld_agent(&dist[s[k]]) : SSSP_INF_BITS;
+#pragma unroll
+        for (int k = 0; k < SSSP_MLP; ++k)
+            if (ds[k] != SSSP_INF_BITS) { // sssp.rs:176: an unreached source offers nothing
+                const uint32_t nb = __float_as_uint(__fadd_rn(__uint_as_float(ds[k]), wj[k]));
+                best = nb < best ? nb : best;
+            }
+    }
+    return best;
+}
+
+__device__ __forceinline__ void sssp_pull_apply(uint32_t *dist, uint32_t *flags, uint32_t *wmin, uint32_t t, uint32_t best,
+                                                uint32_t thr, RelaxOut &ro)
+{
+    relax_checked(dist, flags, wmin, best, best != NO_BUCKET ? ld_agent(&dist[t]) : 0u, t, thr, ro);
+}
+
+__device__ void sssp_pull_round(const uint32_t *__restrict__ in_off, const uint32_t *__restrict__ in_src,
+                                const float *__restrict__ in_w, uint32_t *dist, uint32_t *flags, uint32_t *wmin,
+                                const uint32_t *settled, uint32_t nwords, uint32_t n, uint32_t thr, RelaxOut &ro)
+{
+    constexpr uint32_t OWN = 256; // in-edges a lane reads by itself
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t ngroups = (nwords * 2u + kWave - 1) / kWave;
+    const uint32_t sh = (lane & 1u) * 16u;
+    for (uint32_t grp = wave; grp < ngroups; grp += nwaves) {
+        const uint32_t my_word = (grp * kWave + lane) >> 1;
+        const uint32_t base = my_word * 32u + sh;
+        uint32_t un = my_word < nwords ? ~(ld_agent(&settled[my_word]) >> sh) & 0xFFFFu : 0u; // never taken up
+        uint32_t big = 0u;                                                                   // ... with a long in-list
+        for (uint32_t bits = un; bits; bits &= bits - 1u) {
+            const uint32_t c = (uint32_t)__ffs((int)bits) - 1u, t = base + c;
+            if (t >= n)
+                break;
+            const uint32_t s0 = in_off[t], s1 = in_off[t + 1];
+            if (s1 - s0 > OWN) {
+                big |= 1u << c;
+                continue;
+            }
+            if (s1 > s0)
+                sssp_pull_apply(dist, flags, wmin, t, sssp_pull_list(in_src, in_w, dist, s0, s1, 1u), thr, ro);
+        }
+        uint64_t who;
+        while ((who = __ballot(big != 0u)) != 0ull) {
+            const int src_lane = __ffsll((unsigned long long)who) - 1;
+            const uint32_t bbits = __shfl(big, src_lane, kWave), bbase = __shfl(base, src_lane, kWave);
+            const uint32_t c = (uint32_t)__ffs((int)bbits) - 1u, t = bbase + c;
+            if ((int)lane == src_lane)
+                big &= big - 1u;
+            const uint32_t s0 = in_off[t], s1 = in_off[t + 1];
+            const uint32_t best = wave_min(sssp_pull_list(in_src, in_w, dist, s0 + lane, s1, kWave));
+            if (lane == 0)
+                sssp_pull_apply(dist, flags, wmin, t, best, thr, ro);
+        }
+    }
+}
+
+// the transposed lists, once per handle: in-degrees, their exclusive scan (host side: rocprim), then every edge to the next
+// free slot of its target (the order inside an in-list is whatever the atomics make it: a minimum is taken over it)
+__global__ void sssp_in_count_kernel(const uint32_t *__restrict__ tgt, uint64_t m, uint32_t *__restrict__ cnt)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride)
+        atomicAdd(&cnt[tgt[i]], 1u);
+}
+
+__global__ __launch_bounds__(SSSP_BLOCK) void sssp_in_fill_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt,
+                                                                  const float *__restrict__ w, uint32_t n, uint32_t *cursor,
+                                                                  uint32_t *__restrict__ in_src, float *__restrict__ in_w)
+{
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t n_pad = (n + kWave - 1) / kWave * kWave;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_pad; r += stride) {
+        const uint32_t s = r < n ? off[r] : 0u, e = r < n ? off[r + 1] : 0u;
+        const uint32_t len = e - s;
+        if (len <= SSSP_COOP)
+            for (uint32_t i = s; i < e; ++i) {
+                const uint32_t p = atomicAdd(&cursor[tgt[i]], 1u);
+                in_src[p] = r;
+                in_w[p] = w[i];
+            }
+        uint64_t big = __ballot(len > SSSP_COOP);
+        while (big) {
+            const int src = __ffsll((unsigned long long)big) - 1;
+            big &= big - 1;
+            const uint32_t bs = __shfl(s, src, kWave), be = __shfl(e, src, kWave), br = __shfl(r, src, kWave);
+            for (uint32_t i = bs + lane; i < be; i += kWave) {
+                const uint32_t p = atomicAdd(&cursor[tgt[i]], 1u);
+                in_src[p] = br;
+                in_w[p] = w[i];
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(SSSP_BLOCK) void sssp_round_kernel(const uint32_t *__restrict__ off,
                                                                 const uint32_t *__restrict__ tgt,
                                                                 const float *__restrict__ w, uint32_t *dist,
-                                                                uint32_t *flags, uint32_t *wmin, uint32_t *hflags,
+                                                                uint32_t *flags, uint32_t *wmin, uint32_t *hflags, uint32_t *fflags,
                                                                 uint32_t *settled, uint32_t *done, uint32_t done_min,
                                                                 uint32_t nwords, uint2 *__restrict__ chunks,
                                                                 QueueState *__restrict__ qs, uint32_t *ctrl,
-                                                                uint32_t chunk_edges, uint32_t coop)
+                                                                uint32_t chunk_edges, uint32_t coop,
+                                                                const uint32_t *__restrict__ in_off,
+                                                                const uint32_t *__restrict__ in_src,
+                                                                const float *__restrict__ in_w, uint32_t n_nodes)
 {
     __shared__ uint16_t list[SSSP_BLOCK / kWave][SSSP_GROUP];          // node - first node of the group
     __shared__ uint8_t owner[SSSP_BLOCK / kWave][kWave * SSSP_COOP];    // short-list edge slot -> lane holding its node
     if (ld_agent(&ctrl[C_DONE]))
         return; // a round enqueued behind the last one of its batch
     const uint32_t thr = ld_agent(&ctrl[C_THR]);
-    const bool heavy = ld_agent(&ctrl[C_HEAVY]) != 0u;
+    const uint32_t mode = ld_agent(&ctrl[C_HEAVY]);
+    const bool heavy = mode != 0u; // heavy or far round: the nodes come from a bitmap of their own, only long lists
+    uint32_t *owed = mode == 2u ? fflags : hflags;
+    const bool cut_on = mode == 1u && ld_agent(&ctrl[C_CUT]) != NO_BUCKET; // their edges beyond the cut wait for the far round
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wv = threadIdx.x >> 6;
+    if (mode == 2u && in_off) { // the far round as a pull: nothing is queued, the chunk kernel finds no items
+        RelaxOut pro{0u};
+        sssp_pull_round(in_off, in_src, in_w, dist, flags, wmin, settled, nwords, n_nodes, thr, pro);
+        if (__ballot(pro.again != 0) && lane == 0 && !ld_agent(&ctrl[C_AGAIN]))
+            atomicOr(&ctrl[C_AGAIN], 1u);
+        return;
+    }
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t ngroups = (nwords * 2u + kWave - 1) / kWave;
@@ -190,11 +338,17 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_round_kernel(const uint32_t *
         }
         uint32_t near = 0u; // 16 bits
         if (heavy) {
-            near = valid ? (ld_agent(&hflags[my_word]) >> sh) & 0xFFFFu : 0u;
+            near = valid ? (ld_agent(&owed[my_word]) >> sh) & 0xFFFFu : 0u;
             if (!__ballot(near != 0u))
                 continue;
-            if (near)
-                atomicAnd(&hflags[my_word], ~(near << sh));
+            if (near) {
+                atomicAnd(&owed[my_word], ~(near << sh));
+                if (cut_on) {
+                    atomicOr(&fflags[my_word], near << sh);
+                    if (!ld_agent(&ctrl[C_FAROWED]))
+                        atomicOr(&ctrl[C_FAROWED], 1u);
+                }
+            }
         } else {
             const uint32_t lo = valid ? ld_agent(&wmin[my_word]) : NO_BUCKET;
             // every lane opens its half word if the word can hold a node at or below the threshold: all candidate
@@ -372,7 +526,8 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_chunk_kernel(const uint32_t *
                                                                 const uint32_t *__restrict__ done, uint32_t done_min,
                                                                 const uint2 *__restrict__ chunks,
                                                                 const QueueState *__restrict__ qs, uint32_t *ctrl,
-                                                                uint32_t chunk_edges)
+                                                                uint32_t chunk_edges, const uint32_t *__restrict__ tgt_by_w,
+                                                                const float *__restrict__ w_by_w)
 {
     if (ld_agent(&ctrl[C_DONE]))
         return;
@@ -392,7 +547,9 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_chunk_kernel(const uint32_t *
         return;
     const uint32_t q_base = qs->start[lane] - (q_incl - q_items); // slot of item f of sub-queue q = q_base + f
     const uint32_t thr = ld_agent(&ctrl[C_THR]);
-    const bool heavy = ld_agent(&ctrl[C_HEAVY]) != 0u;
+    const uint32_t mode = ld_agent(&ctrl[C_HEAVY]);
+    const bool heavy = mode != 0u;
+    const uint32_t cut = ld_agent(&ctrl[C_CUT]);
     // heavy round: targets ever taken up; light round: targets taken up in earlier phases (once there are enough of them)
     const uint32_t *final_bits = heavy ? settled : (done && ld_agent(&ctrl[C_NDONE]) >= done_min ? done : nullptr);
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -404,7 +561,29 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_chunk_kernel(const uint32_t *
         const float du = __uint_as_float(ld_agent(&dist[ch.x]));
         const uint32_t end_u = off[ch.x + 1];
         const uint32_t end = ch.y + chunk_edges < end_u ? ch.y + chunk_edges : end_u;
-        relax_range(tgt, w, dist, flags, wmin, du, ch.y + lane, end, kWave, thr, heavy ? R_HEAVY : R_LIGHT, final_bits, ro);
+        // Light rounds read the lists ordered by weight (SsspOrder): fl(du + w) does not decrease along such a list, so the
+        // light edges are a prefix — an item whose first edge already lands beyond the threshold has nothing to do: two loads
+        // instead of 256 edges.  The heavy round (nearly every edge of the list) reads the CSR's own, target-ordered lists:
+        // consecutive edges of a hub probe neighbouring words of `settled` (14 lines per item instead of 256).
+        if (!heavy && w_by_w) {
+            if (__float_as_uint(__fadd_rn(du, w_by_w[ch.y])) > thr)
+                continue;
+            relax_range(tgt_by_w, w_by_w, dist, flags, wmin, du, ch.y + lane, end, kWave, thr, R_LIGHT, final_bits, ro);
+            continue;
+        }
+        // A cut above the threshold (sssp_advance sets it once, at the end of the first large phase): the heavy round relaxes
+        // only the candidates up to the cut — a slice of the weight-ordered list, items outside it dropped after two loads —
+        // and the others wait for ONE far round, run when the threshold is about to pass the cut.  By then most targets have
+        // been taken up and are skipped by their bit in `settled` (2 MB, L2) instead of a probe of the 64 MB distance vector:
+        // the heavy round of the large phase had 130 M L2 misses for its 142 M edges (rocprofv3 TCC_MISS, scale 24).
+        if (mode == 1u && cut != NO_BUCKET && w_by_w) {
+            if (__float_as_uint(__fadd_rn(du, w_by_w[ch.y])) > cut || __float_as_uint(__fadd_rn(du, w_by_w[end - 1u])) <= thr)
+                continue;
+            relax_range(tgt_by_w, w_by_w, dist, flags, wmin, du, ch.y + lane, end, kWave, thr, R_NEAR, final_bits, ro, cut);
+            continue;
+        }
+        relax_range(tgt, w, dist, flags, wmin, du, ch.y + lane, end, kWave, thr, mode == 2u ? R_FAR : heavy ? R_HEAVY : R_LIGHT,
+                    final_bits, ro, cut);
     }
     if (__ballot(ro.again != 0) && lane == 0 && !ld_agent(&ctrl[C_AGAIN]))
         atomicOr(&ctrl[C_AGAIN], 1u);
@@ -445,8 +624,13 @@ __global__ void sssp_qstart_kernel(QueueState *qs)
 // adapt_lo / adapt_hi (units of 64 relaxed edges; 0 = fixed width): the step halves when the phase that
 // just ended relaxed more than adapt_hi and doubles when it relaxed less than adapt_lo, within
 // [width_min, width_max] — coarse steps re-relax every edge ~6 times, fine steps leave the chip idle.
-__device__ void sssp_advance(uint32_t *ctrl, QueueState *qs, uint32_t adapt_lo, uint32_t adapt_hi, float width_min,
-                             float width_max)
+struct AdvanceParams {
+    uint32_t adapt_lo, adapt_hi; // units of 64 streamed edges; 0 = fixed width
+    float width_min, width_max;
+    float cut_mult;    // the cut = threshold + cut_mult x width at the end of the first large phase; 0: no cut
+    uint32_t cut_work; // "large": the phase streamed at least this much (units of 64 edges)
+};
+__device__ void sssp_advance(uint32_t *ctrl, QueueState *qs, const AdvanceParams p)
 {
     // 64 threads: thread q reads and clears sub-queue q's counter; thread 0 does the rest
     const uint64_t round_work = wave_sum((uint64_t)(qs->ctr[threadIdx.x * SSSP_QSTRIDE] >> 32));
@@ -460,32 +644,56 @@ __device__ void sssp_advance(uint32_t *ctrl, QueueState *qs, uint32_t adapt_lo, 
     }
     ctrl[C_SNAP] = 0u;
     const uint32_t far = ld_agent(&ctrl[C_FAR]); // folded in by other workgroups of this launch: not through L1
-    if (!ctrl[C_HEAVY]) {
-        if (!ctrl[C_AGAIN])
+    const uint32_t mode = ctrl[C_HEAVY];
+    if (mode == 0u) {
+        if (!ctrl[C_AGAIN]) {
             ctrl[C_HEAVY] = 1u; // the phase has run dry: next, the heavy round of the nodes it took up
+            // ... which, from the first large phase on, stops at a cut above the threshold (sssp_chunk_kernel): once per call
+            if (p.cut_mult > 0.0f && ctrl[C_CUT] == NO_BUCKET && !ctrl[C_CUTUSED] && ctrl[C_WORK] - ctrl[C_MARK] >= p.cut_work) {
+                const float c = __fadd_rn(__uint_as_float(ctrl[C_THR]), p.cut_mult * __uint_as_float(ctrl[C_WIDTH]));
+                if (c < 3.0e38f && __float_as_uint(c) > ctrl[C_THR])
+                    ctrl[C_CUT] = __float_as_uint(c);
+            }
+        }
     } else {
+        const bool after_far = mode == 2u;
+        if (after_far) { // every waiting edge has been relaxed: from here on heavy rounds are whole again
+            ctrl[C_FAROWED] = 0u;
+            ctrl[C_CUT] = NO_BUCKET;
+            ctrl[C_CUTUSED] = 1u;
+        }
         ctrl[C_HEAVY] = 0u;
+        const bool owed = ctrl[C_FAROWED] != 0u;
         if (ctrl[C_AGAIN]) {
             // cannot happen (a heavy round only writes distances beyond the threshold); if it did, the phase goes on
         } else if (far == NO_BUCKET) {
-            ctrl[C_DONE] = 1u;
+            if (owed)
+                ctrl[C_HEAVY] = 2u; // nothing pending, but edges are: the far round may still find nodes
+            else
+                ctrl[C_DONE] = 1u;
         } else {
             float width = __uint_as_float(ctrl[C_WIDTH]);
-            if (adapt_hi) {
+            if (p.adapt_hi && !after_far) { // (the far round is not a phase: the step was adapted when the phase before it ended)
                 const uint32_t phase = ctrl[C_WORK] - ctrl[C_MARK];
-                if (phase > adapt_hi)
-                    width = fmaxf(width * 0.5f, width_min);
-                else if (phase < adapt_lo)
-                    width = fminf(width * 2.0f, width_max);
-                ctrl[C_WIDTH] = __float_as_uint(width);
-                ctrl[C_MARK] = ctrl[C_WORK];
+                if (phase > p.adapt_hi)
+                    width = fmaxf(width * 0.5f, p.width_min);
+                else if (phase < p.adapt_lo)
+                    width = fminf(width * 2.0f, p.width_max);
             }
             const float next = __fadd_rn(__uint_as_float(far), width);
             uint32_t nb = __float_as_uint(next);
             nb = nb > far && next < 3.0e38f ? nb : far; // always covers the pending minimum
-            ctrl[C_THR] = nb > ctrl[C_THR] ? nb : ctrl[C_THR];         // (a stale-low word bound never moves it back)
-            ctrl[C_ADVANCES] += 1u;
-            ctrl[C_SNAP] = 1u; // the next round snapshots `settled` into `done` and counts it
+            if (p.adapt_hi) {
+                ctrl[C_WIDTH] = __float_as_uint(width);
+                ctrl[C_MARK] = ctrl[C_WORK];
+            }
+            if (owed && nb > ctrl[C_CUT]) {
+                ctrl[C_HEAVY] = 2u; // the threshold is about to pass the cut: first the edges that wait beyond it
+            } else {
+                ctrl[C_THR] = nb > ctrl[C_THR] ? nb : ctrl[C_THR]; // (a stale-low word bound never moves it back)
+                ctrl[C_ADVANCES] += 1u;
+                ctrl[C_SNAP] = 1u; // the next round snapshots `settled` into `done` and counts it
+            }
         }
     }
     ctrl[C_AGAIN] = 0u;
@@ -499,8 +707,7 @@ __device__ void sssp_advance(uint32_t *ctrl, QueueState *qs, uint32_t adapt_lo, 
 // moves the threshold; after a light round workgroup 0 does the bookkeeping alone.  (Thousands of wavefronts each
 // folding their own minimum into one ctrl word was ~0.1 ms of every round; a separate launch for the bookkeeping ~4 us.)
 __global__ __launch_bounds__(SSSP_BLOCK) void sssp_finish_kernel(const uint32_t *__restrict__ wmin, uint32_t nwords,
-                                                                 uint32_t *ctrl, QueueState *qs, uint32_t adapt_lo,
-                                                                 uint32_t adapt_hi, float width_min, float width_max)
+                                                                 uint32_t *ctrl, QueueState *qs, const AdvanceParams p)
 {
     __shared__ uint32_t part[SSSP_BLOCK / kWave];
     __shared__ uint32_t last;
@@ -508,7 +715,7 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_finish_kernel(const uint32_t 
         return;
     if (!ld_agent(&ctrl[C_HEAVY])) {
         if (blockIdx.x == 0 && threadIdx.x < kWave)
-            sssp_advance(ctrl, qs, adapt_lo, adapt_hi, width_min, width_max);
+            sssp_advance(ctrl, qs, p);
         return;
     }
     uint32_t lo = NO_BUCKET;
@@ -536,7 +743,7 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_finish_kernel(const uint32_t 
         st_agent(&ctrl[C_TICKET], 0u);
     __threadfence();
     if (threadIdx.x < kWave)
-        sssp_advance(ctrl, qs, adapt_lo, adapt_hi, width_min, width_max);
+        sssp_advance(ctrl, qs, p);
 }
 
 // Partitioned building block: relax every out-edge of the slice's rows whose distance is finite
@@ -655,12 +862,76 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
         GM_TRY(sc->hflags.alloc(((size_t)nwords + kWave) * 4));
         GM_TRY(sc->settled.alloc(((size_t)nwords + kWave) * 4));
         GM_TRY(sc->done.alloc(((size_t)nwords + kWave) * 4));
-        GM_TRY(sc->ctrl.alloc(64));
+        GM_TRY(sc->ctrl.alloc(C_WORDS * 4));
+        GM_TRY(sc->fflags.alloc(((size_t)nwords + kWave) * 4));
         GM_TRY(sc->queues.alloc(sizeof(QueueState)));
-        GM_TRY(sc->hctrl.alloc(64));
+        GM_TRY(sc->hctrl.alloc(C_WORDS * 4));
         GM_TRY(sc->chunks.alloc(items * sizeof(uint2)));
         sc->items = items;
     }
+    // The lists once more, ordered by weight (built by the first call on a handle, ~8 B per edge, released by gm_csr_trim):
+    // a long list is relaxed in two parts — while its phase is busy only the edges that land at or below the threshold,
+    // once, when the phase has run dry, the others — and with the thresholds a graph of this kind needs (distances of a
+    // few hundredths under weights uniform in (0, 1]) the first part is a few per cent of the list.  In target order the
+    // whole list is streamed every time its node is taken up (2.9 x m edges per call at RMAT scale 24).  Any order of a
+    // list gives the same distances (the least fixed point does not depend on the schedule).  GM_SSSP_ORDER=0: CSR order, 1: also below 2^20 edges.
+    std::shared_ptr<const gm::SsspOrder> order;
+    const char *ord_env = getenv("GM_SSSP_ORDER");
+    if (g->m && (ord_env ? atoi(ord_env) != 0 : g->m >= ((uint64_t)1 << 20))) { // (small graphs: the rounds are launch-bound anyway)
+        {
+            std::lock_guard<std::mutex> lock(g->cache_mu);
+            order = g->sssp_order;
+        }
+        if (!order) {
+            auto fresh = std::make_shared<gm::SsspOrder>();
+            GM_TRY(fresh->targets.alloc((size_t)g->m * 4));
+            GM_TRY(fresh->weights.alloc((size_t)g->m * 4));
+            size_t temp_bytes = 0;
+            GM_HIP(rocprim::segmented_radix_sort_pairs(nullptr, temp_bytes, g->weights, fresh->weights.as<float>(), g->targets,
+                                                       fresh->targets.as<uint32_t>(), (unsigned int)g->m, (unsigned int)n,
+                                                       g->offsets, g->offsets + 1, 0u, 32u, (hipStream_t)0));
+            gm::DevBuf temp;
+            GM_TRY(temp.alloc(temp_bytes ? temp_bytes : 4));
+            GM_HIP(rocprim::segmented_radix_sort_pairs(temp.p, temp_bytes, g->weights, fresh->weights.as<float>(), g->targets,
+                                                       fresh->targets.as<uint32_t>(), (unsigned int)g->m, (unsigned int)n,
+                                                       g->offsets, g->offsets + 1, 0u, 32u, (hipStream_t)0));
+            if (!(getenv("GM_SSSP_PULL") && atoi(getenv("GM_SSSP_PULL")) == 0)) { // the transposed lists for the far round
+                gm::DevBuf cursor;
+                GM_TRY(fresh->in_off.alloc(((size_t)n + 1) * 4));
+                GM_TRY(fresh->in_src.alloc((size_t)g->m * 4));
+                GM_TRY(fresh->in_w.alloc((size_t)g->m * 4));
+                GM_TRY(cursor.alloc(((size_t)n + 1) * 4));
+                GM_HIP(hipMemsetAsync(cursor.p, 0, ((size_t)n + 1) * 4, (hipStream_t)0));
+                unsigned cg = gm::div_up(g->m, 256);
+                hipLaunchKernelGGL(sssp_in_count_kernel, dim3(cg > 16384 ? 16384 : cg), dim3(256), 0, (hipStream_t)0, g->targets,
+                                   g->m, cursor.as<uint32_t>());
+                size_t scan_bytes = 0;
+                GM_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, cursor.as<uint32_t>(), fresh->in_off.as<uint32_t>(), 0u,
+                                               (size_t)n + 1, rocprim::plus<uint32_t>(), (hipStream_t)0));
+                gm::DevBuf scan_tmp;
+                GM_TRY(scan_tmp.alloc(scan_bytes ? scan_bytes : 4));
+                GM_HIP(rocprim::exclusive_scan(scan_tmp.p, scan_bytes, cursor.as<uint32_t>(), fresh->in_off.as<uint32_t>(), 0u,
+                                               (size_t)n + 1, rocprim::plus<uint32_t>(), (hipStream_t)0));
+                GM_HIP(hipMemcpyAsync(cursor.p, fresh->in_off.p, ((size_t)n + 1) * 4, hipMemcpyDeviceToDevice, (hipStream_t)0));
+                unsigned fg = gm::div_up(n, SSSP_BLOCK);
+                hipLaunchKernelGGL(sssp_in_fill_kernel, dim3(fg > 8192 ? 8192 : fg), dim3(SSSP_BLOCK), 0, (hipStream_t)0,
+                                   g->offsets, g->targets, g->weights, n, cursor.as<uint32_t>(), fresh->in_src.as<uint32_t>(),
+                                   fresh->in_w.as<float>());
+                GM_HIP(hipGetLastError());
+                GM_HIP(hipStreamSynchronize((hipStream_t)0));
+            }
+            GM_HIP(hipStreamSynchronize((hipStream_t)0));
+            if (times)
+                fprintf(stderr, "sssp: lists ordered by weight%s in %.3f ms (kept in the handle)\n",
+                        fresh->in_off.p ? " and transposed" : "", since(t_call));
+            std::lock_guard<std::mutex> lock(g->cache_mu);
+            if (!g->sssp_order)
+                g->sssp_order = fresh;
+            order = g->sssp_order;
+        }
+    }
+    const uint32_t *e_tgt = order ? order->targets.as<uint32_t>() : g->targets;
+    const float *e_w = order ? order->weights.as<float>() : g->weights;
     gm::DevBuf &dist = sc->dist, &flags = sc->flags, &wmin = sc->wmin, &hflags = sc->hflags, &settled = sc->settled,
                &ctrl = sc->ctrl,
                &chunks = sc->chunks;
@@ -697,9 +968,10 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
     }
 
     // ctrl: again 0, far NONE, bad 0, threshold 0.0 (only the start node qualifies), done 0, round 0, advances 0
-    uint32_t init_ctrl[16] = {0u, NO_BUCKET, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    uint32_t init_ctrl[C_WORDS] = {0u, NO_BUCKET};
+    init_ctrl[C_CUT] = NO_BUCKET;
     memcpy(&init_ctrl[C_WIDTH], &width, 4);
-    GM_HIP(hipMemcpyAsync(ctrl.p, init_ctrl, 64, hipMemcpyHostToDevice, st));
+    GM_HIP(hipMemcpyAsync(ctrl.p, init_ctrl, C_WORDS * 4, hipMemcpyHostToDevice, st));
     // the weights of a handle do not change: one look per handle (0.3 ms of a 10 ms call at scale 24)
     const bool check_weights = g->m && g->weights_ok.load(std::memory_order_relaxed) == 0;
     if (check_weights) {
@@ -711,6 +983,7 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
                        (uint32_t)start_node);
     GM_HIP(hipMemsetAsync(flags.p, 0, flags.bytes, st));
     GM_HIP(hipMemsetAsync(hflags.p, 0, hflags.bytes, st));
+    GM_HIP(hipMemsetAsync(sc->fflags.p, 0, sc->fflags.bytes, st));
     GM_HIP(hipMemsetAsync(settled.p, 0, settled.bytes, st));
     GM_HIP(hipMemsetAsync(sc->done.p, 0, sc->done.bytes, st));
     GM_HIP(hipMemsetAsync(qs, 0, sizeof(QueueState), st));
@@ -721,7 +994,7 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
     GM_HIP(hipMemcpyAsync(flags.as<uint32_t>() + (start_node >> 5), &start_bit, 4, hipMemcpyHostToDevice, st));
     GM_HIP(hipMemsetAsync(wmin.p, 0xFF, wmin.bytes, st));
     GM_HIP(hipMemsetAsync(wmin.as<uint32_t>() + (start_node >> 5), 0, 4, st)); // the start node's distance: 0.0
-    GM_HIP(hipMemcpyAsync(hctrl.p, ctrl.p, 64, hipMemcpyDeviceToHost, st));
+    GM_HIP(hipMemcpyAsync(hctrl.p, ctrl.p, C_WORDS * 4, hipMemcpyDeviceToHost, st));
     GM_HIP(hipStreamSynchronize(st));
     GM_CHECK(hctrl.as<uint32_t>()[C_BAD] == 0, GM_ERR_UNSUPPORTED,
              "gm_sssp_delta_stepping: negative or NaN edge weight (the reference assumes weights >= 0)");
@@ -740,30 +1013,46 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
     const int done_div = getenv("GM_SSSP_DONE_DIV") && atoi(getenv("GM_SSSP_DONE_DIV")) > 0 ? atoi(getenv("GM_SSSP_DONE_DIV")) : 8;
     uint32_t *done_bits = done_mode ? sc->done.as<uint32_t>() : nullptr;
     const uint32_t done_min = done_mode >= 2 ? 0u : n / (uint32_t)done_div + 1u;
+    // GM_SSSP_CUT=<multiples of the step> (default 8, 0: heavy rounds are whole): where the cut lies above the threshold of
+    // the first phase that streamed at least m / 8 edges.  Needs the weight-ordered lists (the edges up to the cut are a slice).
+    float cut_mult = order ? 8.0f : 0.0f;
+    if (const char *v = getenv("GM_SSSP_CUT"))
+        cut_mult = order ? (float)atof(v) : 0.0f;
+    const AdvanceParams adv{adapt_lo, adapt_hi, delta / 1024.0f, 1.0e30f, cut_mult > 0.0f ? cut_mult : 0.0f,
+                            (uint32_t)(g->m / 8 / 64) + 1u};
     const bool stats = getenv("GM_SSSP_STATS") != nullptr;
     const int batch = stats ? 1 : 8; // rounds enqueued per host synchronisation
     auto t_prev = std::chrono::steady_clock::now();
     for (;;) {
         for (int k = 0; k < batch; ++k) {
-            hipLaunchKernelGGL(sssp_round_kernel, dim3(round_grid), dim3(SSSP_BLOCK), 0, st, g->offsets, g->targets, g->weights,
+            hipLaunchKernelGGL(sssp_round_kernel, dim3(round_grid), dim3(SSSP_BLOCK), 0, st, g->offsets, e_tgt, e_w,
                                dist.as<uint32_t>(), flags.as<uint32_t>(), wmin.as<uint32_t>(), hflags.as<uint32_t>(),
-                               settled.as<uint32_t>(), done_bits, done_min, nwords,
+                               sc->fflags.as<uint32_t>(), settled.as<uint32_t>(), done_bits, done_min, nwords,
                                chunks.as<uint2>(), qs,
-                               ctrl.as<uint32_t>(), chunk_edges, coop);
+                               ctrl.as<uint32_t>(), chunk_edges, coop,
+                               order && order->in_off.p ? order->in_off.as<uint32_t>() : (const uint32_t *)nullptr,
+                               order && order->in_off.p ? order->in_src.as<uint32_t>() : (const uint32_t *)nullptr,
+                               order && order->in_off.p ? order->in_w.as<float>() : (const float *)nullptr, n);
             hipLaunchKernelGGL(sssp_chunk_kernel, dim3(grid), dim3(SSSP_BLOCK), 0, st, g->offsets, g->targets, g->weights,
                                dist.as<uint32_t>(), flags.as<uint32_t>(), wmin.as<uint32_t>(), use_settled ? settled.as<uint32_t>() : (const uint32_t *)nullptr, done_bits, done_min,
-                               chunks.as<uint2>(), qs, ctrl.as<uint32_t>(), chunk_edges);
+                               chunks.as<uint2>(), qs, ctrl.as<uint32_t>(), chunk_edges,
+                               order ? order->targets.as<uint32_t>() : (const uint32_t *)nullptr,
+                               order ? order->weights.as<float>() : (const float *)nullptr);
             hipLaunchKernelGGL(sssp_finish_kernel, dim3(far_grid), dim3(SSSP_BLOCK), 0, st, wmin.as<uint32_t>(), nwords,
-                               ctrl.as<uint32_t>(), qs, adapt_lo, adapt_hi, delta / 1024.0f, 1.0e30f);
+                               ctrl.as<uint32_t>(), qs, adv);
         }
         GM_HIP(hipGetLastError());
-        GM_HIP(hipMemcpyAsync(hctrl.p, ctrl.p, 64, hipMemcpyDeviceToHost, st));
+        GM_HIP(hipMemcpyAsync(hctrl.p, ctrl.p, C_WORDS * 4, hipMemcpyDeviceToHost, st));
         GM_HIP(hipStreamSynchronize(st));
         const uint32_t *hc = hctrl.as<uint32_t>();
         if (stats) { // batch = 1: wall clock between synchronisations is the round time
             const auto t_now = std::chrono::steady_clock::now();
-            fprintf(stderr, "sssp round %u threshold %.6f: %.3f ms\n", hc[C_ROUND], __builtin_bit_cast(float, hc[C_THR]),
-                    std::chrono::duration<double, std::milli>(t_now - t_prev).count());
+            static thread_local uint32_t work_prev = 0;
+            work_prev = hc[C_ROUND] <= 1 ? 0u : work_prev;
+            fprintf(stderr, "sssp round %u threshold %.6f: %.3f ms, ~%u edges streamed%s\n", hc[C_ROUND],
+                    __builtin_bit_cast(float, hc[C_THR]), std::chrono::duration<double, std::milli>(t_now - t_prev).count(),
+                    (hc[C_WORK] - work_prev) * 64u, hc[C_HEAVY] == 2u ? " (next: far)" : hc[C_HEAVY] ? " (next: heavy)" : "");
+            work_prev = hc[C_WORK];
             t_prev = t_now;
         }
         if (hc[C_DONE])

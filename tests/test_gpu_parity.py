@@ -488,6 +488,69 @@ def test_sssp_final_targets_are_skipped_without_changing_the_result(P, oracle, m
         assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("order", ["0", "1"])
+@pytest.mark.parametrize("width,adapt,chunk", [("0.03125", "0.75,3", "256"), ("0.001", "0.001,0.01", "64"), ("1000", "0,0", "1024"),
+                                               ("0.25", "1,4", "128")])
+def test_sssp_lists_ordered_by_weight_give_the_same_bits(P, oracle, monkeypatch, order, width, adapt, chunk):
+    """GM_SSSP_ORDER=1 (the default from 2^20 edges): every list once more, ordered by weight, so that the edges a node relaxes
+    while its phase is busy are a prefix of its list and a work item whose first edge lands beyond the threshold is dropped
+    after two loads (likewise the all-light items of a heavy round).  The least fixed point does not depend on the order of a
+    list (sssp.rs:170-204 relaxes in CSR order; any order converges to the same distances): the oracle's bits, with weights
+    that tie (multiples of 1/8), zero weights and duplicate edges, under four schedules and item sizes."""
+    scale = 15
+    s, d = oracle.rmat_edges(scale, seed=37)
+    w = oracle.rmat_weights(s.size, seed=38)
+    w[::5] = np.round(w[::5] * 8.0) / 8.0  # ties, and zeros among them
+    n = 1 << scale
+    g = _directed(P, n, s, d, P.CsrLayout.Sorted, w)
+    off, tgt, wv = oracle.csr_build(n, s, d, oracle.OUTGOING, oracle.SORTED, w)
+    assert int(np.diff(off).max()) > 2048
+    start = int(np.flatnonzero(np.diff(off) > 0)[0])
+    ref = oracle.sssp_fixed_point(off, tgt, wv, start)
+    monkeypatch.setenv("GM_SSSP_ORDER", order)
+    monkeypatch.setenv("GM_SSSP_WIDTH", width)
+    monkeypatch.setenv("GM_SSSP_ADAPT", adapt)
+    monkeypatch.setenv("GM_SSSP_CHUNK", chunk)
+    for delta in (0.1, 0.02):
+        got = P.delta_stepping(g, P.DeltaSteppingConfig(start, delta))
+        assert np.array_equal(got, ref)
+    # the ordered copy lives in the handle: gm_csr_trim releases it, the next call builds it again
+    g.csr_out.trim()
+    assert np.array_equal(P.delta_stepping(g, P.DeltaSteppingConfig(start, 0.1)), ref)
+
+
+@pytest.mark.parametrize("cut", ["0", "0.5", "8", "64", "100000"])
+@pytest.mark.parametrize("width,adapt", [("0.03125", "0.75,3"), ("0.001", "0.001,0.01"), ("0.25", "0,0")])
+def test_sssp_heavy_edges_beyond_a_cut_wait_for_one_far_round(P, oracle, monkeypatch, cut, width, adapt):
+    """From the first large phase on a heavy round relaxes only the candidates up to a cut above the threshold; the others
+    wait for ONE far round, run when the threshold is about to pass the cut (or when nothing else is pending) — by then most
+    of their targets have been taken up and are skipped by a bit test.  Any cut (none, below one step, the default 8 steps,
+    beyond every distance) gives the oracle's bits: the least fixed point does not depend on when an edge is relaxed
+    (sssp.rs:170-204).  Nodes reachable only over far edges (a chain of weight-0.9 edges behind the hub) are found by
+    the far round."""
+    scale = 15
+    s, d = oracle.rmat_edges(scale, seed=47)
+    w = oracle.rmat_weights(s.size, seed=48)
+    n = (1 << scale) + 40
+    hub = int(np.bincount(s).argmax())
+    chain = np.arange(1 << scale, n, dtype=s.dtype)  # hub -> c0 -> c1 -> ... each 0.9: only heavy edges lead there
+    s = np.concatenate([s, [hub], chain[:-1]]).astype(s.dtype)
+    d = np.concatenate([d, [chain[0]], chain[1:]]).astype(d.dtype)
+    w = np.concatenate([w, np.full(chain.size, 0.9, np.float32)]).astype(np.float32)
+    g = _directed(P, n, s, d, P.CsrLayout.Sorted, w)
+    off, tgt, wv = oracle.csr_build(n, s, d, oracle.OUTGOING, oracle.SORTED, w)
+    start = int(np.flatnonzero(np.diff(off) > 0)[0])
+    ref = oracle.sssp_fixed_point(off, tgt, wv, start)
+    assert ref[chain[-1]] > 30.0 and ref[chain[-1]] < 3.0e38
+    monkeypatch.setenv("GM_SSSP_ORDER", "1")
+    monkeypatch.setenv("GM_SSSP_CUT", cut)
+    monkeypatch.setenv("GM_SSSP_WIDTH", width)
+    monkeypatch.setenv("GM_SSSP_ADAPT", adapt)
+    for delta in (0.1, 0.02):
+        got = P.delta_stepping(g, P.DeltaSteppingConfig(start, delta))
+        assert np.array_equal(got, ref)
+
+
 def test_sssp_many_start_nodes_on_one_handle(P, oracle):
     """The working buffers are parked in the CSR handle between calls and the weight check runs once per handle:
     later calls (other start nodes, other deltas, an isolated start node) must not see anything of the earlier ones."""
