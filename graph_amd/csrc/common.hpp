@@ -559,9 +559,9 @@ struct WccScratch {
 // busy are then a PREFIX of its list, the others a suffix); immutable once built, kept in the handle like the PageRank plan
 struct SsspOrder {
     DevBuf targets, weights;
-    // ... and transposed (in_off u32[n + 1], the sources and weights of every node's in-edges, in no particular order):
-    // the far round pulls (sssp.hip)
-    DevBuf in_off, in_src, in_w;
+    // ... and transposed (in_off u32[n + 1], in_edge uint2[m] = (source, weight bits) of every node's in-edges, in no
+    // particular order): the far round pulls (sssp.hip)
+    DevBuf in_off, in_edge;
 };
 struct SsspScratch {
     DevBuf dist, flags, wmin, hflags, fflags, settled, done, ctrl, chunks, queues;

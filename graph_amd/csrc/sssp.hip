@@ -171,8 +171,8 @@ __device__ __forceinline__ void sssp_drain() { asm volatile("s_waitcnt vmcnt(0)"
 // the distances are the least fixed point).  The in-edges come from the transposed copy of the lists in the handle
 // (SsspOrder::in_*).  One lane per node (16 nodes per lane, a wavefront per 1024 as everywhere); in-lists longer than
 // 256 are read by the whole wavefront.
-__device__ __forceinline__ uint32_t sssp_pull_list(const uint32_t *__restrict__ in_src, const float *__restrict__ in_w,
-                                                   const uint32_t *dist, uint32_t first, uint32_t end, uint32_t step)
+__device__ __forceinline__ uint32_t sssp_pull_list(const uint2 *__restrict__ in_edge, const uint32_t *dist, uint32_t first,
+                                                   uint32_t end, uint32_t step)
 {
     uint32_t best = NO_BUCKET;
     for (uint32_t j = first; j < end; j += step * SSSP_MLP) {
@@ -181,8 +181,9 @@ __device__ __forceinline__ uint32_t sssp_pull_list(const uint32_t *__restrict__ 
 #pragma unroll
         for (int k = 0; k < SSSP_MLP; ++k) {
             const uint32_t i = j + (uint32_t)k * step;
-            s[k] = i < end ? in_src[i] : 0xFFFFFFFFu;
-            wj[k] = i < end ? in_w[i] : 0.0f;
+            const uint2 e = i < end ? in_edge[i] : make_uint2(0xFFFFFFFFu, 0u);
+            s[k] = e.x;
+            wj[k] = __uint_as_float(e.y);
         }
 #pragma unroll
         for (int k = 0; k < SSSP_MLP; ++k)
@@ -203,8 +204,8 @@ __device__ __forceinline__ void sssp_pull_apply(uint32_t *dist, uint32_t *flags,
     relax_checked(dist, flags, wmin, best, best != NO_BUCKET ? ld_agent(&dist[t]) : 0u, t, thr, ro);
 }
 
-__device__ void sssp_pull_round(const uint32_t *__restrict__ in_off, const uint32_t *__restrict__ in_src,
-                                const float *__restrict__ in_w, uint32_t *dist, uint32_t *flags, uint32_t *wmin,
+__device__ void sssp_pull_round(const uint32_t *__restrict__ in_off, const uint2 *__restrict__ in_edge, uint32_t *dist,
+                                uint32_t *flags, uint32_t *wmin,
                                 const uint32_t *settled, uint32_t nwords, uint32_t n, uint32_t thr, RelaxOut &ro)
 {
     constexpr uint32_t OWN = 256; // in-edges a lane reads by itself
@@ -228,7 +229,7 @@ __device__ void sssp_pull_round(const uint32_t *__restrict__ in_off, const uint3
                 continue;
             }
             if (s1 > s0)
-                sssp_pull_apply(dist, flags, wmin, t, sssp_pull_list(in_src, in_w, dist, s0, s1, 1u), thr, ro);
+                sssp_pull_apply(dist, flags, wmin, t, sssp_pull_list(in_edge, dist, s0, s1, 1u), thr, ro);
         }
         uint64_t who;
         while ((who = __ballot(big != 0u)) != 0ull) {
@@ -238,7 +239,7 @@ __device__ void sssp_pull_round(const uint32_t *__restrict__ in_off, const uint3
             if ((int)lane == src_lane)
                 big &= big - 1u;
             const uint32_t s0 = in_off[t], s1 = in_off[t + 1];
-            const uint32_t best = wave_min(sssp_pull_list(in_src, in_w, dist, s0 + lane, s1, kWave));
+            const uint32_t best = wave_min(sssp_pull_list(in_edge, dist, s0 + lane, s1, kWave));
             if (lane == 0)
                 sssp_pull_apply(dist, flags, wmin, t, best, thr, ro);
         }
@@ -256,7 +257,7 @@ __global__ void sssp_in_count_kernel(const uint32_t *__restrict__ tgt, uint64_t 
 
 __global__ __launch_bounds__(SSSP_BLOCK) void sssp_in_fill_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt,
                                                                   const float *__restrict__ w, uint32_t n, uint32_t *cursor,
-                                                                  uint32_t *__restrict__ in_src, float *__restrict__ in_w)
+                                                                  uint2 *__restrict__ in_edge)
 {
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -267,8 +268,7 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_in_fill_kernel(const uint32_t
         if (len <= SSSP_COOP)
             for (uint32_t i = s; i < e; ++i) {
                 const uint32_t p = atomicAdd(&cursor[tgt[i]], 1u);
-                in_src[p] = r;
-                in_w[p] = w[i];
+                in_edge[p] = make_uint2(r, __float_as_uint(w[i]));
             }
         uint64_t big = __ballot(len > SSSP_COOP);
         while (big) {
@@ -277,8 +277,7 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_in_fill_kernel(const uint32_t
             const uint32_t bs = __shfl(s, src, kWave), be = __shfl(e, src, kWave), br = __shfl(r, src, kWave);
             for (uint32_t i = bs + lane; i < be; i += kWave) {
                 const uint32_t p = atomicAdd(&cursor[tgt[i]], 1u);
-                in_src[p] = br;
-                in_w[p] = w[i];
+                in_edge[p] = make_uint2(br, __float_as_uint(w[i]));
             }
         }
     }
@@ -293,8 +292,7 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_round_kernel(const uint32_t *
                                                                 QueueState *__restrict__ qs, uint32_t *ctrl,
                                                                 uint32_t chunk_edges, uint32_t coop,
                                                                 const uint32_t *__restrict__ in_off,
-                                                                const uint32_t *__restrict__ in_src,
-                                                                const float *__restrict__ in_w, uint32_t n_nodes)
+                                                                const uint2 *__restrict__ in_edge, uint32_t n_nodes)
 {
     __shared__ uint16_t list[SSSP_BLOCK / kWave][SSSP_GROUP];          // node - first node of the group
     __shared__ uint8_t owner[SSSP_BLOCK / kWave][kWave * SSSP_COOP];    // short-list edge slot -> lane holding its node
@@ -309,7 +307,7 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_round_kernel(const uint32_t *
     const uint32_t wv = threadIdx.x >> 6;
     if (mode == 2u && in_off) { // the far round as a pull: nothing is queued, the chunk kernel finds no items
         RelaxOut pro{0u};
-        sssp_pull_round(in_off, in_src, in_w, dist, flags, wmin, settled, nwords, n_nodes, thr, pro);
+        sssp_pull_round(in_off, in_edge, dist, flags, wmin, settled, nwords, n_nodes, thr, pro);
         if (__ballot(pro.again != 0) && lane == 0 && !ld_agent(&ctrl[C_AGAIN]))
             atomicOr(&ctrl[C_AGAIN], 1u);
         return;
@@ -555,6 +553,9 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_chunk_kernel(const uint32_t *
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     RelaxOut ro{0u};
+    // (Testing 64 items at once, one per lane, and relaxing the survivors one after the other was measured and dropped:
+    // the test got cheaper, but a hub's light items — consecutive in the queue — then ran one behind the other in a few
+    // wavefronts, improvements spread more slowly and the phase needed more passes: 2.94 -> 3.20 x m edges, 5.56 -> 5.75 ms.)
     for (uint32_t c = wave; c < nchunks; c += nwaves) {
         const int q = __popcll(__ballot(q_incl <= c)); // sub-queues that end at or before item c
         const uint2 ch = chunks[__shfl(q_base, q, kWave) + c];
@@ -898,8 +899,7 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
             if (!(getenv("GM_SSSP_PULL") && atoi(getenv("GM_SSSP_PULL")) == 0)) { // the transposed lists for the far round
                 gm::DevBuf cursor;
                 GM_TRY(fresh->in_off.alloc(((size_t)n + 1) * 4));
-                GM_TRY(fresh->in_src.alloc((size_t)g->m * 4));
-                GM_TRY(fresh->in_w.alloc((size_t)g->m * 4));
+                GM_TRY(fresh->in_edge.alloc((size_t)g->m * 8));
                 GM_TRY(cursor.alloc(((size_t)n + 1) * 4));
                 GM_HIP(hipMemsetAsync(cursor.p, 0, ((size_t)n + 1) * 4, (hipStream_t)0));
                 unsigned cg = gm::div_up(g->m, 256);
@@ -915,8 +915,7 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
                 GM_HIP(hipMemcpyAsync(cursor.p, fresh->in_off.p, ((size_t)n + 1) * 4, hipMemcpyDeviceToDevice, (hipStream_t)0));
                 unsigned fg = gm::div_up(n, SSSP_BLOCK);
                 hipLaunchKernelGGL(sssp_in_fill_kernel, dim3(fg > 8192 ? 8192 : fg), dim3(SSSP_BLOCK), 0, (hipStream_t)0,
-                                   g->offsets, g->targets, g->weights, n, cursor.as<uint32_t>(), fresh->in_src.as<uint32_t>(),
-                                   fresh->in_w.as<float>());
+                                   g->offsets, g->targets, g->weights, n, cursor.as<uint32_t>(), fresh->in_edge.as<uint2>());
                 GM_HIP(hipGetLastError());
                 GM_HIP(hipStreamSynchronize((hipStream_t)0));
             }
@@ -1031,8 +1030,7 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
                                chunks.as<uint2>(), qs,
                                ctrl.as<uint32_t>(), chunk_edges, coop,
                                order && order->in_off.p ? order->in_off.as<uint32_t>() : (const uint32_t *)nullptr,
-                               order && order->in_off.p ? order->in_src.as<uint32_t>() : (const uint32_t *)nullptr,
-                               order && order->in_off.p ? order->in_w.as<float>() : (const float *)nullptr, n);
+                               order && order->in_off.p ? order->in_edge.as<uint2>() : (const uint2 *)nullptr, n);
             hipLaunchKernelGGL(sssp_chunk_kernel, dim3(grid), dim3(SSSP_BLOCK), 0, st, g->offsets, g->targets, g->weights,
                                dist.as<uint32_t>(), flags.as<uint32_t>(), wmin.as<uint32_t>(), use_settled ? settled.as<uint32_t>() : (const uint32_t *)nullptr, done_bits, done_min,
                                chunks.as<uint2>(), qs, ctrl.as<uint32_t>(), chunk_edges,
