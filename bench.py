@@ -508,10 +508,14 @@ def main():
                     else rec[k]["parity"].get("equals_the_count_pinned_by_that_test"), "parity": rec[k]["parity"],
                     "cpu_baseline": rec[k].get("cpu_baseline"),
                     **({"triangles": rec[k]["triangles"]} if k == "tc" else {}),
-                    **({"relaxed_edges": rec[k]["relaxed_edges"]} if k == "sssp" else {})}
+                    **({"relaxed_edges": rec[k]["relaxed_edges"], "first_call_ms": round(rec[k]["first_call_ms"], 3),
+                        "second_call_ms_builds_the_ordered_lists": round(rec[k]["second_call_ms_builds_the_ordered_lists"], 3)}
+                       if k == "sssp" else {})}
                 for k in ("wcc", "sssp", "tc") if k in rec}
             result["extra"]["protocol"] = ("tools/bench_algos.py in this process after the PageRank leg: best of 3 calls through the "
-                                           "prelude API (results downloaded), crates/app/src/app.rs:124-153")
+                                           "prelude API (results downloaded), crates/app/src/app.rs:124-153; SSSP: calls 3-5 on the "
+                                           "handle (the first runs on the CSR's lists, the second builds the weight-ordered and "
+                                           "transposed copies the later ones use: both timed beside `ms`)")
         except Exception as exc:  # the headline line must not depend on the extras
             result["extra"] = {"error": repr(exc)}
     if emu:

@@ -564,7 +564,8 @@ struct SsspOrder {
     DevBuf in_off, in_edge;
 };
 struct SsspScratch {
-    DevBuf dist, flags, wmin, hflags, fflags, settled, done, ctrl, chunks, queues;
+    DevBuf dist, flags, wmin, hflags, fflags, settled, done, ctrl, chunks, queues, queues_init;
+    uint64_t caps_key = 0; // (chunk_edges << 32 | coop) + 1 the sub-queue capacities in queues_init were computed for; 0: none
     PinnedBuf hctrl;
     size_t items = 0; // capacity of `chunks` in work items; 0: not (completely) allocated
 };
@@ -587,7 +588,8 @@ struct gm_csr {
     mutable std::atomic<uint64_t> page_rank_calls{0}; // gm_page_rank calls seen by this handle (engine choice); calls may run concurrently
     mutable std::atomic<int> weights_ok{0};                // 1: gm_sssp_delta_stepping has seen that no weight is negative or NaN
     mutable std::unique_ptr<gm::SsspScratch> sssp_scratch; // parked between calls (under cache_mu)
-    mutable std::shared_ptr<const gm::SsspOrder> sssp_order; // likewise; built by the first gm_sssp_delta_stepping call
+    mutable std::shared_ptr<const gm::SsspOrder> sssp_order; // likewise; built by the SECOND gm_sssp_delta_stepping call
+    mutable std::atomic<uint64_t> sssp_calls{0};             // gm_sssp_delta_stepping calls seen by this handle
     mutable std::unique_ptr<gm::WccScratch> wcc_scratch;   // likewise
     mutable std::shared_ptr<gm::PrCallState> pr_call;      // likewise (stream, vectors, engine + its scratch)
     mutable std::shared_ptr<const gm::TcDag> tc_dag;       // the DAG of lower prefixes + list records of gm_triangle_count

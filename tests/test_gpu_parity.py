@@ -519,15 +519,18 @@ def test_sssp_lists_ordered_by_weight_give_the_same_bits(P, oracle, monkeypatch,
     assert np.array_equal(P.delta_stepping(g, P.DeltaSteppingConfig(start, 0.1)), ref)
 
 
+@pytest.mark.parametrize("pull", ["1", "0"])
 @pytest.mark.parametrize("cut", ["0", "0.5", "8", "64", "100000"])
 @pytest.mark.parametrize("width,adapt", [("0.03125", "0.75,3"), ("0.001", "0.001,0.01"), ("0.25", "0,0")])
-def test_sssp_heavy_edges_beyond_a_cut_wait_for_one_far_round(P, oracle, monkeypatch, cut, width, adapt):
+def test_sssp_heavy_edges_beyond_a_cut_wait_for_one_far_round(P, oracle, monkeypatch, cut, width, adapt, pull):
     """From the first large phase on a heavy round relaxes only the candidates up to a cut above the threshold; the others
     wait for ONE far round, run when the threshold is about to pass the cut (or when nothing else is pending) — by then most
     of their targets have been taken up and are skipped by a bit test.  Any cut (none, below one step, the default 8 steps,
     beyond every distance) gives the oracle's bits: the least fixed point does not depend on when an edge is relaxed
     (sssp.rs:170-204).  Nodes reachable only over far edges (a chain of weight-0.9 edges behind the hub) are found by
-    the far round."""
+    the far round.  The far round PULLS by default (every node never taken up takes the minimum over its in-edges, read
+    from transposed lists kept in the handle; the cut is then set in the middle of the first large phase and binds the
+    short lists too); GM_SSSP_PULL=0: it pushes the waiting edges of the nodes marked for it."""
     scale = 15
     s, d = oracle.rmat_edges(scale, seed=47)
     w = oracle.rmat_weights(s.size, seed=48)
@@ -543,6 +546,7 @@ def test_sssp_heavy_edges_beyond_a_cut_wait_for_one_far_round(P, oracle, monkeyp
     ref = oracle.sssp_fixed_point(off, tgt, wv, start)
     assert ref[chain[-1]] > 30.0 and ref[chain[-1]] < 3.0e38
     monkeypatch.setenv("GM_SSSP_ORDER", "1")
+    monkeypatch.setenv("GM_SSSP_PULL", pull)
     monkeypatch.setenv("GM_SSSP_CUT", cut)
     monkeypatch.setenv("GM_SSSP_WIDTH", width)
     monkeypatch.setenv("GM_SSSP_ADAPT", adapt)

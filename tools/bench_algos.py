@@ -150,11 +150,13 @@ def measure(args):
         deg = g_out.degrees()
         start = int(np.flatnonzero(deg > 0)[0])
         t_first, _ = timed(lambda: P.delta_stepping(g, P.DeltaSteppingConfig(start, 0.1)), reps=1)  # allocates the scratch
+        # the second call on a handle orders the lists by weight and transposes them (kept in the handle), then runs on them
+        t_plan, _ = timed(lambda: P.delta_stepping(g, P.DeltaSteppingConfig(start, 0.1)), reps=1)
         t_s, dist = timed(lambda: P.delta_stepping(g, P.DeltaSteppingConfig(start, 0.1)))
         reached = dist < np.float32(3.0e38)
         relaxed = int(deg[reached].astype(np.int64).sum())
         rec = {"config": f"RMAT scale-{sc}, f32 weights uniform (0,1] seed 44, delta 0.1, start node {start}", "nodes": n,
-               "edges": m, "ms": t_s * 1e3, "first_call_ms": t_first * 1e3, "reached": int(reached.sum()), "relaxed_edges": relaxed,
+               "edges": m, "ms": t_s * 1e3, "first_call_ms": t_first * 1e3, "second_call_ms_builds_the_ordered_lists": t_plan * 1e3, "reached": int(reached.sum()), "relaxed_edges": relaxed,
                "relaxed_edges_per_s": relaxed / t_s}
         rec["roofline"] = roofline(12 * relaxed + 4 * int(reached.sum()), t_s)
         if O is not None:
