@@ -19,7 +19,8 @@
  *     or last worked in, so that repeated calls (the reference's app times each algorithm in a loop)
  *     do not pay for it again: PageRank's propagation-blocking plan (~4.3 B/edge) and the stream,
  *     vectors and engine of the last gm_page_rank call (~3.4 B/edge + 12 B/node: ~9 GB at RMAT
- *     scale 26); the working set of the last gm_sssp_delta_stepping (~9 B/node) and gm_wcc_* call
+ *     scale 26); the working set of the last gm_sssp_delta_stepping (~9 B/node; from the second call on a graph of
+ *     2^20 edges or more also its lists ordered by weight and transposed, ~20 B/edge) and gm_wcc_* call
  *     (~8 B/node); gm_triangle_count's DAG of lower prefixes and list records (~6 B/entry +
  *     128 B/node: 4.7 GB at scale 24); the partition of the last gm_page_rank_multi call (slices,
  *     engines, exchange buffers on every device it named).  A concurrent second call of one algorithm allocates its own
