@@ -171,8 +171,8 @@ __device__ __forceinline__ void sssp_drain() { asm volatile("s_waitcnt vmcnt(0)"
 // the distances are the least fixed point).  The in-edges come from the transposed copy of the lists in the handle
 // (SsspOrder::in_*).  One lane per node (16 nodes per lane, a wavefront per 1024 as everywhere); in-lists longer than
 // 256 are read by the whole wavefront.
-__device__ __forceinline__ uint32_t sssp_pull_list(const uint2 *__restrict__ in_edge, const uint32_t *dist, uint32_t first,
-                                                   uint32_t end, uint32_t step)
+__device__ __forceinline__ uint32_t sssp_pull_list(const uint2 *__restrict__ in_edge, const uint32_t *dist,
+                                                   const uint32_t *settled, uint32_t first, uint32_t end, uint32_t step)
 {
     uint32_t best = NO_BUCKET;
     for (uint32_t j = first; j < end; j += step * SSSP_MLP) {
@@ -184,6 +184,19 @@ __device__ __forceinline__ uint32_t sssp_pull_list(const uint2 *__restrict__ in_
             const uint2 e = i < end ? in_edge[i] : make_uint2(0xFFFFFFFFu, 0u);
             s[k] = e.x;
             wj[k] = __uint_as_float(e.y);
+        }
+        // GM_SSSP_PULL_FILTER=1 (measured slower: 6.56 against 6.40 ms at scale 24 — nearly every source HAS been taken up by
+        // then, the bit test is one more dependent access): only sources that have been taken up matter here (the others
+        // relax their edges when their turn comes), so a bit of the L2-resident map could spare the read of the distance
+        if (settled) {
+            uint32_t sb[SSSP_MLP];
+#pragma unroll
+            for (int k = 0; k < SSSP_MLP; ++k)
+                sb[k] = s[k] != 0xFFFFFFFFu ? ld_agent(&settled[s[k] >> 5]) : 0u;
+#pragma unroll
+            for (int k = 0; k < SSSP_MLP; ++k)
+                if (!((sb[k] >> (s[k] & 31u)) & 1u))
+                    s[k] = 0xFFFFFFFFu;
         }
 #pragma unroll
         for (int k = 0; k < SSSP_MLP; ++k)
@@ -206,7 +219,8 @@ __device__ __forceinline__ void sssp_pull_apply(uint32_t *dist, uint32_t *flags,
 
 __device__ void sssp_pull_round(const uint32_t *__restrict__ in_off, const uint2 *__restrict__ in_edge, uint32_t *dist,
                                 uint32_t *flags, uint32_t *wmin,
-                                const uint32_t *settled, uint32_t nwords, uint32_t n, uint32_t thr, RelaxOut &ro)
+                                const uint32_t *settled, uint32_t nwords, uint32_t n, uint32_t thr, RelaxOut &ro,
+                                const uint32_t *src_bits)
 {
     constexpr uint32_t OWN = 256; // in-edges a lane reads by itself
     const uint32_t lane = threadIdx.x & (kWave - 1);
@@ -229,7 +243,7 @@ __device__ void sssp_pull_round(const uint32_t *__restrict__ in_off, const uint2
                 continue;
             }
             if (s1 > s0)
-                sssp_pull_apply(dist, flags, wmin, t, sssp_pull_list(in_edge, dist, s0, s1, 1u), thr, ro);
+                sssp_pull_apply(dist, flags, wmin, t, sssp_pull_list(in_edge, dist, src_bits, s0, s1, 1u), thr, ro);
         }
         uint64_t who;
         while ((who = __ballot(big != 0u)) != 0ull) {
@@ -239,7 +253,7 @@ __device__ void sssp_pull_round(const uint32_t *__restrict__ in_off, const uint2
             if ((int)lane == src_lane)
                 big &= big - 1u;
             const uint32_t s0 = in_off[t], s1 = in_off[t + 1];
-            const uint32_t best = wave_min(sssp_pull_list(in_edge, dist, s0 + lane, s1, kWave));
+            const uint32_t best = wave_min(sssp_pull_list(in_edge, dist, src_bits, s0 + lane, s1, kWave));
             if (lane == 0)
                 sssp_pull_apply(dist, flags, wmin, t, best, thr, ro);
         }
@@ -292,7 +306,8 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_round_kernel(const uint32_t *
                                                                 QueueState *__restrict__ qs, uint32_t *ctrl,
                                                                 uint32_t chunk_edges, uint32_t coop,
                                                                 const uint32_t *__restrict__ in_off,
-                                                                const uint2 *__restrict__ in_edge, uint32_t n_nodes)
+                                                                const uint2 *__restrict__ in_edge, uint32_t n_nodes,
+                                                                uint32_t pull_filter)
 {
     __shared__ uint16_t list[SSSP_BLOCK / kWave][SSSP_GROUP];          // node - first node of the group
     __shared__ uint8_t owner[SSSP_BLOCK / kWave][kWave * SSSP_COOP];    // short-list edge slot -> lane holding its node
@@ -310,7 +325,8 @@ __global__ __launch_bounds__(SSSP_BLOCK) void sssp_round_kernel(const uint32_t *
     const uint32_t short_cut = in_off && mode == 0u ? ld_agent(&ctrl[C_CUT]) : NO_BUCKET;
     if (mode == 2u && in_off) { // the far round as a pull: nothing is queued, the chunk kernel finds no items
         RelaxOut pro{0u};
-        sssp_pull_round(in_off, in_edge, dist, flags, wmin, settled, nwords, n_nodes, thr, pro);
+        sssp_pull_round(in_off, in_edge, dist, flags, wmin, settled, nwords, n_nodes, thr, pro,
+                        pull_filter ? settled : (const uint32_t *)nullptr);
         if (__ballot(pro.again != 0) && lane == 0 && !ld_agent(&ctrl[C_AGAIN]))
             atomicOr(&ctrl[C_AGAIN], 1u);
         return;
@@ -1058,7 +1074,8 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
                                chunks.as<uint2>(), qs,
                                ctrl.as<uint32_t>(), chunk_edges, coop,
                                order && order->in_off.p ? order->in_off.as<uint32_t>() : (const uint32_t *)nullptr,
-                               order && order->in_off.p ? order->in_edge.as<uint2>() : (const uint2 *)nullptr, n);
+                               order && order->in_off.p ? order->in_edge.as<uint2>() : (const uint2 *)nullptr, n,
+                               getenv("GM_SSSP_PULL_FILTER") && atoi(getenv("GM_SSSP_PULL_FILTER")) != 0 ? 1u : 0u);
             hipLaunchKernelGGL(sssp_chunk_kernel, dim3(grid), dim3(SSSP_BLOCK), 0, st, g->offsets, g->targets, g->weights,
                                dist.as<uint32_t>(), flags.as<uint32_t>(), wmin.as<uint32_t>(), use_settled ? settled.as<uint32_t>() : (const uint32_t *)nullptr, done_bits, done_min,
                                chunks.as<uint2>(), qs, ctrl.as<uint32_t>(), chunk_edges,
