@@ -50,6 +50,8 @@ def parse_args():
     ap.add_argument("--scale", type=int, default=26)   # BASELINE.json metric: RMAT scale-26
     ap.add_argument("--edge-factor", type=int, default=16)
     ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--pretouch-frac", type=float, default=0.0, help="experiment: allocate and free this fraction of the free "
+                    "device memory before anything else (does the placement level follow the driver's allocation history?)")
     ap.add_argument("--cpu-sweeps", type=int, default=20, help="sweeps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores (available_parallelism)")
     ap.add_argument("--parity", type=int, default=1, help="N = 1, inside the cpu_baseline leg: run the timed engine and the CPU "
@@ -175,6 +177,14 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
+    if args.pretouch_frac > 0:
+        free_b, _ = torch.cuda.mem_get_info(dev)
+        t_pt = time.time()
+        blocks = [torch.empty(int(free_b * args.pretouch_frac / 8), dtype=torch.uint8, device=dev) for _ in range(8)]
+        del blocks
+        torch.cuda.empty_cache()
+        torch.cuda.synchronize()
+        print(f"pretouch: {free_b * args.pretouch_frac / 2**30:.0f} GiB allocated and freed in {time.time() - t_pt:.2f} s", file=sys.stderr)
     scale, n = args.scale, 1 << args.scale
     t_build = time.time()
     src, dst = synth.rmat_edges(scale, args.seed, args.edge_factor, local_rank)
