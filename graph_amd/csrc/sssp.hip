@@ -917,24 +917,26 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
             order = g->sssp_order;
         }
         if (!order) {
-            auto fresh = std::make_shared<gm::SsspOrder>();
-            GM_TRY(fresh->targets.alloc((size_t)g->m * 4));
-            GM_TRY(fresh->weights.alloc((size_t)g->m * 4));
-            size_t temp_bytes = 0;
-            GM_HIP(rocprim::segmented_radix_sort_pairs(nullptr, temp_bytes, g->weights, fresh->weights.as<float>(), g->targets,
-                                                       fresh->targets.as<uint32_t>(), (unsigned int)g->m, (unsigned int)n,
-                                                       g->offsets, g->offsets + 1, 0u, 32u, (hipStream_t)0));
-            gm::DevBuf temp;
-            GM_TRY(temp.alloc(temp_bytes ? temp_bytes : 4));
-            GM_HIP(rocprim::segmented_radix_sort_pairs(temp.p, temp_bytes, g->weights, fresh->weights.as<float>(), g->targets,
-                                                       fresh->targets.as<uint32_t>(), (unsigned int)g->m, (unsigned int)n,
-                                                       g->offsets, g->offsets + 1, 0u, 32u, (hipStream_t)0));
-            if (times) {
+            // out of memory while building them is not an error of the call: it runs on the CSR's lists, as the first call did
+            auto build = [&](std::shared_ptr<gm::SsspOrder> &fresh) -> int {
+                GM_TRY(fresh->targets.alloc((size_t)g->m * 4));
+                GM_TRY(fresh->weights.alloc((size_t)g->m * 4));
+                size_t temp_bytes = 0;
+                GM_HIP(rocprim::segmented_radix_sort_pairs(nullptr, temp_bytes, g->weights, fresh->weights.as<float>(), g->targets,
+                                                           fresh->targets.as<uint32_t>(), (unsigned int)g->m, (unsigned int)n,
+                                                           g->offsets, g->offsets + 1, 0u, 32u, (hipStream_t)0));
+                gm::DevBuf temp;
+                GM_TRY(temp.alloc(temp_bytes ? temp_bytes : 4));
+                GM_HIP(rocprim::segmented_radix_sort_pairs(temp.p, temp_bytes, g->weights, fresh->weights.as<float>(), g->targets,
+                                                           fresh->targets.as<uint32_t>(), (unsigned int)g->m, (unsigned int)n,
+                                                           g->offsets, g->offsets + 1, 0u, 32u, (hipStream_t)0));
                 GM_HIP(hipStreamSynchronize((hipStream_t)0));
-                fprintf(stderr, "sssp: segmented sort by weight done after %.3f ms\n", since(t_call));
-            }
-            if (!(getenv("GM_SSSP_PULL") && atoi(getenv("GM_SSSP_PULL")) == 0)) { // the transposed lists for the far round
-                gm::DevBuf cursor;
+                if (times)
+                    fprintf(stderr, "sssp: segmented sort by weight done after %.3f ms\n", since(t_call));
+                return GM_OK;
+            };
+            auto transpose = [&](std::shared_ptr<gm::SsspOrder> &fresh) -> int { // the in-edges for the far round's pull
+                gm::DevBuf cursor, scan_tmp;
                 GM_TRY(fresh->in_off.alloc(((size_t)n + 1) * 4));
                 GM_TRY(fresh->in_edge.alloc((size_t)g->m * 8));
                 GM_TRY(cursor.alloc(((size_t)n + 1) * 4));
@@ -945,7 +947,6 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
                 size_t scan_bytes = 0;
                 GM_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, cursor.as<uint32_t>(), fresh->in_off.as<uint32_t>(), 0u,
                                                (size_t)n + 1, rocprim::plus<uint32_t>(), (hipStream_t)0));
-                gm::DevBuf scan_tmp;
                 GM_TRY(scan_tmp.alloc(scan_bytes ? scan_bytes : 4));
                 GM_HIP(rocprim::exclusive_scan(scan_tmp.p, scan_bytes, cursor.as<uint32_t>(), fresh->in_off.as<uint32_t>(), 0u,
                                                (size_t)n + 1, rocprim::plus<uint32_t>(), (hipStream_t)0));
@@ -955,15 +956,28 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
                                    g->offsets, g->targets, g->weights, n, cursor.as<uint32_t>(), fresh->in_edge.as<uint2>());
                 GM_HIP(hipGetLastError());
                 GM_HIP(hipStreamSynchronize((hipStream_t)0));
+                return GM_OK;
+            };
+            auto fresh = std::make_shared<gm::SsspOrder>();
+            if (build(fresh) == GM_OK) {
+                if (!(getenv("GM_SSSP_PULL") && atoi(getenv("GM_SSSP_PULL")) == 0) && transpose(fresh) != GM_OK) {
+                    (void)hipGetLastError();
+                    fresh->in_off.release(); // the far round pushes
+                    fresh->in_edge.release();
+                }
+                if (times)
+                    fprintf(stderr, "sssp: lists ordered by weight%s in %.3f ms (kept in the handle)\n",
+                            fresh->in_off.p ? " and transposed" : "", since(t_call));
+                std::lock_guard<std::mutex> lock(g->cache_mu);
+                if (!g->sssp_order)
+                    g->sssp_order = fresh;
+                order = g->sssp_order;
+            } else {
+                (void)hipGetLastError();
+                if (gm::log_enabled())
+                    fprintf(stderr, "[graph_mi355x] sssp: no room for the weight-ordered lists (%s): running on the CSR's own\n",
+                            gm_last_error());
             }
-            GM_HIP(hipStreamSynchronize((hipStream_t)0));
-            if (times)
-                fprintf(stderr, "sssp: lists ordered by weight%s in %.3f ms (kept in the handle)\n",
-                        fresh->in_off.p ? " and transposed" : "", since(t_call));
-            std::lock_guard<std::mutex> lock(g->cache_mu);
-            if (!g->sssp_order)
-                g->sssp_order = fresh;
-            order = g->sssp_order;
         }
     }
     const uint32_t *e_tgt = order ? order->targets.as<uint32_t>() : g->targets;
