@@ -215,7 +215,12 @@ struct PbPlan {
     uint32_t Htot = 0;  // hot sources in all (<= T * H; the last tier may be partly filled)
     DevBuf hot_ids;     // u32[Htot] x index of each hot source, by rank
     DevBuf hot_ent;     // u32[Mh]  hot edges, (bin, tier)-major: row_in_bin << 16 | index inside the tier; 0xFFFFFFFF = padding
-    DevBuf hbin_v;      // u32[(B + G) T + 1] hot-edge range of each (bin, tier) (multiples of 4)
+    DevBuf hbin_v;      // u32[(B + G) T + 1] hot-edge range of each (bin, tier) (multiples of 4; of 512 with 2-byte records)
+    // 2-byte hot records (hot16): hot_ent is u16[Mh], a record = row slot << 2 | how far its table index lies beyond the
+    // record before it (0..3; slot Racc = a filler that only moves the index on); every 512 records — one wavefront's share
+    // of a batch — have the index they start from in hot_base
+    DevBuf hot_base;    // u16[Mh / 8 + 1]: the index the eight records of a lane start from
+    uint32_t hot16 = 0;
     uint64_t Mh = 0;
     // host copies for launches over a range of source tiles / a group of bins (partitioned sweeps that
     // overlap the exchange of one part of x with the work on another)
@@ -400,6 +405,83 @@ __global__ void pb_pad4_sizes_kernel(const uint32_t *__restrict__ start, uint32_
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b <= count; b += stride)
         padded[b] = b == count ? 0u : ((start[b + 1] - start[b] + 3u) & ~3u);
+}
+
+// ---- 2-byte hot records -------------------------------------------------------------------------------------------------
+// Inside a (bin, tier) cell the hot keys are sorted by table index, and a cell holds about as many records as the table has
+// entries: the index of a record is that of the record before it plus 0..3 nearly always.  entries[i] = 1 + the fillers
+// record i needs in front of it (each moves the index on by 3); the first record of a cell starts from its own index.
+constexpr uint32_t PB_H16_CHUNK = 512; // a cell's records are padded to whole wavefront shares (eight per lane)
+constexpr uint32_t PB_H16_LANE = 8;    // records with one base index: a lane's 16-byte load (a scan over the wavefront
+                                       // instead — one base per 512 records — cost more than these 0.25 B per record save:
+                                       // 2.93 against 2.81 ms per sweep at scale 26, tools/runs/r04_call56.sh)
+__device__ __forceinline__ uint32_t pb_h16_gap(const uint64_t *__restrict__ hkeys, uint32_t i, int sb, int bb, uint32_t H, uint32_t T)
+{
+    const uint64_t k = hkeys[i];
+    if (i == 0 || pb_hot_cell(hkeys[i - 1], sb, bb, H, T) != pb_hot_cell(k, sb, bb, H, T))
+        return 0u;
+    const uint32_t r = (uint32_t)(k & ((1ull << sb) - 1ull)), rp = (uint32_t)(hkeys[i - 1] & ((1ull << sb) - 1ull));
+    return r % H - rp % H; // same cell: same tier, sorted by rank
+}
+
+__global__ void pb_h16_count_kernel(const uint64_t *__restrict__ hkeys, uint32_t mh, int sb, int bb, uint32_t H, uint32_t T,
+                                    uint32_t *__restrict__ entries)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= mh; i += stride) {
+        if (i == mh) {
+            entries[i] = 0u;
+            continue;
+        }
+        const uint32_t gap = pb_h16_gap(hkeys, i, sb, bb, H, T);
+        entries[i] = 1u + (gap > 3u ? (gap - 1u) / 3u : 0u);
+    }
+}
+
+// padded[c] = the cell's entries (records + fillers) rounded up to a whole chunk
+__global__ void pb_h16_sizes_kernel(const uint32_t *__restrict__ hstart, const uint32_t *__restrict__ epos, uint32_t cells,
+                                    uint32_t *__restrict__ padded)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c <= cells; c += stride)
+        padded[c] = c == cells ? 0u : ((epos[hstart[c + 1]] - epos[hstart[c]] + PB_H16_CHUNK - 1u) & ~(PB_H16_CHUNK - 1u));
+}
+
+__global__ void pb_h16_pattern_kernel(uint16_t *__restrict__ out, uint64_t count, uint16_t value)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride)
+        out[i] = value;
+}
+
+__global__ void pb_h16_fill_kernel(const uint64_t *__restrict__ hkeys, uint32_t mh, const uint32_t *__restrict__ hstart,
+                                   const uint32_t *__restrict__ epos, const uint32_t *__restrict__ hbin_v, int sb, int bb,
+                                   uint32_t H, uint32_t T, uint32_t filler_slot, uint16_t *__restrict__ hot16,
+                                   uint16_t *__restrict__ hot_base)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < mh; i += stride) {
+        const uint64_t k = hkeys[i];
+        const uint32_t cell = pb_hot_cell(k, sb, bb, H, T);
+        const uint32_t slot = (uint32_t)(k >> (sb + bb + 1));
+        const uint32_t idx = (uint32_t)(k & ((1ull << sb) - 1ull)) % H;
+        const uint32_t gap = pb_h16_gap(hkeys, i, sb, bb, H, T);
+        const uint32_t nf = gap > 3u ? (gap - 1u) / 3u : 0u;
+        const uint32_t cell_at = hbin_v[cell], cell_end = hbin_v[cell + 1];
+        uint32_t pos = cell_at + (epos[i] - epos[hstart[cell]]);
+        uint32_t running = idx - gap; // the index the entries in front of this record start from
+        if (i == hstart[cell])
+            hot_base[cell_at / PB_H16_LANE] = (uint16_t)idx; // a cell's first record: gap 0 from its own index
+        for (uint32_t f = 0; f < nf; ++f, ++pos) {
+            running += 3u;
+            hot16[pos] = (uint16_t)((filler_slot << 2) | 3u);
+            if ((pos & (PB_H16_LANE - 1u)) == PB_H16_LANE - 1u && pos + 1u < cell_end)
+                hot_base[(pos + 1u) / PB_H16_LANE] = (uint16_t)running;
+        }
+        hot16[pos] = (uint16_t)((slot << 2) | (idx - running));
+        if ((pos & (PB_H16_LANE - 1u)) == PB_H16_LANE - 1u && pos + 1u < cell_end)
+            hot_base[(pos + 1u) / PB_H16_LANE] = (uint16_t)idx;
+    }
 }
 
 __global__ void pb_hot_gather_kernel(const float *__restrict__ x_in, const uint32_t *__restrict__ hot_ids, uint32_t H,
@@ -870,7 +952,7 @@ __device__ __forceinline__ unsigned long long pb_to_fix(float x)
 // branched around (a compare, a scalar mask save / restore and a branch for each of the 1.1 G entries of a sweep at scale 26).
 // Measured in alternating fresh processes on one box (tools/runs/r04_call25.sh): SLOWER, 1831 against 1620 us — the 2 % of
 // padding entries then meet on ONE LDS address and same-address atomics serialise.
-template <int ABL, int D = PB_ACC_DEPTH, bool BF = false>
+template <int ABL, int D = PB_ACC_DEPTH, bool BF = false, bool H16 = false>
 __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__restrict__ vals,
                                                                 const uint16_t *__restrict__ p2_dst,
                                                                 const PbItem *__restrict__ items,
@@ -882,7 +964,7 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
                                                                 const uint32_t *__restrict__ outdeg, float *__restrict__ scores,
                                                                 float *__restrict__ x_out, double *__restrict__ bin_err,
                                                                 uint32_t n_local, uint32_t R, uint32_t Racc, float base,
-                                                                float damping)
+                                                                float damping, const uint16_t *__restrict__ hot_base)
 {
     extern __shared__ unsigned long long acc[]; // Racc fixed-point sums (one per ordinary row WITH in-edges)
     __shared__ double red[PB_ACC_BLOCK / kWave];
@@ -923,7 +1005,8 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
         ha = hbin_v[b * T + t];
         hb = hbin_v[b * T + t + 1];
         if (item.nparts > 1) {
-            const uint32_t per = (((hb - ha) + item.nparts - 1u) / item.nparts + 3u) & ~3u;
+            constexpr uint32_t GRAN = H16 ? PB_H16_CHUNK : 4u; // (2-byte records: whole chunks, they share a base index)
+            const uint32_t per = (((hb - ha) + item.nparts - 1u) / item.nparts + GRAN - 1u) & ~(GRAN - 1u);
             const uint32_t lo = ha + item.part * per;
             ha = lo < hb ? lo : hb;
             hb = (hb - ha) < per ? hb : ha + per;
@@ -1002,7 +1085,66 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
     // the next tier, when this tier is done — are requested before this batch is processed, and the next tier's
     // table is requested at this tier's first batch.  A tier with a few thousand edges per bin is a single, partly
     // filled batch: without the pipeline across the tier switch every tier cost one exposed HBM round trip.
-    if (tier < T) {
+    if (H16 && tier < T) {
+        // 2-byte records: eight per lane and batch in ONE 16-byte load (half the bytes of the 4-byte records); a record's
+        // table index = the base index of the lane's eight records (2 more bytes per lane) + the deltas up to it.  Same
+        // software pipeline as below.
+        constexpr uint32_t BATCH = PB_ACC_BLOCK * 8u;
+        const uint16_t *h16 = reinterpret_cast<const uint16_t *>(hot_ent);
+        const uint32_t filler = (Racc << 2) | (Racc << 18);
+        uint32_t base, h_end;
+        tier_range(tier, base, h_end);
+        auto fetch16 = [&](uint32_t b0, uint32_t end, uint4 &ee, uint32_t &bi) {
+            const uint32_t h = b0 + tid * 8u;
+            ee = make_uint4(filler, filler, filler, filler);
+            bi = 0u;
+            if (h < end) {
+                ee = *reinterpret_cast<const uint4 *>(h16 + h);
+                bi = hot_base[h / PB_H16_LANE];
+            }
+        };
+        uint4 e, en;
+        uint32_t bi, bin_ = 0u;
+        fetch16(base, h_end, e, bi);
+        uint32_t after = next_tier(tier + 1);
+        if (after < T)
+            tier_fetch(after, 0);
+        for (;;) {
+            uint32_t nbase = base + BATCH, nend = h_end, ntier = tier;
+            if (nbase >= h_end) {
+                ntier = after;
+                if (ntier < T)
+                    tier_range(ntier, nbase, nend);
+            }
+            if (ntier < T)
+                fetch16(nbase, nend, en, bin_);
+            {
+                uint32_t idx = bi; // the lane's records one after the other: index, then the add
+                auto two = [&](uint32_t w) {
+                    idx += w & 3u;
+                    if (((w >> 2) & 0x3FFFu) != Racc)
+                        atomicAdd(&acc[(w >> 2) & 0x3FFFu], pb_to_fix(table[idx]));
+                    idx += (w >> 16) & 3u;
+                    if ((w >> 18) != Racc)
+                        atomicAdd(&acc[w >> 18], pb_to_fix(table[idx]));
+                };
+                two(e.x), two(e.y), two(e.z), two(e.w);
+            }
+            if (ntier >= T)
+                break;
+            if (ntier != tier) {
+                float *other = table == hot ? hot + Hpad : hot;
+                tier_store(ntier, 0, other);
+                __syncthreads();
+                table = other;
+                after = next_tier(ntier + 1);
+                if (after < T)
+                    tier_fetch(after, 0);
+            }
+            e = en, bi = bin_;
+            tier = ntier, base = nbase, h_end = nend;
+        }
+    } else if (tier < T) {
         constexpr int HU = 2; // uint4 of hot records per lane and batch (1 / 2 / 3 measured alike: 2.70-2.72 ms per sweep, tools/runs/r04_call28.sh)
         constexpr uint32_t BATCH = PB_ACC_BLOCK * PB_VEC * HU; // entries of one batch
         uint32_t base, h_end; // this batch starts at `base` (workgroup-uniform) of the tier's range [.., h_end)
@@ -2299,6 +2441,36 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
             GM_TRY(hpad.alloc(((size_t)cells + 1) * 4));
             hipLaunchKernelGGL(pb_hot_bounds_kernel, dim3(pb_grid(mh)), dim3(256), 0, 0, hkeys, mh, sb, bin_bits, H, T, cells,
                                hstart.as<uint32_t>());
+            // 2-byte records (GM_PB_HOT16=0: 4-byte ones): the row slot must leave a 14-bit code free for the fillers.
+            // Measured at scale 26 (tools/runs/r04_call57.sh / r04_call58.sh): 0.54 GB fewer bytes per sweep and 0.5 GB less
+            // plan, the accumulate kernel 1552 against 1572 us — its hot phase is not what the memory system bounds.
+            pl->hot16 = pb_env("GM_PB_HOT16", 1) && pl->Racc < 16384u && H <= 16384u ? 1u : 0u;
+            if (pl->hot16) {
+                DevBuf entries, epos;
+                GM_TRY(entries.alloc_scratch(((size_t)mh + 1) * 4));
+                GM_TRY(epos.alloc_scratch(((size_t)mh + 1) * 4));
+                hipLaunchKernelGGL(pb_h16_count_kernel, dim3(pb_grid((uint64_t)mh + 1)), dim3(256), 0, 0, hkeys, mh, sb, bin_bits, H,
+                                   T, entries.as<uint32_t>());
+                GM_HIP(hipGetLastError());
+                GM_TRY(scan_exclusive<uint32_t>(entries.as<uint32_t>(), epos.as<uint32_t>(), (uint64_t)mh + 1));
+                hipLaunchKernelGGL(pb_h16_sizes_kernel, dim3(pb_grid((uint64_t)cells + 1)), dim3(256), 0, 0, hstart.as<uint32_t>(),
+                                   epos.as<uint32_t>(), cells, hpad.as<uint32_t>());
+                GM_HIP(hipGetLastError());
+                GM_TRY(scan_exclusive<uint32_t>(hpad.as<uint32_t>(), pl->hbin_v.as<uint32_t>(), (uint64_t)cells + 1));
+                uint32_t Mh = 0;
+                GM_HIP(hipMemcpy(&Mh, pl->hbin_v.as<uint32_t>() + cells, 4, hipMemcpyDeviceToHost));
+                pl->Mh = Mh;
+                GM_TRY(pl->hot_ent.alloc_big((size_t)Mh * 2 + 16, 0x407E, 4, 0, ~0ull, 0, 4));
+                GM_TRY(pl->hot_base.alloc(((size_t)Mh / PB_H16_LANE + 2) * 2));
+                GM_HIP(hipMemset(pl->hot_base.p, 0, pl->hot_base.bytes));
+                hipLaunchKernelGGL(pb_h16_pattern_kernel, dim3(pb_grid((uint64_t)Mh + 8)), dim3(256), 0, 0, pl->hot_ent.as<uint16_t>(),
+                                   (uint64_t)Mh + 8, (uint16_t)(pl->Racc << 2));
+                hipLaunchKernelGGL(pb_h16_fill_kernel, dim3(pb_grid(mh)), dim3(256), 0, 0, hkeys, mh, hstart.as<uint32_t>(),
+                                   epos.as<uint32_t>(), pl->hbin_v.as<uint32_t>(), sb, bin_bits, H, T, pl->Racc,
+                                   pl->hot_ent.as<uint16_t>(), pl->hot_base.as<uint16_t>());
+                GM_HIP(hipGetLastError());
+                GM_HIP(hipDeviceSynchronize());
+            } else {
             hipLaunchKernelGGL(pb_pad4_sizes_kernel, dim3(pb_grid((uint64_t)cells + 1)), dim3(256), 0, 0,
                                hstart.as<uint32_t>(), cells, hpad.as<uint32_t>());
             GM_HIP(hipGetLastError());
@@ -2312,6 +2484,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
                                pl->hbin_v.as<uint32_t>(), sb, bin_bits, H, T, pl->hot_ent.as<uint32_t>());
             GM_HIP(hipGetLastError());
             GM_HIP(hipDeviceSynchronize());
+            }
         }
     }
     pl->Mhh = mhh;
@@ -2573,6 +2746,7 @@ static hipError_t pb_set_kernel_attributes()
                              reinterpret_cast<const void *>(&pb_accum_kernel<0, 2>),
                              reinterpret_cast<const void *>(&pb_accum_kernel<0, 6>),
                              reinterpret_cast<const void *>(&pb_accum_kernel<0, PB_ACC_DEPTH, true>),
+                             reinterpret_cast<const void *>(&pb_accum_kernel<0, PB_ACC_DEPTH, false, true>),
                              reinterpret_cast<const void *>(&pb_accum_kernel<3>),
                              reinterpret_cast<const void *>(&pb_accum_kernel<4>)};
     hipError_t e = hipSuccess;
@@ -2990,7 +3164,7 @@ uint64_t pb_work_items(const PbPlan *plan) { return plan ? (uint64_t)plan->NW + 
 void pb_plan_info(const PbPlan *pl, const PbScratch *sc, uint64_t *info, uint32_t count)
 {
     const DevBuf *bufs[] = {&pl->cidx, &pl->hub_rows, &pl->p1_src, &pl->chunk_seg, &pl->delta, &pl->tile_p, &pl->wg_tile,
-                            &pl->wg_p0,  &pl->p2_dst, &pl->bin_v,  &pl->items,     &pl->hot_ids, &pl->hot_ent, &pl->hbin_v,
+                            &pl->wg_p0,  &pl->p2_dst, &pl->bin_v,  &pl->items,     &pl->hot_ids, &pl->hot_ent, &pl->hbin_v, &pl->hot_base,
                             &pl->seq_rows, &pl->seq_blk, &pl->hh_ent};
     uint64_t plan_bytes = 0;
     for (const DevBuf *b : bufs)
@@ -3039,16 +3213,16 @@ void pb_launch_bin(const PbPlan *pl, PbScratch *sc, const float *x_in, uint32_t 
                        pl->Htot, sc->hot_x.as<float>());
 }
 
-template <int ABL, int D = PB_ACC_DEPTH, bool BF = false>
+template <int ABL, int D = PB_ACC_DEPTH, bool BF = false, bool H16 = false>
 void pb_launch_accum(const PbPlan *pl, PbScratch *sc, const PbItem *items, uint32_t count, float *x_out, float *scores,
                      const uint32_t *outdeg, float base, float damping, hipStream_t st, bool any_order = false)
 {
-    (void)pb_launch_flags(pb_accum_kernel<ABL, D, BF>, dim3(count), dim3(PB_ACC_BLOCK),
+    (void)pb_launch_flags(pb_accum_kernel<ABL, D, BF, H16>, dim3(count), dim3(PB_ACC_BLOCK),
                           (size_t)pl->Racc * 8 + 16 + (((size_t)pl->H + 3) & ~(size_t)3) * 4 * (pl->T > 1 ? 2 : 1), st, any_order,
                           sc->vals, pl->p2_dst.as<uint16_t>(), items, pl->hot_ent.as<uint32_t>(), pl->hbin_v.as<uint32_t>(),
                           sc->hot_x.as<float>(), pl->H, pl->T, pl->Htot, sc->partials.as<unsigned long long>(),
                           sc->tickets.as<uint32_t>(), pl->cidx.as<uint16_t>(), outdeg, scores, x_out, sc->bin_err.as<double>(),
-                          pl->n_local, pl->R, pl->Racc, base, damping);
+                          pl->n_local, pl->R, pl->Racc, base, damping, pl->hot_base.as<uint16_t>());
 }
 
 // GM_PB_ABLATE = 10*accumulate variant + bin variant; 0 = the product kernels (re-read per call so that
@@ -3085,6 +3259,10 @@ static void pb_accum_dispatch(const PbPlan *pl, PbScratch *sc, const PbItem *ite
 {
     if (count == 0)
         return;
+    if (pl->hot16) { // a plan with 2-byte hot records: the one kernel that reads them (no measurement variants)
+        pb_launch_accum<0, PB_ACC_DEPTH, false, true>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st, any_order);
+        return;
+    }
     switch (pb_env("GM_PB_ABLATE", 0) / 10) {
     case 3: pb_launch_accum<3>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
     case 4: pb_launch_accum<4>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;

@@ -706,6 +706,35 @@ def test_page_rank_pb_engine_matches_exact_row_sums(P, oracle):
         np.testing.assert_allclose(a[0], c[0], rtol=2e-6, atol=0)
 
 
+@pytest.mark.parametrize("scale,hot,tiers", [(16, "0", "0"), (18, "0", "0"), (18, "600", "3"), (20, "0", "0")])
+def test_page_rank_pb_two_byte_hot_records_give_the_bits_of_the_four_byte_ones(P, oracle, monkeypatch, scale, hot, tiers):
+    """The hot edges of the propagation-blocking plan as 2-byte records (row slot << 2 | how far the table index lies beyond
+    the record before it, a base index per eight records, fillers where the gap exceeds 3: the default) against 4-byte
+    ones (GM_PB_HOT16=0): the accumulators are integers, so the same edges in another encoding must give the same bits
+    — on whole sweeps, with one table and with several tiers (small tables: long gaps, many fillers), and through the
+    partitioned engine, whose over-long bins are shared by several workgroups (hot ranges cut at whole 512-record shares)."""
+    s, d = oracle.rmat_edges(scale, seed=11)
+    n = 1 << scale
+    g = _directed(P, n, s, d, P.CsrLayout.Sorted)
+    monkeypatch.setenv("GM_PB_NOCACHE", "1")
+    if hot != "0":
+        monkeypatch.setenv("GM_PB_HOT", hot)
+        monkeypatch.setenv("GM_PB_TIERS", tiers)
+    cfg = P.PageRankConfig(6, 0.0, 0.85)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GM_PB_HOT16", mode)
+        out[mode] = P.page_rank(g, cfg, P.PageRankMode.JacobiPB)
+    assert np.array_equal(out["1"][0], out["0"][0]) and out["1"][2] == out["0"][2]
+    monkeypatch.setenv("GM_MULTI_ENGINE", "pb")
+    monkeypatch.setenv("GM_MULTI_NOCACHE", "1")
+    part = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GM_PB_HOT16", mode)
+        part[mode] = P.page_rank_multi(g, cfg, devices=[0, 0, 0])
+    assert np.array_equal(part["1"][0], part["0"][0]) and np.array_equal(part["1"][0], out["1"][0])
+
+
 @pytest.mark.parametrize("scale", [16, 20])
 def test_page_rank_pb_engine_converged(P, oracle, scale):
     """every row exactly rounded (GM_PB_HUB_DEG=0): within 2e-6 of the f64 fixed point on every row; against the
