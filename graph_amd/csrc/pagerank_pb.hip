@@ -972,7 +972,7 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
     const PbItem item = items[blockIdx.x]; // longest items are dispatched first
     const uint32_t b = item.bin, tid = threadIdx.x;
     float *hot = reinterpret_cast<float *>(acc + Racc + 2); // the out_scores of one tier of hot sources (H at most); acc[Racc]: padding
-    const uint32_t qb = item.q0, qe = (ABL == 4 ? item.q0 : item.q1); // multiples of 4
+    const uint32_t qb = item.q0, qe = (ABL == 4 || ABL == 5 ? item.q0 : item.q1); // multiples of 4 (ABL 5: hot edges only, 6: stream only)
     constexpr uint32_t STEP = PB_ACC_BLOCK * PB_VEC;
     // Every phase keeps several independent loads per lane in flight and the first group of the value
     // stream is requested before the prologue: with one or two workgroups per CU nothing else hides a
@@ -1043,13 +1043,13 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
     };
     // the first tier with edges for this item at or behind t (T: none); uniform over the workgroup
     auto next_tier = [&](uint32_t t) {
-        for (; H && t < T && ABL != 4; ++t) {
+        for (; H && t < T && ABL != 4 && ABL != 6; ++t) {
             uint32_t ha, hb;
             tier_range(t, ha, hb);
             if (hb > ha)
                 break;
         }
-        return (H && ABL != 4) ? t : T;
+        return (H && ABL != 4 && ABL != 6) ? t : T;
     };
     uint32_t tier = next_tier(0);
     float *table = hot; // the table the current tier's edges gather from
@@ -2747,8 +2747,12 @@ static hipError_t pb_set_kernel_attributes()
                              reinterpret_cast<const void *>(&pb_accum_kernel<0, 6>),
                              reinterpret_cast<const void *>(&pb_accum_kernel<0, PB_ACC_DEPTH, true>),
                              reinterpret_cast<const void *>(&pb_accum_kernel<0, PB_ACC_DEPTH, false, true>),
+                             reinterpret_cast<const void *>(&pb_accum_kernel<5, PB_ACC_DEPTH, false, true>),
+                             reinterpret_cast<const void *>(&pb_accum_kernel<6, PB_ACC_DEPTH, false, true>),
                              reinterpret_cast<const void *>(&pb_accum_kernel<3>),
-                             reinterpret_cast<const void *>(&pb_accum_kernel<4>)};
+                             reinterpret_cast<const void *>(&pb_accum_kernel<4>),
+                             reinterpret_cast<const void *>(&pb_accum_kernel<5>),
+                             reinterpret_cast<const void *>(&pb_accum_kernel<6>)};
     hipError_t e = hipSuccess;
     for (const void *f : bin_fns)
         if (e == hipSuccess)
@@ -3259,13 +3263,21 @@ static void pb_accum_dispatch(const PbPlan *pl, PbScratch *sc, const PbItem *ite
 {
     if (count == 0)
         return;
-    if (pl->hot16) { // a plan with 2-byte hot records: the one kernel that reads them (no measurement variants)
-        pb_launch_accum<0, PB_ACC_DEPTH, false, true>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st, any_order);
+    if (pl->hot16) { // a plan with 2-byte hot records: the kernels that read them (measurement variants: 50 / 60 only)
+        switch (pb_env("GM_PB_ABLATE", 0) / 10) {
+        case 5: pb_launch_accum<5, PB_ACC_DEPTH, false, true>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
+        case 6: pb_launch_accum<6, PB_ACC_DEPTH, false, true>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
+        default:
+            pb_launch_accum<0, PB_ACC_DEPTH, false, true>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st, any_order);
+            break;
+        }
         return;
     }
     switch (pb_env("GM_PB_ABLATE", 0) / 10) {
     case 3: pb_launch_accum<3>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
     case 4: pb_launch_accum<4>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
+    case 5: pb_launch_accum<5>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
+    case 6: pb_launch_accum<6>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
     default:
         switch (pb_env("GM_PB_ACC_DEPTH", PB_ACC_DEPTH)) { // measurement: register groups of the value stream in flight
         case 2: pb_launch_accum<0, 2>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;

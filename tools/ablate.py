@@ -10,9 +10,10 @@ from graph_amd import synth
 from graph_amd.engine import PageRankEngine
 from graph_amd.prelude import CsrLayout, Direction
 scale = int(sys.argv[1]) if len(sys.argv) > 1 else 26
-codes = [int(c) for c in sys.argv[2:]] or [1, 3, 4, 5, 30, 40]
+codes = [int(c) for c in sys.argv[2:]] or [1, 3, 4, 5, 30, 40, 50, 60]
 NAMES = {0: "product", 1: "bin: no LDS gather", 3: "bin: no stores", 4: "bin: no x tile load", 5: "bin: x tile load only",
-         30: "accum: no epilogue", 40: "accum: no streaming loops"}
+         30: "accum: no epilogue", 40: "accum: no streaming loops", 50: "accum: hot edges + epilogue only",
+         60: "accum: value stream + epilogue only"}
 n = 1 << scale
 src, dst = synth.rmat_edges(scale, 42)
 od = torch.bincount(src, minlength=n).to(torch.int32)
