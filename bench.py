@@ -58,6 +58,8 @@ def parse_args():
                     "path to their fixed points and compare every row (about 20 s of host time at scale 26; 0 = skip)")
     ap.add_argument("--algos", type=int, default=1, help="N = 1, default scale only: WCC scale 22 / SSSP scale 24 / triangle count scale 24 "
                     "after the PageRank leg -> `extra` (about 15 s; 0 = skip)")
+    ap.add_argument("--tc-oracle", type=int, default=1, help="`extra`: check the scale-24 triangle count against orc_triangle_count in "
+                    "this process (about 24 s on 16 host cores; 0 = compare with the count tests/test_gpu_fullsize.py pins)")
     ap.add_argument("--relabel", type=int, default=0, help="(experimental) internal degree-ordered layout")
     ap.add_argument("--engine", choices=["auto", "pull", "pb"], default="auto")
     ap.add_argument("--prewarm-ms", type=float, default=400.0, help="untimed sweeps before the W warm-up steps so "
@@ -186,29 +188,14 @@ def main():
         torch.cuda.synchronize()
         print(f"pretouch: {free_b * args.pretouch_frac / 2**30:.0f} GiB allocated and freed in {time.time() - t_pt:.2f} s", file=sys.stderr)
     scale, n = args.scale, 1 << args.scale
-    t_build = time.time()
-    src, dst = synth.rmat_edges(scale, args.seed, args.edge_factor, local_rank)
-    m = src.numel()
-    if args.relabel:
-        # experiment: ids re-ranked by out-degree (descending) so the most-gathered out_scores are packed
-        deg = torch.bincount(src, minlength=n)
-        if args.relabel == 2:
-            deg = deg + torch.bincount(dst, minlength=n)
-        order = torch.argsort(deg, descending=True, stable=True)
-        new_id = torch.empty(n, dtype=torch.int32, device=dev)
-        new_id[order] = torch.arange(n, dtype=torch.int32, device=dev)
-        src = new_id[src.long()]
-        dst = new_id[dst.long()]
-        del deg, order, new_id
-    out_deg = torch.bincount(src, minlength=n).to(torch.int32)
-    in_csr = synth.build_csr(n, src, dst, Direction.Incoming, CsrLayout.Sorted, None, local_rank)
-    sparse = world > 1 and args.exchange == "sparse"
-    edges = (src, dst) if sparse else None
-    del src, dst
-    torch.cuda.empty_cache()
-    t_build = time.time() - t_build
+    m = args.edge_factor << scale
+    mem_peak = [0]
 
-    # ---- partition --------------------------------------------------------------------------
+    def mem_sample():
+        """device bytes in use (everything on the device: torch, the library's arena, RCCL), sampled at the checkpoints below"""
+        free_b, total_b = torch.cuda.mem_get_info(dev)
+        mem_peak[0] = max(mem_peak[0], total_b - free_b)
+
     emu = args.emulate_parts if world == 1 else 0
     if emu:
         world, rank = emu, args.emulate_rank  # pretend; no process group exists
@@ -218,26 +205,69 @@ def main():
         args.bin_pieces = 1
     if args.piece_streams < 0:
         args.piece_streams = 1 if world >= 4 else 0
+    sparse = world > 1 and args.exchange == "sparse" and not emu
     piecewise = world > 1 and args.exchange_parts > 1 and args.engine != "pull" and args.exchange != "sparse"
     ex = None
+    t_build = time.time()
+    if world == 1 or sparse or args.relabel:
+        # N = 1: the whole graph on this GPU.  (Also the opt-in sparse exchange, whose layout is derived from the whole edge
+        # list: gloo-tested with a stand-in engine, never the metric's path.)
+        src, dst = synth.rmat_edges(scale, args.seed, args.edge_factor, local_rank)
+        if args.relabel:
+            # experiment: ids re-ranked by out-degree (descending) so the most-gathered out_scores are packed
+            deg = torch.bincount(src, minlength=n)
+            if args.relabel == 2:
+                deg = deg + torch.bincount(dst, minlength=n)
+            order = torch.argsort(deg, descending=True, stable=True)
+            new_id = torch.empty(n, dtype=torch.int32, device=dev)
+            new_id[order] = torch.arange(n, dtype=torch.int32, device=dev)
+            src = new_id[src.long()]
+            dst = new_id[dst.long()]
+            del deg, order, new_id
+        out_deg = torch.bincount(src, minlength=n).to(torch.int32)
+        in_csr = synth.build_csr(n, src, dst, Direction.Incoming, CsrLayout.Sorted, None, local_rank)
+        edges = (src, dst) if sparse else None
+        del src, dst
+        torch.cuda.empty_cache()
+        mem_sample()
+        construction = "whole graph on the device"
+        if world > 1:
+            from graph_amd.distributed import greedy_degree_partition, pad_bounds
+
+            off_host = np.empty(n + 1, np.uint32)
+            check(lib().gm_csr_download(in_csr.handle, off_host.ctypes.data_as(vp), None, None))
+            bounds, _ = pad_bounds(greedy_degree_partition(off_host, world), world, n)
+            del off_host
+    else:
+        # N > 1 (and the one-device emulation of a rank): PARTITION-LOCAL construction — no rank generates the whole edge list
+        # or builds the whole in-CSR (graph_amd/distributed.py:rank_local_rows): degree histograms of m / N edges summed over the
+        # ranks, the reference's greedy in-degree ranges, then only the edges whose destination this rank owns
+        from graph_amd.distributed import rank_local_rows
+
+        in_csr, bounds, out_deg, edge_peak = rank_local_rows(scale, args.seed, rank, world, local_rank, args.edge_factor,
+                                                             collective=not emu)
+        edges = None
+        mem_sample()
+        construction = (f"partition-local: this rank generated and kept only the edges into its own rows "
+                        f"({in_csr.m} of {m}); degree histograms of m / {world} edges per rank, summed with an all-reduce"
+                        + (" (emulated rank: all of them scanned here)" if emu else ""))
+    t_build = time.time() - t_build
+
+    # ---- partition --------------------------------------------------------------------------
     if world == 1:
         local_csr, row_lo, n_local, stride = in_csr, 0, n, n
         out_deg_local = out_deg
         x_len = n
     else:
-        from graph_amd.distributed import (PiecewiseExchange, compact_exchange_layout, greedy_degree_partition, pad_bounds,
-                                           split_exchange_layout)
+        from graph_amd.distributed import PiecewiseExchange, compact_exchange_layout, split_exchange_layout
 
-        off_host = np.empty(n + 1, np.uint32)
-        check(lib().gm_csr_download(in_csr.handle, off_host.ctypes.data_as(vp), None, None))
-        bounds, _ = pad_bounds(greedy_degree_partition(off_host, world), world, n)
         row_lo, row_hi = int(bounds[rank]), int(bounds[rank + 1])
         n_local = row_hi - row_lo
         # exchange only the out_scores of nodes that have out-edges (the others are never gathered)
         if piecewise:
             layout = split_exchange_layout(out_deg, bounds, parts=args.exchange_parts)
             node_map, x_len, stride = layout["node_map"], layout["x_len"], sum(layout["strides"])
-        elif args.exchange == "sparse" and not emu:
+        elif sparse:
             from graph_amd.distributed import SparseExchange, sparse_exchange_layout
 
             layout = sparse_exchange_layout(None, None, bounds, rank, edges=edges)
@@ -256,14 +286,17 @@ def main():
 
         local_csr = DeviceCsr(h)
         out_deg_local = out_deg[row_lo:row_hi].contiguous() if n_local else torch.zeros(1, dtype=torch.int32, device=dev)
-        del in_csr, off_host
+        del in_csr
+        in_csr = None
         torch.cuda.empty_cache()
+        mem_sample()
     m_local = local_csr.m
 
     engine = PageRankEngine(local_csr.handle, n, row_lo, out_deg_local, 0.85, x_len=x_len,
                             engine={"auto": 2 if piecewise else 0, "pull": 1, "pb": 2}[args.engine])
     scores = torch.zeros(max(n_local, 1), dtype=torch.float32, device=dev)
     err = torch.zeros(1, dtype=torch.float64, device=dev)
+    mem_sample()
     if piecewise:
         gather = None
         if emu:  # stand-in for the collective: only this rank's slot of the region is refreshed
@@ -350,12 +383,19 @@ def main():
         step(evs)
     sync_all()
     seconds = time.perf_counter() - t0
+    mem_sample()
     if piecewise:
         ex.finish()
     if world > 1 and not emu:
         tt = torch.tensor([seconds], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         seconds = float(tt.item())
+    mem_ranks = [mem_peak[0]]
+    if world > 1 and not emu:
+        mine = torch.tensor([mem_peak[0]], dtype=torch.int64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        mem_ranks = [int(t.item()) for t in every]
     tile_ms_avg = sum(a.elapsed_time(b) for a, b in evs) / max(args.steps, 1)  # kernel time per sweep
     if world > 1 and not emu:
         dist.all_reduce(err, op=dist.ReduceOp.SUM)
@@ -430,6 +470,10 @@ def main():
                                                             if piecewise else "") if not sparse else
                          f"1-D vertex ranges (greedy in-degree), {world} ranks, sparse pairwise exchange: this rank receives "
                          f"{stride * 4} B/sweep (the out_scores its rows read)",
+            "construction": construction,
+            # per rank (everything on its device: torch, the library's arena, RCCL), sampled after the build, the slice, the
+            # plan and the timed sweeps; with --single-device every rank sees the same device
+            "device_bytes_in_use_peak_per_rank": mem_ranks,
             "device": _device_note(torch, dev),
             "csr_build_s": round(t_build, 3), "final_sweep_error": final_err, "workgroups_per_sweep": engine.tiles, "engine": engine.engine,
             "plan_build_ms": round(plan["plan_build_us"] / 1e3, 2) if plan else None, "plan_rebuild_ms": plan_rebuild_ms,
@@ -511,9 +555,9 @@ def main():
         import bench_algos
 
         try:
-            rec = bench_algos.measure(bench_algos.parse(["--oracle", "2", "--skip", "prapi", "--reps", "3"]))
+            rec = bench_algos.measure(bench_algos.parse(["--oracle", "2", "--tc-oracle", str(args.tc_oracle), "--skip", "prapi", "--reps", "3"]))
             result["extra"] = {
-                k: {"config": rec[k]["config"], "ms": round(rec[k]["ms"], 3), "roofline": rec[k]["roofline"],
+                k: {"config": rec[k]["config"], "ms": round(rec[k]["ms"], 3), "best_ms": round(rec[k]["best_ms"], 3), "roofline": rec[k]["roofline"],
                     "bit_exact": rec[k]["parity"]["bit_exact_vs_oracle"] if rec[k]["parity"]["bit_exact_vs_oracle"] is not None
                     else rec[k]["parity"].get("equals_the_count_pinned_by_that_test"), "parity": rec[k]["parity"],
                     "cpu_baseline": rec[k].get("cpu_baseline"),
@@ -522,8 +566,9 @@ def main():
                         "second_call_ms_builds_the_ordered_lists": round(rec[k]["second_call_ms_builds_the_ordered_lists"], 3)}
                        if k == "sssp" else {})}
                 for k in ("wcc", "sssp", "tc") if k in rec}
-            result["extra"]["protocol"] = ("tools/bench_algos.py in this process after the PageRank leg: best of 3 calls through the "
-                                           "prelude API (results downloaded), crates/app/src/app.rs:124-153; SSSP: calls 3-5 on the "
+            result["extra"]["protocol"] = ("tools/bench_algos.py in this process after the PageRank leg: `ms` = MEAN of 3 calls through the "
+                                           "prelude API (results downloaded) after warm-up calls, `best_ms` the fastest "
+                                           "(crates/app/src/app.rs:124-153); SSSP: calls 3-5 on the "
                                            "handle (the first runs on the CSR's lists, the second builds the weight-ordered and "
                                            "transposed copies the later ones use: both timed beside `ms`)")
         except Exception as exc:  # the headline line must not depend on the extras

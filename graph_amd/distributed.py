@@ -534,3 +534,59 @@ def partition_local_slices(scale: int, seed: int, ranks: int, devices=None, edge
         del local
         out_full.append(outd.to(torch.device("cuda", dev)).to(torch.int32).contiguous())
     return slices, [int(b) for b in bounds], out_full, devices
+
+
+def rank_local_rows(scale: int, seed: int, rank: int, world: int, device: int = 0, edge_factor: int = 16, group=None,
+                    collective: bool = True, chunk: int = 1 << 26):
+    """One rank's share of the R-MAT graph for the one-process-per-GPU front (bench.py --gpus N), built WITHOUT the whole
+    edge list or the whole CSR on any device:
+
+      1. degree histograms: this rank scans edge indices [rank m / world, (rank + 1) m / world) of the counter-based generator
+         in chunks and the ranks SUM their in- / out-degree vectors (`collective`; without a process group — the one-device
+         emulation of a rank — the caller scans all of them);
+      2. the reference's greedy in-degree ranges over the summed in-degrees (graph_ops.rs:431-439,479-509) — every rank computes
+         the same bounds;
+      3. the edges whose destination lies in this rank's range, kept from a chunked scan of the generator;
+      4. a Sorted in-CSR over them (n rows, all but the rank's own empty).
+
+    Returns (csr over the rank's edges, bounds uint32[world + 1], out_degree int32[n] on the device, peak bytes of the edge
+    buffers).  The caller slices rows [bounds[rank], bounds[rank + 1]) out of the CSR (gm_csr_slice_rows_map: targets rewritten
+    into the exchange index space) and drops it."""
+    from . import synth
+    from .prelude import CsrLayout, Direction
+
+    n, m = 1 << scale, edge_factor << scale
+    dev = torch.device("cuda", device)
+    ind = torch.zeros(n, dtype=torch.int64, device=dev)
+    outd = torch.zeros(n, dtype=torch.int64, device=dev)
+    shared = collective and world > 1
+    e_lo, e_hi = (rank * m // world, (rank + 1) * m // world) if shared else (0, m)
+    for first in range(e_lo, e_hi, chunk):
+        src, dst = synth.rmat_edge_range(scale, seed, first, min(chunk, e_hi - first), device)
+        ind += torch.bincount(dst, minlength=n)
+        outd += torch.bincount(src, minlength=n)
+        del src, dst
+    if shared:
+        dist.all_reduce(ind, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(outd, op=dist.ReduceOp.SUM, group=group)
+    off = np.zeros(n + 1, np.int64)
+    np.cumsum(ind.cpu().numpy(), out=off[1:])
+    del ind
+    bounds, _ = pad_bounds(greedy_degree_partition(off, world), world, n)
+    del off
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    keep_s, keep_d, peak = [], [], 0
+    for first in range(0, m, chunk):
+        src, dst = synth.rmat_edge_range(scale, seed, first, min(chunk, m - first), device)
+        mine = (dst >= lo) & (dst < hi)
+        keep_s.append(src[mine])
+        keep_d.append(dst[mine])
+        del src, dst, mine
+    s = torch.cat(keep_s) if keep_s else torch.empty(0, dtype=torch.int32, device=dev)
+    d = torch.cat(keep_d) if keep_d else torch.empty(0, dtype=torch.int32, device=dev)
+    del keep_s, keep_d
+    peak = int(s.numel()) * 8 * 2 + min(chunk, m) * 9  # the kept edges twice (list + concatenation) + one chunk and its mask
+    local = synth.build_csr(n, s, d, Direction.Incoming, CsrLayout.Sorted, None, device)
+    del s, d
+    torch.cuda.empty_cache()
+    return local, bounds, outd.to(torch.int32), peak

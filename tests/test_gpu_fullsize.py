@@ -171,6 +171,7 @@ def test_scale26_page_rank_within_1e5_every_row(env, rmat26):
     print(f"scale 26: device {it_g} sweeps, reference {rmat26['it_ref']} iterations; max rel {rel.max():.2e} on every row, "
           f"{rel[deg >= 4096].max():.2e} on rows with >= 4096 in-edges (max in-degree {int(deg.max())}), {over} rows over 1e-5")
     assert over == 0 and rel.max() <= 1e-5, (rel.max(), over)
+    rmat26["single"] = got  # the partitioned runs below must reproduce these BITS
     g.csr_inc.trim()  # the single engine's plan and parked stream: the eight slices of the next test bring their own
 
 
@@ -188,7 +189,33 @@ def test_scale26_partitioned_8_virtual_ranks_within_1e5_every_row(env, rmat26):
           f"{rel[deg >= 4096].max():.2e} on rows with >= 4096 in-edges, {over} rows over 1e-5")
     assert over == 0 and rel.max() <= 1e-5, (rel.max(), over)
     assert rel.max() <= 8e-6  # guard: margin erosion against the 1e-5 bar must be visible
+    # exactly rounded ordinary rows + the reference's own left-to-right sums on hub rows: the partition is not in the bits
+    assert np.array_equal(got, rmat26["single"])
     g.csr_inc.trim()
+
+
+def test_scale26_pieces_built_without_the_whole_graph_8_virtual_ranks(env, rmat26):
+    """The same configuration with NO device-wide graph behind it (north_star: "graphs larger than one GPU are 1-D
+    vertex-range partitioned"): every rank's rows are built from the edges whose destination lies in its range
+    (graph_amd/distributed.py:partition_local_slices — the reference's greedy in-degree ranges, graph_ops.rs:431-439,479-509,
+    from degree histograms) and run through gm_page_rank_multi_slices.  The single-GPU engine's bits, and within 1e-5 of
+    the reference's threaded path on every row."""
+    P, synth, torch = env
+    from graph_amd.distributed import partition_local_slices
+
+    ref, deg = rmat26["ref"], rmat26["deg"]
+    slices, bounds, out_full, devices = partition_local_slices(26, 42, 8)
+    assert bounds[0] == 0 and bounds[-1] == 1 << 26 and sum(s.m for s in slices) == 16 << 26
+    assert all(int(deg[bounds[p]:bounds[p + 1]].sum()) == slices[p].m for p in range(8))
+    got, it_g, _ = P.page_rank_multi_slices(slices, bounds, out_full, P.PageRankConfig(200, 1e-10, 0.85), devices)
+    rel = _rel(got, ref)
+    print(f"scale 26, 8 virtual ranks from pieces: {it_g} sweeps; max rel vs the reference {rel.max():.2e}, "
+          f"{int((rel > 1e-5).sum())} rows over 1e-5; edges per rank {[s.m for s in slices]}")
+    assert rel.max() <= 1e-5, rel.max()
+    assert np.array_equal(got, rmat26["single"])
+    del slices, out_full
+    torch.cuda.empty_cache()
+    P.trim_device(0)
 
 
 @pytest.mark.parametrize("ranks", [2, 4])
