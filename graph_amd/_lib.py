@@ -11,7 +11,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgraph_mi355x.so")
+# GRAPH_MI355X_LIB: another build of the same ABI (tools/ablate.py loads the measurement library `make measure` produces)
+LIB_PATH = os.environ.get("GRAPH_MI355X_LIB") or os.path.join(_HERE, "libgraph_mi355x.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 GM_OK = 0

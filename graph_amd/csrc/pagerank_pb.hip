@@ -135,6 +135,10 @@ struct PbScratch {
             (void)hipEventDestroy(ev_join);
     }
     DevBuf hot_x;    // f32[H]    out_scores of the hot sources, refreshed every sweep
+    // pb_hublong_kernel, a row over several workgroups: the item counter (u64), one hand-off word per item, the sums at the
+    // pass boundaries of the sweep before (what the next sweep predicts from), the launch number
+    DevBuf long_state; // u64 ticket | u64 handoff[n_long_items] | f32 sbs[long_sbs_len]
+    uint32_t long_epoch = 0;
 };
 
 struct PbItem {
@@ -168,6 +172,9 @@ struct PbPlan {
     uint32_t hub_long = 8192;  // rows with at least this many in-edges are a group of their own (pb_hublong_kernel): see pb_build
     uint32_t G_long = 0;
     uint64_t long_terms = 0;   // in-edges of the long rows
+    DevBuf long_items;         // PbLongItem[n_long_items]: the long rows cut into items of a few passes, row by row (longest row first)
+    uint32_t n_long_items = 0;
+    uint32_t long_sbs_len = 0; // entries of an engine's array of pass-boundary sums (every long row: its passes + 1)
     std::vector<uint32_t> hub_first_host;
     std::vector<uint8_t> hub_long_host; // per group: 1 = one long row
     std::vector<PbHubItem> hub_items_host;
@@ -1708,31 +1715,68 @@ __global__ __launch_bounds__(PB_SEQ_WG) __attribute__((amdgpu_waves_per_eu(5, 8)
 //   an exclusive scan over the workgroup gives every thread the J its run starts from;
 //   the first thread whose run ends at or beyond 2^24 — S leaves the binade there — starts from an exactly known S and
 //   adds its 16 terms with v_add_f32, one after the other; everything behind it is redone on the new grid.
-// S leaves a binade a few dozen times per row (and at every doubling of the first few thousand terms), so a super-block of
-// 8192 terms costs one pass (one barrier), sometimes two.  Bit for bit the reference's sum: tests/test_gpu_hub_adversarial.py compares
-// rows of up to 2^20 + 1 terms with orc_page_rank_jacobi_sweep's sequential sums for equality.
+// S leaves a binade a few dozen times per row (and at every doubling of the first few thousand terms), so a PASS — a
+// super-block of 8192 terms — costs one round (one barrier), sometimes two.  Bit for bit the reference's sum:
+// tests/test_gpu_hub_adversarial.py compares rows of up to 2^20 + 1 terms with orc_page_rank_jacobi_sweep's sequential sums
+// for equality.
+//
+// A ROW OVER SEVERAL WORKGROUPS (round 5).  One workgroup per row made the 854,315-term row of RMAT scale 26 a chain of 105
+// passes (0.35 ms: the critical path of its rank in an 8-way partition).  A row longer than `passes_per_item` passes is now
+// cut into ITEMS of that many passes, one workgroup each:
+//   1. (no dependence on the items before) for every pass whose sum stayed inside ONE binade in the PREVIOUS sweep — the
+//      sums at the pass boundaries are kept per engine (`sbs`); between two sweeps of a converging iteration they move by
+//      ulps — the workgroup forms the pass's pair (count from an even J, count from an odd J) on that binade's grid;
+//   2. it waits for the exact S the item before it hands over (a 64-bit word per item: launch epoch << 32 | bits of S;
+//      items are drawn from a counter in row order, so the item waited for is always running or done);
+//   3. pass by pass: if S lies in the binade the pair was formed for and J + count stays below 2^24, S = (J + count) ulp —
+//      a few scalar operations; otherwise (a pass in which S leaves its binade, the first pass of a row, a prediction
+//      that no longer holds, the first sweep of an engine) the pass is redone the way described above, from the exact S;
+//   4. the exact S is handed on, or the row is finished (pr_finalize).
+// What is predicted is only WHICH passes can be skipped through; every S is either (J + count) ulp with the count's grid
+// verified against the exact S, or the result of the sequential pass — the bits cannot depend on the prediction.
 // (at most 96 VGPRs: two of its wavefronts, one of pb_hubseq_kernel's (112) and four of the accumulate kernel's (56) share a SIMD's 512)
+constexpr uint32_t PB_LONG_PMAX = 16;  // passes of an item, at most
+struct PbLongItem {
+    uint32_t row;    // the row's entry of hub_items
+    uint32_t pass0;  // first pass (super-block of PB_LONG_WG x PB_LONG_PER stream entries) of the row this item covers
+    uint32_t npass;  // ... and how many (<= PB_LONG_PMAX)
+    uint32_t prev;   // the item whose S this one starts from; 0xFFFFFFFF: the row's first item (S = 0)
+    uint32_t sb0;    // the row's first entry of the per-engine array of pass-boundary sums (its passes + 1 entries)
+    uint32_t flags;  // 1: the row's last item (finishes the row); 2: the row has other items (pairs are formed ahead)
+};
+
 __global__ __launch_bounds__(PB_LONG_WG) __attribute__((amdgpu_waves_per_eu(5, 8))) void pb_hublong_kernel(const float *__restrict__ vals, const uint16_t *__restrict__ p2_dst,
                                                                 const PbHubItem *__restrict__ items,
+                                                                const PbLongItem *__restrict__ litems, uint32_t n_items,
+                                                                unsigned long long *__restrict__ ticket,
+                                                                unsigned long long *handoff, float *sbs,
+                                                                uint32_t epoch,
                                                                 const uint32_t *__restrict__ hub_rows,
                                                                 const uint32_t *__restrict__ outdeg, float *__restrict__ scores,
                                                                 float *__restrict__ x_out, double *__restrict__ group_err, float base,
-                                                                float damping, uint32_t n_rows)
+                                                                float damping)
 {
     constexpr uint32_t NWV = PB_LONG_WG / kWave, PER = PB_LONG_PER, SUPER = PB_LONG_WG * PER, SAT = 1u << 30, NONE = 0xFFFFFFFFu;
     constexpr uint32_t WARM = 1024 / PER; // threads whose terms (the row's first 1024) are added one after the other, see below
     // per wavefront: its runs composed, the first thread whose run leaves the binade; two copies used in turn: a wavefront
-    // that leaves a pass through its single barrier may write the next pass's totals while another still reads these
+    // that leaves a round through its single barrier may write the next round's totals while another still reads these
     __shared__ uint32_t w_a0s[2][NWV], w_a1s[2][NWV], w_firsts[2][NWV];
     __shared__ float s_bcast;
+    __shared__ uint32_t s_item;
+    __shared__ uint32_t sum_t0[PB_LONG_PMAX], sum_t1[PB_LONG_PMAX], sum_e[PB_LONG_PMAX]; // the passes' pairs and their binade (0: none)
     constexpr uint32_t TROW = PER + 4;          // floats between two threads' rows in the turning buffer (conflict-free 16-byte reads)
     constexpr uint32_t TOWN = PB_LONG_WG * 4 / PER; // threads that own the 2048 terms of one round
     __shared__ __attribute__((aligned(16))) float tbuf[TOWN * TROW]; // 2048 terms of the super-block at a time: 10 KiB
     static_assert(PB_LONG_WG == 512 && (PB_LONG_PER == 16 || PB_LONG_PER == 32) && WARM <= (uint32_t)kWave, "turning buffer / warm-up layout");
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     uint32_t flip = 0;
-    for (uint32_t row = blockIdx.x; row < n_rows; row += gridDim.x) { // (a grid smaller than the rows: pb_hub_dispatch)
-    const PbHubItem item = items[row]; // one row: slot 0 (padding entries: PB_NULL)
+    // the items in row order from a counter: exactly n_items draws per launch, so the counter needs no reset
+    if (tid == 0)
+        s_item = (uint32_t)(atomicAdd(ticket, 1ull) % n_items);
+    lds_barrier();
+    const uint32_t me = s_item;
+    const PbLongItem li = litems[me];
+    const PbHubItem item = items[li.row]; // one row: slot 0 (padding entries: PB_NULL)
     // (counts from an even / odd start) of run F followed by run G; saturated: beyond the first run that leaves the binade
     // nothing is used
     auto compose = [&](uint32_t f0, uint32_t f1, uint32_t g0, uint32_t g1, uint32_t &h0, uint32_t &h1) {
@@ -1786,16 +1830,41 @@ __global__ __launch_bounds__(PB_LONG_WG) __attribute__((amdgpu_waves_per_eu(5, 8
     };
     float S = 0.0f; // page_rank.rs:143
     float v[PER];
-    fetch(item.q0);
-    for (uint32_t sb = item.q0; sb < item.q1; sb += SUPER) {
-        turn(v);
-        if (item.q1 - sb > SUPER) // the next super-block's terms travel while this one's are added (every barrier below waits
-            fetch(sb + SUPER);     // for LDS traffic only: __syncthreads() would wait for these loads as well)
+    // my run of v on the grid of binade e as (count from an even J, count from an odd J); a term of 2^24 ulps or more makes the
+    // count reach 2^24 by itself, which is what marks the run as one in which S leaves the binade
+    auto my_pair = [&](float iu, uint32_t &a0, uint32_t &a1, bool &tie) {
+        uint32_t sum = 0;
+        tie = false;
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j) {
+            const float t = __builtin_fminf(v[j] * iu, 16777216.0f); // exact: a power-of-two scaling
+            const float r = __builtin_rintf(t);
+            sum += (uint32_t)r;
+            tie |= __builtin_fabsf(t - r) == 0.5f; // t - r is exact
+        }
+        a0 = a1 = sum; // <= PER x 2^24 < SAT
+        if (tie) { // the two-state walk: a tie goes to the even J
+            uint32_t x0 = 0, x1 = 0, p0 = 0, p1 = 1;
+#pragma unroll 4
+            for (uint32_t j = 0; j < PER; ++j) {
+                const float t = __builtin_fminf(v[j] * iu, 16777216.0f), fl = __builtin_floorf(t);
+                const uint32_t c = (uint32_t)__builtin_rintf(t), f = (uint32_t)fl;
+                const bool half = (t - fl) == 0.5f;
+                const uint32_t c0 = half ? f + ((p0 + f) & 1u) : c, c1 = half ? f + ((p1 + f) & 1u) : c;
+                x0 += c0, x1 += c1;
+                p0 = (p0 + c0) & 1u, p1 = (p1 + c1) & 1u;
+            }
+            a0 = x0, a1 = x1;
+        }
+    };
+    // One pass from an exactly known S: rounds of "everyone's pair, the workgroup's scan, the first run that leaves the
+    // binade added the slow way" until every thread's terms are in.
+    auto seq_pass = [&](bool row_start) {
         uint32_t done = 0; // threads below `done` have had their terms added
-        if (sb == item.q0) {
+        if (row_start) {
             // The row's first terms: a sum that starts at zero doubles after 2, 4, 8, ... terms, and every doubling would
-            // be a pass of its own.  The first 64 threads' terms (1024) are simply added in order by wavefront 0, the sum
-            // handed from lane to lane: ~100 cycles per thread instead of a pass of the whole workgroup per doubling.
+            // be a round of its own.  The first 64 threads' terms (1024) are simply added in order by wavefront 0, the sum
+            // handed from lane to lane: ~100 cycles per thread instead of a round of the whole workgroup per doubling.
             if (wave == 0) {
                 float s = 0.0f;
                 for (uint32_t k = 0; k < WARM; ++k) {
@@ -1820,37 +1889,13 @@ __global__ __launch_bounds__(PB_LONG_WG) __attribute__((amdgpu_waves_per_eu(5, 8
             const uint32_t J0 = (sbits & 0x7FFFFFu) | 0x800000u;
             const float iu = __uint_as_float((277u - (binade ? e : 150u)) << 23); // 1 / ulp(S)
             const float ulp = __uint_as_float(((binade ? e : 150u) - 23u) << 23);
-            // my run as (count from an even J, count from an odd J); a term of 2^24 ulps or more makes the count reach 2^24 by
-            // itself, which is what marks the run as the one where S leaves the binade
             uint32_t a0 = 0, a1 = 0;
             bool tie = false;
             if (tid >= done) {
-                if (!binade) {
+                if (!binade)
                     a0 = a1 = SAT; // S is still zero (or tiny): the first thread adds its terms the slow way
-                } else {
-                    uint32_t sum = 0;
-#pragma unroll
-                    for (uint32_t j = 0; j < PER; ++j) {
-                        const float t = __builtin_fminf(v[j] * iu, 16777216.0f); // exact: a power-of-two scaling
-                        const float r = __builtin_rintf(t);
-                        sum += (uint32_t)r;
-                        tie |= __builtin_fabsf(t - r) == 0.5f; // t - r is exact
-                    }
-                    a0 = a1 = sum; // <= PER x 2^24 < SAT
-                    if (tie) { // the two-state walk: a tie goes to the even J
-                        uint32_t x0 = 0, x1 = 0, p0 = 0, p1 = 1;
-#pragma unroll 4
-                        for (uint32_t j = 0; j < PER; ++j) {
-                            const float t = __builtin_fminf(v[j] * iu, 16777216.0f), fl = __builtin_floorf(t);
-                            const uint32_t c = (uint32_t)__builtin_rintf(t), f = (uint32_t)fl;
-                            const bool half = (t - fl) == 0.5f;
-                            const uint32_t c0 = half ? f + ((p0 + f) & 1u) : c, c1 = half ? f + ((p1 + f) & 1u) : c;
-                            x0 += c0, x1 += c1;
-                            p0 = (p0 + c0) & 1u, p1 = (p1 + c1) & 1u;
-                        }
-                        a0 = x0, a1 = x1;
-                    }
-                }
+                else
+                    my_pair(iu, a0, a1, tie);
             }
             // the wavefront's runs composed.  Without a tie in the wavefront a run adds the same count from either parity and
             // composing is adding: a butterfly sum of one value; otherwise the inclusive scan of the pairs.
@@ -1891,7 +1936,7 @@ __global__ __launch_bounds__(PB_LONG_WG) __attribute__((amdgpu_waves_per_eu(5, 8
             }
             const uint32_t P0 = J0 & 1u;
             if (binade && J0 + (P0 ? t1 : t0) < (1u << 24)) { // every remaining run stayed inside the binade:
-                S = (float)(J0 + (P0 ? t1 : t0)) * ulp;        // S = (J0 + count) ulp, exactly — the common pass, one barrier
+                S = (float)(J0 + (P0 ? t1 : t0)) * ulp;        // S = (J0 + count) ulp, exactly — the common round, one barrier
                 break;
             }
             // S leaves the binade somewhere: the first thread in whose run it does
@@ -1927,11 +1972,111 @@ __global__ __launch_bounds__(PB_LONG_WG) __attribute__((amdgpu_waves_per_eu(5, 8
             if (done >= PB_LONG_WG)
                 break;
         }
+    };
+    const uint32_t q_first = item.q0 + li.pass0 * SUPER;
+    float *my_sbs = sbs + li.sb0 + li.pass0; // the sums at my passes' boundaries: [p] before pass p, [npass] behind the last
+    uint32_t held = NONE; // the pass whose entries are in `raw`
+    // 1. the pairs of the passes that stayed inside one binade in the sweep before — only where there is something to wait for
+    uint32_t ahead = 0; // bit p: pass p gets its pair formed ahead
+    if (li.flags & 2u) {
+        for (uint32_t p = 0; p < li.npass; ++p) {
+            const uint32_t ea = __float_as_uint(my_sbs[p]) >> 23, eb = __float_as_uint(my_sbs[p + 1u]) >> 23;
+            if (ea == eb && ea >= 24u && ea < 255u && li.pass0 + p != 0u)
+                ahead |= 1u << p;
+        }
     }
-    if (tid == 0)
-        group_err[item.group] = pr_finalize(hub_rows[item.row0], S, base, damping, outdeg, scores, x_out);
-    lds_barrier();
-    } // rows of this workgroup
+    if (tid < PB_LONG_PMAX)
+        sum_e[tid] = 0u;
+    if (ahead) {
+        uint32_t p = (uint32_t)__ffs((int)ahead) - 1u;
+        fetch(q_first + p * SUPER);
+        for (uint32_t left = ahead; left;) {
+            left &= left - 1u;
+            turn(v);
+            const uint32_t pn = left ? (uint32_t)__ffs((int)left) - 1u : NONE;
+            if (pn != NONE)
+                fetch(q_first + pn * SUPER); // the next pass's entries travel while this one's pair is formed
+            held = pn;
+            const uint32_t e = __float_as_uint(my_sbs[p]) >> 23;
+            uint32_t a0, a1;
+            bool tie;
+            my_pair(__uint_as_float((277u - e) << 23), a0, a1, tie);
+            uint32_t *w_a0 = w_a0s[flip], *w_a1 = w_a1s[flip];
+            flip ^= 1u;
+            uint32_t wt0, wt1;
+            if (__ballot(tie) != 0ull) { // the runs of a wavefront composed in order: the last lane of an inclusive scan
+                uint32_t i0 = a0, i1 = a1;
+#pragma unroll
+                for (uint32_t o = 1; o < (uint32_t)kWave; o <<= 1) {
+                    const uint32_t f0 = (uint32_t)__shfl_up((int)i0, o, kWave), f1 = (uint32_t)__shfl_up((int)i1, o, kWave);
+                    if (lane >= o)
+                        compose(f0, f1, i0, i1, i0, i1);
+                }
+                wt0 = (uint32_t)__shfl((int)i0, kWave - 1, kWave), wt1 = (uint32_t)__shfl((int)i1, kWave - 1, kWave);
+            } else {
+                uint32_t x = a0;
+#pragma unroll
+                for (int o = kWave / 2; o > 0; o >>= 1) {
+                    x += (uint32_t)__shfl_xor((int)x, o, kWave);
+                    x = x < SAT ? x : SAT;
+                }
+                wt0 = wt1 = x;
+            }
+            if (lane == 0)
+                w_a0[wave] = wt0, w_a1[wave] = wt1;
+            lds_barrier();
+            if (tid == 0) {
+                uint32_t t0 = 0, t1 = 0;
+                for (uint32_t w = 0; w < NWV; ++w)
+                    compose(t0, t1, w_a0[w], w_a1[w], t0, t1);
+                sum_t0[p] = t0, sum_t1[p] = t1, sum_e[p] = e;
+            }
+            p = pn;
+        }
+    }
+    // 2. the exact sum in front of my first term
+    if (li.prev != NONE) {
+        if (tid == 0) {
+            unsigned long long w;
+            while (((w = __hip_atomic_load(handoff + li.prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != epoch)
+                __builtin_amdgcn_s_sleep(8);
+            s_bcast = __uint_as_float((uint32_t)w);
+        }
+        lds_barrier();
+        S = s_bcast;
+    }
+    lds_barrier(); // (the pairs of step 1 are in LDS; s_bcast has been read by everyone before a pass writes it again)
+    // 3. pass by pass
+    for (uint32_t p = 0; p < li.npass; ++p) {
+        if (tid == 0)
+            my_sbs[p] = S; // what the next sweep predicts from
+        const uint32_t sbits = __float_as_uint(S), e = sbits >> 23;
+        if (sum_e[p] == e && e != 0u) { // the pair was formed on the grid S lies on
+            const uint32_t J0 = (sbits & 0x7FFFFFu) | 0x800000u, cnt = (J0 & 1u) ? sum_t1[p] : sum_t0[p];
+            if (J0 + cnt < (1u << 24)) {
+                S = (float)(J0 + cnt) * __uint_as_float((e - 23u) << 23); // (J0 + count) ulp, exactly
+                continue;
+            }
+        }
+        if (held != p)
+            fetch(q_first + p * SUPER);
+        turn(v);
+        held = NONE;
+        if (p + 1u < li.npass && sum_e[p + 1u] == 0u) { // the next pass is walked as well: its entries travel meanwhile
+            fetch(q_first + (p + 1u) * SUPER);           // (every barrier below waits for LDS traffic only)
+            held = p + 1u;
+        }
+        seq_pass(li.pass0 + p == 0u);
+    }
+    // 4. hand the sum on, or finish the row
+    if (tid == 0) {
+        my_sbs[li.npass] = S;
+        if (li.flags & 1u)
+            group_err[item.group] = pr_finalize(hub_rows[item.row0], S, base, damping, outdeg, scores, x_out);
+        else
+            __hip_atomic_store(handoff + me, ((unsigned long long)epoch << 32) | __float_as_uint(S), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 __global__ __launch_bounds__(1024) void pb_err_kernel(const double *__restrict__ bin_err, uint32_t B, double *__restrict__ err_out)
@@ -2092,6 +2237,28 @@ int pb_make_items(PbPlan *pl)
     if (!hubs.empty())
         GM_HIP(hipMemcpy(pl->hub_items.p, hubs.data(), hubs.size() * sizeof(PbHubItem), hipMemcpyHostToDevice));
     pl->hub_items_host = hubs;
+    // the long rows as items of GM_PB_LONG_PASSES passes (default 8: 65536 terms; 0 / >= 16: 16), row by row
+    {
+        constexpr uint32_t SUPER = PB_LONG_WG * PB_LONG_PER;
+        uint32_t per = (uint32_t)pb_env("GM_PB_LONG_PASSES", 8);
+        per = per >= 1 && per <= PB_LONG_PMAX ? per : PB_LONG_PMAX;
+        std::vector<PbLongItem> li;
+        uint32_t sb = 0;
+        for (uint32_t r = 0; r < pl->G_long; ++r) {
+            const uint32_t len = hubs[r].q1 - hubs[r].q0, passes = len ? (len + SUPER - 1u) / SUPER : 1u;
+            for (uint32_t p0 = 0; p0 < passes; p0 += per) {
+                const uint32_t np = passes - p0 < per ? passes - p0 : per;
+                li.push_back(PbLongItem{r, p0, np, p0 ? (uint32_t)li.size() - 1u : 0xFFFFFFFFu, sb,
+                                        (p0 + np == passes ? 1u : 0u) | (passes > per ? 2u : 0u)});
+            }
+            sb += passes + 1u;
+        }
+        pl->n_long_items = (uint32_t)li.size();
+        pl->long_sbs_len = sb;
+        GM_TRY(pl->long_items.alloc((li.size() ? li.size() : 1) * sizeof(PbLongItem)));
+        if (!li.empty())
+            GM_HIP(hipMemcpy(pl->long_items.p, li.data(), li.size() * sizeof(PbLongItem), hipMemcpyHostToDevice));
+    }
     return GM_OK;
 }
 
@@ -3119,12 +3286,15 @@ int pb_scratch_create(const PbPlan *pl, PbScratch **out, DevBuf *early)
     if ((rc = sc->vals_raw.p ? GM_OK : sc->vals_raw.alloc((size_t)(pl->Mv ? pl->Mv : 4) * 4 + slack)) ||
         (rc = sc->partials.alloc((size_t)(pl->slots ? pl->slots : 1) * pl->Racc * 8)) ||
         (rc = sc->tickets.alloc((size_t)pl->B * 4)) || (rc = sc->bin_err.alloc(((size_t)pl->B + pl->G) * 8)) ||
-        (rc = sc->hot_x.alloc(((size_t)pl->H * pl->T + 4) * 4))) {
+        (rc = sc->hot_x.alloc(((size_t)pl->H * pl->T + 4) * 4)) ||
+        (rc = sc->long_state.alloc(8 + (size_t)pl->n_long_items * 8 + (size_t)pl->long_sbs_len * 4 + 8))) {
         delete sc;
         return rc;
     }
     sc->vals = sc->vals_raw.as<float>();
     hipError_t e = hipMemset(sc->tickets.p, 0, (size_t)pl->B * 4);
+    if (e == hipSuccess) // (no hand-off word carries epoch 0, the counter starts at 0, sums of 0 predict nothing)
+        e = hipMemset(sc->long_state.p, 0, sc->long_state.bytes);
     if (e == hipSuccess)
         e = hipMemset(sc->vals_raw.p, 0, sc->vals_raw.bytes);
     // The hub kernels' streams get the LOWEST priority the device offers (GM_PB_SIDE_PRIO=0: the default one): their small
@@ -3237,23 +3407,28 @@ static bool pb_bin_dispatch(const PbPlan *pl, PbScratch *sc, const float *x_in, 
 {
     if (w_count == 0)
         return false;
+    fold_hot = fold_hot && pl->Htot && (uint64_t)w_count * PB_BIN_BLOCK >= pl->Htot;
+#ifdef GM_MEASURE // the measurement library only (make measure; tools/ablate.py): variants that leave one ingredient out
     const int abl = item_list ? 0 : pb_env("GM_PB_ABLATE", 0) % 10;
-    fold_hot = fold_hot && abl == 0 && pl->Htot && (uint64_t)w_count * PB_BIN_BLOCK >= pl->Htot;
-    if (pl->s_log == 15) {
+    fold_hot = fold_hot && abl == 0;
+    if (pl->s_log == 15 && (abl == 3 || abl == 5)) {
+        abl == 3 ? pb_launch_bin<3, 15>(pl, sc, x_in, w_first, w_count, st) : pb_launch_bin<5, 15>(pl, sc, x_in, w_first, w_count, st);
+        return false;
+    }
+    if (pl->s_log == 14 && abl) {
         switch (abl) {
-        case 3: pb_launch_bin<3, 15>(pl, sc, x_in, w_first, w_count, st); break;
-        case 5: pb_launch_bin<5, 15>(pl, sc, x_in, w_first, w_count, st); break;
-        default: pb_launch_bin<0, 15>(pl, sc, x_in, w_first, w_count, st, item_list, fold_hot); break;
+        case 1: pb_launch_bin<1, 14>(pl, sc, x_in, w_first, w_count, st); return false;
+        case 3: pb_launch_bin<3, 14>(pl, sc, x_in, w_first, w_count, st); return false;
+        case 4: pb_launch_bin<4, 14>(pl, sc, x_in, w_first, w_count, st); return false;
+        case 5: pb_launch_bin<5, 14>(pl, sc, x_in, w_first, w_count, st); return false;
+        default: break;
         }
-        return fold_hot;
     }
-    switch (abl) {
-    case 1: pb_launch_bin<1, 14>(pl, sc, x_in, w_first, w_count, st); break;
-    case 3: pb_launch_bin<3, 14>(pl, sc, x_in, w_first, w_count, st); break;
-    case 4: pb_launch_bin<4, 14>(pl, sc, x_in, w_first, w_count, st); break;
-    case 5: pb_launch_bin<5, 14>(pl, sc, x_in, w_first, w_count, st); break;
-    default: pb_launch_bin<0, 14>(pl, sc, x_in, w_first, w_count, st, item_list, fold_hot); break;
-    }
+#endif
+    if (pl->s_log == 15)
+        pb_launch_bin<0, 15>(pl, sc, x_in, w_first, w_count, st, item_list, fold_hot);
+    else
+        pb_launch_bin<0, 14>(pl, sc, x_in, w_first, w_count, st, item_list, fold_hot);
     return fold_hot;
 }
 
@@ -3263,34 +3438,36 @@ static void pb_accum_dispatch(const PbPlan *pl, PbScratch *sc, const PbItem *ite
 {
     if (count == 0)
         return;
-    if (pl->hot16) { // a plan with 2-byte hot records: the kernels that read them (measurement variants: 50 / 60 only)
+#ifdef GM_MEASURE // the measurement library only: a phase left out (GM_PB_ABLATE / 10), other ring depths, branch-free padding
+    if (pl->hot16) {
         switch (pb_env("GM_PB_ABLATE", 0) / 10) {
-        case 5: pb_launch_accum<5, PB_ACC_DEPTH, false, true>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
-        case 6: pb_launch_accum<6, PB_ACC_DEPTH, false, true>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
-        default:
-            pb_launch_accum<0, PB_ACC_DEPTH, false, true>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st, any_order);
-            break;
+        case 5: pb_launch_accum<5, PB_ACC_DEPTH, false, true>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); return;
+        case 6: pb_launch_accum<6, PB_ACC_DEPTH, false, true>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); return;
+        default: break;
         }
-        return;
-    }
-    switch (pb_env("GM_PB_ABLATE", 0) / 10) {
-    case 3: pb_launch_accum<3>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
-    case 4: pb_launch_accum<4>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
-    case 5: pb_launch_accum<5>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
-    case 6: pb_launch_accum<6>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
-    default:
-        switch (pb_env("GM_PB_ACC_DEPTH", PB_ACC_DEPTH)) { // measurement: register groups of the value stream in flight
-        case 2: pb_launch_accum<0, 2>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
-        case 6: pb_launch_accum<0, 6>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); break;
-        default:
-            if (pb_env("GM_PB_ACC_BRANCHFREE", 0))
-                pb_launch_accum<0, PB_ACC_DEPTH, true>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st);
-            else
-                pb_launch_accum<0>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st, any_order);
-            break;
+    } else {
+        switch (pb_env("GM_PB_ABLATE", 0) / 10) {
+        case 3: pb_launch_accum<3>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); return;
+        case 4: pb_launch_accum<4>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); return;
+        case 5: pb_launch_accum<5>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); return;
+        case 6: pb_launch_accum<6>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); return;
+        default: break;
         }
-        break;
+        switch (pb_env("GM_PB_ACC_DEPTH", PB_ACC_DEPTH)) { // register groups of the value stream in flight
+        case 2: pb_launch_accum<0, 2>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); return;
+        case 6: pb_launch_accum<0, 6>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st); return;
+        default: break;
+        }
+        if (pb_env("GM_PB_ACC_BRANCHFREE", 0)) {
+            pb_launch_accum<0, PB_ACC_DEPTH, true>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st);
+            return;
+        }
     }
+#endif
+    if (pl->hot16) // a plan with 2-byte hot records
+        pb_launch_accum<0, PB_ACC_DEPTH, false, true>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st, any_order);
+    else
+        pb_launch_accum<0>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st, any_order);
 }
 
 // every hub group of the plan (its value-stream part must have been written: after the bin kernel)
@@ -3301,19 +3478,28 @@ static bool pb_hub_dispatch(const PbPlan *pl, PbScratch *sc, float *x_out, float
 {
     double *gerr = sc->bin_err.as<double>() + pl->B;
     const PbHubItem *items = pl->hub_items.as<PbHubItem>();
+#ifdef GM_MEASURE
     const int skip = pb_env("GM_PB_HUB_SKIP", 0); // measurement (wrong results by design): 1 = no pb_hubseq_kernel, 2 = no long rows
+#else
+    constexpr int skip = 0;
+#endif
     // GM_PB_LONG_WGS / GM_PB_SEQ_WGS: workgroups of the two kernels (0 = one per row / group)
     const uint32_t n_seq = pl->G - pl->G_long;
-    uint32_t long_wgs = (uint32_t)pb_env("GM_PB_LONG_WGS", 0), seq_wgs = (uint32_t)pb_env("GM_PB_SEQ_WGS", 0);
-    long_wgs = long_wgs && long_wgs < pl->G_long ? long_wgs : pl->G_long;
+    uint32_t seq_wgs = (uint32_t)pb_env("GM_PB_SEQ_WGS", 0);
     seq_wgs = seq_wgs && seq_wgs < n_seq ? seq_wgs : n_seq;
+    // the long rows: one workgroup per item (a row, or a few passes of a longer one), exactly n_long_items draws of the counter
+    unsigned long long *l_ticket = sc->long_state.as<unsigned long long>(), *l_handoff = l_ticket + 1;
+    float *l_sbs = reinterpret_cast<float *>(l_handoff + pl->n_long_items);
+    const PbLongItem *l_items = pl->long_items.as<PbLongItem>();
+    const uint32_t l_epoch = pl->G_long && !(skip & 2) ? ++sc->long_epoch : 0u;
     const uint32_t v_safe = (uint32_t)(pl->Mv >= 4 ? (pl->Mv - 4) & ~3ull : 0), h_safe = (uint32_t)(pl->Mhh ? pl->Mhh - 1u : 0u);
+#ifdef GM_MEASURE // launches without the barrier bit on one stream (gfx950 serialises them: DESIGN.md)
     if (inline_any) {
         bool launched = false;
         if (pl->G_long && !(skip & 2)) {
-            (void)pb_launch_flags(pb_hublong_kernel, dim3(long_wgs), dim3(PB_LONG_WG), 0, st, launched, sc->vals,
-                                  pl->p2_dst.as<uint16_t>(), items, pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr, base,
-                                  damping, pl->G_long);
+            (void)pb_launch_flags(pb_hublong_kernel, dim3(pl->n_long_items), dim3(PB_LONG_WG), 0, st, launched, sc->vals,
+                                  pl->p2_dst.as<uint16_t>(), items, l_items, pl->n_long_items, l_ticket, l_handoff, l_sbs, l_epoch,
+                                  pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr, base, damping);
             launched = true;
         }
         if (pl->G > pl->G_long && !(skip & 1)) {
@@ -3326,6 +3512,7 @@ static bool pb_hub_dispatch(const PbPlan *pl, PbScratch *sc, float *x_out, float
         }
         return launched;
     }
+#endif
     // the long rows on a stream of their own beside the other groups (when there are both)
     const bool own = pl->G_long && sc->chain;
     hipStream_t ls = own ? sc->chain : st;
@@ -3334,8 +3521,9 @@ static bool pb_hub_dispatch(const PbPlan *pl, PbScratch *sc, float *x_out, float
             (void)hipEventRecord(sc->ev_chain_fork, st);
             (void)hipStreamWaitEvent(ls, sc->ev_chain_fork, 0);
         }
-        hipLaunchKernelGGL(pb_hublong_kernel, dim3(long_wgs), dim3(PB_LONG_WG), 0, ls, sc->vals, pl->p2_dst.as<uint16_t>(), items,
-                           pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr, base, damping, pl->G_long);
+        hipLaunchKernelGGL(pb_hublong_kernel, dim3(pl->n_long_items), dim3(PB_LONG_WG), 0, ls, sc->vals, pl->p2_dst.as<uint16_t>(), items,
+                           l_items, pl->n_long_items, l_ticket, l_handoff, l_sbs, l_epoch, pl->hub_rows.as<uint32_t>(), outdeg, scores,
+                           x_out, gerr, base, damping);
         if (own)
             (void)hipEventRecord(sc->ev_chain_join, ls);
     }
@@ -3377,12 +3565,14 @@ int pb_sweep_main(const PbPlan *pl, PbScratch *sc, const float *x_in, float *x_o
     // (measured at scale 26 / 22 on one box: 3.12 / 3.24 ms forked vs 3.33 / 3.44 ms in line, 0.216 vs 0.252 ms;
     // with the 85-VGPR version of the kernel the two could not share a CU and forking gained nothing)
     const bool fork = pl->G && sc->side && pl->hub_edges >= (1u << 20) && pb_env("GM_PB_HUB_FORK", 1);
+#ifdef GM_MEASURE
     if (pl->G && pb_env("GM_PB_ANYORDER", 0)) {
         const bool any = pb_hub_dispatch(pl, sc, x_out, scores, outdeg, base, damping, st, true);
         pb_accum_dispatch(pl, sc, pl->items.as<PbItem>(), pl->NI, x_out, scores, outdeg, base, damping, st, any);
         GM_HIP(hipGetLastError());
         return GM_OK;
     }
+#endif
     if (fork) {
         GM_HIP(hipEventRecord(sc->ev_fork, st));
         GM_HIP(hipStreamWaitEvent(sc->side, sc->ev_fork, 0));
@@ -3516,9 +3706,14 @@ int pb_sweep_accum_part(const PbPlan *pl, PbScratch *sc, const float *x_in, floa
     if (stage_hot)
         pb_hot_dispatch(pl, sc, x_in, st);
     bool any = false;
-    if (part == 0) // every hub row is finished with the first part: before any region of x_out is exchanged
+    if (part == 0) { // every hub row is finished with the first part: before any region of x_out is exchanged
+#ifdef GM_MEASURE
         any = pb_hub_dispatch(pl, sc, x_out, scores, outdeg, base, damping, st, pl->G && pb_env("GM_PB_ANYORDER", 0)) &&
               pl->G && pb_env("GM_PB_ANYORDER", 0);
+#else
+        pb_hub_dispatch(pl, sc, x_out, scores, outdeg, base, damping, st);
+#endif
+    }
     const uint32_t i0 = sc->part_off[part], i1 = sc->part_off[part + 1];
     pb_accum_dispatch(pl, sc, sc->part_items.as<PbItem>() + i0, i1 - i0, x_out, scores, outdeg, base, damping, st, any);
     GM_HIP(hipGetLastError());

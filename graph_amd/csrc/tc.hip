@@ -20,7 +20,9 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include <algorithm>
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -314,19 +316,36 @@ __global__ __launch_bounds__(BLOCK) void tc_rows_kernel(const uint32_t *__restri
                                                             const uint32_t *__restrict__ item_first /* K+1, exclusive scan */,
                                                             const uint32_t *__restrict__ item_row,
                                                             uint32_t item_base /* first item of this launch */,
+                                                            uint32_t n_items /* items of this launch */,
+                                                            uint32_t row_words /* 4-byte words of the launch's longest row */,
+                                                            uint32_t *__restrict__ ticket /* this launch's item counter */,
                                                             uint32_t per_item, uint32_t dyn,
                                                             unsigned long long *__restrict__ total)
 {
     extern __shared__ uint32_t tc_row[];
     __shared__ uint64_t red[BLOCK / kWave];
-    __shared__ uint32_t next_u;
+    __shared__ uint32_t next_u, next_item;
     constexpr int TCR_BLOCK = BLOCK;
-    const uint32_t item = item_base + blockIdx.x;
-    const uint32_t v = item_row[item];
-    const uint32_t words = (v + 31u) >> 5;
-    for (uint32_t i = threadIdx.x; i < words; i += TCR_BLOCK)
+    // A workgroup DRAWS its items from the launch's counter and keeps its bit row between them: the row is cleared once,
+    // an item sets the bits of its L(v) and takes them back afterwards.  One workgroup per item (rounds 1-4) cleared
+    // v / 8 bytes of LDS for every item: 32-64 KiB for each of the 262 k one-item rows beyond 2^18, whose lists hold a
+    // few dozen entries (profiles/r05_algos_profile.txt: 4.2 of the 28 ms of this kernel for those rows alone).
+    for (uint32_t i = threadIdx.x; i < row_words; i += TCR_BLOCK)
         tc_row[i] = 0u;
-    __syncthreads();
+    uint32_t count = 0;
+    constexpr uint64_t GMASK = GROUP == 64 ? ~0ull : ((1ull << (GROUP & 63)) - 1ull);
+    constexpr uint32_t MLP16 = MLP > 1 ? MLP / 2 : 1; // 8-byte loads of four 2-byte ids
+    const uint32_t l = threadIdx.x % GROUP;
+    const uint32_t gshift = (threadIdx.x & (kWave - 1)) / GROUP * GROUP; // this group's bits of a wavefront ballot
+    for (;;) {
+    if (threadIdx.x == 0)
+        next_item = atomicAdd(ticket, 1u);
+    __syncthreads(); // (also: the row is clean — the first clear, or the bits the item before took back)
+    const uint32_t drawn = next_item;
+    if (drawn >= n_items)
+        break;
+    const uint32_t item = item_base + drawn;
+    const uint32_t v = item_row[item];
     const uint32_t lv = loff[v], nv = loff[v + 1] - lv;
     for (uint32_t i = threadIdx.x; i < nv; i += TCR_BLOCK) {
         const uint32_t w = dag_tgt[lv + i]; // < v: lists are strictly increasing and hold no self-loop on this path
@@ -337,11 +356,6 @@ __global__ __launch_bounds__(BLOCK) void tc_rows_kernel(const uint32_t *__restri
     if (threadIdx.x == 0)
         next_u = ubeg;
     __syncthreads();
-    constexpr uint64_t GMASK = GROUP == 64 ? ~0ull : ((1ull << (GROUP & 63)) - 1ull);
-    constexpr uint32_t MLP16 = MLP > 1 ? MLP / 2 : 1; // 8-byte loads of four 2-byte ids
-    const uint32_t l = threadIdx.x % GROUP;
-    const uint32_t gshift = (threadIdx.x & (kWave - 1)) / GROUP * GROUP; // this group's bits of a wavefront ballot
-    uint32_t count = 0;
     // four bits of a packed load against the row: entries base .. base + 3 of a 2-byte front of `lim` entries
     auto probe4 = [&](unsigned long long pk, uint32_t base, uint32_t lim, bool &over) {
 #pragma unroll
@@ -463,6 +477,17 @@ __global__ __launch_bounds__(BLOCK) void tc_rows_kernel(const uint32_t *__restri
             }
         }
     }
+    // the item is done: its bits leave the row (every group has finished probing it)
+    __syncthreads();
+    const uint32_t words = (v + 31u) >> 5;
+    if (nv < words) {
+        for (uint32_t i = threadIdx.x; i < nv; i += TCR_BLOCK)
+            tc_row[dag_tgt[lv + i] >> 5] = 0u;
+    } else {
+        for (uint32_t i = threadIdx.x; i < words; i += TCR_BLOCK)
+            tc_row[i] = 0u;
+    }
+    } // items of this workgroup
     const uint64_t block_total = block_sum<uint64_t, BLOCK / kWave>((uint64_t)count, red);
     if (threadIdx.x == 0 && block_total)
         atomicAdd(total, (unsigned long long)block_total);
@@ -659,9 +684,9 @@ GM_API int gm_triangle_count(const gm_csr *g, uint64_t *triangles_out)
         return GM_OK;
     const gm::DevBuf &low_len = dag->low_len, &loff = dag->loff, &dag_src = dag->dag_src, &dag_tgt = dag->dag_tgt,
                      &dag16 = dag->dag16, &rec = dag->rec;
-    gm::DevBuf ctrl;
-    GM_TRY(ctrl.alloc(16));
-    GM_HIP(hipMemset(ctrl.p, 0, 16));
+    gm::DevBuf ctrl; // the count (8 bytes, 16 reserved), then one item counter per tc_rows_kernel launch
+    GM_TRY(ctrl.alloc(16 + 64 * 4));
+    GM_HIP(hipMemset(ctrl.p, 0, 16 + 64 * 4));
     unsigned cgrid = gm::div_up(dag_m, TC_BLOCK);
     if (cgrid > 256 * 16)
         cgrid = 256 * 16;
@@ -711,16 +736,37 @@ GM_API int gm_triangle_count(const gm_csr *g, uint64_t *triangles_out)
         // measured best at scale 24 (1024 x 16: +12 %, 256 x 16: +11 %; four lists per draw: 45.9 ms against 39.3 for one —
         // with the lists drawn from the counter the balance is worth more than the overlap of the dependent loads)
         int shape_b = 512, shape_g = 8, shape_m = 4, shape_u = 1;
-        // GM_TC_HUB="<rows>,<lists per draw>": the launches of rows below <rows> draw that many lists at a time (their
-        // fronts are all short, so there is nothing to balance; measured at scale 24: 2, 4 or 8 lists per draw for the
-        // rows below 16384 or 65536 change nothing, 39.7-40.7 ms against 40.1: those 143 M visits are not waiting on
-        // their own dependent loads either)
-        uint32_t hub_rows_hi = 0;
-        int hub_ub = 1;
-        if (const char *e = getenv("GM_TC_HUB"))
-            (void)sscanf(e, "%u,%d", &hub_rows_hi, &hub_ub);
+        // (2, 4 or 8 lists per draw for the hub rows' launches changed nothing, 39.7-40.7 against 40.1 ms: round 2, removed)
         if (const char *e = getenv("GM_TC_SHAPE"))
             (void)sscanf(e, "%d,%d,%d,%d", &shape_b, &shape_g, &shape_m, &shape_u);
+        // workgroups of a launch: as many as the chip holds at once (LDS and wavefront slots), times GM_TC_WAVES (default 2:
+        // a workgroup that arrives late finds the counter run out and leaves) — never more than the items
+        const uint32_t tc_waves = getenv("GM_TC_WAVES") && atoi(getenv("GM_TC_WAVES")) > 0 ? (uint32_t)atoi(getenv("GM_TC_WAVES")) : 2u;
+        int n_cus = 256;
+        (void)hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, g->device);
+        auto wgs_of = [&](uint32_t n_items, size_t lds, int block) {
+            const uint32_t by_lds = (uint32_t)((160u * 1024u) / (lds + 1024u)), by_waves = 2048u / (uint32_t)block;
+            const uint32_t per_cu = std::max(1u, std::min(by_lds, by_waves));
+            const uint64_t wgs = (uint64_t)n_cus * per_cu * tc_waves;
+            return (uint32_t)std::min<uint64_t>(n_items, getenv("GM_TC_PERSIST") && atoi(getenv("GM_TC_PERSIST")) == 0 ? n_items : wgs);
+        };
+        uint32_t launch_no = 0; // (at most 1 + log2(K / 16384) <= 7 launches)
+        // GM_TC_STREAMS=1: every range on a stream of its own (ordered behind the set-up work on the null stream), so
+        // that the tail of one range — a few workgroups on their last, long items — runs under the next range's start
+        static hipStream_t pool[16][8] = {};
+        static std::mutex pool_mu;
+        const bool multi = getenv("GM_TC_STREAMS") && atoi(getenv("GM_TC_STREAMS")) != 0; // measured (tools/runs/r05_call04.sh): 30.1 against 29.0 ms at scale 24 — the 64 KiB rows take CUs from the hub rows: off
+        auto stream_of = [&](uint32_t k) -> hipStream_t {
+            if (!multi || g->device < 0 || g->device >= 16)
+                return (hipStream_t)0;
+            std::lock_guard<std::mutex> lock(pool_mu);
+            hipStream_t &st = pool[g->device][k % 8u];
+            if (!st && hipStreamCreate(&st) != hipSuccess) { // (blocking streams: they wait for the null stream's earlier work)
+                (void)hipGetLastError();
+                st = nullptr;
+            }
+            return st;
+        };
         for (uint32_t v_lo = 0; v_lo < K;) {
             uint32_t v_hi = v_lo < (1u << 14) ? (1u << 14) : v_lo * 2u;
             v_hi = v_hi < K ? v_hi : K;
@@ -731,64 +777,38 @@ GM_API int gm_triangle_count(const gm_csr *g, uint64_t *triangles_out)
     do {                                                                                                                \
         GM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tc_rows_kernel<B_, G_, M_, U_>),                     \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, TCR_K_MAX / 8));                         \
-        hipLaunchKernelGGL((tc_rows_kernel<B_, G_, M_, U_>), dim3(n_items), dim3(B_), lds, 0, g->offsets, g->targets,   \
-                           low_len.as<uint32_t>(), loff.as<uint32_t>(), rec.as<uint4>(), dag_tgt.as<uint32_t>(),       \
-                           dag16.as<uint16_t>(), item_first.as<uint32_t>(), item_row.as<uint32_t>(), first_host[v_lo],  \
-                           per_item, dyn, d_total);                                                                     \
+        hipLaunchKernelGGL((tc_rows_kernel<B_, G_, M_, U_>), dim3(wgs_of(n_items, lds, B_)), dim3(B_), lds, stream_of(launch_no), g->offsets, \
+                           g->targets, low_len.as<uint32_t>(), loff.as<uint32_t>(), rec.as<uint4>(),                   \
+                           dag_tgt.as<uint32_t>(), dag16.as<uint16_t>(), item_first.as<uint32_t>(),                    \
+                           item_row.as<uint32_t>(), first_host[v_lo], n_items, (uint32_t)(lds / 4),                    \
+                           reinterpret_cast<uint32_t *>(ctrl.p) + 4 + launch_no, per_item, dyn, d_total);              \
+        ++launch_no;                                                                                                    \
     } while (0)
+                // the product shape, and the ones tests/test_gpu_parity.py walks through ("every way the work can be split
+                // gives the same count"); anything else runs as the product shape
                 if (shape_b == 1024 && shape_g == 16)
                     GM_TC_ROWS(1024, 16, 4, 4);
-                else if (shape_b == 1024 && shape_g == 8 && shape_u == 4)
-                    GM_TC_ROWS(1024, 8, 4, 4);
-                else if (shape_b == 512 && shape_g == 16 && shape_u == 4)
-                    GM_TC_ROWS(512, 16, 4, 4);
+                else if (shape_b == 1024 && shape_g == 8)
+                    GM_TC_ROWS(1024, 8, 4, 1);
+                else if (shape_b == 512 && shape_g == 16)
+                    GM_TC_ROWS(512, 16, 4, 2);
+                else if (shape_b == 512 && shape_g == 8 && shape_m == 8)
+                    GM_TC_ROWS(512, 8, 8, 8);
+                else if (shape_b == 512 && shape_g == 8 && shape_u == 4)
+                    GM_TC_ROWS(512, 8, 4, 4);
                 else if (shape_b == 256 && shape_g == 16)
                     GM_TC_ROWS(256, 16, 4, 4);
-                else if (shape_b == 256 && shape_g == 8 && shape_u == 4)
+                else if (shape_b == 256 && shape_g == 8)
                     GM_TC_ROWS(256, 8, 4, 4);
                 else if (shape_b == 128 && shape_g == 8)
                     GM_TC_ROWS(128, 8, 4, 4);
-                else if (shape_b == 512 && shape_g == 8 && shape_m == 4 && shape_u == 8)
-                    GM_TC_ROWS(512, 8, 4, 8);
-                else if (shape_b == 512 && shape_g == 8 && shape_m == 8 && shape_u == 4)
-                    GM_TC_ROWS(512, 8, 8, 4);
-                else if (shape_b == 512 && shape_g == 8 && shape_m == 8 && shape_u == 8)
-                    GM_TC_ROWS(512, 8, 8, 8);
-                else if (shape_b == 512 && shape_g == 8 && shape_m == 4 && shape_u == 2)
-                    GM_TC_ROWS(512, 8, 4, 2);
-                else if (shape_b == 512 && shape_g == 8 && shape_m == 4 && shape_u == 1)
-                    GM_TC_ROWS(512, 8, 4, 1);
-                else if (shape_b == 512 && shape_g == 8 && shape_m == 4 && shape_u == 3)
-                    GM_TC_ROWS(512, 8, 4, 3);
-                else if (shape_b == 512 && shape_g == 16 && shape_u == 2)
-                    GM_TC_ROWS(512, 16, 4, 2);
-                else if (shape_b == 1024 && shape_g == 8 && shape_u == 2)
-                    GM_TC_ROWS(1024, 8, 4, 2);
-                else if (shape_b == 256 && shape_g == 8 && shape_u == 2)
-                    GM_TC_ROWS(256, 8, 4, 2);
-                else if (shape_b == 512 && shape_g == 8 && shape_m == 4 && shape_u == 4)
-                    GM_TC_ROWS(512, 8, 4, 4);
-                else if (shape_b == 256 && shape_g == 8 && shape_u == 1)
-                    GM_TC_ROWS(256, 8, 4, 1);
-                else if (shape_b == 1024 && shape_g == 8 && shape_u == 1)
-                    GM_TC_ROWS(1024, 8, 4, 1);
-                else if (shape_b == 512 && shape_g == 16 && shape_u == 1)
-                    GM_TC_ROWS(512, 16, 4, 1);
-                else if (shape_b == 512 && shape_g == 8 && shape_m == 8 && shape_u == 1)
-                    GM_TC_ROWS(512, 8, 8, 1);
-                else if (v_hi <= hub_rows_hi && hub_ub == 4)
-                    GM_TC_ROWS(512, 8, 4, 4); // hub rows: every front is short, nothing to balance, overlap the loads
-                else if (v_hi <= hub_rows_hi && hub_ub == 2)
-                    GM_TC_ROWS(512, 8, 4, 2);
-                else if (v_hi <= hub_rows_hi && hub_ub == 8)
-                    GM_TC_ROWS(512, 8, 4, 8);
                 else
                     GM_TC_ROWS(512, 8, 4, 1);
 #undef GM_TC_ROWS
             }
             v_lo = v_hi;
         }
-        hipLaunchKernelGGL(tc_count_kernel<true>, dim3(cgrid), dim3(TC_BLOCK), 0, 0, loff.as<uint32_t>(),
+        hipLaunchKernelGGL(tc_count_kernel<true>, dim3(cgrid), dim3(TC_BLOCK), 0, stream_of(7), loff.as<uint32_t>(),
                            dag_src.as<uint32_t>(), dag_tgt.as<uint32_t>(), (uint64_t)dag_m, K, d_total);
         GM_HIP(hipGetLastError());
         GM_HIP(hipDeviceSynchronize()); // the item tables are released on scope exit

@@ -35,7 +35,7 @@ class PageRankEngine:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h and not sys.is_finalizing():
+        if h and sys is not None and not sys.is_finalizing():
             lib().gm_pr_destroy(h)
 
     @property

@@ -115,7 +115,7 @@ class DeviceCsr:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h and not sys.is_finalizing():  # at interpreter exit the HIP runtime may already be gone
+        if h and sys is not None and not sys.is_finalizing():  # at interpreter exit the HIP runtime may already be gone
             try:
                 lib().gm_csr_free(h)
             except Exception:

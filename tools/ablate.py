@@ -5,6 +5,10 @@ by design).  Usage: tools/ablate.py [scale] [codes...]; the product (0) is re-ti
 because the clock drifts over a run."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+# the variants live in the MEASUREMENT library only (make -C graph_amd/csrc measure: the sources with -DGM_MEASURE)
+import subprocess
+subprocess.check_call(["make", "-C", os.path.join(ROOT, "graph_amd", "csrc"), "measure", "-j8"], stdout=subprocess.DEVNULL)
+os.environ["GRAPH_MI355X_LIB"] = os.path.join(ROOT, "graph_amd", "libgraph_mi355x_measure.so")
 import torch
 from graph_amd import synth
 from graph_amd.engine import PageRankEngine
