@@ -172,6 +172,12 @@ struct PbPlan {
     uint32_t hub_long = 8192;  // rows with at least this many in-edges are a group of their own (pb_hublong_kernel): see pb_build
     uint32_t G_long = 0;
     uint64_t long_terms = 0;   // in-edges of the long rows
+    // hub rows whose lists are not ascending (CsrLayout::Unsorted): summed in CSR order through `hub_gidx` (pb_hublong_kernel<true>)
+    uint32_t hub_csr = 0;
+    uint32_t err_slots = 0;    // error sums behind the B bins': one per hub group, or (hub_csr) one per hub row
+    DevBuf hub_gidx;           // u32[..] per hub row (4-aligned stretches): value-stream position of its k-th in-neighbour's out_score
+    DevBuf csr_items;          // PbHubItem[n_hub]: {first, end of the row's stretch of hub_gidx, 1, index in hub_rows, error slot}
+    std::vector<uint32_t> hub_degs_host;
     DevBuf long_items;         // PbLongItem[n_long_items]: the long rows cut into items of a few passes, row by row (longest row first)
     uint32_t n_long_items = 0;
     uint32_t long_sbs_len = 0; // entries of an engine's array of pass-boundary sums (every long row: its passes + 1)
@@ -267,6 +273,51 @@ __device__ __forceinline__ uint64_t pb_make_key(uint64_t hi_cold, uint32_t src, 
         }
     }
     return hi_cold | src;
+}
+
+// is any hub row's list out of ascending order?  one wavefront per row
+__global__ void pb_hub_sorted_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt,
+                                     const uint32_t *__restrict__ hub_rows, uint32_t n_hub, uint32_t *__restrict__ unsorted)
+{
+    const uint32_t lane = threadIdx.x & (kWave - 1), wave = (blockIdx.x * blockDim.x + threadIdx.x) / kWave,
+                   nwaves = gridDim.x * blockDim.x / kWave;
+    bool bad = false;
+    for (uint32_t h = wave; h < n_hub; h += nwaves) {
+        const uint32_t r = hub_rows[h], s = off[r], e = off[r + 1];
+        for (uint32_t i = s + lane; i + 1u < e; i += kWave)
+            bad |= tgt[i] > tgt[i + 1u];
+    }
+    if (__ballot(bad) && lane == 0)
+        atomicOr(unsorted, 1u);
+}
+
+// gidx of row h's k-th in-neighbour (CSR order): the first entry of the row's group with that source.  `hubsrc` holds the source
+// of every entry of the hub groups' part of the stream, non-decreasing inside a group, padding entries as the source before them
+// — so the first entry with a given source is a real one, and it holds that source's out_score after the bin kernel.
+__global__ __launch_bounds__(256) void pb_hubcsr_index_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt,
+                                                              const uint32_t *__restrict__ hub_rows,
+                                                              const uint32_t *__restrict__ g0, const uint32_t *__restrict__ rq0,
+                                                              const uint32_t *__restrict__ rq1,
+                                                              const uint32_t *__restrict__ hubsrc, uint32_t hub_q0, uint32_t n_hub,
+                                                              uint32_t *__restrict__ gidx, uint32_t *__restrict__ missing)
+{
+    for (uint32_t h = blockIdx.x; h < n_hub; h += gridDim.x) {
+        const uint32_t r = hub_rows[h], s = off[r], deg = off[r + 1] - s, q0 = rq0[h], q1 = rq1[h], base = g0[h];
+        const uint32_t *cs = hubsrc + (q0 - hub_q0);
+        const uint32_t padded = (deg + 3u) & ~3u;
+        for (uint32_t k = threadIdx.x; k < padded; k += blockDim.x) {
+            uint32_t at = q0;
+            if (k < deg) {
+                const uint32_t src = tgt[s + k];
+                const uint32_t i = (uint32_t)lower_bound_fn(0, q1 - q0, src, [&](uint64_t j) { return (uint64_t)cs[j]; });
+                if (i >= q1 - q0 || cs[i] != src)
+                    atomicAdd(missing, 1u);
+                else
+                    at = q0 + i;
+            }
+            gidx[base + k] = at;
+        }
+    }
 }
 
 // hub rows: >= hub_deg in-edges
@@ -1745,7 +1796,15 @@ struct PbLongItem {
     uint32_t flags;  // 1: the row's last item (finishes the row); 2: the row has other items (pairs are formed ahead)
 };
 
+// GATHER (a plan whose hub rows' lists are NOT ascending — CsrLayout::Unsorted, the reference's default, csr.rs:34-45 — so that the
+// order the value stream delivers a row's terms in, ascending source, is not the order of page_rank.rs:143-146): EVERY hub row
+// is an item list of this kernel, its range [q0, q1) counts entries of `gidx`, which names for the row's k-th in-neighbour IN
+// CSR ORDER a position of the value stream that holds that source's out_score (any entry of the row's group with that source:
+// a 1 MiB stretch, L2-resident while the group's rows are summed).  4 bytes and an L2 gather more per hub term than the
+// source-ordered path; the sums are the reference's for whatever order the lists are in.
+template <bool GATHER>
 __global__ __launch_bounds__(PB_LONG_WG) __attribute__((amdgpu_waves_per_eu(5, 8))) void pb_hublong_kernel(const float *__restrict__ vals, const uint16_t *__restrict__ p2_dst,
+                                                                const uint32_t *__restrict__ gidx,
                                                                 const PbHubItem *__restrict__ items,
                                                                 const PbLongItem *__restrict__ litems, uint32_t n_items,
                                                                 unsigned long long *__restrict__ ticket,
@@ -1798,7 +1857,14 @@ __global__ __launch_bounds__(PB_LONG_WG) __attribute__((amdgpu_waves_per_eu(5, 8
             const uint32_t q = sb + (k * PB_LONG_WG + tid) * 4u;
             raw.d[k].x = raw.d[k].y = 0xFFFFFFFFu; // behind the row: padding
             raw.x[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            if (q < item.q1) {
+            if (GATHER) {
+                if (q < item.q1) { // (a row's stretch of gidx starts on a multiple of 4 and is padded with valid positions)
+                    const uint4 ix = *reinterpret_cast<const uint4 *>(gidx + q);
+                    raw.x[k] = f32x4{vals[ix.x], vals[ix.y], vals[ix.z], vals[ix.w]};
+                    raw.d[k].x = (q + 1u < item.q1 ? 0u : 0xFFFF0000u);
+                    raw.d[k].y = (q + 2u < item.q1 ? 0u : 0x0000FFFFu) | (q + 3u < item.q1 ? 0u : 0xFFFF0000u);
+                }
+            } else if (q < item.q1) {
                 raw.x[k] = *reinterpret_cast<const f32x4 *>(vals + q);
                 raw.d[k] = *reinterpret_cast<const u32x2 *>(p2_dst + q);
             }
@@ -2164,6 +2230,32 @@ __global__ void pb_clear_bit_kernel(uint64_t *__restrict__ keys, uint32_t count,
 // rows that attracts a large share of the edges, e.g. degree-sorted ids) is cut into slices so that no
 // workgroup streams more than ~2x the average; longest first.  Built on the host from the B+1 bin
 // boundaries (a few KiB).
+// the rows pb_hublong_kernel sums (rows[0 .. count)) as items of GM_PB_LONG_PASSES passes (default 8: 65536 terms; 0 / >= 16: 16),
+// row by row
+int pb_make_long_items(PbPlan *pl, const std::vector<PbHubItem> &rows, uint32_t count)
+{
+    constexpr uint32_t SUPER = PB_LONG_WG * PB_LONG_PER;
+    uint32_t per = (uint32_t)pb_env("GM_PB_LONG_PASSES", 8);
+    per = per >= 1 && per <= PB_LONG_PMAX ? per : PB_LONG_PMAX;
+    std::vector<PbLongItem> li;
+    uint32_t sb = 0;
+    for (uint32_t r = 0; r < count; ++r) {
+        const uint32_t len = rows[r].q1 - rows[r].q0, passes = len ? (len + SUPER - 1u) / SUPER : 1u;
+        for (uint32_t p0 = 0; p0 < passes; p0 += per) {
+            const uint32_t np = passes - p0 < per ? passes - p0 : per;
+            li.push_back(PbLongItem{r, p0, np, p0 ? (uint32_t)li.size() - 1u : 0xFFFFFFFFu, sb,
+                                    (p0 + np == passes ? 1u : 0u) | (passes > per ? 2u : 0u)});
+        }
+        sb += passes + 1u;
+    }
+    pl->n_long_items = (uint32_t)li.size();
+    pl->long_sbs_len = sb;
+    GM_TRY(pl->long_items.alloc((li.size() ? li.size() : 1) * sizeof(PbLongItem)));
+    if (!li.empty())
+        GM_HIP(hipMemcpy(pl->long_items.p, li.data(), li.size() * sizeof(PbLongItem), hipMemcpyHostToDevice));
+    return GM_OK;
+}
+
 int pb_make_items(PbPlan *pl)
 {
     const uint32_t Bv = pl->B + pl->G; // virtual bins of the streams
@@ -2237,29 +2329,8 @@ int pb_make_items(PbPlan *pl)
     if (!hubs.empty())
         GM_HIP(hipMemcpy(pl->hub_items.p, hubs.data(), hubs.size() * sizeof(PbHubItem), hipMemcpyHostToDevice));
     pl->hub_items_host = hubs;
-    // the long rows as items of GM_PB_LONG_PASSES passes (default 8: 65536 terms; 0 / >= 16: 16), row by row
-    {
-        constexpr uint32_t SUPER = PB_LONG_WG * PB_LONG_PER;
-        uint32_t per = (uint32_t)pb_env("GM_PB_LONG_PASSES", 8);
-        per = per >= 1 && per <= PB_LONG_PMAX ? per : PB_LONG_PMAX;
-        std::vector<PbLongItem> li;
-        uint32_t sb = 0;
-        for (uint32_t r = 0; r < pl->G_long; ++r) {
-            const uint32_t len = hubs[r].q1 - hubs[r].q0, passes = len ? (len + SUPER - 1u) / SUPER : 1u;
-            for (uint32_t p0 = 0; p0 < passes; p0 += per) {
-                const uint32_t np = passes - p0 < per ? passes - p0 : per;
-                li.push_back(PbLongItem{r, p0, np, p0 ? (uint32_t)li.size() - 1u : 0xFFFFFFFFu, sb,
-                                        (p0 + np == passes ? 1u : 0u) | (passes > per ? 2u : 0u)});
-            }
-            sb += passes + 1u;
-        }
-        pl->n_long_items = (uint32_t)li.size();
-        pl->long_sbs_len = sb;
-        GM_TRY(pl->long_items.alloc((li.size() ? li.size() : 1) * sizeof(PbLongItem)));
-        if (!li.empty())
-            GM_HIP(hipMemcpy(pl->long_items.p, li.data(), li.size() * sizeof(PbLongItem), hipMemcpyHostToDevice));
-    }
-    return GM_OK;
+    pl->err_slots = pl->G;
+    return pb_make_long_items(pl, hubs, pl->G_long);
 }
 
 int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
@@ -2337,6 +2408,21 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
             GM_HIP(hipGetLastError());
             std::vector<uint32_t> degs(pl->n_hub);
             GM_HIP(hipMemcpy(degs.data(), hub_degs.p, (size_t)pl->n_hub * 4, hipMemcpyDeviceToHost));
+            pl->hub_degs_host = degs;
+            // Are the hub rows' lists ascending?  Then the order the value stream delivers their terms in IS the CSR order
+            // (Sorted / Deduplicated layouts).  If not (CsrLayout::Unsorted), the rows are summed through a per-term index in
+            // CSR order (pb_hublong_kernel<true>; GM_PB_HUB_CSR=0: in source order all the same, round 4's behaviour).
+            {
+                DevBuf unsorted;
+                GM_TRY(unsorted.alloc(4));
+                GM_HIP(hipMemset(unsorted.p, 0, 4));
+                hipLaunchKernelGGL(pb_hub_sorted_kernel, dim3(pb_grid((uint64_t)pl->n_hub * kWave)), dim3(256), 0, 0, csr->offsets,
+                                   csr->targets, pl->hub_rows.as<uint32_t>(), pl->n_hub, unsorted.as<uint32_t>());
+                GM_HIP(hipGetLastError());
+                uint32_t flag_host = 0;
+                GM_HIP(hipMemcpy(&flag_host, unsorted.p, 4, hipMemcpyDeviceToHost));
+                pl->hub_csr = flag_host && pb_env("GM_PB_HUB_CSR", 1) ? 1u : 0u;
+            }
             uint64_t target = (uint64_t)m_all / pl->B;
             if (target < 65536)
                 target = 65536;
@@ -2535,7 +2621,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     const int hot_bit = bin_bits + sb; // the flag bit of a hot edge: the highest sorted bit
     // hub groups walked by pb_hubseq_kernel take their terms from hot sources off the value stream (GM_PB_HUB_HOT=0: not): the
     // flag of such an edge sits above the slot
-    const bool hub_hot = H && pl->G > 0 && pb_env("GM_PB_HUB_HOT", 1) != 0 && pl->Htot < (1u << 18);
+    const bool hub_hot = H && pl->G > 0 && pb_env("GM_PB_HUB_HOT", 1) != 0 && pl->Htot < (1u << 18) && !pl->hub_csr; // (CSR order: every term in the stream)
     const uint64_t hh_bit = hub_hot ? 1ull : 0ull; // (a switch for pb_keys_kernel: the key itself carries no extra bit)
     DevBuf group_long;
     {
@@ -2785,7 +2871,47 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     GM_HIP(hipGetLastError());
     timer.done("pb plan: segment layout + stream fill");
     GM_TRY(pb_make_items(pl));
-    if (pl->G > pl->G_long) { // the hub groups walked by pb_hubseq_kernel: blocks, places, hot records
+    if (pl->G && pl->hub_csr) {
+        // every hub row an item list of pb_hublong_kernel<true>: its stretch of hub_gidx, its group's part of the stream
+        std::vector<uint32_t> g0(pl->n_hub), rq0(pl->n_hub), rq1(pl->n_hub);
+        std::vector<PbHubItem> rows(pl->n_hub);
+        uint64_t Mg = 0;
+        for (const PbHubItem &grp : pl->hub_items_host)
+            for (uint32_t j = 0; j < grp.nh; ++j) {
+                const uint32_t h = grp.row0 + j;
+                rq0[h] = grp.q0, rq1[h] = grp.q1;
+            }
+        for (uint32_t h = 0; h < pl->n_hub; ++h) {
+            g0[h] = (uint32_t)Mg;
+            rows[h] = PbHubItem{(uint32_t)Mg, (uint32_t)Mg + pl->hub_degs_host[h], 1u, h, h};
+            Mg += (pl->hub_degs_host[h] + 3u) & ~3u;
+        }
+        GM_CHECK(Mg < (1ull << 32), GM_ERR_RANGE, "pb_build: %llu hub terms in CSR order exceed the 32-bit index", (unsigned long long)Mg);
+        std::stable_sort(rows.begin(), rows.end(), [](const PbHubItem &a, const PbHubItem &c) { return a.q1 - a.q0 > c.q1 - c.q0; });
+        GM_TRY(pl->hub_gidx.alloc_big((size_t)(Mg ? Mg : 4) * 4, 0x61D7, 4, 0, ~0ull, 0, 4));
+        GM_TRY(pl->csr_items.alloc(rows.size() * sizeof(PbHubItem)));
+        GM_HIP(hipMemcpy(pl->csr_items.p, rows.data(), rows.size() * sizeof(PbHubItem), hipMemcpyHostToDevice));
+        DevBuf d_g0, d_q0, d_q1, d_missing;
+        GM_TRY(d_g0.alloc((size_t)pl->n_hub * 4));
+        GM_TRY(d_q0.alloc((size_t)pl->n_hub * 4));
+        GM_TRY(d_q1.alloc((size_t)pl->n_hub * 4));
+        GM_TRY(d_missing.alloc(4));
+        GM_HIP(hipMemcpy(d_g0.p, g0.data(), (size_t)pl->n_hub * 4, hipMemcpyHostToDevice));
+        GM_HIP(hipMemcpy(d_q0.p, rq0.data(), (size_t)pl->n_hub * 4, hipMemcpyHostToDevice));
+        GM_HIP(hipMemcpy(d_q1.p, rq1.data(), (size_t)pl->n_hub * 4, hipMemcpyHostToDevice));
+        GM_HIP(hipMemset(d_missing.p, 0, 4));
+        hipLaunchKernelGGL(pb_hubcsr_index_kernel, dim3(pl->n_hub < 65536u ? pl->n_hub : 65536u), dim3(256), 0, 0, csr->offsets,
+                           csr->targets, pl->hub_rows.as<uint32_t>(), d_g0.as<uint32_t>(), d_q0.as<uint32_t>(), d_q1.as<uint32_t>(),
+                           hubsrc.as<uint32_t>(), hub_q0, pl->n_hub, pl->hub_gidx.as<uint32_t>(), d_missing.as<uint32_t>());
+        GM_HIP(hipGetLastError());
+        uint32_t missing = 0;
+        GM_HIP(hipMemcpy(&missing, d_missing.p, 4, hipMemcpyDeviceToHost));
+        GM_CHECK(missing == 0, GM_ERR_INVALID, "pb_build: %u hub terms have no entry in their group's part of the stream", missing);
+        pl->err_slots = pl->n_hub;
+        GM_TRY(pb_make_long_items(pl, rows, pl->n_hub));
+        timer.done("pb plan: hub rows in CSR order (%u rows, %llu index entries)", pl->n_hub, (unsigned long long)Mg);
+    }
+    if (pl->G > pl->G_long && !pl->hub_csr) { // the hub groups walked by pb_hubseq_kernel: blocks, places, hot records
         const uint32_t GS = pl->G - pl->G_long;
         // where each group's hot-hub keys lie (sorted by (virtual bin, source))
         std::vector<uint32_t> hk_start((size_t)Bv + 1, 0u);
@@ -3285,7 +3411,7 @@ int pb_scratch_create(const PbPlan *pl, PbScratch **out, DevBuf *early)
     }
     if ((rc = sc->vals_raw.p ? GM_OK : sc->vals_raw.alloc((size_t)(pl->Mv ? pl->Mv : 4) * 4 + slack)) ||
         (rc = sc->partials.alloc((size_t)(pl->slots ? pl->slots : 1) * pl->Racc * 8)) ||
-        (rc = sc->tickets.alloc((size_t)pl->B * 4)) || (rc = sc->bin_err.alloc(((size_t)pl->B + pl->G) * 8)) ||
+        (rc = sc->tickets.alloc((size_t)pl->B * 4)) || (rc = sc->bin_err.alloc(((size_t)pl->B + pl->err_slots) * 8)) ||
         (rc = sc->hot_x.alloc(((size_t)pl->H * pl->T + 4) * 4)) ||
         (rc = sc->long_state.alloc(8 + (size_t)pl->n_long_items * 8 + (size_t)pl->long_sbs_len * 4 + 8))) {
         delete sc;
@@ -3339,12 +3465,12 @@ void pb_plan_info(const PbPlan *pl, const PbScratch *sc, uint64_t *info, uint32_
 {
     const DevBuf *bufs[] = {&pl->cidx, &pl->hub_rows, &pl->p1_src, &pl->chunk_seg, &pl->delta, &pl->tile_p, &pl->wg_tile,
                             &pl->wg_p0,  &pl->p2_dst, &pl->bin_v,  &pl->items,     &pl->hot_ids, &pl->hot_ent, &pl->hbin_v, &pl->hot_base,
-                            &pl->seq_rows, &pl->seq_blk, &pl->hh_ent};
+                            &pl->seq_rows, &pl->seq_blk, &pl->hh_ent, &pl->hub_gidx, &pl->csr_items, &pl->long_items};
     uint64_t plan_bytes = 0;
     for (const DevBuf *b : bufs)
         plan_bytes += b->bytes;
     const uint64_t scratch_bytes = sc ? sc->vals_raw.bytes + sc->partials.bytes + sc->tickets.bytes + sc->bin_err.bytes +
-                                            sc->hot_x.bytes : 0;
+                                            sc->hot_x.bytes + sc->long_state.bytes : 0;
     const uint64_t v[] = {plan_bytes, (uint64_t)(pl->build_ms * 1000.0), pl->n_hub, pl->hub_edges, pl->hub_deg, pl->Htot,
                           pl->Mv, pl->Mh, scratch_bytes, pl->B, pl->NT, pl->NS, pl->G, pl->T, pl->G_long, pl->long_terms, pl->seq_blocks,
                           sc ? sc->draw_best_us : 0u, sc ? sc->draw_worst_us : 0u, sc ? sc->draws_timed : 0u,
@@ -3491,14 +3617,20 @@ static bool pb_hub_dispatch(const PbPlan *pl, PbScratch *sc, float *x_out, float
     unsigned long long *l_ticket = sc->long_state.as<unsigned long long>(), *l_handoff = l_ticket + 1;
     float *l_sbs = reinterpret_cast<float *>(l_handoff + pl->n_long_items);
     const PbLongItem *l_items = pl->long_items.as<PbLongItem>();
-    const uint32_t l_epoch = pl->G_long && !(skip & 2) ? ++sc->long_epoch : 0u;
+    const uint32_t l_epoch = (pl->hub_csr ? pl->n_hub : pl->G_long) && !(skip & 2) ? ++sc->long_epoch : 0u;
+    if (pl->hub_csr) { // lists that are not ascending: every hub row in CSR order through its index
+        hipLaunchKernelGGL(pb_hublong_kernel<true>, dim3(pl->n_long_items), dim3(PB_LONG_WG), 0, st, sc->vals, pl->p2_dst.as<uint16_t>(),
+                           pl->hub_gidx.as<uint32_t>(), pl->csr_items.as<PbHubItem>(), l_items, pl->n_long_items, l_ticket, l_handoff,
+                           l_sbs, l_epoch, pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr, base, damping);
+        return true;
+    }
     const uint32_t v_safe = (uint32_t)(pl->Mv >= 4 ? (pl->Mv - 4) & ~3ull : 0), h_safe = (uint32_t)(pl->Mhh ? pl->Mhh - 1u : 0u);
 #ifdef GM_MEASURE // launches without the barrier bit on one stream (gfx950 serialises them: DESIGN.md)
     if (inline_any) {
         bool launched = false;
         if (pl->G_long && !(skip & 2)) {
-            (void)pb_launch_flags(pb_hublong_kernel, dim3(pl->n_long_items), dim3(PB_LONG_WG), 0, st, launched, sc->vals,
-                                  pl->p2_dst.as<uint16_t>(), items, l_items, pl->n_long_items, l_ticket, l_handoff, l_sbs, l_epoch,
+            (void)pb_launch_flags(pb_hublong_kernel<false>, dim3(pl->n_long_items), dim3(PB_LONG_WG), 0, st, launched, sc->vals,
+                                  pl->p2_dst.as<uint16_t>(), (const uint32_t *)nullptr, items, l_items, pl->n_long_items, l_ticket, l_handoff, l_sbs, l_epoch,
                                   pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr, base, damping);
             launched = true;
         }
@@ -3521,8 +3653,8 @@ static bool pb_hub_dispatch(const PbPlan *pl, PbScratch *sc, float *x_out, float
             (void)hipEventRecord(sc->ev_chain_fork, st);
             (void)hipStreamWaitEvent(ls, sc->ev_chain_fork, 0);
         }
-        hipLaunchKernelGGL(pb_hublong_kernel, dim3(pl->n_long_items), dim3(PB_LONG_WG), 0, ls, sc->vals, pl->p2_dst.as<uint16_t>(), items,
-                           l_items, pl->n_long_items, l_ticket, l_handoff, l_sbs, l_epoch, pl->hub_rows.as<uint32_t>(), outdeg, scores,
+        hipLaunchKernelGGL(pb_hublong_kernel<false>, dim3(pl->n_long_items), dim3(PB_LONG_WG), 0, ls, sc->vals, pl->p2_dst.as<uint16_t>(),
+                           (const uint32_t *)nullptr, items, l_items, pl->n_long_items, l_ticket, l_handoff, l_sbs, l_epoch, pl->hub_rows.as<uint32_t>(), outdeg, scores,
                            x_out, gerr, base, damping);
         if (own)
             (void)hipEventRecord(sc->ev_chain_join, ls);
@@ -3705,24 +3837,41 @@ int pb_sweep_accum_part(const PbPlan *pl, PbScratch *sc, const float *x_in, floa
              sc->part_off.empty() ? (size_t)0 : sc->part_off.size() - 1);
     if (stage_hot)
         pb_hot_dispatch(pl, sc, x_in, st);
+    // The hub rows (any of them may lie in any part's rows) are summed by launches that go out with part 0 — BESIDE its
+    // accumulate kernel, on the engine's side streams, as in a whole sweep (round 5: until then they ran in line in front of
+    // it, and the rank's first accumulate piece waited 0.22 ms for the lane walks at scale 26 / 8 ranks) — and EVERY part's
+    // stream waits for them behind its own accumulate kernel: whatever the caller enqueues next on that stream (the
+    // exchange of the part's rows) sees its hub rows finished.
+    const bool fork = pl->G && sc->side && pl->hub_edges >= (1u << 20) && pb_env("GM_PB_HUB_FORK", 1);
     bool any = false;
-    if (part == 0) { // every hub row is finished with the first part: before any region of x_out is exchanged
+    if (part == 0) {
 #ifdef GM_MEASURE
-        any = pb_hub_dispatch(pl, sc, x_out, scores, outdeg, base, damping, st, pl->G && pb_env("GM_PB_ANYORDER", 0)) &&
-              pl->G && pb_env("GM_PB_ANYORDER", 0);
-#else
-        pb_hub_dispatch(pl, sc, x_out, scores, outdeg, base, damping, st);
+        if (pl->G && pb_env("GM_PB_ANYORDER", 0)) {
+            any = pb_hub_dispatch(pl, sc, x_out, scores, outdeg, base, damping, st, true);
+        } else
 #endif
+        if (fork) {
+            GM_HIP(hipEventRecord(sc->ev_fork, st));
+            GM_HIP(hipStreamWaitEvent(sc->side, sc->ev_fork, 0));
+            pb_hub_dispatch(pl, sc, x_out, scores, outdeg, base, damping, sc->side);
+            GM_HIP(hipEventRecord(sc->ev_join, sc->side));
+        } else {
+            pb_hub_dispatch(pl, sc, x_out, scores, outdeg, base, damping, st); // (few hub edges: in line, no events)
+            if (pl->G && sc->ev_join)
+                GM_HIP(hipEventRecord(sc->ev_join, st));
+        }
     }
     const uint32_t i0 = sc->part_off[part], i1 = sc->part_off[part + 1];
     pb_accum_dispatch(pl, sc, sc->part_items.as<PbItem>() + i0, i1 - i0, x_out, scores, outdeg, base, damping, st, any);
+    if (pl->G && sc->ev_join && !any && (fork || part != 0)) // (recorded by this sweep's part 0: the parts are enqueued in order)
+        GM_HIP(hipStreamWaitEvent(st, sc->ev_join, 0));
     GM_HIP(hipGetLastError());
     return GM_OK;
 }
 
 int pb_sweep_error(const PbPlan *pl, PbScratch *sc, double *err_out, hipStream_t st)
 {
-    hipLaunchKernelGGL(pb_err_kernel, dim3(1), dim3(1024), 0, st, sc->bin_err.as<double>(), pl->B + pl->G, err_out);
+    hipLaunchKernelGGL(pb_err_kernel, dim3(1), dim3(1024), 0, st, sc->bin_err.as<double>(), pl->B + pl->err_slots, err_out);
     GM_HIP(hipGetLastError());
     return GM_OK;
 }
