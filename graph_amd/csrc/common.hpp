@@ -590,6 +590,8 @@ struct gm_csr {
     mutable std::unique_ptr<gm::SsspScratch> sssp_scratch; // parked between calls (under cache_mu)
     mutable std::shared_ptr<const gm::SsspOrder> sssp_order; // likewise; built by the SECOND gm_sssp_delta_stepping call
     mutable std::atomic<uint64_t> sssp_calls{0};             // gm_sssp_delta_stepping calls seen by this handle
+    mutable std::mutex sssp_build_mu;                        // one builder of sssp_order per handle (a second caller waits and finds it)
+    mutable std::atomic<int> sssp_order_failed{0};           // 1: the build found no room; not retried until gm_csr_trim
     mutable std::unique_ptr<gm::WccScratch> wcc_scratch;   // likewise
     mutable std::shared_ptr<gm::PrCallState> pr_call;      // likewise (stream, vectors, engine + its scratch)
     mutable std::shared_ptr<const gm::TcDag> tc_dag;       // the DAG of lower prefixes + list records of gm_triangle_count

@@ -238,6 +238,7 @@ GM_API int gm_csr_trim(const gm_csr *csr)
         plans.swap(csr->pb_plans);
         sssp = std::move(csr->sssp_scratch);
         sssp_order = std::move(csr->sssp_order);
+        csr->sssp_order_failed.store(0, std::memory_order_relaxed); // room may have been made: the next loop of calls may build them
         wcc = std::move(csr->wcc_scratch);
         pr = std::move(csr->pr_call);
         dag = std::move(csr->tc_dag);

@@ -273,7 +273,7 @@ struct gm::MultiState {
     std::vector<int> devs;
     float damping = 0.f;
     int engine = 0;
-    uint64_t env_hash = 0; // the GM_PB_* / GM_MULTI_* / GM_ARENA* knobs the engines were built under
+    uint64_t env_hash = 0; // the plan- and layout-shaping GM_PB_* / GM_MULTI_* knobs the engines were built under (multi_env_hash: by name)
     uint32_t K = 1;
     uint32_t P = 0, n = 0;
     bool distinct = true, pieces = false;
@@ -304,17 +304,39 @@ struct RankInput {
 };
 
 // the plan / engine knobs of the environment as one number: a parked state built under other knobs is not reused
+__global__ void mg_max_target_kernel(const uint32_t *__restrict__ tgt, uint64_t m, uint32_t *__restrict__ out)
+{
+    uint32_t mx = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride)
+        mx = tgt[i] > mx ? tgt[i] : mx;
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+        const uint32_t w = __shfl_xor(mx, o, kWave);
+        mx = w > mx ? w : mx;
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0 && mx)
+        atomicMax(out, mx);
+}
+
 uint64_t multi_env_hash()
 {
-    uint64_t h = 0;
-    for (char **e = ::environ; e && *e; ++e) {
-        const char *v = *e;
-        if (strncmp(v, "GM_PB_", 6) != 0 && strncmp(v, "GM_MULTI_", 9) != 0 && strncmp(v, "GM_PR_", 6) != 0)
-            continue;
-        uint64_t x = 1469598103934665603ull;
-        for (const char *c = v; *c; ++c)
-            x = (x ^ (uint64_t)(unsigned char)*c) * 1099511628211ull;
-        h += x; // order of the entries does not matter
+    // the knobs that shape a plan or the run's layout, by name (getenv, like everywhere else; the *_NOCACHE switches and the
+    // per-launch measurement knobs are not among them: toggling those must not look like another configuration)
+    static const char *const knobs[] = {"GM_PB_HOT",       "GM_PB_RB",        "GM_PB_SLOG",      "GM_PB_CHUNK",     "GM_PB_SPLIT",
+                                        "GM_PB_WGS",       "GM_PB_COMPACT",   "GM_PB_ORDER",     "GM_PB_XCD",       "GM_PB_HUB_DEG",
+                                        "GM_PB_HUB_GROUP", "GM_PB_HUB_LONG",  "GM_PB_HUB_HOT",   "GM_PB_HUB_CSR",   "GM_PB_HUB_ROOM",
+                                        "GM_PB_HUB_FORK",  "GM_PB_LONG_PASSES", "GM_PB_TIERS",   "GM_PB_HOT16",     "GM_PB_SEGPAD",
+                                        "GM_PB_SPREAD",    "GM_PB_SPREAD_PLAN", "GM_PB_FILTER_BITS", "GM_PB_WG_GROUP", "GM_PB_BIN_GAP",
+                                        "GM_MULTI_ENGINE", "GM_MULTI_PARTS"};
+    uint64_t h = 1469598103934665603ull;
+    for (const char *name : knobs) {
+        const char *v = getenv(name);
+        for (const char *c = name; *c; ++c)
+            h = (h ^ (uint64_t)(unsigned char)*c) * 1099511628211ull;
+        h = (h ^ 0x3Dull) * 1099511628211ull;
+        for (const char *c = v ? v : ""; *c; ++c)
+            h = (h ^ (uint64_t)(unsigned char)*c) * 1099511628211ull;
     }
     return h;
 }
@@ -811,6 +833,28 @@ GM_API int gm_page_rank_multi_slices(const gm_csr *const *in_slices, const uint6
         ri.device = devs[p];
         ri.edges = sl->m;
         DeviceGuard g(ri.device);
+        // a piece is the caller's: its offsets must run from 0 to its edge count and its targets must be global ids below n
+        // (they index the n-sized node map on this device) — GM_ERR_RANGE instead of a memory fault
+        {
+            uint32_t ends[2] = {0u, 0u};
+            GM_HIP(hipMemcpy(&ends[0], sl->offsets, 4, hipMemcpyDeviceToHost));
+            GM_HIP(hipMemcpy(&ends[1], sl->offsets + sl->n, 4, hipMemcpyDeviceToHost));
+            GM_CHECK(ends[0] == 0u && ends[1] == sl->m, GM_ERR_INVALID,
+                     "gm_page_rank_multi_slices: piece %u: offsets run from %u to %u, the piece has %llu edges", p, ends[0], ends[1],
+                     (unsigned long long)sl->m);
+            if (sl->m) {
+                DevBuf d_max;
+                GM_TRY(d_max.alloc(4));
+                GM_HIP(hipMemset(d_max.p, 0, 4));
+                unsigned mg = gm::div_up(sl->m, 256);
+                hipLaunchKernelGGL(mg_max_target_kernel, dim3(mg > 4096 ? 4096 : mg), dim3(256), 0, 0, sl->targets, sl->m, d_max.as<uint32_t>());
+                GM_HIP(hipGetLastError());
+                uint32_t mx = 0;
+                GM_HIP(hipMemcpy(&mx, d_max.p, 4, hipMemcpyDeviceToHost));
+                GM_CHECK(mx < n, GM_ERR_RANGE, "gm_page_rank_multi_slices: piece %u names node %u of %llu (targets are GLOBAL ids)", p, mx,
+                         (unsigned long long)n);
+            }
+        }
         GM_TRY(ri.off.alloc(((size_t)sl->n + 1) * 4));
         GM_TRY(ri.tgt.alloc((size_t)sl->m * 4));
         GM_TRY(ri.outdeg_full.alloc((size_t)n * 4));

@@ -3112,6 +3112,7 @@ int pb_scratch_create(const PbPlan *pl, PbScratch **out, DevBuf *early)
     int rc;
     if (early && early->p && early->bytes >= (size_t)(pl->Mv ? pl->Mv : 4) * 4)
         sc->vals_raw = std::move(*early);
+#ifdef GM_MEASURE // the measurement library only: other ways of giving the value stream its memory (round 3's placement study)
     // GM_PB_VALS_SLACK=<MiB> (measurements): room behind the value stream so that GM_PB_VALS_OFFSET=<KiB>, read at
     // every sweep, can move it inside one allocation — does the sweep time depend on the offset or on the pages?
     const size_t slack = (size_t)pb_env("GM_PB_VALS_SLACK", 0) << 20;
@@ -3222,6 +3223,9 @@ int pb_scratch_create(const PbPlan *pl, PbScratch **out, DevBuf *early)
             return rc;
         }
     }
+#else
+    const size_t slack = 0;
+#endif
     // The default: the stream mapped from 64 MiB pieces of the arena (arena.hip — right after a plan build its free list
     // holds the build's ~20-30 GB of temporaries), several candidate sets timed with the bin kernel itself, the fastest
     // kept.  Which physical memory the stream lies in — relative to the index stream read beside it — decides up to a third
@@ -3680,11 +3684,15 @@ static void pb_hot_dispatch(const PbPlan *pl, PbScratch *sc, const float *x_in, 
 // stream starts, re-read at every launch
 static void pb_apply_vals_offset(const PbPlan *pl, PbScratch *sc)
 {
+#ifndef GM_MEASURE
+    (void)pl, (void)sc;
+#else
     if (const char *off = getenv("GM_PB_VALS_OFFSET")) {
         const size_t bytes = (size_t)atoll(off) << 10;
         if (bytes + (size_t)pl->Mv * 4 <= sc->vals_raw.bytes)
             sc->vals = reinterpret_cast<float *>(sc->vals_raw.as<char>() + bytes);
     }
+#endif
 }
 
 int pb_sweep_main(const PbPlan *pl, PbScratch *sc, const float *x_in, float *x_out, float *scores,

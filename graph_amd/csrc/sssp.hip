@@ -181,9 +181,9 @@ __device__ __forceinline__ uint32_t sssp_pull_list(const uint2 *__restrict__ in_
 #pragma unroll
         for (int k = 0; k < SSSP_MLP; ++k) {
             const uint32_t i = j + (uint32_t)k * step;
-            const uint2 e = i < end ? in_edge[i] : make_uint2(0xFFFFFFFFu, 0u);
-            s[k] = e.x;
-            wj[k] = __uint_as_float(e.y);
+            const uint2 e = i < end ? in_edge[i] : make_uint2(0u, 0xFFFFFFFFu); // {weight bits, source}: the low / high word of the sort key
+            s[k] = e.y;
+            wj[k] = __uint_as_float(e.x);
         }
         // GM_SSSP_PULL_FILTER=1 (measured slower: 6.56 against 6.40 ms at scale 24 — nearly every source HAS been taken up by
         // then, the bit test is one more dependent access): only sources that have been taken up matter here (the others
@@ -260,40 +260,55 @@ __device__ void sssp_pull_round(const uint32_t *__restrict__ in_off, const uint2
     }
 }
 
-// the transposed lists, once per handle: in-degrees, their exclusive scan (host side: rocprim), then every edge to the next
-// free slot of its target (the order inside an in-list is whatever the atomics make it: a minimum is taken over it)
-__global__ void sssp_in_count_kernel(const uint32_t *__restrict__ tgt, uint64_t m, uint32_t *__restrict__ cnt)
-{
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride)
-        atomicAdd(&cnt[tgt[i]], 1u);
-}
-
-__global__ __launch_bounds__(SSSP_BLOCK) void sssp_in_fill_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt,
-                                                                  const float *__restrict__ w, uint32_t n, uint32_t *cursor,
-                                                                  uint2 *__restrict__ in_edge)
+// The plan of a handle (SsspOrder), built by two FLAT radix sorts (round 5; until then a segmented sort by weight, 23 ms at
+// scale 24, and a transposition by atomics — a histogram of the targets and a cursor per target — 29 ms):
+//   key[i] = source << 32 | weight bits of edge i (non-negative floats order like their bit patterns; -0.0 is stored as +0.0,
+//   which adds to the same distances)
+//   sorted by the whole key with the targets as values  -> every list ordered by weight (targets + the keys' low words)
+//   as VALUES of a sort of the targets                   -> the transposed lists: in_edge = {weight bits, source} per in-edge
+__global__ __launch_bounds__(SSSP_BLOCK) void sssp_expand_kernel(const uint32_t *__restrict__ off, const float *__restrict__ w, uint32_t n,
+                                                                 unsigned long long *__restrict__ key)
 {
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t n_pad = (n + kWave - 1) / kWave * kWave;
+    auto make = [](uint32_t r, float x) {
+        const uint32_t b = __float_as_uint(x);
+        return (unsigned long long)r << 32 | (b == 0x80000000u ? 0u : b);
+    };
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_pad; r += stride) {
         const uint32_t s = r < n ? off[r] : 0u, e = r < n ? off[r + 1] : 0u;
         const uint32_t len = e - s;
         if (len <= SSSP_COOP)
-            for (uint32_t i = s; i < e; ++i) {
-                const uint32_t p = atomicAdd(&cursor[tgt[i]], 1u);
-                in_edge[p] = make_uint2(r, __float_as_uint(w[i]));
-            }
+            for (uint32_t i = s; i < e; ++i)
+                key[i] = make(r, w[i]);
         uint64_t big = __ballot(len > SSSP_COOP);
         while (big) {
             const int src = __ffsll((unsigned long long)big) - 1;
             big &= big - 1;
             const uint32_t bs = __shfl(s, src, kWave), be = __shfl(e, src, kWave), br = __shfl(r, src, kWave);
-            for (uint32_t i = bs + lane; i < be; i += kWave) {
-                const uint32_t p = atomicAdd(&cursor[tgt[i]], 1u);
-                in_edge[p] = make_uint2(br, __float_as_uint(w[i]));
-            }
+            for (uint32_t i = bs + lane; i < be; i += kWave)
+                key[i] = make(br, w[i]);
         }
+    }
+}
+
+__global__ void sssp_key_weights_kernel(const unsigned long long *__restrict__ key, uint64_t m, float *__restrict__ w)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride)
+        w[i] = __uint_as_float((uint32_t)key[i]);
+}
+
+// in_off[t] = first position of the sorted targets with a target >= t (t = 0 .. n)
+__global__ void sssp_in_bounds_kernel(const uint32_t *__restrict__ sorted_tgt, uint64_t m, uint32_t n, uint32_t *__restrict__ in_off)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= m; i += stride) {
+        const uint32_t lo = i == 0 ? 0u : sorted_tgt[i - 1] + 1u;
+        const uint32_t hi = i == m ? n : sorted_tgt[i];
+        for (uint32_t t = lo; t <= hi; ++t)
+            in_off[t] = (uint32_t)i;
     }
 }
 
@@ -916,44 +931,74 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
             std::lock_guard<std::mutex> lock(g->cache_mu);
             order = g->sssp_order;
         }
-        if (!order) {
+        std::unique_lock<std::mutex> build_lock(g->sssp_build_mu, std::defer_lock);
+        if (!order && !g->sssp_order_failed.load(std::memory_order_relaxed)) {
+            build_lock.lock(); // one builder per handle: a concurrent second call waits here and finds the lists built
+            std::lock_guard<std::mutex> lock(g->cache_mu);
+            order = g->sssp_order;
+        }
+        // Room: the lists keep 16 B per edge + 4 B per node; the two sorts hold about 36 B per edge at their peak.  The build
+        // only starts when the device has that, and a quarter more, FREE (another plan or the caller's tensors may need the
+        // rest); a build that did not happen is remembered in the handle (until gm_csr_trim) instead of retried by every call.
+        if (!order && build_lock.owns_lock() && !g->sssp_order_failed.load(std::memory_order_relaxed)) {
+            size_t free_b = 0, total_b = 0;
+            const size_t need = (size_t)g->m * 36 + ((size_t)n + 1) * 4;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need + need / 4) {
+                (void)hipGetLastError();
+                g->sssp_order_failed.store(1, std::memory_order_relaxed);
+                if (gm::log_enabled())
+                    fprintf(stderr, "[graph_mi355x] sssp: %zu MiB free, the weight-ordered lists need %zu MiB while they are built: "
+                                    "running on the CSR's own\n", free_b >> 20, (need + need / 4) >> 20);
+            }
+        }
+        if (!order && build_lock.owns_lock() && !g->sssp_order_failed.load(std::memory_order_relaxed)) {
             // out of memory while building them is not an error of the call: it runs on the CSR's lists, as the first call did
+            int key_bits = 0;
+            while (((uint64_t)1 << key_bits) < n)
+                ++key_bits;
+            gm::DevBuf key; // source << 32 | weight bits of every edge, CSR order: the key of one sort, the values of the other
             auto build = [&](std::shared_ptr<gm::SsspOrder> &fresh) -> int {
+                gm::DevBuf key_sorted, temp;
                 GM_TRY(fresh->targets.alloc((size_t)g->m * 4));
                 GM_TRY(fresh->weights.alloc((size_t)g->m * 4));
+                GM_TRY(key.alloc_scratch((size_t)g->m * 8));
+                GM_TRY(key_sorted.alloc_scratch((size_t)g->m * 8));
+                unsigned eg = gm::div_up(n, SSSP_BLOCK);
+                hipLaunchKernelGGL(sssp_expand_kernel, dim3(eg > 8192 ? 8192 : eg), dim3(SSSP_BLOCK), 0, (hipStream_t)0, g->offsets,
+                                   g->weights, n, key.as<unsigned long long>());
                 size_t temp_bytes = 0;
-                GM_HIP(rocprim::segmented_radix_sort_pairs(nullptr, temp_bytes, g->weights, fresh->weights.as<float>(), g->targets,
-                                                           fresh->targets.as<uint32_t>(), (unsigned int)g->m, (unsigned int)n,
-                                                           g->offsets, g->offsets + 1, 0u, 32u, (hipStream_t)0));
-                gm::DevBuf temp;
-                GM_TRY(temp.alloc(temp_bytes ? temp_bytes : 4));
-                GM_HIP(rocprim::segmented_radix_sort_pairs(temp.p, temp_bytes, g->weights, fresh->weights.as<float>(), g->targets,
-                                                           fresh->targets.as<uint32_t>(), (unsigned int)g->m, (unsigned int)n,
-                                                           g->offsets, g->offsets + 1, 0u, 32u, (hipStream_t)0));
+                GM_HIP(rocprim::radix_sort_pairs(nullptr, temp_bytes, key.as<unsigned long long>(), key_sorted.as<unsigned long long>(),
+                                                 g->targets, fresh->targets.as<uint32_t>(), (size_t)g->m, 0u, 32u + (unsigned)key_bits,
+                                                 (hipStream_t)0));
+                GM_TRY(temp.alloc_scratch(temp_bytes ? temp_bytes : 4));
+                GM_HIP(rocprim::radix_sort_pairs(temp.p, temp_bytes, key.as<unsigned long long>(), key_sorted.as<unsigned long long>(),
+                                                 g->targets, fresh->targets.as<uint32_t>(), (size_t)g->m, 0u, 32u + (unsigned)key_bits,
+                                                 (hipStream_t)0));
+                unsigned wg = gm::div_up(g->m, 256);
+                hipLaunchKernelGGL(sssp_key_weights_kernel, dim3(wg > 16384 ? 16384 : wg), dim3(256), 0, (hipStream_t)0,
+                                   key_sorted.as<unsigned long long>(), g->m, fresh->weights.as<float>());
+                GM_HIP(hipGetLastError());
                 GM_HIP(hipStreamSynchronize((hipStream_t)0));
                 if (times)
-                    fprintf(stderr, "sssp: segmented sort by weight done after %.3f ms\n", since(t_call));
+                    fprintf(stderr, "sssp: lists sorted by (node, weight) after %.3f ms\n", since(t_call));
                 return GM_OK;
             };
             auto transpose = [&](std::shared_ptr<gm::SsspOrder> &fresh) -> int { // the in-edges for the far round's pull
-                gm::DevBuf cursor, scan_tmp;
+                gm::DevBuf tgt_sorted, temp;
                 GM_TRY(fresh->in_off.alloc(((size_t)n + 1) * 4));
                 GM_TRY(fresh->in_edge.alloc((size_t)g->m * 8));
-                GM_TRY(cursor.alloc(((size_t)n + 1) * 4));
-                GM_HIP(hipMemsetAsync(cursor.p, 0, ((size_t)n + 1) * 4, (hipStream_t)0));
-                unsigned cg = gm::div_up(g->m, 256);
-                hipLaunchKernelGGL(sssp_in_count_kernel, dim3(cg > 16384 ? 16384 : cg), dim3(256), 0, (hipStream_t)0, g->targets,
-                                   g->m, cursor.as<uint32_t>());
-                size_t scan_bytes = 0;
-                GM_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, cursor.as<uint32_t>(), fresh->in_off.as<uint32_t>(), 0u,
-                                               (size_t)n + 1, rocprim::plus<uint32_t>(), (hipStream_t)0));
-                GM_TRY(scan_tmp.alloc(scan_bytes ? scan_bytes : 4));
-                GM_HIP(rocprim::exclusive_scan(scan_tmp.p, scan_bytes, cursor.as<uint32_t>(), fresh->in_off.as<uint32_t>(), 0u,
-                                               (size_t)n + 1, rocprim::plus<uint32_t>(), (hipStream_t)0));
-                GM_HIP(hipMemcpyAsync(cursor.p, fresh->in_off.p, ((size_t)n + 1) * 4, hipMemcpyDeviceToDevice, (hipStream_t)0));
-                unsigned fg = gm::div_up(n, SSSP_BLOCK);
-                hipLaunchKernelGGL(sssp_in_fill_kernel, dim3(fg > 8192 ? 8192 : fg), dim3(SSSP_BLOCK), 0, (hipStream_t)0,
-                                   g->offsets, g->targets, g->weights, n, cursor.as<uint32_t>(), fresh->in_edge.as<uint2>());
+                GM_TRY(tgt_sorted.alloc_scratch((size_t)g->m * 4));
+                size_t temp_bytes = 0;
+                GM_HIP(rocprim::radix_sort_pairs(nullptr, temp_bytes, g->targets, tgt_sorted.as<uint32_t>(), key.as<unsigned long long>(),
+                                                 fresh->in_edge.as<unsigned long long>(), (size_t)g->m, 0u, (unsigned)(key_bits ? key_bits : 1),
+                                                 (hipStream_t)0));
+                GM_TRY(temp.alloc_scratch(temp_bytes ? temp_bytes : 4));
+                GM_HIP(rocprim::radix_sort_pairs(temp.p, temp_bytes, g->targets, tgt_sorted.as<uint32_t>(), key.as<unsigned long long>(),
+                                                 fresh->in_edge.as<unsigned long long>(), (size_t)g->m, 0u, (unsigned)(key_bits ? key_bits : 1),
+                                                 (hipStream_t)0));
+                unsigned bg = gm::div_up(g->m + 1, 256);
+                hipLaunchKernelGGL(sssp_in_bounds_kernel, dim3(bg > 16384 ? 16384 : bg), dim3(256), 0, (hipStream_t)0,
+                                   tgt_sorted.as<uint32_t>(), g->m, n, fresh->in_off.as<uint32_t>());
                 GM_HIP(hipGetLastError());
                 GM_HIP(hipStreamSynchronize((hipStream_t)0));
                 return GM_OK;
@@ -974,6 +1019,7 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
                 order = g->sssp_order;
             } else {
                 (void)hipGetLastError();
+                g->sssp_order_failed.store(1, std::memory_order_relaxed);
                 if (gm::log_enabled())
                     fprintf(stderr, "[graph_mi355x] sssp: no room for the weight-ordered lists (%s): running on the CSR's own\n",
                             gm_last_error());

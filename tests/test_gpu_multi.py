@@ -186,6 +186,36 @@ def test_rank_local_rows_are_the_rows_of_the_whole_graph(P, world):
         assert np.array_equal(ltgt, tgt[int(off[lo]):int(off[hi])])
 
 
+def test_pieces_with_targets_beyond_n_are_refused(P):
+    """gm_page_rank_multi_slices indexes an n-sized node map with the pieces' targets: a piece that names a node >= n
+    (built over another graph, or with local ids) is GM_ERR_RANGE, not a memory fault."""
+    import torch
+
+    from graph_amd._lib import GraphMI355XError
+
+    import ctypes as C
+
+    from graph_amd._lib import check, lib, vp
+
+    def rows(whole, lo, hi):
+        h = vp()
+        check(lib().gm_csr_slice_rows(whole.handle, lo, hi, None, 0, 0, C.byref(h)))
+        return P.DeviceCsr(h)
+
+    n = 8
+    src, dst = np.array([5, 6, 7, 0, 1], np.uint32), np.array([0, 1, 3, 4, 6], np.uint32)
+    whole = P.DeviceCsr.from_edges(n, src, dst, None, P.Direction.Incoming, P.CsrLayout.Sorted)
+    out_deg = torch.from_numpy(np.bincount(src, minlength=n).astype(np.int32)).cuda()
+    good = [rows(whole, 0, 4), rows(whole, 4, 8)]
+    got, it, _ = P.page_rank_multi_slices(good, [0, 4, 8], [out_deg, out_deg], P.PageRankConfig(3, 0.0, 0.85), [0, 0])
+    assert it == 3 and got.shape == (n,)
+    # rows 4..7 of ANOTHER graph (16 nodes) with an in-neighbour 12: not a piece of an 8-node graph
+    other = P.DeviceCsr.from_edges(16, np.array([12, 1], np.uint32), np.array([5, 6], np.uint32), None, P.Direction.Incoming,
+                                   P.CsrLayout.Sorted)
+    with pytest.raises(GraphMI355XError, match="names node 12"):
+        P.page_rank_multi_slices([good[0], rows(other, 4, 8)], [0, 4, 8], [out_deg, out_deg], P.PageRankConfig(3, 0.0, 0.85), [0, 0])
+
+
 def test_real_collectives_on_two_gpus(P, oracle):
     """The RCCL path with more than one rank (grouped broadcasts per region on exchange streams): needs >= 2 GPUs, which the
     boxes of this pool do not have — kept so that the first multi-GPU run exercises it."""
