@@ -2598,6 +2598,22 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
                     H = H_single < candidates ? H_single : candidates;
                 pl->Htot = (uint32_t)(((uint64_t)H * T) < candidates ? (uint64_t)H * T : candidates);
             }
+            if (T == 1 && pb_env("GM_PB_HOT_TRIM", 1) && H > 1024) {
+                // ONE table: every accumulate workgroup stages all of it before its first hot edge (4 H bytes from L2 and a
+                // barrier), so a source belongs in it only if its edges pay for that.  The same break-even as a tier's
+                // (6000 edges per bin for ~10,000 sources): a source with fewer edges than half the number of bins is left
+                // to the value stream.  Measured at RMAT scale 22 (tools/runs/r05_call14.sh, 2048 bins): the whole room
+                // (15,360 sources, the last ones ~800 edges each) 0.2155 ms per sweep, 8,192 sources (~1,100) 0.2069, 4,096
+                // (~1,900) 0.2096.
+                std::vector<uint64_t> top(H);
+                GM_HIP(hipMemcpy(top.data(), ckeys.p, (size_t)H * 8, hipMemcpyDeviceToHost));
+                const double least = 0.5 * pl->B;
+                uint32_t keep = H;
+                while (keep > 1024 && (double)(uint32_t)~(uint32_t)(top[keep - 1] >> 32) * sample_step < least)
+                    keep -= 64;
+                H = keep & ~63u;
+                pl->Htot = H;
+            }
             pl->T = T;
             hipLaunchKernelGGL(pb_hot_select_kernel, dim3(div_up(pl->Htot, 256)), dim3(256), 0, 0, ckeys.as<uint64_t>(), pl->Htot,
                                pl->hot_ids.as<uint32_t>(), hot_rank.as<uint32_t>(), hot_blk.as<uint32_t>(), fshift);
