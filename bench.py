@@ -300,9 +300,8 @@ def main():
     if piecewise:
         gather = None
         if emu:  # stand-in for the collective: only this rank's slot of the region is refreshed
-            def gather(dst_region, src, k):
-                st = layout["strides"][k]
-                dst_region[rank * st:(rank + 1) * st] = src
+            def gather(dst_views, src, k):
+                dst_views[rank].copy_(src)
         ex = PiecewiseExchange(engine, layout, rank, n_local, dev, gather=gather, split_bin=bool(args.bin_pieces),
                                streams=bool(args.piece_streams))
         if emu:  # the slots of the ranks that do not exist: a typical out_score instead of zeros (rows that sum to 0 are not

@@ -184,12 +184,19 @@ SOURCE_TILE = 32768  # x regions of a sweep in pieces: a multiple of any plan's 
 
 
 def split_exchange_layout(out_degree, bounds, parts: int = 2, row_align: int = ROW_ALIGN, tile: int = SOURCE_TILE):
-    """compact_exchange_layout for a sweep in pieces: every rank cuts its rows into `parts` groups (at
-    multiples of row_align) and the exchanged vector into as many regions, region k holding group k of
-    every rank (rank-major, `strides[k]` floats per rank, a multiple of `tile`), so that region k can be
-    all-gathered while the ranks still work on group k+1 and be consumed (elements
-    [region_off[k], region_off[k] + world * strides[k]) of x) while region k+1 is still in flight.
-    Returns a dict: node_map int32[n] (-1: never a source), x_len, strides[k], region_off[k],
+    """compact_exchange_layout for a sweep in pieces: every rank cuts its rows into `parts` groups (at multiples of
+    row_align) and the exchanged vector into as many regions, region k holding group k of every rank, so that region k can
+    be all-gathered while the ranks still work on group k+1 and be consumed while region k+1 is still in flight.
+
+    The vector is RANK-MAJOR (round 5; the C ABI front, multi.hip, has been from the start): rank p's block of `block` =
+    sum(strides) floats holds its groups one behind the other (group k: `strides[k]` floats, a multiple of `tile`), so a
+    node's slot ascends with its id and a Sorted row of a rank's slice stays ascending in the exchange index space — the
+    order the hub rows' left-to-right sums follow (page_rank.rs:143-146).  Region k is therefore not one stretch of x but P
+    of them: elements [p * block + group_off[k], + strides[k]) for every rank p (`region_ranges(layout, k)`).  (Until round 5
+    the vector was REGION-major — what one all_gather_into_tensor per region writes — and a slice's hub rows were summed in
+    an order that was neither the reference's nor the single-GPU run's.)
+
+    Returns a dict: node_map int32[n] (-1: never a source), x_len, strides[k], group_off[k], block, world,
     row_splits[rank] (parts+1 local row indices), send_rows[rank][k] (local rows, slot order)."""
     has_out = out_degree > 0
     world = len(bounds) - 1
@@ -204,20 +211,27 @@ def split_exchange_layout(out_degree, bounds, parts: int = 2, row_align: int = R
         row_splits.append(sp)
         send_rows.append([sp[k] + torch.nonzero(has_out[lo + sp[k]:lo + sp[k + 1]], as_tuple=False).flatten()
                           for k in range(parts)])
-    strides, region_off, off = [], [], 0
+    strides, group_off, off = [], [], 0
     for k in range(parts):
         most = max(int(send_rows[p][k].numel()) for p in range(world))
         stride = max(tile, -(-most // tile) * tile)
         strides.append(stride)
-        region_off.append(off)
-        off += world * stride
+        group_off.append(off)
+        off += stride
+    block = off
     for p in range(world):
         lo = int(bounds[p])
         for k in range(parts):
             rows = send_rows[p][k]
-            node_map[lo + rows] = (region_off[k] + p * strides[k] + torch.arange(rows.numel(), device=dev)).to(torch.int32)
-    return {"node_map": node_map, "x_len": off, "strides": strides, "region_off": region_off,
-            "row_splits": row_splits, "send_rows": send_rows, "parts": parts}
+            node_map[lo + rows] = (p * block + group_off[k] + torch.arange(rows.numel(), device=dev)).to(torch.int32)
+    return {"node_map": node_map, "x_len": world * block, "strides": strides, "group_off": group_off, "block": block,
+            "world": world, "row_splits": row_splits, "send_rows": send_rows, "parts": parts}
+
+
+def region_ranges(layout, k: int):
+    """[(lo, hi)] of region k of a split_exchange_layout vector: one stretch per rank"""
+    return [(p * layout["block"] + layout["group_off"][k], p * layout["block"] + layout["group_off"][k] + layout["strides"][k])
+            for p in range(layout["world"])]
 
 
 class PiecewiseExchange:
@@ -231,7 +245,7 @@ class PiecewiseExchange:
     set_parts (graph_amd.engine.PageRankEngine, or a stand-in with the same methods)."""
 
     def __init__(self, engine, layout, rank: int, n_local: int, device, group=None, gather=None, split_bin=True,
-                 streams=False):
+                 streams=False, x=None):
         # split_bin=False: one propagation launch after every region has landed (only the accumulate is cut into
         # row groups) — region k still travels under the accumulate of the later groups, and the short kernels
         # of a many-rank run are not cut in four
@@ -242,15 +256,22 @@ class PiecewiseExchange:
         self.engine, self.layout, self.rank, self.group = engine, layout, rank, group
         world = len(layout["row_splits"])
         self.parts = layout["parts"]
-        self.x = [torch.zeros(layout["x_len"], dtype=torch.float32, device=device) for _ in range(2)]
+        # x: the two exchanged vectors (tests with virtual ranks on one device hand every rank the SAME pair)
+        self.x = x if x is not None else [torch.zeros(layout["x_len"], dtype=torch.float32, device=device) for _ in range(2)]
         self.x_loc = torch.zeros(max(n_local, 1), dtype=torch.float32, device=device)
         self.x_send = [torch.zeros(s, dtype=torch.float32, device=device) for s in layout["strides"]]
         self.send_rows = [r.to(device) for r in layout["send_rows"][rank]]
-        self.regions = [(layout["region_off"][k], layout["region_off"][k] + world * layout["strides"][k])
-                        for k in range(self.parts)]
+        # region k = one stretch per rank (rank-major vector): the all-gather of a region lands in P views of x
+        self.ranges = [region_ranges(layout, k) for k in range(self.parts)]
+        self.views = [[[x[lo:hi] for (lo, hi) in self.ranges[k]] for k in range(self.parts)] for x in self.x]
+        self._region_launch = hasattr(engine, "set_bin_regions")  # one propagation launch per region (graph_amd.engine)
+        if self._region_launch:
+            flat = [(lo, hi, k) for k in range(self.parts) for (lo, hi) in self.ranges[k]]
+            engine.set_bin_regions([f[0] for f in flat], [f[1] for f in flat], [f[2] for f in flat], self.parts)
         self.cur = 0
         self.works = [None] * self.parts
-        # gather(dst_region, src, k): stand-in for the collective (single-process emulation); default RCCL/gloo
+        # gather(dst_views, src, k): stand-in for the collective (single-process emulation: dst_views[p] is where rank p's
+        # group k lands); default RCCL / gloo
         self._gather = gather
         engine.set_parts(layout["row_splits"][rank])
         if streams and self.parts > 1 and torch.cuda.is_available():
@@ -260,13 +281,19 @@ class PiecewiseExchange:
     def _start_gather(self, buf: int, k: int):
         rows = self.send_rows[k]
         self.x_send[k][: rows.numel()] = self.x_loc[rows]  # compaction: only nodes with out-edges travel
-        lo, hi = self.regions[k]
-        dst = self.x[buf][lo:hi]
+        dst = self.views[buf][k]  # rank p's group k lands in rank p's block of x
         if self._gather is not None:
             self._gather(dst, self.x_send[k], k)
             self.works[k] = None
         else:
-            self.works[k] = dist.all_gather_into_tensor(dst, self.x_send[k], group=self.group, async_op=True)
+            self.works[k] = dist.all_gather(dst, self.x_send[k], group=self.group, async_op=True)
+
+    def _bin_region(self, x_in, k: int):
+        if self._region_launch:
+            self.engine.sweep_bin_region(x_in, k)
+        else:  # (stand-in engines of the gloo tests: one call per stretch)
+            for lo, hi in self.ranges[k]:
+                self.engine.sweep_bin(x_in, lo, hi)
 
     def start(self, scores: torch.Tensor):
         """page_rank.rs:70-81 initial values, then the first exchange"""
@@ -293,9 +320,8 @@ class PiecewiseExchange:
         for k in range(self.parts):
             if self.works[k] is not None:
                 self.works[k].wait()  # orders the current stream behind the collective; the host does not block
-            lo, hi = self.regions[k]
             if self.split_bin:
-                timed(e.sweep_bin, x_in, lo, hi)
+                timed(self._bin_region, x_in, k)
         if not self.split_bin:
             timed(e.sweep_bin, x_in, 0, x_in.numel())
         for k in range(self.parts):
@@ -322,8 +348,7 @@ class PiecewiseExchange:
                         st.wait_event(ev)
                 if self.works[k] is not None:
                     self.works[k].wait()
-                lo, hi = self.regions[k]
-                e.sweep_bin(x_in, lo, hi)
+                self._bin_region(x_in, k)
                 ev = torch.cuda.Event()
                 ev.record(st)
                 ev_bin.append(ev)

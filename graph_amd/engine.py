@@ -94,6 +94,18 @@ class PageRankEngine:
         # propagate x_in[x_lo:x_hi] (whole source tiles) into the value stream
         check(lib().gm_pr_sweep_bin(self._h, x_in.data_ptr(), x_lo, x_hi, current_stream_ptr()))
 
+    def set_bin_regions(self, x_lo, x_hi, region, n_regions: int):
+        """regions of x as LISTS of tile ranges (a rank-major exchanged vector: region k = group k of every rank)"""
+        cnt = len(x_lo)
+        lo = (C.c_uint64 * cnt)(*[int(v) for v in x_lo])
+        hi = (C.c_uint64 * cnt)(*[int(v) for v in x_hi])
+        rg = (C.c_uint32 * cnt)(*[int(v) for v in region])
+        check(lib().gm_pr_set_bin_regions(self._h, lo, hi, rg, cnt, int(n_regions)))
+
+    def sweep_bin_region(self, x_in: torch.Tensor, region: int):
+        # propagate every tile range of one region into the value stream: ONE launch
+        check(lib().gm_pr_sweep_bin_region(self._h, x_in.data_ptr(), int(region), current_stream_ptr()))
+
     def sweep_hot(self, x_in: torch.Tensor):
         check(lib().gm_pr_sweep_hot(self._h, x_in.data_ptr(), current_stream_ptr()))
 

@@ -131,8 +131,10 @@ def _overlap_worker(rank, world, port, scale, max_iter, tol, parts, q):
     lay = split_exchange_layout(torch.from_numpy(od.astype(np.int64)), bounds, parts=parts, row_align=8, tile=16)
     nm = lay["node_map"].numpy()
     assert int((nm >= 0).sum()) == int((od > 0).sum()) and len(set(nm[nm >= 0].tolist())) == int((nm >= 0).sum())
-    for k in range(parts):  # regions are whole tiles and every slot of region k lies inside it
-        assert lay["region_off"][k] % 16 == 0 and lay["strides"][k] % 16 == 0
+    for k in range(parts):  # regions are whole tiles ...
+        assert lay["group_off"][k] % 16 == 0 and lay["strides"][k] % 16 == 0 and lay["block"] % 16 == 0
+    live = nm[nm >= 0]
+    assert np.all(np.diff(live) > 0)  # ... and a node's slot ascends with its id (rank-major: what the hub rows' order needs)
     eng = _OraclePiecewiseEngine(O, ioff, itgt, od, bounds, 0, rank, 0.85, nm)
     eng.TILE = 16
     scores, it, err = page_rank_partitioned_overlapped(eng, lay, rank, int(bounds[rank + 1] - bounds[rank]), max_iter, tol,

@@ -905,12 +905,10 @@ def test_page_rank_sweep_in_pieces_matches_whole_sweep(P, oracle, scale):
             rows_per_bin, tile = e.part_geometry()
             assert 32768 % tile == 0 and 16384 % rows_per_bin == 0
 
-            def gather(dst_region, src, k, r=r):  # this rank's slot of region k
-                st = lay["strides"][k]
-                dst_region[r * st:(r + 1) * st] = src
+            def gather(dst_views, src, k, r=r):  # this rank's slot of region k
+                dst_views[r].copy_(src)
 
-            ex = PiecewiseExchange(e, lay, r, hi - lo, dev, gather=gather, streams=streams)
-            ex.x = shared
+            ex = PiecewiseExchange(e, lay, r, hi - lo, dev, gather=gather, streams=streams, x=shared)
             ranks.append((csr, odl, e, ex, torch.zeros(hi - lo, device=dev), torch.zeros(1, dtype=torch.float64, device=dev)))
         for (_, _, _, ex, scl, _) in ranks:
             ex.start(scl)
