@@ -325,7 +325,7 @@ uint64_t multi_env_hash()
     // per-launch measurement knobs are not among them: toggling those must not look like another configuration)
     static const char *const knobs[] = {"GM_PB_HOT",       "GM_PB_RB",        "GM_PB_SLOG",      "GM_PB_CHUNK",     "GM_PB_SPLIT",
                                         "GM_PB_WGS",       "GM_PB_COMPACT",   "GM_PB_ORDER",     "GM_PB_XCD",       "GM_PB_HUB_DEG",
-                                        "GM_PB_HUB_GROUP", "GM_PB_HUB_LONG",  "GM_PB_HUB_HOT",   "GM_PB_HUB_CSR",   "GM_PB_HUB_ROOM",
+                                        "GM_PB_HUB_GROUP", "GM_PB_HUB_LONG",  "GM_PB_HUB_HOT",   "GM_PB_HUB_CSR",   "GM_PB_HUB_ROOM", "GM_PB_HUB_THIN", "GM_PB_HOT_TRIM",
                                         "GM_PB_HUB_FORK",  "GM_PB_LONG_PASSES", "GM_PB_TIERS",   "GM_PB_HOT16",     "GM_PB_SEGPAD",
                                         "GM_PB_SPREAD",    "GM_PB_SPREAD_PLAN", "GM_PB_FILTER_BITS", "GM_PB_WG_GROUP", "GM_PB_BIN_GAP",
                                         "GM_MULTI_ENGINE", "GM_MULTI_PARTS"};

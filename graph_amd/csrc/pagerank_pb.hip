@@ -178,6 +178,8 @@ struct PbPlan {
     DevBuf hub_gidx;           // u32[..] per hub row (4-aligned stretches): value-stream position of its k-th in-neighbour's out_score
     DevBuf csr_items;          // PbHubItem[n_hub]: {first, end of the row's stretch of hub_gidx, 1, index in hub_rows, error slot}
     std::vector<uint32_t> hub_degs_host;
+    DevBuf long_rows;          // PbHubItem[n_long_rows]: the rows pb_hublong_kernel sums ({q0, q1: the group's stretch; nh: the row's SLOT; row0; error slot})
+    uint32_t n_long_rows = 0;
     DevBuf long_items;         // PbLongItem[n_long_items]: the long rows cut into items of a few passes, row by row (longest row first)
     uint32_t n_long_items = 0;
     uint32_t long_sbs_len = 0; // entries of an engine's array of pass-boundary sums (every long row: its passes + 1)
@@ -1821,8 +1823,9 @@ __global__ __launch_bounds__(PB_LONG_WG) __attribute__((amdgpu_waves_per_eu(5, 8
     // that leaves a round through its single barrier may write the next round's totals while another still reads these
     __shared__ uint32_t w_a0s[2][NWV], w_a1s[2][NWV], w_firsts[2][NWV];
     __shared__ float s_bcast;
-    __shared__ uint32_t s_item;
+    __shared__ uint32_t s_item, s_ahead;
     __shared__ uint32_t sum_t0[PB_LONG_PMAX], sum_t1[PB_LONG_PMAX], sum_e[PB_LONG_PMAX]; // the passes' pairs and their binade (0: none)
+    __shared__ uint32_t pred_e[PB_LONG_PMAX]; // the binade a pass is predicted to stay in (read once, by one thread)
     constexpr uint32_t TROW = PER + 4;          // floats between two threads' rows in the turning buffer (conflict-free 16-byte reads)
     constexpr uint32_t TOWN = PB_LONG_WG * 4 / PER; // threads that own the 2048 terms of one round
     __shared__ __attribute__((aligned(16))) float tbuf[TOWN * TROW]; // 2048 terms of the super-block at a time: 10 KiB
@@ -1835,7 +1838,8 @@ __global__ __launch_bounds__(PB_LONG_WG) __attribute__((amdgpu_waves_per_eu(5, 8
     lds_barrier();
     const uint32_t me = s_item;
     const PbLongItem li = litems[me];
-    const PbHubItem item = items[li.row]; // one row: slot 0 (padding entries: PB_NULL)
+    const PbHubItem item = items[li.row]; // one row: the entries of its group's stretch whose slot is item.nh (padding entries: PB_NULL)
+    const uint32_t my_slot = item.nh;
     // (counts from an even / odd start) of run F followed by run G; saturated: beyond the first run that leaves the binade
     // nothing is used
     auto compose = [&](uint32_t f0, uint32_t f1, uint32_t g0, uint32_t g1, uint32_t &h0, uint32_t &h1) {
@@ -1878,10 +1882,10 @@ __global__ __launch_bounds__(PB_LONG_WG) __attribute__((amdgpu_waves_per_eu(5, 8
             const uint32_t i = tid * 4u; // place inside the round's 2048 terms
             f32x4 x = raw.x[r];
             const u32x2 d = raw.d[r];
-            x.x = (d.x & 0xFFFFu) == 0u ? x.x : 0.0f;
-            x.y = (d.x >> 16) == 0u ? x.y : 0.0f;
-            x.z = (d.y & 0xFFFFu) == 0u ? x.z : 0.0f;
-            x.w = (d.y >> 16) == 0u ? x.w : 0.0f;
+            x.x = (d.x & 0xFFFFu) == my_slot ? x.x : 0.0f; // (another row's term, or padding: + 0 leaves every sum as it is)
+            x.y = (d.x >> 16) == my_slot ? x.y : 0.0f;
+            x.z = (d.y & 0xFFFFu) == my_slot ? x.z : 0.0f;
+            x.w = (d.y >> 16) == my_slot ? x.w : 0.0f;
             *reinterpret_cast<f32x4 *>(tbuf + (i / PER) * TROW + (i % PER)) = x;
             lds_barrier();
             if (tid / TOWN == r) {
@@ -2042,17 +2046,32 @@ __global__ __launch_bounds__(PB_LONG_WG) __attribute__((amdgpu_waves_per_eu(5, 8
     const uint32_t q_first = item.q0 + li.pass0 * SUPER;
     float *my_sbs = sbs + li.sb0 + li.pass0; // the sums at my passes' boundaries: [p] before pass p, [npass] behind the last
     uint32_t held = NONE; // the pass whose entries are in `raw`
-    // 1. the pairs of the passes that stayed inside one binade in the sweep before — only where there is something to wait for
-    uint32_t ahead = 0; // bit p: pass p gets its pair formed ahead
-    if (li.flags & 2u) {
-        for (uint32_t p = 0; p < li.npass; ++p) {
-            const uint32_t ea = __float_as_uint(my_sbs[p]) >> 23, eb = __float_as_uint(my_sbs[p + 1u]) >> 23;
-            if (ea == eb && ea >= 24u && ea < 255u && li.pass0 + p != 0u)
-                ahead |= 1u << p;
-        }
-    }
+    // 1. the pairs of the passes that stayed inside one binade in the sweep before — only where there is something to wait for.
+    // ONE thread reads the boundary sums, once: the items before and behind this one write the two outer ones (their exact S
+    // of THIS sweep) while this one runs, so two threads could see two different sums — with different exponents when a sum
+    // has just crossed a power of two — and disagree about which passes are formed ahead, i.e. about the barriers they meet,
+    // or form their pairs on two different grids.  (The first version of this kernel had every thread read them for itself; no
+    // wrong sum was ever traced to it — tools/debug_unsorted.py compares every hub row with the REFORDER engine sweep by sweep —
+    // but nothing ruled it out either.)
     if (tid < PB_LONG_PMAX)
         sum_e[tid] = 0u;
+    if (tid == 0) {
+        uint32_t mask = 0;
+        if (li.flags & 2u) {
+            uint32_t ea = __float_as_uint(my_sbs[0]) >> 23;
+            for (uint32_t p = 0; p < li.npass; ++p) {
+                const uint32_t eb = __float_as_uint(my_sbs[p + 1u]) >> 23;
+                if (ea == eb && ea >= 24u && ea < 255u && li.pass0 + p != 0u) {
+                    mask |= 1u << p;
+                    pred_e[p] = ea;
+                }
+                ea = eb;
+            }
+        }
+        s_ahead = mask;
+    }
+    lds_barrier();
+    const uint32_t ahead = s_ahead; // bit p: pass p gets its pair formed ahead, on the grid of binade pred_e[p]
     if (ahead) {
         uint32_t p = (uint32_t)__ffs((int)ahead) - 1u;
         fetch(q_first + p * SUPER);
@@ -2063,7 +2082,7 @@ __global__ __launch_bounds__(PB_LONG_WG) __attribute__((amdgpu_waves_per_eu(5, 8
             if (pn != NONE)
                 fetch(q_first + pn * SUPER); // the next pass's entries travel while this one's pair is formed
             held = pn;
-            const uint32_t e = __float_as_uint(my_sbs[p]) >> 23;
+            const uint32_t e = pred_e[p];
             uint32_t a0, a1;
             bool tie;
             my_pair(__uint_as_float((277u - e) << 23), a0, a1, tie);
@@ -2329,8 +2348,20 @@ int pb_make_items(PbPlan *pl)
     if (!hubs.empty())
         GM_HIP(hipMemcpy(pl->hub_items.p, hubs.data(), hubs.size() * sizeof(PbHubItem), hipMemcpyHostToDevice));
     pl->hub_items_host = hubs;
-    pl->err_slots = pl->G;
-    return pb_make_long_items(pl, hubs, pl->G_long);
+    // error sums behind the B bins': one per hub group (written by pb_hubseq_kernel), then one per hub row (pb_hublong_kernel);
+    // a slot nobody writes stays zero (pb_scratch_create)
+    pl->err_slots = pl->G + pl->n_hub;
+    // the rows pb_hublong_kernel sums: every row of every "long" group (one long row, or a thin group's few rows) as
+    // {the group's stretch of the stream, the row's SLOT inside the group, its index in hub_rows, its error slot}, longest first
+    std::vector<PbHubItem> rows;
+    for (uint32_t g = 0; g < pl->G_long; ++g)
+        for (uint32_t j = 0; j < hubs[g].nh; ++j)
+            rows.push_back(PbHubItem{hubs[g].q0, hubs[g].q1, j, hubs[g].row0 + j, pl->G + hubs[g].row0 + j});
+    pl->n_long_rows = (uint32_t)rows.size();
+    GM_TRY(pl->long_rows.alloc((rows.size() ? rows.size() : 1) * sizeof(PbHubItem)));
+    if (!rows.empty())
+        GM_HIP(hipMemcpy(pl->long_rows.p, rows.data(), rows.size() * sizeof(PbHubItem), hipMemcpyHostToDevice));
+    return pb_make_long_items(pl, rows, (uint32_t)rows.size());
 }
 
 int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
@@ -2458,6 +2489,25 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
             pl->hub_long_host.push_back(prev_long ? 1 : 0);
             pl->hub_first_host.push_back(pl->n_hub);
             pl->G = (uint32_t)pl->hub_first_host.size() - 1;
+            // THIN groups (GM_PB_HUB_THIN=<rows>, default 0 = off; round 5): a group of few rows leaves most lanes of
+            // pb_hubseq_kernel's walking wavefront idle — in a rank's slice of a partitioned graph, where hub rows are seldom
+            // neighbours, that is most groups (an 8-way rank at scale 26: 2,310 hub rows in 902 groups).  Such a group can be
+            // summed by pb_hublong_kernel instead, one item list per ROW, each reading the group's stretch of the stream and
+            // taking the entries of its slot.  Bit-identical (tests/test_gpu_hub_adversarial.py) and MEASURED SLOWER with 4
+            // (tools/runs/r05_call20.sh, alternating processes): rank 0 / 1 of 8 0.586 / 0.529 against 0.565 / 0.500 ms, scale
+            // 26 2.70 against 2.65, scale 22 0.210-0.226 against 0.207 — the 512-thread workgroups of twice as many rows cost the
+            // accumulate kernel beside them more than the idle lanes of the walks did: off.
+            {
+                const uint32_t thin = (uint32_t)pb_env("GM_PB_HUB_THIN", 0);
+                for (uint32_t g = 0; g < pl->G; ++g) {
+                    const uint32_t nh = pl->hub_first_host[g + 1] - pl->hub_first_host[g];
+                    if (!pl->hub_long_host[g] && nh <= thin) {
+                        pl->hub_long_host[g] = 1;
+                        for (uint32_t h = pl->hub_first_host[g]; h < pl->hub_first_host[g + 1]; ++h)
+                            pl->long_terms += degs[h];
+                    }
+                }
+            }
         }
         GM_TRY(pl->hub_first.alloc(pl->hub_first_host.size() * 4));
         GM_HIP(hipMemcpy(pl->hub_first.p, pl->hub_first_host.data(), pl->hub_first_host.size() * 4, hipMemcpyHostToDevice));
@@ -2899,7 +2949,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
             }
         for (uint32_t h = 0; h < pl->n_hub; ++h) {
             g0[h] = (uint32_t)Mg;
-            rows[h] = PbHubItem{(uint32_t)Mg, (uint32_t)Mg + pl->hub_degs_host[h], 1u, h, h};
+            rows[h] = PbHubItem{(uint32_t)Mg, (uint32_t)Mg + pl->hub_degs_host[h], 0u, h, pl->G + h};
             Mg += (pl->hub_degs_host[h] + 3u) & ~3u;
         }
         GM_CHECK(Mg < (1ull << 32), GM_ERR_RANGE, "pb_build: %llu hub terms in CSR order exceed the 32-bit index", (unsigned long long)Mg);
@@ -2923,7 +2973,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
         uint32_t missing = 0;
         GM_HIP(hipMemcpy(&missing, d_missing.p, 4, hipMemcpyDeviceToHost));
         GM_CHECK(missing == 0, GM_ERR_INVALID, "pb_build: %u hub terms have no entry in their group's part of the stream", missing);
-        pl->err_slots = pl->n_hub;
+        pl->n_long_rows = pl->n_hub;
         GM_TRY(pb_make_long_items(pl, rows, pl->n_hub));
         timer.done("pb plan: hub rows in CSR order (%u rows, %llu index entries)", pl->n_hub, (unsigned long long)Mg);
     }
@@ -3441,6 +3491,8 @@ int pb_scratch_create(const PbPlan *pl, PbScratch **out, DevBuf *early)
     hipError_t e = hipMemset(sc->tickets.p, 0, (size_t)pl->B * 4);
     if (e == hipSuccess) // (no hand-off word carries epoch 0, the counter starts at 0, sums of 0 predict nothing)
         e = hipMemset(sc->long_state.p, 0, sc->long_state.bytes);
+    if (e == hipSuccess) // (an error slot no kernel of this plan writes — a hub row's or a hub group's, whichever sums it — stays 0)
+        e = hipMemset(sc->bin_err.p, 0, sc->bin_err.bytes);
     if (e == hipSuccess)
         e = hipMemset(sc->vals_raw.p, 0, sc->vals_raw.bytes);
     // The hub kernels' streams get the LOWEST priority the device offers (GM_PB_SIDE_PRIO=0: the default one): their small
@@ -3485,14 +3537,14 @@ void pb_plan_info(const PbPlan *pl, const PbScratch *sc, uint64_t *info, uint32_
 {
     const DevBuf *bufs[] = {&pl->cidx, &pl->hub_rows, &pl->p1_src, &pl->chunk_seg, &pl->delta, &pl->tile_p, &pl->wg_tile,
                             &pl->wg_p0,  &pl->p2_dst, &pl->bin_v,  &pl->items,     &pl->hot_ids, &pl->hot_ent, &pl->hbin_v, &pl->hot_base,
-                            &pl->seq_rows, &pl->seq_blk, &pl->hh_ent, &pl->hub_gidx, &pl->csr_items, &pl->long_items};
+                            &pl->seq_rows, &pl->seq_blk, &pl->hh_ent, &pl->hub_gidx, &pl->csr_items, &pl->long_items, &pl->long_rows};
     uint64_t plan_bytes = 0;
     for (const DevBuf *b : bufs)
         plan_bytes += b->bytes;
     const uint64_t scratch_bytes = sc ? sc->vals_raw.bytes + sc->partials.bytes + sc->tickets.bytes + sc->bin_err.bytes +
                                             sc->hot_x.bytes + sc->long_state.bytes : 0;
     const uint64_t v[] = {plan_bytes, (uint64_t)(pl->build_ms * 1000.0), pl->n_hub, pl->hub_edges, pl->hub_deg, pl->Htot,
-                          pl->Mv, pl->Mh, scratch_bytes, pl->B, pl->NT, pl->NS, pl->G, pl->T, pl->G_long, pl->long_terms, pl->seq_blocks,
+                          pl->Mv, pl->Mh, scratch_bytes, pl->B, pl->NT, pl->NS, pl->G, pl->T, pl->n_long_rows, pl->long_terms, pl->seq_blocks,
                           sc ? sc->draw_best_us : 0u, sc ? sc->draw_worst_us : 0u, sc ? sc->draws_timed : 0u,
                           sc ? sc->grown_pieces : 0u, sc && !sc->vals_raw.arena.empty() ? 1u : 0u, pl->Mhh};
     for (uint32_t i = 0; i < count; ++i)
@@ -3650,7 +3702,7 @@ static bool pb_hub_dispatch(const PbPlan *pl, PbScratch *sc, float *x_out, float
         bool launched = false;
         if (pl->G_long && !(skip & 2)) {
             (void)pb_launch_flags(pb_hublong_kernel<false>, dim3(pl->n_long_items), dim3(PB_LONG_WG), 0, st, launched, sc->vals,
-                                  pl->p2_dst.as<uint16_t>(), (const uint32_t *)nullptr, items, l_items, pl->n_long_items, l_ticket, l_handoff, l_sbs, l_epoch,
+                                  pl->p2_dst.as<uint16_t>(), (const uint32_t *)nullptr, pl->long_rows.as<PbHubItem>(), l_items, pl->n_long_items, l_ticket, l_handoff, l_sbs, l_epoch,
                                   pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr, base, damping);
             launched = true;
         }
@@ -3674,7 +3726,7 @@ static bool pb_hub_dispatch(const PbPlan *pl, PbScratch *sc, float *x_out, float
             (void)hipStreamWaitEvent(ls, sc->ev_chain_fork, 0);
         }
         hipLaunchKernelGGL(pb_hublong_kernel<false>, dim3(pl->n_long_items), dim3(PB_LONG_WG), 0, ls, sc->vals, pl->p2_dst.as<uint16_t>(),
-                           (const uint32_t *)nullptr, items, l_items, pl->n_long_items, l_ticket, l_handoff, l_sbs, l_epoch, pl->hub_rows.as<uint32_t>(), outdeg, scores,
+                           (const uint32_t *)nullptr, pl->long_rows.as<PbHubItem>(), l_items, pl->n_long_items, l_ticket, l_handoff, l_sbs, l_epoch, pl->hub_rows.as<uint32_t>(), outdeg, scores,
                            x_out, gerr, base, damping);
         if (own)
             (void)hipEventRecord(sc->ev_chain_join, ls);

@@ -20,7 +20,7 @@
  *     do not pay for it again: PageRank's propagation-blocking plan (~4.3 B/edge) and the stream,
  *     vectors and engine of the last gm_page_rank call (~3.4 B/edge + 12 B/node: ~9 GB at RMAT
  *     scale 26); the working set of the last gm_sssp_delta_stepping (~9 B/node; from the second call on a graph of
- *     2^20 edges or more also its lists ordered by weight and transposed, ~20 B/edge) and gm_wcc_* call
+ *     2^20 edges or more also its lists ordered by weight and transposed, 16 B/edge + 4 B/node) and gm_wcc_* call
  *     (~8 B/node); gm_triangle_count's DAG of lower prefixes and list records (~6 B/entry +
  *     128 B/node: 4.7 GB at scale 24); the partition of the last gm_page_rank_multi call (slices,
  *     engines, exchange buffers on every device it named).  A concurrent second call of one algorithm allocates its own
@@ -251,7 +251,11 @@ int gm_pr_sweep_fixup(gm_pr *pr, uint64_t d_x_out_local, uint64_t d_scores_local
  * gm_pr_sweep_bin for every region [x_lo, x_hi) of the vector as it arrives; once all of it is there the hot
  * sources are staged (gm_pr_sweep_hot, or stage_hot = 1 on the first accumulate) and gm_pr_sweep_accum runs
  * for every part — on one stream in order, or on several streams ordered by events; gm_pr_sweep_fixup for the
- * error.  Together they do exactly what gm_pr_sweep_tiles does: same kernels, same bits. */
+ * error.  Together they do exactly what gm_pr_sweep_tiles does: same kernels, same bits.
+ * Hub rows (page_rank.rs:143-146 order) may lie in any part: their kernels are launched with part 0, beside its
+ * accumulate kernel on the engine's own side streams, and gm_pr_sweep_accum of EVERY part makes its stream wait for
+ * them behind its own accumulate kernel — what the caller enqueues next on that stream (the exchange of the part's
+ * rows) sees the part's hub rows finished.  Enqueue part 0 first. */
 int gm_pr_part_geometry(const gm_pr *pr, uint64_t *rows_per_bin_out, uint64_t *source_tile_out);
 int gm_pr_set_parts(gm_pr *pr, const uint64_t *row_splits /* n_parts + 1 values: 0 .. n_local */, uint64_t n_parts);
 int gm_pr_sweep_bin(gm_pr *pr, uint64_t d_x_in_global, uint64_t x_lo, uint64_t x_hi /* elements of x_in */, void *stream);
@@ -274,11 +278,15 @@ uint64_t gm_pr_tile_count(const gm_pr *pr); /* workgroups per sweep (diagnostics
  * (page_rank.rs:143-146), [3] their in-edges, [4] the in-degree threshold for that (GM_PB_HUB_DEG, default
  * 4096, 0 = off), [5] hot sources, [6] entries of the value stream, [7] hot edges, [8] bytes of this engine's
  * scratch (value stream etc.), [9] bins, [10] source tiles, [11] (tile, bin) segments, [12] hub groups (the hub
- * rows are walked in groups of <= 64 rows, one workgroup each), [13] tiers of hot sources, [14] hub groups of one or
- * two rows (the long chains, walked block-parallel), [15] their 4096-entry blocks, [16] how many of them fell back to
- * the sequential walk in the last sweep (scratch != NULL), [17] / [18] bin-kernel time (us) of the fastest / slowest timed
+ * rows are walked in groups of <= 64 rows, one workgroup each), [13] tiers of hot sources, [14] long rows (summed by
+ * pb_hublong_kernel: a scan over parity pairs, a row of more than 8 passes over several workgroups), [15] their in-edges,
+ * [16] 2040-term blocks of the other hub groups, [17] / [18] bin-kernel time (us) of the fastest / slowest timed
  * placement draw of the engine's value stream, [19] draws timed, [20] 64 MiB pieces the device arena was grown by for it,
- * [21] 1: the value stream is mapped from arena pieces (0: hipMalloc).  Further entries are 0. */
+ * [21] 1: the value stream is mapped from arena pieces (0: hipMalloc), [22] hub terms taken from hot sources (off the
+ * value stream).  Further entries are 0.
+ * A CSR whose hub rows' lists are NOT ascending (CsrLayout::Unsorted, csr.rs:34-45) is noticed when the plan is built:
+ * its hub rows are summed in the order the lists lie in the CSR (the reference's, page_rank.rs:143-146) through a
+ * per-term index (4 bytes per hub edge more plan data, an L2 gather per hub term and sweep). */
 int gm_pr_plan_info(const gm_pr *pr, uint64_t *info, uint32_t count);
 
 /* ---------------------------------------------------------------------------------------------
@@ -308,6 +316,10 @@ int gm_wcc_link_rows(const gm_csr *out_rows, const gm_csr *in_rows, uint64_t row
  * memory.  The handle keeps the call's working buffers (~9 bytes per node + 0.3 bytes per edge) for the
  * next call and remembers that its weights passed the >= 0 / not-NaN check; the arrays of a wrapped CSR
  * must not change while the handle lives (the same rule as for PageRank's cached plan).
+ * The SECOND call on a handle with >= 2^20 edges builds a plan (every list once more ordered by weight, and the lists
+ * transposed: 16 bytes per edge + 4 per node, kept until gm_csr_trim; two radix sorts, ~36 bytes per edge while they
+ * run) — only if the device has that much, and a quarter more, free; otherwise (and after a failed build, until
+ * gm_csr_trim) calls keep running on the CSR's own lists.  One builder per handle; the distances do not depend on it.
  * ------------------------------------------------------------------------------------------- */
 int gm_sssp_delta_stepping(const gm_csr *out_csr, uint64_t start_node, float delta, float *distances_out);
 /* Partitioned run (distances replicated on every GPU as u32 bit patterns of non-negative f32, so an

@@ -61,10 +61,13 @@ TERMS = {
 }
 
 
-@pytest.mark.parametrize("hubs,sources", [(1, 1 << 20), (1, (1 << 20) + 1), (2, 300_000), (5, 1 << 17), (40, 9000), (64, 4500)])
+@pytest.mark.parametrize("hubs,sources", [(1, 1 << 20), (1, (1 << 20) + 1), (2, 300_000), (5, 1 << 17), (40, 9000), (64, 4500),
+                                          (2, 5000), (3, 7001), (4, 4500)])  # (the last three with GM_PB_HUB_THIN=4: groups of few rows, row by row through the long-row kernel)
 @pytest.mark.parametrize("kind", list(TERMS))
 def test_one_sweep_of_adversarial_term_sequences_matches_the_sequential_sum(P, monkeypatch, hubs, sources, kind):
     monkeypatch.setenv("GM_PB_NOCACHE", "1")
+    if hubs <= 4 and sources < 8192:
+        monkeypatch.setenv("GM_PB_HUB_THIN", "4")
     rng = np.random.default_rng(hubs * 1000003 + sources)
     n, s, d = _star(hubs, sources)
     x0 = np.full(n, np.inf, np.float32)  # hubs have no out-edges: never gathered
@@ -76,6 +79,48 @@ def test_one_sweep_of_adversarial_term_sequences_matches_the_sequential_sum(P, m
     # the hub rows: the reference's left-to-right f32 sum of the same terms, bit for bit (rounds 2-3: an emulation within
     # 3e-6, 6.4e-6 with one giant term last)
     assert np.array_equal(got[:hubs], seq[:hubs]), np.abs(got[:hubs].astype(np.float64) - seq[:hubs]).max()
+
+
+def test_item_boundary_sums_that_hop_over_a_power_of_two_between_sweeps(P, monkeypatch):
+    """A long row is summed by several workgroups, each forming the pairs of its passes AHEAD on the binade the sums at the
+    pass boundaries had in the sweep before (pb_hublong_kernel).  Two input vectors are swept in turn whose boundary sums lie
+    on either side of a power of two — every prediction is wrong in every sweep, and the neighbouring items overwrite the
+    boundary sums this item predicts from while it runs: whatever a workgroup reads, the row's sum must be the sequential one,
+    sweep after sweep (the first version let every thread read the boundary sums for itself; threads that saw different
+    exponents disagreed about the barriers they would meet)."""
+    import torch
+    from graph_amd.engine import PageRankEngine
+    from oracle import oracle as O
+
+    monkeypatch.setenv("GM_PB_NOCACHE", "1")
+    monkeypatch.setenv("GM_PB_LONG_PASSES", "2")
+    hubs, sources = 64, 1 << 19  # 64 rows of 32 items of 16384 terms: 2048 workgroups, most of which start while others finish
+    n, s, d = _star(hubs, sources)
+    inc = P.DeviceCsr.from_edges(n, s, d, None, P.Direction.Incoming, P.CsrLayout.Sorted)
+    ioff, itgt, _ = inc.host()
+    od = np.bincount(s, minlength=n).astype(np.uint32)
+    eng = PageRankEngine(inc.handle, n, 0, torch.from_numpy(od.astype(np.int32)).cuda(), 0.85, engine=PageRankEngine.PB)
+    assert eng.plan_info()["long_rows"] == hubs
+    scores0 = np.full(n, np.float32(1.0) / np.float32(n), np.float32)
+    xs, want = [], []
+    for c in (0.97, 1.03):  # 16384 terms of c * 2^-40: the first item ends just below / just above 2^-26, the second 2^-25, ...
+        x0 = np.full(n, np.inf, np.float32)
+        x0[hubs:] = np.float32(c) * np.float32(2.0 ** -40)
+        seq = scores0.copy()
+        O.page_rank_jacobi_sweep(ioff, itgt, od, 0.85, seq, np.where(np.isfinite(x0), x0, np.float32(0)))
+        xs.append(torch.from_numpy(x0).cuda())
+        want.append(seq[:hubs].copy())
+    assert not np.array_equal(want[0], want[1])
+    scores = torch.from_numpy(scores0.copy()).cuda()
+    x_out = torch.empty_like(xs[0])
+    err = torch.zeros(1, dtype=torch.float64, device="cuda")
+    for k in range(60):
+        eng.sweep(xs[k % 2], x_out, scores, err)
+        got = scores[:hubs].cpu().numpy()
+        assert np.array_equal(got, want[k % 2]), (k, got, want[k % 2])
+    for k in range(20):  # ... and with predictions that hold (the same vector again and again: the pairs formed ahead are used)
+        eng.sweep(xs[0], x_out, scores, err)
+        assert np.array_equal(scores[:hubs].cpu().numpy(), want[0]), k
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5])

@@ -186,6 +186,29 @@ def test_rank_local_rows_are_the_rows_of_the_whole_graph(P, world):
         assert np.array_equal(ltgt, tgt[int(off[lo]):int(off[hi])])
 
 
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]])
+def test_unsorted_layout_partitioned_gives_the_single_engines_bits_and_the_references_order(P, oracle, devices, monkeypatch):
+    """CsrLayout::Unsorted through gm_page_rank_multi: every rank's slice keeps the arrival order of its rows' lists, notices
+    that its hub rows are not ascending and sums them in CSR order (pb_hublong_kernel<true>) — the single-GPU engine's bits,
+    and within 1e-5 of the oracle run on the same arrays (page_rank.rs:143-146)."""
+    monkeypatch.setenv("GM_MULTI_ENGINE", "pb")
+    scale, n = 17, 1 << 17
+    s, d = oracle.rmat_edges(scale, seed=5)
+    g = P.DirectedCsrGraph(P.DeviceCsr.from_edges(n, s, d, None, P.Direction.Outgoing, P.CsrLayout.Unsorted),
+                           P.DeviceCsr.from_edges(n, s, d, None, P.Direction.Incoming, P.CsrLayout.Unsorted), P.CsrLayout.Unsorted)
+    ioff, itgt, _ = g.csr_inc.host()
+    deg = np.diff(ioff.astype(np.int64))
+    assert int((deg >= 4096).sum()) >= 10
+    cfg = P.PageRankConfig(200, 1e-10, 0.85)
+    one, it1, _ = P.page_rank(g, cfg, P.PageRankMode.JacobiPB)
+    got, it, _ = P.page_rank_multi(g, cfg, devices=devices)
+    assert it == it1 and np.array_equal(got, one)
+    ref, _, _ = oracle.page_rank_chunked(ioff, itgt, g.csr_out.degrees().astype(np.uint32), 200, 1e-10, 0.85)
+    rel = np.abs(got.astype(np.float64) - ref) / ref
+    print(f"Unsorted, {len(devices)} virtual ranks: max rel {rel.max():.2e}, hub rows {rel[deg >= 4096].max():.2e}")
+    assert rel.max() <= 1e-5 and rel[deg >= 4096].max() <= 2e-6
+
+
 def test_pieces_with_targets_beyond_n_are_refused(P):
     """gm_page_rank_multi_slices indexes an n-sized node map with the pieces' targets: a piece that names a node >= n
     (built over another graph, or with local ids) is GM_ERR_RANGE, not a memory fault."""
