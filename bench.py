@@ -562,6 +562,7 @@ def main():
                     "cpu_baseline": rec[k].get("cpu_baseline"),
                     **({"triangles": rec[k]["triangles"]} if k == "tc" else {}),
                     **({"relaxed_edges": rec[k]["relaxed_edges"], "first_call_ms": round(rec[k]["first_call_ms"], 3),
+                        "ms_result_left_on_device": round(rec[k]["ms_result_left_on_device"], 3) if rec[k].get("ms_result_left_on_device") else None,
                         "second_call_ms_builds_the_ordered_lists": round(rec[k]["second_call_ms_builds_the_ordered_lists"], 3)}
                        if k == "sssp" else {})}
                 for k in ("wcc", "sssp", "tc") if k in rec}

@@ -475,10 +475,17 @@ class DeltaSteppingConfig:
     delta: float
 
 
-def delta_stepping(graph: DirectedCsrGraph, config: DeltaSteppingConfig):
-    """delta_stepping — crates/algos/src/sssp.rs:38-102; returns f32 distances, f32::MAX = unreachable."""
+def delta_stepping(graph: DirectedCsrGraph, config: DeltaSteppingConfig, device_out=None):
+    """delta_stepping — crates/algos/src/sssp.rs:38-102; returns f32 distances, f32::MAX = unreachable.
+    device_out (optional): an object with data_ptr() over f32[n] on the graph's device (e.g. a torch tensor) — the distances
+    are left THERE and it is returned: a caller that goes on working on the GPU spares the n * 4 bytes over PCIe (64 MB =
+    1.2 ms of a 6.5 ms call at RMAT scale 24)."""
     if not 0 <= config.start_node < graph.node_count():
         raise IndexError(f"start_node {config.start_node} out of range")  # sssp.rs:52 panics
+    if device_out is not None:
+        check(lib().gm_sssp_delta_stepping(graph.csr_out.handle, int(config.start_node), float(config.delta),
+                                           C.c_void_p(int(device_out.data_ptr()))))
+        return device_out
     dist = _result_buffer(graph.node_count(), np.float32)
     check(lib().gm_sssp_delta_stepping(graph.csr_out.handle, int(config.start_node), float(config.delta),
                                        _ptr(dist)))

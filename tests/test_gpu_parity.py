@@ -348,6 +348,22 @@ def test_wcc_component_ids_bit_exact(P, oracle, scale8):
 # ------------------------------------------------------------------------------------------------
 # SSSP
 # ------------------------------------------------------------------------------------------------
+def test_sssp_result_left_on_the_device_is_the_host_result(P, oracle):
+    """gm_sssp_delta_stepping takes a device address for the distances as well (no n * 4 bytes over PCIe): the same bits"""
+    import torch
+
+    s, d = oracle.rmat_edges(14, seed=9)
+    n = 1 << 14
+    w = oracle.rmat_weights(s.size, seed=44) if hasattr(oracle, "rmat_weights") else np.random.default_rng(44).random(s.size, dtype=np.float32)
+    out = P.DeviceCsr.from_edges(n, s, d, w, P.Direction.Outgoing, P.CsrLayout.Sorted)
+    g = P.DirectedCsrGraph(out, out, P.CsrLayout.Sorted)
+    start = int(np.flatnonzero(np.bincount(s, minlength=n))[0])
+    host = P.delta_stepping(g, P.DeltaSteppingConfig(start, 0.1))
+    dev = torch.empty(n, dtype=torch.float32, device="cuda")
+    back = P.delta_stepping(g, P.DeltaSteppingConfig(start, 0.1), device_out=dev)
+    assert back is dev and np.array_equal(dev.cpu().numpy().view(np.uint32), host.view(np.uint32))
+
+
 def test_sssp_golden(P):
     # crates/algos/src/sssp.rs:282-313
     g = (P.GraphBuilder().csr_layout(P.CsrLayout.Deduplicated)
