@@ -78,10 +78,14 @@ def parse_args():
                     help="overlapped exchange: 1 = propagate every region as it lands, 0 = one propagation launch per sweep "
                          "(only the accumulate is cut; measured no cheaper: P = 8 kernels 0.41 -> 0.48 / 0.46-0.49 ms), -1 = 1")
     ap.add_argument("--piece-streams", type=int, default=-1,
-                    help="overlapped exchange: 1 = one HIP stream per part (the pieces of a phase overlap each other's tails: "
-                         "cutting the sweep in two costs +0.04 ms of kernels at P = 8 instead of +0.11; at P = 2 the long "
-                         "kernels only get in each other's way: 1.31 / 1.38 / 1.57 ms for one launch / pieces / pieces on "
-                         "streams), 0 = one stream, -1 = automatic: from 4 ranks up")
+                    help="overlapped exchange: 0 = every part on the caller's stream, in order (the default, -1, at every N: the "
+                         "schedule whose results 8 gloo ranks on one GPU reproduce bit for bit — 10 runs of 10 at scale 22, 2 of 2 "
+                         "at scale 26); 1 = one HIP stream per part (the pieces of a phase overlap each other's tails: an emulated "
+                         "rank of 8 takes 0.53-0.59 ms instead of 0.62-0.66).  Round 5: with 1, 8 processes on one GPU differed "
+                         "from the single engine in 8 runs of 12 (a part's kernels overtaken by a consumer on another stream "
+                         "although an event orders them), and still in 1 of 14 with GPU_MAX_HW_QUEUES=16 (the runtime maps a "
+                         "process's HIP streams onto 4 hardware queues by default; this schedule uses 8) — which this option sets "
+                         "when the variable is not set; cause not understood (profiles/r05_multi_rank_streams.txt)")
     ap.add_argument("--emulate-parts", type=int, default=0, help="debug (1 process): time only the row slice that "
                     "rank --emulate-rank of an N-way partition would own, without the exchange")
     ap.add_argument("--emulate-rank", type=int, default=0)
@@ -139,6 +143,8 @@ def _placement(plan, engine, scale):
 
 def main():
     args = parse_args()
+    if args.piece_streams == 1:  # before the HIP runtime is loaded (import torch below): one hardware queue per stream of the schedule
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.emulate_parts:
         raise SystemExit(self_launch(args))
     if args.launch_check:
@@ -204,7 +210,7 @@ def main():
     if args.bin_pieces < 0:
         args.bin_pieces = 1
     if args.piece_streams < 0:
-        args.piece_streams = 1 if world >= 4 else 0
+        args.piece_streams = 0  # (until round 5: from 4 ranks up; see --piece-streams)
     sparse = world > 1 and args.exchange == "sparse" and not emu
     piecewise = world > 1 and args.exchange_parts > 1 and args.engine != "pull" and args.exchange != "sparse"
     ex = None
@@ -466,6 +472,7 @@ def main():
             "partition": "none" if world == 1 else
                          f"1-D vertex ranges (greedy in-degree), {world} ranks, all-gather of {stride * 4} B/rank/sweep "
                          f"(only nodes with out-edges)" + (f" in {args.exchange_parts} regions overlapped with the work"
+                                                            + (", part k on its own stream" if args.piece_streams else ", parts in order on one stream")
                                                             if piecewise else "") if not sparse else
                          f"1-D vertex ranges (greedy in-degree), {world} ranks, sparse pairwise exchange: this rank receives "
                          f"{stride * 4} B/sweep (the out_scores its rows read)",

@@ -251,7 +251,13 @@ class PiecewiseExchange:
         # of a many-rank run are not cut in four
         self.split_bin = split_bin
         # streams=True: part k runs on its own HIP stream (events order them), so that the pieces of one phase
-        # overlap each other's tails instead of running back to back — what cutting a short kernel in two costs
+        # overlap each other's tails instead of running back to back — what cutting a short kernel in two costs.
+        # NOT the default since round 5: with 8 ranks as 8 processes on one GPU (gloo) this schedule differed from the single
+        # engine in 8 runs of 12 — rows of one rank one sweep behind, or hub rows not yet written when the consumer on the
+        # other stream ran — and still in 1 of 14 with GPU_MAX_HW_QUEUES=16 (the HIP runtime maps a process's streams onto 4
+        # hardware queues by default; this schedule uses 8 with the collective's).  The in-order schedule: 0 of 10, and
+        # bench.py --gpus 8 at scale 26 equal to one rank to the last digit (profiles/r05_multi_rank_streams.txt,
+        # tools/debug_multi_gloo.py).  Cause not understood; in one process (virtual ranks) it has never been seen.
         self.streams = None
         self.engine, self.layout, self.rank, self.group = engine, layout, rank, group
         world = len(layout["row_splits"])

@@ -251,3 +251,29 @@ def test_real_collectives_on_two_gpus(P, oracle):
     one, _, err1 = P.page_rank(g, cfg, P.PageRankMode.JacobiPB)
     two, it, err = P.page_rank_multi(g, cfg, devices=[0, 1])
     assert it == 9 and np.array_equal(two, one)
+
+
+def test_one_process_per_rank_over_gloo_on_one_gpu_gives_the_single_engines_bits():
+    """Front (b) as the driver launches it — torch.distributed.run, one process per rank, bench.py's partition-local
+    construction and PiecewiseExchange with the in-order schedule — with the 8 ranks on ONE GPU and gloo standing in for RCCL
+    (tools/debug_multi_gloo.py): after every sweep the summed error, after the last one every row's score, equal to the single
+    engine's on the whole graph.  (The stream-per-part schedule fails this in most runs: DESIGN.md §6.)  A launch that does
+    not come up (port taken, no room for 8 processes) skips; only a run that reports differences fails."""
+    import json, os, random, subprocess, sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+           "--master-port", str(29500 + random.randrange(400)), os.path.join(root, "tools", "debug_multi_gloo.py"),
+           "--scale", "22", "--sweeps", "12", "--streams", "0"]
+    try:
+        out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=240)
+    except subprocess.TimeoutExpired:
+        pytest.skip("8 gloo processes did not finish in 240 s")
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    if out.returncode != 0 or not lines:
+        pytest.skip(f"launch failed (rc {out.returncode}): {out.stderr[-300:]}")
+    rec = json.loads(lines[-1])
+    assert rec["world"] == 8 and rec["streams"] == 0 and rec["sweeps"] == 12
+    assert rec["rows_that_differ"] == 0 and rec["first_sweep_whose_error_differs"] is None, rec
