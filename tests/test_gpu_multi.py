@@ -259,7 +259,7 @@ def test_one_process_per_rank_over_gloo_on_one_gpu_gives_the_single_engines_bits
     (tools/debug_multi_gloo.py): after every sweep the summed error, after the last one every row's score, equal to the single
     engine's on the whole graph.  (The stream-per-part schedule fails this in most runs: DESIGN.md §6.)  A launch that does
     not come up (port taken, no room for 8 processes) skips; only a run that reports differences fails."""
-    import json, os, random, subprocess, sys
+    import json, os, random, signal, subprocess, sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, OMP_NUM_THREADS="1")
@@ -267,13 +267,16 @@ def test_one_process_per_rank_over_gloo_on_one_gpu_gives_the_single_engines_bits
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
            "--master-port", str(29500 + random.randrange(400)), os.path.join(root, "tools", "debug_multi_gloo.py"),
            "--scale", "22", "--sweeps", "12", "--streams", "0"]
+    proc = subprocess.Popen(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
     try:
-        out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=240)
+        stdout, stderr = proc.communicate(timeout=240)
     except subprocess.TimeoutExpired:
+        os.killpg(proc.pid, signal.SIGKILL)  # the launcher and its 8 workers: the session this test started, nothing else
+        proc.communicate()
         pytest.skip("8 gloo processes did not finish in 240 s")
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    if out.returncode != 0 or not lines:
-        pytest.skip(f"launch failed (rc {out.returncode}): {out.stderr[-300:]}")
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    if proc.returncode != 0 or not lines:
+        pytest.skip(f"launch failed (rc {proc.returncode}): {stderr[-300:]}")
     rec = json.loads(lines[-1])
     assert rec["world"] == 8 and rec["streams"] == 0 and rec["sweeps"] == 12
     assert rec["rows_that_differ"] == 0 and rec["first_sweep_whose_error_differs"] is None, rec
