@@ -50,6 +50,47 @@ def _from_array(arr, layout, kind):
     return _builder(layout).edges(a.astype(np.uint64)).build(kind)
 
 
+def _timed(prev_micros, fn):
+    """crates/mate/src/graphs/mod.rs:400-432 (`time` / `timed`): the call's result and its wall time in microseconds added to
+    what the graph has cost so far"""
+    t = time.perf_counter()
+    out = fn()
+    return out, int(prev_micros) + int((time.perf_counter() - t) * 1e6)
+
+
+def _duration_debug(micros: int) -> str:
+    """`{:?}` of core::time::Duration::from_micros(micros), the way the reference's __repr__ prints `load_took`
+    (crates/mate/src/graphs/mod.rs:374-383): the largest unit that leaves an integer part, fraction without trailing zeros"""
+    nanos_total = int(micros) * 1000
+    secs, nanos = divmod(nanos_total, 1_000_000_000)
+
+    def dec(integer, frac, width, unit):
+        digits = f"{frac:0{width}d}".rstrip("0")
+        return f"{integer}.{digits}{unit}" if digits else f"{integer}{unit}"
+
+    if secs > 0:
+        return dec(secs, nanos, 9, "s")
+    if nanos >= 1_000_000:
+        return dec(nanos // 1_000_000, nanos % 1_000_000, 6, "ms")
+    if nanos >= 1_000:
+        return dec(nanos // 1_000, nanos % 1_000, 3, "\u00b5s")
+    return f"{nanos}ns"
+
+
+class _GraphRepr:
+    """what DiGraph and Graph share: `load_micros` (#[pyo3(get)], digraph.rs:20-22 / graph.rs:17-19) and the Debug form of
+    PyGraph as __repr__ (mod.rs:279-281, 374-383)"""
+    _load_micros = 0
+
+    @property
+    def load_micros(self) -> int:
+        return self._load_micros
+
+    def __repr__(self):
+        return (f"Graph {{ node_count: {self.node_count()}, edge_count: {self.edge_count()}, "
+                f"load_took: {_duration_debug(self._load_micros)} }}")
+
+
 class _Timed:
     def __init__(self, micros):
         self._micros = max(int(micros), 1)
@@ -106,23 +147,24 @@ class TriangleCountResult(_Timed):
         return f"TriangleCountResult(triangles={self._triangles}, micros={self.micros})"
 
 
-class DiGraph:
+class DiGraph(_GraphRepr):
     """A directed graph using 32 bits for node ids (graph_mate.pyi:46-117)."""
 
-    def __init__(self, inner: P.DirectedCsrGraph):
+    def __init__(self, inner: P.DirectedCsrGraph, load_micros: int = 0):
         self._g = inner
+        self._load_micros = int(load_micros)
 
     @staticmethod
     def load(path, layout: Layout = Layout.Unsorted, file_format=FileFormat.Graph500) -> "DiGraph":
-        return DiGraph(_from_file(path, layout, file_format, P.DirectedCsrGraph))
+        return DiGraph(*_timed(0, lambda: _from_file(path, layout, file_format, P.DirectedCsrGraph)))
 
     @staticmethod
     def from_numpy(np_array, layout: Layout = Layout.Unsorted) -> "DiGraph":
-        return DiGraph(_from_array(np_array, layout, P.DirectedCsrGraph))
+        return DiGraph(*_timed(0, lambda: _from_array(np_array, layout, P.DirectedCsrGraph)))
 
     @staticmethod
     def from_pandas(df, layout: Layout = Layout.Unsorted) -> "DiGraph":
-        return DiGraph(_from_array(df.iloc[:, :2].to_numpy(), layout, P.DirectedCsrGraph))
+        return DiGraph(*_timed(0, lambda: _from_array(df.iloc[:, :2].to_numpy(), layout, P.DirectedCsrGraph)))
 
     def node_count(self) -> int:
         return self._g.node_count()
@@ -149,7 +191,8 @@ class DiGraph:
         return self._g.in_neighbors(node).tolist()
 
     def to_undirected(self, layout: Layout = None) -> "Graph":
-        return Graph(self._g.to_undirected(None if layout is None else _LAYOUT[layout]))
+        # (mod.rs:248: the new graph's load_micros = this graph's + the conversion)
+        return Graph(*_timed(self._load_micros, lambda: self._g.to_undirected(None if layout is None else _LAYOUT[layout])))
 
     def page_rank(self, *, max_iterations: int = 20, tolerance: float = 1e-4,
                   damping_factor: float = 0.85) -> PageRankResult:
@@ -163,23 +206,24 @@ class DiGraph:
         return WccResult(comp, (time.perf_counter() - t) * 1e6)
 
 
-class Graph:
+class Graph(_GraphRepr):
     """An undirected graph using 32 bits for node ids (graph_mate.pyi:119-171)."""
 
-    def __init__(self, inner: P.UndirectedCsrGraph):
+    def __init__(self, inner: P.UndirectedCsrGraph, load_micros: int = 0):
         self._g = inner
+        self._load_micros = int(load_micros)
 
     @staticmethod
     def load(path, layout: Layout = Layout.Unsorted, file_format=FileFormat.Graph500) -> "Graph":
-        return Graph(_from_file(path, layout, file_format, P.UndirectedCsrGraph))
+        return Graph(*_timed(0, lambda: _from_file(path, layout, file_format, P.UndirectedCsrGraph)))
 
     @staticmethod
     def from_numpy(np_array, layout: Layout = Layout.Unsorted) -> "Graph":
-        return Graph(_from_array(np_array, layout, P.UndirectedCsrGraph))
+        return Graph(*_timed(0, lambda: _from_array(np_array, layout, P.UndirectedCsrGraph)))
 
     @staticmethod
     def from_pandas(df, layout: Layout = Layout.Unsorted) -> "Graph":
-        return Graph(_from_array(df.iloc[:, :2].to_numpy(), layout, P.UndirectedCsrGraph))
+        return Graph(*_timed(0, lambda: _from_array(df.iloc[:, :2].to_numpy(), layout, P.UndirectedCsrGraph)))
 
     def node_count(self) -> int:
         return self._g.node_count()
@@ -197,7 +241,8 @@ class Graph:
         return self._g.neighbors(node).tolist()
 
     def make_degree_ordered(self):
-        self._g.make_degree_ordered()
+        # (mod.rs:275: the relabelling is added to load_micros)
+        _, self._load_micros = _timed(self._load_micros, self._g.make_degree_ordered)
 
     def global_triangle_count(self) -> TriangleCountResult:
         t = time.perf_counter()

@@ -85,6 +85,23 @@ def test_to_undirected_layouts(M, digraph, shared_undirected):
     assert [small.to_undirected(M.Layout.Deduplicated).copy_neighbors(n) for n in range(4)] == [[1, 2, 3], [0, 2], [0, 1], [0]]
 
 
+# ---- load_micros and __repr__ (crates/mate/src/graphs/digraph.rs:20-22, graph.rs:17-19, mod.rs:248,275,279-281,374-383)
+def test_load_micros_accumulate_and_repr_is_the_debug_form(M, golden_dir):
+    import re
+
+    d = M.DiGraph.load(os.path.join(golden_dir, "scale_8.graph500"), layout=M.Layout.Sorted)
+    assert isinstance(d.load_micros, int) and d.load_micros > 0
+    u = d.to_undirected()
+    assert u.load_micros >= d.load_micros  # the conversion is added to what the source graph cost
+    before = u.load_micros
+    u.make_degree_ordered()
+    assert u.load_micros >= before
+    form = r"^Graph \{ node_count: 256, edge_count: 4096, load_took: \d+(\.\d+)?(ns|\u00b5s|ms|s) \}$"
+    assert re.match(form, repr(d)) and re.match(form, repr(u)), (repr(d), repr(u))
+    with pytest.raises(AttributeError):
+        d.load_micros = 1  # #[pyo3(get)] only
+
+
 # ---- PageRank (page_rank_test.py:6-38)
 def test_page_rank_results_and_config(digraph):
     pr = digraph.page_rank()
