@@ -17,32 +17,15 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from .graph_ops import degree_partition_of_offsets
+
 
 def greedy_degree_partition(offsets: np.ndarray, concurrency: int):
     """in_degree_partition + greedy_node_map_partition (graph_ops.rs:431-439, 479-509): walk nodes
     in order, close a range once its degree sum reaches ceil(edge_count / concurrency) while fewer
-    than concurrency-1 ranges exist; the last range ends at node_count.  Returns [(start, end)]."""
-    n = offsets.size - 1
-    if n == 0:
-        return []
-    total = int(offsets[n])
-    batch = -(-total // concurrency) if total else 0
-    ranges, start = [], 0
-    off64 = offsets.astype(np.int64)
-    while start < n:
-        if len(ranges) < concurrency - 1:
-            # first node u >= start with offsets[u+1] - offsets[start] >= batch
-            u = int(np.searchsorted(off64, off64[start] + batch, side="left")) - 1
-            u = max(u, start)
-            if u >= n - 1:
-                ranges.append((start, n))
-                break
-            ranges.append((start, u + 1))
-            start = u + 1
-        else:
-            ranges.append((start, n))
-            break
-    return ranges
+    than concurrency-1 ranges exist; the last range ends at node_count.  Returns [(start, end)].
+    (graph_amd/graph_ops.py holds the walk; the graph classes expose it under the reference's names.)"""
+    return degree_partition_of_offsets(offsets, concurrency)
 
 
 def pad_bounds(ranges, world_size: int, n: int):

@@ -26,6 +26,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import check, lib, vp, u64, f64
+from .graph_ops import degree_partition_of_offsets
 
 
 class CsrLayout(enum.IntEnum):
@@ -209,6 +210,15 @@ class DirectedCsrGraph(_GraphBase):
         off, tgt, w = self.csr_inc.host()
         return list(zip(tgt[off[u]:off[u + 1]].tolist(), w[off[u]:off[u + 1]].tolist()))
 
+    def out_degree_partition(self, concurrency: int):
+        """OutDegreePartitionOp (graph_ops.rs:29-38, 368-403): at most `concurrency` ranges of roughly equal total out-degree;
+        a list of `range` (the reference's Vec<Range<NI>>)"""
+        return [range(a, b) for a, b in degree_partition_of_offsets(self.csr_out.host()[0], concurrency, self.edge_count())]
+
+    def in_degree_partition(self, concurrency: int):
+        """InDegreePartitionOp (graph_ops.rs:41-50, 405-440) — the partition the multi-GPU PageRank shards its rows by"""
+        return [range(a, b) for a, b in degree_partition_of_offsets(self.csr_inc.host()[0], concurrency, self.edge_count())]
+
     def to_undirected(self, layout=None):
         """ToUndirectedOp (crates/builder/src/graph_ops.rs:176-230, csr.rs:391-464): an Undirected
         build over this graph's out-edges."""
@@ -238,6 +248,11 @@ class UndirectedCsrGraph(_GraphBase):
         self._check_node(u)
         off, tgt, _ = self.csr.host()
         return tgt[off[u]:off[u + 1]]
+
+    def degree_partition(self, concurrency: int):
+        """DegreePartitionOp (graph_ops.rs:17-26, 331-366): batch = ceil(2 edge_count / concurrency) — every edge counts at
+        both of its ends"""
+        return [range(a, b) for a, b in degree_partition_of_offsets(self.csr.host()[0], concurrency, 2 * self.edge_count())]
 
     def make_degree_ordered(self):
         """RelabelByDegreeOp (graph_ops.rs:240-253, 511-638); swaps the CSR in place and returns
