@@ -75,6 +75,44 @@ template <class T> struct Slice { // what `slice::Iter<NI>` gives the reference'
     const T &operator[](size_t i) const { return ptr[i]; }
 };
 
+// ---- greedy range partitions (crates/builder/src/graph_ops.rs:17-50 the traits, 331-440 their implementations) ----------
+// A node range [first, second): the reference's std::ops::Range<NI>.
+template <class NI> using Range = std::pair<NI, NI>;
+
+// graph_ops.rs:479-509 over node_map(v) = prefix[v + 1] - prefix[v]: one pass over the nodes; a range is closed as soon as its
+// sum reaches batch_size while fewer than max_batches - 1 ranges exist, the last range ends at the last node.
+template <class NI, class Off>
+inline std::vector<Range<NI>> greedy_node_map_partition(const std::vector<Off> &prefix, uint64_t batch_size, size_t max_batches)
+{
+    if (max_batches < 1)
+        throw Error(GM_ERR_INVALID, "greedy_node_map_partition: max_batches must be at least 1");
+    std::vector<Range<NI>> parts;
+    if (prefix.size() < 2)
+        return parts;
+    const size_t n = prefix.size() - 1;
+    uint64_t size = 0;
+    size_t start = 0;
+    for (size_t node = 0; node < n; ++node) {
+        size += (uint64_t)(prefix[node + 1] - prefix[node]);
+        if ((parts.size() < max_batches - 1 && size >= batch_size) || node == n - 1) {
+            parts.emplace_back((NI)start, (NI)(node + 1));
+            size = 0;
+            start = node + 1;
+        }
+    }
+    return parts;
+}
+
+namespace detail {
+// batch = ceil(total / concurrency) (graph_ops.rs:358, 395, 432), then the greedy walk over the CSR's offsets
+template <class NI> inline std::vector<Range<NI>> degree_partition(const std::vector<uint32_t> &offsets, uint64_t total, size_t concurrency)
+{
+    if (concurrency < 1)
+        throw Error(GM_ERR_INVALID, "degree partition: concurrency must be at least 1");
+    return greedy_node_map_partition<NI>(offsets, (total + concurrency - 1) / concurrency, concurrency);
+}
+} // namespace detail
+
 // DirectedCsrGraph = csr_out + csr_inc (crates/builder/src/graph/csr.rs:364-520), resident in HBM.
 template <class NI = uint32_t> class DirectedCsrGraph {
 public:
@@ -86,6 +124,10 @@ public:
     NI in_degree(NI u) const { const auto &h = host_inc(); check_node(u); return (NI)(h.offsets[u + 1] - h.offsets[u]); }
     Slice<uint32_t> out_neighbors(NI u) const { const auto &h = host_out(); check_node(u); return {h.targets.data() + h.offsets[u], h.offsets[u + 1] - h.offsets[u]}; }
     Slice<uint32_t> in_neighbors(NI u) const { const auto &h = host_inc(); check_node(u); return {h.targets.data() + h.offsets[u], h.offsets[u + 1] - h.offsets[u]}; }
+    // OutDegreePartitionOp / InDegreePartitionOp (graph_ops.rs:29-50, 368-440): at most `concurrency` ranges of roughly equal
+    // total out- / in-degree (the in-degree ranges are what the multi-GPU PageRank shards its rows by)
+    std::vector<Range<NI>> out_degree_partition(size_t concurrency) const { return detail::degree_partition<NI>(host_out().offsets, edge_count(), concurrency); }
+    std::vector<Range<NI>> in_degree_partition(size_t concurrency) const { return detail::degree_partition<NI>(host_inc().offsets, edge_count(), concurrency); }
     const gm_csr *csr_out() const { return out_.get(); }
     const gm_csr *csr_inc() const { return inc_.get(); }
     CsrLayout layout() const { return layout_; }
@@ -116,6 +158,8 @@ public:
     NI edge_count() const { return (NI)(gm_csr_edge_count(csr_.get()) / 2); } // csr.rs:687-689
     NI degree(NI u) const { const auto &h = host(); return (NI)(h.offsets[u + 1] - h.offsets[u]); }
     Slice<uint32_t> neighbors(NI u) const { const auto &h = host(); return {h.targets.data() + h.offsets[u], h.offsets[u + 1] - h.offsets[u]}; }
+    // DegreePartitionOp (graph_ops.rs:17-26, 331-366): batch = ceil(2 edge_count / concurrency), every edge counts at both ends
+    std::vector<Range<NI>> degree_partition(size_t concurrency) const { return detail::degree_partition<NI>(host().offsets, 2 * (uint64_t)edge_count(), concurrency); }
     // RelabelByDegreeOp::make_degree_ordered (crates/builder/src/graph_ops.rs:240-253, 511-638)
     void make_degree_ordered()
     {

@@ -77,6 +77,12 @@ def test_cpp_prelude_file_readers_match_python_readers(golden_dir):
                          check=True).stdout.strip().splitlines()
     got = {ln.split()[0]: dict(kv.split("=") for kv in ln.split()[1:]) for ln in out if " " in ln}
     assert out[-1] == "missing-file-throws=1"
+    # the header's greedy_node_map_partition on the reference's own unit tests (crates/builder/src/graph_ops.rs:673-708)
+    assert got["partition_1_part"]["ranges"] == "0-10"
+    assert got["partition_2_parts"]["ranges"] == "0-8,8-10"
+    assert got["partition_6_parts"]["ranges"] == "0-4,4-6,6-7,7-8,8-9,9-10"
+    assert got["partition_max_batches"]["ranges"] == "0-4,4-6,6-10"
+    assert got["partition_empty"]["ranges"] == ""
 
     def fnv(src, dst):
         h = 1469598103934665603
