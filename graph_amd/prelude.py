@@ -160,8 +160,15 @@ class DeviceCsr:
 
 
 class _GraphBase:
+    _node_values = None  # NodeValues<NV> (csr.rs:316-322); None = the reference's NV = ()
+
     def node_count(self):
         return self._n
+
+    def node_value(self, u):
+        """NodeValues::node_value (lib.rs:323-326, csr.rs:475-479, 692-696); a graph built without values has NV = (): None"""
+        self._check_node(u)
+        return None if self._node_values is None else self._node_values[u]
 
     def _check_node(self, u):
         if not 0 <= u < self._n:
@@ -225,7 +232,9 @@ class DirectedCsrGraph(_GraphBase):
         layout = self.layout if layout is None else layout
         h = vp()
         check(lib().gm_csr_to_undirected(self.csr_out.handle, int(layout), C.byref(h)))
-        return UndirectedCsrGraph(DeviceCsr(h), layout)
+        ug = UndirectedCsrGraph(DeviceCsr(h), layout)
+        ug._node_values = None if self._node_values is None else list(self._node_values)  # csr.rs:400
+        return ug
 
 
 class UndirectedCsrGraph(_GraphBase):
@@ -312,6 +321,7 @@ class GraphBuilder:
         self._format = None
         self._path = None
         self._device = 0
+        self._node_values = None
 
     def csr_layout(self, layout):
         self._layout = CsrLayout(layout)
@@ -334,6 +344,14 @@ class GraphBuilder:
         self._edges = (s, d, w)
         return self
 
+    def node_values(self, values):
+        """builder.rs:388-403, 425-440 (after .edges / .edges_with_values): one value per node; their NUMBER is the graph's node
+        count — it may exceed the edge list's largest id + 1 (csr.rs:1221-1261), it must not be smaller (csr.rs:552-563: panic)"""
+        if self._edges is None:
+            raise ValueError("GraphBuilder: node_values() follows edges() / edges_with_values()")  # (a type error in the reference)
+        self._node_values = list(values)
+        return self
+
     def file_format(self, fmt):
         self._format = fmt
         return self
@@ -347,6 +365,10 @@ class GraphBuilder:
         if self._edges is not None:
             src, dst, w = self._edges
             n = int(max(src.max(), dst.max())) + 1 if src.size else 0
+            if self._node_values is not None:
+                if len(self._node_values) < n:
+                    raise ValueError(f"number of node values ({len(self._node_values)}) does not match node count of edge list ({n})")
+                n = len(self._node_values)
         elif self._format is not None and self._path is not None:
             src, dst, w, n = self._format.read(self._path)
         else:
@@ -357,10 +379,14 @@ class GraphBuilder:
         if kind is DirectedCsrGraph:
             out = DeviceCsr.from_edges(n, src, dst, w, Direction.Outgoing, self._layout, self._device)
             inc = DeviceCsr.from_edges(n, src, dst, w, Direction.Incoming, self._layout, self._device)
-            return DirectedCsrGraph(out, inc, self._layout)
+            g = DirectedCsrGraph(out, inc, self._layout)
+            g._node_values = self._node_values
+            return g
         if kind is UndirectedCsrGraph:
             csr = DeviceCsr.from_edges(n, src, dst, w, Direction.Undirected, self._layout, self._device)
-            return UndirectedCsrGraph(csr, self._layout)
+            g = UndirectedCsrGraph(csr, self._layout)
+            g._node_values = self._node_values
+            return g
         raise TypeError(f"unknown graph kind {kind!r}")
 
 

@@ -90,3 +90,36 @@ def test_random_degree_sequences_against_the_oracle_and_the_loop(seed, oracle):
 def test_empty_graph_has_no_ranges():
     assert degree_partition_of_offsets(np.zeros(1, np.uint32), 4) == []
     assert greedy_node_map_partition(np.zeros(1, np.uint32), 3, 2) == []
+
+
+def test_node_values_set_the_node_count(monkeypatch):
+    """csr.rs:1221-1261 (directed_ / undirected_from_node_values_exceeding_edge_list_max_id) at the builder: the values' number is
+    the node count handed to the device build; fewer values than the edge list needs is the reference's panic (csr.rs:556-562).
+    The device build is replaced by the stand-in CSR: what is checked here is the host logic in front of it."""
+    from graph_amd import prelude as P
+
+    seen = []
+
+    def from_edges(cls, n, src, dst, weights, direction, layout, device=0):
+        seen.append((n, int(direction)))
+        if int(direction) == int(P.Direction.Incoming):
+            return _Csr(n, dst, src)
+        if int(direction) == int(P.Direction.Undirected):
+            return _Csr(n, np.concatenate([src, dst]), np.concatenate([dst, src]))
+        return _Csr(n, src, dst)
+
+    monkeypatch.setattr(P.DeviceCsr, "from_edges", classmethod(from_edges))
+    g = P.GraphBuilder().edges([(0, 1), (1, 2)]).node_values([0, 1, 2, 3]).build(P.DirectedCsrGraph)
+    assert g.node_count() == 4 and [n for n, _ in seen] == [4, 4]
+    assert [g.node_value(v) for v in range(4)] == [0, 1, 2, 3]
+    assert [g.out_degree(v) for v in range(4)] == [1, 1, 0, 0]
+    u = P.GraphBuilder().edges([(0, 1), (1, 2)]).node_values(["a", "b", "c", "d"]).build(P.UndirectedCsrGraph)
+    assert u.node_count() == 4 and [u.degree(v) for v in range(4)] == [1, 2, 1, 0] and u.node_value(3) == "d"
+    with pytest.raises(ValueError, match=r"number of node values \(2\) does not match node count of edge list \(3\)"):
+        P.GraphBuilder().edges([(0, 1), (1, 2)]).node_values([0, 1]).build(P.DirectedCsrGraph)
+    with pytest.raises(ValueError):
+        P.GraphBuilder().node_values([1])
+    plain = P.GraphBuilder().edges([(0, 1)]).build(P.DirectedCsrGraph)
+    assert plain.node_count() == 2 and plain.node_value(1) is None
+    with pytest.raises(IndexError):
+        plain.node_value(2)
