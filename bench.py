@@ -77,15 +77,6 @@ def parse_args():
     ap.add_argument("--bin-pieces", type=int, default=-1,
                     help="overlapped exchange: 1 = propagate every region as it lands, 0 = one propagation launch per sweep "
                          "(only the accumulate is cut; measured no cheaper: P = 8 kernels 0.41 -> 0.48 / 0.46-0.49 ms), -1 = 1")
-    ap.add_argument("--piece-streams", type=int, default=-1,
-                    help="overlapped exchange: 0 = every part on the caller's stream, in order (the default, -1, at every N: the "
-                         "schedule whose results 8 gloo ranks on one GPU reproduce bit for bit — 10 runs of 10 at scale 22, 2 of 2 "
-                         "at scale 26); 1 = one HIP stream per part (the pieces of a phase overlap each other's tails: an emulated "
-                         "rank of 8 takes 0.53-0.59 ms instead of 0.62-0.66).  Round 5: with 1, 8 processes on one GPU differed "
-                         "from the single engine in 8 runs of 12 (a part's kernels overtaken by a consumer on another stream "
-                         "although an event orders them), and still in 1 of 14 with GPU_MAX_HW_QUEUES=16 (the runtime maps a "
-                         "process's HIP streams onto 4 hardware queues by default; this schedule uses 8) — which this option sets "
-                         "when the variable is not set; cause not understood (profiles/r05_multi_rank_streams.txt)")
     ap.add_argument("--emulate-parts", type=int, default=0, help="debug (1 process): time only the row slice that "
                     "rank --emulate-rank of an N-way partition would own, without the exchange")
     ap.add_argument("--emulate-rank", type=int, default=0)
@@ -143,8 +134,6 @@ def _placement(plan, engine, scale):
 
 def main():
     args = parse_args()
-    if args.piece_streams == 1:  # before the HIP runtime is loaded (import torch below): one hardware queue per stream of the schedule
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.emulate_parts:
         raise SystemExit(self_launch(args))
     if args.launch_check:
@@ -209,8 +198,6 @@ def main():
         args.exchange_parts = 2
     if args.bin_pieces < 0:
         args.bin_pieces = 1
-    if args.piece_streams < 0:
-        args.piece_streams = 0  # (until round 5: from 4 ranks up; see --piece-streams)
     sparse = world > 1 and args.exchange == "sparse" and not emu
     piecewise = world > 1 and args.exchange_parts > 1 and args.engine != "pull" and args.exchange != "sparse"
     ex = None
@@ -308,8 +295,7 @@ def main():
         if emu:  # stand-in for the collective: only this rank's slot of the region is refreshed
             def gather(dst_views, src, k):
                 dst_views[rank].copy_(src)
-        ex = PiecewiseExchange(engine, layout, rank, n_local, dev, gather=gather, split_bin=bool(args.bin_pieces),
-                               streams=bool(args.piece_streams))
+        ex = PiecewiseExchange(engine, layout, rank, n_local, dev, gather=gather, split_bin=bool(args.bin_pieces))
         if emu:  # the slots of the ranks that do not exist: a typical out_score instead of zeros (rows that sum to 0 are not
             for buf in ex.x:  # what a sweep of the partitioned job walks)
                 buf.fill_(1.0 / (16.0 * n))
@@ -472,7 +458,7 @@ def main():
             "partition": "none" if world == 1 else
                          f"1-D vertex ranges (greedy in-degree), {world} ranks, all-gather of {stride * 4} B/rank/sweep "
                          f"(only nodes with out-edges)" + (f" in {args.exchange_parts} regions overlapped with the work"
-                                                            + (", part k on its own stream" if args.piece_streams else ", parts in order on one stream")
+                                                            + ", parts in order on one stream"
                                                             if piecewise else "") if not sparse else
                          f"1-D vertex ranges (greedy in-degree), {world} ranks, sparse pairwise exchange: this rank receives "
                          f"{stride * 4} B/sweep (the out_scores its rows read)",
@@ -499,9 +485,6 @@ def main():
             "edges_per_launch": m_local, "rows_per_launch": n_local,
         },
     }
-    if piecewise and args.piece_streams:
-        result["roofline"]["note"] = ("avg_launch_ms spans the rank's whole sweep (its pieces overlap on several streams), "
-                                      "waits for regions of out_scores still in flight included")
 
     # ---- CPU baseline on rank 0 at N = 1 (bounded sample: a few sweeps of the same graph) -----
     if world == 1 and args.cpu_sweeps > 0:

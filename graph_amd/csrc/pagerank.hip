@@ -709,6 +709,7 @@ struct gm::PrCallState {
     gm::DevBuf outdeg, scores, x0, x1, dres;
     gm::PinnedBuf hres;
     gm_pr *engine = nullptr;
+    std::vector<uint64_t> gs_splits; // row blocks of the block-Gauss-Seidel sweeps the parked engine is set up for
     ~PrCallState()
     {
         delete engine;
@@ -724,7 +725,7 @@ static int page_rank_impl(const gm_csr *in_csr, const uint32_t *out_degree, cons
     GM_CHECK(in_csr && iterations_out && error_out, GM_ERR_INVALID, "gm_page_rank: null argument");
     GM_CHECK(!out_csr || (out_csr->n == in_csr->n && out_csr->m == in_csr->m && out_csr->device == in_csr->device),
              GM_ERR_INVALID, "gm_page_rank_directed: the two CSRs are not the out- and in-lists of one graph on one device");
-    GM_CHECK(mode >= GM_PR_AUTO && mode <= GM_PR_JACOBI_REFORDER, GM_ERR_INVALID, "gm_page_rank: unknown mode %d", mode);
+    GM_CHECK(mode >= GM_PR_AUTO && mode <= GM_PR_BLOCK_GS, GM_ERR_INVALID, "gm_page_rank: unknown mode %d", mode);
     // page_rank.rs:105-109: the loop only ends on error < tolerance or iteration == max_iterations
     GM_CHECK(max_iterations != 0 || tolerance > 0.0, GM_ERR_INVALID,
              "gm_page_rank: max_iterations == 0 with tolerance <= 0 never terminates (reference: infinite loop)");
@@ -737,6 +738,7 @@ static int page_rank_impl(const gm_csr *in_csr, const uint32_t *out_degree, cons
         return GM_OK;
     }
     GM_CHECK(scores_out, GM_ERR_INVALID, "gm_page_rank: scores_out is null");
+    const bool auto_mode = mode == GM_PR_AUTO;
     if (mode == GM_PR_AUTO)
         mode = n <= 16384 ? GM_PR_SEQUENTIAL : GM_PR_JACOBI;
 
@@ -815,6 +817,7 @@ static int page_rank_impl(const gm_csr *in_csr, const uint32_t *out_degree, cons
     struct { gm_pr *p; } ph{nullptr};
     int engine = mode == GM_PR_JACOBI_PULL       ? GM_PR_ENGINE_PULL
                  : mode == GM_PR_JACOBI_PB       ? GM_PR_ENGINE_PB
+                 : mode == GM_PR_BLOCK_GS        ? GM_PR_ENGINE_PB
                  : mode == GM_PR_JACOBI_REFORDER ? GM_PR_ENGINE_REFORDER
                                                  : GM_PR_ENGINE_AUTO;
     if (engine == GM_PR_ENGINE_AUTO) {
@@ -838,16 +841,85 @@ static int page_rank_impl(const gm_csr *in_csr, const uint32_t *out_degree, cons
         cs->engine = nullptr;
     }
     if (!cs->engine)
+        cs->gs_splits.clear(); // (a new engine has no row blocks yet)
+    if (!cs->engine)
         GM_TRY(gm_pr_create_with(in_csr, n, 0, n, (uint64_t)outdeg.p, damping_factor, engine, &cs->engine));
     ph.p = cs->engine;
+    // Block-Gauss-Seidel sweeps (GM_PR_BLOCK_GS; what GM_PR_AUTO runs on the propagation-blocking engine unless
+    // GM_PR_BLOCK_GS=0).  The reference updates out_scores IN PLACE while it sweeps the nodes in ascending chunks
+    // (page_rank.rs:142-160): a row sees this sweep's values of the rows before it.  Synchronous sweeps need about twice as
+    // many iterations for the same error, so with PageRankConfig::default() (20 / 1e-4, page_rank.rs:17-56) they run out of
+    // iterations where the reference stops on its tolerance.  Here the rows are cut into K blocks of about equal in-edges
+    // (whole source tiles); per sweep and block j, in order: accumulate and finish the rows of block j (from the value stream
+    // as it stands: this sweep's out_scores of the blocks before j, the last sweep's of the others), then propagate block j's new
+    // out_scores into the value stream.  One vector, updated in place; the hub rows (any block) are summed with block 0,
+    // from the last sweep's values: every row's equation is the one of page_rank.rs:143-159, only WHICH sweep's value a
+    // term carries differs — as it does between two runs of the reference itself.  Deterministic; same fixed point.
+    std::vector<uint64_t> gs_splits;
+    {
+        const char *gs_env_s = getenv("GM_PR_BLOCK_GS");
+        const int gs_env = gs_env_s ? atoi(gs_env_s) : -1;
+        const bool want = ph.p->engine == GM_PR_ENGINE_PB && (mode == GM_PR_BLOCK_GS || (auto_mode && gs_env != 0));
+        uint64_t rows_per_bin = 0, tile = 0;
+        if (want)
+            GM_TRY(gm_pr_part_geometry(ph.p, &rows_per_bin, &tile));
+        const uint64_t tiles = tile ? (n + tile - 1) / tile : 0;
+        uint64_t K = gs_env > 1 ? (uint64_t)gs_env : 8;
+        if (K > 64)
+            K = 64;
+        if (K > tiles)
+            K = tiles;
+        if (want && K >= 2) {
+            if (cs->gs_splits.size() == K + 1 && cs->gs_splits.back() == n) {
+                gs_splits = cs->gs_splits; // the parked engine is set up for these blocks
+            } else {
+                // block j ends at the first tile boundary with at least j / K of the in-edges in front of it
+                gs_splits.assign(K + 1, 0);
+                gs_splits[K] = n;
+                for (uint64_t j = 1; j < K; ++j) {
+                    const uint64_t want_edges = in_csr->m / K * j;
+                    uint64_t lo = gs_splits[j - 1] / tile, hi = tiles; // answer in (lo, hi]
+                    while (hi - lo > 1) {
+                        const uint64_t mid = (lo + hi) / 2;
+                        uint32_t off = 0;
+                        GM_HIP(hipMemcpy(&off, in_csr->offsets + mid * tile, 4, hipMemcpyDeviceToHost));
+                        if (off >= want_edges)
+                            hi = mid;
+                        else
+                            lo = mid;
+                    }
+                    gs_splits[j] = hi * tile < n ? hi * tile : n;
+                }
+                GM_TRY(gm_pr_set_parts(ph.p, gs_splits.data(), K));
+                std::vector<uint64_t> lo(gs_splits.begin(), gs_splits.end() - 1), hi(gs_splits.begin() + 1, gs_splits.end());
+                std::vector<uint32_t> reg(K);
+                for (uint64_t j = 0; j < K; ++j)
+                    reg[j] = (uint32_t)j;
+                GM_TRY(gm_pr_set_bin_regions(ph.p, lo.data(), hi.data(), reg.data(), K, (uint32_t)K));
+                cs->gs_splits = gs_splits;
+            }
+        }
+    }
     GM_TRY(gm_pr_init(ph.p, (uint64_t)scores.p, (uint64_t)x0.p, st));
     uint64_t iter = 0;
     double err = 0.0;
     float *xin = x0.as<float>(), *xout = x1.as<float>();
     const bool can_stop_early = tolerance > 0.0; // error >= 0 always
+    const uint64_t gs_blocks = gs_splits.empty() ? 0 : gs_splits.size() - 1;
+    if (gs_blocks) {
+        xout = xin; // in place
+        GM_TRY(gm_pr_sweep_bin(ph.p, (uint64_t)xin, 0, n, st)); // the initial out_scores of every block (page_rank.rs:70-81)
+    }
     for (;;) {
         gm::PhaseTimer timer(st);
-        GM_TRY(gm_pr_sweep(ph.p, (uint64_t)xin, (uint64_t)xout, (uint64_t)scores.p, (uint64_t)dres.p, st));
+        if (gs_blocks) {
+            for (uint64_t j = 0; j < gs_blocks; ++j) {
+                GM_TRY(gm_pr_sweep_accum(ph.p, (uint64_t)xin, (uint64_t)xin, (uint64_t)scores.p, j, 1, st));
+                GM_TRY(gm_pr_sweep_bin_region(ph.p, (uint64_t)xin, (uint32_t)j, st));
+            }
+            GM_TRY(gm_pr_sweep_fixup(ph.p, (uint64_t)xin, (uint64_t)scores.p, (uint64_t)dres.p, st));
+        } else
+            GM_TRY(gm_pr_sweep(ph.p, (uint64_t)xin, (uint64_t)xout, (uint64_t)scores.p, (uint64_t)dres.p, st));
         if (gm::log_enabled()) { // page_rank.rs:95-100: "Finished iteration {} with an error of {:.6} in {:?}"
             double e = 0.0;
             (void)hipMemcpyAsync(&e, dres.p, 8, hipMemcpyDeviceToHost, st);

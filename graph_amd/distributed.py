@@ -227,21 +227,18 @@ class PiecewiseExchange:
     the propagation of regions < k of the next sweep.  engine: sweep_bin / sweep_accum / sweep_fixup /
     set_parts (graph_amd.engine.PageRankEngine, or a stand-in with the same methods)."""
 
-    def __init__(self, engine, layout, rank: int, n_local: int, device, group=None, gather=None, split_bin=True,
-                 streams=False, x=None):
+    def __init__(self, engine, layout, rank: int, n_local: int, device, group=None, gather=None, split_bin=True, x=None):
         # split_bin=False: one propagation launch after every region has landed (only the accumulate is cut into
         # row groups) — region k still travels under the accumulate of the later groups, and the short kernels
         # of a many-rank run are not cut in four
         self.split_bin = split_bin
-        # streams=True: part k runs on its own HIP stream (events order them), so that the pieces of one phase
-        # overlap each other's tails instead of running back to back — what cutting a short kernel in two costs.
-        # NOT the default since round 5: with 8 ranks as 8 processes on one GPU (gloo) this schedule differed from the single
-        # engine in 8 runs of 12 — rows of one rank one sweep behind, or hub rows not yet written when the consumer on the
-        # other stream ran — and still in 1 of 14 with GPU_MAX_HW_QUEUES=16 (the HIP runtime maps a process's streams onto 4
-        # hardware queues by default; this schedule uses 8 with the collective's).  The in-order schedule: 0 of 10, and
-        # bench.py --gpus 8 at scale 26 equal to one rank to the last digit (profiles/r05_multi_rank_streams.txt,
-        # tools/debug_multi_gloo.py).  Cause not understood; in one process (virtual ranks) it has never been seen.
-        self.streams = None
+        # Every part runs on the caller's stream, in order.  Until round 5 there was a second schedule with part k on a
+        # HIP stream of its own (10-15 % per emulated rank at 4 and 8 ranks); with one PROCESS per rank sharing a GPU over
+        # gloo it computed wrong intermediate sweeps in two runs of three (profiles/r05_multi_rank_streams.txt) — a consumer
+        # overtaking its producer across streams although an event ordered them.  Round 6: the same event graph as a
+        # torch-free HIP program with stamping kernels, 8-16 processes on one GPU, held in 30 runs of 30 x 300 sweeps
+        # (tools/streams_repro.hip, profiles/r06_streams_repro.txt) while this class still failed beside it on the same box:
+        # the fault is not in the HIP event graph itself and was not found; the schedule was REMOVED, not fixed.
         self.engine, self.layout, self.rank, self.group = engine, layout, rank, group
         world = len(layout["row_splits"])
         self.parts = layout["parts"]
@@ -263,9 +260,6 @@ class PiecewiseExchange:
         # group k lands); default RCCL / gloo
         self._gather = gather
         engine.set_parts(layout["row_splits"][rank])
-        if streams and self.parts > 1 and torch.cuda.is_available():
-            self.streams = [None] + [torch.cuda.Stream(device=device) for _ in range(self.parts - 1)]
-            self._ev_acc = None
 
     def _start_gather(self, buf: int, k: int):
         rows = self.send_rows[k]
@@ -293,8 +287,6 @@ class PiecewiseExchange:
     def sweep(self, scores: torch.Tensor, err: torch.Tensor, events=None):
         """events: optional list receiving a (start, end) torch.cuda.Event pair around every kernel piece
         (bench.py: kernel time without the waits for the collectives)"""
-        if self.streams is not None:
-            return self._sweep_streams(scores, err, events)
         e, x_in = self.engine, self.x[self.cur]
 
         def timed(fn, *a):
@@ -316,54 +308,6 @@ class PiecewiseExchange:
         for k in range(self.parts):
             timed(e.sweep_accum, x_in, self.x_loc, scores, k)
             self._start_gather(1 - self.cur, k)
-        e.sweep_fixup(self.x_loc, scores, err)
-        self.cur = 1 - self.cur
-
-    def _sweep_streams(self, scores: torch.Tensor, err: torch.Tensor, events=None):
-        """the same sweep with part k on stream k (stream 0 = the caller's current stream); events receives one
-        (start, end) pair around the whole sweep — with overlapping pieces that span, waits for regions still in
-        flight included, is the only well-defined time"""
-        e, x_in = self.engine, self.x[self.cur]
-        main = torch.cuda.current_stream()
-        strs = [main] + self.streams[1:]
-        start = torch.cuda.Event(enable_timing=events is not None)
-        start.record(main)  # everything the caller enqueued so far (the previous sweep's fixup included)
-        ev_bin = []
-        for k, st in enumerate(strs):
-            with torch.cuda.stream(st):
-                st.wait_event(start)
-                if self._ev_acc is not None:  # the value stream is rewritten: every accumulate of the last sweep is done
-                    for ev in self._ev_acc:
-                        st.wait_event(ev)
-                if self.works[k] is not None:
-                    self.works[k].wait()
-                self._bin_region(x_in, k)
-                ev = torch.cuda.Event()
-                ev.record(st)
-                ev_bin.append(ev)
-        for ev in ev_bin:
-            main.wait_event(ev)
-        e.sweep_hot(x_in)
-        ev_hot = torch.cuda.Event()
-        ev_hot.record(main)
-        ev_acc = []
-        for k, st in enumerate(strs):
-            with torch.cuda.stream(st):
-                for ev in ev_bin:
-                    st.wait_event(ev)
-                st.wait_event(ev_hot)
-                e.sweep_accum(x_in, self.x_loc, scores, k, stage_hot=False)
-                self._start_gather(1 - self.cur, k)
-                ev = torch.cuda.Event()
-                ev.record(st)
-                ev_acc.append(ev)
-        for ev in ev_acc:
-            main.wait_event(ev)
-        self._ev_acc = ev_acc
-        if events is not None:
-            end = torch.cuda.Event(enable_timing=True)
-            end.record(main)
-            events.append((start, end))
         e.sweep_fixup(self.x_loc, scores, err)
         self.cur = 1 - self.cur
 

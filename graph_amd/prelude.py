@@ -412,6 +412,7 @@ class PageRankMode(enum.IntEnum):
     JacobiPull = 3  # force the pull-tile sweep kernels
     JacobiPB = 4    # force the propagation-blocking sweep kernels
     JacobiRefOrder = 5  # synchronous sweeps with the reference's left-to-right f32 row sums (parity instrument)
+    BlockGS = 6     # block-Gauss-Seidel sweeps (the reference's in-place update at block granularity; PB engine)
 
 
 def page_rank(graph: DirectedCsrGraph, config: PageRankConfig | None = None, mode=PageRankMode.Auto):

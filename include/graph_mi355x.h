@@ -144,7 +144,7 @@ int gm_csr_slice_rows_map(const gm_csr *full, uint64_t row_lo, uint64_t row_hi, 
  * per-node out-degrees (host, n; NULL = derive them on the device by counting each id's
  * occurrences in the in-lists, which equals out_degree for a DirectedCsrGraph).
  *
- * mode GM_PR_AUTO   : n <= 16384 -> GM_PR_SEQUENTIAL, else GM_PR_JACOBI
+ * mode GM_PR_AUTO   : n <= 16384 -> GM_PR_SEQUENTIAL, else GM_PR_JACOBI (as GM_PR_BLOCK_GS where the engine is PB)
  *      GM_PR_JACOBI : synchronous sweeps (double-buffered out_scores), deterministic
  *      GM_PR_SEQUENTIAL : the reference's exact in-place ascending-u order on one wavefront;
  *                     bit-exact with the reference wherever the reference itself is
@@ -161,9 +161,15 @@ typedef enum gm_pr_mode {
     GM_PR_SEQUENTIAL = 2,
     GM_PR_JACOBI_PULL = 3, /* synchronous sweeps, force the pull-tile engine */
     GM_PR_JACOBI_PB = 4,   /* synchronous sweeps, force the propagation-blocking engine */
-    GM_PR_JACOBI_REFORDER = 5 /* synchronous sweeps whose row sums are added left to right in f32 in CSR
+    GM_PR_JACOBI_REFORDER = 5, /* synchronous sweeps whose row sums are added left to right in f32 in CSR
                                  order, exactly like page_rank.rs:143-146 (one lane per row: a parity
                                  instrument, not a fast path) */
+    GM_PR_BLOCK_GS = 6 /* block-Gauss-Seidel sweeps on the propagation-blocking engine: K row blocks (GM_PR_BLOCK_GS=K,
+                          default 8) in ascending order, block j sees this sweep's out_scores of the blocks before it —
+                          the reference's in-place update (page_rank.rs:142-160) at block granularity, deterministic.
+                          About half the iterations of the synchronous sweeps for the same error; same fixed point.
+                          GM_PR_AUTO runs these whenever it picks the propagation-blocking engine (GM_PR_BLOCK_GS=0:
+                          synchronous sweeps instead). */
 } gm_pr_mode;
 
 int gm_page_rank(const gm_csr *in_csr, const uint32_t *out_degree, uint64_t max_iterations, double tolerance,
@@ -250,8 +256,8 @@ int gm_pr_sweep_fixup(gm_pr *pr, uint64_t d_x_out_local, uint64_t d_scores_local
  * (gm_pr_part_geometry) and splits its rows at multiples of rows_per_bin; then per sweep:
  * gm_pr_sweep_bin for every region [x_lo, x_hi) of the vector as it arrives; once all of it is there the hot
  * sources are staged (gm_pr_sweep_hot, or stage_hot = 1 on the first accumulate) and gm_pr_sweep_accum runs
- * for every part — on one stream in order, or on several streams ordered by events; gm_pr_sweep_fixup for the
- * error.  Together they do exactly what gm_pr_sweep_tiles does: same kernels, same bits.
+ * for every part, in order on one stream (what both fronts of this library do; parts on streams of their own, ordered by
+ * events, were dropped in round 6: DESIGN.md section 6); gm_pr_sweep_fixup for the error.  Together they do exactly what gm_pr_sweep_tiles does: same kernels, same bits.
  * Hub rows (page_rank.rs:143-146 order) may lie in any part: their kernels are launched with part 0, beside its
  * accumulate kernel on the engine's own side streams, and gm_pr_sweep_accum of EVERY part makes its stream wait for
  * them behind its own accumulate kernel — what the caller enqueues next on that stream (the exchange of the part's

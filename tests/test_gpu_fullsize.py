@@ -66,15 +66,17 @@ def test_scale22_page_rank_engines_agree_and_match_reference_order(env, oracle, 
     print(f"scale 22, reference summation order on every row: {it_ro} sweeps, max rel vs reference {rel_ro.max():.2e}")
 
 
-def test_scale22_default_config_gap_to_the_reference_is_what_integration_md_says(env, oracle, rmat22):
-    """PageRankConfig::default() = (20 iterations, tolerance 1e-4) (page_rank.rs:14-56).  The device sweeps synchronously
-    (Jacobi); the reference updates out_scores in place inside a sweep (page_rank.rs:155-159), converges in fewer iterations
-    and stops on the TOLERANCE where the device stops on the COUNT.  A drop-in caller sees that difference (INTEGRATION.md,
-    "what differs"); this test pins its size so that it cannot drift silently (profiles/r05_default_config_gap_scale22.json:
-    device 20 iterations / error 1.33e-4, reference 14 / 9.6e-5, results 1.4e-3 apart at most, 4.7e-4 in L1)."""
+def test_scale22_default_config_stops_on_the_tolerance_like_the_reference(env, oracle, rmat22):
+    """PageRankConfig::default() = (20 iterations, tolerance 1e-4) (page_rank.rs:14-56).  The reference updates out_scores in
+    place inside a sweep (page_rank.rs:155-159) and stops on the TOLERANCE after 14 iterations; synchronous sweeps need 22 and
+    run out of the 20 (round 5: the two results 1.4e-3 apart, profiles/r05_default_config_gap_scale22.json).  Round 6: the
+    drop-in's default call runs block-Gauss-Seidel sweeps (GM_PR_BLOCK_GS: row blocks in ascending order, a block sees this
+    sweep's values of the blocks before it) and stops on the tolerance as the reference does."""
     P, synth, torch = env
     g, src, dst, n = rmat22
     got, it_g, err_g = P.page_rank(g, P.PageRankConfig())
+    again, it_a, err_a = P.page_rank(g, P.PageRankConfig())
+    assert np.array_equal(got, again) and it_g == it_a and err_g == err_a   # deterministic
     ioff, itgt, _ = g.csr_inc.host()
     od = g.csr_out.degrees().astype(np.uint32)
     ref, it_r, err_r = oracle.page_rank_chunked(ioff, itgt, od, 20, 1e-4, 0.85)
@@ -82,13 +84,23 @@ def test_scale22_default_config_gap_to_the_reference_is_what_integration_md_says
     l1 = float(np.abs(got.astype(np.float64) - ref).sum())
     print(f"default config, scale 22: device {it_g} iterations (error {err_g:.3e}), reference {it_r} (error {err_r:.3e}); "
           f"results max rel {rel.max():.2e}, L1 {l1:.2e}")
-    assert it_g == 20 and 1.0e-4 <= err_g <= 2.0e-4     # the device runs out of iterations just short of the tolerance
-    assert it_r < 20 and err_r < 1.0e-4                 # the reference's in-place sweeps get there first
-    assert rel.max() <= 5e-3 and l1 <= 1.5e-3           # two UNCONVERGED iterates of the same fixed point
-    # given the iterations, the device stops on the tolerance too, a little later, and lands as close
-    got2, it2, err2 = P.page_rank(g, P.PageRankConfig(200, 1e-4, 0.85))
-    rel2 = np.abs(got2.astype(np.float64) - ref) / ref
-    assert 20 < it2 <= 30 and err2 < 1e-4 and rel2.max() <= 3e-3
+    assert it_r < 20 and err_r < 1.0e-4                 # the reference's in-place sweeps stop on the tolerance
+    assert it_g <= 16 and err_g < 1.0e-4                # ... and so does the default call (<= 16)
+    assert rel.max() <= 2e-4, rel.max()                 # two iterates stopped by the same rule, a different schedule each
+    # the explicit mode is the same thing
+    gs, it_gs, err_gs = P.page_rank(g, P.PageRankConfig(), P.PageRankMode.BlockGS)
+    assert np.array_equal(gs, got) and it_gs == it_g and err_gs == err_g
+    # synchronous sweeps (explicit): out of iterations just short of the tolerance, as round 5 measured
+    jac, it_j, err_j = P.page_rank(g, P.PageRankConfig(), P.PageRankMode.JacobiPB)
+    assert it_j == 20 and 1.0e-4 <= err_j <= 2.0e-4
+    # the fixed point is the same one: every row within 1e-5 of the reference's threaded path
+    fix, it_f, _ = P.page_rank(g, P.PageRankConfig(200, 1e-10, 0.85), P.PageRankMode.BlockGS)
+    jfix, it_jf, _ = P.page_rank(g, P.PageRankConfig(200, 1e-10, 0.85), P.PageRankMode.JacobiPB)
+    rfix, it_rf, _ = oracle.page_rank_chunked(ioff, itgt, od, 200, 1e-10, 0.85)
+    relf = np.abs(fix.astype(np.float64) - rfix) / rfix
+    print(f"to 1e-10, scale 22: block-GS {it_f} sweeps, synchronous {it_jf}, reference {it_rf}; block-GS vs reference max rel {relf.max():.2e}")
+    assert relf.max() <= 1e-5, relf.max()
+    assert it_f < it_jf and it_f <= it_rf + 12
 
 
 def test_scale22_wcc_bit_exact(env, oracle, rmat22):
@@ -189,7 +201,7 @@ def _single26(env, rmat26):
     """the single-GPU engine's scores at its fixed point (computed by whichever scale-26 test runs first)"""
     if "single" not in rmat26:
         P, synth, torch = env
-        rmat26["single"], rmat26["single_sweeps"], _ = P.page_rank(rmat26["g"], P.PageRankConfig(200, 1e-10, 0.85))
+        rmat26["single"], rmat26["single_sweeps"], _ = P.page_rank(rmat26["g"], P.PageRankConfig(200, 1e-10, 0.85), P.PageRankMode.JacobiPB)
         rmat26["g"].csr_inc.trim()  # the single engine's plan and parked stream: the partitioned runs bring their own
     return rmat26["single"]
 
@@ -199,13 +211,28 @@ def test_scale26_page_rank_within_1e5_every_row(env, rmat26):
     of the reference's threaded path (orc_page_rank_chunked, page_rank.rs:113-168), both at their fixed points."""
     P, synth, torch = env
     g, ref, deg = rmat26["g"], rmat26["ref"], rmat26["deg"]
-    got = _single26(env, rmat26)  # Auto: propagation blocking, hub rows in reference order
+    got = _single26(env, rmat26)  # propagation blocking, synchronous sweeps (what bench.py times), hub rows in reference order
     it_g = rmat26["single_sweeps"]
     rel = _rel(got, ref)
     over = int((rel > 1e-5).sum())
     print(f"scale 26: device {it_g} sweeps, reference {rmat26['it_ref']} iterations; max rel {rel.max():.2e} on every row, "
           f"{rel[deg >= 4096].max():.2e} on rows with >= 4096 in-edges (max in-degree {int(deg.max())}), {over} rows over 1e-5")
     assert over == 0 and rel.max() <= 1e-5, (rel.max(), over)
+
+
+def test_scale26_block_gauss_seidel_default_call(env, rmat26):
+    """The drop-in's default mode at BASELINE's size: block-Gauss-Seidel sweeps reach 1e-10 in about the reference's number of
+    iterations (53; synchronous sweeps: 100) and end on the same fixed point, every row within 1e-5 (<= 65)."""
+    P, synth, torch = env
+    g, ref = rmat26["g"], rmat26["ref"]
+    got, it_g, err_g = P.page_rank(g, P.PageRankConfig(200, 1e-10, 0.85))   # Auto
+    rel = _rel(got, ref)
+    print(f"scale 26, block-GS (Auto): {it_g} sweeps (reference {rmat26['it_ref']}), error {err_g:.3e}; max rel {rel.max():.2e}, "
+          f"{int((rel > 1e-5).sum())} rows over 1e-5")
+    assert rel.max() <= 1e-5, rel.max()
+    assert it_g <= 65, it_g
+    assert 0.0 < float(got.astype(np.float64).sum()) <= 1.0 + 1e-6
+    g.csr_inc.trim()
 
 
 def test_scale26_partitioned_8_virtual_ranks_within_1e5_every_row(env, rmat26):

@@ -257,7 +257,8 @@ def test_one_process_per_rank_over_gloo_on_one_gpu_gives_the_single_engines_bits
     """Front (b) as the driver launches it — torch.distributed.run, one process per rank, bench.py's partition-local
     construction and PiecewiseExchange with the in-order schedule — with the 8 ranks on ONE GPU and gloo standing in for RCCL
     (tools/debug_multi_gloo.py): after every sweep the summed error, after the last one every row's score, equal to the single
-    engine's on the whole graph.  (The stream-per-part schedule fails this in most runs: DESIGN.md §6.)  A launch that does
+    engine's on the whole graph.  (The stream-per-part schedule of rounds 2-5 failed this in most runs and was removed in
+    round 6: DESIGN.md §6, profiles/r06_streams_repro.txt.)  A launch that does
     not come up (port taken, no room for 8 processes) skips; only a run that reports differences fails."""
     import json, os, random, signal, subprocess, sys
 

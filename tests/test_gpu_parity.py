@@ -906,7 +906,7 @@ def test_page_rank_sweep_in_pieces_matches_whole_sweep(P, oracle, scale):
     for k in range(sweeps):
         eng.sweep(x[k % 2], x[1 - k % 2], sc, err)
         errs.append(float(err.item()))
-    for parts, streams in ((2, False), (3, False), (2, True), (3, True)):
+    for parts in (2, 3):
         lay = split_exchange_layout(od, bounds, parts=parts)
         assert lay["x_len"] % 32768 == 0
         shared = [torch.zeros(lay["x_len"], device=dev) for _ in range(2)]
@@ -924,7 +924,7 @@ def test_page_rank_sweep_in_pieces_matches_whole_sweep(P, oracle, scale):
             def gather(dst_views, src, k, r=r):  # this rank's slot of region k
                 dst_views[r].copy_(src)
 
-            ex = PiecewiseExchange(e, lay, r, hi - lo, dev, gather=gather, streams=streams, x=shared)
+            ex = PiecewiseExchange(e, lay, r, hi - lo, dev, gather=gather, x=shared)
             ranks.append((csr, odl, e, ex, torch.zeros(hi - lo, device=dev), torch.zeros(1, dtype=torch.float64, device=dev)))
         for (_, _, _, ex, scl, _) in ranks:
             ex.start(scl)
@@ -933,8 +933,6 @@ def test_page_rank_sweep_in_pieces_matches_whole_sweep(P, oracle, scale):
             for (_, _, _, ex, scl, el) in ranks:
                 ex.sweep(scl, el)
                 tot += float(el.item())
-                if streams:  # the virtual ranks share one vector: a real rank's side streams are its own device's
-                    torch.cuda.synchronize()
             assert abs(tot - errs[k]) <= 1e-11 * errs[k] + 1e-15
         got = torch.cat([rk[4] for rk in ranks])
         assert torch.equal(got, sc)

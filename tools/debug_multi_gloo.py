@@ -2,7 +2,7 @@
 """Front (b) — one process per rank, bench.py's construction and PiecewiseExchange — with all ranks on ONE GPU over gloo,
 against the single engine on the whole graph: the summed sweep error after EVERY sweep and the final scores, row by row.
 Launch: python -m torch.distributed.run --nnodes=1 --nproc-per-node P --master-addr 127.0.0.1 --master-port 29533 \
-        tools/debug_multi_gloo.py --scale 20 --sweeps 25 --streams 1"""
+        tools/debug_multi_gloo.py --scale 20 --sweeps 25"""
 import argparse, ctypes as C, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np
@@ -12,7 +12,7 @@ import torch.distributed as dist
 ap = argparse.ArgumentParser()
 ap.add_argument("--scale", type=int, default=20)
 ap.add_argument("--sweeps", type=int, default=25)
-ap.add_argument("--streams", type=int, default=1)
+ap.add_argument("--streams", type=int, default=0, help="(round 6: the stream-per-part schedule is gone; only 0 is accepted)")
 ap.add_argument("--parts", type=int, default=2)
 ap.add_argument("--sync", type=int, default=0, help="1: torch.cuda.synchronize() + barrier after every sweep")
 ap.add_argument("--snap", type=int, default=0, help="1: keep the scores of every sweep (a copy per sweep on the caller's stream: changes the timing)")
@@ -43,7 +43,8 @@ out_deg_local = out_deg[row_lo:row_hi].contiguous() if n_local else torch.zeros(
 engine = PageRankEngine(local_csr.handle, n, row_lo, out_deg_local, 0.85, x_len=layout["x_len"], engine=2)
 scores = torch.zeros(max(n_local, 1), dtype=torch.float32, device=dev)
 err = torch.zeros(1, dtype=torch.float64, device=dev)
-ex = PiecewiseExchange(engine, layout, rank, n_local, dev, streams=bool(args.streams))
+assert args.streams == 0, "PiecewiseExchange(streams=True) was removed in round 6 (profiles/r06_streams_repro.txt)"
+ex = PiecewiseExchange(engine, layout, rank, n_local, dev)
 if args.gather != "async":
     orig, main_stream = ex._start_gather, torch.cuda.current_stream()
 
