@@ -658,6 +658,16 @@ GM_API int gm_pr_sweep(gm_pr *pr, uint64_t d_x_in_global, uint64_t d_x_out_local
                        uint64_t d_error_out, void *stream)
 {
     GM_CHECK(pr && d_error_out, GM_ERR_INVALID, "gm_pr_sweep: null argument");
+    if (pr->engine == GM_PR_ENGINE_PB) { // the error comes out of the sweep's own launches where it can (pb_err_fold)
+        gm::DeviceGuard guard(pr->csr->device);
+        bool folded = false;
+        GM_TRY(gm::pb_sweep_main(pr->pb, pr->pb_scratch, reinterpret_cast<const float *>(d_x_in_global),
+                                 reinterpret_cast<float *>(d_x_out_local), reinterpret_cast<float *>(d_scores_local), pr->outdeg,
+                                 pr->base, pr->damping, (hipStream_t)stream, reinterpret_cast<double *>(d_error_out), &folded));
+        if (folded)
+            return GM_OK;
+        return gm::pb_sweep_error(pr->pb, pr->pb_scratch, reinterpret_cast<double *>(d_error_out), (hipStream_t)stream);
+    }
     GM_TRY(gm_pr_sweep_tiles(pr, d_x_in_global, d_x_out_local, d_scores_local, stream));
     return gm_pr_sweep_fixup(pr, d_x_out_local, d_scores_local, d_error_out, stream);
 }

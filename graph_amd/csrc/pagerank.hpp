@@ -31,7 +31,8 @@ int pb_plan_get(const gm_csr *csr, uint64_t x_len, std::shared_ptr<const PbPlan>
 int pb_scratch_create(const PbPlan *plan, PbScratch **out, DevBuf *early = nullptr);
 void pb_scratch_destroy(PbScratch *scratch);
 int pb_sweep_main(const PbPlan *plan, PbScratch *scratch, const float *x_in, float *x_out, float *scores,
-                  const uint32_t *outdeg, float base, float damping, hipStream_t st);
+                  const uint32_t *outdeg, float base, float damping, hipStream_t st, double *err_out = nullptr,
+                  bool *folded_out = nullptr);
 int pb_sweep_error(const PbPlan *plan, PbScratch *scratch, double *err_out, hipStream_t st);
 // a sweep in pieces, for partitioned runs that overlap the exchange of x with the work (pagerank_pb.hip)
 uint32_t pb_rows_per_bin(const PbPlan *plan);

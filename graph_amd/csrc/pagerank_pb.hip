@@ -94,8 +94,19 @@ constexpr float PB_FIX_INV = 2.168404344971008868e-19f;    // 2^-62
 
 } // namespace
 
+// the sweep's error summed by the last workgroup of the accumulate / hub launches (pb_err_fold below)
+struct PbErrFold {
+    uint32_t *ctr = nullptr;       // null: off
+    uint32_t total = 0;            // workgroups that take part: the accumulate launch's + the hub launches'
+    uint32_t count = 0;            // error slots: the bins', then the hub groups' / rows'
+    const double *slots = nullptr;
+    double *out = nullptr;
+};
+
 // mutable per-engine buffers: engines on one shared plan never touch each other's data
 struct PbScratch {
+    DevBuf fold_ctr;  // u32: tickets drawn by the workgroups of a whole sweep's accumulate and hub launches (self-resetting)
+    PbErrFold fold;   // what the launches being enqueued right now are given (pb_sweep_main sets and clears it)
     // row parts of a partitioned sweep (gm_pr_set_parts): the items of part k are
     // part_items[part_off[k] .. part_off[k+1]), each part longest-first
     DevBuf part_items;
@@ -1003,6 +1014,42 @@ __global__ __launch_bounds__(PB_BIN_BLOCK) void pb_bin_kernel(const float *__res
         vals[tid] = sink;
 }
 
+// The sweep's error WITHOUT a kernel of its own (round 6; pb_err_kernel + the gap in front of it were 15-20 us of a 200 us sweep
+// at scale 22): every workgroup of the accumulate launch and of the hub launches writes its error slot write-through, waits
+// for that store, and draws a ticket; the workgroup that draws the last one sums the slots — by its first 256 threads, slot b
+// in lane b mod 256, a wavefront butterfly, then the four wavefronts' sums left to right: the same order whichever kernel's
+// workgroup happens to be last, so the value does not depend on the schedule.  (pb_sweep_accum_part's pieces keep the kernel:
+// their launches are the caller's to count.)
+__device__ __forceinline__ void pb_err_fold(const PbErrFold &f)
+{
+    if (!f.ctr) // (a kernel argument: uniform)
+        return;
+    __shared__ double fold_red[4];
+    __shared__ uint32_t fold_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this thread's error store, if it made one, has left the CU
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t prev = atomicAdd(f.ctr, 1u);
+        fold_last = prev + 1u == f.total ? 1u : 0u;
+        if (fold_last)
+            st_agent(f.ctr, 0u); // ready for the next sweep (which starts behind this launch and the hub launches' join)
+    }
+    __syncthreads();
+    if (!fold_last)
+        return;
+    double a = 0.0;
+    if (threadIdx.x < 256u) {
+        for (uint32_t b = threadIdx.x; b < f.count; b += 256u)
+            a += ld_agent(f.slots + b);
+        a = wave_sum(a);
+        if ((threadIdx.x & (kWave - 1)) == 0)
+            fold_red[threadIdx.x / kWave] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        *f.out = ((fold_red[0] + fold_red[1]) + fold_red[2]) + fold_red[3];
+}
+
 __device__ __forceinline__ unsigned long long pb_to_fix(float x)
 {
     return (unsigned long long)(x * PB_FIX_SCALE); // exact scaling by 2^62, truncation below 2^-62
@@ -1024,7 +1071,7 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
                                                                 const uint32_t *__restrict__ outdeg, float *__restrict__ scores,
                                                                 float *__restrict__ x_out, double *__restrict__ bin_err,
                                                                 uint32_t n_local, uint32_t R, uint32_t Racc, float base,
-                                                                float damping, const uint16_t *__restrict__ hot_base)
+                                                                float damping, const uint16_t *__restrict__ hot_base, PbErrFold fold)
 {
     extern __shared__ unsigned long long acc[]; // Racc fixed-point sums (one per ordinary row WITH in-edges)
     __shared__ double red[PB_ACC_BLOCK / kWave];
@@ -1290,8 +1337,10 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
             }
         }
         __syncthreads();
-        if (!is_last)
+        if (!is_last) {
+            pb_err_fold(fold); // (it owns no error slot; it is one of the launch's workgroups)
             return;
+        }
     }
     double err = 0.0;
     const uint32_t r0 = b * R;
@@ -1383,7 +1432,8 @@ __global__ __launch_bounds__(PB_ACC_BLOCK) void pb_accum_kernel(const float *__r
     }
     const double total = block_sum<double, PB_ACC_BLOCK / kWave>(err, red);
     if (tid == 0)
-        bin_err[b] = total;
+        st_agent(&bin_err[b], total);
+    pb_err_fold(fold);
 }
 
 // ---- hub rows: the reference's own sums ---------------------------------------------------------------------------------
@@ -1585,7 +1635,8 @@ __global__ __launch_bounds__(PB_SEQ_WG) __attribute__((amdgpu_waves_per_eu(5, 8)
                                                               const uint32_t *__restrict__ hub_rows,
                                                               const uint32_t *__restrict__ outdeg, float *__restrict__ scores,
                                                               float *__restrict__ x_out, double *__restrict__ group_err, float base,
-                                                              float damping, uint32_t v_safe, uint32_t h_safe, uint32_t n_groups, uint32_t walk_prio)
+                                                              float damping, uint32_t v_safe, uint32_t h_safe, uint32_t n_groups, uint32_t walk_prio,
+                                                              PbErrFold fold)
 {
     constexpr uint32_t STEP = PB_SEQ_STEP;                      // stream entries one round of loads covers
     constexpr int PER = (int)(STEP / (PB_SEQ_WG * PB_VEC));     // float4 + 4 places per thread and block
@@ -1753,9 +1804,10 @@ __global__ __launch_bounds__(PB_SEQ_WG) __attribute__((amdgpu_waves_per_eu(5, 8)
         err = pr_finalize(hub_rows[item.row0 + tid], S, base, damping, outdeg, scores, x_out);
     const double total = block_sum<double, PB_SEQ_WG / kWave>(err, red);
     if (tid == 0)
-        group_err[item.group] = total;
+        st_agent(&group_err[item.group], total);
     lds_barrier();
     } // groups of this workgroup
+    pb_err_fold(fold);
 }
 
 // ---- long rows: the same sums, in parallel ----------------------------------------------------------------------------
@@ -1815,7 +1867,7 @@ __global__ __launch_bounds__(PB_LONG_WG) __attribute__((amdgpu_waves_per_eu(5, 8
                                                                 const uint32_t *__restrict__ hub_rows,
                                                                 const uint32_t *__restrict__ outdeg, float *__restrict__ scores,
                                                                 float *__restrict__ x_out, double *__restrict__ group_err, float base,
-                                                                float damping)
+                                                                float damping, PbErrFold fold)
 {
     constexpr uint32_t NWV = PB_LONG_WG / kWave, PER = PB_LONG_PER, SUPER = PB_LONG_WG * PER, SAT = 1u << 30, NONE = 0xFFFFFFFFu;
     constexpr uint32_t WARM = 1024 / PER; // threads whose terms (the row's first 1024) are added one after the other, see below
@@ -2157,11 +2209,12 @@ __global__ __launch_bounds__(PB_LONG_WG) __attribute__((amdgpu_waves_per_eu(5, 8
     if (tid == 0) {
         my_sbs[li.npass] = S;
         if (li.flags & 1u)
-            group_err[item.group] = pr_finalize(hub_rows[item.row0], S, base, damping, outdeg, scores, x_out);
+            st_agent(&group_err[item.group], pr_finalize(hub_rows[item.row0], S, base, damping, outdeg, scores, x_out));
         else
             __hip_atomic_store(handoff + me, ((unsigned long long)epoch << 32) | __float_as_uint(S), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
     }
+    pb_err_fold(fold);
 }
 
 __global__ __launch_bounds__(1024) void pb_err_kernel(const double *__restrict__ bin_err, uint32_t B, double *__restrict__ err_out)
@@ -3488,7 +3541,16 @@ int pb_scratch_create(const PbPlan *pl, PbScratch **out, DevBuf *early)
         return rc;
     }
     sc->vals = sc->vals_raw.as<float>();
+    {
+        const int rc = sc->fold_ctr.alloc(16);
+        if (rc != GM_OK) {
+            delete sc;
+            return rc;
+        }
+    }
     hipError_t e = hipMemset(sc->tickets.p, 0, (size_t)pl->B * 4);
+    if (e == hipSuccess)
+        e = hipMemset(sc->fold_ctr.p, 0, 16);
     if (e == hipSuccess) // (no hand-off word carries epoch 0, the counter starts at 0, sums of 0 predict nothing)
         e = hipMemset(sc->long_state.p, 0, sc->long_state.bytes);
     if (e == hipSuccess) // (an error slot no kernel of this plan writes — a hub row's or a hub group's, whichever sums it — stays 0)
@@ -3594,7 +3656,7 @@ void pb_launch_accum(const PbPlan *pl, PbScratch *sc, const PbItem *items, uint3
                           sc->vals, pl->p2_dst.as<uint16_t>(), items, pl->hot_ent.as<uint32_t>(), pl->hbin_v.as<uint32_t>(),
                           sc->hot_x.as<float>(), pl->H, pl->T, pl->Htot, sc->partials.as<unsigned long long>(),
                           sc->tickets.as<uint32_t>(), pl->cidx.as<uint16_t>(), outdeg, scores, x_out, sc->bin_err.as<double>(),
-                          pl->n_local, pl->R, pl->Racc, base, damping, pl->hot_base.as<uint16_t>());
+                          pl->n_local, pl->R, pl->Racc, base, damping, pl->hot_base.as<uint16_t>(), sc->fold);
 }
 
 // GM_PB_ABLATE = 10*accumulate variant + bin variant; 0 = the product kernels (re-read per call so that
@@ -3668,6 +3730,24 @@ static void pb_accum_dispatch(const PbPlan *pl, PbScratch *sc, const PbItem *ite
         pb_launch_accum<0>(pl, sc, items, count, x_out, scores, outdeg, base, damping, st, any_order);
 }
 
+// workgroups of pb_hubseq_kernel (GM_PB_SEQ_WGS: fewer than one per group, each looping over several)
+static uint32_t pb_seq_wgs(const PbPlan *pl)
+{
+    const uint32_t n_seq = pl->G - pl->G_long;
+    const uint32_t want = (uint32_t)pb_env("GM_PB_SEQ_WGS", 0);
+    return want && want < n_seq ? want : n_seq;
+}
+
+// workgroups the hub launches of a sweep have in all (pb_hub_dispatch)
+static uint32_t pb_hub_workgroups(const PbPlan *pl)
+{
+    if (!pl->G)
+        return 0;
+    if (pl->hub_csr)
+        return pl->n_long_items;
+    return (pl->G_long ? pl->n_long_items : 0u) + (pl->G > pl->G_long ? pb_seq_wgs(pl) : 0u);
+}
+
 // every hub group of the plan (its value-stream part must have been written: after the bin kernel)
 // `inline_any`: both kernels on `st`, the second one (and, by the caller, the accumulate kernel behind them) launched in any
 // order; returns whether anything was launched (the first launch behind the bin kernel must be an ordered one)
@@ -3683,8 +3763,7 @@ static bool pb_hub_dispatch(const PbPlan *pl, PbScratch *sc, float *x_out, float
 #endif
     // GM_PB_LONG_WGS / GM_PB_SEQ_WGS: workgroups of the two kernels (0 = one per row / group)
     const uint32_t n_seq = pl->G - pl->G_long;
-    uint32_t seq_wgs = (uint32_t)pb_env("GM_PB_SEQ_WGS", 0);
-    seq_wgs = seq_wgs && seq_wgs < n_seq ? seq_wgs : n_seq;
+    const uint32_t seq_wgs = pb_seq_wgs(pl);
     // the long rows: one workgroup per item (a row, or a few passes of a longer one), exactly n_long_items draws of the counter
     unsigned long long *l_ticket = sc->long_state.as<unsigned long long>(), *l_handoff = l_ticket + 1;
     float *l_sbs = reinterpret_cast<float *>(l_handoff + pl->n_long_items);
@@ -3693,7 +3772,7 @@ static bool pb_hub_dispatch(const PbPlan *pl, PbScratch *sc, float *x_out, float
     if (pl->hub_csr) { // lists that are not ascending: every hub row in CSR order through its index
         hipLaunchKernelGGL(pb_hublong_kernel<true>, dim3(pl->n_long_items), dim3(PB_LONG_WG), 0, st, sc->vals, pl->p2_dst.as<uint16_t>(),
                            pl->hub_gidx.as<uint32_t>(), pl->csr_items.as<PbHubItem>(), l_items, pl->n_long_items, l_ticket, l_handoff,
-                           l_sbs, l_epoch, pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr, base, damping);
+                           l_sbs, l_epoch, pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr, base, damping, sc->fold);
         return true;
     }
     const uint32_t v_safe = (uint32_t)(pl->Mv >= 4 ? (pl->Mv - 4) & ~3ull : 0), h_safe = (uint32_t)(pl->Mhh ? pl->Mhh - 1u : 0u);
@@ -3703,7 +3782,7 @@ static bool pb_hub_dispatch(const PbPlan *pl, PbScratch *sc, float *x_out, float
         if (pl->G_long && !(skip & 2)) {
             (void)pb_launch_flags(pb_hublong_kernel<false>, dim3(pl->n_long_items), dim3(PB_LONG_WG), 0, st, launched, sc->vals,
                                   pl->p2_dst.as<uint16_t>(), (const uint32_t *)nullptr, pl->long_rows.as<PbHubItem>(), l_items, pl->n_long_items, l_ticket, l_handoff, l_sbs, l_epoch,
-                                  pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr, base, damping);
+                                  pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr, base, damping, PbErrFold{});
             launched = true;
         }
         if (pl->G > pl->G_long && !(skip & 1)) {
@@ -3711,7 +3790,7 @@ static bool pb_hub_dispatch(const PbPlan *pl, PbScratch *sc, float *x_out, float
                                   pl->p2_dst.as<uint16_t>(), items + pl->G_long, pl->seq_blk_first.as<uint32_t>(),
                                   pl->seq_blk.as<uint4>(), pl->seq_rows.as<uint32_t>(), pl->hh_ent.as<uint32_t>(),
                                   sc->hot_x.as<float>(), pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr, base, damping,
-                                  v_safe, h_safe, n_seq, (uint32_t)pb_env("GM_PB_SEQ_PRIO", 1));
+                                  v_safe, h_safe, n_seq, (uint32_t)pb_env("GM_PB_SEQ_PRIO", 1), PbErrFold{});
             launched = true;
         }
         return launched;
@@ -3727,7 +3806,7 @@ static bool pb_hub_dispatch(const PbPlan *pl, PbScratch *sc, float *x_out, float
         }
         hipLaunchKernelGGL(pb_hublong_kernel<false>, dim3(pl->n_long_items), dim3(PB_LONG_WG), 0, ls, sc->vals, pl->p2_dst.as<uint16_t>(),
                            (const uint32_t *)nullptr, pl->long_rows.as<PbHubItem>(), l_items, pl->n_long_items, l_ticket, l_handoff, l_sbs, l_epoch, pl->hub_rows.as<uint32_t>(), outdeg, scores,
-                           x_out, gerr, base, damping);
+                           x_out, gerr, base, damping, sc->fold);
         if (own)
             (void)hipEventRecord(sc->ev_chain_join, ls);
     }
@@ -3735,7 +3814,7 @@ static bool pb_hub_dispatch(const PbPlan *pl, PbScratch *sc, float *x_out, float
         hipLaunchKernelGGL(pb_hubseq_kernel, dim3(seq_wgs), dim3(PB_SEQ_WG), 0, st, sc->vals, pl->p2_dst.as<uint16_t>(),
                            items + pl->G_long, pl->seq_blk_first.as<uint32_t>(), pl->seq_blk.as<uint4>(), pl->seq_rows.as<uint32_t>(),
                            pl->hh_ent.as<uint32_t>(), sc->hot_x.as<float>(), pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr,
-                           base, damping, v_safe, h_safe, n_seq, (uint32_t)pb_env("GM_PB_SEQ_PRIO", 1));
+                           base, damping, v_safe, h_safe, n_seq, (uint32_t)pb_env("GM_PB_SEQ_PRIO", 1), sc->fold);
     if (pl->G_long && !(skip & 2) && own)
         (void)hipStreamWaitEvent(st, sc->ev_chain_join, 0);
     return true;
@@ -3763,9 +3842,27 @@ static void pb_apply_vals_offset(const PbPlan *pl, PbScratch *sc)
 #endif
 }
 
+// err_out != null: the sweep's error as well (pb_err_fold: no launch of its own); *folded_out says whether that happened —
+// if not (nothing to launch, the measurement library) the caller runs pb_sweep_error
 int pb_sweep_main(const PbPlan *pl, PbScratch *sc, const float *x_in, float *x_out, float *scores,
-                  const uint32_t *outdeg, float base, float damping, hipStream_t st)
+                  const uint32_t *outdeg, float base, float damping, hipStream_t st, double *err_out, bool *folded_out)
 {
+    if (folded_out)
+        *folded_out = false;
+    struct FoldScope { // the launches below, and only they, carry the fold
+        PbScratch *sc;
+        ~FoldScope() { sc->fold = PbErrFold{}; }
+    } fold_scope{sc};
+#ifndef GM_MEASURE
+    if (err_out && folded_out && pl->NI && sc->fold_ctr.p && pb_env("GM_PB_FOLD_ERR", 1)) {
+        sc->fold.ctr = sc->fold_ctr.as<uint32_t>();
+        sc->fold.total = pl->NI + pb_hub_workgroups(pl);
+        sc->fold.count = pl->B + pl->err_slots;
+        sc->fold.slots = sc->bin_err.as<double>();
+        sc->fold.out = err_out;
+        *folded_out = true;
+    }
+#endif
     pb_apply_vals_offset(pl, sc);
     if (!pb_bin_dispatch(pl, sc, x_in, 0, pl->NW, st, nullptr, pb_env("GM_PB_FOLD_HOT", 1) != 0))
         pb_hot_dispatch(pl, sc, x_in, st); // (in front of the accumulate kernel, which reads hot_x; the bin kernel does not)

@@ -899,7 +899,9 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
     const size_t items = (size_t)g->m / chunk_edges + (size_t)g->m / (coop + 1u) + 64;
     if (!sc || sc->items < items) {
         sc.reset(new gm::SsspScratch);
-        GM_TRY(sc->dist.alloc((size_t)n * 4));
+        // (the two large ones from the arena's idle pieces where it has them: a hipMalloc behind another process's — or this
+        //  one's — hipFree waits for the driver to clear the freed memory, 8 ms of a first call at scale 24)
+        GM_TRY(sc->dist.alloc_scratch((size_t)n * 4));
         GM_TRY(sc->flags.alloc(((size_t)nwords + kWave) * 4));
         GM_TRY(sc->wmin.alloc(((size_t)nwords + kWave) * 4));
         GM_TRY(sc->hflags.alloc(((size_t)nwords + kWave) * 4));
@@ -911,7 +913,7 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
         GM_TRY(sc->queues_init.alloc(sizeof(QueueState)));
         sc->caps_key = 0;
         GM_TRY(sc->hctrl.alloc(C_WORDS * 4));
-        GM_TRY(sc->chunks.alloc(items * sizeof(uint2)));
+        GM_TRY(sc->chunks.alloc_scratch(items * sizeof(uint2)));
         sc->items = items;
     }
     // The lists once more, ordered by weight and transposed (~20 B per edge, released by gm_csr_trim):
@@ -943,7 +945,10 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
         if (!order && build_lock.owns_lock() && !g->sssp_order_failed.load(std::memory_order_relaxed)) {
             size_t free_b = 0, total_b = 0;
             const size_t need = (size_t)g->m * 36 + ((size_t)n + 1) * 4;
-            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need + need / 4) {
+            uint64_t arena_b[4] = {0, 0, 0, 0}; // the arena's idle pieces do not show up as free memory, and serve every buffer below
+            if (gm::arena_enabled())
+                gm::arena_stats(g->device, arena_b);
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b + arena_b[1] < need + need / 4) {
                 (void)hipGetLastError();
                 g->sssp_order_failed.store(1, std::memory_order_relaxed);
                 if (gm::log_enabled())
@@ -959,8 +964,11 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
             gm::DevBuf key; // source << 32 | weight bits of every edge, CSR order: the key of one sort, the values of the other
             auto build = [&](std::shared_ptr<gm::SsspOrder> &fresh) -> int {
                 gm::DevBuf key_sorted, temp;
-                GM_TRY(fresh->targets.alloc((size_t)g->m * 4));
-                GM_TRY(fresh->weights.alloc((size_t)g->m * 4));
+                // (the kept lists from the arena as well, round 6: the second call took 40 ms on a box that had run nothing
+                //  else and 160 ms behind other processes' frees — on the driver's box and here alike: hipMalloc of 4 GB waiting
+                //  for the driver to clear what others had freed)
+                GM_TRY(fresh->targets.alloc_big((size_t)g->m * 4));
+                GM_TRY(fresh->weights.alloc_big((size_t)g->m * 4));
                 GM_TRY(key.alloc_scratch((size_t)g->m * 8));
                 GM_TRY(key_sorted.alloc_scratch((size_t)g->m * 8));
                 unsigned eg = gm::div_up(n, SSSP_BLOCK);
@@ -985,8 +993,8 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
             };
             auto transpose = [&](std::shared_ptr<gm::SsspOrder> &fresh) -> int { // the in-edges for the far round's pull
                 gm::DevBuf tgt_sorted, temp;
-                GM_TRY(fresh->in_off.alloc(((size_t)n + 1) * 4));
-                GM_TRY(fresh->in_edge.alloc((size_t)g->m * 8));
+                GM_TRY(fresh->in_off.alloc_scratch(((size_t)n + 1) * 4));
+                GM_TRY(fresh->in_edge.alloc_big((size_t)g->m * 8));
                 GM_TRY(tgt_sorted.alloc_scratch((size_t)g->m * 4));
                 size_t temp_bytes = 0;
                 GM_HIP(rocprim::radix_sort_pairs(nullptr, temp_bytes, g->targets, tgt_sorted.as<uint32_t>(), key.as<unsigned long long>(),

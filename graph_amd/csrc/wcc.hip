@@ -21,11 +21,11 @@ using namespace gm;
 constexpr int WCC_BLOCK = 256;
 constexpr uint32_t WCC_COOP = 32; // lists longer than this are linked by the whole wavefront
 
-// afforest.rs:22-39
-__device__ __forceinline__ void af_link(uint32_t *parent, uint32_t u, uint32_t v)
+// afforest.rs:22-39, from any node p1 of u's tree and any node p2 of v's (the parents the caller has loaded: several
+// independent loads in flight instead of one after the other; a parent read a moment ago is still a node of the same tree —
+// trees only merge — and the loop climbs from wherever it starts)
+__device__ __forceinline__ void af_link_from(uint32_t *parent, uint32_t p1, uint32_t p2)
 {
-    uint32_t p1 = ld_agent(&parent[u]);
-    uint32_t p2 = ld_agent(&parent[v]);
     while (p1 != p2) {
         const uint32_t high = p1 > p2 ? p1 : p2;
         const uint32_t low = p1 + p2 - high;
@@ -37,6 +37,13 @@ __device__ __forceinline__ void af_link(uint32_t *parent, uint32_t u, uint32_t v
         p1 = ld_agent(&parent[ld_agent(&parent[high])]);
         p2 = ld_agent(&parent[low]);
     }
+}
+
+__device__ __forceinline__ void af_link(uint32_t *parent, uint32_t u, uint32_t v)
+{
+    const uint32_t p1 = ld_agent(&parent[u]);
+    const uint32_t p2 = ld_agent(&parent[v]);
+    af_link_from(parent, p1, p2);
 }
 
 __global__ void wcc_init_kernel(uint32_t *__restrict__ parent, uint32_t n)
@@ -61,16 +68,50 @@ __global__ void wcc_compress_kernel(uint32_t *parent, uint32_t n)
     }
 }
 
-// wcc.rs:186-204: link u with its first `rounds` out-neighbours
-__global__ void wcc_sample_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt,
-                                  uint32_t *parent, uint32_t n, uint64_t rounds)
+// wcc.rs:186-204: link u with its first `rounds` out-neighbours.
+// One lane per node was a chain of dependent random accesses per node (offsets -> first target -> parent[u], parent[v] ->
+// parent[high] -> CAS, then the same for the second target): 23 M L2 requests in 0.26 ms at scale 22, 62 % of the call's
+// kernel time (profiles/algos_traffic.json, round 5).  Round 6: a lane takes WCC_SAMPLE_U nodes at a time and BOTH sampled
+// targets of each, and every level of the chain is loaded for all of them before the next level is touched — offsets,
+// then up to 2 x U targets, then 3 x U parents — so 4 to 12 independent requests per lane are in flight where there was one.
+// The unions are the same ones; their order never matters (module header).
+constexpr int WCC_SAMPLE_U = 4;
+__global__ __launch_bounds__(WCC_BLOCK) void wcc_sample_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt,
+                                                               uint32_t *parent, uint32_t n, uint64_t rounds)
 {
+    constexpr int U = WCC_SAMPLE_U;
     const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += stride) {
-        const uint32_t s = off[u], e = off[u + 1];
-        const uint64_t take = (uint64_t)(e - s) < rounds ? (uint64_t)(e - s) : rounds;
-        for (uint64_t k = 0; k < take; ++k)
-            af_link(parent, u, tgt[s + k]);
+    for (uint64_t base = blockIdx.x * blockDim.x + threadIdx.x; base < n; base += (uint64_t)stride * U) {
+        uint32_t u[U], s[U], take[U], v0[U], v1[U], pu[U], p0[U], p1[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const uint64_t uu = base + (uint64_t)k * stride;
+            const bool in = uu < n;
+            u[k] = in ? (uint32_t)uu : 0u;
+            s[k] = in ? off[u[k]] : 0u;
+            const uint32_t e = in ? off[u[k] + 1] : 0u;
+            take[k] = (uint64_t)(e - s[k]) < rounds ? e - s[k] : (uint32_t)rounds;
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            v0[k] = take[k] >= 1u ? tgt[s[k]] : u[k]; // (u itself: a union that does nothing)
+            v1[k] = take[k] >= 2u ? tgt[s[k] + 1u] : u[k];
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            pu[k] = ld_agent(&parent[u[k]]);
+            p0[k] = ld_agent(&parent[v0[k]]);
+            p1[k] = ld_agent(&parent[v1[k]]);
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            if (take[k] >= 1u)
+                af_link_from(parent, pu[k], p0[k]);
+            if (take[k] >= 2u)
+                af_link_from(parent, pu[k], p1[k]);
+            for (uint32_t j = 2; j < take[k]; ++j) // (neighbor_rounds > 2: the rest one after the other)
+                af_link(parent, u[k], tgt[s[k] + j]);
+        }
     }
 }
 
@@ -170,16 +211,27 @@ constexpr uint32_t WCC_MODE_LDS = 4096;
 // wcc.rs:245-271: most frequent component among `samples` random nodes.  The reference draws from
 // an unseeded WyRand; the choice only decides which component link_remaining skips and never
 // changes the result.  One workgroup; ties -> smallest id.
+// Up to WCC_MODE_LDS / 2 samples (the default is 1024) are COUNTED in an LDS hash table — one insertion per sample;
+// until round 6 every sample was compared with every other (samples^2 LDS reads: 51 us of a 418 us pipeline at scale 22).
+// More samples than that: the quadratic count, from LDS or from the work buffer.
 __global__ __launch_bounds__(WCC_BLOCK) void wcc_sample_mode_kernel(const uint32_t *parent, uint32_t n,
                                                                      uint32_t samples, uint64_t seed,
                                                                      uint32_t *__restrict__ sample_buf,
                                                                      uint32_t *__restrict__ skip_out)
 {
     __shared__ unsigned long long best; // (count << 32) | ~id  -> max picks highest count, then smallest id
-    __shared__ uint32_t staged[WCC_MODE_LDS]; // the samples, when they fit: the count below is samples^2 compares
+    __shared__ uint32_t staged[WCC_MODE_LDS]; // the samples (quadratic count) / the table's keys (hash count)
+    __shared__ uint32_t counts[WCC_MODE_LDS];
     if (threadIdx.x == 0)
         best = 0ull;
+    const bool hashed = samples <= WCC_MODE_LDS / 2;
     const bool in_lds = samples <= WCC_MODE_LDS;
+    if (hashed)
+        for (uint32_t i = threadIdx.x; i < WCC_MODE_LDS; i += WCC_BLOCK) {
+            staged[i] = 0xFFFFFFFFu; // (no label: labels are node ids, at most 2^32 - 2)
+            counts[i] = 0u;
+        }
+    __syncthreads();
     for (uint32_t k = threadIdx.x; k < samples; k += WCC_BLOCK) {
         uint64_t x = seed + k;
         x += 0x9E3779B97F4A7C15ull;
@@ -187,26 +239,41 @@ __global__ __launch_bounds__(WCC_BLOCK) void wcc_sample_mode_kernel(const uint32
         x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
         x ^= x >> 31;
         const uint32_t c = ld_agent(&parent[(uint32_t)(x % n)]);
-        if (in_lds)
+        if (hashed) {
+            uint32_t h = (c * 2654435761u) >> 20; // 12 bits
+            for (;;) {
+                const uint32_t prev = atomicCAS(&staged[h], 0xFFFFFFFFu, c);
+                if (prev == 0xFFFFFFFFu || prev == c) {
+                    atomicAdd(&counts[h], 1u);
+                    break;
+                }
+                h = (h + 1u) & (WCC_MODE_LDS - 1u); // (at most samples <= half the table's keys: a free slot exists)
+            }
+        } else if (in_lds)
             staged[k] = c;
         else
             sample_buf[k] = c;
     }
     __syncthreads();
-    for (uint32_t k = threadIdx.x; k < samples; k += WCC_BLOCK) {
-        uint32_t cnt = 0;
-        uint32_t c;
-        if (in_lds) { // every lane reads the same word per step: an LDS broadcast (1024 samples from global memory
-                      // were 0.18 ms of a 0.6 ms pipeline at scale 22)
-            c = staged[k];
-            for (uint32_t j = 0; j < samples; ++j)
-                cnt += staged[j] == c;
-        } else {
-            c = sample_buf[k];
-            for (uint32_t j = 0; j < samples; ++j)
-                cnt += sample_buf[j] == c;
+    if (hashed) {
+        for (uint32_t i = threadIdx.x; i < WCC_MODE_LDS; i += WCC_BLOCK)
+            if (staged[i] != 0xFFFFFFFFu)
+                atomicMax(&best, ((unsigned long long)counts[i] << 32) | (uint32_t)~staged[i]);
+    } else {
+        for (uint32_t k = threadIdx.x; k < samples; k += WCC_BLOCK) {
+            uint32_t cnt = 0;
+            uint32_t c;
+            if (in_lds) { // every lane reads the same word per step: an LDS broadcast
+                c = staged[k];
+                for (uint32_t j = 0; j < samples; ++j)
+                    cnt += staged[j] == c;
+            } else {
+                c = sample_buf[k];
+                for (uint32_t j = 0; j < samples; ++j)
+                    cnt += sample_buf[j] == c;
+            }
+            atomicMax(&best, ((unsigned long long)cnt << 32) | (uint32_t)~c);
         }
-        atomicMax(&best, ((unsigned long long)cnt << 32) | (uint32_t)~c);
     }
     __syncthreads();
     if (threadIdx.x == 0)

@@ -488,9 +488,16 @@ class Components:
         return self._labels
 
 
-def wcc_afforest(graph: DirectedCsrGraph, config: WccConfig | None = None) -> Components:
-    """wcc_afforest — crates/algos/src/wcc.rs:127-141"""
+def wcc_afforest(graph: DirectedCsrGraph, config: WccConfig | None = None, device_out=None) -> Components:
+    """wcc_afforest — crates/algos/src/wcc.rs:127-141.
+    device_out (optional): an object with data_ptr() over u32 / i32 [n] on the graph's device (e.g. a torch tensor) — the
+    component ids are left THERE and it is returned instead of a Components: a caller that goes on working on the GPU
+    spares the n * 4 bytes over PCIe (16.8 MB = 0.3 ms of a 0.6 ms call at RMAT scale 22)."""
     config = config or WccConfig()
+    if device_out is not None:
+        check(lib().gm_wcc_afforest(graph.csr_out.handle, graph.csr_inc.handle, int(config.neighbor_rounds),
+                                    int(config.sampling_size), C.c_void_p(int(device_out.data_ptr()))))
+        return device_out
     labels = _result_buffer(graph.node_count(), np.uint32)
     check(lib().gm_wcc_afforest(graph.csr_out.handle, graph.csr_inc.handle, int(config.neighbor_rounds),
                                 int(config.sampling_size), _ptr(labels) if labels.size else None))

@@ -158,6 +158,11 @@ def measure(args):
                          f"wcc means, SURVEY a-5)", "nodes": n, "edges": m, "ms": t_aff * 1e3, "best_ms": t_aff_best * 1e3, "first_call_ms": t_wcc_first * 1e3,
                "edges_per_s": m / t_aff, "components": int(np.unique(comp).size)}
         rec["roofline"] = roofline(4 * (n + 1) + 4 * (2 * m) + 8 * n, t_aff, "wcc")
+        if not args.profile:  # the same call with the ids LEFT ON THE DEVICE (components_out may be a device address)
+            d_lab = torch.empty(n, dtype=torch.int32, device="cuda")
+            t_dev, lab_dev = timed(lambda: P.wcc_afforest(g, P.WccConfig(), device_out=d_lab), label="wcc steady, device result")
+            rec["ms_result_left_on_device"], rec["best_ms_result_left_on_device"] = t_dev * 1e3, timed.best * 1e3
+            assert np.array_equal(lab_dev.cpu().numpy().view(np.uint32), comp)
         if not args.profile:
             t_base, comp_b = timed(lambda: P.wcc_baseline(g).to_vec())
             rec["baseline_ms"] = t_base * 1e3
