@@ -862,9 +862,11 @@ static int page_rank_impl(const gm_csr *in_csr, const uint32_t *out_degree, cons
     // iterations where the reference stops on its tolerance.  Here the rows are cut into K blocks of about equal in-edges
     // (whole source tiles); per sweep and block j, in order: accumulate and finish the rows of block j (from the value stream
     // as it stands: this sweep's out_scores of the blocks before j, the last sweep's of the others), then propagate block j's new
-    // out_scores into the value stream.  One vector, updated in place; the hub rows (any block) are summed with block 0,
-    // from the last sweep's values: every row's equation is the one of page_rank.rs:143-159, only WHICH sweep's value a
-    // term carries differs — as it does between two runs of the reference itself.  Deterministic; same fixed point.
+    // out_scores into the value stream.  One vector, updated in place; a hub row is summed with the block its row lies in
+    // (pb_set_parts(.., hub_by_part): with all of them summed beside block 0 from the last sweep's values, the rows that carry
+    // most of the error converged at the synchronous rate — 20 iterations at scale 22 instead of 16).  Every row's equation is
+    // the one of page_rank.rs:143-159, only WHICH sweep's value a term carries differs — as it does between two runs of the
+    // reference itself.  Deterministic; same fixed point.  K = 16 blocks (GM_PR_BLOCK_GS=K).
     std::vector<uint64_t> gs_splits;
     {
         const char *gs_env_s = getenv("GM_PR_BLOCK_GS");
@@ -874,7 +876,7 @@ static int page_rank_impl(const gm_csr *in_csr, const uint32_t *out_degree, cons
         if (want)
             GM_TRY(gm_pr_part_geometry(ph.p, &rows_per_bin, &tile));
         const uint64_t tiles = tile ? (n + tile - 1) / tile : 0;
-        uint64_t K = gs_env > 1 ? (uint64_t)gs_env : 8;
+        uint64_t K = gs_env > 1 ? (uint64_t)gs_env : 16;
         if (K > 64)
             K = 64;
         if (K > tiles)
@@ -900,7 +902,7 @@ static int page_rank_impl(const gm_csr *in_csr, const uint32_t *out_degree, cons
                     }
                     gs_splits[j] = hi * tile < n ? hi * tile : n;
                 }
-                GM_TRY(gm_pr_set_parts(ph.p, gs_splits.data(), K));
+                GM_TRY(gm::pb_set_parts(ph.p->pb, ph.p->pb_scratch, gs_splits.data(), (uint32_t)K, /*hub_by_part=*/true));
                 std::vector<uint64_t> lo(gs_splits.begin(), gs_splits.end() - 1), hi(gs_splits.begin() + 1, gs_splits.end());
                 std::vector<uint32_t> reg(K);
                 for (uint64_t j = 0; j < K; ++j)

@@ -37,7 +37,7 @@ int pb_sweep_error(const PbPlan *plan, PbScratch *scratch, double *err_out, hipS
 // a sweep in pieces, for partitioned runs that overlap the exchange of x with the work (pagerank_pb.hip)
 uint32_t pb_rows_per_bin(const PbPlan *plan);
 uint32_t pb_source_tile(const PbPlan *plan);
-int pb_set_parts(const PbPlan *plan, PbScratch *scratch, const uint64_t *row_splits, uint32_t n_parts);
+int pb_set_parts(const PbPlan *plan, PbScratch *scratch, const uint64_t *row_splits, uint32_t n_parts, bool hub_by_part = false);
 int pb_sweep_bin_range(const PbPlan *plan, PbScratch *scratch, const float *x_in, uint64_t x_lo, uint64_t x_hi,
                        hipStream_t st);
 int pb_set_regions(const PbPlan *plan, PbScratch *scratch, const uint64_t *x_lo, const uint64_t *x_hi, const uint32_t *reg,

@@ -105,6 +105,12 @@ struct PbErrFold {
 
 // mutable per-engine buffers: engines on one shared plan never touch each other's data
 struct PbScratch {
+    // hub rows summed WITH THE PART THEIR ROWS LIE IN (pb_set_parts(.., hub_by_part): block-Gauss-Seidel sweeps) instead of all
+    // of them with part 0: per part the lane-walk groups (indices into hub_items behind the long ones) and the long rows'
+    // items (indices into long_items, every row's in pass order), and an item counter per part
+    bool hub_by_part = false;
+    DevBuf part_seq_list, part_long_list, part_long_tickets;
+    std::vector<uint32_t> part_seq_off, part_long_off;
     DevBuf fold_ctr;  // u32: tickets drawn by the workgroups of a whole sweep's accumulate and hub launches (self-resetting)
     PbErrFold fold;   // what the launches being enqueued right now are given (pb_sweep_main sets and clears it)
     // row parts of a partitioned sweep (gm_pr_set_parts): the items of part k are
@@ -165,6 +171,16 @@ struct PbHubItem {
     uint32_t group;
 };
 
+// an item of pb_hublong_kernel (described there)
+struct PbLongItem {
+    uint32_t row;    // the row's entry of hub_items
+    uint32_t pass0;  // first pass (super-block of PB_LONG_WG x PB_LONG_PER stream entries) of the row this item covers
+    uint32_t npass;  // ... and how many (<= PB_LONG_PMAX)
+    uint32_t prev;   // the item whose S this one starts from; 0xFFFFFFFF: the row's first item (S = 0)
+    uint32_t sb0;    // the row's first entry of the per-engine array of pass-boundary sums (its passes + 1 entries)
+    uint32_t flags;  // 1: the row's last item (finishes the row); 2: the row has other items (pairs are formed ahead)
+};
+
 struct PbPlan {
     uint32_t n_local = 0, m = 0;
     uint64_t x_len = 0;
@@ -197,6 +213,8 @@ struct PbPlan {
     std::vector<uint32_t> hub_first_host;
     std::vector<uint8_t> hub_long_host; // per group: 1 = one long row
     std::vector<PbHubItem> hub_items_host;
+    std::vector<PbHubItem> long_rows_host;   // host copy of long_rows
+    std::vector<PbLongItem> long_items_host; // ... and of long_items (declared below)
     // the other hub groups, hub_items[G_long .. G): walked by pb_hubseq_kernel with one lane per row.  Their part of p2_dst
     // holds, instead of the row slot, the entry's place in the row-major LDS arrangement of its 2048-entry block
     // (pb_hubseq_layout_kernel).
@@ -1636,7 +1654,7 @@ __global__ __launch_bounds__(PB_SEQ_WG) __attribute__((amdgpu_waves_per_eu(5, 8)
                                                               const uint32_t *__restrict__ outdeg, float *__restrict__ scores,
                                                               float *__restrict__ x_out, double *__restrict__ group_err, float base,
                                                               float damping, uint32_t v_safe, uint32_t h_safe, uint32_t n_groups, uint32_t walk_prio,
-                                                              PbErrFold fold)
+                                                              PbErrFold fold, const uint32_t *__restrict__ grp_list)
 {
     constexpr uint32_t STEP = PB_SEQ_STEP;                      // stream entries one round of loads covers
     constexpr int PER = (int)(STEP / (PB_SEQ_WG * PB_VEC));     // float4 + 4 places per thread and block
@@ -1648,7 +1666,9 @@ __global__ __launch_bounds__(PB_SEQ_WG) __attribute__((amdgpu_waves_per_eu(5, 8)
     if (walk_prio && tid < kWave)
         __builtin_amdgcn_s_setprio(3); // the walk is the group's critical path: first in line at its SIMD's issue
     // the grid may be smaller than the number of groups (pb_hub_dispatch): workgroup w then takes groups w, w + grid, ...
-    for (uint32_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    // grp_list (a sweep in row blocks, pb_set_parts with hub_by_part): the groups of this launch, n_groups of them
+    for (uint32_t gi = blockIdx.x; gi < n_groups; gi += gridDim.x) {
+    const uint32_t grp = grp_list ? grp_list[gi] : gi;
     const PbHubItem item = items[grp]; // longest groups first
     const uint32_t nh = item.nh;
     const bool walker = tid < nh; // nh <= 64: lane g of wavefront 0 owns row g
@@ -1841,14 +1861,6 @@ __global__ __launch_bounds__(PB_SEQ_WG) __attribute__((amdgpu_waves_per_eu(5, 8)
 // verified against the exact S, or the result of the sequential pass — the bits cannot depend on the prediction.
 // (at most 96 VGPRs: two of its wavefronts, one of pb_hubseq_kernel's (112) and four of the accumulate kernel's (56) share a SIMD's 512)
 constexpr uint32_t PB_LONG_PMAX = 16;  // passes of an item, at most
-struct PbLongItem {
-    uint32_t row;    // the row's entry of hub_items
-    uint32_t pass0;  // first pass (super-block of PB_LONG_WG x PB_LONG_PER stream entries) of the row this item covers
-    uint32_t npass;  // ... and how many (<= PB_LONG_PMAX)
-    uint32_t prev;   // the item whose S this one starts from; 0xFFFFFFFF: the row's first item (S = 0)
-    uint32_t sb0;    // the row's first entry of the per-engine array of pass-boundary sums (its passes + 1 entries)
-    uint32_t flags;  // 1: the row's last item (finishes the row); 2: the row has other items (pairs are formed ahead)
-};
 
 // GATHER (a plan whose hub rows' lists are NOT ascending — CsrLayout::Unsorted, the reference's default, csr.rs:34-45 — so that the
 // order the value stream delivers a row's terms in, ascending source, is not the order of page_rank.rs:143-146): EVERY hub row
@@ -1867,7 +1879,7 @@ __global__ __launch_bounds__(PB_LONG_WG) __attribute__((amdgpu_waves_per_eu(5, 8
                                                                 const uint32_t *__restrict__ hub_rows,
                                                                 const uint32_t *__restrict__ outdeg, float *__restrict__ scores,
                                                                 float *__restrict__ x_out, double *__restrict__ group_err, float base,
-                                                                float damping, PbErrFold fold)
+                                                                float damping, PbErrFold fold, const uint32_t *__restrict__ item_list)
 {
     constexpr uint32_t NWV = PB_LONG_WG / kWave, PER = PB_LONG_PER, SUPER = PB_LONG_WG * PER, SAT = 1u << 30, NONE = 0xFFFFFFFFu;
     constexpr uint32_t WARM = 1024 / PER; // threads whose terms (the row's first 1024) are added one after the other, see below
@@ -1885,8 +1897,12 @@ __global__ __launch_bounds__(PB_LONG_WG) __attribute__((amdgpu_waves_per_eu(5, 8
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     uint32_t flip = 0;
     // the items in row order from a counter: exactly n_items draws per launch, so the counter needs no reset
-    if (tid == 0)
-        s_item = (uint32_t)(atomicAdd(ticket, 1ull) % n_items);
+    // item_list (a sweep in row blocks): the n_items items of this launch, every row's in pass order — whoever an item waits
+    // for stands in front of it in the list as well
+    if (tid == 0) {
+        const uint32_t draw = (uint32_t)(atomicAdd(ticket, 1ull) % n_items);
+        s_item = item_list ? item_list[draw] : draw;
+    }
     lds_barrier();
     const uint32_t me = s_item;
     const PbLongItem li = litems[me];
@@ -2320,6 +2336,7 @@ int pb_make_long_items(PbPlan *pl, const std::vector<PbHubItem> &rows, uint32_t 
         }
         sb += passes + 1u;
     }
+    pl->long_items_host = li;
     pl->n_long_items = (uint32_t)li.size();
     pl->long_sbs_len = sb;
     GM_TRY(pl->long_items.alloc((li.size() ? li.size() : 1) * sizeof(PbLongItem)));
@@ -2410,6 +2427,7 @@ int pb_make_items(PbPlan *pl)
     for (uint32_t g = 0; g < pl->G_long; ++g)
         for (uint32_t j = 0; j < hubs[g].nh; ++j)
             rows.push_back(PbHubItem{hubs[g].q0, hubs[g].q1, j, hubs[g].row0 + j, pl->G + hubs[g].row0 + j});
+    pl->long_rows_host = rows;
     pl->n_long_rows = (uint32_t)rows.size();
     GM_TRY(pl->long_rows.alloc((rows.size() ? rows.size() : 1) * sizeof(PbHubItem)));
     if (!rows.empty())
@@ -3751,8 +3769,16 @@ static uint32_t pb_hub_workgroups(const PbPlan *pl)
 // every hub group of the plan (its value-stream part must have been written: after the bin kernel)
 // `inline_any`: both kernels on `st`, the second one (and, by the caller, the accumulate kernel behind them) launched in any
 // order; returns whether anything was launched (the first launch behind the bin kernel must be an ordered one)
+struct PbHubSubset { // the hub work of one part (hub_by_part); null lists with a count = nothing of that kind
+    const uint32_t *seq_list = nullptr;
+    uint32_t n_seq = 0;
+    const uint32_t *long_list = nullptr;
+    uint32_t n_long = 0;
+    unsigned long long *ticket = nullptr;
+};
+
 static bool pb_hub_dispatch(const PbPlan *pl, PbScratch *sc, float *x_out, float *scores, const uint32_t *outdeg, float base,
-                            float damping, hipStream_t st, bool inline_any = false)
+                            float damping, hipStream_t st, bool inline_any = false, const PbHubSubset *sub = nullptr)
 {
     double *gerr = sc->bin_err.as<double>() + pl->B;
     const PbHubItem *items = pl->hub_items.as<PbHubItem>();
@@ -3762,17 +3788,22 @@ static bool pb_hub_dispatch(const PbPlan *pl, PbScratch *sc, float *x_out, float
     constexpr int skip = 0;
 #endif
     // GM_PB_LONG_WGS / GM_PB_SEQ_WGS: workgroups of the two kernels (0 = one per row / group)
-    const uint32_t n_seq = pl->G - pl->G_long;
-    const uint32_t seq_wgs = pb_seq_wgs(pl);
+    const uint32_t n_seq = sub ? sub->n_seq : pl->G - pl->G_long;
+    const uint32_t seq_wgs = sub ? sub->n_seq : pb_seq_wgs(pl);
+    const uint32_t n_long_launch = sub ? sub->n_long : pl->n_long_items;
+    const uint32_t *seq_list = sub ? sub->seq_list : nullptr, *long_list = sub ? sub->long_list : nullptr;
     // the long rows: one workgroup per item (a row, or a few passes of a longer one), exactly n_long_items draws of the counter
     unsigned long long *l_ticket = sc->long_state.as<unsigned long long>(), *l_handoff = l_ticket + 1;
+    if (sub)
+        l_ticket = sub->ticket; // (a counter per part: each is drawn exactly as often as its part has items, launch after launch)
     float *l_sbs = reinterpret_cast<float *>(l_handoff + pl->n_long_items);
     const PbLongItem *l_items = pl->long_items.as<PbLongItem>();
     const uint32_t l_epoch = (pl->hub_csr ? pl->n_hub : pl->G_long) && !(skip & 2) ? ++sc->long_epoch : 0u;
     if (pl->hub_csr) { // lists that are not ascending: every hub row in CSR order through its index
         hipLaunchKernelGGL(pb_hublong_kernel<true>, dim3(pl->n_long_items), dim3(PB_LONG_WG), 0, st, sc->vals, pl->p2_dst.as<uint16_t>(),
                            pl->hub_gidx.as<uint32_t>(), pl->csr_items.as<PbHubItem>(), l_items, pl->n_long_items, l_ticket, l_handoff,
-                           l_sbs, l_epoch, pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr, base, damping, sc->fold);
+                           l_sbs, l_epoch, pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr, base, damping, sc->fold,
+                           (const uint32_t *)nullptr);
         return true;
     }
     const uint32_t v_safe = (uint32_t)(pl->Mv >= 4 ? (pl->Mv - 4) & ~3ull : 0), h_safe = (uint32_t)(pl->Mhh ? pl->Mhh - 1u : 0u);
@@ -3782,7 +3813,7 @@ static bool pb_hub_dispatch(const PbPlan *pl, PbScratch *sc, float *x_out, float
         if (pl->G_long && !(skip & 2)) {
             (void)pb_launch_flags(pb_hublong_kernel<false>, dim3(pl->n_long_items), dim3(PB_LONG_WG), 0, st, launched, sc->vals,
                                   pl->p2_dst.as<uint16_t>(), (const uint32_t *)nullptr, pl->long_rows.as<PbHubItem>(), l_items, pl->n_long_items, l_ticket, l_handoff, l_sbs, l_epoch,
-                                  pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr, base, damping, PbErrFold{});
+                                  pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr, base, damping, PbErrFold{}, (const uint32_t *)nullptr);
             launched = true;
         }
         if (pl->G > pl->G_long && !(skip & 1)) {
@@ -3790,34 +3821,35 @@ static bool pb_hub_dispatch(const PbPlan *pl, PbScratch *sc, float *x_out, float
                                   pl->p2_dst.as<uint16_t>(), items + pl->G_long, pl->seq_blk_first.as<uint32_t>(),
                                   pl->seq_blk.as<uint4>(), pl->seq_rows.as<uint32_t>(), pl->hh_ent.as<uint32_t>(),
                                   sc->hot_x.as<float>(), pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr, base, damping,
-                                  v_safe, h_safe, n_seq, (uint32_t)pb_env("GM_PB_SEQ_PRIO", 1), PbErrFold{});
+                                  v_safe, h_safe, n_seq, (uint32_t)pb_env("GM_PB_SEQ_PRIO", 1), PbErrFold{}, (const uint32_t *)nullptr);
             launched = true;
         }
         return launched;
     }
 #endif
     // the long rows on a stream of their own beside the other groups (when there are both)
-    const bool own = pl->G_long && sc->chain;
+    const bool have_long = pl->G_long && n_long_launch && !(skip & 2), have_seq = pl->G > pl->G_long && n_seq && !(skip & 1);
+    const bool own = have_long && have_seq && sc->chain;
     hipStream_t ls = own ? sc->chain : st;
-    if (pl->G_long && !(skip & 2)) {
+    if (have_long) {
         if (own) {
             (void)hipEventRecord(sc->ev_chain_fork, st);
             (void)hipStreamWaitEvent(ls, sc->ev_chain_fork, 0);
         }
-        hipLaunchKernelGGL(pb_hublong_kernel<false>, dim3(pl->n_long_items), dim3(PB_LONG_WG), 0, ls, sc->vals, pl->p2_dst.as<uint16_t>(),
-                           (const uint32_t *)nullptr, pl->long_rows.as<PbHubItem>(), l_items, pl->n_long_items, l_ticket, l_handoff, l_sbs, l_epoch, pl->hub_rows.as<uint32_t>(), outdeg, scores,
-                           x_out, gerr, base, damping, sc->fold);
+        hipLaunchKernelGGL(pb_hublong_kernel<false>, dim3(n_long_launch), dim3(PB_LONG_WG), 0, ls, sc->vals, pl->p2_dst.as<uint16_t>(),
+                           (const uint32_t *)nullptr, pl->long_rows.as<PbHubItem>(), l_items, n_long_launch, l_ticket, l_handoff, l_sbs, l_epoch, pl->hub_rows.as<uint32_t>(), outdeg, scores,
+                           x_out, gerr, base, damping, sc->fold, long_list);
         if (own)
             (void)hipEventRecord(sc->ev_chain_join, ls);
     }
-    if (pl->G > pl->G_long && !(skip & 1))
+    if (have_seq)
         hipLaunchKernelGGL(pb_hubseq_kernel, dim3(seq_wgs), dim3(PB_SEQ_WG), 0, st, sc->vals, pl->p2_dst.as<uint16_t>(),
                            items + pl->G_long, pl->seq_blk_first.as<uint32_t>(), pl->seq_blk.as<uint4>(), pl->seq_rows.as<uint32_t>(),
                            pl->hh_ent.as<uint32_t>(), sc->hot_x.as<float>(), pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr,
-                           base, damping, v_safe, h_safe, n_seq, (uint32_t)pb_env("GM_PB_SEQ_PRIO", 1), sc->fold);
-    if (pl->G_long && !(skip & 2) && own)
+                           base, damping, v_safe, h_safe, n_seq, (uint32_t)pb_env("GM_PB_SEQ_PRIO", 1), sc->fold, seq_list);
+    if (own)
         (void)hipStreamWaitEvent(st, sc->ev_chain_join, 0);
-    return true;
+    return have_long || have_seq;
 }
 
 static void pb_hot_dispatch(const PbPlan *pl, PbScratch *sc, const float *x_in, hipStream_t st)
@@ -3899,7 +3931,7 @@ uint32_t pb_source_tile(const PbPlan *pl) { return 1u << pl->s_log; }
 
 // bins [row_splits[k] / R, row_splits[k+1] / R) form part k; row_splits[0] = 0, the last one = n_local,
 // the inner ones multiples of R
-int pb_set_parts(const PbPlan *pl, PbScratch *sc, const uint64_t *row_splits, uint32_t n_parts)
+int pb_set_parts(const PbPlan *pl, PbScratch *sc, const uint64_t *row_splits, uint32_t n_parts, bool hub_by_part)
 {
     GM_CHECK(n_parts >= 1 && row_splits && row_splits[0] == 0 && row_splits[n_parts] == pl->n_local, GM_ERR_INVALID,
              "gm_pr_set_parts: the splits must start at 0 and end at the %u local rows", pl->n_local);
@@ -3925,6 +3957,46 @@ int pb_set_parts(const PbPlan *pl, PbScratch *sc, const uint64_t *row_splits, ui
     GM_CHECK(ordered.size() == pl->items_host.size(), GM_ERR_INVALID, "gm_pr_set_parts: the parts do not cover every bin");
     GM_TRY(sc->part_items.alloc(ordered.size() * sizeof(PbItem)));
     GM_HIP(hipMemcpy(sc->part_items.p, ordered.data(), ordered.size() * sizeof(PbItem), hipMemcpyHostToDevice));
+    // hub rows with the part their rows lie in (block-Gauss-Seidel sweeps: a hub row sees this sweep's values of the blocks
+    // before it, like every other row).  A lane-walk group goes with the part of its FIRST row (its other rows lie in that
+    // part or later ones: finished no later than their own part's turn).  Lists that are not ascending (hub_csr) stay with part 0.
+    sc->hub_by_part = false;
+    if (hub_by_part && pl->G && !pl->hub_csr && n_parts > 1) {
+        std::vector<uint32_t> hub_rows_host(pl->n_hub);
+        GM_HIP(hipMemcpy(hub_rows_host.data(), pl->hub_rows.p, (size_t)pl->n_hub * 4, hipMemcpyDeviceToHost));
+        auto part_of = [&](uint32_t row) {
+            uint32_t k = 0;
+            while (k + 1 < n_parts && row_splits[k + 1] <= row)
+                ++k;
+            return k;
+        };
+        std::vector<std::vector<uint32_t>> seq(n_parts), lng(n_parts);
+        for (uint32_t gi = 0; gi + pl->G_long < pl->G; ++gi)
+            seq[part_of(hub_rows_host[pl->hub_items_host[pl->G_long + gi].row0])].push_back(gi);
+        for (uint32_t i = 0; i < pl->long_items_host.size(); ++i) // (row by row, every row's items in pass order)
+            lng[part_of(hub_rows_host[pl->long_rows_host[pl->long_items_host[i].row].row0])].push_back(i);
+        std::vector<uint32_t> flat_s, flat_l;
+        sc->part_seq_off.assign(n_parts + 1, 0);
+        sc->part_long_off.assign(n_parts + 1, 0);
+        for (uint32_t k = 0; k < n_parts; ++k) {
+            sc->part_seq_off[k] = (uint32_t)flat_s.size();
+            sc->part_long_off[k] = (uint32_t)flat_l.size();
+            flat_s.insert(flat_s.end(), seq[k].begin(), seq[k].end());
+            flat_l.insert(flat_l.end(), lng[k].begin(), lng[k].end());
+        }
+        sc->part_seq_off[n_parts] = (uint32_t)flat_s.size();
+        sc->part_long_off[n_parts] = (uint32_t)flat_l.size();
+        GM_TRY(sc->part_seq_list.alloc((flat_s.size() ? flat_s.size() : 1) * 4));
+        GM_TRY(sc->part_long_list.alloc((flat_l.size() ? flat_l.size() : 1) * 4));
+        GM_TRY(sc->part_long_tickets.alloc((size_t)n_parts * 8));
+        if (!flat_s.empty())
+            GM_HIP(hipMemcpy(sc->part_seq_list.p, flat_s.data(), flat_s.size() * 4, hipMemcpyHostToDevice));
+        if (!flat_l.empty())
+            GM_HIP(hipMemcpy(sc->part_long_list.p, flat_l.data(), flat_l.size() * 4, hipMemcpyHostToDevice));
+        GM_HIP(hipMemset(sc->part_long_tickets.p, 0, (size_t)n_parts * 8));
+        GM_HIP(hipDeviceSynchronize());
+        sc->hub_by_part = true;
+    }
     return GM_OK;
 }
 
@@ -4017,6 +4089,31 @@ int pb_sweep_accum_part(const PbPlan *pl, PbScratch *sc, const float *x_in, floa
     // exchange of the part's rows) sees its hub rows finished.
     const bool fork = pl->G && sc->side && pl->hub_edges >= (1u << 20) && pb_env("GM_PB_HUB_FORK", 1);
     bool any = false;
+    if (sc->hub_by_part && part + 1 < sc->part_seq_off.size()) {
+        // this part's hub rows, beside this part's accumulate kernel (block-Gauss-Seidel sweeps: the parts follow each other
+        // on one stream, so the events are free again when the next part records them)
+        PbHubSubset sub;
+        sub.seq_list = sc->part_seq_list.as<uint32_t>() + sc->part_seq_off[part];
+        sub.n_seq = sc->part_seq_off[part + 1] - sc->part_seq_off[part];
+        sub.long_list = sc->part_long_list.as<uint32_t>() + sc->part_long_off[part];
+        sub.n_long = sc->part_long_off[part + 1] - sc->part_long_off[part];
+        sub.ticket = sc->part_long_tickets.as<unsigned long long>() + part;
+        const bool work = sub.n_seq || sub.n_long;
+        if (work && fork) {
+            GM_HIP(hipEventRecord(sc->ev_fork, st));
+            GM_HIP(hipStreamWaitEvent(sc->side, sc->ev_fork, 0));
+            pb_hub_dispatch(pl, sc, x_out, scores, outdeg, base, damping, sc->side, false, &sub);
+            GM_HIP(hipEventRecord(sc->ev_join, sc->side));
+        } else if (work) {
+            pb_hub_dispatch(pl, sc, x_out, scores, outdeg, base, damping, st, false, &sub);
+        }
+        const uint32_t i0 = sc->part_off[part], i1 = sc->part_off[part + 1];
+        pb_accum_dispatch(pl, sc, sc->part_items.as<PbItem>() + i0, i1 - i0, x_out, scores, outdeg, base, damping, st);
+        if (work && fork)
+            GM_HIP(hipStreamWaitEvent(st, sc->ev_join, 0));
+        GM_HIP(hipGetLastError());
+        return GM_OK;
+    }
     if (part == 0) {
 #ifdef GM_MEASURE
         if (pl->G && pb_env("GM_PB_ANYORDER", 0)) {

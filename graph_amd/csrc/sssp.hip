@@ -879,6 +879,8 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
     if (const char *v = getenv("GM_SSSP_COOP"))
         if (atoi(v) >= 1 && atoi(v) <= (int)SSSP_COOP)
             coop = (uint32_t)atoi(v);
+    // GM_SSSP_ARENA=<mask> (debugging): which buffers come from the arena — 1 the call's scratch, 2 the kept lists, 4 the transposed lists
+    const int arena_mask = getenv("GM_SSSP_ARENA") ? atoi(getenv("GM_SSSP_ARENA")) : 7;
     std::unique_ptr<gm::SsspScratch> sc;
     {
         std::lock_guard<std::mutex> lock(g->cache_mu);
@@ -901,7 +903,7 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
         sc.reset(new gm::SsspScratch);
         // (the two large ones from the arena's idle pieces where it has them: a hipMalloc behind another process's — or this
         //  one's — hipFree waits for the driver to clear the freed memory, 8 ms of a first call at scale 24)
-        GM_TRY(sc->dist.alloc_scratch((size_t)n * 4));
+        GM_TRY((arena_mask & 1) ? sc->dist.alloc_scratch((size_t)n * 4) : sc->dist.alloc((size_t)n * 4));
         GM_TRY(sc->flags.alloc(((size_t)nwords + kWave) * 4));
         GM_TRY(sc->wmin.alloc(((size_t)nwords + kWave) * 4));
         GM_TRY(sc->hflags.alloc(((size_t)nwords + kWave) * 4));
@@ -913,7 +915,7 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
         GM_TRY(sc->queues_init.alloc(sizeof(QueueState)));
         sc->caps_key = 0;
         GM_TRY(sc->hctrl.alloc(C_WORDS * 4));
-        GM_TRY(sc->chunks.alloc_scratch(items * sizeof(uint2)));
+        GM_TRY((arena_mask & 1) ? sc->chunks.alloc_scratch(items * sizeof(uint2)) : sc->chunks.alloc(items * sizeof(uint2)));
         sc->items = items;
     }
     // The lists once more, ordered by weight and transposed (~20 B per edge, released by gm_csr_trim):
@@ -967,8 +969,8 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
                 // (the kept lists from the arena as well, round 6: the second call took 40 ms on a box that had run nothing
                 //  else and 160 ms behind other processes' frees — on the driver's box and here alike: hipMalloc of 4 GB waiting
                 //  for the driver to clear what others had freed)
-                GM_TRY(fresh->targets.alloc_big((size_t)g->m * 4));
-                GM_TRY(fresh->weights.alloc_big((size_t)g->m * 4));
+                GM_TRY((arena_mask & 2) ? fresh->targets.alloc_big((size_t)g->m * 4) : fresh->targets.alloc((size_t)g->m * 4));
+                GM_TRY((arena_mask & 2) ? fresh->weights.alloc_big((size_t)g->m * 4) : fresh->weights.alloc((size_t)g->m * 4));
                 GM_TRY(key.alloc_scratch((size_t)g->m * 8));
                 GM_TRY(key_sorted.alloc_scratch((size_t)g->m * 8));
                 unsigned eg = gm::div_up(n, SSSP_BLOCK);
@@ -993,8 +995,8 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
             };
             auto transpose = [&](std::shared_ptr<gm::SsspOrder> &fresh) -> int { // the in-edges for the far round's pull
                 gm::DevBuf tgt_sorted, temp;
-                GM_TRY(fresh->in_off.alloc_scratch(((size_t)n + 1) * 4));
-                GM_TRY(fresh->in_edge.alloc_big((size_t)g->m * 8));
+                GM_TRY((arena_mask & 4) ? fresh->in_off.alloc_scratch(((size_t)n + 1) * 4) : fresh->in_off.alloc(((size_t)n + 1) * 4));
+                GM_TRY((arena_mask & 4) ? fresh->in_edge.alloc_big((size_t)g->m * 8) : fresh->in_edge.alloc((size_t)g->m * 8));
                 GM_TRY(tgt_sorted.alloc_scratch((size_t)g->m * 4));
                 size_t temp_bytes = 0;
                 GM_HIP(rocprim::radix_sort_pairs(nullptr, temp_bytes, g->targets, tgt_sorted.as<uint32_t>(), key.as<unsigned long long>(),

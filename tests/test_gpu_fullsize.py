@@ -360,3 +360,68 @@ def test_scale24_triangle_count_equals_oracle(env, oracle):
     ref = oracle.triangle_count(off, tgt, oracle.effective_cores())
     print(f"scale 24 triangle count: device {tri}, oracle {ref}")
     assert tri == ref
+
+
+def test_scale28_more_than_u32_edges_in_all_through_the_partitioned_entry(env):
+    """north_star: "graphs larger than one GPU are 1-D vertex-range partitioned"; the reference's ids default to 64 bits
+    (crates/app/src/runner.rs:29-33, builder/src/index.rs:9-103).  RMAT scale 28 = 2^28 nodes and 2^32 edges IN ALL — more than
+    one u32-offset CSR can hold, so no single engine exists to compare with — as 8 pieces of < 2^32 edges each through
+    gm_page_rank_multi_slices (8 virtual ranks on this box's one GPU: 288 GB hold all eight).  Checked by what does not need a
+    second implementation at that size: the pieces' edge sums, mass that only leaks, errors that fall, the
+    same BITS from a 5-way partition of the same graph, and the fixed-point equation (page_rank.rs:143-159) on a sample of rows
+    whose in-lists are downloaded."""
+    P, synth, torch = env
+    import ctypes as C
+
+    from graph_amd._lib import check, lib, vp
+    from graph_amd.distributed import partition_local_slices
+
+    torch.cuda.empty_cache()
+    P.trim_device(0)
+    free, _ = torch.cuda.mem_get_info()
+    if free < 150 << 30:
+        pytest.skip(f"{free >> 30} GiB free on the device: the eight scale-28 pieces with their plans need about 120")
+    scale, n, m = 28, 1 << 28, 16 << 28
+    assert m == 1 << 32
+    results = {}
+    for ranks in (8, 5):
+        slices, bounds, out_full, devices = partition_local_slices(scale, 42, ranks)
+        edges = [s.m for s in slices]
+        assert bounds[0] == 0 and bounds[-1] == n and sum(edges) == m and max(edges) < 1 << 32
+        assert int(out_full[0].to(torch.int64).sum()) == m        # every edge has a source: the out-degrees sum to m as well
+        runs = {}
+        for iters in ((3, 12) if ranks == 8 else (12,)):
+            got, it, err = P.page_rank_multi_slices(slices, bounds, out_full, P.PageRankConfig(iters, 0.0, 0.85), devices)
+            assert it == iters
+            runs[iters] = (got, err)
+        got, err = runs[12]
+        mass = float(got.astype(np.float64).sum())
+        print(f"scale 28, {ranks} virtual ranks from pieces: edges per rank {edges}; 12 sweeps, error {err:.3e}, mass {mass:.6f}")
+        assert 0.0 < mass <= 1.0 + 1e-6 and np.all(got >= (np.float32(1) - np.float32(0.85)) / np.float32(n))
+        if ranks == 8:
+            assert runs[3][1] > runs[12][1] > 0.0                  # the error falls
+            # the sweep equation on the first 2^20 rows of rank 3: score = (1 - d) / n + d * sum of in-neighbours' out_scores, with
+            # the out_scores of the sweep BEFORE — so run 11 sweeps, take x = score / out_degree, and compare with sweep 12
+            prev, _, _ = P.page_rank_multi_slices(slices, bounds, out_full, P.PageRankConfig(11, 0.0, 0.85), devices)
+            od = out_full[0].cpu().numpy().astype(np.float64)
+            x = np.where(od > 0, prev.astype(np.float64) / np.maximum(od, 1.0), 0.0)
+            h = vp()
+            rows = 1 << 20
+            check(lib().gm_csr_slice_rows(slices[3].handle, 0, rows, None, 0, 0, C.byref(h)))
+            off, tgt, _ = P.DeviceCsr(h).host()
+            sums = np.add.reduceat(np.concatenate([x[tgt.astype(np.int64)], [0.0]]), np.minimum(off[:-1].astype(np.int64), tgt.size))
+            sums[np.diff(off.astype(np.int64)) == 0] = 0.0
+            want = 0.15 / n + 0.85 * sums
+            have = got[bounds[3]:bounds[3] + rows].astype(np.float64)
+            rel = np.abs(have - want) / want
+            long_row = np.diff(off.astype(np.int64)) >= 4096       # summed left to right in f32 (page_rank.rs:143-146): they drift
+            print(f"   sweep equation on {rows} rows of rank 3 ({tgt.size} in-edges, {int(long_row.sum())} rows of >= 4096): max rel "
+                  f"{rel[~long_row].max():.2e} on exactly rounded rows, {rel[long_row].max() if long_row.any() else 0.0:.2e} on the others")
+            assert rel[~long_row].max() <= 1e-6                    # one f32 rounding of the sum, one of the division, one of d * s + b
+            assert not long_row.any() or rel[long_row].max() <= 2e-3
+        results[ranks] = got
+        del slices, out_full, runs
+        torch.cuda.empty_cache()
+        P.trim_device(0)
+    # ordinary rows are exactly rounded sums and hub rows the reference's left-to-right sums: the partition is not in the bits
+    assert np.array_equal(results[8], results[5])
