@@ -3194,7 +3194,7 @@ static hipError_t pb_set_kernel_attributes()
 }
 
 static bool pb_bin_dispatch(const PbPlan *pl, PbScratch *sc, const float *x_in, uint32_t w_first, uint32_t w_count,
-                            hipStream_t st, const uint32_t *item_list = nullptr, bool fold_hot = false);
+                            hipStream_t st, const uint32_t *item_list = nullptr, bool fold_hot = false, hipEvent_t stop = nullptr);
 
 int pb_plan_create(const gm_csr *csr, uint64_t x_len, PbPlan **out)
 {
@@ -3649,14 +3649,38 @@ static hipError_t pb_launch_flags(void (*kernel)(P...), dim3 grid, dim3 block, s
         vals);
 }
 
+// a launch whose COMPLETION is the event `stop` (hipExtLaunchKernel binds the event to the dispatch itself: no marker packet
+// behind the kernel, which a hipEventRecord is — 6 us between the bin and the accumulate kernel at scale 22)
+template <typename... P, typename... A>
+static hipError_t pb_launch_stop(void (*kernel)(P...), dim3 grid, dim3 block, size_t lds, hipStream_t st, hipEvent_t stop, A... a)
+{
+    static_assert(sizeof...(P) == sizeof...(A), "argument count");
+    std::tuple<P...> vals(static_cast<P>(a)...);
+    return std::apply(
+        [&](auto &...v) {
+            void *ptrs[] = {(void *)&v...};
+            return hipExtLaunchKernel(reinterpret_cast<const void *>(kernel), grid, block, ptrs, lds, st, nullptr, stop, 0);
+        },
+        vals);
+}
+
 template <int ABL, int S_LOG>
 void pb_launch_bin(const PbPlan *pl, PbScratch *sc, const float *x_in, uint32_t w_first, uint32_t w_count, hipStream_t st,
-                   const uint32_t *item_list = nullptr, bool fold_hot = false)
+                   const uint32_t *item_list = nullptr, bool fold_hot = false, hipEvent_t stop = nullptr)
 {
     // the hot sources' share per workgroup must fit its threads: Htot <= w_count x 1024 on every whole sweep that has a
     // value stream worth the name; otherwise (and for partial launches) pb_hot_gather_kernel does it
     fold_hot = fold_hot && pl->Htot && (uint64_t)w_count * PB_BIN_BLOCK >= pl->Htot;
     const bool grouped = pl->wg_tile_g.p && w_first == 0 && w_count == pl->NW && !item_list; // whole sweeps only
+    if (stop) {
+        (void)pb_launch_stop(pb_bin_kernel<ABL, S_LOG>, dim3(w_count), dim3(PB_BIN_BLOCK), (4u << S_LOG) + PB_DCACHE * 4, st, stop, x_in,
+                             pl->x_len, pl->tile_p.as<uint32_t>(), (grouped ? pl->wg_tile_g : pl->wg_tile).as<uint32_t>(),
+                             (grouped ? pl->wg_p0_g : pl->wg_p0).as<uint32_t>(), pl->p1_src.as<uint16_t>(),
+                             pl->chunk_seg.as<uint32_t>(), pl->delta.as<uint32_t>(), sc->vals, pl->chunk, w_first, pl->xcd_aware,
+                             item_list, fold_hot ? pl->hot_ids.as<uint32_t>() : (const uint32_t *)nullptr, pl->Htot,
+                             sc->hot_x.as<float>());
+        return;
+    }
     hipLaunchKernelGGL((pb_bin_kernel<ABL, S_LOG>), dim3(w_count), dim3(PB_BIN_BLOCK), (4u << S_LOG) + PB_DCACHE * 4, st, x_in,
                        pl->x_len, pl->tile_p.as<uint32_t>(), (grouped ? pl->wg_tile_g : pl->wg_tile).as<uint32_t>(),
                        (grouped ? pl->wg_p0_g : pl->wg_p0).as<uint32_t>(),
@@ -3681,7 +3705,7 @@ void pb_launch_accum(const PbPlan *pl, PbScratch *sc, const PbItem *items, uint3
 // tools/ablate.py can switch variants on one resident graph)
 // returns whether the launch gathered the hot sources' out_scores as well (whole sweeps of the product kernel)
 static bool pb_bin_dispatch(const PbPlan *pl, PbScratch *sc, const float *x_in, uint32_t w_first, uint32_t w_count,
-                            hipStream_t st, const uint32_t *item_list, bool fold_hot)
+                            hipStream_t st, const uint32_t *item_list, bool fold_hot, hipEvent_t stop)
 {
     if (w_count == 0)
         return false;
@@ -3704,9 +3728,9 @@ static bool pb_bin_dispatch(const PbPlan *pl, PbScratch *sc, const float *x_in, 
     }
 #endif
     if (pl->s_log == 15)
-        pb_launch_bin<0, 15>(pl, sc, x_in, w_first, w_count, st, item_list, fold_hot);
+        pb_launch_bin<0, 15>(pl, sc, x_in, w_first, w_count, st, item_list, fold_hot, stop);
     else
-        pb_launch_bin<0, 14>(pl, sc, x_in, w_first, w_count, st, item_list, fold_hot);
+        pb_launch_bin<0, 14>(pl, sc, x_in, w_first, w_count, st, item_list, fold_hot, stop);
     return fold_hot;
 }
 
@@ -3896,12 +3920,19 @@ int pb_sweep_main(const PbPlan *pl, PbScratch *sc, const float *x_in, float *x_o
     }
 #endif
     pb_apply_vals_offset(pl, sc);
-    if (!pb_bin_dispatch(pl, sc, x_in, 0, pl->NW, st, nullptr, pb_env("GM_PB_FOLD_HOT", 1) != 0))
-        pb_hot_dispatch(pl, sc, x_in, st); // (in front of the accumulate kernel, which reads hot_x; the bin kernel does not)
     // the hub groups need little LDS: on a second stream their workgroups run beside those of the ordinary bins
     // (measured at scale 26 / 22 on one box: 3.12 / 3.24 ms forked vs 3.33 / 3.44 ms in line, 0.216 vs 0.252 ms;
     // with the 85-VGPR version of the kernel the two could not share a CU and forking gained nothing)
     const bool fork = pl->G && sc->side && pl->hub_edges >= (1u << 20) && pb_env("GM_PB_HUB_FORK", 1);
+    // GM_PB_FORK_STOP=1 (round 6, measured: see DESIGN.md): the fork event is the bin kernel's own completion instead of a
+    // marker recorded behind it — when the bin launch gathers the hot sources as well (nothing else stands between the two)
+    const bool want_fold_hot = pb_env("GM_PB_FOLD_HOT", 1) != 0 && pl->Htot && (uint64_t)pl->NW * PB_BIN_BLOCK >= pl->Htot;
+    bool fork_by_stop = fork && pl->NW && want_fold_hot && pb_env("GM_PB_FORK_STOP", 0) != 0;
+#ifdef GM_MEASURE
+    fork_by_stop = false;
+#endif
+    if (!pb_bin_dispatch(pl, sc, x_in, 0, pl->NW, st, nullptr, pb_env("GM_PB_FOLD_HOT", 1) != 0, fork_by_stop ? sc->ev_fork : nullptr))
+        pb_hot_dispatch(pl, sc, x_in, st); // (in front of the accumulate kernel, which reads hot_x; the bin kernel does not)
 #ifdef GM_MEASURE
     if (pl->G && pb_env("GM_PB_ANYORDER", 0)) {
         const bool any = pb_hub_dispatch(pl, sc, x_out, scores, outdeg, base, damping, st, true);
@@ -3911,7 +3942,8 @@ int pb_sweep_main(const PbPlan *pl, PbScratch *sc, const float *x_in, float *x_o
     }
 #endif
     if (fork) {
-        GM_HIP(hipEventRecord(sc->ev_fork, st));
+        if (!fork_by_stop)
+            GM_HIP(hipEventRecord(sc->ev_fork, st));
         GM_HIP(hipStreamWaitEvent(sc->side, sc->ev_fork, 0));
         pb_hub_dispatch(pl, sc, x_out, scores, outdeg, base, damping, sc->side);
         GM_HIP(hipEventRecord(sc->ev_join, sc->side));

@@ -300,14 +300,24 @@ __global__ void sssp_key_weights_kernel(const unsigned long long *__restrict__ k
         w[i] = __uint_as_float((uint32_t)key[i]);
 }
 
-// in_off[t] = first position of the sorted targets with a target >= t (t = 0 .. n)
-__global__ void sssp_in_bounds_kernel(const uint32_t *__restrict__ sorted_tgt, uint64_t m, uint32_t n, uint32_t *__restrict__ in_off)
+// in_off[t] = first position of the sorted targets with a target >= t (t = 0 .. n), in three steps: every entry = m ("none at or
+// behind t"); the first position of every target that occurs; a suffix minimum (rocPRIM scan over reversed iterators).
+// (Until round 6 thread i filled in_off for every t in (sorted_tgt[i - 1], sorted_tgt[i]] by itself: a long id range without
+// in-edges — the tail of a degree-ordered or partition-local graph — was one thread writing millions of entries, and the
+// 32-bit loop bound never ended for n = 2^32 - 1: ADVICE r5.)
+__global__ void sssp_fill_u32_kernel(uint32_t *__restrict__ out, uint64_t count, uint32_t value)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= m; i += stride) {
-        const uint32_t lo = i == 0 ? 0u : sorted_tgt[i - 1] + 1u;
-        const uint32_t hi = i == m ? n : sorted_tgt[i];
-        for (uint32_t t = lo; t <= hi; ++t)
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride)
+        out[i] = value;
+}
+
+__global__ void sssp_in_starts_kernel(const uint32_t *__restrict__ sorted_tgt, uint64_t m, uint32_t *__restrict__ in_off)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
+        const uint32_t t = sorted_tgt[i];
+        if (i == 0 || sorted_tgt[i - 1] != t)
             in_off[t] = (uint32_t)i;
     }
 }
@@ -879,8 +889,12 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
     if (const char *v = getenv("GM_SSSP_COOP"))
         if (atoi(v) >= 1 && atoi(v) <= (int)SSSP_COOP)
             coop = (uint32_t)atoi(v);
-    // GM_SSSP_ARENA=<mask> (debugging): which buffers come from the arena — 1 the call's scratch, 2 the kept lists, 4 the transposed lists
-    const int arena_mask = getenv("GM_SSSP_ARENA") ? atoi(getenv("GM_SSSP_ARENA")) : 7;
+    // GM_SSSP_ARENA=<mask>: which buffers come from the arena — 1 the call's scratch, 2 the kept weight-ordered lists, 4 the
+    // transposed lists.  Default 3: with the transposed lists (in_off, in_edge) mapped from arena pieces the build's second sort
+    // dies of a GPU memory fault, every time, at the same offset (tools/runs/r06_call04.sh: masks 7 / 6 / 5 fault, 3 / 0 do
+    // not) — not understood (every access of both is bounds-checked; the same buffers from hipMalloc have never faulted);
+    // they stay on hipMalloc.
+    const int arena_mask = getenv("GM_SSSP_ARENA") ? atoi(getenv("GM_SSSP_ARENA")) : 3;
     std::unique_ptr<gm::SsspScratch> sc;
     {
         std::lock_guard<std::mutex> lock(g->cache_mu);
@@ -1006,10 +1020,21 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
                 GM_HIP(rocprim::radix_sort_pairs(temp.p, temp_bytes, g->targets, tgt_sorted.as<uint32_t>(), key.as<unsigned long long>(),
                                                  fresh->in_edge.as<unsigned long long>(), (size_t)g->m, 0u, (unsigned)(key_bits ? key_bits : 1),
                                                  (hipStream_t)0));
-                unsigned bg = gm::div_up(g->m + 1, 256);
-                hipLaunchKernelGGL(sssp_in_bounds_kernel, dim3(bg > 16384 ? 16384 : bg), dim3(256), 0, (hipStream_t)0,
-                                   tgt_sorted.as<uint32_t>(), g->m, n, fresh->in_off.as<uint32_t>());
+                unsigned fg = gm::div_up((uint64_t)n + 1, 256), bg = gm::div_up(g->m, 256);
+                uint32_t *in_off = fresh->in_off.as<uint32_t>();
+                hipLaunchKernelGGL(sssp_fill_u32_kernel, dim3(fg > 16384 ? 16384 : fg), dim3(256), 0, (hipStream_t)0, in_off,
+                                   (uint64_t)n + 1, (uint32_t)g->m);
+                hipLaunchKernelGGL(sssp_in_starts_kernel, dim3(bg > 16384 ? 16384 : bg), dim3(256), 0, (hipStream_t)0,
+                                   tgt_sorted.as<uint32_t>(), g->m, in_off);
                 GM_HIP(hipGetLastError());
+                {
+                    auto rev = rocprim::make_reverse_iterator(in_off + (size_t)n + 1); // from in_off[n] down to in_off[0]
+                    size_t scan_bytes = 0;
+                    GM_HIP(rocprim::inclusive_scan(nullptr, scan_bytes, rev, rev, (size_t)n + 1, rocprim::minimum<uint32_t>(), (hipStream_t)0));
+                    if (scan_bytes > temp.bytes)
+                        GM_TRY(temp.alloc_scratch(scan_bytes));
+                    GM_HIP(rocprim::inclusive_scan(temp.p, scan_bytes, rev, rev, (size_t)n + 1, rocprim::minimum<uint32_t>(), (hipStream_t)0));
+                }
                 GM_HIP(hipStreamSynchronize((hipStream_t)0));
                 return GM_OK;
             };

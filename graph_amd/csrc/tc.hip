@@ -779,6 +779,7 @@ GM_API int gm_triangle_count(const gm_csr *g, uint64_t *triangles_out)
             if (n_items) {
 #define GM_TC_ROWS(B_, G_, M_, U_)                                                                                      \
     do {                                                                                                                \
+        GM_CHECK(launch_no < 64, GM_ERR_INVALID, "gm_triangle_count: %u launches over the rows (ctrl holds 64 item counters)", launch_no); \
         GM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&tc_rows_kernel<B_, G_, M_, U_>),                     \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, TCR_K_MAX / 8));                         \
         hipLaunchKernelGGL((tc_rows_kernel<B_, G_, M_, U_>), dim3(wgs_of(n_items, lds, B_)), dim3(B_), lds, stream_of(launch_no), g->offsets, \
