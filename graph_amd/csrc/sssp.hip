@@ -889,8 +889,8 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
     if (const char *v = getenv("GM_SSSP_COOP"))
         if (atoi(v) >= 1 && atoi(v) <= (int)SSSP_COOP)
             coop = (uint32_t)atoi(v);
-    // GM_SSSP_ARENA=<mask>: which buffers come from the arena — 1 the call's scratch, 2 the kept weight-ordered lists, 4 the
-    // transposed lists.  Default 3: with the transposed lists (in_off, in_edge) mapped from arena pieces the build's second sort
+    // GM_SSSP_ARENA=<mask>: which buffers come from the arena — 1 the call's scratch, 2 the kept weight-ordered lists, 4 / 8 the
+    // transposed lists (in_edge / in_off).  Default 3: with the transposed lists (in_off, in_edge) mapped from arena pieces the build's second sort
     // dies of a GPU memory fault, every time, at the same offset (tools/runs/r06_call04.sh: masks 7 / 6 / 5 fault, 3 / 0 do
     // not) — not understood (every access of both is bounds-checked; the same buffers from hipMalloc have never faulted);
     // they stay on hipMalloc.
@@ -1009,7 +1009,7 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
             };
             auto transpose = [&](std::shared_ptr<gm::SsspOrder> &fresh) -> int { // the in-edges for the far round's pull
                 gm::DevBuf tgt_sorted, temp;
-                GM_TRY((arena_mask & 4) ? fresh->in_off.alloc_scratch(((size_t)n + 1) * 4) : fresh->in_off.alloc(((size_t)n + 1) * 4));
+                GM_TRY((arena_mask & 8) ? fresh->in_off.alloc_scratch(((size_t)n + 1) * 4) : fresh->in_off.alloc(((size_t)n + 1) * 4));
                 GM_TRY((arena_mask & 4) ? fresh->in_edge.alloc_big((size_t)g->m * 8) : fresh->in_edge.alloc((size_t)g->m * 8));
                 GM_TRY(tgt_sorted.alloc_scratch((size_t)g->m * 4));
                 size_t temp_bytes = 0;

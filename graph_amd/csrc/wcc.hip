@@ -39,6 +39,19 @@ __device__ __forceinline__ void af_link_from(uint32_t *parent, uint32_t p1, uint
     }
 }
 
+// the same for nodes a, b whose parents pa, pb have just been loaded: when the higher of the two parents is a or b itself and
+// was its own parent a moment ago — nearly every union of the sampling phase: the forest starts as n roots — the first
+// `parent[high]` is known and the union is ONE round trip (the CAS) instead of two
+__device__ __forceinline__ void af_link_known(uint32_t *parent, uint32_t a, uint32_t pa, uint32_t b, uint32_t pb)
+{
+    if (pa == pb)
+        return;
+    const uint32_t high = pa > pb ? pa : pb, low = pa + pb - high;
+    if (((high == a && pa == a) || (high == b && pb == b)) && atomicCAS(&parent[high], high, low) == high)
+        return;
+    af_link_from(parent, pa, pb);
+}
+
 __device__ __forceinline__ void af_link(uint32_t *parent, uint32_t u, uint32_t v)
 {
     const uint32_t p1 = ld_agent(&parent[u]);
@@ -73,9 +86,10 @@ __global__ void wcc_compress_kernel(uint32_t *parent, uint32_t n)
 // parent[high] -> CAS, then the same for the second target): 23 M L2 requests in 0.26 ms at scale 22, 62 % of the call's
 // kernel time (profiles/algos_traffic.json, round 5).  Round 6: a lane takes WCC_SAMPLE_U nodes at a time and BOTH sampled
 // targets of each, and every level of the chain is loaded for all of them before the next level is touched — offsets,
-// then up to 2 x U targets, then 3 x U parents — so 4 to 12 independent requests per lane are in flight where there was one.
+// then up to 2 x U targets, then 3 x U parents — so 8 to 24 independent requests per lane are in flight where there was one —
+// and a union of two nodes that were roots a moment ago goes straight to its CAS (af_link_known).
 // The unions are the same ones; their order never matters (module header).
-constexpr int WCC_SAMPLE_U = 4;
+constexpr int WCC_SAMPLE_U = 8;
 __global__ __launch_bounds__(WCC_BLOCK) void wcc_sample_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt,
                                                                uint32_t *parent, uint32_t n, uint64_t rounds)
 {
@@ -106,9 +120,9 @@ __global__ __launch_bounds__(WCC_BLOCK) void wcc_sample_kernel(const uint32_t *_
 #pragma unroll
         for (int k = 0; k < U; ++k) {
             if (take[k] >= 1u)
-                af_link_from(parent, pu[k], p0[k]);
-            if (take[k] >= 2u)
-                af_link_from(parent, pu[k], p1[k]);
+                af_link_known(parent, u[k], pu[k], v0[k], p0[k]);
+            if (take[k] >= 2u) // (pu may be stale by now — the first union may have moved u's root: still a node of u's tree)
+                af_link_known(parent, u[k], pu[k], v1[k], p1[k]);
             for (uint32_t j = 2; j < take[k]; ++j) // (neighbor_rounds > 2: the rest one after the other)
                 af_link(parent, u[k], tgt[s[k] + j]);
         }
