@@ -272,7 +272,8 @@ where
             gm_page_rank_multi(out, inc, std::ptr::null(), devices, max_iterations as u64, tolerance, damping_factor,
                                scores.as_mut_ptr(), &mut iterations, &mut error)
         } else {
-            // mode 0 = GM_PR_AUTO: n <= 16384 runs the reference's exact in-place order, else synchronous sweeps
+            // mode 0 = GM_PR_AUTO: n <= 16384 runs the reference's exact in-place order; beyond that block-Gauss-Seidel sweeps on the
+            // propagation-blocking engine (the in-place update of page_rank.rs:142-160 at block granularity), synchronous ones on the pull engine
             gm_page_rank_directed(out, inc, max_iterations as u64, tolerance, damping_factor, 0, scores.as_mut_ptr(),
                                   &mut iterations, &mut error)
         }

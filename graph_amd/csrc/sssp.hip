@@ -890,11 +890,11 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
         if (atoi(v) >= 1 && atoi(v) <= (int)SSSP_COOP)
             coop = (uint32_t)atoi(v);
     // GM_SSSP_ARENA=<mask>: which buffers come from the arena — 1 the call's scratch, 2 the kept weight-ordered lists, 4 / 8 the
-    // transposed lists (in_edge / in_off).  Default 3: with the transposed lists (in_off, in_edge) mapped from arena pieces the build's second sort
-    // dies of a GPU memory fault, every time, at the same offset (tools/runs/r06_call04.sh: masks 7 / 6 / 5 fault, 3 / 0 do
-    // not) — not understood (every access of both is bounds-checked; the same buffers from hipMalloc have never faulted);
-    // they stay on hipMalloc.
-    const int arena_mask = getenv("GM_SSSP_ARENA") ? atoi(getenv("GM_SSSP_ARENA")) : 3;
+    // transposed lists (in_edge / in_off), 16: those two allocated before the build's first temporary is released.  Default 15.
+    // (With round 5's in-bounds kernel — thread i filling in_off over (sorted_tgt[i - 1], sorted_tgt[i]] — masks with the
+    // transposed lists in the arena died of a GPU memory fault in the build's second half, every time, at the same offset
+    // (tools/runs/r06_call04.sh: 7 / 6 / 5 faulted, 3 / 0 did not); with in_off filled by a scan they do not (r06_call06.sh).)
+    const int arena_mask = getenv("GM_SSSP_ARENA") ? atoi(getenv("GM_SSSP_ARENA")) : 15;
     std::unique_ptr<gm::SsspScratch> sc;
     {
         std::lock_guard<std::mutex> lock(g->cache_mu);
@@ -985,6 +985,13 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
                 //  for the driver to clear what others had freed)
                 GM_TRY((arena_mask & 2) ? fresh->targets.alloc_big((size_t)g->m * 4) : fresh->targets.alloc((size_t)g->m * 4));
                 GM_TRY((arena_mask & 2) ? fresh->weights.alloc_big((size_t)g->m * 4) : fresh->weights.alloc((size_t)g->m * 4));
+                // GM_SSSP_ARENA bit 16: the transposed lists' buffers NOW, before any temporary of this build has been released —
+                // an arena buffer that takes over the address range a temporary has just given up (exact-size reuse: in_edge
+                // and key_sorted are both 8 B per edge) is what the fault of masks 4 / 8 looks like it needs
+                if ((arena_mask & 16) && !(getenv("GM_SSSP_PULL") && atoi(getenv("GM_SSSP_PULL")) == 0)) {
+                    GM_TRY(fresh->in_off.alloc_scratch(((size_t)n + 1) * 4));
+                    GM_TRY(fresh->in_edge.alloc_big((size_t)g->m * 8));
+                }
                 GM_TRY(key.alloc_scratch((size_t)g->m * 8));
                 GM_TRY(key_sorted.alloc_scratch((size_t)g->m * 8));
                 unsigned eg = gm::div_up(n, SSSP_BLOCK);
@@ -1009,8 +1016,10 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
             };
             auto transpose = [&](std::shared_ptr<gm::SsspOrder> &fresh) -> int { // the in-edges for the far round's pull
                 gm::DevBuf tgt_sorted, temp;
-                GM_TRY((arena_mask & 8) ? fresh->in_off.alloc_scratch(((size_t)n + 1) * 4) : fresh->in_off.alloc(((size_t)n + 1) * 4));
-                GM_TRY((arena_mask & 4) ? fresh->in_edge.alloc_big((size_t)g->m * 8) : fresh->in_edge.alloc((size_t)g->m * 8));
+                if (!fresh->in_off.p)
+                    GM_TRY((arena_mask & 8) ? fresh->in_off.alloc_scratch(((size_t)n + 1) * 4) : fresh->in_off.alloc(((size_t)n + 1) * 4));
+                if (!fresh->in_edge.p)
+                    GM_TRY((arena_mask & 4) ? fresh->in_edge.alloc_big((size_t)g->m * 8) : fresh->in_edge.alloc((size_t)g->m * 8));
                 GM_TRY(tgt_sorted.alloc_scratch((size_t)g->m * 4));
                 size_t temp_bytes = 0;
                 GM_HIP(rocprim::radix_sort_pairs(nullptr, temp_bytes, g->targets, tgt_sorted.as<uint32_t>(), key.as<unsigned long long>(),

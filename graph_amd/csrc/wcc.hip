@@ -39,19 +39,6 @@ __device__ __forceinline__ void af_link_from(uint32_t *parent, uint32_t p1, uint
     }
 }
 
-// the same for nodes a, b whose parents pa, pb have just been loaded: when the higher of the two parents is a or b itself and
-// was its own parent a moment ago — nearly every union of the sampling phase: the forest starts as n roots — the first
-// `parent[high]` is known and the union is ONE round trip (the CAS) instead of two
-__device__ __forceinline__ void af_link_known(uint32_t *parent, uint32_t a, uint32_t pa, uint32_t b, uint32_t pb)
-{
-    if (pa == pb)
-        return;
-    const uint32_t high = pa > pb ? pa : pb, low = pa + pb - high;
-    if (((high == a && pa == a) || (high == b && pb == b)) && atomicCAS(&parent[high], high, low) == high)
-        return;
-    af_link_from(parent, pa, pb);
-}
-
 __device__ __forceinline__ void af_link(uint32_t *parent, uint32_t u, uint32_t v)
 {
     const uint32_t p1 = ld_agent(&parent[u]);
@@ -81,51 +68,20 @@ __global__ void wcc_compress_kernel(uint32_t *parent, uint32_t n)
     }
 }
 
-// wcc.rs:186-204: link u with its first `rounds` out-neighbours.
-// One lane per node was a chain of dependent random accesses per node (offsets -> first target -> parent[u], parent[v] ->
-// parent[high] -> CAS, then the same for the second target): 23 M L2 requests in 0.26 ms at scale 22, 62 % of the call's
-// kernel time (profiles/algos_traffic.json, round 5).  Round 6: a lane takes WCC_SAMPLE_U nodes at a time and BOTH sampled
-// targets of each, and every level of the chain is loaded for all of them before the next level is touched — offsets,
-// then up to 2 x U targets, then 3 x U parents — so 8 to 24 independent requests per lane are in flight where there was one —
-// and a union of two nodes that were roots a moment ago goes straight to its CAS (af_link_known).
-// The unions are the same ones; their order never matters (module header).
-constexpr int WCC_SAMPLE_U = 8;
-__global__ __launch_bounds__(WCC_BLOCK) void wcc_sample_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt,
-                                                               uint32_t *parent, uint32_t n, uint64_t rounds)
+// wcc.rs:186-204: link u with its first `rounds` out-neighbours
+// (Round 6 measured two ways of putting more of a node's chain of dependent accesses in flight — 4 or 8 nodes per lane with
+// every level of the chain loaded for all of them before the next, and unions of two known roots going straight to their CAS:
+// 257 -> 257 / 330 us at scale 22, tools/runs/r06_call05.sh / r06_call06.sh.  The kernel is bound by the number of random
+// 128-byte transactions and device-scope atomics, not by their latency; a CAS that fails costs more than the load it replaced.)
+__global__ void wcc_sample_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ tgt,
+                                  uint32_t *parent, uint32_t n, uint64_t rounds)
 {
-    constexpr int U = WCC_SAMPLE_U;
     const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint64_t base = blockIdx.x * blockDim.x + threadIdx.x; base < n; base += (uint64_t)stride * U) {
-        uint32_t u[U], s[U], take[U], v0[U], v1[U], pu[U], p0[U], p1[U];
-#pragma unroll
-        for (int k = 0; k < U; ++k) {
-            const uint64_t uu = base + (uint64_t)k * stride;
-            const bool in = uu < n;
-            u[k] = in ? (uint32_t)uu : 0u;
-            s[k] = in ? off[u[k]] : 0u;
-            const uint32_t e = in ? off[u[k] + 1] : 0u;
-            take[k] = (uint64_t)(e - s[k]) < rounds ? e - s[k] : (uint32_t)rounds;
-        }
-#pragma unroll
-        for (int k = 0; k < U; ++k) {
-            v0[k] = take[k] >= 1u ? tgt[s[k]] : u[k]; // (u itself: a union that does nothing)
-            v1[k] = take[k] >= 2u ? tgt[s[k] + 1u] : u[k];
-        }
-#pragma unroll
-        for (int k = 0; k < U; ++k) {
-            pu[k] = ld_agent(&parent[u[k]]);
-            p0[k] = ld_agent(&parent[v0[k]]);
-            p1[k] = ld_agent(&parent[v1[k]]);
-        }
-#pragma unroll
-        for (int k = 0; k < U; ++k) {
-            if (take[k] >= 1u)
-                af_link_known(parent, u[k], pu[k], v0[k], p0[k]);
-            if (take[k] >= 2u) // (pu may be stale by now — the first union may have moved u's root: still a node of u's tree)
-                af_link_known(parent, u[k], pu[k], v1[k], p1[k]);
-            for (uint32_t j = 2; j < take[k]; ++j) // (neighbor_rounds > 2: the rest one after the other)
-                af_link(parent, u[k], tgt[s[k] + j]);
-        }
+    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += stride) {
+        const uint32_t s = off[u], e = off[u + 1];
+        const uint64_t take = (uint64_t)(e - s) < rounds ? (uint64_t)(e - s) : rounds;
+        for (uint64_t k = 0; k < take; ++k)
+            af_link(parent, u, tgt[s + k]);
     }
 }
 

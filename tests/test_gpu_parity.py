@@ -279,6 +279,46 @@ def test_page_rank_converged_matches_reference_order(P, oracle, scale):
     assert 1 <= it_d <= 20 and (err_d < 1e-4 or it_d == 20)
 
 
+@pytest.mark.parametrize("scale,layout", [(15, "Sorted"), (18, "Sorted"), (18, "Unsorted")])
+def test_page_rank_block_gauss_seidel_same_fixed_point_fewer_sweeps(P, oracle, monkeypatch, scale, layout):
+    """GM_PR_BLOCK_GS (the default call on the propagation-blocking engine since round 6): row blocks in ascending order, a block
+    sees this sweep's out_scores of the blocks before it — the reference's in-place update (page_rank.rs:142-160) at block
+    granularity.  Same fixed point as the synchronous sweeps and as the reference's threaded path (1e-5 on every row), in
+    fewer sweeps, deterministic, for every number of blocks; calls of different modes on one handle do not see each other."""
+    lay = getattr(P.CsrLayout, layout)
+    s, d = oracle.rmat_edges(scale, seed=42)
+    n = 1 << scale
+    g = _directed(P, n, s, d, lay)
+    ioff, itgt, _ = g.csr_inc.host()
+    od = oracle.out_degrees_from(n, s)
+    cfg = P.PageRankConfig(200, 1e-10, 0.85)
+    ref, it_ref, _ = oracle.page_rank_chunked(ioff, itgt, od, 200, 1e-10, 0.85)
+    jac, it_jac, _ = P.page_rank(g, cfg, P.PageRankMode.JacobiPB)
+    gs, it_gs, err_gs = P.page_rank(g, cfg, P.PageRankMode.BlockGS)
+    again, it_again, err_again = P.page_rank(g, cfg, P.PageRankMode.BlockGS)
+    assert np.array_equal(gs, again) and it_gs == it_again and err_gs == err_again
+    rel = np.abs(gs.astype(np.float64) - ref) / ref
+    print(f"scale {scale} {layout}: block-GS {it_gs} sweeps, synchronous {it_jac}, reference {it_ref}; max rel vs the reference {rel.max():.2e}")
+    assert rel.max() <= 1e-5, rel.max()
+    assert it_gs < it_jac or n < 4 * 16384   # (two blocks of a 32768-node graph gain little)
+    jac2, it_jac2, _ = P.page_rank(g, cfg, P.PageRankMode.JacobiPB)   # the parked engine serves both kinds of sweep
+    assert np.array_equal(jac, jac2) and it_jac == it_jac2
+    for blocks in ("2", "5", "64"):
+        monkeypatch.setenv("GM_PR_BLOCK_GS", blocks)
+        monkeypatch.setenv("GM_PB_NOCACHE", "1")                     # (the parked engine's row blocks belong to the default K)
+        got, it, _ = P.page_rank(g, cfg, P.PageRankMode.BlockGS)
+        relb = np.abs(got.astype(np.float64) - ref) / ref
+        assert relb.max() <= 1e-5, (blocks, relb.max())
+        assert it <= it_jac
+    monkeypatch.delenv("GM_PR_BLOCK_GS")
+    monkeypatch.delenv("GM_PB_NOCACHE")
+    # the stop rule (page_rank.rs:105-109) and a fixed number of sweeps
+    one = P.page_rank(g, P.PageRankConfig(1, 1e-4, 0.85), P.PageRankMode.BlockGS)
+    assert one[1] == 1
+    five = P.page_rank(g, P.PageRankConfig(5, 0.0, 0.85), P.PageRankMode.BlockGS)
+    assert five[1] == 5 and 0.0 < float(five[0].astype(np.float64).sum()) <= 1.0 + 1e-6
+
+
 def test_page_rank_calls_on_one_handle_do_not_see_each_other(P, oracle):
     """gm_page_rank parks its stream, vectors and engine in the in-CSR's handle.  A sequence of calls that changes
     the mode (another engine), the damping factor, the iteration count and the tolerance on ONE graph object must
