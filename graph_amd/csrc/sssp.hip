@@ -890,11 +890,13 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
         if (atoi(v) >= 1 && atoi(v) <= (int)SSSP_COOP)
             coop = (uint32_t)atoi(v);
     // GM_SSSP_ARENA=<mask>: which buffers come from the arena — 1 the call's scratch, 2 the kept weight-ordered lists, 4 / 8 the
-    // transposed lists (in_edge / in_off), 16: those two allocated before the build's first temporary is released.  Default 15.
-    // (With round 5's in-bounds kernel — thread i filling in_off over (sorted_tgt[i - 1], sorted_tgt[i]] — masks with the
-    // transposed lists in the arena died of a GPU memory fault in the build's second half, every time, at the same offset
-    // (tools/runs/r06_call04.sh: 7 / 6 / 5 faulted, 3 / 0 did not); with in_off filled by a scan they do not (r06_call06.sh).)
-    const int arena_mask = getenv("GM_SSSP_ARENA") ? atoi(getenv("GM_SSSP_ARENA")) : 15;
+    // transposed lists (in_edge / in_off), 16: those two allocated before the build's first temporary is released.  Default 3:
+    // with BOTH transposed lists mapped from arena pieces the build's second half dies of a GPU memory fault — every time (8 runs
+    // of 8: tools/runs/r06_call04.sh, r06_call07.sh; with either one alone 2 of 2 passed, r06_call06.sh; with neither every run of
+    // the round).  The pieces and the address range of a temporary the first half has just released are what they get (LIFO,
+    // exact-size reuse); every access of both buffers is bounds-checked and the same buffers from hipMalloc have never faulted.
+    // Not understood; they stay on hipMalloc.
+    const int arena_mask = getenv("GM_SSSP_ARENA") ? atoi(getenv("GM_SSSP_ARENA")) : 3;
     std::unique_ptr<gm::SsspScratch> sc;
     {
         std::lock_guard<std::mutex> lock(g->cache_mu);

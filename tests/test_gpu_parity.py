@@ -279,6 +279,7 @@ def test_page_rank_converged_matches_reference_order(P, oracle, scale):
     assert 1 <= it_d <= 20 and (err_d < 1e-4 or it_d == 20)
 
 
+@pytest.mark.hub_order
 @pytest.mark.parametrize("scale,layout", [(15, "Sorted"), (18, "Sorted"), (18, "Unsorted")])
 def test_page_rank_block_gauss_seidel_same_fixed_point_fewer_sweeps(P, oracle, monkeypatch, scale, layout):
     """GM_PR_BLOCK_GS (the default call on the propagation-blocking engine since round 6): row blocks in ascending order, a block
