@@ -890,13 +890,15 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
         if (atoi(v) >= 1 && atoi(v) <= (int)SSSP_COOP)
             coop = (uint32_t)atoi(v);
     // GM_SSSP_ARENA=<mask>: which buffers come from the arena — 1 the call's scratch, 2 the kept weight-ordered lists, 4 / 8 the
-    // transposed lists (in_edge / in_off), 16: those two allocated before the build's first temporary is released.  Default 3:
-    // with BOTH transposed lists mapped from arena pieces the build's second half dies of a GPU memory fault — every time (8 runs
-    // of 8: tools/runs/r06_call04.sh, r06_call07.sh; with either one alone 2 of 2 passed, r06_call06.sh; with neither every run of
-    // the round).  The pieces and the address range of a temporary the first half has just released are what they get (LIFO,
-    // exact-size reuse); every access of both buffers is bounds-checked and the same buffers from hipMalloc have never faulted.
-    // Not understood; they stay on hipMalloc.
-    const int arena_mask = getenv("GM_SSSP_ARENA") ? atoi(getenv("GM_SSSP_ARENA")) : 3;
+    // transposed lists (in_edge / in_off) allocated where the transposition starts, 16 the transposed lists allocated BEFORE the
+    // build's first temporary is released.  Default 19 = 1 + 2 + 16: no hipMalloc in a plan build (its 4 GB at scale 24 waited
+    // for the driver to clear what other processes had freed: 161 ms instead of 41 on the driver's box in round 5).
+    // Why 16 and not 4 + 8: with BOTH transposed lists mapped at the transposition's start — into the pieces and the address
+    // ranges the build's first half has just released (LIFO, exact-size reuse) — the second sort dies of a GPU memory fault, every
+    // time (9 runs of 9: tools/runs/r06_call04.sh, r06_call07.sh, r06_call10.sh; either one alone 2 of 2 passed; allocated up
+    // front 4 of 4 passed, bit-exact).  Every access of both buffers is bounds-checked and the same code on hipMalloc'd buffers
+    // has never faulted: a runtime problem with that unmap / map sequence, not understood further.
+    const int arena_mask = getenv("GM_SSSP_ARENA") ? atoi(getenv("GM_SSSP_ARENA")) : 19;
     std::unique_ptr<gm::SsspScratch> sc;
     {
         std::lock_guard<std::mutex> lock(g->cache_mu);
@@ -933,6 +935,8 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
         GM_TRY(sc->hctrl.alloc(C_WORDS * 4));
         GM_TRY((arena_mask & 1) ? sc->chunks.alloc_scratch(items * sizeof(uint2)) : sc->chunks.alloc(items * sizeof(uint2)));
         sc->items = items;
+        if (times)
+            fprintf(stderr, "sssp: the call's buffers allocated after %.3f ms\n", since(t_call));
     }
     // The lists once more, ordered by weight and transposed (~20 B per edge, released by gm_csr_trim):
     // a long list is relaxed in two parts — while its phase is busy only the edges that land at or below the threshold,
@@ -962,7 +966,7 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
         // rest); a build that did not happen is remembered in the handle (until gm_csr_trim) instead of retried by every call.
         if (!order && build_lock.owns_lock() && !g->sssp_order_failed.load(std::memory_order_relaxed)) {
             size_t free_b = 0, total_b = 0;
-            const size_t need = (size_t)g->m * 36 + ((size_t)n + 1) * 4;
+            const size_t need = (size_t)g->m * ((arena_mask & 16) ? 44 : 36) + ((size_t)n + 1) * 4; // (the transposed lists up front: 8 B per edge earlier)
             uint64_t arena_b[4] = {0, 0, 0, 0}; // the arena's idle pieces do not show up as free memory, and serve every buffer below
             if (gm::arena_enabled())
                 gm::arena_stats(g->device, arena_b);
@@ -1144,7 +1148,10 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
     GM_HIP(hipMemsetAsync(wmin.p, 0xFF, wmin.bytes, st));
     GM_HIP(hipMemsetAsync(wmin.as<uint32_t>() + (start_node >> 5), 0, 4, st)); // the start node's distance: 0.0
     GM_HIP(hipMemcpyAsync(hctrl.p, ctrl.p, C_WORDS * 4, hipMemcpyDeviceToHost, st));
+    const double ms_enqueued = since(t_call);
     GM_HIP(hipStreamSynchronize(st));
+    if (times)
+        fprintf(stderr, "sssp: initialisation enqueued after %.3f ms, done after %.3f ms\n", ms_enqueued, since(t_call));
     GM_CHECK(hctrl.as<uint32_t>()[C_BAD] == 0, GM_ERR_UNSUPPORTED,
              "gm_sssp_delta_stepping: negative or NaN edge weight (the reference assumes weights >= 0)");
     if (check_weights)
