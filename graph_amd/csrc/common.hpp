@@ -80,6 +80,17 @@ struct ArenaPiece {
     hipMemGenericAllocationHandle_t handle;
     uint64_t serial; // creation order
 };
+// HIP loads the code object of a translation unit when the first kernel of it is launched: ~10 ms each for the larger ones,
+// which made every algorithm's FIRST call on a process pay for its own (SSSP: 9.7 of a first call's 10.4 ms of set-up were the
+// launch of its first kernel, tools/runs/r06_call11.sh).  The handle constructors load all of them once, where a graph is being
+// built or uploaded anyway (GM_WARM=0: as before).
+void warm_code_objects();
+void warm_pagerank();
+void warm_pagerank_pb();
+void warm_wcc();
+void warm_sssp();
+void warm_tc();
+void warm_multi();
 bool arena_enabled(); // GM_ARENA=0: every buffer from hipMalloc
 inline int &arena_site() // which part of the library is allocating (1 CSR build, 2 plan temporaries, 4 plan streams, 8 value stream)
 {

@@ -52,6 +52,7 @@ using namespace gm;
 
 int new_owned_csr(uint64_t n, uint64_t m, bool weighted, int device, gm_csr **out)
 {
+    gm::warm_code_objects(); // (once per process)
     gm_csr *c = new (std::nothrow) gm_csr();
     GM_CHECK(c, GM_ERR_NOMEM, "out of host memory");
     c->n = n;
@@ -132,6 +133,24 @@ int validate_csr_arrays(const uint32_t *d_off, const uint32_t *d_tgt, uint64_t n
 
 } // namespace
 
+namespace gm {
+void warm_code_objects()
+{
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *v = getenv("GM_WARM");
+        if (v && *v == '0')
+            return;
+        warm_pagerank();
+        warm_pagerank_pb();
+        warm_wcc();
+        warm_sssp();
+        warm_tc();
+        warm_multi();
+    });
+}
+} // namespace gm
+
 GM_API int gm_csr_upload_u32(const uint32_t *offsets, const uint32_t *targets, const float *weights, uint64_t n,
                              uint64_t m, int device, gm_csr **out)
 {
@@ -200,6 +219,7 @@ GM_API int gm_csr_wrap_device(uint64_t d_offsets, uint64_t d_targets, uint64_t d
         GM_TRY(validate_csr_arrays(reinterpret_cast<const uint32_t *>(d_offsets), reinterpret_cast<const uint32_t *>(d_targets),
                                    n, m, "gm_csr_wrap_device"));
     }
+    gm::warm_code_objects(); // (once per process)
     gm_csr *c = new (std::nothrow) gm_csr();
     GM_CHECK(c, GM_ERR_NOMEM, "out of host memory");
     c->n = n;

@@ -867,3 +867,12 @@ GM_API int gm_page_rank_multi_slices(const gm_csr *const *in_slices, const uint6
     GM_TRY(multi_build_from(in, b32, (uint32_t)n, devs, distinct, damping_factor, engine, K, &ms));
     return multi_run(*ms, max_iterations, tolerance, scores_out, iterations_out, error_out);
 }
+
+namespace gm {
+void warm_multi() // (common.hpp: the code object of this file, loaded ahead of an algorithm's first call)
+{
+    hipFuncAttributes attr;
+    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&mg_has_out_degree_kernel)) != hipSuccess)
+        (void)hipGetLastError();
+}
+} // namespace gm

@@ -976,3 +976,12 @@ GM_API int gm_page_rank_directed(const gm_csr *out_csr, const gm_csr *in_csr, ui
     return page_rank_impl(in_csr, nullptr, out_csr, max_iterations, tolerance, damping_factor, mode, scores_out,
                           iterations_out, error_out);
 }
+
+namespace gm {
+void warm_pagerank() // (common.hpp: the code object of this file, loaded ahead of an algorithm's first call)
+{
+    hipFuncAttributes attr;
+    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&pr_init_kernel)) != hipSuccess)
+        (void)hipGetLastError();
+}
+} // namespace gm

@@ -4178,4 +4178,11 @@ int pb_sweep_error(const PbPlan *pl, PbScratch *sc, double *err_out, hipStream_t
     return GM_OK;
 }
 
+void warm_pagerank_pb() // (common.hpp: the code object of this file, loaded ahead of the first plan build)
+{
+    hipFuncAttributes attr;
+    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&pb_hot_gather_kernel)) != hipSuccess)
+        (void)hipGetLastError();
+}
+
 } // namespace gm

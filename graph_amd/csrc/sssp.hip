@@ -1268,3 +1268,12 @@ GM_API int gm_sssp_relax_rows(const gm_csr *out_rows, uint64_t row_begin, uint64
     GM_HIP(hipGetLastError());
     return GM_OK;
 }
+
+namespace gm {
+void warm_sssp() // (common.hpp: the code object of this file, loaded ahead of an algorithm's first call)
+{
+    hipFuncAttributes attr;
+    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&sssp_init_kernel)) != hipSuccess)
+        (void)hipGetLastError();
+}
+} // namespace gm

@@ -824,3 +824,12 @@ GM_API int gm_triangle_count(const gm_csr *g, uint64_t *triangles_out)
     *triangles_out = total;
     return GM_OK;
 }
+
+namespace gm {
+void warm_tc() // (common.hpp: the code object of this file, loaded ahead of an algorithm's first call)
+{
+    hipFuncAttributes attr;
+    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&tc_order_kernel)) != hipSuccess)
+        (void)hipGetLastError();
+}
+} // namespace gm

@@ -415,3 +415,12 @@ GM_API int gm_wcc_link_rows(const gm_csr *out_rows, const gm_csr *in_rows, uint6
     GM_HIP(hipGetLastError());
     return GM_OK;
 }
+
+namespace gm {
+void warm_wcc() // (common.hpp: the code object of this file, loaded ahead of an algorithm's first call)
+{
+    hipFuncAttributes attr;
+    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&wcc_init_kernel)) != hipSuccess)
+        (void)hipGetLastError();
+}
+} // namespace gm
