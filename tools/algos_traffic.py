@@ -14,7 +14,9 @@ sha = hashlib.sha256(open(lib, "rb").read()).hexdigest()
 LABELS = {"wcc": "wcc steady", "sssp": "sssp steady (call 3+)", "tc": "tc steady"}
 OURS = ("wcc_", "sssp_", "tc_")
 out = {"library_sha256": sha, "measured": note,
-       "corrections": "FETCH_SIZE x 2 (128-byte requests tallied as 64 on gfx950), WRITE_SIZE as reported; KiB -> bytes"}
+       "corrections": "FETCH_SIZE x 2 (128-byte requests tallied as 64 on gfx950: calibrated for these kernels' access patterns — random "
+                      "128-byte records, random 4-byte probes plain and sc1, 8 B/lane streams — in profiles/r06_fetch_size_calibration.txt), "
+                      "WRITE_SIZE as reported (a random 4-byte store = one 32-byte write request); KiB -> bytes"}
 for key, label in LABELS.items():
     seg = prof.get(label)
     if not seg or "counters" not in seg:

@@ -134,9 +134,14 @@ def measure(args):
         t_first, _ = timed(lambda: P.page_rank(g, cfg), reps=1)
         t_next, res = timed(lambda: P.page_rank(g, cfg), reps=3)
         t_def, res_d = timed(lambda: P.page_rank(g, P.PageRankConfig()), reps=2)
+        # (Auto = block-Gauss-Seidel sweeps on the propagation-blocking engine since round 6; the synchronous ones beside them)
+        t_jac, res_j = timed(lambda: P.page_rank(g, cfg, P.PageRankMode.JacobiPB), reps=3)
+        t_jdef, res_jd = timed(lambda: P.page_rank(g, P.PageRankConfig(), P.PageRankMode.JacobiPB), reps=2)
         out["page_rank_api"] = {"scale": sc, "first_call_ms": t_first * 1e3, "next_call_ms": t_next * 1e3,
                                 "sweeps": res[1], "default_config_ms": t_def * 1e3, "default_config_sweeps": res_d[1],
-                                "default_config_error": res_d[2]}
+                                "default_config_error": res_d[2], "synchronous_20_sweeps_ms": t_jac * 1e3,
+                                "synchronous_default_config_ms": t_jdef * 1e3, "synchronous_default_config_sweeps": res_jd[1],
+                                "synchronous_default_config_error": res_jd[2]}
         del g
         torch.cuda.empty_cache()
 

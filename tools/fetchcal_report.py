@@ -13,7 +13,7 @@ for db in sorted(glob.glob(os.path.join(sys.argv[1], "**", "*.db"), recursive=Tr
     cols = [r[1] for r in c.execute("pragma table_info(counters_collection)")]
     key = "dispatch_id" if "dispatch_id" in cols else "id"
     for d, k, cn, v in c.execute(f"select {key}, kernel_name, counter_name, value from counters_collection order by {key}"):
-        name = next((n for n in KNOWN if k.startswith(n.split("<")[0]) and (("<" not in n) or (n.split("<")[1][:-1] in k))), None)
+        name = next((n for n in KNOWN if n.split("<")[0] + ("<" if "<" in n else "(") in k.replace(" ", "") and (("<" not in n) or ("<" + n.split("<")[1] in k.replace(" ", "")))), None)
         if name:
             rows.setdefault(name, {}).setdefault(cn, {}).setdefault(d, 0.0)
             rows[name][cn][d] += v
