@@ -21,6 +21,7 @@ for k in ('wcc','sssp','tc'): print(k, round(d[k]['ms'],3), 'best', round(d[k]['
 print(d.get('page_rank_api'))"
 for s in 22 24; do timeout 300 python bench.py --cpu-sweeps 0 --algos 0 --scale $s > $OUT/bench_scale$s.json 2>/dev/null; python -c "
 import json; d=json.loads(open('$OUT/bench_scale$s.json').read().strip().splitlines()[-1]); print('scale $s ms', d['ms_per_step'], 'GTEPS', d['value'], 'frac', d['roofline']['frac'])"; done
+timeout -s KILL 300 rocprofv3 --kernel-trace -d $OUT/t26 -o t -- python bench.py --cpu-sweeps 0 --algos 0 > $OUT/t26.log 2>&1; python tools/timeline.py $OUT/t26 2 > $OUT/timeline26.txt 2>&1; cat $OUT/timeline26.txt | cut -c1-100
 timeout -s KILL 300 rocprofv3 --kernel-trace -d $OUT/t22 -o t -- python bench.py --scale 22 --cpu-sweeps 0 --algos 0 > $OUT/t22.log 2>&1; python tools/timeline.py $OUT/t22 2 > $OUT/timeline22.txt 2>&1; cat $OUT/timeline22.txt | cut -c1-100
 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -1 $OUT/bench.json | python -c "import sys, json; d = json.loads(sys.stdin.read()); print('default:', d['ms_per_step'], d['roofline']['frac'], d['roofline']['traffic'], d['config']['value_stream_placement'].get('level'), d['config']['parity']['max_rel_vs_reference'], {k: (v.get('ms'), v.get('bit_exact'), v['roofline'].get('frac'), v['roofline'].get('traffic'), v.get('ms_result_left_on_device')) for k, v in d['extra'].items() if isinstance(v, dict)})"
 find $OUT -name "*.db" -delete
