@@ -335,15 +335,24 @@ def main():
             ex.sweep(scores, err, timed_events)
             return
         out_local = x[1 - cur] if world == 1 else x_loc
+        # one rank: the whole sweep through gm_pr_sweep, error included — on the propagation-blocking engine the error comes out of
+        # the sweep's own launches (round 6: no pb_err_kernel; until then sweep_tiles + sweep_fixup, the events around the first)
+        whole = world == 1
         if timed_events is not None:
             pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             pair[0].record()
-            engine.sweep_tiles(x[cur], out_local, scores)
+            if whole:
+                engine.sweep(x[cur], out_local, scores, err)
+            else:
+                engine.sweep_tiles(x[cur], out_local, scores)
             pair[1].record()
             timed_events.append(pair)
+        elif whole:
+            engine.sweep(x[cur], out_local, scores, err)
         else:
             engine.sweep_tiles(x[cur], out_local, scores)
-        engine.sweep_fixup(out_local, scores, err)
+        if not whole:
+            engine.sweep_fixup(out_local, scores, err)
         if world > 1:
             exchange(x[1 - cur])
         cur = 1 - cur
