@@ -866,7 +866,11 @@ static int page_rank_impl(const gm_csr *in_csr, const uint32_t *out_degree, cons
     // (pb_set_parts(.., hub_by_part): with all of them summed beside block 0 from the last sweep's values, the rows that carry
     // most of the error converged at the synchronous rate — 20 iterations at scale 22 instead of 16).  Every row's equation is
     // the one of page_rank.rs:143-159, only WHICH sweep's value a term carries differs — as it does between two runs of the
-    // reference itself.  Deterministic; same fixed point.  K = 16 blocks (GM_PR_BLOCK_GS=K).
+    // reference itself.  Deterministic; same fixed point.  K = 8 blocks (GM_PR_BLOCK_GS=K): every block costs a hub launch whose
+    // lane walks are a fixed ~0.1 ms (scale 22) to ~0.35 ms (scale 26) of latency, and every halving of K one iteration more —
+    // measured with PageRankConfig::default() (tools/runs/r06_call15.sh): scale 22 K = 16 / 8 / 4: 15 / 16 / 17 iterations in
+    // 31 / 17 / 11 ms (reference: 14 iterations; synchronous sweeps: out of their 20 in 4.7 ms); scale 26: 14 / 14 / 15
+    // iterations in 118 / 73 / 54 ms (synchronous: 20 in 66 ms).
     std::vector<uint64_t> gs_splits;
     {
         const char *gs_env_s = getenv("GM_PR_BLOCK_GS");
@@ -876,7 +880,7 @@ static int page_rank_impl(const gm_csr *in_csr, const uint32_t *out_degree, cons
         if (want)
             GM_TRY(gm_pr_part_geometry(ph.p, &rows_per_bin, &tile));
         const uint64_t tiles = tile ? (n + tile - 1) / tile : 0;
-        uint64_t K = gs_env > 1 ? (uint64_t)gs_env : 16;
+        uint64_t K = gs_env > 1 ? (uint64_t)gs_env : 8;
         if (K > 64)
             K = 64;
         if (K > tiles)

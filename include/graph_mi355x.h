@@ -165,7 +165,7 @@ typedef enum gm_pr_mode {
                                  order, exactly like page_rank.rs:143-146 (one lane per row: a parity
                                  instrument, not a fast path) */
     GM_PR_BLOCK_GS = 6 /* block-Gauss-Seidel sweeps on the propagation-blocking engine: K row blocks (GM_PR_BLOCK_GS=K,
-                          default 16) in ascending order, block j sees this sweep's out_scores of the blocks before it —
+                          default 8) in ascending order, block j sees this sweep's out_scores of the blocks before it —
                           the reference's in-place update (page_rank.rs:142-160) at block granularity, deterministic.
                           About half the iterations of the synchronous sweeps for the same error; same fixed point.
                           GM_PR_AUTO runs these whenever it picks the propagation-blocking engine (GM_PR_BLOCK_GS=0:
