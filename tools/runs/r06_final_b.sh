@@ -25,3 +25,5 @@ timeout -s KILL 300 rocprofv3 --kernel-trace -d $OUT/t26 -o t -- python bench.py
 timeout -s KILL 300 rocprofv3 --kernel-trace -d $OUT/t22 -o t -- python bench.py --scale 22 --cpu-sweeps 0 --algos 0 > $OUT/t22.log 2>&1; python tools/timeline.py $OUT/t22 2 > $OUT/timeline22.txt 2>&1; cat $OUT/timeline22.txt | cut -c1-100
 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -1 $OUT/bench.json | python -c "import sys, json; d = json.loads(sys.stdin.read()); print('default:', d['ms_per_step'], d['roofline']['frac'], d['roofline']['traffic'], d['config']['value_stream_placement'].get('level'), d['config']['parity']['max_rel_vs_reference'], {k: (v.get('ms'), v.get('bit_exact'), v['roofline'].get('frac'), v['roofline'].get('traffic'), v.get('ms_result_left_on_device')) for k, v in d['extra'].items() if isinstance(v, dict)})"
 find $OUT -name "*.db" -delete
+timeout 600 python tools/bench_algos.py --skip wcc,sssp,tc --prapi-scale 26 --oracle 0 > $OUT/prapi26.json 2> $OUT/prapi26.err; python -c "
+import json; print(json.load(open('$OUT/prapi26.json'))['page_rank_api'])"
