@@ -85,7 +85,8 @@ def test_scale22_default_config_stops_on_the_tolerance_like_the_reference(env, o
     print(f"default config, scale 22: device {it_g} iterations (error {err_g:.3e}), reference {it_r} (error {err_r:.3e}); "
           f"results max rel {rel.max():.2e}, L1 {l1:.2e}")
     assert it_r < 20 and err_r < 1.0e-4                 # the reference's in-place sweeps stop on the tolerance
-    assert it_g <= 16 and err_g < 1.0e-4                # ... and so does the default call (<= 16)
+    assert it_g <= 16 and err_g < 1.0e-4                # ... and so does the default call (<= 16; measured 16 with
+                                                        # the 8 blocks that ship, 15 with 16 blocks at twice the time per call)
     assert rel.max() <= 2e-4, rel.max()                 # two iterates stopped by the same rule, a different schedule each
     # the explicit mode is the same thing
     gs, it_gs, err_gs = P.page_rank(g, P.PageRankConfig(), P.PageRankMode.BlockGS)
