@@ -91,6 +91,12 @@ void warm_wcc();
 void warm_sssp();
 void warm_tc();
 void warm_multi();
+// an environment variable that only measurements ever set (A/B records: CHANGELOG.md): absent in the product library
+#ifdef GM_MEASURE
+inline const char *measure_env(const char *name) { return getenv(name); }
+#else
+inline const char *measure_env(const char *) { return nullptr; }
+#endif
 bool arena_enabled(); // GM_ARENA=0: every buffer from hipMalloc
 inline int &arena_site() // which part of the library is allocating (1 CSR build, 2 plan temporaries, 4 plan streams, 8 value stream)
 {

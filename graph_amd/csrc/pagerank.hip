@@ -907,7 +907,7 @@ static int page_rank_impl(const gm_csr *in_csr, const uint32_t *out_degree, cons
                     gs_splits[j] = hi * tile < n ? hi * tile : n;
                 }
                 // (GM_PR_GS_HUBS=0, measurements: every hub row beside block 0, from the last sweep's values — round 6's first version)
-                const bool hubs_by_block = !(getenv("GM_PR_GS_HUBS") && atoi(getenv("GM_PR_GS_HUBS")) == 0);
+                const bool hubs_by_block = !(gm::measure_env("GM_PR_GS_HUBS") && atoi(gm::measure_env("GM_PR_GS_HUBS")) == 0);
                 GM_TRY(gm::pb_set_parts(ph.p->pb, ph.p->pb_scratch, gs_splits.data(), (uint32_t)K, hubs_by_block));
                 std::vector<uint64_t> lo(gs_splits.begin(), gs_splits.end() - 1), hi(gs_splits.begin() + 1, gs_splits.end());
                 std::vector<uint32_t> reg(K);

@@ -2244,6 +2244,15 @@ __global__ __launch_bounds__(1024) void pb_err_kernel(const double *__restrict__
         *err_out = total;
 }
 
+// Knobs that only measurements ever set (their A/B records: CHANGELOG.md) are compiled out of the product library: they read
+// as their defaults there (round 6: the product library had grown ~80 environment variables).
+#ifdef GM_MEASURE
+#define pb_env_m(name, dflt) pb_env(name, dflt)
+#define pb_getenv_m(name) getenv(name)
+#else
+#define pb_env_m(name, dflt) (dflt)
+#define pb_getenv_m(name) (static_cast<const char *>(nullptr))
+#endif
 // tuning knobs (environment, read once): GM_PB_ABLATE measurement variants, GM_PB_CHUNK=<entries> phase-1
 // workgroup size (0 = automatic), GM_PB_ORDER=0/1 longest-bin-first dispatch, GM_PB_RB=<log2 rows per bin>
 int pb_env(const char *name, int dflt)
@@ -2386,7 +2395,7 @@ int pb_make_items(PbPlan *pl)
         }
         slots += parts;
     }
-    if (pb_env("GM_PB_ORDER", 1))
+    if (pb_env_m("GM_PB_ORDER", 1))
         std::stable_sort(items.begin(), items.end(),
                          [](const PbItem &a, const PbItem &c) {
                              return (uint64_t)(a.q1 - a.q0) + (a.h1 - a.h0) > (uint64_t)(c.q1 - c.q0) + (c.h1 - c.h0);
@@ -2528,8 +2537,8 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
             uint64_t target = (uint64_t)m_all / pl->B;
             if (target < 65536)
                 target = 65536;
-            if (pb_env("GM_PB_HUB_GROUP", 0) > 0)
-                target = (uint64_t)pb_env("GM_PB_HUB_GROUP", 0);
+            if (pb_env_m("GM_PB_HUB_GROUP", 0) > 0)
+                target = (uint64_t)pb_env_m("GM_PB_HUB_GROUP", 0);
             // Which rows are "long"?  A row walked by one lane of pb_hubseq_kernel costs ~6 ns per term, all of it latency (a
             // chain of dependent adds); pb_hublong_kernel sums a row of 10^4 terms in ~15 us and one of 10^6 in ~100, but
             // keeps a 512-thread workgroup busy with vector work.  So: rows of at least 8192 in-edges, but not more than
@@ -2599,7 +2608,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
         pl->Racc = (mx + 63u) & ~63u;
         if (pl->Racc > pl->R)
             pl->Racc = pl->R;
-        if (pb_env("GM_PB_COMPACT", 1) == 0)
+        if (pb_env_m("GM_PB_COMPACT", 1) == 0)
             pl->Racc = pl->R; // keep the slot numbering, size the LDS as if every row had one
     } else {
         GM_TRY(pl->hub_first.alloc(4));
@@ -2616,13 +2625,13 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     {
         const size_t acc_bytes = (size_t)pl->Racc * 8 + 16; // + the accumulator the padding entries go to
         int wgs = acc_bytes > 65536 ? 1 : 2; // accumulate workgroups per CU the LDS request should allow
-        if (pb_env("GM_PB_WGS", 0) == 1 || (pb_env("GM_PB_WGS", 0) == 0 && acc_bytes > 32768))
+        if (pb_env_m("GM_PB_WGS", 0) == 1 || (pb_env_m("GM_PB_WGS", 0) == 0 && acc_bytes > 32768))
             wgs = 1;
         // static LDS of the accumulate kernel: PB_ACC_STATIC; with hub groups, room for one pb_hubseq_kernel workgroup
         // and one pb_hublong_kernel workgroup (21.5 KiB together) beside the accumulate workgroup(s) of a CU
         size_t hub_room = (pl->G && pb_env("GM_PB_HUB_FORK", 1)) ? PB_HUB_ROOM : 0;
-        if (pb_env("GM_PB_HUB_ROOM", -1) >= 0) // measurement: LDS left free beside an accumulate workgroup
-            hub_room = (size_t)pb_env("GM_PB_HUB_ROOM", -1);
+        if (pb_env_m("GM_PB_HUB_ROOM", -1) >= 0) // measurement: LDS left free beside an accumulate workgroup
+            hub_room = (size_t)pb_env_m("GM_PB_HUB_ROOM", -1);
         const size_t budget = wgs == 1 ? (163840 - hub_room - PB_ACC_STATIC - acc_bytes)
                                        : ((163840 - hub_room) / 2 - PB_ACC_STATIC - acc_bytes);
         H = (uint32_t)(budget / 4) & ~63u;
@@ -2664,7 +2673,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     timer.done("pb plan: accumulator slots");
     // ---- hot sources: the H most frequent source ids (>= 2 edges) of this rank's edges ----------------
     DevBuf hot_rank, hot_blk;
-    int filter_bits = pb_env("GM_PB_FILTER_BITS", PB_FILTER_DEFAULT); // log2 of the block filter's size in bits
+    int filter_bits = pb_env_m("GM_PB_FILTER_BITS", PB_FILTER_DEFAULT); // log2 of the block filter's size in bits
     filter_bits = filter_bits < 10 ? 10 : (filter_bits > PB_FILTER_BITS ? PB_FILTER_BITS : filter_bits);
     const int fshift = sb > filter_bits ? sb - filter_bits : 0;
     const uint32_t filter_words = (uint32_t)(((x_len >> fshift) + 32) / 32);
@@ -2719,7 +2728,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
                     H = H_single < candidates ? H_single : candidates;
                 pl->Htot = (uint32_t)(((uint64_t)H * T) < candidates ? (uint64_t)H * T : candidates);
             }
-            if (T == 1 && pb_env("GM_PB_HOT_TRIM", 1) && H > 1024) {
+            if (T == 1 && pb_env_m("GM_PB_HOT_TRIM", 1) && H > 1024) {
                 // ONE table: every accumulate workgroup stages all of it before its first hot edge (4 H bytes from L2 and a
                 // barrier), so a source belongs in it only if its edges pay for that.  The same break-even as a tier's
                 // (6000 edges per bin for ~10,000 sources): a source with fewer edges than half the number of bins is left
@@ -2948,7 +2957,7 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     hipLaunchKernelGGL(pb_seg_counts_kernel, dim3(gs), dim3(256), 0, 0, segval.as<uint32_t>(), vstart.as<uint32_t>(), NS,
                        m, cnt.as<uint32_t>(), cntv.as<uint32_t>(),
                        // GM_PB_SEGPAD=8 (measurement): every segment starts on a 32-byte sector of the value stream
-                       pb_env("GM_PB_SEGPAD", (int)PB_VEC) == 8 ? 8u : PB_VEC);
+                       pb_env_m("GM_PB_SEGPAD", (int)PB_VEC) == 8 ? 8u : PB_VEC);
     GM_HIP(hipGetLastError());
     GM_TRY(scan_exclusive<uint32_t>(cnt.as<uint32_t>(), cs.as<uint32_t>(), (uint64_t)NS + 1));
     hipLaunchKernelGGL(pb_bounds_kernel, dim3(gs), dim3(256), 0, 0, segkey.as<uint64_t>(), NS, tile_shift, pl->NT,
@@ -2957,9 +2966,9 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
                        tile_seg.as<uint32_t>(), cs.as<uint32_t>(), pl->NT, tile_pad.as<uint32_t>());
     hipLaunchKernelGGL(pb_tile_tail_kernel, dim3(pb_grid(pl->NT)), dim3(256), 0, 0, tile_seg.as<uint32_t>(),
                        cs.as<uint32_t>(), tile_pad.as<uint32_t>(), segval.as<uint32_t>(), pl->NT, cntv.as<uint32_t>());
-    if (pb_env("GM_PB_BIN_GAP", 0) >= 8)
+    if (pb_env_m("GM_PB_BIN_GAP", 0) >= 8)
         hipLaunchKernelGGL(pb_bin_gap_kernel, dim3(pb_grid(Bv)), dim3(256), 0, 0, bin_seg.as<uint32_t>(), Bv,
-                           (uint32_t)pb_env("GM_PB_BIN_GAP", 0), cntv.as<uint32_t>());
+                           (uint32_t)pb_env_m("GM_PB_BIN_GAP", 0), cntv.as<uint32_t>());
     GM_HIP(hipGetLastError());
     GM_TRY(scan_exclusive<uint32_t>(cntv.as<uint32_t>(), vstart4.as<uint32_t>(), (uint64_t)NS + 1));
     uint32_t Mv = 0;
@@ -2977,9 +2986,9 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
                        tile_shift, pstart.as<uint32_t>(), pl->delta.as<uint32_t>(), rank_of.as<uint32_t>());
     GM_HIP(hipGetLastError());
 
-    if (getenv("GM_PB_SPREAD_PLAN")) { // measurement: the two index streams spread the same way
+    if (pb_getenv_m("GM_PB_SPREAD_PLAN")) { // measurement: the two index streams spread the same way
         unsigned mib = 64, factor = 8, seed = 1;
-        (void)sscanf(getenv("GM_PB_SPREAD_PLAN"), "%u,%u,%u", &mib, &factor, &seed);
+        (void)sscanf(pb_getenv_m("GM_PB_SPREAD_PLAN"), "%u,%u,%u", &mib, &factor, &seed);
         GM_TRY(pl->p2_dst.alloc_spread((size_t)Mv * 2, (size_t)mib << 20, factor, seed + 101));
         GM_TRY(pl->p1_src.alloc_spread((size_t)Mp * 2, (size_t)mib << 20, factor, seed + 202));
     } else { // streamed once per sweep: pieces from all over the arena (arena.hip)
@@ -3125,12 +3134,12 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
     GM_TRY(pl->wg_p0.alloc((size_t)NW * 4));
     hipLaunchKernelGGL(pb_wg_fill_kernel, dim3(pb_grid(NW)), dim3(256), 0, 0, pl->tile_p.as<uint32_t>(),
                        wg_first.as<uint32_t>(), pl->NT, pl->chunk, NW, pl->wg_tile.as<uint32_t>(), pl->wg_p0.as<uint32_t>());
-    pl->xcd_aware = pb_env("GM_PB_XCD", 1);
+    pl->xcd_aware = pb_env_m("GM_PB_XCD", 1);
     pl->wg_first_host.resize((size_t)pl->NT + 1);
     GM_HIP(hipMemcpy(pl->wg_first_host.data(), wg_first.p, ((size_t)pl->NT + 1) * 4, hipMemcpyDeviceToHost));
     GM_HIP(hipGetLastError());
     GM_HIP(hipDeviceSynchronize());
-    if (const uint32_t G = (uint32_t)pb_env("GM_PB_WG_GROUP", 0)) {
+    if (const uint32_t G = (uint32_t)pb_env_m("GM_PB_WG_GROUP", 0)) {
         // Tile-major order has the chunks of one tile next to each other: the workgroups running at one time on an XCD
         // are a few tiles x all their chunks, and what they write to one bin is a few adjacent runs.  Group-major order
         // (G tiles x ONE chunk at a time) makes it G adjacent runs per bin — longer contiguous stretches of the value
@@ -3321,9 +3330,9 @@ int pb_scratch_create(const PbPlan *pl, PbScratch **out, DevBuf *early)
         }
     }
     // GM_PB_SPREAD="<MiB per piece>,<pool factor>,<seed>": a pseudo-random subset of a pool of pieces (DevBuf::alloc_spread)
-    if (!sc->vals_raw.p && getenv("GM_PB_SPREAD")) {
+    if (!sc->vals_raw.p && pb_getenv_m("GM_PB_SPREAD")) {
         unsigned mib = 64, factor = 8, seed = 1;
-        (void)sscanf(getenv("GM_PB_SPREAD"), "%u,%u,%u", &mib, &factor, &seed);
+        (void)sscanf(pb_getenv_m("GM_PB_SPREAD"), "%u,%u,%u", &mib, &factor, &seed);
         const auto t0 = std::chrono::steady_clock::now();
         if ((rc = sc->vals_raw.alloc_spread((size_t)(pl->Mv ? pl->Mv : 4) * 4 + slack, (size_t)mib << 20, factor, seed))) {
             delete sc;
@@ -3487,7 +3496,7 @@ int pb_scratch_create(const PbPlan *pl, PbScratch **out, DevBuf *early)
         // eight arena candidates (profiles/r03_placement_piece_size.txt, third box) — although both are slower than the
         // arena wherever the arena is fast.  So they are tried only here, and only kept if they win.
         if (draws > 1 && rc == GM_OK && he == hipSuccess && sc->vals_raw.p && moved / (best_ms * 1e-3) < bw_min &&
-            pb_env("GM_PB_LAST_RESORT", 1)) {
+            pb_env_m("GM_PB_LAST_RESORT", 1)) {
             {
                 DevBuf cand;
                 if (cand.alloc_vmm(bytes, (size_t)256 << 20, 0) == GM_OK)
@@ -3503,7 +3512,7 @@ int pb_scratch_create(const PbPlan *pl, PbScratch **out, DevBuf *early)
                     (void)hipGetLastError();
             }
         }
-        if (const char *gm = getenv("GM_PB_GROW_MAP")) { // measurement (profiles/r03_placement_grow_map.txt): which later stretches
+        if (const char *gm = pb_getenv_m("GM_PB_GROW_MAP")) { // measurement (profiles/r03_placement_grow_map.txt): which later stretches
             // of memory are fast alone, which pair well with the pool?  k-th stretch of 8 GiB created behind the pool, timed
             // alone and half-and-half with the pool as it was; one candidate at a time
             uint64_t pool_end = 0;
@@ -3579,7 +3588,7 @@ int pb_scratch_create(const PbPlan *pl, PbScratch **out, DevBuf *early)
     // workgroups are meant to fill the room the accumulate workgroups leave on a CU, not to take CUs from them — several of
     // them on one CU leave no room for an accumulate workgroup (143 KiB of LDS) until they have finished.
     int prio_least = 0, prio_greatest = 0;
-    if (e == hipSuccess && pb_env("GM_PB_SIDE_PRIO", 1))
+    if (e == hipSuccess && pb_env_m("GM_PB_SIDE_PRIO", 1))
         e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     if (e == hipSuccess && pl->G_long && pl->G > pl->G_long) { // the long rows' own stream
         e = hipStreamCreateWithPriority(&sc->chain, hipStreamNonBlocking, prio_least);
@@ -3776,12 +3785,12 @@ static void pb_accum_dispatch(const PbPlan *pl, PbScratch *sc, const PbItem *ite
 static uint32_t pb_seq_wgs(const PbPlan *pl)
 {
     const uint32_t n_seq = pl->G - pl->G_long;
-    const uint32_t want = (uint32_t)pb_env("GM_PB_SEQ_WGS", 0);
+    const uint32_t want = (uint32_t)pb_env_m("GM_PB_SEQ_WGS", 0);
     return want && want < n_seq ? want : n_seq;
 }
 
 // workgroups the hub launches of a sweep have in all (pb_hub_dispatch)
-static uint32_t pb_hub_workgroups(const PbPlan *pl)
+[[maybe_unused]] static uint32_t pb_hub_workgroups(const PbPlan *pl)
 {
     if (!pl->G)
         return 0;
@@ -3845,7 +3854,7 @@ static bool pb_hub_dispatch(const PbPlan *pl, PbScratch *sc, float *x_out, float
                                   pl->p2_dst.as<uint16_t>(), items + pl->G_long, pl->seq_blk_first.as<uint32_t>(),
                                   pl->seq_blk.as<uint4>(), pl->seq_rows.as<uint32_t>(), pl->hh_ent.as<uint32_t>(),
                                   sc->hot_x.as<float>(), pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr, base, damping,
-                                  v_safe, h_safe, n_seq, (uint32_t)pb_env("GM_PB_SEQ_PRIO", 1), PbErrFold{}, (const uint32_t *)nullptr);
+                                  v_safe, h_safe, n_seq, (uint32_t)pb_env_m("GM_PB_SEQ_PRIO", 1), PbErrFold{}, (const uint32_t *)nullptr);
             launched = true;
         }
         return launched;
@@ -3870,7 +3879,7 @@ static bool pb_hub_dispatch(const PbPlan *pl, PbScratch *sc, float *x_out, float
         hipLaunchKernelGGL(pb_hubseq_kernel, dim3(seq_wgs), dim3(PB_SEQ_WG), 0, st, sc->vals, pl->p2_dst.as<uint16_t>(),
                            items + pl->G_long, pl->seq_blk_first.as<uint32_t>(), pl->seq_blk.as<uint4>(), pl->seq_rows.as<uint32_t>(),
                            pl->hh_ent.as<uint32_t>(), sc->hot_x.as<float>(), pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr,
-                           base, damping, v_safe, h_safe, n_seq, (uint32_t)pb_env("GM_PB_SEQ_PRIO", 1), sc->fold, seq_list);
+                           base, damping, v_safe, h_safe, n_seq, (uint32_t)pb_env_m("GM_PB_SEQ_PRIO", 1), sc->fold, seq_list);
     if (own)
         (void)hipStreamWaitEvent(st, sc->ev_chain_join, 0);
     return have_long || have_seq;
@@ -3910,7 +3919,7 @@ int pb_sweep_main(const PbPlan *pl, PbScratch *sc, const float *x_in, float *x_o
         ~FoldScope() { sc->fold = PbErrFold{}; }
     } fold_scope{sc};
 #ifndef GM_MEASURE
-    if (err_out && folded_out && pl->NI && sc->fold_ctr.p && pb_env("GM_PB_FOLD_ERR", 1)) {
+    if (err_out && folded_out && pl->NI && sc->fold_ctr.p && pb_env_m("GM_PB_FOLD_ERR", 1)) {
         sc->fold.ctr = sc->fold_ctr.as<uint32_t>();
         sc->fold.total = pl->NI + pb_hub_workgroups(pl);
         sc->fold.count = pl->B + pl->err_slots;
@@ -3926,12 +3935,12 @@ int pb_sweep_main(const PbPlan *pl, PbScratch *sc, const float *x_in, float *x_o
     const bool fork = pl->G && sc->side && pl->hub_edges >= (1u << 20) && pb_env("GM_PB_HUB_FORK", 1);
     // GM_PB_FORK_STOP=1 (round 6, measured: see DESIGN.md): the fork event is the bin kernel's own completion instead of a
     // marker recorded behind it — when the bin launch gathers the hot sources as well (nothing else stands between the two)
-    const bool want_fold_hot = pb_env("GM_PB_FOLD_HOT", 1) != 0 && pl->Htot && (uint64_t)pl->NW * PB_BIN_BLOCK >= pl->Htot;
-    bool fork_by_stop = fork && pl->NW && want_fold_hot && pb_env("GM_PB_FORK_STOP", 0) != 0;
+    const bool want_fold_hot = pb_env_m("GM_PB_FOLD_HOT", 1) != 0 && pl->Htot && (uint64_t)pl->NW * PB_BIN_BLOCK >= pl->Htot;
+    bool fork_by_stop = fork && pl->NW && want_fold_hot && pb_env_m("GM_PB_FORK_STOP", 0) != 0;
 #ifdef GM_MEASURE
     fork_by_stop = false;
 #endif
-    if (!pb_bin_dispatch(pl, sc, x_in, 0, pl->NW, st, nullptr, pb_env("GM_PB_FOLD_HOT", 1) != 0, fork_by_stop ? sc->ev_fork : nullptr))
+    if (!pb_bin_dispatch(pl, sc, x_in, 0, pl->NW, st, nullptr, pb_env_m("GM_PB_FOLD_HOT", 1) != 0, fork_by_stop ? sc->ev_fork : nullptr))
         pb_hot_dispatch(pl, sc, x_in, st); // (in front of the accumulate kernel, which reads hot_x; the bin kernel does not)
 #ifdef GM_MEASURE
     if (pl->G && pb_env("GM_PB_ANYORDER", 0)) {

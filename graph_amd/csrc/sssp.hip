@@ -898,7 +898,7 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
     // time (9 runs of 9: tools/runs/r06_call04.sh, r06_call07.sh, r06_call10.sh; either one alone 2 of 2 passed; allocated up
     // front 4 of 4 passed, bit-exact).  Every access of both buffers is bounds-checked and the same code on hipMalloc'd buffers
     // has never faulted: a runtime problem with that unmap / map sequence, not understood further.
-    const int arena_mask = getenv("GM_SSSP_ARENA") ? atoi(getenv("GM_SSSP_ARENA")) : 19;
+    const int arena_mask = gm::measure_env("GM_SSSP_ARENA") ? atoi(gm::measure_env("GM_SSSP_ARENA")) : 19;
     std::unique_ptr<gm::SsspScratch> sc;
     {
         std::lock_guard<std::mutex> lock(g->cache_mu);
@@ -1160,13 +1160,13 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
     const double ms_setup = since(t_call);
     unsigned far_grid = gm::div_up(nwords, SSSP_BLOCK * 8);
     far_grid = far_grid > 256 ? 256 : far_grid;
-    const bool use_settled = getenv("GM_SSSP_SETTLED") == nullptr || atoi(getenv("GM_SSSP_SETTLED")) != 0;
+    const bool use_settled = gm::measure_env("GM_SSSP_SETTLED") == nullptr || atoi(gm::measure_env("GM_SSSP_SETTLED")) != 0;
     // GM_SSSP_DONE: 0 (default) = light rounds probe every target's distance, 1 = targets taken up in earlier phases are
     // skipped by their bit once n / GM_SSSP_DONE_DIV (default 8) nodes are final, 2 = from the first phase on.  Measured at
     // scale 24 (tools/runs/r03_call39.sh, one box, bit-identical results): 9.26 ms off, 9.60 ms mode 1, 9.71 ms mode 2 — the
     // light rounds' probes of already-final targets are too few to pay for a second dependent access; off.
     const int done_mode = getenv("GM_SSSP_DONE") ? atoi(getenv("GM_SSSP_DONE")) : 0;
-    const int done_div = getenv("GM_SSSP_DONE_DIV") && atoi(getenv("GM_SSSP_DONE_DIV")) > 0 ? atoi(getenv("GM_SSSP_DONE_DIV")) : 8;
+    const int done_div = gm::measure_env("GM_SSSP_DONE_DIV") && atoi(gm::measure_env("GM_SSSP_DONE_DIV")) > 0 ? atoi(gm::measure_env("GM_SSSP_DONE_DIV")) : 8;
     uint32_t *done_bits = done_mode ? sc->done.as<uint32_t>() : nullptr;
     const uint32_t done_min = done_mode >= 2 ? 0u : n / (uint32_t)done_div + 1u;
     // GM_SSSP_CUT=<multiples of the step> (default 8, 0: heavy rounds are whole): where the cut lies above the threshold of
@@ -1188,7 +1188,7 @@ GM_API int gm_sssp_delta_stepping(const gm_csr *g, uint64_t start_node, float de
                                ctrl.as<uint32_t>(), chunk_edges, coop,
                                order && order->in_off.p ? order->in_off.as<uint32_t>() : (const uint32_t *)nullptr,
                                order && order->in_off.p ? order->in_edge.as<uint2>() : (const uint2 *)nullptr, n,
-                               getenv("GM_SSSP_PULL_FILTER") && atoi(getenv("GM_SSSP_PULL_FILTER")) != 0 ? 1u : 0u);
+                               gm::measure_env("GM_SSSP_PULL_FILTER") && atoi(gm::measure_env("GM_SSSP_PULL_FILTER")) != 0 ? 1u : 0u);
             hipLaunchKernelGGL(sssp_chunk_kernel, dim3(grid), dim3(SSSP_BLOCK), 0, st, g->offsets, g->targets, g->weights,
                                dist.as<uint32_t>(), flags.as<uint32_t>(), wmin.as<uint32_t>(), use_settled ? settled.as<uint32_t>() : (const uint32_t *)nullptr, done_bits, done_min,
                                chunks.as<uint2>(), qs, ctrl.as<uint32_t>(), chunk_edges,

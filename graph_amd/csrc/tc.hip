@@ -745,21 +745,21 @@ GM_API int gm_triangle_count(const gm_csr *g, uint64_t *triangles_out)
             (void)sscanf(e, "%d,%d,%d,%d", &shape_b, &shape_g, &shape_m, &shape_u);
         // workgroups of a launch: as many as the chip holds at once (LDS and wavefront slots), times GM_TC_WAVES (default 2:
         // a workgroup that arrives late finds the counter run out and leaves) — never more than the items
-        const uint32_t tc_waves = getenv("GM_TC_WAVES") && atoi(getenv("GM_TC_WAVES")) > 0 ? (uint32_t)atoi(getenv("GM_TC_WAVES")) : 2u;
+        const uint32_t tc_waves = gm::measure_env("GM_TC_WAVES") && atoi(gm::measure_env("GM_TC_WAVES")) > 0 ? (uint32_t)atoi(gm::measure_env("GM_TC_WAVES")) : 2u;
         int n_cus = 256;
         (void)hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, g->device);
         auto wgs_of = [&](uint32_t n_items, size_t lds, int block) {
             const uint32_t by_lds = (uint32_t)((160u * 1024u) / (lds + 1024u)), by_waves = 2048u / (uint32_t)block;
             const uint32_t per_cu = std::max(1u, std::min(by_lds, by_waves));
             const uint64_t wgs = (uint64_t)n_cus * per_cu * tc_waves;
-            return (uint32_t)std::min<uint64_t>(n_items, getenv("GM_TC_PERSIST") && atoi(getenv("GM_TC_PERSIST")) == 0 ? n_items : wgs);
+            return (uint32_t)std::min<uint64_t>(n_items, gm::measure_env("GM_TC_PERSIST") && atoi(gm::measure_env("GM_TC_PERSIST")) == 0 ? n_items : wgs);
         };
         uint32_t launch_no = 0; // (at most 1 + log2(K / 16384) <= 7 launches)
         // GM_TC_STREAMS=1: every range on a stream of its own (ordered behind the set-up work on the null stream), so
         // that the tail of one range — a few workgroups on their last, long items — runs under the next range's start
         static hipStream_t pool[16][8] = {};
         static std::mutex pool_mu;
-        const bool multi = getenv("GM_TC_STREAMS") && atoi(getenv("GM_TC_STREAMS")) != 0; // measured (tools/runs/r05_call04.sh): 30.1 against 29.0 ms at scale 24 — the 64 KiB rows take CUs from the hub rows: off
+        const bool multi = gm::measure_env("GM_TC_STREAMS") && atoi(gm::measure_env("GM_TC_STREAMS")) != 0; // measured (tools/runs/r05_call04.sh): 30.1 against 29.0 ms at scale 24 — the 64 KiB rows take CUs from the hub rows: off
         auto stream_of = [&](uint32_t k) -> hipStream_t {
             if (!multi || g->device < 0 || g->device >= 16)
                 return (hipStream_t)0;
