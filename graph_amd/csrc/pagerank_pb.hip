@@ -193,7 +193,7 @@ struct PbPlan {
     uint32_t n_hub = 0;    // such rows
     uint32_t G = 0;        // hub groups: virtual bins B .. B + G - 1 of the streams
     uint64_t hub_edges = 0;
-    DevBuf hub_rows;       // u32[n_hub] row id of every hub row, ascending
+    DevBuf hub_rows;       // u32[n_hub] row id of every hub row: the walked ones ascending, then the long ones ascending (pb_build)
     DevBuf hub_first;      // u32[G+1]   first hub row (index into hub_rows) of every group
     DevBuf hub_items;      // PbHubItem[G]: the G_long groups that are one long row first, each part longest first
     uint32_t hub_long = 8192;  // rows with at least this many in-edges are a group of their own (pb_hublong_kernel): see pb_build
@@ -374,6 +374,14 @@ __global__ void pb_hub_rows_kernel(const uint32_t *__restrict__ off, const uint3
 }
 
 // accumulator slots of the ordinary bins: rows with in-edges that are not hub rows, numbered consecutively
+// pos_h[hub_rows[k]] = k: the hub rows' index space after pb_build has regrouped it
+__global__ void pb_hub_repos_kernel(const uint32_t *__restrict__ hub_rows, uint32_t n_hub, uint32_t *__restrict__ pos_h)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n_hub; k += stride)
+        pos_h[hub_rows[k]] = k;
+}
+
 __global__ void pb_rowflag_kernel(const uint32_t *__restrict__ off, uint32_t n, uint32_t hub_deg, uint32_t *__restrict__ flag)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -2549,6 +2557,37 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
                 pl->hub_long = 8192;
                 if (sorted.size() > 512 && sorted[512] + 1u > pl->hub_long)
                     pl->hub_long = sorted[512] + 1u;
+            }
+            // The hub rows' index space, regrouped for the SLICES of a partitioned graph (round 6; GM_PB_HUB_REGROUP=0 / 1: never /
+            // always): the rows one lane walks come first, in ascending order, the long ones — a group of their own each — behind
+            // them.  Groups are RANGES of that index space, and in ascending row order a long row between two walked ones ended a
+            // group: in a rank's slice, where 22 % of the hub rows are long, the walked groups held runs of 4.6 rows (an 8-way rank
+            // at scale 26: 2,310 hub rows in 902 groups, one pb_hubseq_kernel workgroup each beside the accumulate kernel, 60 of
+            // 64 lanes of every walk idle; regrouped: 630 groups).  A row's sum does not depend on its group: same bits (the whole
+            // GPU suite with it on everywhere).  Measured (tools/runs/r06_call23.sh, alternating processes): emulated ranks 0 / 6
+            // of 8 0.650 / 0.704 -> 0.595 / 0.609 ms, rank 0 of 4 1.056 -> 0.998; the whole graph at scale 26 2.74-2.78 -> 2.71-2.74
+            // (1530 -> 1266 groups), but at scale 22 0.203-0.206 -> 0.214-0.217 (507 -> 378 groups: the fuller groups' walks
+            // outlast the 116 us accumulate kernel they run beside) — hence slices only.
+            if (pb_env("GM_PB_HUB_REGROUP", x_len != n ? 1 : 0)) {
+                std::vector<uint32_t> rows_old(pl->n_hub), order;
+                GM_HIP(hipMemcpy(rows_old.data(), pl->hub_rows.p, (size_t)pl->n_hub * 4, hipMemcpyDeviceToHost));
+                order.reserve(pl->n_hub);
+                for (uint32_t h = 0; h < pl->n_hub; ++h)
+                    if (degs[h] < pl->hub_long)
+                        order.push_back(h);
+                for (uint32_t h = 0; h < pl->n_hub; ++h)
+                    if (degs[h] >= pl->hub_long)
+                        order.push_back(h);
+                std::vector<uint32_t> rows_new(pl->n_hub), degs_new(pl->n_hub);
+                for (uint32_t k = 0; k < pl->n_hub; ++k)
+                    rows_new[k] = rows_old[order[k]], degs_new[k] = degs[order[k]];
+                GM_HIP(hipMemcpy(pl->hub_rows.p, rows_new.data(), (size_t)pl->n_hub * 4, hipMemcpyHostToDevice));
+                degs = degs_new;
+                pl->hub_degs_host = degs;
+                // pos_h[row] = the row's index in that space (what the key kernel looks a hub row up by)
+                hipLaunchKernelGGL(pb_hub_repos_kernel, dim3(pb_grid(pl->n_hub)), dim3(256), 0, 0, pl->hub_rows.as<uint32_t>(), pl->n_hub,
+                                   pos_h.as<uint32_t>());
+                GM_HIP(hipGetLastError());
             }
             uint64_t acc_edges = 0;
             uint32_t count = 0;
