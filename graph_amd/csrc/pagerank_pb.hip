@@ -2589,6 +2589,22 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
                                    pos_h.as<uint32_t>());
                 GM_HIP(hipGetLastError());
             }
+            // ... and in a slice the walked groups are made SMALLER, so that there is about one per CU (GM_PB_HUB_SLICE_GROUPS, default
+            // 224; 0: the whole-graph target): a group's walk is a chain whose length is its terms (one lane per row, a 2040-term
+            // block at a time: ~1.6 us per block), and a slice's accumulate phase is short — at 8 ranks the full-size groups' walks
+            // (207-217 us) outlasted BOTH accumulate pieces of the rank (106 + 75 us) and the first piece's exchange waited 125 us
+            // for them (profiles/r06_rank_of_8_sweep_timeline.txt).
+            if (x_len != n) {
+                const uint64_t want_groups = (uint64_t)pb_env("GM_PB_HUB_SLICE_GROUPS", 224);
+                uint64_t walked_terms = 0;
+                for (uint32_t h = 0; h < pl->n_hub; ++h)
+                    walked_terms += degs[h] < pl->hub_long ? degs[h] : 0u;
+                if (want_groups) {
+                    uint64_t t = walked_terms / want_groups;
+                    t = t < 32768 ? 32768 : t;
+                    target = t < target ? t : target;
+                }
+            }
             uint64_t acc_edges = 0;
             uint32_t count = 0;
             bool prev_long = false;
@@ -3629,6 +3645,8 @@ int pb_scratch_create(const PbPlan *pl, PbScratch **out, DevBuf *early)
     int prio_least = 0, prio_greatest = 0;
     if (e == hipSuccess && pb_env_m("GM_PB_SIDE_PRIO", 1))
         e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (pb_env_m("GM_PB_SIDE_PRIO", 1) == 2) // (measurements: the HIGHEST one)
+        prio_least = prio_greatest;
     if (e == hipSuccess && pl->G_long && pl->G > pl->G_long) { // the long rows' own stream
         e = hipStreamCreateWithPriority(&sc->chain, hipStreamNonBlocking, prio_least);
         if (e == hipSuccess)
