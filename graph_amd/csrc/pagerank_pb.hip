@@ -76,11 +76,12 @@ constexpr size_t PB_ACC_STATIC = 512;  // static LDS of pb_accum_kernel, rounded
 constexpr uint32_t PB_HUB_MAX = 64;  // rows of a hub group (one lane of a wavefront each)
 constexpr uint16_t PB_HUBROW = 0xFFFEu; // cidx of a hub row: its sum is produced by pb_hubseq_kernel / pb_hublong_kernel, not by its bin
 constexpr uint16_t PB_FLAG = 0x8000u;
-constexpr uint32_t PB_SEQ_WG = 256;  // threads of a pb_hubseq_kernel workgroup (wavefront 0 walks, all four stage)
+constexpr uint32_t PB_SEQ_WG = 256;  // threads of a pb_hubseq_kernel workgroup (wavefront 0 walks, all four stage) ...
+constexpr uint32_t PB_SEQ_WG_WIDE = 512; // ... and of the launches that are a sweep's critical path (a part's hub rows, a slice's): see the kernel
 constexpr uint32_t PB_SEQ_PAD = 16;  // a row's stretch of the staged block is padded to 16 floats (4 x ds_read_b128 per step)
 constexpr uint32_t PB_SEQ_STEP = 2048; // entries of a block of pb_hubseq_kernel: what one round of loads covers
 constexpr uint32_t PB_SEQ_CAP = 2040;  // terms of a block (its stretch of the value stream may start 3 entries into a float4)
-constexpr uint32_t PB_SEQ_HOT = 4;     // hot records per thread and block that travel through the prefetch registers
+constexpr uint32_t PB_SEQ_HOT = 1024;  // hot records per block that travel through the prefetch registers (4 / 2 per thread)
 constexpr uint32_t PB_SEQ_BUF = PB_SEQ_STEP + PB_HUB_MAX * (PB_SEQ_PAD - 1); // floats: 2048 terms + the rows' padding (12 KiB)
 // LDS left free beside an accumulate workgroup: ONE pb_hubseq_kernel workgroup (12.1 KiB) AND one pb_hublong_kernel workgroup
 // (9.3 KiB).  With room for only one of the two (20 KiB blocks / an 18 KiB turning buffer, the first version) the long rows
@@ -1653,7 +1654,18 @@ __global__ __launch_bounds__(PB_SEQ_STEP / PB_VEC) void pb_hubseq_layout_kernel(
 // issued and waits with vmcnt(0) — for the block requested a moment ago as well.  Every round paid a full memory latency
 // under the accumulate kernel's traffic (~8 us per block; the walk of a block's 32..120 terms per row is 0.2..0.8 us).
 // (at most 96 VGPRs: one wavefront of this kernel, two of pb_hublong_kernel's and four of the accumulate kernel's share a SIMD)
-__global__ __launch_bounds__(PB_SEQ_WG) __attribute__((amdgpu_waves_per_eu(5, 8))) void pb_hubseq_kernel(const float *__restrict__ vals, const uint16_t *__restrict__ p2_dst,
+//
+// WG threads (round 6): what a round costs is mostly the instructions of ONE wavefront per SIMD — with the walk, the scatter, the hot
+// addresses and the padding zeros taken out one by one (a throw-away build, tools/runs/r06_call31.sh) a launch of the block-Gauss-
+// Seidel call went 78 -> 46 us at scale 22 and 414 -> 237 at scale 26 without the walk and stayed there without the rest: 1.4-1.7 us
+// of a 2.4-3.2 us round are neither memory latency nor the adds.  (Loading a block's ranges once instead of three dependent scalar
+// loads per round, and skewing the rows' LDS stretches over the 16-byte slots, changed nothing: r06_call32.sh.)  Twice the threads
+// halve every wavefront's share of the staging: 66 / 358 us per launch (r06_call32.sh, second pass).  512 threads are what a launch
+// gets whose walks ARE the critical path — a part's hub rows in a sweep in blocks, a partition slice's; beside the accumulate kernel
+// of a whole synchronous sweep, where the walks have slack, their 2 x 80 registers per SIMD crowd the other two kernels (scale 26:
+// pb_hubseq_kernel 713 -> 968 us, pb_hublong_kernel 674 -> 921, the sweep +2-3 %): those keep 256.
+template <uint32_t WG>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5, 8))) void pb_hubseq_kernel(const float *__restrict__ vals, const uint16_t *__restrict__ p2_dst,
                                                               const PbHubItem *__restrict__ items,
                                                               const uint32_t *__restrict__ blk_first,
                                                               const uint4 *__restrict__ blk, const uint32_t *__restrict__ rows,
@@ -1665,11 +1677,11 @@ __global__ __launch_bounds__(PB_SEQ_WG) __attribute__((amdgpu_waves_per_eu(5, 8)
                                                               PbErrFold fold, const uint32_t *__restrict__ grp_list)
 {
     constexpr uint32_t STEP = PB_SEQ_STEP;                      // stream entries one round of loads covers
-    constexpr int PER = (int)(STEP / (PB_SEQ_WG * PB_VEC));     // float4 + 4 places per thread and block
-    constexpr int HP = (int)PB_SEQ_HOT;                         // hot records per thread and block in the pipeline
+    constexpr int PER = (int)(STEP / (WG * PB_VEC));     // float4 + 4 places per thread and block
+    constexpr int HP = (int)(PB_SEQ_HOT / WG);                        // hot records per thread and block in the pipeline
     constexpr uint32_t DUMP = PB_SEQ_BUF;                       // where everything that is not a term lands
     __shared__ __attribute__((aligned(16))) float buf[PB_SEQ_BUF + 4];
-    __shared__ double red[PB_SEQ_WG / kWave];
+    __shared__ double red[WG / kWave];
     const uint32_t tid = threadIdx.x;
     if (walk_prio && tid < kWave)
         __builtin_amdgcn_s_setprio(3); // the walk is the group's critical path: first in line at its SIMD's issue
@@ -1700,7 +1712,7 @@ __global__ __launch_bounds__(PB_SEQ_WG) __attribute__((amdgpu_waves_per_eu(5, 8)
         const uint4 rg = range_of(k);
 #pragma unroll
         for (int j = 0; j < HP; ++j) {
-            const uint32_t h = rg.z + (uint32_t)j * PB_SEQ_WG + tid;
+            const uint32_t h = rg.z + (uint32_t)j * WG + tid;
             rx[j] = hh_ent[h < h_safe ? h : h_safe];
         }
     };
@@ -1708,7 +1720,7 @@ __global__ __launch_bounds__(PB_SEQ_WG) __attribute__((amdgpu_waves_per_eu(5, 8)
         const uint4 rg = range_of(k);
 #pragma unroll
         for (int j = 0; j < HP; ++j) {
-            const bool is = rg.z + (uint32_t)j * PB_SEQ_WG + tid < rg.w;
+            const bool is = rg.z + (uint32_t)j * WG + tid < rg.w;
             ht.x[j] = hot_x[is ? rx[j] & 0x3FFFFu : 0u];
             const uint32_t at = is ? rx[j] >> 18 : DUMP;
             if (j & 1)
@@ -1721,7 +1733,7 @@ __global__ __launch_bounds__(PB_SEQ_WG) __attribute__((amdgpu_waves_per_eu(5, 8)
         const uint32_t qa = range_of(k).x & ~3u;
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
-            const uint32_t q = qa + ((uint32_t)j * PB_SEQ_WG + tid) * PB_VEC, qc = q < v_safe ? q : v_safe;
+            const uint32_t q = qa + ((uint32_t)j * WG + tid) * PB_VEC, qc = q < v_safe ? q : v_safe;
             st.v[j] = *reinterpret_cast<const f32x4 *>(vals + qc);
             st.d[j] = *reinterpret_cast<const u32x2 *>(p2_dst + qc);
         }
@@ -1732,7 +1744,7 @@ __global__ __launch_bounds__(PB_SEQ_WG) __attribute__((amdgpu_waves_per_eu(5, 8)
         const uint32_t qa = rg.x & ~3u;
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
-            const uint32_t q = qa + ((uint32_t)j * PB_SEQ_WG + tid) * PB_VEC;
+            const uint32_t q = qa + ((uint32_t)j * WG + tid) * PB_VEC;
             const uint32_t p0 = st.d[j].x & 0xFFFFu, p1 = st.d[j].x >> 16, p2 = st.d[j].y & 0xFFFFu, p3 = st.d[j].y >> 16;
             buf[(p0 < DUMP && q >= rg.x && q < rg.y) ? p0 : DUMP] = st.v[j].x;
             buf[(p1 < DUMP && q + 1u >= rg.x && q + 1u < rg.y) ? p1 : DUMP] = st.v[j].y;
@@ -1743,7 +1755,7 @@ __global__ __launch_bounds__(PB_SEQ_WG) __attribute__((amdgpu_waves_per_eu(5, 8)
         for (int j = 0; j < HP; ++j)
             buf[(ht.at[j / 2] >> ((j & 1) * 16)) & 0xFFFFu] = ht.x[j];
         // a block with more than 1024 hot terms (rare: more than half of its terms): the rest without the pipeline
-        for (uint32_t h = rg.z + (uint32_t)HP * PB_SEQ_WG + tid; h < rg.w; h += PB_SEQ_WG) {
+        for (uint32_t h = rg.z + (uint32_t)HP * WG + tid; h < rg.w; h += WG) {
             const uint32_t rec = hh_ent[h];
             buf[rec >> 18] = hot_x[rec & 0x3FFFFu];
         }
@@ -1830,7 +1842,7 @@ __global__ __launch_bounds__(PB_SEQ_WG) __attribute__((amdgpu_waves_per_eu(5, 8)
     double err = 0.0;
     if (walker)
         err = pr_finalize(hub_rows[item.row0 + tid], S, base, damping, outdeg, scores, x_out);
-    const double total = block_sum<double, PB_SEQ_WG / kWave>(err, red);
+    const double total = block_sum<double, WG / kWave>(err, red);
     if (tid == 0)
         st_agent(&group_err[item.group], total);
     lds_barrier();
@@ -3907,7 +3919,7 @@ static bool pb_hub_dispatch(const PbPlan *pl, PbScratch *sc, float *x_out, float
             launched = true;
         }
         if (pl->G > pl->G_long && !(skip & 1)) {
-            (void)pb_launch_flags(pb_hubseq_kernel, dim3(seq_wgs), dim3(PB_SEQ_WG), 0, st, launched, sc->vals,
+            (void)pb_launch_flags(pb_hubseq_kernel<PB_SEQ_WG>, dim3(seq_wgs), dim3(PB_SEQ_WG), 0, st, launched, sc->vals,
                                   pl->p2_dst.as<uint16_t>(), items + pl->G_long, pl->seq_blk_first.as<uint32_t>(),
                                   pl->seq_blk.as<uint4>(), pl->seq_rows.as<uint32_t>(), pl->hh_ent.as<uint32_t>(),
                                   sc->hot_x.as<float>(), pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr, base, damping,
@@ -3932,11 +3944,15 @@ static bool pb_hub_dispatch(const PbPlan *pl, PbScratch *sc, float *x_out, float
         if (own)
             (void)hipEventRecord(sc->ev_chain_join, ls);
     }
-    if (have_seq)
-        hipLaunchKernelGGL(pb_hubseq_kernel, dim3(seq_wgs), dim3(PB_SEQ_WG), 0, st, sc->vals, pl->p2_dst.as<uint16_t>(),
+    if (have_seq) {
+        // (GM_PB_SEQ_WIDE=0 / 1, measurements: never / always the 512-thread workgroups)
+        const bool wide = pb_env_m("GM_PB_SEQ_WIDE", (sub != nullptr || pl->x_len != pl->n_local) ? 1 : 0) != 0;
+        auto *kernel = wide ? pb_hubseq_kernel<PB_SEQ_WG_WIDE> : pb_hubseq_kernel<PB_SEQ_WG>;
+        hipLaunchKernelGGL(kernel, dim3(seq_wgs), dim3(wide ? PB_SEQ_WG_WIDE : PB_SEQ_WG), 0, st, sc->vals, pl->p2_dst.as<uint16_t>(),
                            items + pl->G_long, pl->seq_blk_first.as<uint32_t>(), pl->seq_blk.as<uint4>(), pl->seq_rows.as<uint32_t>(),
                            pl->hh_ent.as<uint32_t>(), sc->hot_x.as<float>(), pl->hub_rows.as<uint32_t>(), outdeg, scores, x_out, gerr,
                            base, damping, v_safe, h_safe, n_seq, (uint32_t)pb_env_m("GM_PB_SEQ_PRIO", 1), sc->fold, seq_list);
+    }
     if (own)
         (void)hipStreamWaitEvent(st, sc->ev_chain_join, 0);
     return have_long || have_seq;
