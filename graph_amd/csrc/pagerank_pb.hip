@@ -1784,7 +1784,6 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5, 8))) void
     info_a = issue_i(1u);
     lds_barrier();
     float S = 0.0f; // page_rank.rs:143: the row's sum starts at zero ...
-    const f32x4 *b4 = reinterpret_cast<const f32x4 *>(buf);
     // round b: `cur` / `hcur` / `info_cur` hold block b + 1 (requested one round ago), block b + 2 goes into `nxt` / `hnxt`
     auto round = [&](uint32_t b, Stream &cur, Hot &hcur, uint32_t &info_cur, Stream &nxt, Hot &hnxt, uint32_t &info_nxt) {
         issue_g(b + 2u, hnxt);
@@ -1801,7 +1800,23 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5, 8))) void
                 // (page_rank.rs:144-146).
                 constexpr uint32_t Q = PB_SEQ_PAD / 4u;
                 f32x4 a0, a1, a2, a3, n0, n1, n2, n3;
-#define GM_SEQ_GET(x0, x1, x2, x3, at) x0 = b4[at], x1 = b4[(at) + 1], x2 = b4[(at) + 2], x3 = b4[(at) + 3]
+                // The LDS reads are INLINE ASSEMBLY with hand-placed waits (round 6).  Written as plain loads, the request for the
+                // next step sat behind `if (k + Q < end)`: the compiler could not count the reads in flight and waited for the step
+                // it had just requested before the first add of the one at hand (s_waitcnt lgkmcnt(3) with four younger reads
+                // outstanding) — every step paid an LDS round trip; made unconditional, the compiler moved each request down to its
+                // first use, same round trip.  Here the next step's four reads are requested (behind a row's last step they read
+                // whatever follows, clamped to the buffer, and nothing is added), then lgkmcnt(4) — LDS returns in order: the step
+                // at hand has arrived, the four younger reads stay in flight under its 16 dependent adds.  (Waits the compiler
+                // places for its own LDS accesses stay correct with older or younger reads of these outstanding: a count-based wait
+                // can only wait for more.)
+                constexpr uint32_t K_SAFE = (PB_SEQ_BUF + 4u) / 4u - Q;
+                const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(buf); // (a flat LDS address: its low half is the offset)
+#define GM_SEQ_GET(x0, x1, x2, x3, at)                                                                                      \
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48" \
+                 : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3)                                                                \
+                 : "v"(lds0 + (at) * 16u)                                                                                   \
+                 : "memory")
+#define GM_SEQ_ARRIVED(x0, x1, x2, x3) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3))
 #define GM_SEQ_ADD(x0, x1, x2, x3)                                                                                          \
     S = __fadd_rn(S, x0.x), S = __fadd_rn(S, x0.y), S = __fadd_rn(S, x0.z), S = __fadd_rn(S, x0.w);                         \
     S = __fadd_rn(S, x1.x), S = __fadd_rn(S, x1.y), S = __fadd_rn(S, x1.z), S = __fadd_rn(S, x1.w);                         \
@@ -1809,20 +1824,22 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5, 8))) void
     S = __fadd_rn(S, x3.x), S = __fadd_rn(S, x3.y), S = __fadd_rn(S, x3.z), S = __fadd_rn(S, x3.w)
                 GM_SEQ_GET(a0, a1, a2, a3, k);
                 for (;;) {
-                    if (k + Q < end)
-                        GM_SEQ_GET(n0, n1, n2, n3, k + Q);
+                    GM_SEQ_GET(n0, n1, n2, n3, (k + Q < K_SAFE ? k + Q : K_SAFE));
+                    GM_SEQ_ARRIVED(a0, a1, a2, a3);
                     GM_SEQ_ADD(a0, a1, a2, a3);
                     k += Q;
                     if (k >= end)
                         break;
-                    if (k + Q < end)
-                        GM_SEQ_GET(a0, a1, a2, a3, k + Q);
+                    GM_SEQ_GET(a0, a1, a2, a3, (k + Q < K_SAFE ? k + Q : K_SAFE));
+                    GM_SEQ_ARRIVED(n0, n1, n2, n3);
                     GM_SEQ_ADD(n0, n1, n2, n3);
                     k += Q;
                     if (k >= end)
                         break;
                 }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #undef GM_SEQ_ADD
+#undef GM_SEQ_ARRIVED
 #undef GM_SEQ_GET
             }
             if (more)
