@@ -360,16 +360,49 @@ __global__ void pb_hubflag_kernel(const uint32_t *__restrict__ off, uint32_t n, 
         flag[r] = (r < n && hub_deg && off[r + 1] - off[r] >= hub_deg) ? 1u : 0u;
 }
 
+// ... and rows BELOW it that sum many CONSTANT terms (round 6; whole graphs: a row's sources are rows of the same CSR).  A source without
+// in-edges carries (1 - d) / n in every sweep, so the out_scores of such sources are equal within an out-degree class, and the
+// reference's left-to-right f32 sum of equal terms drifts SYSTEMATICALLY (every add rounds the same way while the sum stays in one
+// binade): an exactly rounded sum misses the reference by that drift — by up to 6e-5 on a row of 4000 leaf followers, for most n that
+// are not powers of two once a row has 2000 of them, never with 500 (tests/test_gpu_hub_order.py).  With
+// GM_PB_HUB_LEAVES=<leaf_t> a row with at least that many such sources is a hub row whatever its length: summed the reference's way.
+// (RMAT: rows below 4096 in-edges have at most 55 of them at scale 22 / 24 / 26 — no BASELINE row would be flagged;
+// tools/leaf_sources_count.py; 7 ms of the plan build at scale 26.)  One wavefront looks at
+// 64 consecutive rows and walks the lists of those whose in-degree lies in [leaf_t, hub_deg).
+__global__ __launch_bounds__(256) void pb_leafflag_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ src, uint32_t n,
+                                                          uint32_t hub_deg, uint32_t leaf_t, uint32_t *__restrict__ flag)
+{
+    const uint32_t lane = threadIdx.x & (kWave - 1u);
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave, waves = (uint64_t)gridDim.x * blockDim.x / kWave;
+    for (uint64_t r0 = wave * kWave; r0 < n; r0 += waves * kWave) {
+        const uint32_t r = (uint32_t)r0 + lane;
+        const uint32_t b = r < n ? off[r] : 0u, e = r < n ? off[r + 1] : 0u;
+        uint64_t todo = __ballot(e - b >= leaf_t && e - b < hub_deg);
+        while (todo) {
+            const int l = __ffsll((unsigned long long)todo) - 1;
+            todo &= todo - 1;
+            const uint32_t rb_ = __shfl(b, l), re_ = __shfl(e, l);
+            uint32_t c = 0;
+            for (uint32_t k = rb_ + lane; k < re_; k += kWave) {
+                const uint32_t s_ = src[k];
+                c += (s_ < n && off[s_ + 1] == off[s_]) ? 1u : 0u;
+            }
+            const uint32_t total = (uint32_t)wave_sum((uint64_t)c);
+            if (lane == 0 && total >= leaf_t)
+                flag[(uint32_t)r0 + (uint32_t)l] = 1u;
+        }
+    }
+}
+
 // their ids and in-degrees in ascending row order (pos_h = exclusive scan of the hub flags)
-__global__ void pb_hub_rows_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ pos_h, uint32_t n,
-                                   uint32_t hub_deg, uint32_t *__restrict__ hub_rows, uint32_t *__restrict__ hub_degs)
+__global__ void pb_hub_rows_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ pos_h, const uint32_t *__restrict__ flag,
+                                   uint32_t n, uint32_t *__restrict__ hub_rows, uint32_t *__restrict__ hub_degs)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
-        const uint32_t deg = off[r + 1] - off[r];
-        if (hub_deg && deg >= hub_deg) {
+        if (flag[r]) {
             hub_rows[pos_h[r]] = r;
-            hub_degs[pos_h[r]] = deg;
+            hub_degs[pos_h[r]] = off[r + 1] - off[r];
         }
     }
 }
@@ -383,23 +416,25 @@ __global__ void pb_hub_repos_kernel(const uint32_t *__restrict__ hub_rows, uint3
         pos_h[hub_rows[k]] = k;
 }
 
-__global__ void pb_rowflag_kernel(const uint32_t *__restrict__ off, uint32_t n, uint32_t hub_deg, uint32_t *__restrict__ flag)
+// (in place: flag holds the hub flags and receives "a row with in-edges that is no hub row")
+__global__ void pb_rowflag_kernel(const uint32_t *__restrict__ off, uint32_t n, uint32_t *__restrict__ flag)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r <= n; r += stride) {
         const uint32_t deg = r < n ? off[r + 1] - off[r] : 0u;
-        flag[r] = (deg && !(hub_deg && deg >= hub_deg)) ? 1u : 0u;
+        flag[r] = (deg && !(r < n && flag[r])) ? 1u : 0u;
     }
 }
 
-__global__ void pb_cidx_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ pos, uint32_t n, int rb,
-                               uint32_t hub_deg, uint16_t *__restrict__ cidx, uint32_t *__restrict__ bin_rows)
+// (ordinary: pb_rowflag_kernel's flags — a row with in-edges that is not ordinary is a hub row)
+__global__ void pb_cidx_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ pos, const uint32_t *__restrict__ ordinary,
+                               uint32_t n, int rb, uint16_t *__restrict__ cidx, uint32_t *__restrict__ bin_rows)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
         const uint32_t base = pos[(r >> rb) << rb];
         const uint32_t deg = off[r + 1] - off[r];
-        cidx[r] = !deg ? PB_NULL : (hub_deg && deg >= hub_deg) ? PB_HUBROW : (uint16_t)(pos[r] - base);
+        cidx[r] = !deg ? PB_NULL : !ordinary[r] ? PB_HUBROW : (uint16_t)(pos[r] - base);
         if ((r & ((1u << rb) - 1u)) == 0) {
             const uint64_t end = ((uint64_t)((r >> rb) + 1) << rb);
             bin_rows[r >> rb] = pos[end < n ? end : n] - base;
@@ -2541,6 +2576,14 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
         GM_TRY(bin_rows.alloc((size_t)pl->B * 4));
         hipLaunchKernelGGL(pb_hubflag_kernel, dim3(pb_grid((uint64_t)n + 1)), dim3(256), 0, 0, csr->offsets, n, pl->hub_deg,
                            flag.as<uint32_t>());
+        // rows below the threshold with many sources that have no in-edges themselves (GM_PB_HUB_LEAVES=<how many>, e.g. 512; default
+        // 0 = OFF): see pb_leafflag_kernel.  Whole graphs only — in a partition slice a source's in-degree is another rank's knowledge,
+        // and that is why the rule is not the default yet: where it flags a row, the single engine's bits are no longer the
+        // partitioned run's (tests/test_gpu_multi.py at scale 17), until both partitioned fronts hand their slices the same flags.
+        const uint32_t leaf_t = (uint32_t)pb_env("GM_PB_HUB_LEAVES", 0);
+        if (x_len == n && leaf_t && pl->hub_deg > leaf_t)
+            hipLaunchKernelGGL(pb_leafflag_kernel, dim3(pb_grid(n)), dim3(256), 0, 0, csr->offsets, csr->targets, n, pl->hub_deg, leaf_t,
+                               flag.as<uint32_t>());
         GM_HIP(hipGetLastError());
         GM_TRY(scan_exclusive<uint32_t>(flag.as<uint32_t>(), pos_h.as<uint32_t>(), (uint64_t)n + 1));
         GM_HIP(hipMemcpy(&pl->n_hub, pos_h.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost));
@@ -2551,8 +2594,8 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
             DevBuf hub_degs;
             GM_TRY(pl->hub_rows.alloc((size_t)pl->n_hub * 4));
             GM_TRY(hub_degs.alloc((size_t)pl->n_hub * 4));
-            hipLaunchKernelGGL(pb_hub_rows_kernel, dim3(pb_grid(n)), dim3(256), 0, 0, csr->offsets, pos_h.as<uint32_t>(), n,
-                               pl->hub_deg, pl->hub_rows.as<uint32_t>(), hub_degs.as<uint32_t>());
+            hipLaunchKernelGGL(pb_hub_rows_kernel, dim3(pb_grid(n)), dim3(256), 0, 0, csr->offsets, pos_h.as<uint32_t>(), flag.as<uint32_t>(),
+                               n, pl->hub_rows.as<uint32_t>(), hub_degs.as<uint32_t>());
             GM_HIP(hipGetLastError());
             std::vector<uint32_t> degs(pl->n_hub);
             GM_HIP(hipMemcpy(degs.data(), hub_degs.p, (size_t)pl->n_hub * 4, hipMemcpyDeviceToHost));
@@ -2676,12 +2719,11 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
         GM_TRY(pl->hub_first.alloc(pl->hub_first_host.size() * 4));
         GM_HIP(hipMemcpy(pl->hub_first.p, pl->hub_first_host.data(), pl->hub_first_host.size() * 4, hipMemcpyHostToDevice));
         timer.done("pb plan: - hub groups");
-        hipLaunchKernelGGL(pb_rowflag_kernel, dim3(pb_grid((uint64_t)n + 1)), dim3(256), 0, 0, csr->offsets, n, pl->hub_deg,
-                           flag.as<uint32_t>());
+        hipLaunchKernelGGL(pb_rowflag_kernel, dim3(pb_grid((uint64_t)n + 1)), dim3(256), 0, 0, csr->offsets, n, flag.as<uint32_t>());
         GM_HIP(hipGetLastError());
         GM_TRY(scan_exclusive<uint32_t>(flag.as<uint32_t>(), pos.as<uint32_t>(), (uint64_t)n + 1));
-        hipLaunchKernelGGL(pb_cidx_kernel, dim3(pb_grid(n)), dim3(256), 0, 0, csr->offsets, pos.as<uint32_t>(), n, rb,
-                           pl->hub_deg, pl->cidx.as<uint16_t>(), bin_rows.as<uint32_t>());
+        hipLaunchKernelGGL(pb_cidx_kernel, dim3(pb_grid(n)), dim3(256), 0, 0, csr->offsets, pos.as<uint32_t>(), flag.as<uint32_t>(), n, rb,
+                           pl->cidx.as<uint16_t>(), bin_rows.as<uint32_t>());
         GM_HIP(hipGetLastError());
         std::vector<uint32_t> rows(pl->B);
         GM_HIP(hipMemcpy(rows.data(), bin_rows.p, (size_t)pl->B * 4, hipMemcpyDeviceToHost));

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6, GPU call 16: differential fuzz of the final library (a7520f35, 3c8d66f2, c03c6d43) against the oracle and the SSSP schedule stress, as at the end of round 5
+# round 6, GPU call 16: differential fuzz of the final library (a7520f35, 3c8d66f2, c03c6d43, c94a0cfe) against the oracle and the SSSP schedule stress, as at the end of round 5
 OUT=gpurun_out/r06o; mkdir -p $OUT; export TMPDIR=/tmp
 sha256sum graph_amd/libgraph_mi355x.so > $OUT/lib.sha256
 ( time timeout 300 python tools/fuzz_parity.py 200 601 3000 20000 ) > $OUT/fuzz_a.log 2>&1; tail -4 $OUT/fuzz_a.log
