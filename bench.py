@@ -276,10 +276,16 @@ def main():
             x_len = world * stride
         h = vp()
         check(lib().gm_csr_slice_rows_map(in_csr.handle, row_lo, row_hi, node_map.data_ptr(), C.byref(h)))
-        del node_map
         from graph_amd.prelude import DeviceCsr
 
         local_csr = DeviceCsr(h)
+        # which slots of the exchanged vector hold nodes without in-edges (global knowledge: rank_local_rows' summed histogram), so that
+        # the slice's plan flags the rows the whole graph's plan would (rows of many constant terms; RMAT: none)
+        if getattr(in_csr, "no_in_edges", None) is not None:
+            from graph_amd.distributed import source_flags
+
+            local_csr.set_source_flags(source_flags(node_map, in_csr.no_in_edges, x_len))
+        del node_map
         out_deg_local = out_deg[row_lo:row_hi].contiguous() if n_local else torch.zeros(1, dtype=torch.int32, device=dev)
         del in_csr
         in_csr = None

@@ -31,6 +31,7 @@ SIGNATURES = {
     "gm_csr_wrap_device": (i32, [u64, u64, u64, u64, u64, i32, PP]),
     "gm_csr_free": (None, [vp]),
     "gm_csr_trim": (i32, [vp]),
+    "gm_csr_set_source_flags": (i32, [vp, u64, u64]),
     "gm_trim": (i32, [i32]),
     "gm_arena_info": (i32, [i32, vp]),
     "gm_arena_va_info": (i32, [i32, vp]),

@@ -589,6 +589,17 @@ struct SsspScratch {
 } // namespace gm
 
 // The opaque handle of include/graph_mi355x.h.
+namespace gm {
+// GM_PB_HUB_LEAVES: a row with at least this many sources that have no in-edges themselves is summed in the reference's order whatever
+// its length (pagerank_pb.hip: pb_leafflag_kernel); 0 = the rule is off.  One reader for the plan builder and the partitioned front.
+constexpr uint32_t kHubLeavesDefault = 512;
+inline uint32_t hub_leaves_threshold()
+{
+    const char *v = getenv("GM_PB_HUB_LEAVES");
+    return v && *v ? (uint32_t)atoi(v) : kHubLeavesDefault;
+}
+} // namespace gm
+
 struct gm_csr {
     uint64_t n = 0;
     uint64_t m = 0;
@@ -615,4 +626,8 @@ struct gm_csr {
     mutable std::unique_ptr<gm::MultiState, gm::MultiStateDeleter> multi; // gm_page_rank_multi's resident run (in-CSR handle)
     // (threshold << 1 | answer) of the last look: does some row have >= GM_PB_HUB_DEG entries?  -1: not looked at yet
     mutable std::atomic<long long> long_rows{-1};
+    // gm_csr_set_source_flags: one byte per entry of the x vector the rows' lists index (a partition slice: exchange slots), non-zero =
+    // "this source has no in-edges" — what a slice cannot see in its own offsets (the plan builder's rule for rows of constant terms)
+    gm::DevBuf source_flags;
+    uint64_t source_flags_len = 0;
 };

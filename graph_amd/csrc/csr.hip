@@ -240,6 +240,26 @@ GM_API void gm_csr_free(gm_csr *csr)
     delete csr;
 }
 
+GM_API int gm_csr_set_source_flags(gm_csr *csr, uint64_t d_flags, uint64_t len)
+{
+    GM_CHECK(csr, GM_ERR_INVALID, "gm_csr_set_source_flags: null handle");
+    gm::DeviceGuard guard(csr->device);
+    std::map<uint64_t, std::shared_ptr<const gm::PbPlan>> plans; // (a plan built without the flags is not the plan with them)
+    {
+        std::lock_guard<std::mutex> lock(csr->cache_mu);
+        plans.swap(csr->pb_plans);
+    }
+    plans.clear();
+    csr->source_flags.release();
+    csr->source_flags_len = 0;
+    if (!d_flags || !len)
+        return GM_OK;
+    GM_TRY(csr->source_flags.alloc((size_t)len));
+    GM_HIP(hipMemcpy(csr->source_flags.p, reinterpret_cast<const void *>(d_flags), (size_t)len, hipMemcpyDeviceToDevice));
+    csr->source_flags_len = len;
+    return GM_OK;
+}
+
 GM_API int gm_csr_trim(const gm_csr *csr)
 {
     GM_CHECK(csr, GM_ERR_INVALID, "gm_csr_trim: null handle");

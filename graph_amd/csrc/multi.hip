@@ -297,6 +297,24 @@ using MultiPtr = std::unique_ptr<gm::MultiState, gm::MultiStateDeleter>;
 
 // What a rank is built from, all of it on the rank's own device: its rows of the in-CSR (offsets rebased to 0, targets as
 // GLOBAL node ids) and the out-degree of EVERY node (which nodes are ever gathered, and its own rows' divisors).  Consumed.
+// which local rows have in-edges (one byte per row)
+__global__ void mg_has_in_kernel(const uint32_t *__restrict__ off, uint32_t rows, uint8_t *__restrict__ out)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += stride)
+        out[r] = off[r + 1] != off[r] ? 1 : 0;
+}
+
+// per entry of the exchange vector: does the node in that slot have NO in-edges?  (gm_csr_set_source_flags)
+__global__ void mg_slot_flags_kernel(const uint32_t *__restrict__ node_map, const uint8_t *__restrict__ has_in, uint32_t n,
+                                     uint8_t *__restrict__ slot_flags)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += stride)
+        if (node_map[v] != 0xFFFFFFFFu && !has_in[v])
+            slot_flags[node_map[v]] = 1;
+}
+
 struct RankInput {
     int device = 0;
     DevBuf off, tgt, outdeg_full;
@@ -328,7 +346,7 @@ uint64_t multi_env_hash()
                                         "GM_PB_HUB_GROUP", "GM_PB_HUB_LONG",  "GM_PB_HUB_HOT",   "GM_PB_HUB_CSR",   "GM_PB_HUB_ROOM", "GM_PB_HUB_THIN", "GM_PB_HOT_TRIM",
                                         "GM_PB_HUB_FORK",  "GM_PB_LONG_PASSES", "GM_PB_TIERS",   "GM_PB_HOT16",     "GM_PB_SEGPAD",
                                         "GM_PB_SPREAD",    "GM_PB_SPREAD_PLAN", "GM_PB_FILTER_BITS", "GM_PB_WG_GROUP", "GM_PB_BIN_GAP",
-                                        "GM_MULTI_ENGINE", "GM_MULTI_PARTS"};
+                                        "GM_MULTI_ENGINE", "GM_MULTI_PARTS",  "GM_PB_HUB_LEAVES", "GM_PB_HUB_REGROUP", "GM_PB_HUB_SLICE_GROUPS"};
     uint64_t h = 1469598103934665603ull;
     for (const char *name : knobs) {
         const char *v = getenv(name);
@@ -428,6 +446,24 @@ int multi_build_from(std::vector<RankInput> &in, const std::vector<uint32_t> &bo
     }
     const uint64_t x_len = ms->x_len;
     timer.done("multi: partition + exchange layout (%u ranks, %u regions)", P, K);
+    // Which nodes have no in-edges at all?  Every rank knows it of its own rows; the plan builder's rule for rows of constant terms
+    // (GM_PB_HUB_LEAVES) needs it of every SOURCE, so that a slice flags the rows the whole graph's plan flags and the partitioned
+    // run's bits stay the single engine's.  n bytes through the host (any topology), only when the rule is on.
+    std::vector<uint8_t> has_in;
+    if (gm::hub_leaves_threshold()) {
+        has_in.assign((size_t)n, 0);
+        for (uint32_t p = 0; p < P; ++p) {
+            const uint32_t rows = bounds[p + 1] - bounds[p];
+            if (!rows)
+                continue;
+            DeviceGuard g(devs[p]);
+            DevBuf d;
+            GM_TRY(d.alloc(rows));
+            hipLaunchKernelGGL(mg_has_in_kernel, dim3(mg_grid(rows)), dim3(256), 0, 0, in[p].off.as<uint32_t>(), rows, d.as<uint8_t>());
+            GM_HIP(hipGetLastError());
+            GM_HIP(hipMemcpy(has_in.data() + bounds[p], d.p, rows, hipMemcpyDeviceToHost));
+        }
+    }
 
     // ---- one rank per device: row slice, exchange buffers, engine ------------------------------------------
     for (uint32_t p = 0; p < P; ++p) {
@@ -461,6 +497,18 @@ int multi_build_from(std::vector<RankInput> &in, const std::vector<uint32_t> &bo
             hipLaunchKernelGGL(mg_map_targets_kernel, dim3(mg_grid(cnt)), dim3(256), 0, 0, in[p].tgt.as<uint32_t>(), cnt,
                                loc[p].node_map.as<uint32_t>());
         GM_HIP(hipGetLastError());
+        DevBuf slot_flags;
+        if (!has_in.empty() && n) {
+            DevBuf d_has_in;
+            GM_TRY(d_has_in.alloc((size_t)n));
+            GM_TRY(slot_flags.alloc((size_t)(x_len ? x_len : 1)));
+            GM_HIP(hipMemcpy(d_has_in.p, has_in.data(), (size_t)n, hipMemcpyHostToDevice));
+            GM_HIP(hipMemset(slot_flags.p, 0, (size_t)(x_len ? x_len : 1)));
+            hipLaunchKernelGGL(mg_slot_flags_kernel, dim3(mg_grid(n)), dim3(256), 0, 0, loc[p].node_map.as<uint32_t>(), d_has_in.as<uint8_t>(),
+                               n, slot_flags.as<uint8_t>());
+            GM_HIP(hipGetLastError());
+            GM_HIP(hipDeviceSynchronize());
+        }
         GM_HIP(hipDeviceSynchronize());
         loc[p].flag.release(), loc[p].pos.release(), loc[p].node_map.release();
         in[p].outdeg_full.release();
@@ -473,6 +521,9 @@ int multi_build_from(std::vector<RankInput> &in, const std::vector<uint32_t> &bo
         c->offsets = c->own_offsets.as<uint32_t>();
         c->targets = c->own_targets.as<uint32_t>();
         r.rows = c;
+        if (slot_flags.p && x_len)
+            GM_TRY(gm_csr_set_source_flags(c, (uint64_t)slot_flags.p, x_len));
+        slot_flags.release();
         GM_TRY(r.scores.alloc((size_t)(rows ? rows : 1) * 4));
         GM_TRY(r.x_loc.alloc((size_t)(rows ? rows : 1) * 4));
         GM_TRY(r.x[0].alloc((size_t)x_len * 4));

@@ -364,13 +364,15 @@ __global__ void pb_hubflag_kernel(const uint32_t *__restrict__ off, uint32_t n, 
 // in-edges carries (1 - d) / n in every sweep, so the out_scores of such sources are equal within an out-degree class, and the
 // reference's left-to-right f32 sum of equal terms drifts SYSTEMATICALLY (every add rounds the same way while the sum stays in one
 // binade): an exactly rounded sum misses the reference by that drift — by up to 6e-5 on a row of 4000 leaf followers, for most n that
-// are not powers of two once a row has 2000 of them, never with 500 (tests/test_gpu_hub_order.py).  With
-// GM_PB_HUB_LEAVES=<leaf_t> a row with at least that many such sources is a hub row whatever its length: summed the reference's way.
-// (RMAT: rows below 4096 in-edges have at most 55 of them at scale 22 / 24 / 26 — no BASELINE row would be flagged;
+// are not powers of two once a row has 2000 of them, never with 500 (tests/test_gpu_hub_order.py).  A row with at least
+// `leaf_t` such sources (GM_PB_HUB_LEAVES, default 512) is therefore a hub row whatever its length: summed the reference's way.
+// (RMAT: rows below 4096 in-edges have at most 55 of them at scale 22 / 24 / 26 — no BASELINE row is flagged;
 // tools/leaf_sources_count.py; 7 ms of the plan build at scale 26.)  One wavefront looks at
 // 64 consecutive rows and walks the lists of those whose in-degree lies in [leaf_t, hub_deg).
+// (src_flags: a partition slice's list of which entries of its x vector are such sources, gm_csr_set_source_flags; null: whole graph)
 __global__ __launch_bounds__(256) void pb_leafflag_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ src, uint32_t n,
-                                                          uint32_t hub_deg, uint32_t leaf_t, uint32_t *__restrict__ flag)
+                                                          uint32_t hub_deg, uint32_t leaf_t, const uint8_t *__restrict__ src_flags,
+                                                          uint64_t src_flags_len, uint32_t *__restrict__ flag)
 {
     const uint32_t lane = threadIdx.x & (kWave - 1u);
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave, waves = (uint64_t)gridDim.x * blockDim.x / kWave;
@@ -385,7 +387,10 @@ __global__ __launch_bounds__(256) void pb_leafflag_kernel(const uint32_t *__rest
             uint32_t c = 0;
             for (uint32_t k = rb_ + lane; k < re_; k += kWave) {
                 const uint32_t s_ = src[k];
-                c += (s_ < n && off[s_ + 1] == off[s_]) ? 1u : 0u;
+                if (src_flags)
+                    c += (s_ < src_flags_len && src_flags[s_]) ? 1u : 0u;
+                else
+                    c += (s_ < n && off[s_ + 1] == off[s_]) ? 1u : 0u;
             }
             const uint32_t total = (uint32_t)wave_sum((uint64_t)c);
             if (lane == 0 && total >= leaf_t)
@@ -2576,13 +2581,15 @@ int pb_build(const gm_csr *csr, uint64_t x_len, PbPlan *pl)
         GM_TRY(bin_rows.alloc((size_t)pl->B * 4));
         hipLaunchKernelGGL(pb_hubflag_kernel, dim3(pb_grid((uint64_t)n + 1)), dim3(256), 0, 0, csr->offsets, n, pl->hub_deg,
                            flag.as<uint32_t>());
-        // rows below the threshold with many sources that have no in-edges themselves (GM_PB_HUB_LEAVES=<how many>, e.g. 512; default
-        // 0 = OFF): see pb_leafflag_kernel.  Whole graphs only — in a partition slice a source's in-degree is another rank's knowledge,
-        // and that is why the rule is not the default yet: where it flags a row, the single engine's bits are no longer the
-        // partitioned run's (tests/test_gpu_multi.py at scale 17), until both partitioned fronts hand their slices the same flags.
-        const uint32_t leaf_t = (uint32_t)pb_env("GM_PB_HUB_LEAVES", 0);
-        if (x_len == n && leaf_t && pl->hub_deg > leaf_t)
+        // rows below the threshold with many sources that have no in-edges themselves (GM_PB_HUB_LEAVES=<how many>, default 512; 0 = off):
+        // see pb_leafflag_kernel.  A whole graph reads a source's in-degree off its own offsets; a partition slice needs the flags
+        // of gm_csr_set_source_flags (the C++ partitioned front hands them over, multi.hip) — without them the rule is skipped
+        // there, and where it would have flagged a row the slice's bits are not the single engine's.
+        const uint32_t leaf_t = hub_leaves_threshold();
+        const bool have_flags = csr->source_flags_len >= x_len && csr->source_flags.p;
+        if ((x_len == n || have_flags) && leaf_t && pl->hub_deg > leaf_t)
             hipLaunchKernelGGL(pb_leafflag_kernel, dim3(pb_grid(n)), dim3(256), 0, 0, csr->offsets, csr->targets, n, pl->hub_deg, leaf_t,
+                               have_flags ? csr->source_flags.as<uint8_t>() : (const uint8_t *)nullptr, csr->source_flags_len,
                                flag.as<uint32_t>());
         GM_HIP(hipGetLastError());
         GM_TRY(scan_exclusive<uint32_t>(flag.as<uint32_t>(), pos_h.as<uint32_t>(), (uint64_t)n + 1));

@@ -211,6 +211,17 @@ def split_exchange_layout(out_degree, bounds, parts: int = 2, row_align: int = R
             "world": world, "row_splits": row_splits, "send_rows": send_rows, "parts": parts}
 
 
+def source_flags(node_map: torch.Tensor, no_in_edges: torch.Tensor, x_len: int):
+    """uint8[x_len] for DeviceCsr.set_source_flags (gm_csr_set_source_flags): 1 where the node in that slot of the exchanged vector
+    has no in-edges.  node_map int32[n] (-1: never a source), no_in_edges bool / uint8 [n] over the GLOBAL in-degrees (a rank's
+    slice cannot see them in its own offsets).  With the flags a slice's propagation-blocking plan flags the rows the whole graph's
+    plan flags — rows that sum many constant terms are summed the reference's way (GM_PB_HUB_LEAVES)."""
+    flags = torch.zeros(max(int(x_len), 1), dtype=torch.uint8, device=node_map.device)
+    sel = (node_map >= 0) & no_in_edges.to(node_map.device).bool()
+    flags[node_map[sel].long()] = 1
+    return flags
+
+
 def region_ranges(layout, k: int):
     """[(lo, hi)] of region k of a split_exchange_layout vector: one stretch per rank"""
     return [(p * layout["block"] + layout["group_off"][k], p * layout["block"] + layout["group_off"][k] + layout["strides"][k])
@@ -507,8 +518,8 @@ def rank_local_rows(scale: int, seed: int, rank: int, world: int, device: int = 
       3. the edges whose destination lies in this rank's range, kept from a chunked scan of the generator;
       4. a Sorted in-CSR over them (n rows, all but the rank's own empty).
 
-    Returns (csr over the rank's edges, bounds uint32[world + 1], out_degree int32[n] on the device, peak bytes of the edge
-    buffers).  The caller slices rows [bounds[rank], bounds[rank + 1]) out of the CSR (gm_csr_slice_rows_map: targets rewritten
+    Returns (csr over the rank's edges — with `.no_in_edges`, uint8[n] over the GLOBAL in-degrees, for source_flags() —, bounds
+    uint32[world + 1], out_degree int32[n] on the device, peak bytes of the edge buffers).  The caller slices rows [bounds[rank], bounds[rank + 1]) out of the CSR (gm_csr_slice_rows_map: targets rewritten
     into the exchange index space) and drops it."""
     from . import synth
     from .prelude import CsrLayout, Direction
@@ -529,6 +540,7 @@ def rank_local_rows(scale: int, seed: int, rank: int, world: int, device: int = 
         dist.all_reduce(outd, op=dist.ReduceOp.SUM, group=group)
     off = np.zeros(n + 1, np.int64)
     np.cumsum(ind.cpu().numpy(), out=off[1:])
+    no_in_edges = (ind == 0).to(torch.uint8)  # (global: the summed histogram) -> source_flags() for the rank's slice
     del ind
     bounds, _ = pad_bounds(greedy_degree_partition(off, world), world, n)
     del off
@@ -547,4 +559,5 @@ def rank_local_rows(scale: int, seed: int, rank: int, world: int, device: int = 
     local = synth.build_csr(n, s, d, Direction.Incoming, CsrLayout.Sorted, None, device)
     del s, d
     torch.cuda.empty_cache()
+    local.no_in_edges = no_in_edges
     return local, bounds, outd.to(torch.int32), peak

@@ -153,6 +153,18 @@ class DeviceCsr:
         check(lib().gm_csr_degrees(self._h, _ptr(d) if self.n else None))
         return d
 
+    def set_source_flags(self, flags):
+        """gm_csr_set_source_flags: for a ROW SLICE of a partitioned graph — one uint8 per entry of the exchange vector its lists index
+        (a torch CUDA tensor on the handle's device, or None to remove them), non-zero = the node in that slot has no in-edges.  Lets
+        the propagation-blocking plan flag the rows the whole graph's plan flags (GM_PB_HUB_LEAVES)."""
+        if flags is None:
+            check(lib().gm_csr_set_source_flags(self._h, 0, 0))
+            return
+        import torch
+
+        assert flags.dtype == torch.uint8 and flags.is_cuda and flags.is_contiguous()
+        check(lib().gm_csr_set_source_flags(self._h, int(flags.data_ptr()), int(flags.numel())))
+
     def trim(self):
         """gm_csr_trim: release what the handle parked for later calls (PageRank plan and call state, SSSP / WCC working
         sets, the triangle count's DAG, the multi-GPU state); the graph stays, the next call rebuilds what it needs."""

@@ -81,6 +81,13 @@ int gm_csr_upload_u64(const uint64_t *offsets, const uint64_t *targets, const fl
 int gm_csr_wrap_device(uint64_t d_offsets, uint64_t d_targets, uint64_t d_weights, uint64_t n, uint64_t m,
                        int device, gm_csr **out);
 void gm_csr_free(gm_csr *csr);
+/* For a handle that holds a ROW SLICE of a partitioned graph whose lists index an exchange vector (gm_pr_create_with's x_len): one byte
+ * per entry of that vector in device memory, non-zero = "the node in this slot has no in-edges".  A slice cannot see that in its own
+ * offsets, and the propagation-blocking plan's rule for rows that sum many constant terms (GM_PB_HUB_LEAVES; the reference's
+ * left-to-right sum of equal terms, page_rank.rs:143-146, drifts systematically: such rows are summed its way whatever their length)
+ * needs it to flag the same rows as the single-GPU plan of the whole graph does.  The bytes are copied; plans built before the call are
+ * dropped.  d_flags = 0 or len = 0 removes them.  Whole graphs need no flags: a source's in-degree is in the handle's own offsets. */
+int gm_csr_set_source_flags(gm_csr *csr, uint64_t d_flags, uint64_t len);
 /* Releases what the handle has parked for later calls (see "WHAT A HANDLE RETAINS" above): plans, DAGs,
  * working sets.  The graph itself stays; calls in flight keep what they are using. */
 int gm_csr_trim(const gm_csr *csr);

@@ -130,11 +130,11 @@ def test_rows_of_equal_terms_below_the_threshold_follow_the_reference(P, oracle,
     (in-degree 0, out-degree 1: each at exactly (1 - d) / n) — the reference's left-to-right f32 sum (page_rank.rs:143-146)
     drifts systematically and an exact sum does not follow it: by an amount that depends on n through the bits of (1 - d) / n and
     exceeds the north-star 1e-5 for most n once k >= 2000 (the model below: a cumsum in f32 against the rounded product; found in
-    round 6, profiles/r06_leaf_fan_probe.txt) — a KNOWN DEVIATION of the default plan.  With GM_PB_HUB_LEAVES=512 (whole graphs; not
-    the default yet: partition slices cannot evaluate it) a row with at least 512 sources that have no in-edges
-    themselves is a hub row whatever its length — summed the reference's way: its bits.  Checked here at an n where the drift is
-    large (6e-5 at 4095 terms): the plan with the rule against the reference on every row, and — without it, the default — that the
-    deviation is what the model says."""
+    round 6, profiles/r06_leaf_fan_probe.txt).  Since then a row with at least 512 sources that have no in-edges themselves
+    (GM_PB_HUB_LEAVES) is a hub row whatever its length — summed the reference's way: its bits.  Checked here at an n where the drift
+    is large (6e-5 at 4095 terms): the default plan against the reference on every row, the same graph cut over three ranks (the
+    partitioned front hands its slices the flags: the single engine's bits), and — with the rule off — that the deviation is what the
+    model says (so the test would notice the rule going missing)."""
     scale, fans = 16, [300, 511, 1000, 2687, 4095]
     s, d = oracle.rmat_edges(scale, seed=42)
     n0 = 1 << scale
@@ -151,20 +151,23 @@ def test_rows_of_equal_terms_below_the_threshold_follow_the_reference(P, oracle,
     od = oracle.out_degrees_from(n, s)
     ref, _, _ = oracle.page_rank_chunked(ioff, itgt, od, 200, 1e-10, 0.85)
     monkeypatch.setenv("GM_PB_NOCACHE", "1")
-    monkeypatch.setenv("GM_PB_HUB_LEAVES", "512")
+    monkeypatch.setenv("GM_MULTI_ENGINE", "pb")
 
-    def run():
+    def run(devices=None):
         out = P.DeviceCsr.from_edges(n, s, d, None, P.Direction.Outgoing, P.CsrLayout.Sorted)
         inc = P.DeviceCsr.from_edges(n, s, d, None, P.Direction.Incoming, P.CsrLayout.Sorted)
-        got, _, _ = P.page_rank(P.DirectedCsrGraph(out, inc, P.CsrLayout.Sorted), P.PageRankConfig(200, 1e-10, 0.85), P.PageRankMode.JacobiPB)
+        g = P.DirectedCsrGraph(out, inc, P.CsrLayout.Sorted)
+        cfg = P.PageRankConfig(200, 1e-10, 0.85)
+        got, _, _ = P.page_rank(g, cfg, P.PageRankMode.JacobiPB) if devices is None else P.page_rank_multi(g, cfg, devices=devices)
         return np.asarray(got)
 
     got = run()
+    assert np.array_equal(run(devices=[0, 0, 0]), got)          # three virtual ranks: the same bits
     rel = np.abs(got.astype(np.float64) - ref) / ref
-    print(f"n {n}, fans of {fans} equal terms, GM_PB_HUB_LEAVES=512: max rel on every row {rel.max():.2e}; the fans' rows {rel[centres]}")
+    print(f"n {n}, fans of {fans} equal terms, default plan: max rel on every row {rel.max():.2e}; the fans' rows {rel[centres]}")
     assert np.array_equal(got[centres[2:]], ref[centres[2:]])  # 1000 / 2687 / 4095 leaf sources: summed the reference's way, its bits
     assert rel.max() <= 1e-5                                    # (300 and 511 stay exactly rounded sums: within the tolerance)
-    monkeypatch.delenv("GM_PB_HUB_LEAVES")                      # the default plan
+    monkeypatch.setenv("GM_PB_HUB_LEAVES", "0")                 # the rule off: what the plans did until round 6
     off = run()
     v = np.float32((np.float32(1.0) - np.float32(0.85)) / np.float32(n))  # a leaf's score = its out_score (out-degree 1)
     for c, k in zip(centres, fans):
@@ -172,8 +175,8 @@ def test_rows_of_equal_terms_below_the_threshold_follow_the_reference(P, oracle,
         exact = np.float32(float(v) * k)                                      # the exactly rounded one
         model = abs(float(seq) - float(exact)) * 0.85 / float(ref[c])
         r = abs(float(off[c]) - float(ref[c])) / float(ref[c])
-        print(f"   default plan, fan of {k} equal terms: device vs reference {r:.2e}, the model's drift {model:.2e}")
+        print(f"   rule off, fan of {k} equal terms: device vs reference {r:.2e}, the model's drift {model:.2e}")
         assert abs(r - model) <= 0.1 * model + 2e-7
     rel_off = np.abs(off.astype(np.float64) - ref) / ref
-    print(f"   default plan: {int((rel_off > 1e-5).sum())} rows over 1e-5 (max {rel_off.max():.2e}): the fans' rows and what is downstream of them")
+    print(f"   rule off: {int((rel_off > 1e-5).sum())} rows over 1e-5 (max {rel_off.max():.2e}): the fans' rows and what is downstream of them")
     assert rel_off[centres[-1]] > 1e-5 and rel_off.max() <= 1e-4

@@ -39,6 +39,8 @@ layout = split_exchange_layout(out_deg, bounds, parts=args.parts)
 h = vp()
 check(lib().gm_csr_slice_rows_map(in_csr.handle, row_lo, row_hi, layout["node_map"].data_ptr(), C.byref(h)))
 local_csr = DeviceCsr(h)
+from graph_amd.distributed import source_flags
+local_csr.set_source_flags(source_flags(layout["node_map"], in_csr.no_in_edges, layout["x_len"]))
 out_deg_local = out_deg[row_lo:row_hi].contiguous() if n_local else torch.zeros(1, dtype=torch.int32, device=dev)
 engine = PageRankEngine(local_csr.handle, n, row_lo, out_deg_local, 0.85, x_len=layout["x_len"], engine=2)
 scores = torch.zeros(max(n_local, 1), dtype=torch.float32, device=dev)
