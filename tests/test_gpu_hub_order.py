@@ -180,3 +180,70 @@ def test_rows_of_equal_terms_below_the_threshold_follow_the_reference(P, oracle,
     rel_off = np.abs(off.astype(np.float64) - ref) / ref
     print(f"   rule off: {int((rel_off > 1e-5).sum())} rows over 1e-5 (max {rel_off.max():.2e}): the fans' rows and what is downstream of them")
     assert rel_off[centres[-1]] > 1e-5 and rel_off.max() <= 1e-4
+
+
+def test_python_front_slices_with_source_flags_give_the_single_engines_bits(P, oracle):
+    """The one-process-per-rank front (graph_amd/distributed.py) on the graph of the test above: three virtual ranks, a sweep in two
+    pieces each, the slices' handles given the per-slot flags (distributed.source_flags -> DeviceCsr.set_source_flags) — the single
+    engine's bits after every sweep; WITHOUT the flags the slices cannot see that the fans' sources have no in-edges, sum those rows
+    exactly rounded, and differ from the single engine (which is why the flags exist)."""
+    import ctypes as C
+
+    import torch
+    from graph_amd._lib import check, lib, vp
+    from graph_amd.distributed import PiecewiseExchange, greedy_degree_partition, pad_bounds, source_flags, split_exchange_layout
+    from graph_amd.engine import PageRankEngine
+
+    scale, fans, world, sweeps = 16, [1000, 2687, 4095], 3, 6
+    s, d = oracle.rmat_edges(scale, seed=42)
+    n0 = 1 << scale
+    centres = n0 + np.arange(len(fans))
+    at, ls, ld = n0 + len(fans), [], []
+    for c, k in zip(centres, fans):
+        ls.append(np.arange(at, at + k, dtype=np.uint32)); ld.append(np.full(k, c, np.uint32)); at += k
+    s = np.concatenate([s] + ls + [centres.astype(np.uint32)])
+    d = np.concatenate([d] + ld + [np.zeros(len(fans), np.uint32)])
+    n = 297676
+    inc = P.DeviceCsr.from_edges(n, s, d, None, P.Direction.Incoming, P.CsrLayout.Sorted)
+    ioff = inc.host()[0]
+    dev = torch.device("cuda", 0)
+    od = torch.from_numpy(oracle.out_degrees_from(n, s).astype(np.int32)).cuda()
+    no_in = torch.from_numpy((np.diff(ioff.astype(np.int64)) == 0).astype(np.uint8)).cuda()
+    bounds, _ = pad_bounds(greedy_degree_partition(ioff, world), world, n)
+    eng = PageRankEngine(inc.handle, n, 0, od, 0.85, engine=PageRankEngine.PB)
+    assert eng.plan_info()["hub_rows"] >= 3  # (the three fans among them: flagged by the whole graph's plan from its own offsets)
+    x = [torch.zeros(n, device=dev), torch.zeros(n, device=dev)]
+    sc = torch.zeros(n, device=dev)
+    err = torch.zeros(1, dtype=torch.float64, device=dev)
+    eng.init(sc, x[0])
+    for k in range(sweeps):
+        eng.sweep(x[k % 2], x[1 - k % 2], sc, err)
+    lay = split_exchange_layout(od, bounds, parts=2)
+    results = {}
+    for with_flags in (True, False):
+        shared = [torch.zeros(lay["x_len"], device=dev) for _ in range(2)]
+        ranks = []
+        for r in range(world):
+            lo, hi = int(bounds[r]), int(bounds[r + 1])
+            h = vp()
+            check(lib().gm_csr_slice_rows_map(inc.handle, lo, hi, lay["node_map"].data_ptr(), C.byref(h)))
+            csr = P.DeviceCsr(h)
+            if with_flags:
+                csr.set_source_flags(source_flags(lay["node_map"], no_in, lay["x_len"]))
+            e = PageRankEngine(csr.handle, n, lo, od[lo:hi].contiguous(), 0.85, x_len=lay["x_len"], engine=PageRankEngine.PB)
+
+            def gather(dst_views, src, k, r=r):  # this rank's slot of region k
+                dst_views[r].copy_(src)
+
+            ex = PiecewiseExchange(e, lay, r, hi - lo, dev, gather=gather, x=shared)
+            ranks.append((csr, e, ex, torch.zeros(hi - lo, device=dev), torch.zeros(1, dtype=torch.float64, device=dev)))
+        for (_, _, ex, scl, _) in ranks:
+            ex.start(scl)
+        for k in range(sweeps):
+            for (_, _, ex, scl, el) in ranks:
+                ex.sweep(scl, el)
+        results[with_flags] = torch.cat([rk[3] for rk in ranks])
+    assert torch.equal(results[True], sc)
+    assert not torch.equal(results[False], sc)
+    worst = float(((results[False] - sc).abs() / sc).max())
+    print(f"three virtual ranks, {sweeps} sweeps: with the flags the single engine's bits; without them max rel {worst:.2e} from it")
