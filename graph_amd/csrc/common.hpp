@@ -590,7 +590,7 @@ struct SsspScratch {
 
 // The opaque handle of include/graph_mi355x.h.
 namespace gm {
-// GM_PB_HUB_LEAVES: a row with at least this many sources that have no in-edges themselves is summed in the reference's order whatever
+// GM_PB_HUB_LEAVES: a row with at least this many sources that have at most one in-edge themselves is summed in the reference's order whatever
 // its length (pagerank_pb.hip: pb_leafflag_kernel); 0 = the rule is off.  One reader for the plan builder and the partitioned front.
 constexpr uint32_t kHubLeavesDefault = 512;
 inline uint32_t hub_leaves_threshold()
@@ -627,7 +627,7 @@ struct gm_csr {
     // (threshold << 1 | answer) of the last look: does some row have >= GM_PB_HUB_DEG entries?  -1: not looked at yet
     mutable std::atomic<long long> long_rows{-1};
     // gm_csr_set_source_flags: one byte per entry of the x vector the rows' lists index (a partition slice: exchange slots), non-zero =
-    // "this source has no in-edges" — what a slice cannot see in its own offsets (the plan builder's rule for rows of constant terms)
+    // "this source has at most one in-edge" — what a slice cannot see in its own offsets (the plan builder's rule for rows of constant terms)
     gm::DevBuf source_flags;
     uint64_t source_flags_len = 0;
 };

@@ -297,15 +297,15 @@ using MultiPtr = std::unique_ptr<gm::MultiState, gm::MultiStateDeleter>;
 
 // What a rank is built from, all of it on the rank's own device: its rows of the in-CSR (offsets rebased to 0, targets as
 // GLOBAL node ids) and the out-degree of EVERY node (which nodes are ever gathered, and its own rows' divisors).  Consumed.
-// which local rows have in-edges (one byte per row)
+// which local rows have MORE THAN ONE in-edge (one byte per row): the others' scores are constants or copies of one node's
 __global__ void mg_has_in_kernel(const uint32_t *__restrict__ off, uint32_t rows, uint8_t *__restrict__ out)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += stride)
-        out[r] = off[r + 1] != off[r] ? 1 : 0;
+        out[r] = off[r + 1] - off[r] > 1u ? 1 : 0;
 }
 
-// per entry of the exchange vector: does the node in that slot have NO in-edges?  (gm_csr_set_source_flags)
+// per entry of the exchange vector: does the node in that slot have at most one in-edge?  (gm_csr_set_source_flags)
 __global__ void mg_slot_flags_kernel(const uint32_t *__restrict__ node_map, const uint8_t *__restrict__ has_in, uint32_t n,
                                      uint8_t *__restrict__ slot_flags)
 {

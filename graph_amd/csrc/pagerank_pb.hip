@@ -360,13 +360,14 @@ __global__ void pb_hubflag_kernel(const uint32_t *__restrict__ off, uint32_t n, 
         flag[r] = (r < n && hub_deg && off[r + 1] - off[r] >= hub_deg) ? 1u : 0u;
 }
 
-// ... and rows BELOW it that sum many CONSTANT terms (round 6; whole graphs: a row's sources are rows of the same CSR).  A source without
-// in-edges carries (1 - d) / n in every sweep, so the out_scores of such sources are equal within an out-degree class, and the
+// ... and rows BELOW it that sum many EQUAL terms (round 6; whole graphs: a row's sources are rows of the same CSR).  A source without
+// in-edges carries (1 - d) / n in every sweep — the out_scores of such sources are equal within an out-degree class —, and sources with
+// ONE in-edge from the same node (the pages of a site that only its front page links to) carry equal scores as well; the
 // reference's left-to-right f32 sum of equal terms drifts SYSTEMATICALLY (every add rounds the same way while the sum stays in one
 // binade): an exactly rounded sum misses the reference by that drift — by up to 6e-5 on a row of 4000 leaf followers, for most n that
 // are not powers of two once a row has 2000 of them, never with 500 (tests/test_gpu_hub_order.py).  A row with at least
-// `leaf_t` such sources (GM_PB_HUB_LEAVES, default 512) is therefore a hub row whatever its length: summed the reference's way.
-// (RMAT: rows below 4096 in-edges have at most 55 of them at scale 22 / 24 / 26 — no BASELINE row is flagged;
+// `leaf_t` sources that have AT MOST ONE in-edge (GM_PB_HUB_LEAVES, default 512) is therefore a hub row whatever its length: summed
+// the reference's way.  (RMAT: rows below 4096 in-edges have at most 92 of them at scale 22 / 24 / 26 — no BASELINE row is flagged;
 // tools/leaf_sources_count.py; 7 ms of the plan build at scale 26.)  One wavefront looks at
 // 64 consecutive rows and walks the lists of those whose in-degree lies in [leaf_t, hub_deg).
 // (src_flags: a partition slice's list of which entries of its x vector are such sources, gm_csr_set_source_flags; null: whole graph)
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(256) void pb_leafflag_kernel(const uint32_t *__rest
                 if (src_flags)
                     c += (s_ < src_flags_len && src_flags[s_]) ? 1u : 0u;
                 else
-                    c += (s_ < n && off[s_ + 1] == off[s_]) ? 1u : 0u;
+                    c += (s_ < n && off[s_ + 1] - off[s_] <= 1u) ? 1u : 0u;
             }
             const uint32_t total = (uint32_t)wave_sum((uint64_t)c);
             if (lane == 0 && total >= leaf_t)

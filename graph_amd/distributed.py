@@ -213,8 +213,8 @@ def split_exchange_layout(out_degree, bounds, parts: int = 2, row_align: int = R
 
 def source_flags(node_map: torch.Tensor, no_in_edges: torch.Tensor, x_len: int):
     """uint8[x_len] for DeviceCsr.set_source_flags (gm_csr_set_source_flags): 1 where the node in that slot of the exchanged vector
-    has no in-edges.  node_map int32[n] (-1: never a source), no_in_edges bool / uint8 [n] over the GLOBAL in-degrees (a rank's
-    slice cannot see them in its own offsets).  With the flags a slice's propagation-blocking plan flags the rows the whole graph's
+    has at most ONE in-edge.  node_map int32[n] (-1: never a source), no_in_edges bool / uint8 [n]: in-degree <= 1, over the GLOBAL
+    in-degrees (a rank's slice cannot see them in its own offsets).  With the flags a slice's propagation-blocking plan flags the rows the whole graph's
     plan flags — rows that sum many constant terms are summed the reference's way (GM_PB_HUB_LEAVES)."""
     flags = torch.zeros(max(int(x_len), 1), dtype=torch.uint8, device=node_map.device)
     sel = (node_map >= 0) & no_in_edges.to(node_map.device).bool()
@@ -540,7 +540,7 @@ def rank_local_rows(scale: int, seed: int, rank: int, world: int, device: int = 
         dist.all_reduce(outd, op=dist.ReduceOp.SUM, group=group)
     off = np.zeros(n + 1, np.int64)
     np.cumsum(ind.cpu().numpy(), out=off[1:])
-    no_in_edges = (ind == 0).to(torch.uint8)  # (global: the summed histogram) -> source_flags() for the rank's slice
+    no_in_edges = (ind <= 1).to(torch.uint8)  # at most ONE in-edge (global: the summed histogram) -> source_flags() for the rank's slice
     del ind
     bounds, _ = pad_bounds(greedy_degree_partition(off, world), world, n)
     del off

@@ -155,7 +155,7 @@ class DeviceCsr:
 
     def set_source_flags(self, flags):
         """gm_csr_set_source_flags: for a ROW SLICE of a partitioned graph — one uint8 per entry of the exchange vector its lists index
-        (a torch CUDA tensor on the handle's device, or None to remove them), non-zero = the node in that slot has no in-edges.  Lets
+        (a torch CUDA tensor on the handle's device, or None to remove them), non-zero = the node in that slot has at most one in-edge.  Lets
         the propagation-blocking plan flag the rows the whole graph's plan flags (GM_PB_HUB_LEAVES)."""
         if flags is None:
             check(lib().gm_csr_set_source_flags(self._h, 0, 0))

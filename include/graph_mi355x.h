@@ -82,8 +82,8 @@ int gm_csr_wrap_device(uint64_t d_offsets, uint64_t d_targets, uint64_t d_weight
                        int device, gm_csr **out);
 void gm_csr_free(gm_csr *csr);
 /* For a handle that holds a ROW SLICE of a partitioned graph whose lists index an exchange vector (gm_pr_create_with's x_len): one byte
- * per entry of that vector in device memory, non-zero = "the node in this slot has no in-edges".  A slice cannot see that in its own
- * offsets, and the propagation-blocking plan's rule for rows that sum many constant terms (GM_PB_HUB_LEAVES; the reference's
+ * per entry of that vector in device memory, non-zero = "the node in this slot has at most ONE in-edge".  A slice cannot see that in its own
+ * offsets, and the propagation-blocking plan's rule for rows that sum many equal terms (GM_PB_HUB_LEAVES; the reference's
  * left-to-right sum of equal terms, page_rank.rs:143-146, drifts systematically: such rows are summed its way whatever their length)
  * needs it to flag the same rows as the single-GPU plan of the whole graph does.  The bytes are copied; plans built before the call are
  * dropped.  d_flags = 0 or len = 0 removes them.  Whole graphs need no flags: a source's in-degree is in the handle's own offsets. */

@@ -14,7 +14,8 @@ for scale in [int(a) for a in sys.argv[1:]]:
     for lo in range(0, src.numel(), 1 << 26):
         hi = min(lo + (1 << 26), src.numel())
         indeg.index_add_(0, dst[lo:hi].long(), one[: hi - lo]); outdeg.index_add_(0, src[lo:hi].long(), one[: hi - lo])
-    leaf = indeg == 0
+    most = int(os.environ.get("LEAF_MAX_INDEG", "0"))  # sources with at most this many in-edges count (0: the plan's rule)
+    leaf = indeg <= most
     cnt = torch.zeros(n, dtype=torch.int32, device=src.device)   # leaf sources per row
     cnt1 = torch.zeros(n, dtype=torch.int32, device=src.device)  # ... of out-degree 1 (the largest class of equal terms a row can have)
     for lo in range(0, src.numel(), 1 << 26):
@@ -24,7 +25,7 @@ for scale in [int(a) for a in sys.argv[1:]]:
         cnt.index_add_(0, d[m], one[: int(m.sum())])
         m1 = m & (outdeg[s] == 1)
         cnt1.index_add_(0, d[m1], one[: int(m1.sum())])
-    print(f"scale {scale}: {int(leaf.sum())} of {n} nodes have no in-edges; {int((leaf & (outdeg > 0)).sum())} of them have out-edges, "
+    print(f"scale {scale} (sources with <= {most} in-edges): {int(leaf.sum())} of {n} nodes; {int((leaf & (outdeg > 0)).sum())} of them have out-edges, "
           f"{int(outdeg[leaf].sum())} edges in all ({100.0 * int(outdeg[leaf].sum()) / src.numel():.1f} %)")
     for lo_d, hi_d in ((256, 512), (512, 1024), (1024, 2048), (2048, 4096), (4096, 1 << 30)):
         sel = (indeg >= lo_d) & (indeg < hi_d)
