@@ -76,12 +76,28 @@ __global__ void pr_degrees_from_offsets_kernel(const uint32_t *__restrict__ off,
         deg[u] = off[u + 1] - off[u];
 }
 
-__global__ void pr_long_row_kernel(const uint32_t *__restrict__ off, uint32_t n, uint32_t min_len, uint32_t *__restrict__ flag)
+// Is there a row that must be summed in the reference's order?  One of at least min_len entries — or (leaf_t != 0) a shorter one with at
+// least leaf_t sources that have at most one in-edge themselves: many EQUAL terms, on which the reference's left-to-right sum drifts
+// systematically (pagerank_pb.hip: pb_leafflag_kernel; whole graphs read a source's in-degree off the same offsets, a partition slice
+// needs gm_csr_set_source_flags' bytes).  Rows between leaf_t and min_len entries are rare below 2^24 edges; a lane walks one.
+__global__ void pr_long_row_kernel(const uint32_t *__restrict__ off, const uint32_t *__restrict__ src, uint32_t n, uint32_t min_len,
+                                   uint32_t leaf_t, const uint8_t *__restrict__ src_flags, uint64_t src_flags_len, int whole,
+                                   uint32_t *__restrict__ flag)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
     bool any = false;
-    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += stride)
-        any = any || off[u + 1] - off[u] >= min_len;
+    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < n && !any; u += stride) {
+        const uint32_t b = off[u], deg = off[u + 1] - b;
+        any = deg >= min_len;
+        if (!any && leaf_t && deg >= leaf_t && (whole || src_flags)) {
+            uint32_t c = 0;
+            for (uint32_t k = 0; k < deg; ++k) {
+                const uint32_t s = src[b + k];
+                c += src_flags ? ((s < src_flags_len && src_flags[s]) ? 1u : 0u) : ((s < n && off[s + 1] - off[s] <= 1u) ? 1u : 0u);
+            }
+            any = c >= leaf_t;
+        }
+    }
     if (any)
         *flag = 1u;
 }
@@ -379,27 +395,37 @@ __global__ __launch_bounds__(kWave) void pr_seq_kernel(const uint32_t *__restric
 // engine, which sums them in the reference's left-to-right f32 order (pagerank_pb.hip): the pull tiles reduce a
 // long row as a tree, and on long rows the two differ by more than the 1e-5 the results must agree to
 // (measured 1.2e-5 at RMAT scale 18).  Looked at once per handle and threshold.
-static int pr_has_long_rows(const gm_csr *csr, bool *out)
+static int pr_has_long_rows(const gm_csr *csr, bool whole, bool *out)
 {
     const char *v = getenv("GM_PB_HUB_DEG");
     const long thr = v && *v && atol(v) > 0 ? atol(v) : (v && *v ? 0 : 4096);
+    const long leaf_t = thr > 0 ? (long)gm::hub_leaves_threshold() : 0; // (GM_PB_HUB_DEG=0: every row exactly rounded, no rule either)
+    const bool have_flags = csr->source_flags.p && csr->source_flags_len;
+    const long long key = ((long long)thr << 21) | ((long long)(leaf_t & 0xFFFFF) << 1) | (have_flags ? 1 : 0);
     const long long cached = csr->long_rows.load();
-    int state = cached >= 0 && (cached >> 1) == (long long)thr ? (int)(cached & 1) : -1; // an answer for another threshold does not count
+    int state = cached >= 0 && (cached >> 1) == key ? (int)(cached & 1) : -1; // an answer for other thresholds does not count
     if (state < 0) {
         state = 0;
-        if (thr > 0 && csr->n && csr->m >= (uint64_t)thr) {
+        if (thr > 0 && csr->n && csr->m >= (uint64_t)(leaf_t && leaf_t < thr ? leaf_t : thr)) {
             gm::DevBuf flag;
             GM_TRY(flag.alloc(4));
             GM_HIP(hipMemset(flag.p, 0, 4));
             unsigned grid = gm::div_up(csr->n, 256);
-            hipLaunchKernelGGL(pr_long_row_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0, 0, csr->offsets, (uint32_t)csr->n,
-                               (uint32_t)thr, flag.as<uint32_t>());
-            GM_HIP(hipGetLastError());
+            // the cheap question first (a row of thr entries?); the lists of the rows between leaf_t and thr entries are walked only if not
             uint32_t h = 0;
-            GM_HIP(hipMemcpy(&h, flag.p, 4, hipMemcpyDeviceToHost));
+            for (int pass = 0; pass < 2 && !h; ++pass) {
+                const uint32_t lt = pass == 0 ? 0u : (uint32_t)(leaf_t < thr ? leaf_t : 0);
+                if (pass == 1 && !lt)
+                    break;
+                hipLaunchKernelGGL(pr_long_row_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0, 0, csr->offsets, csr->targets,
+                                   (uint32_t)csr->n, (uint32_t)thr, lt, have_flags ? csr->source_flags.as<uint8_t>() : (const uint8_t *)nullptr,
+                                   csr->source_flags_len, whole ? 1 : 0, flag.as<uint32_t>());
+                GM_HIP(hipGetLastError());
+                GM_HIP(hipMemcpy(&h, flag.p, 4, hipMemcpyDeviceToHost));
+            }
             state = h ? 1 : 0;
         }
-        csr->long_rows.store(((long long)thr << 1) | (long long)state);
+        csr->long_rows.store((key << 1) | (long long)state);
     }
     *out = state == 1;
     return GM_OK;
@@ -423,7 +449,8 @@ GM_API int gm_pr_create_with(const gm_csr *csr, uint64_t n_global, uint64_t row_
     gm::DeviceGuard guard(csr->device);
     if (engine == GM_PR_ENGINE_AUTO) { // below ~16M edges the gathered vector is cache-resident: the pull tiles win
         bool long_rows = false;         // ... unless a long row needs the reference's summation order
-        GM_TRY(pr_has_long_rows(csr, &long_rows));
+        if (csr->m < (1ull << 24))
+            GM_TRY(pr_has_long_rows(csr, x_len == csr->n, &long_rows));
         engine = (csr->m >= (1ull << 24) || long_rows) ? GM_PR_ENGINE_PB : GM_PR_ENGINE_PULL;
     }
     gm_pr *pr = new (std::nothrow) gm_pr();
@@ -837,7 +864,8 @@ static int page_rank_impl(const gm_csr *in_csr, const uint32_t *out_degree, cons
         // run this call on the pull tiles and build the plan on the second call of the same graph (the
         // reference's app runs 5 warm-ups + N timed runs on one graph, crates/app/src/app.rs:124-153).
         bool long_rows = false; // rows that must be summed in the reference's order: only the PB engine does that
-        GM_TRY(pr_has_long_rows(in_csr, &long_rows));
+        if (in_csr->m < (1ull << 28))
+            GM_TRY(pr_has_long_rows(in_csr, true, &long_rows));
         std::lock_guard<std::mutex> lock(in_csr->cache_mu);
         const uint64_t calls = ++in_csr->page_rank_calls;
         const bool cached = in_csr->pb_plans.count(n) != 0;

@@ -256,3 +256,41 @@ def test_python_front_slices_with_source_flags_give_the_single_engines_bits(P, o
     assert not torch.equal(results[False], sc)
     worst = float(((results[False] - sc).abs() / sc).max())
     print(f"three virtual ranks, {sweeps} sweeps: with the flags the single engine's bits; without them max rel {worst:.2e} from it")
+
+
+def test_small_graph_with_rows_of_equal_terms_gets_the_engine_that_follows_the_reference(P, oracle, monkeypatch):
+    """Below 2^24 edges the default call runs on the pull tiles, which sum a long row as a tree — unless some row must be summed in
+    the reference's order: a row of >= 4096 entries, or (round 6) a shorter one with >= 512 sources of at most one in-edge, i.e. many
+    equal terms.  A graph of 300 K edges with two leaf fans and no long row: the default call gives the fans' rows the reference's
+    bits; with the rule off it takes the pull tiles and the 3000-fan is off by the reference's drift."""
+    nb, fans = 100_000, [2000, 3000]
+    base = np.arange(nb, dtype=np.uint32)
+    s = np.concatenate([base, base])
+    d = np.concatenate([(base * 7 + 3) % nb, (base * 13 + 5) % nb]).astype(np.uint32)  # in-degree 2 everywhere
+    centres = nb + np.arange(len(fans))
+    at, ls, ld = nb + len(fans), [], []
+    for c, k in zip(centres, fans):
+        ls.append(np.arange(at, at + k, dtype=np.uint32)); ld.append(np.full(k, c, np.uint32)); at += k
+    s = np.concatenate([s] + ls + [centres.astype(np.uint32)])
+    d = np.concatenate([d] + ld + [np.zeros(len(fans), np.uint32)])
+    n = 297676
+    ioff, itgt = oracle.csr_build(n, s, d, oracle.INCOMING, oracle.SORTED)
+    assert int(np.diff(ioff.astype(np.int64)).max()) == 3000
+    od = oracle.out_degrees_from(n, s)
+    ref, _, _ = oracle.page_rank_chunked(ioff, itgt, od, 200, 1e-10, 0.85)
+
+    def run():
+        out = P.DeviceCsr.from_edges(n, s, d, None, P.Direction.Outgoing, P.CsrLayout.Sorted)
+        inc = P.DeviceCsr.from_edges(n, s, d, None, P.Direction.Incoming, P.CsrLayout.Sorted)
+        got, _, _ = P.page_rank(P.DirectedCsrGraph(out, inc, P.CsrLayout.Sorted), P.PageRankConfig(200, 1e-10, 0.85))
+        return np.asarray(got)
+
+    got = run()
+    rel = np.abs(got.astype(np.float64) - ref) / ref
+    print(f"default call, {s.size} edges, fans of {fans}: max rel on every row {rel.max():.2e}, the fans' rows {rel[centres]}")
+    assert np.array_equal(got[centres], ref[centres]) and rel.max() <= 1e-5
+    monkeypatch.setenv("GM_PB_HUB_LEAVES", "0")
+    off = run()
+    rel_off = np.abs(off.astype(np.float64) - ref) / ref
+    print(f"   rule off (pull tiles): the fans' rows {rel_off[centres]}")
+    assert rel_off[centres[1]] > 1e-5
